@@ -1,0 +1,92 @@
+/* libwmz_hip.so -- C ABI of the MI355X (gfx950) denoiser hot path.
+ *
+ * The reference (world-modelz/world-modelz, vq-video-diffusion/) has no FFI: its boundary for this path is
+ * the Python nn.Module surface.  These entry points are what the drop-in modules in
+ * world_modelz_amd/ call through ctypes; each one names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless named host_*; tensors are row-major / channels-last,
+ *    exactly the layouts the reference holds at that point ([B,S,H,W,C] token grids, [N,E] latents);
+ *  - `dtype` selects the element type of activations: WMZ_F32 or WMZ_BF16 (accumulation is always fp32);
+ *    parameters marked `float*` are always fp32, indices are int64 like the reference's LongTensors;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued;
+ *  - no allocation, no host sync, no global state: safe to capture in a hipGraph, re-entrant per stream;
+ *  - return 0 on success, WMZ_ERR_* otherwise; wmz_last_error() gives the message (thread-local).
+ */
+#ifndef WMZ_H_
+#define WMZ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WMZ_VERSION 100
+
+enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
+enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
+
+/* epilogue / prologue flags of wmz_linear_fwd */
+enum { WMZ_LIN_GELU = 1 /* exact erf GELU on (A W^T + b) */ };
+
+int wmz_version(void);
+const char* wmz_last_error(void);
+
+/* ---- Local3dAttention.local_attention (local_3d_attention.py:78-99; pad :57-63, unfold :65-69, mask :71-76)
+ * q,k,v: [B,S,H,W,heads*dh] (row strides ldq/ldk/ldv in elements, head-major channels), out same shape
+ * (row stride ldo).  Softmax runs over the in-grid neighbours of the (2eS+1)(2eH+1)(2eW+1) window, which
+ * equals the reference's zero-pad + -1e9 masking.  lse (optional, fp32 [B*S*H*W, heads]) receives
+ * log-sum-exp of the scaled logits for the backward.  logits_dbg (optional, fp32 [N, heads, K], caller
+ * pre-fills with -1e9) receives the scaled logits in the reference's (i j k) slot order: parity probe only. */
+int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, float* logits_dbg,
+                         int B, int S, int H, int W, int heads, int dh, int eS, int eH, int eW,
+                         long ldq, long ldk, long ldv, long ldo, int dtype, void* stream);
+
+/* Backward of the above given the saved lse: dq, dk, dv (same layouts / strides as q, k, v).
+ * Replaces the checkpoint re-run + autograd of local_3d_attention.py:110-111. */
+int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                         const void* dout, void* dq, void* dk, void* dv,
+                         int B, int S, int H, int W, int heads, int dh, int eS, int eH, int eW,
+                         long ldq, long ldk, long ldv, long ldo, int dtype, void* stream);
+
+/* ---- nn.Linear family (local_3d_attention.py:46-53 to_q/to_k/to_v/to_out, :23-29 FeedForward, main.py:31
+ * logit_proj), optionally fused with the PreNorm LayerNorm in front (:14-17) and the residual add behind
+ * (:160-161):   C[M,N] = act( LN?(A)[M,K] @ Wt[N,K]^T + bias[N] ) + residual[M,N]
+ * A, C, residual: activation dtype (lda/ldc/ldr row strides in elements); Wt: activation dtype, row-major
+ * [N,K] (nn.Linear.weight layout); bias, ln_gamma, ln_beta: fp32 or NULL; ln_gamma != NULL enables the
+ * LayerNorm prologue over the K axis (eps = ln_eps).  out_f32 != 0 stores C as fp32 regardless of dtype
+ * (logits).  Requires K % 8 == 0. */
+int wmz_linear_fwd(const void* A, long lda, const void* Wt, const float* bias, const void* residual, long ldr,
+                   void* C, long ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
+                   float ln_eps, int flags, int out_f32, int dtype, void* stream);
+
+/* ---- Local3dAttentionTransformer embedding (local_3d_attention.py:140-157):
+ * x[b,s,h,w,:] = emb[z[b,s,h,w]] + ((pos_s[s] + pos_h[h]) + pos_w[w]); tables fp32, x in `dtype`. */
+int wmz_embed_pos3d_fwd(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+                        const float* pos_w, void* x, int B, int S, int H, int W, int D, int num_classes,
+                        int dtype, void* stream);
+
+/* ---- VectorQuantizerEMA (vq.py) ----
+ * wmz_vq_argmin: encode / codebook_distance+argmin (vq.py:77-87, :30-33).  x [N,E] fp32 (row stride ldx),
+ * codebook [C,E] fp32.  dist = sum_e (x-e)^2 evaluated in the exact fp32 order ATen uses on x86
+ * (8 lanes x 4 accumulators, no FMA contraction), ties -> lowest index: indices are bit-identical to the
+ * reference.  idx int64 [N]; dist_min (optional) fp32 [N]. */
+int wmz_vq_argmin(const float* x, long ldx, const float* codebook, int64_t* idx, float* dist_min,
+                  int N, int C, int E, void* stream);
+/* decode (vq.py:89-94): out[n,:] = codebook[idx[n],:]; out in `dtype` (row stride ldo). */
+int wmz_vq_gather(const int64_t* idx, const float* codebook, void* out, long ldo, int N, int C, int E,
+                  int dtype, void* stream);
+/* statistics of forward (vq.py:35-36, :43-46): counts[c] += #{n: idx[n]==c}, dw[c,:] += sum x[n,:],
+ * sqerr[c] += sum |codebook[c]-x[n]|^2.  Caller zeroes counts/dw (sqerr accumulates into accumulated_error). */
+int wmz_vq_ema_stats(const float* x, long ldx, const int64_t* idx, const float* codebook, float* counts,
+                     float* dw, float* sqerr, int N, int C, int E, void* stream);
+/* EMA update (vq.py:53-65): cluster_size = g*cs + (1-g)*counts; n = sum(cs);
+ * embedding = g*embedding + (1-g) * dw / ((cs+eps)/(n+C*eps)*n).   activation_count += counts (vq.py:44). */
+int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_count, const float* counts,
+                      const float* dw, int C, int E, double decay, double eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMZ_H_ */

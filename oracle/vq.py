@@ -10,7 +10,8 @@ not change the per-(n,c) reduction), so the distances -- and hence argmin -- are
 to the reference on the same host.  Measured in the build container: ATen's CPU reduction for
 this expression is the contiguous-inner `vectorized_inner_sum` (the broadcast output is laid out
 E-innermost): 8 SIMD lanes x 4 interleaved accumulators,
-  acc[k][j] += sq[8*(4*i+k)+j];  t[j] = ((acc0+acc1)+acc2)+acc3;  d = (((0+t0)+t1)+...)+t7
+  acc[k][j] += sq[8*(4*i+k)+j];  acc0 += leftover vectors;  t[j] = ((acc0+acc1)+acc2)+acc3;
+  d = (((tail scalars + t0)+t1)+...)+t7
 `distances_avx_order` below spells that order out; the HIP argmin kernel uses the same one.
 """
 import torch
@@ -57,10 +58,10 @@ def distances_avx_order(x, embedding):
             v0 = (i * ILP + k) * V
             acc[k] = acc[k] + sq[:, :, v0:v0 + V]
     t = acc[0]
+    for i in range(n_ilp * ILP, nv):                      # leftover vectors join accumulator 0 first
+        t = t + sq[:, :, i * V:(i + 1) * V]
     for k in range(1, ILP):
         t = t + acc[k]
-    for i in range(n_ilp * ILP, nv):
-        t = t + sq[:, :, i * V:(i + 1) * V]
     fin = torch.zeros(sq.shape[0], C)
     for e in range(nv * V, E):
         fin = fin + sq[:, :, e]

@@ -1,0 +1,244 @@
+"""GPU parity: each HIP kernel, called through the C ABI (ctypes), against the CPU oracle and the golden
+vectors captured from the reference.  Tolerances are written next to each check."""
+import pytest
+import torch
+
+from conftest import load_golden, sub
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention as oat          # noqa: E402
+from oracle import denoiser as oden          # noqa: E402
+from oracle import vq as ovq                 # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'gpu tests need a ROCm device'
+    from world_modelz_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------- attention
+
+@pytest.mark.parametrize('tag', list('abcdef'))
+def test_attention_fp32_vs_golden(ops, tag):
+    """fp32 mode (exact-f32 MFMA): out and logits against the reference capture.  1e-5 rel on out;
+    logits at live slots 1e-5 rel / 1e-5 abs; masked slots are the literal -1e9."""
+    g = load_golden(f'attn_core_{tag}')
+    ext = tuple(int(e) for e in g['extents'])
+    heads = int(g['heads'])
+    out, lse, dbg = ops.local3d_attention_fwd(dev(g['q']), dev(g['k']), dev(g['v']), ext, heads, need_lse=True,
+                                              logits_dbg=True)
+    assert rel(out, g['out']) < 1e-5
+    B, S, H, W, I = g['q'].shape
+    logits = dbg.cpu().reshape(B, S, H, W, heads, -1)
+    assert torch.equal(logits == -1e9, g['logits'] == -1e9)
+    live = g['logits'] != -1e9
+    assert torch.allclose(logits[live], g['logits'][live], rtol=1e-5, atol=1e-5)
+    lse_ref = torch.logsumexp(g['logits'], dim=-1).reshape(-1, heads)
+    assert torch.allclose(lse.cpu(), lse_ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('tag', ['e', 'f'])
+def test_attention_bf16_logits_vs_golden(ops, tag):
+    """bf16 mode on bf16-representable q,k,v (SURVEY 7 'Parity definition' (i)): logits <= 1e-3 rel
+    (north_star bar; measured ~1e-6 because bf16 products are exact in the fp32 accumulator);
+    out within 1e-2 rel (P is rounded to bf16 for the PV MFMA)."""
+    g = load_golden(f'attn_core_{tag}')
+    ext = tuple(int(e) for e in g['extents'])
+    heads = int(g['heads'])
+    q, k, v = (dev(g[n]).to(torch.bfloat16) for n in 'qkv')
+    assert torch.equal(q.float().cpu(), g['q'])          # inputs are exactly representable
+    out, _, dbg = ops.local3d_attention_fwd(q, k, v, ext, heads, logits_dbg=True)
+    B, S, H, W, I = g['q'].shape
+    logits = dbg.cpu().reshape(B, S, H, W, heads, -1)
+    assert torch.equal(logits == -1e9, g['logits'] == -1e9)
+    live = g['logits'] != -1e9
+    err = (logits[live] - g['logits'][live]).abs().max() / g['logits'][live].abs().max()
+    assert float(err) < 1e-3
+    assert rel(logits[live], g['logits'][live]) < 1e-3
+    assert rel(out, g['out']) < 1e-2
+
+
+@pytest.mark.parametrize('shape,heads,dh,ext,dtype', [
+    ((1, 8, 8, 8), 1, 128, (3, 3, 3), torch.bfloat16),     # BASELINE config 2
+    ((1, 8, 8, 8), 1, 128, (3, 1, 1), torch.bfloat16),
+    ((2, 5, 16, 16), 1, 128, (3, 3, 3), torch.bfloat16),   # 16x16 planes as in configs 3/4
+    ((1, 3, 6, 40), 2, 64, (1, 2, 3), torch.bfloat16),     # W > 16: tiles narrower than a row
+    ((1, 2, 3, 5), 1, 8, (1, 1, 1), torch.float32),        # ragged single tile, tiny head
+    ((1, 4, 7, 9), 3, 16, (0, 0, 0), torch.float32),       # window of one: out == v
+    ((2, 3, 5, 33), 1, 128, (2, 2, 2), torch.float32),
+])
+def test_attention_vs_oracle(ops, shape, heads, dh, ext, dtype):
+    torch.manual_seed(1)
+    B, S, H, W = shape
+    I = heads * dh
+    q, k, v = (torch.randn(B, S, H, W, I).to(dtype).float() for _ in range(3))
+    ref, ref_logits = oat.local_attention(k, v, q, ext, heads, return_logits=True)
+    out, lse, dbg = ops.local3d_attention_fwd(dev(q).to(dtype), dev(k).to(dtype), dev(v).to(dtype), ext, heads,
+                                              need_lse=True, logits_dbg=True)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel(out, ref) < tol
+    logits = dbg.cpu().reshape(ref_logits.shape)
+    live = ref_logits != -1e9
+    assert torch.equal(logits == -1e9, ~live)
+    assert rel(logits[live], ref_logits[live]) < 1e-5
+    assert torch.allclose(lse.cpu().reshape(-1), torch.logsumexp(ref_logits, -1).reshape(-1), rtol=1e-5, atol=1e-5)
+    if ext == (0, 0, 0):
+        assert rel(out, v) < tol
+
+
+def test_attention_strided_qkv(ops):
+    """q,k,v as column slices of one fused [N, 3I] buffer (what the fused projection writes)."""
+    torch.manual_seed(2)
+    B, S, H, W, I = 1, 3, 4, 16, 64
+    qkv = torch.randn(B, S, H, W, 3 * I)
+    q, k, v = qkv[..., :I], qkv[..., I:2 * I], qkv[..., 2 * I:]
+    ref = oat.local_attention(k, v, q, (1, 1, 1), 2)
+    d = dev(qkv)
+    out, _, _ = ops.local3d_attention_fwd(d[..., :I], d[..., I:2 * I], d[..., 2 * I:], (1, 1, 1), 2)
+    assert rel(out, ref) < 1e-5
+
+
+def test_attention_large_logits_rescale(ops):
+    """Force the online-softmax rescale: one key far above the running max late in the walk."""
+    torch.manual_seed(3)
+    B, S, H, W, I = 1, 7, 16, 16, 32
+    q, k, v = (torch.randn(B, S, H, W, I) for _ in range(3))
+    k[0, 6, 15, 15] = 40.0 * q[0, 4, 13, 13] / q[0, 4, 13, 13].norm()   # visited last for that query
+    k[0, 0, 0, 0] = 30.0 * q[0, 2, 2, 2] / q[0, 2, 2, 2].norm()         # visited first
+    ref = oat.local_attention(k, v, q, (3, 3, 3), 1)
+    out, _, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), (3, 3, 3), 1)
+    assert rel(out, ref) < 1e-5
+    assert torch.isfinite(out).all()
+
+
+# ---------------------------------------------------------------------------------------------- linear
+
+@pytest.mark.parametrize('M,N,K', [(300, 96, 64), (128, 128, 256), (1000, 384, 256), (77, 50, 24), (513, 1024, 256)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_plain_bias_gelu_residual(ops, M, N, K, dtype):
+    torch.manual_seed(4)
+    a = torch.randn(M, K).to(dtype)
+    w = (torch.randn(N, K) / K ** 0.5).to(dtype)
+    b = torch.randn(N)
+    r = torch.randn(M, N).to(dtype)
+    af, wf, rf = a.float(), w.float(), r.float()
+    tol = 2e-6 if dtype == torch.float32 else 6e-3
+    y = ops.linear_fwd(dev(a), dev(w))
+    assert rel(y, af @ wf.t()) < tol
+    y = ops.linear_fwd(dev(a), dev(w), bias=dev(b), gelu=True)
+    assert rel(y, torch.nn.functional.gelu(af @ wf.t() + b)) < tol
+    y = ops.linear_fwd(dev(a), dev(w), bias=dev(b), residual=dev(r))
+    assert rel(y, af @ wf.t() + b + rf) < tol
+    y = ops.linear_fwd(dev(a), dev(w), bias=dev(b), out_f32=True)
+    assert y.dtype == torch.float32 and rel(y, af @ wf.t() + b) < (2e-6 if dtype == torch.float32 else 1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_layernorm_prologue(ops, dtype):
+    torch.manual_seed(5)
+    M, N, K = 333, 256, 256
+    a = (torch.randn(M, K) * 2 + 0.7).to(dtype)
+    w = (torch.randn(N, K) / K ** 0.5).to(dtype)
+    gam, bet, b = torch.rand(K) + 0.5, torch.randn(K) * 0.1, torch.randn(N)
+    ln = torch.nn.functional.layer_norm(a.float(), (K,), gam, bet, 1e-5)
+    if dtype == torch.bfloat16:
+        ln = ln.to(dtype).float()       # the kernel rounds LN(x) to the MFMA operand type
+    ref = ln @ w.float().t() + b
+    y = ops.linear_fwd(dev(a), dev(w), bias=dev(b), ln=(dev(gam), dev(bet)))
+    assert rel(y, ref) < (3e-6 if dtype == torch.float32 else 6e-3)
+
+
+def test_embed_pos3d(ops):
+    g = load_golden('transformer_tiny')
+    sd = sub(g, 'sd/')
+    ref = oden.embed_tokens(sd, g['z'])
+    x = ops.embed_pos3d_fwd(dev(g['z']), dev(sd['transformer.embedding.weight']),
+                            dev(sd['transformer.pos_emb_s.weight']), dev(sd['transformer.pos_emb_h.weight']),
+                            dev(sd['transformer.pos_emb_w.weight']), torch.float32)
+    assert torch.equal(x.cpu(), ref)                      # same fp32 additions in the same order
+    xb = ops.embed_pos3d_fwd(dev(g['z']), dev(sd['transformer.embedding.weight']),
+                             dev(sd['transformer.pos_emb_s.weight']), dev(sd['transformer.pos_emb_h.weight']),
+                             dev(sd['transformer.pos_emb_w.weight']), torch.bfloat16)
+    assert torch.equal(xb.cpu(), ref.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------- VQ
+
+@pytest.mark.parametrize('name', ['vq_encode_512', 'vq_encode_1024', 'vq_encode_8192', 'vq_encode_odd'])
+def test_vq_argmin_bit_exact_vs_golden(ops, name):
+    g = load_golden(name)
+    cb = g['embedding'][0]
+    idx, dmin = ops.vq_argmin(dev(g['x']), dev(cb), need_dist=True)
+    assert idx.dtype == torch.int64
+    assert torch.equal(idx.cpu(), g['idx'][:, 0])                        # bit-identical indices
+    if 'dist_min' in g:
+        assert torch.equal(dmin.cpu(), g['dist_min'])                    # and bit-identical distances
+    else:
+        assert torch.equal(dmin.cpu(), g['dist'].min(dim=-1).values)
+    dec = ops.vq_gather(idx, dev(cb))
+    assert torch.equal(dec.cpu(), ovq.decode(g['idx'], g['embedding'])[:, 0])
+
+
+@pytest.mark.parametrize('N,C,E', [(65536, 1024, 64), (4097, 512, 64), (1000, 8192, 64), (999, 100, 32),
+                                   (500, 77, 24), (64, 33, 40), (129, 16, 8)])
+def test_vq_argmin_vs_oracle(ops, N, C, E):
+    """Full-size encode stage of configs 3/4 (N = 65 536, C = 1024) and ragged shapes: indices and min
+    distances bit-identical to the oracle (which evaluates the reference's own tensor expression)."""
+    torch.manual_seed(6)
+    x, cb = torch.randn(N, E), torch.randn(C, E)
+    ref = ovq.distances(x, cb[None])[:, 0]
+    idx, dmin = ops.vq_argmin(dev(x), dev(cb), need_dist=True)
+    assert torch.equal(idx.cpu(), ref.argmin(-1))
+    assert torch.equal(dmin.cpu(), ref.min(-1).values)
+
+
+def test_vq_ties_and_duplicates(ops):
+    torch.manual_seed(7)
+    cb = torch.randn(40, 16)
+    cb[33] = cb[2]
+    cb[17] = cb[2]
+    x = cb[[2, 33, 17, 5]].clone()
+    idx = ops.vq_argmin(dev(x), dev(cb))
+    assert idx.cpu().tolist() == [2, 2, 2, 5]
+    # all-equal codebook: index 0
+    idx = ops.vq_argmin(dev(torch.randn(10, 16)), dev(torch.ones(7, 16)))
+    assert idx.cpu().tolist() == [0] * 10
+
+
+def test_vq_forward_sequence_vs_golden(ops):
+    """EMA statistics + update kernels reproduce the reference's buffer trajectory (quirk Q4)."""
+    g = load_golden('vq_forward_train')
+    emb = dev(g['embedding0'][0].clone())
+    cs = dev(g['cluster_size0'][0].clone())
+    act = torch.zeros(32, device='cuda')
+    err = torch.zeros(32, device='cuda')
+    for tag in ['t0', 't1', 't2']:
+        x = dev(g[f'{tag}/x'])
+        idx = ops.vq_argmin(x, emb)
+        assert torch.equal(idx.cpu(), g[f'{tag}/encodings_argmax'][:, 0])
+        counts = torch.zeros(32, device='cuda')
+        dw = torch.zeros(32, 8, device='cuda')
+        ops.vq_ema_stats(x, idx, emb, counts, dw, err)
+        ops.vq_ema_update(emb, cs, act, counts, dw, 0.99, 1e-5)
+        assert torch.allclose(emb.cpu(), g[f'{tag}/embedding'][0], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(cs.cpu(), g[f'{tag}/cluster_size'][0], rtol=1e-6)
+        assert torch.equal(act.cpu(), g[f'{tag}/activation_count'][0])
+        assert torch.allclose(err.cpu(), g[f'{tag}/accumulated_error'][0], rtol=1e-5)
+
+
+def test_library_refuses_cpu_tensors(ops):
+    from world_modelz_amd._lib import WmzError
+    with pytest.raises(WmzError):
+        ops.vq_argmin(torch.randn(4, 8), torch.randn(3, 8))

@@ -205,3 +205,12 @@ def test_sparse_tiny():
     shape = tuple(int(e) for e in g['shape'])
     out = oden.sparse_denoiser_forward(sd, g['x'], g['indices'], shape, int(g['heads']))
     assert rel(out, g['logits']) < 2e-6
+
+
+@pytest.mark.parametrize('E', [8, 16, 17, 20, 24, 32, 40, 56, 64, 72, 100, 128, 200, 256])
+def test_vq_distance_summation_order(E):
+    """ATen's reduction order for the reference expression (vq.py:30), restated explicitly -- this is the
+    order the HIP argmin kernel implements, so it must be bitwise the torch result on this host."""
+    torch.manual_seed(E)
+    x, emb = torch.randn(37, E), torch.randn(1, 29, E)
+    assert torch.equal(ovq.distances_avx_order(x, emb), ovq.distances(x, emb))

@@ -1,0 +1,89 @@
+"""ctypes binding of libwmz_hip.so (the C ABI declared in include/wmz.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libwmz_hip.so')
+
+WMZ_F32, WMZ_BF16 = 0, 1
+WMZ_LIN_GELU = 1
+
+_lib = None
+
+c_void_p, c_int, c_long, c_float, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float,
+                                              ctypes.c_double)
+
+# name -> argtypes, mirrors include/wmz.h one to one
+SIGNATURES = {
+    'wmz_local3d_attn_fwd': [c_void_p] * 6 + [c_int] * 9 + [c_long] * 4 + [c_int, c_void_p],
+    'wmz_local3d_attn_bwd': [c_void_p] * 9 + [c_int] * 9 + [c_long] * 4 + [c_int, c_void_p],
+    'wmz_linear_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
+                       c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p],
+    'wmz_embed_pos3d_fwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],
+    'wmz_vq_argmin': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'wmz_vq_gather': [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
+    'wmz_vq_ema_stats': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                         c_void_p],
+    'wmz_vq_ema_update': [c_void_p] * 5 + [c_int, c_int, c_double, c_double, c_void_p],
+}
+
+
+class WmzError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises WmzError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WmzError(f'{LIB_PATH} not found: build it with `python -m world_modelz_amd.build` '
+                           '(there is no CPU fallback for the HIP path)')
+        L = ctypes.CDLL(LIB_PATH)
+        L.wmz_version.restype = c_int
+        L.wmz_last_error.restype = ctypes.c_char_p
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name, None)
+            if fn is None:
+                continue  # declared but not built yet: calling it raises below
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    L = lib()
+    fn = getattr(L, name, None)
+    if fn is None:
+        raise WmzError(f'{name} is not exported by {LIB_PATH}')
+    rc = fn(*args)
+    if rc != 0:
+        raise WmzError(f'{name} failed (code {rc}): {L.wmz_last_error().decode()}')
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return WMZ_F32
+    if dt == torch.bfloat16:
+        return WMZ_BF16
+    raise WmzError(f'unsupported activation dtype {dt}: the HIP path computes in float32 or bfloat16')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  CPU tensors are refused: the product path is GPU-only."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise WmzError('libwmz_hip.so needs device (ROCm) tensors; got a CPU tensor '
+                       '(the CPU oracle lives under oracle/ and is test infrastructure only)')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,144 @@
+// Shared geometry helpers of the local-3D-attention kernels (forward and backward).
+//
+// Token grid [B,S,H,W]; one (b, s) plane is flattened to p = h*W + w and cut into TILES of 16 consecutive
+// positions (the last tile of a plane may be ragged).  A workgroup owns NWAVES*QPW consecutive query tiles
+// of one plane and one head; key/value tiles of plane s+ds are staged through LDS KC tiles at a time.
+// Window membership of (query, key) is decided from packed (h<<16 | w) coordinates with packed-u16 math.
+#pragma once
+#include "wmz_common.h"
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+struct AttnGeom {
+  int B, S, H, W, heads, dh;
+  int eS, eH, eW;
+  long ldq, ldk, ldv, ldo;
+  int HW;        // H*W
+  int tiles;     // ceil(HW/16)
+  int qgroups;   // workgroups per (b, head, s) plane
+  float scale;   // dh^-0.5
+};
+
+struct TileInfo { int hlo, hhi, wlo, whi; };
+
+#define WMZ_ATTN_INVALID_COORD 0x7FFF7FFF
+
+// coords[p] = (h<<16 | w) for p < HW, INVALID beyond; tinfo[t] = row/col bounding box of tile t.
+__device__ __forceinline__ void attn_build_tables(int* coords, TileInfo* tinfo, int HW, int W, int tiles,
+                                                  int tid, int nthreads) {
+  for (int p = tid; p < tiles * 16; p += nthreads) {
+    int c = WMZ_ATTN_INVALID_COORD;
+    if (p < HW) { const int h = p / W; c = (h << 16) | (p - h * W); }
+    coords[p] = c;
+  }
+  for (int t = tid; t < tiles; t += nthreads) {
+    const int p0 = t * 16, p1 = min(p0 + 15, HW - 1);
+    TileInfo ti;
+    ti.hlo = p0 / W; ti.hhi = p1 / W;
+    if (ti.hlo == ti.hhi) { ti.wlo = p0 - ti.hlo * W; ti.whi = p1 - ti.hhi * W; }
+    else { ti.wlo = 0; ti.whi = W - 1; }
+    tinfo[t] = ti;
+  }
+}
+
+// Packed window test.  cmin = ((hq-eH)&0xFFFF)<<16 | ((wq-eW)&0xFFFF), lim = (2eH<<16)|2eW.
+// Returns t = ck - cmin per 16-bit field; in-window iff both fields <= lim's.
+__device__ __forceinline__ unsigned win_delta(int ck, unsigned cmin) {
+  const u16x2_t t = __builtin_bit_cast(u16x2_t, (unsigned)ck) - __builtin_bit_cast(u16x2_t, cmin);
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ bool win_inside(unsigned t, unsigned lim) {
+  const u16x2_t m = __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, t), __builtin_bit_cast(u16x2_t, lim));
+  return __builtin_bit_cast(unsigned, m) == t;
+}
+__device__ __forceinline__ unsigned win_cmin(int cq, int eH, int eW) {
+  const int hq = cq >> 16, wq = cq & 0xFFFF;
+  return (((unsigned)(hq - eH) & 0xFFFFu) << 16) | ((unsigned)(wq - eW) & 0xFFFFu);
+}
+
+// LDS tile images.  Row r of a tile block holds ROWB bytes; 16-byte chunk c of row r lives at
+//   r*ROWB + ((c*16) ^ swz(r)).
+// kswz makes the row-fragment read (ds_read_b128: lanes = 16 rows x 4 chunks) conflict-free,
+// vswz makes the transposed read (ds_read_b64_tr_b16: 8 rows x 32 B per half-wave) conflict-free.
+template <int ROWB> __device__ __forceinline__ int kswz(int r) {
+  if constexpr (ROWB >= 256) return (r & 15) << 4;
+  else return ((r / (256 / ROWB)) << 4) & (ROWB - 16);
+}
+template <int ROWB> __device__ __forceinline__ int vswz(int r) {
+  if constexpr (ROWB >= 256) return (r & 7) << 5;
+  else if constexpr (ROWB >= 64) return ((r / (256 / ROWB)) << 5) & (ROWB - 32);
+  else return 0;
+}
+
+// Stage `ntiles` 16-row tiles of a [HW, ld] plane (rows c0*16 ...) into an LDS image; rows >= HW and
+// columns >= dh are zero-filled.  VS selects the V swizzle.
+template <typename T, int DH, bool VS>
+__device__ __forceinline__ void attn_stage_tiles(char* dst, const T* plane, long ld, int c0, int ntiles, int HW,
+                                                 int dh, int tid, int nthreads) {
+  constexpr int ROWB = DH * (int)sizeof(T);
+  constexpr int CPR = ROWB / 16;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int total = ntiles * 16 * CPR;
+  for (int idx = tid; idx < total; idx += nthreads) {
+    const int r = idx / CPR, c = idx - r * CPR;
+    const int p = c0 * 16 + r;
+    i32x4 val = (i32x4)(0);
+    if (p < HW && c * EPC < dh) val = *reinterpret_cast<const i32x4*>(plane + (long)p * ld + c * EPC);
+    const int sw = VS ? vswz<ROWB>(r) : kswz<ROWB>(r);
+    *reinterpret_cast<i32x4*>(dst + r * ROWB + ((c << 4) ^ sw)) = val;
+  }
+}
+
+// Row fragment (8 consecutive elements starting at element e0, e0 % 8 == 0) of image row r.
+template <typename T, int DH, bool VS>
+__device__ __forceinline__ void lds_row_frag(Frag8<T>& f, const char* img, int r, int e0) {
+  constexpr int ROWB = DH * (int)sizeof(T);
+  const int sw = VS ? vswz<ROWB>(r) : kswz<ROWB>(r);
+  const char* row = img + r * ROWB;
+  if constexpr (sizeof(T) == 2) {
+    f.v = *reinterpret_cast<const s16x8*>(row + ((e0 * 2) ^ sw));
+  } else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + ((e0 * 4) ^ sw));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(row + ((e0 * 4 + 16) ^ sw));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f.v[i] = a[i]; f.v[4 + i] = b[i]; }
+  }
+}
+
+// Transposed fragment: element j of the result = img[row rbase[j>>2] + 4g + (j&3)][col], i.e. 8 rows of ONE
+// column.  bf16 uses the hardware transpose read (all 64 lanes must execute it: EXEC all ones).
+//   ra / rb: first row of the two 16-row tiles, g = lane>>4, li = lane&15, col0 = first column of the
+//   16-column block; the lane's column is col0 + li.
+template <typename T, int DH, bool VS>
+__device__ __forceinline__ void lds_col_frag(Frag8<T>& f, const char* img, int ra, int rb, int g, int li, int col0) {
+  constexpr int ROWB = DH * (int)sizeof(T);
+  if constexpr (sizeof(T) == 2) {
+    // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the 4x16 block
+    const int q = li >> 2, p = li & 3;
+    const int r0 = ra + 4 * g + q, r1 = rb + 4 * g + q;
+    const int cb = (col0 + 4 * p) * 2;
+    const int sw0 = VS ? vswz<ROWB>(r0) : kswz<ROWB>(r0);
+    const int sw1 = VS ? vswz<ROWB>(r1) : kswz<ROWB>(r1);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r0 * ROWB + (cb ^ sw0)));
+    const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r1 * ROWB + (cb ^ sw1)));
+    f.v = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ((j >> 2) ? rb : ra) + 4 * g + (j & 3);
+      const int sw = VS ? vswz<ROWB>(r) : kswz<ROWB>(r);
+      f.v[j] = *reinterpret_cast<const float*>(img + r * ROWB + (((col0 + li) * 4) ^ sw));
+    }
+  }
+}
+
+template <typename T> __device__ __forceinline__ void frag_from_f32(Frag8<T>& f, const float (&p)[8]);
+template <> __device__ __forceinline__ void frag_from_f32<float>(Frag8<float>& f, const float (&p)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = p[i];
+}
+template <> __device__ __forceinline__ void frag_from_f32<bf16_t>(Frag8<bf16_t>& f, const float (&p)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = (short)f32_to_bf16_bits(p[i]);
+}

@@ -1,0 +1,261 @@
+// Local windowed 3D attention, forward (replaces Local3dAttention.local_attention,
+// vq-video-diffusion/local_3d_attention.py:78-99, without materialising the unfolded K/V).
+//
+// Work split: a workgroup (4 waves) owns 4*QPW consecutive 16-query tiles of one (b, head, s) plane.  For every
+// in-range key plane s+ds it stages KC key tiles of K and V into LDS (swizzled images), and each wave walks the
+// key tiles its query tiles can see, two at a time:
+//   S^T[32 keys x 16 queries] = K . Q^T          (MFMA 16x16x32, A = K rows from LDS, B = Q rows in registers)
+//   window mask (packed u16 coordinate test), online softmax (row max via two wave shuffles)
+//   O^T[dh x 16 queries]    += V^T . P^T          (A = V^T by ds_read_b64_tr_b16, B = P straight from S^T's
+//                                                  accumulator layout: no cross-lane movement)
+// The reference's zero-padded, -1e9-masked slots have probability exactly 0, so they are simply not visited.
+#include "attn_common.h"
+
+namespace {
+
+constexpr int NWAVES = 4;
+constexpr int NTHREADS = NWAVES * 64;
+
+template <typename T, int DH, int QPW, int KC>
+__global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                               const T* __restrict__ V, T* __restrict__ O,
+                                                               float* __restrict__ LSE, float* __restrict__ DBG,
+                                                               AttnGeom G) {
+  constexpr int ROWB = DH * (int)sizeof(T);
+  constexpr int IMG = KC * 16 * ROWB;
+  constexpr int KS = DH / 32;   // k-steps of QK^T
+  constexpr int MT = DH / 16;   // 16-row blocks of O^T
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + IMG;
+  int* coords = reinterpret_cast<int*>(smem + 2 * IMG);
+  TileInfo* tinfo = reinterpret_cast<TileInfo*>(coords + G.tiles * 16);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qg = lid % G.qgroups; lid /= G.qgroups;
+  const int s = lid % G.S; lid /= G.S;
+  const int head = lid % G.heads;
+  const int b = lid / G.heads;
+
+  attn_build_tables(coords, tinfo, G.HW, G.W, G.tiles, tid, NTHREADS);
+  __syncthreads();
+
+  const int HW = G.HW, dh = G.dh;
+  const long plane_q = ((long)b * G.S + s) * HW;
+  const float c2 = G.scale * 1.4426950408889634f;   // logits -> log2 domain
+  const unsigned lim = ((unsigned)(2 * G.eH) << 16) | (unsigned)(2 * G.eW);
+  const int KHW = (2 * G.eH + 1) * (2 * G.eW + 1), KW = 2 * G.eW + 1;
+
+  // ---- per query tile state
+  Frag8<T> qf[QPW][KS];
+  f32x4 o[QPW][MT];
+  float m_run[QPW], l_run[QPW];
+  unsigned cmin[QPW];
+  int need_lo[QPW], need_hi[QPW], qwlo[QPW], qwhi[QPW];
+  bool active[QPW];
+  const int qt0 = (qg * NWAVES + wave) * QPW;
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+    const int qt = qt0 + qi;
+    active[qi] = qt < G.tiles;
+    const int qtc = active[qi] ? qt : G.tiles - 1;
+    const int pq = qtc * 16 + li;
+    cmin[qi] = win_cmin(coords[pq], G.eH, G.eW);
+    const TileInfo ti = tinfo[qtc];
+    const int hlo = __builtin_amdgcn_readfirstlane(ti.hlo), hhi = __builtin_amdgcn_readfirstlane(ti.hhi);
+    qwlo[qi] = __builtin_amdgcn_readfirstlane(ti.wlo) - G.eW;
+    qwhi[qi] = __builtin_amdgcn_readfirstlane(ti.whi) + G.eW;
+    need_lo[qi] = (max(hlo - G.eH, 0) * G.W) >> 4;
+    need_hi[qi] = (min(hhi + G.eH, G.H - 1) * G.W + G.W - 1) >> 4;
+    const bool qok = active[qi] && pq < HW;
+    const T* qrow = Q + (plane_q + pq) * G.ldq + (long)head * dh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      frag_zero(qf[qi][ks]);
+      if (qok && ks * 32 + g * 8 < dh) frag_load(qf[qi][ks], qrow + ks * 32 + g * 8);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) o[qi][mt] = (f32x4)(0.f);
+    m_run[qi] = -1e30f;
+    l_run[qi] = 0.f;
+  }
+
+  // ---- key tile range of the whole workgroup (wave-uniform)
+  const int wq_first = qg * NWAVES * QPW;
+  const int wq_last = min(G.tiles - 1, wq_first + NWAVES * QPW - 1);
+  const int wg_hlo = __builtin_amdgcn_readfirstlane(tinfo[wq_first].hlo);
+  const int wg_hhi = __builtin_amdgcn_readfirstlane(tinfo[wq_last].hhi);
+  const int t_lo = (max(wg_hlo - G.eH, 0) * G.W) >> 4;
+  const int t_hi = (min(wg_hhi + G.eH, G.H - 1) * G.W + G.W - 1) >> 4;
+
+  for (int ds = -G.eS; ds <= G.eS; ++ds) {
+    const int sk = s + ds;
+    if (sk < 0 || sk >= G.S) continue;
+    const long plane_k = ((long)b * G.S + sk) * HW;
+    const T* kplane = K + plane_k * G.ldk + (long)head * dh;
+    const T* vplane = V + plane_k * G.ldv + (long)head * dh;
+    for (int c0 = t_lo; c0 <= t_hi; c0 += KC) {
+      const int ntl = min(KC, t_hi - c0 + 1);
+      __syncthreads();
+      attn_stage_tiles<T, DH, false>(Ks, kplane, G.ldk, c0, ntl, HW, dh, tid, NTHREADS);
+      attn_stage_tiles<T, DH, true>(Vs, vplane, G.ldv, c0, ntl, HW, dh, tid, NTHREADS);
+      __syncthreads();
+      const int c_hi = c0 + ntl - 1;
+#pragma unroll
+      for (int qi = 0; qi < QPW; ++qi) {
+        if (!active[qi]) continue;
+        const int lo = max(c0, need_lo[qi]), hi = min(c_hi, need_hi[qi]);
+        for (int t0 = lo; t0 <= hi; t0 += 2) {
+          const bool has1 = t0 + 1 <= hi;
+          const int t1 = has1 ? t0 + 1 : t0;
+          // column-range test (only bites when a tile is narrower than a row: W > 16)
+          const TileInfo k0 = tinfo[t0], k1 = tinfo[t1];
+          const bool n0 = __builtin_amdgcn_readfirstlane(k0.wlo) <= qwhi[qi] &&
+                          __builtin_amdgcn_readfirstlane(k0.whi) >= qwlo[qi];
+          const bool n1 = has1 && __builtin_amdgcn_readfirstlane(k1.wlo) <= qwhi[qi] &&
+                          __builtin_amdgcn_readfirstlane(k1.whi) >= qwlo[qi];
+          if (!n0 && !n1) continue;
+          const int r0 = (t0 - c0) * 16, r1 = (t1 - c0) * 16;
+
+          // ---- S^T = K Q^T for the two key tiles
+          f32x4 s0 = (f32x4)(0.f), s1 = (f32x4)(0.f);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            Frag8<T> ka, kb;
+            lds_row_frag<T, DH, false>(ka, Ks, r0 + li, ks * 32 + g * 8);
+            lds_row_frag<T, DH, false>(kb, Ks, r1 + li, ks * 32 + g * 8);
+            mma16(s0, ka, qf[qi][ks]);
+            mma16(s1, kb, qf[qi][ks]);
+          }
+          // ---- window mask.  lane holds keys 4g..4g+3 of each tile for query li
+          const i32x4 kc0 = *reinterpret_cast<const i32x4*>(coords + t0 * 16 + 4 * g);
+          const i32x4 kc1 = *reinterpret_cast<const i32x4*>(coords + t1 * 16 + 4 * g);
+          float sv[8];
+          float mx = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned d0 = win_delta(kc0[r], cmin[qi]);
+            const unsigned d1 = win_delta(kc1[r], cmin[qi]);
+            const bool ok0 = win_inside(d0, lim);
+            const bool ok1 = has1 && win_inside(d1, lim);
+            if (DBG != nullptr && qt0 * 16 + qi * 16 + li < HW) {
+              const long qrow = ((plane_q + qt0 * 16 + qi * 16 + li) * G.heads + head) * (long)((2 * G.eS + 1) * KHW);
+              if (ok0) DBG[qrow + (ds + G.eS) * KHW + (int)(d0 >> 16) * KW + (int)(d0 & 0xFFFF)] = s0[r] * G.scale;
+              if (ok1) DBG[qrow + (ds + G.eS) * KHW + (int)(d1 >> 16) * KW + (int)(d1 & 0xFFFF)] = s1[r] * G.scale;
+            }
+            sv[r] = ok0 ? s0[r] : -INFINITY;
+            sv[4 + r] = ok1 ? s1[r] : -INFINITY;
+            mx = fmaxf(mx, fmaxf(sv[r], sv[4 + r]));
+          }
+          // ---- online softmax; all four lane groups of a query agree on the running max
+          mx = wave_xor_max(mx, 16);
+          mx = wave_xor_max(mx, 32);
+          const float m_new = fmaxf(m_run[qi], mx);
+          const float alpha = exp2f((m_run[qi] - m_new) * c2);
+          m_run[qi] = m_new;
+          const float mb = -m_new * c2;
+          float p[8];
+          float psum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            p[r] = exp2f(fmaf(sv[r], c2, mb));
+            psum += p[r];
+          }
+          l_run[qi] = l_run[qi] * alpha + psum;
+          Frag8<T> pf;
+          frag_from_f32<T>(pf, p);
+          // ---- O^T = alpha O^T + V^T P^T
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            Frag8<T> vf;
+            lds_col_frag<T, DH, true>(vf, Vs, r0, r1, g, li, mt * 16);
+            o[qi][mt] *= alpha;
+            mma16(o[qi][mt], vf, pf);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- normalise and store.  lane holds query li, channels 16*mt + 4g + (0..3)
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+    if (!active[qi]) continue;
+    const int pq = (qt0 + qi) * 16 + li;
+    float l = l_run[qi];
+    l = wave_xor_add(l, 16);
+    l = wave_xor_add(l, 32);
+    if (pq >= HW) continue;
+    const float inv = 1.f / l;
+    T* orow = O + (plane_q + pq) * G.ldo + (long)head * dh;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int ch = mt * 16 + 4 * g;
+      if (ch < dh) {
+        if constexpr (sizeof(T) == 2) {
+          s16x4 pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(o[qi][mt][r] * inv);
+          *reinterpret_cast<s16x4*>(orow + ch) = pk;
+        } else {
+          *reinterpret_cast<f32x4*>(orow + ch) = o[qi][mt] * inv;
+        }
+      }
+    }
+    if (LSE != nullptr && g == 0) LSE[(plane_q + pq) * G.heads + head] = m_run[qi] * G.scale + logf(l);
+  }
+}
+
+template <typename T, int DH, int QPW, int KC>
+int launch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg, AttnGeom G,
+           hipStream_t st) {
+  G.qgroups = wmz_cdiv(G.tiles, NWAVES * QPW);
+  const long nwg = (long)G.B * G.heads * G.S * G.qgroups;
+  const size_t smem = 2 * (size_t)KC * 16 * DH * sizeof(T) + (size_t)G.tiles * 16 * 4 + (size_t)G.tiles * sizeof(TileInfo);
+  if (smem > 160 * 1024) { wmz_set_error("wmz_local3d_attn_fwd: plane too large for the LDS tables (H*W=%d)", G.HW); return WMZ_ERR_UNSUPPORTED; }
+  auto kern = attn_fwd_kernel<T, DH, QPW, KC>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, st, (const T*)q, (const T*)k, (const T*)v,
+                     (T*)out, lse, dbg, G);
+  WMZ_LAUNCH_CHECK("wmz_local3d_attn_fwd");
+  return WMZ_OK;
+}
+
+}  // namespace
+
+extern "C" int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                                    float* logits_dbg, int B, int S, int H, int W, int heads, int dh, int eS, int eH,
+                                    int eW, long ldq, long ldk, long ldv, long ldo, int dtype, void* stream) {
+  WMZ_REQUIRE(q && k && v && out, "wmz_local3d_attn_fwd: null tensor");
+  WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && heads > 0 && dh > 0, "wmz_local3d_attn_fwd: bad shape");
+  WMZ_REQUIRE(eS >= 0 && eH >= 0 && eW >= 0, "wmz_local3d_attn_fwd: negative extent");
+  WMZ_REQUIRE(H <= 16384 && W <= 16384, "wmz_local3d_attn_fwd: H, W must be <= 16384");
+  WMZ_REQUIRE(dh % 8 == 0, "wmz_local3d_attn_fwd: dim_head must be a multiple of 8 (got %d)", dh);
+  WMZ_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "wmz_local3d_attn_fwd: row strides must be multiples of 8");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_local3d_attn_fwd: bad dtype %d", dtype);
+  if (dh > 128) { wmz_set_error("wmz_local3d_attn_fwd: dim_head %d > 128 not built", dh); return WMZ_ERR_UNSUPPORTED; }
+  AttnGeom G;
+  G.B = B; G.S = S; G.H = H; G.W = W; G.heads = heads; G.dh = dh; G.eS = eS; G.eH = eH; G.eW = eW;
+  G.ldq = ldq; G.ldk = ldk; G.ldv = ldv; G.ldo = ldo;
+  G.HW = H * W; G.tiles = (G.HW + 15) / 16; G.qgroups = 0;
+  G.scale = 1.0f / sqrtf((float)dh);
+  hipStream_t st = (hipStream_t)stream;
+  const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
+  if (dtype == WMZ_BF16) {
+    if (DHp == 32) return launch<bf16_t, 32, 2, 8>(q, k, v, out, lse, logits_dbg, G, st);
+    if (DHp == 64) return launch<bf16_t, 64, 2, 8>(q, k, v, out, lse, logits_dbg, G, st);
+    return launch<bf16_t, 128, 2, 8>(q, k, v, out, lse, logits_dbg, G, st);
+  }
+  if (DHp == 32) return launch<float, 32, 1, 8>(q, k, v, out, lse, logits_dbg, G, st);
+  if (DHp == 64) return launch<float, 64, 1, 8>(q, k, v, out, lse, logits_dbg, G, st);
+  return launch<float, 128, 1, 4>(q, k, v, out, lse, logits_dbg, G, st);
+}

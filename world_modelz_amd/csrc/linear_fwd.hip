@@ -1,0 +1,246 @@
+// nn.Linear family with fused PreNorm LayerNorm prologue and bias / GELU / residual epilogue
+// (local_3d_attention.py:11-31, :46-53, :159-161; main.py:31).
+//
+//   C[M,N] = act( LN?(A)[M,K] @ Wt[N,K]^T + bias ) + residual
+//
+// 128x128 output tile per workgroup, 4 waves as 2x2, each wave 2x2 MFMA 32x32 blocks.  A and Wt are both
+// K-contiguous, so both tiles are staged row-wise into 128-byte-row LDS images (XOR-swizzled per row pair:
+// conflict-free ds_read_b128 fragment reads) with the next K-slab prefetched into registers while the
+// current one is multiplied.  The LayerNorm statistics of the workgroup's 128 rows are computed in a
+// prologue (two-pass, fp32) and applied while the A slab is written to LDS.
+#include "wmz_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128, CPR = 8, NT = 256;
+
+struct LinParams {
+  const void* A; long lda;
+  const void* Wt;
+  const float* bias;
+  const void* res; long ldr;
+  void* C; long ldc;
+  int M, N, K;
+  const float* gamma; const float* beta; float eps;
+  int flags, out_f32;
+  int nbn;
+};
+
+__device__ __forceinline__ int swz128(int r) { return ((r >> 1) << 4) & 112; }
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const i32x4& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const i32x4& c, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __int_as_float(c[i]);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const i32x4& c, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(((unsigned)c[i]) << 16);
+    f[2 * i + 1] = __uint_as_float(((unsigned)c[i]) & 0xFFFF0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ i32x4 f32_to_chunk(const float* f);
+template <> __device__ __forceinline__ i32x4 f32_to_chunk<float>(const float* f) {
+  i32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = __float_as_int(f[i]);
+  return c;
+}
+template <> __device__ __forceinline__ i32x4 f32_to_chunk<bf16_t>(const float* f) {
+  i32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    c[i] = (int)((unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16));
+  return c;
+}
+
+template <typename T, bool LN>
+__global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
+  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int BK = CPR * EPC;              // 64 (bf16) / 32 (f32)
+  constexpr int KSTEPS = BK / 16;
+  __shared__ __attribute__((aligned(16))) char As[BM * ROWB];
+  __shared__ __attribute__((aligned(16))) char Bs[BN * ROWB];
+  __shared__ float mean_s[BM], rstd_s[BM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bm = lid / P.nbn, bn = lid - bm * P.nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const T* A = reinterpret_cast<const T*>(P.A);
+  const T* Wt = reinterpret_cast<const T*>(P.Wt);
+  const int K = P.K;
+
+  if constexpr (LN) {
+    // 8 lanes per row, 32 rows per sweep; two passes (mean, then centred sum of squares)
+    const int sub = tid & 7;
+    for (int r = tid >> 3; r < BM; r += NT / 8) {
+      const int gm = m0 + r;
+      float sum = 0.f;
+      if (gm < P.M) {
+        const T* row = A + (long)gm * P.lda;
+        for (int c = sub; c * EPC < K; c += 8) {
+          float f[EPC];
+          chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(row + c * EPC), f);
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) sum += f[i];
+        }
+      }
+      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+      const float mean = sum / (float)K;
+      float sq = 0.f;
+      if (gm < P.M) {
+        const T* row = A + (long)gm * P.lda;
+        for (int c = sub; c * EPC < K; c += 8) {
+          float f[EPC];
+          chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(row + c * EPC), f);
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) { const float d = f[i] - mean; sq += d * d; }
+        }
+      }
+      sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+      if (sub == 0) { mean_s[r] = mean; rstd_s[r] = rsqrtf(sq / (float)K + P.eps); }
+    }
+  }
+
+  // this thread's 4 chunks of each slab: rows r_i = (tid>>3) + 32 i, chunk column cc = tid & 7
+  const int cc = tid & 7, rr = tid >> 3;
+  i32x4 ra[4], rb[4];
+  auto fetch = [&](int k0) {
+    const int k = k0 + cc * EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 32 * i;
+      ra[i] = (i32x4)(0);
+      rb[i] = (i32x4)(0);
+      if (k < K) {
+        if (m0 + r < P.M) ra[i] = *reinterpret_cast<const i32x4*>(A + (long)(m0 + r) * P.lda + k);
+        if (n0 + r < P.N) rb[i] = *reinterpret_cast<const i32x4*>(Wt + (long)(n0 + r) * K + k);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    const int k = k0 + cc * EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 32 * i;
+      i32x4 va = ra[i];
+      if constexpr (LN) {
+        if (k < K) {
+          float f[EPC];
+          chunk_to_f32<T>(va, f);
+          const float mu = mean_s[r], rs = rstd_s[r];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k + e] + P.beta[k + e];
+          va = f32_to_chunk<T>(f);
+        }
+      }
+      const int off = r * ROWB + ((cc << 4) ^ swz128(r));
+      *reinterpret_cast<i32x4*>(As + off) = va;
+      *reinterpret_cast<i32x4*>(Bs + off) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      Frag8<T> af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wr + 32 * i + l31;
+        const char* row = As + r * ROWB;
+        const int sw = swz128(r);
+        const int b0 = (kk * 16 + hh * 8) * (int)sizeof(T);
+        if constexpr (sizeof(T) == 2) {
+          af[i].v = *reinterpret_cast<const s16x8*>(row + (b0 ^ sw));
+        } else {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(row + (b0 ^ sw));
+          const f32x4 y = *reinterpret_cast<const f32x4*>(row + ((b0 + 16) ^ sw));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { af[i].v[e] = x[e]; af[i].v[4 + e] = y[e]; }
+        }
+        const int rn = wc + 32 * i + l31;
+        const char* rowb = Bs + rn * ROWB;
+        const int swb = swz128(rn);
+        if constexpr (sizeof(T) == 2) {
+          bf[i].v = *reinterpret_cast<const s16x8*>(rowb + (b0 ^ swb));
+        } else {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(rowb + (b0 ^ swb));
+          const f32x4 y = *reinterpret_cast<const f32x4*>(rowb + ((b0 + 16) ^ swb));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bf[i].v[e] = x[e]; bf[i].v[4 + e] = y[e]; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32(acc[i][j], af[i], bf[j]);
+    }
+  }
+
+  // epilogue: D col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const bool gelu = (P.flags & WMZ_LIN_GELU) != 0;
+  const T* R = reinterpret_cast<const T*>(P.res);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc + 32 * j + l31;
+      if (col >= P.N) continue;
+      const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + wr + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (row >= P.M) continue;
+        float v = acc[i][j][reg] + bv;
+        if (gelu) v = gelu_erf(v);
+        if (R) v += Elem<T>::to_f32(R[(long)row * P.ldr + col]);
+        if (P.out_f32) reinterpret_cast<float*>(P.C)[(long)row * P.ldc + col] = v;
+        else reinterpret_cast<T*>(P.C)[(long)row * P.ldc + col] = Elem<T>::from_f32(v);
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int wmz_linear_fwd(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
+                              long ldr, void* C, long ldc, int M, int N, int K, const float* ln_gamma,
+                              const float* ln_beta, float ln_eps, int flags, int out_f32, int dtype, void* stream) {
+  WMZ_REQUIRE(A && Wt && C, "wmz_linear_fwd: null tensor");
+  WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
+  WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0, "wmz_linear_fwd: K and lda must be multiples of 8 (K=%d lda=%ld)", K, lda);
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd: bad dtype %d", dtype);
+  WMZ_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "wmz_linear_fwd: ln_gamma and ln_beta go together");
+  LinParams P;
+  P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = residual; P.ldr = ldr; P.C = C; P.ldc = ldc;
+  P.M = M; P.N = N; P.K = K; P.gamma = ln_gamma; P.beta = ln_beta; P.eps = ln_eps; P.flags = flags;
+  P.out_f32 = out_f32;
+  const int nbm = wmz_cdiv(M, BM);
+  P.nbn = wmz_cdiv(N, BN);
+  dim3 grid((unsigned)(nbm * P.nbn)), block(NT);
+  hipStream_t st = (hipStream_t)stream;
+  const bool ln = ln_gamma != nullptr;
+  if (dtype == WMZ_BF16) {
+    if (ln) hipLaunchKernelGGL((linear_kernel<bf16_t, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((linear_kernel<bf16_t, false>), grid, block, 0, st, P);
+  } else {
+    if (ln) hipLaunchKernelGGL((linear_kernel<float, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((linear_kernel<float, false>), grid, block, 0, st, P);
+  }
+  WMZ_LAUNCH_CHECK("wmz_linear_fwd");
+  return WMZ_OK;
+}

@@ -1,0 +1,290 @@
+// VectorQuantizerEMA kernels (vq-video-diffusion/vq.py).  Compiled with -ffp-contract=off: the distance
+// arithmetic must round exactly like the reference's separate sub / mul / add tensor ops.
+#include "wmz_common.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int VQ_ROWS = 64;    // rows per workgroup: lane = row
+constexpr int VQ_WAVES = 4;    // each wave scans a quarter of every codebook tile
+constexpr int VQ_NT = VQ_ROWS * VQ_WAVES;
+
+// sum_e (x[e]-c[e])^2 in the order ATen's CPU `vectorized_inner_sum` uses for the reference expression
+// (vq.py:30): 8 SIMD lanes x 4 interleaved accumulators, leftover vectors added to a0, combined ((a0+a1)+a2)+a3, then
+// the scalar tail first and the 8 lanes in order.  Pinned by oracle.vq.distances_avx_order / tests.
+template <int E, typename XF, typename CF>
+__device__ __forceinline__ float dist_exact(XF xf, CF cf) {
+  constexpr int NV = E / 8, NI = NV / 4;
+  float t[8];
+  if constexpr (NI > 0) {
+    float acc[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xf(8 * k + j) - cf(8 * k + j); acc[k][j] = d * d; }
+#pragma unroll
+    for (int i = 1; i < NI; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int e = 8 * (4 * i + k) + j;
+          const float d = xf(e) - cf(e);
+          acc[k][j] = acc[k][j] + d * d;
+        }
+    // leftover vectors join accumulator 0 BEFORE the accumulators are combined (ATen row_sum)
+#pragma unroll
+    for (int v = NI * 4; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xf(8 * v + j) - cf(8 * v + j); acc[0][j] = acc[0][j] + d * d; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xf(8 * v + j) - cf(8 * v + j); t[j] = t[j] + d * d; }
+  }
+  float fin = 0.f;
+#pragma unroll
+  for (int e = NV * 8; e < E; ++e) { const float d = xf(e) - cf(e); fin = fin + d * d; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) fin = fin + t[j];
+  return fin;
+}
+
+// runtime-E variant of the same order (x and code rows read through pointers)
+__device__ __forceinline__ float dist_exact_rt(const float* x, int xs, const float* c, int E) {
+  const int NV = E / 8, NI = NV / 4;
+  float t[8];
+  float acc[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = 8 * (4 * i + k) + j;
+        const float d = x[e * xs] - c[e];
+        acc[k][j] = acc[k][j] + d * d;
+      }
+  for (int v = NI * 4; v < NV; ++v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = x[(8 * v + j) * xs] - c[8 * v + j]; acc[0][j] = acc[0][j] + d * d; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
+  float fin = 0.f;
+  for (int e = NV * 8; e < E; ++e) { const float d = x[e * xs] - c[e]; fin = fin + d * d; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) fin = fin + t[j];
+  return fin;
+}
+
+// E > 0: compile-time embedding dim, x row in registers.  E == 0: runtime dim, x tile in LDS ([e][row] so the
+// lane = row read is conflict-free).
+template <int E>
+__global__ __launch_bounds__(VQ_NT) void vq_argmin_kernel(const float* __restrict__ X, long ldx,
+                                                          const float* __restrict__ CB, int64_t* __restrict__ IDX,
+                                                          float* __restrict__ DMIN, int N, int C, int Ert, int CT) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Ed = E > 0 ? E : Ert;
+  float* cbs = sm;                                   // [CT][Ed]
+  float* xs = sm + (size_t)CT * Ed;                  // E==0 only: [Ed][VQ_ROWS]
+  float* red_d = xs + (E > 0 ? 0 : (size_t)Ed * VQ_ROWS);   // [VQ_WAVES][VQ_ROWS]
+  int* red_c = reinterpret_cast<int*>(red_d + VQ_WAVES * VQ_ROWS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row = (long)blockIdx.x * VQ_ROWS + lane;
+  const bool rok = row < N;
+
+  float xr[E > 0 ? E : 1];
+  if constexpr (E > 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) xr[e] = rok ? X[row * ldx + e] : 0.f;
+  } else {
+    for (int i = tid; i < Ed * VQ_ROWS; i += VQ_NT) {
+      const int r = i / Ed, e = i - r * Ed;
+      const long gr = (long)blockIdx.x * VQ_ROWS + r;
+      xs[e * VQ_ROWS + r] = gr < N ? X[gr * ldx + e] : 0.f;
+    }
+  }
+
+  float best_d = INFINITY;
+  int best_c = INT_MAX;
+  const int per_wave = CT / VQ_WAVES;
+  for (int c0 = 0; c0 < C; c0 += CT) {
+    __syncthreads();
+    const int nc = min(CT, C - c0);
+    for (int i = tid * 4; i < nc * Ed; i += VQ_NT * 4) {
+      if (((Ed & 3) == 0)) *reinterpret_cast<f32x4*>(cbs + i) = *reinterpret_cast<const f32x4*>(CB + (long)c0 * Ed + i);
+      else for (int k = 0; k < 4 && i + k < nc * Ed; ++k) cbs[i + k] = CB[(long)c0 * Ed + i + k];
+    }
+    __syncthreads();
+    const int cw0 = wave * per_wave, cw1 = min(nc, cw0 + per_wave);
+    for (int c = cw0; c < cw1; ++c) {
+      const float* crow = cbs + c * Ed;
+      float d;
+      if constexpr (E > 0) d = dist_exact<E>([&](int e) { return xr[e]; }, [&](int e) { return crow[e]; });
+      else d = dist_exact_rt(xs + lane, VQ_ROWS, crow, Ed);
+      if (d < best_d) { best_d = d; best_c = c0 + c; }
+    }
+  }
+  red_d[wave * VQ_ROWS + lane] = best_d;
+  red_c[wave * VQ_ROWS + lane] = best_c;
+  __syncthreads();
+  if (wave == 0 && rok) {
+    float bd = red_d[lane];
+    int bc = red_c[lane];
+#pragma unroll
+    for (int w = 1; w < VQ_WAVES; ++w) {
+      const float d = red_d[w * VQ_ROWS + lane];
+      const int c = red_c[w * VQ_ROWS + lane];
+      if (d < bd || (d == bd && c < bc)) { bd = d; bc = c; }
+    }
+    if (bc == INT_MAX) bc = 0;
+    IDX[row] = bc;
+    if (DMIN) DMIN[row] = bd;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vq_gather_kernel(const int64_t* __restrict__ idx, const float* __restrict__ cb,
+                                                        T* __restrict__ out, long ldo, long N, int C, int E) {
+  const long total = N * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / E;
+    const int e = (int)(i - n * E);
+    long c = idx[n];
+    c = c < 0 ? 0 : (c >= C ? C - 1 : c);
+    out[n * ldo + e] = Elem<T>::from_f32(cb[c * E + e]);
+  }
+}
+
+// one lane per (row, channel): a wave's atomics land on <= 64 contiguous floats of one dw row
+__global__ __launch_bounds__(256) void vq_stats_kernel(const float* __restrict__ X, long ldx,
+                                                       const int64_t* __restrict__ idx, const float* __restrict__ cb,
+                                                       float* __restrict__ counts, float* __restrict__ dw,
+                                                       float* __restrict__ sqerr, long N, int C, int E) {
+  const long total = N * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / E;
+    const int e = (int)(i - n * E);
+    long c = idx[n];
+    c = c < 0 ? 0 : (c >= C ? C - 1 : c);
+    const float x = X[n * ldx + e];
+    if (dw) atomicAdd(dw + c * E + e, x);
+    if (sqerr) { const float d = cb[c * E + e] - x; atomicAdd(sqerr + c, d * d); }
+    if (counts && e == 0) atomicAdd(counts + c, 1.0f);
+  }
+}
+
+// single workgroup: cluster-size EMA, Laplace smoothing, codebook update (vq.py:44, :53-65)
+__global__ __launch_bounds__(1024) void vq_ema_update_kernel(float* __restrict__ emb, float* __restrict__ cs,
+                                                             float* __restrict__ act, const float* __restrict__ counts,
+                                                             const float* __restrict__ dw, int C, int E, float decay,
+                                                             float one_minus, float eps) {
+  __shared__ float red[1024];
+  __shared__ float n_s;
+  const int tid = threadIdx.x;
+  float part = 0.f;
+  for (int c = tid; c < C; c += 1024) {
+    const float v = cs[c] * decay + one_minus * counts[c];
+    cs[c] = v;
+    if (act) act[c] += counts[c];
+    part += v;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) n_s = red[0];
+  __syncthreads();
+  const float n = n_s;
+  const float denom = n + (float)C * eps;
+  for (int i = tid; i < C * E; i += 1024) {
+    const int c = i / E;
+    const float smooth = (cs[c] + eps) / denom * n;
+    emb[i] = emb[i] * decay + one_minus * (dw[i] / smooth);
+  }
+}
+
+template <int E>
+int launch_argmin(const float* x, long ldx, const float* cb, int64_t* idx, float* dmin, int N, int C, int Ert,
+                  hipStream_t st) {
+  const int Ed = E > 0 ? E : Ert;
+  int CT = 128;
+  while (CT > 4 && (size_t)CT * Ed * 4 > 48 * 1024) CT >>= 1;
+  size_t smem = (size_t)CT * Ed * 4 + (E > 0 ? 0 : (size_t)Ed * VQ_ROWS * 4) + VQ_WAVES * VQ_ROWS * 8;
+  if (smem > 64 * 1024) { wmz_set_error("wmz_vq_argmin: embedding_dim %d too large", Ed); return WMZ_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL(vq_argmin_kernel<E>, dim3(wmz_cdiv(N, VQ_ROWS)), dim3(VQ_NT), smem, st, x, ldx, cb, idx, dmin, N,
+                     C, Ert, CT);
+  WMZ_LAUNCH_CHECK("wmz_vq_argmin");
+  return WMZ_OK;
+}
+
+}  // namespace
+
+extern "C" int wmz_vq_argmin(const float* x, long ldx, const float* codebook, int64_t* idx, float* dist_min, int N,
+                             int C, int E, void* stream) {
+  WMZ_REQUIRE(x && codebook && idx, "wmz_vq_argmin: null tensor");
+  WMZ_REQUIRE(N >= 0 && C > 0 && E > 0, "wmz_vq_argmin: bad shape N=%d C=%d E=%d", N, C, E);
+  WMZ_REQUIRE(E < 512, "wmz_vq_argmin: embedding_dim >= 512 needs ATen's cascade levels (not built)");
+  if (N == 0) return WMZ_OK;
+  hipStream_t st = (hipStream_t)stream;
+  switch (E) {
+    case 64: return launch_argmin<64>(x, ldx, codebook, idx, dist_min, N, C, E, st);
+    case 32: return launch_argmin<32>(x, ldx, codebook, idx, dist_min, N, C, E, st);
+    case 16: return launch_argmin<16>(x, ldx, codebook, idx, dist_min, N, C, E, st);
+    case 8: return launch_argmin<8>(x, ldx, codebook, idx, dist_min, N, C, E, st);
+    default: return launch_argmin<0>(x, ldx, codebook, idx, dist_min, N, C, E, st);
+  }
+}
+
+extern "C" int wmz_vq_gather(const int64_t* idx, const float* codebook, void* out, long ldo, int N, int C, int E,
+                             int dtype, void* stream) {
+  WMZ_REQUIRE(idx && codebook && out, "wmz_vq_gather: null tensor");
+  WMZ_REQUIRE(N >= 0 && C > 0 && E > 0, "wmz_vq_gather: bad shape");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_vq_gather: bad dtype %d", dtype);
+  if (N == 0) return WMZ_OK;
+  const long total = (long)N * E;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16)
+    hipLaunchKernelGGL(vq_gather_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, idx, codebook, (bf16_t*)out, ldo, (long)N, C, E);
+  else
+    hipLaunchKernelGGL(vq_gather_kernel<float>, dim3(grid), dim3(256), 0, st, idx, codebook, (float*)out, ldo, (long)N, C, E);
+  WMZ_LAUNCH_CHECK("wmz_vq_gather");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_vq_ema_stats(const float* x, long ldx, const int64_t* idx, const float* codebook, float* counts,
+                                float* dw, float* sqerr, int N, int C, int E, void* stream) {
+  WMZ_REQUIRE(x && idx && codebook, "wmz_vq_ema_stats: null tensor");
+  WMZ_REQUIRE(N >= 0 && C > 0 && E > 0, "wmz_vq_ema_stats: bad shape");
+  if (N == 0) return WMZ_OK;
+  const long total = (long)N * E;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(vq_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, codebook, counts, dw,
+                     sqerr, (long)N, C, E);
+  WMZ_LAUNCH_CHECK("wmz_vq_ema_stats");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_count, const float* counts,
+                                 const float* dw, int C, int E, double decay, double eps, void* stream) {
+  WMZ_REQUIRE(embedding && cluster_size && counts && dw, "wmz_vq_ema_update: null tensor");
+  WMZ_REQUIRE(C > 0 && E > 0, "wmz_vq_ema_update: bad shape");
+  // the reference multiplies fp32 tensors by the Python doubles `decay` and `1 - decay` (vq.py:53, :65)
+  const float one_minus = (float)(1.0 - decay);
+  hipLaunchKernelGGL(vq_ema_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, embedding, cluster_size,
+                     activation_count, counts, dw, C, E, (float)decay, one_minus, (float)eps);
+  WMZ_LAUNCH_CHECK("wmz_vq_ema_update");
+  return WMZ_OK;
+}

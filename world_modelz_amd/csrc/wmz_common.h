@@ -1,0 +1,117 @@
+// Shared device/host helpers for libwmz_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/wmz.h"
+
+// ---------------------------------------------------------------- error plumbing (host)
+void wmz_set_error(const char* fmt, ...);
+
+#define WMZ_REQUIRE(cond, ...)                       \
+  do {                                               \
+    if (!(cond)) {                                   \
+      wmz_set_error(__VA_ARGS__);                    \
+      return WMZ_ERR_ARG;                            \
+    }                                                \
+  } while (0)
+
+#define WMZ_LAUNCH_CHECK(name)                                               \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      wmz_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+      return WMZ_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+
+static inline int wmz_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- element types
+typedef __hip_bfloat16 bf16_t;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;   // 8 bf16 = one 16x16x32 / 32x32x16 operand
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned)b) << 16);
+}
+// round-to-nearest-even; the plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  bf16_t h = __float2bfloat16(f);
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kDtype = WMZ_F32;
+  static constexpr int kPerChunk = 4;                  // elements per 16-byte chunk
+  __device__ static __forceinline__ float to_f32(float v) { return v; }
+  __device__ static __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kDtype = WMZ_BF16;
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float to_f32(bf16_t v) { return __bfloat162float(v); }
+  __device__ static __forceinline__ bf16_t from_f32(float v) { return __float2bfloat16(v); }
+};
+
+// An MFMA operand fragment of 8 consecutive k-elements (lane-local).
+template <typename T> struct Frag8;
+template <> struct Frag8<float> { float v[8]; };
+template <> struct Frag8<bf16_t> { s16x8 v; };
+
+__device__ __forceinline__ void frag_zero(Frag8<float>& f) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = 0.f;
+}
+__device__ __forceinline__ void frag_zero(Frag8<bf16_t>& f) { f.v = (s16x8)(0); }
+
+// 16-byte chunk loads into a fragment half/whole.  bf16: one chunk = whole fragment; f32: two chunks.
+__device__ __forceinline__ void frag_load(Frag8<bf16_t>& f, const bf16_t* p) {
+  f.v = *reinterpret_cast<const s16x8*>(p);
+}
+__device__ __forceinline__ void frag_load(Frag8<float>& f, const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f.v[i] = a[i]; f.v[4 + i] = b[i]; }
+}
+
+// D(16x16) += A(16x32) * B(32x16).  Lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15],
+// j = 0..7; D: col = l&15, row = 4*(l>>4)+reg.   f32: eight exact-f32 16x16x4 MFMAs (k = 8g+j summed over g).
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag8<bf16_t>& a, const Frag8<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag8<float>& a, const Frag8<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// D(32x32) += A(32x16) * B(16x32).  Lane l holds A[row l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col l&31];
+// D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag8<bf16_t>& a, const Frag8<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag8<float>& a, const Frag8<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// wave64 butterfly helpers
+__device__ __forceinline__ float wave_xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask)); }
+__device__ __forceinline__ float wave_xor_add(float v, int mask) { return v + __shfl_xor(v, mask); }
+
+// XCD-aware block remap: consecutive logical ids land on one XCD (blocks b, b+8, .. share an XCD's L2).
+// Bijective for any grid size (cdna guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
