@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoise-step latent-frames/sec on 32x16x16 latent clips (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one VqVideoDiffusionModel.forward over a batch of synthetic random-token clips (config 4:
+B = 8 clips per GPU, 32x16x16 latents, codebook 1024, dim 256, dim_head 128, extents 3,3,3, depth 4, mlp 256),
+bf16 operands / fp32 accumulation, inputs resident in HBM.  Clips are independent: every rank runs its own
+batch, no data-path collective ("weak" scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG = dict(B=8, S=32, H=16, W=16, C=1024, dim=256, dim_head=128, heads=1, extents=(3, 3, 3), depth=4, mlp_dim=256)
+HBM_PEAK_GBS = 8000.0          # MI355X spec (6290 measured float4 copy), MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(cfg, elt=2):
+    """per layer (5 N D + 8 N I) elt + weights; + tokens + embed write + last-frame logits."""
+    N = cfg['B'] * cfg['S'] * cfg['H'] * cfg['W']
+    D, I, M, L = cfg['dim'], cfg['dim_head'] * cfg['heads'], cfg['mlp_dim'], cfg['depth']
+    layer = (5 * N * D + 8 * N * I) * elt + (4 * D * I + 2 * D * M) * elt
+    step = L * layer + N * 8 + N * D * elt + cfg['B'] * cfg['H'] * cfg['W'] * (D * elt + cfg['C'] * 4)
+    attn = 4 * N * I * elt
+    return step, attn
+
+
+def usable_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota (the GPU box gives 16 of the
+    host's cores to one GPU; os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f2:
+                        n = min(n, max(1, q // int(f2.read().split()[0])))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get('WMZ_CPU_BASELINE_THREADS', '16'))))
+
+
+def log(msg):
+    sys.stderr.write(f'[bench {time.strftime("%H:%M:%S")}] {msg}\n')
+    sys.stderr.flush()
+
+
+def cpu_baseline(cfg, sd, budget_s=20.0):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample: single clips of the same shape."""
+    from oracle import denoiser as oden
+    torch.manual_seed(1234)
+    z = torch.randint(0, cfg['C'] + 1, (1, cfg['S'], cfg['H'], cfg['W']))
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        oden.denoiser_forward(sd, z, cfg['extents'], cfg['heads'])      # warm-up
+        times = []
+        t_end = time.time() + budget_s
+        while len(times) < 5 and (time.time() < t_end or not times):
+            t0 = time.time()
+            oden.denoiser_forward(sd, z, cfg['extents'], cfg['heads'])
+            times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': cfg['S'] / med, 'unit': 'latent-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{len(times)} x one 1x{cfg["S"]}x{cfg["H"]}x{cfg["W"]} clip forward (fp32 torch CPU oracle), '
+                      f'median {med * 1e3:.0f} ms'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from world_modelz_amd import config, ops
+    from world_modelz_amd.main import VqVideoDiffusionModel
+
+    cfg = CFG
+    dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    config.set_compute_dtype(dtype)
+    torch.manual_seed(42)
+    model = VqVideoDiffusionModel(data_shape=(cfg['S'], cfg['H'], cfg['W']), dim=cfg['dim'], num_classes=cfg['C'],
+                                  extents=cfg['extents'], depth=cfg['depth'], dim_head=cfg['dim_head'],
+                                  mlp_dim=cfg['mlp_dim'], heads=cfg['heads'])
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(1234 + rank)
+    z = torch.randint(0, cfg['C'] + 1, (cfg['B'], cfg['S'], cfg['H'], cfg['W']), generator=gen).to(dev)
+
+    # per-launch HIP-event timing of the dominant kernel (the local-3D-attention forward), on torch's current
+    # stream, which is the stream every wmz kernel is enqueued on
+    ev = []
+
+    def hook(name, start):
+        if name != 'wmz_local3d_attn_fwd' or not hook.on:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if start:
+            ev.append([e, None])
+        else:
+            ev[-1][1] = e
+    hook.on = False
+    ops.set_profile_hook(hook)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    log(f'model built, starting {a.warmup} warm-up steps')
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            model(z)
+        barrier()
+        log('warm-up done')
+        hook.on = True
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            y = model(z)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+    hook.on = False
+    elapsed = t1 - t0
+    log(f'{a.steps} timed steps in {elapsed:.3f} s')
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(y).all()
+
+    frames = cfg['B'] * cfg['S'] * world * a.steps
+    ms_per_step = elapsed / a.steps * 1e3
+    elt = 2 if dtype == torch.bfloat16 else 4
+    step_bytes, attn_bytes = algorithmic_bytes(cfg, elt)
+    attn_ms = sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev))
+    attn_gbs = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
+    out = {
+        'metric': 'denoise-step latent-frames/sec (forward, 32x16x16 latent clips)',
+        'value': frames / elapsed, 'unit': 'latent-frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': a.dtype, 'data': 'synthetic random tokens, random-init weights (seed 42)',
+        'config': {'workload': 'BASELINE.json configs[3] per GPU: VqVideoDiffusionModel.forward, B=8 clips/GPU of '
+                               '32x16x16 latents, codebook 1024, dim 256, dim_head 128, heads 1, extents 3,3,3, '
+                               'depth 4, mlp 256',
+                   'clips_per_gpu': cfg['B'], 'latent_shape': [cfg['S'], cfg['H'], cfg['W']], 'codebook': cfg['C'],
+                   'parallelism': f'clips sharded over {world} rank(s), no data-path collective'},
+        'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_kernel (local 3D attention forward)',
+                     'achieved': attn_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': attn_gbs / HBM_PEAK_GBS,
+                     'traffic': None, 'algorithmic_bytes_per_launch': attn_bytes, 'avg_launch_ms': attn_ms,
+                     'launches_timed': len(ev)},
+        'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
+                          'achieved_GBs': step_bytes / (ms_per_step * 1e-3) / 1e9,
+                          'frac_of_8TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            log(f'cpu baseline on {usable_cores()} threads')
+            out['cpu_baseline'] = cpu_baseline(cfg, sd_cpu)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

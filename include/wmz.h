@@ -28,7 +28,10 @@ enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
 
 /* epilogue / prologue flags of wmz_linear_fwd */
-enum { WMZ_LIN_GELU = 1 /* exact erf GELU on (A W^T + b) */ };
+enum {
+  WMZ_LIN_GELU = 1,    /* exact erf GELU on (A W^T + b) */
+  WMZ_LIN_GELU_IN = 2  /* exact erf GELU applied to A while it is staged (A = saved pre-activation) */
+};
 
 int wmz_version(void);
 const char* wmz_last_error(void);

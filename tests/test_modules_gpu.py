@@ -1,0 +1,103 @@
+"""GPU parity of the drop-in nn.Modules (world_modelz_amd/) against the golden vectors and the oracle."""
+import pytest
+import torch
+
+from conftest import load_golden, sub
+
+pytestmark = pytest.mark.gpu
+
+from oracle import denoiser as oden          # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def wmz():
+    assert torch.cuda.is_available()
+    import world_modelz_amd
+    from world_modelz_amd import config, local_3d_attention, main
+    return dict(config=config, l3a=local_3d_attention, main=main)
+
+
+def build_model(wmz, sd, data_shape, extents, heads):
+    D = sd['transformer.embedding.weight'].shape[1]
+    C = sd['logit_proj.weight'].shape[0]
+    depth = oden.depth_of(sd)
+    I = sd['transformer.layers.0.0.fn.to_q.weight'].shape[0]
+    M = sd['transformer.layers.0.1.fn.net.0.weight'].shape[0]
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=data_shape, dim=D, num_classes=C, extents=extents, depth=depth,
+                                          dim_head=I // heads, mlp_dim=M, heads=heads)
+    missing = m.load_state_dict(sd, strict=True)      # reference state_dict loads key-for-key
+    return m.cuda()
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.bfloat16, 3e-2)])
+def test_denoiser_vs_golden(wmz, dtype, tol):
+    g = load_golden('transformer_tiny')
+    sd = sub(g, 'sd/')
+    ext = tuple(int(e) for e in g['extents'])
+    m = build_model(wmz, sd, (4, 5, 6), ext, int(g['heads']))
+    with wmz['config'].compute_dtype(dtype), torch.no_grad():
+        x = m.transformer(g['z'].cuda())
+        logits = m(g['z'].cuda())
+        logits_short = m(g['z_short'].cuda())
+    assert logits.dtype == torch.float32 and logits.shape == g['logits'].shape
+    assert rel(x, g['x_final']) < tol
+    assert rel(logits, g['logits']) < tol
+    assert rel(logits_short, g['logits_short']) < tol
+
+
+def test_denoiser_identity_to_out(wmz):
+    g = load_golden('transformer_identity_out')
+    sd = sub(g, 'sd/')
+    ext = tuple(int(e) for e in g['extents'])
+    m = build_model(wmz, sd, (3, 4, 4), ext, 1)
+    assert isinstance(m.transformer.layers[0][0].fn.to_out, torch.nn.Identity)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        assert rel(m(g['z'].cuda()), g['logits']) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_attention_module_forward(wmz, tag):
+    g = load_golden(f'attn_module_{tag}')
+    sd = sub(g, 'sd/')
+    heads = int(g['heads'])
+    I, D = sd['to_q.weight'].shape
+    m = wmz['l3a'].Local3dAttention(tuple(int(e) for e in g['extents']), D, heads=heads, dim_head=I // heads)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        out = m(g['x'].cuda(), q=g['q'].cuda())
+    assert out.shape == g['out'].shape and rel(out, g['out']) < 1e-5
+
+
+def test_default_config_vs_oracle_bf16(wmz):
+    """Default denoiser (dim 256, dh 128, extents 3,3,3, depth 4, mlp 256) on a 2x6x16x16 grid, bf16 run dtype,
+    against the fp32 oracle: end-to-end bf16 error is reported and bounded (not a parity gate)."""
+    torch.manual_seed(42)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(6, 16, 16), dim=256, num_classes=1024, extents=(3, 3, 3), depth=4,
+                                          dim_head=128, mlp_dim=256, heads=1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    z = torch.randint(0, 1025, (2, 6, 16, 16))
+    ref = oden.denoiser_forward(sd, z, (3, 3, 3), 1)
+    m = m.cuda()
+    with torch.no_grad():
+        with wmz['config'].compute_dtype(torch.float32):
+            y32 = m(z.cuda())
+        with wmz['config'].compute_dtype(torch.bfloat16):
+            y16 = m(z.cuda())
+    assert rel(y32, ref) < 1e-5
+    e16 = rel(y16, ref)
+    print(f'bf16 end-to-end logits error vs fp32 oracle: {e16:.3e}')
+    assert e16 < 3e-2
+
+
+def test_cpu_input_is_refused(wmz):
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(2, 4, 4), dim=16, num_classes=8, extents=(1, 1, 1), depth=1,
+                                          dim_head=8, mlp_dim=16, heads=2).cuda()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 4, 4, dtype=torch.long))

@@ -1,0 +1,31 @@
+"""Operand-dtype copies of fp32 parameters, cached per (parameter version, dtype)."""
+import torch
+
+_cache = {}
+
+
+def _key(ts, dtype, tag):
+    return (tag, dtype) + tuple(id(t) for t in ts)
+
+
+def operand(params, dtype, tag='w', build=None):
+    """Return `build(*params)` (default: the single parameter itself) cast to `dtype`, contiguous, cached until
+    any of the parameters is modified in place (optimizer step, load_state_dict) or re-allocated (.to())."""
+    if not isinstance(params, (tuple, list)):
+        params = (params,)
+    if build is None and len(params) == 1 and params[0].dtype == dtype and params[0].is_contiguous():
+        return params[0].detach()
+    key = _key(params, dtype, tag)
+    ver = tuple((p._version, p.data_ptr()) for p in params)
+    hit = _cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        src = build(*params) if build is not None else params[0]
+        val = src.detach().to(dtype).contiguous()
+    _cache[key] = (ver, val)
+    return val
+
+
+def clear():
+    _cache.clear()

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libwmz_hip.so')
 
 WMZ_F32, WMZ_BF16 = 0, 1
 WMZ_LIN_GELU = 1
+WMZ_LIN_GELU_IN = 2
 
 _lib = None
 

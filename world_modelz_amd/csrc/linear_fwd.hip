@@ -57,8 +57,10 @@ template <> __device__ __forceinline__ i32x4 f32_to_chunk<bf16_t>(const float* f
   return c;
 }
 
-template <typename T, bool LN>
+// PRO: 0 = A as is, 1 = LayerNorm(A) over K, 2 = GELU(A) (FeedForward second GEMM reading the saved pre-activation)
+template <typename T, int PRO>
 __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
+  constexpr bool LN = PRO == 1;
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = CPR * EPC;              // 64 (bf16) / 32 (f32)
   constexpr int KSTEPS = BK / 16;
@@ -149,6 +151,12 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
           for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k + e] + P.beta[k + e];
           va = f32_to_chunk<T>(f);
         }
+      } else if constexpr (PRO == 2) {
+        float f[EPC];
+        chunk_to_f32<T>(va, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
+        va = f32_to_chunk<T>(f);
       }
       const int off = r * ROWB + ((cc << 4) ^ swz128(r));
       *reinterpret_cast<i32x4*>(As + off) = va;
@@ -234,12 +242,16 @@ extern "C" int wmz_linear_fwd(const void* A, long lda, const void* Wt, const flo
   dim3 grid((unsigned)(nbm * P.nbn)), block(NT);
   hipStream_t st = (hipStream_t)stream;
   const bool ln = ln_gamma != nullptr;
+  const bool gin = (flags & WMZ_LIN_GELU_IN) != 0;
+  WMZ_REQUIRE(!(ln && gin), "wmz_linear_fwd: LayerNorm and GELU prologues are exclusive");
   if (dtype == WMZ_BF16) {
-    if (ln) hipLaunchKernelGGL((linear_kernel<bf16_t, true>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((linear_kernel<bf16_t, false>), grid, block, 0, st, P);
+    if (ln) hipLaunchKernelGGL((linear_kernel<bf16_t, 1>), grid, block, 0, st, P);
+    else if (gin) hipLaunchKernelGGL((linear_kernel<bf16_t, 2>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((linear_kernel<bf16_t, 0>), grid, block, 0, st, P);
   } else {
-    if (ln) hipLaunchKernelGGL((linear_kernel<float, true>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((linear_kernel<float, false>), grid, block, 0, st, P);
+    if (ln) hipLaunchKernelGGL((linear_kernel<float, 1>), grid, block, 0, st, P);
+    else if (gin) hipLaunchKernelGGL((linear_kernel<float, 2>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((linear_kernel<float, 0>), grid, block, 0, st, P);
   }
   WMZ_LAUNCH_CHECK("wmz_linear_fwd");
   return WMZ_OK;

@@ -1,0 +1,125 @@
+"""Fused building blocks of the denoiser as torch.autograd.Functions over the HIP kernels.
+
+attention_block : to_out(local_attention(to_q(x_q), to_k(LN?(x_kv)), to_v(LN?(x_kv)))) [+ residual]
+                  (reference: PreNorm + Local3dAttention + the `+ x` of the layer loop,
+                  local_3d_attention.py:16-17, :102-118, :160)
+feed_forward_block : W2 GELU(W1 LN?(x) + b1) + b2 [+ residual]     (local_3d_attention.py:20-31, :161)
+embed_tokens    : token + 3-axis position embedding                 (local_3d_attention.py:140-157)
+
+Parameters arrive as fp32 nn.Parameters; MFMA-operand copies in the compute dtype are cached per parameter
+version (_cast.operand).  Gradients of parameters are returned in fp32.
+"""
+import torch
+
+from . import _cast, ops
+from .config import get_compute_dtype
+
+LN_EPS = 1e-5
+
+
+class _AttentionBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, residual, extents, heads):
+        dt = x_kv.dtype
+        I = wq.shape[0]
+        ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
+        wq_c = _cast.operand(wq, dt)
+        wkv_c = _cast.operand((wk, wv), dt, 'kv', lambda a, b: torch.cat([a, b], dim=0))
+        bkv = _cast.operand((bv,), torch.float32, 'bkv', lambda b: torch.cat([torch.zeros_like(b), b]))
+        lead = x_q.shape[:-1]
+        q = ops.linear_fwd(x_q, wq_c)                                           # to_q: no bias, raw input (Q1)
+        kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS)        # to_k | to_v on LN(x)
+        need_bwd = any(ctx.needs_input_grad)
+        o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], extents, heads, need_lse=need_bwd)
+        if wout is not None:
+            y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual)
+        else:
+            y = o if residual is None else o + residual
+        if need_bwd:
+            ctx.save_for_backward(x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse)
+            ctx.extents, ctx.heads, ctx.has_res = extents, heads, residual is not None
+        return y.reshape(*lead, y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import backward as B
+        return B.attention_block_backward(ctx, dy)
+
+
+class _FeedForwardBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, residual):
+        dt = x.dtype
+        ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
+        need_bwd = any(ctx.needs_input_grad)
+        w1_c, w2_c = _cast.operand(w1, dt), _cast.operand(w2, dt)
+        if need_bwd:
+            # keep the pre-activation; GELU is applied while the second GEMM stages its A operand
+            z = ops.linear_fwd(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS)
+            y = ops.linear_fwd(z, w2_c, bias=b2.detach(), residual=residual, gelu_in=True)
+            ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z)
+            ctx.has_res = residual is not None
+        else:
+            h = ops.linear_fwd(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, gelu=True)
+            y = ops.linear_fwd(h, w2_c, bias=b2.detach(), residual=residual)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import backward as B
+        return B.feed_forward_block_backward(ctx, dy)
+
+
+class _Embed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, emb, pos_s, pos_h, pos_w, dtype):
+        x = ops.embed_pos3d_fwd(z, emb.detach(), pos_s.detach(), pos_h.detach(), pos_w.detach(), dtype)
+        ctx.save_for_backward(z)
+        ctx.shapes = (emb.shape, pos_s.shape, pos_h.shape, pos_w.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        from . import backward as B
+        return B.embed_backward(ctx, dx)
+
+
+class _Linear(torch.autograd.Function):
+    """Plain nn.Linear on the HIP GEMM (logit_proj, main.py:31-36); fp32 output optional."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_f32):
+        y = ops.linear_fwd(x, _cast.operand(w, x.dtype), bias=None if b is None else b.detach(), out_f32=out_f32)
+        ctx.save_for_backward(x, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import backward as B
+        return B.linear_backward(ctx, dy)
+
+
+def _as_compute(x):
+    dt = get_compute_dtype()
+    if not x.is_cuda:
+        raise ops.L.WmzError('world_modelz_amd modules run on the GPU only (no CPU fallback); got a CPU tensor')
+    return x if x.dtype == dt else x.to(dt)
+
+
+def attention_block(x_kv, x_q, ln, wq, wk, wv, bv, wout, bout, residual, extents, heads):
+    g, b = (None, None) if ln is None else ln
+    return _AttentionBlock.apply(x_kv, x_q, g, b, wq, wk, wv, bv, wout, bout, residual, tuple(int(e) for e in extents),
+                                 int(heads))
+
+
+def feed_forward_block(x, ln, w1, b1, w2, b2, residual):
+    g, b = (None, None) if ln is None else ln
+    return _FeedForwardBlock.apply(x, g, b, w1, b1, w2, b2, residual)
+
+
+def embed_tokens(z, emb, pos_s, pos_h, pos_w):
+    return _Embed.apply(z, emb, pos_s, pos_h, pos_w, get_compute_dtype())
+
+
+def linear(x, w, b=None, out_f32=False):
+    return _Linear.apply(x, w, b, out_f32)

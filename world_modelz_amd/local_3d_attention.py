@@ -1,0 +1,145 @@
+"""MI355X drop-in for vq-video-diffusion/local_3d_attention.py.
+
+Same classes, constructor signatures, attribute names and state_dict keys as the reference
+(PreNorm :11-17, FeedForward :20-31, Local3dAttention :34-118, Local3dAttentionTransformer :121-163), so
+reference checkpoints load and `from local_3d_attention import Local3dAttentionTransformer` keeps working
+(see world_modelz_amd/dropin/).  The bodies call the fused HIP blocks in functional.py; nothing here runs on
+the CPU and nothing materialises the unfolded key/value windows.
+"""
+import torch
+from torch import nn
+
+from . import functional as Fw
+
+
+class PreNorm(nn.Module):
+    """LayerNorm in front of `fn` (reference :11-17).  Only the positional input is normalised; keyword
+    arguments (the attention's `q`) pass through untouched -- quirk Q1."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        fused = getattr(self.fn, 'forward_prenorm', None)
+        if fused is not None:
+            return fused(x, self.norm, **kwargs)         # LayerNorm rides in the GEMM prologue
+        return self.fn(nn.functional.layer_norm(x, self.norm.normalized_shape, self.norm.weight, self.norm.bias,
+                                                self.norm.eps), **kwargs)
+
+
+class FeedForward(nn.Module):
+    """Linear -> GELU -> Dropout -> Linear -> Dropout (reference :20-31); `net` indices match the reference."""
+
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+        self.dropout = dropout
+
+    def _run(self, x, ln, residual):
+        if self.dropout > 0 and self.training:
+            raise NotImplementedError('dropout > 0 in training is not built into the fused HIP feed-forward '
+                                      '(reference default and every published run use dropout 0)')
+        x = Fw._as_compute(x)
+        l1, l2 = self.net[0], self.net[3]
+        return Fw.feed_forward_block(x, ln, l1.weight, l1.bias, l2.weight, l2.bias, residual)
+
+    def forward(self, x):
+        return self._run(x, None, None)
+
+    def forward_prenorm(self, x, norm, residual=None):
+        return self._run(x, (norm.weight, norm.bias), residual)
+
+
+class Local3dAttention(nn.Module):
+    """Windowed 3D attention over a [B,S,H,W,dim] token grid (reference :34-118).
+
+    `forward(x, q)`: keys/values are projected from x, queries from q; every token attends to its
+    (2eS+1)(2eH+1)(2eW+1) neighbourhood clipped to the grid.  `use_checkpointing` is accepted for signature
+    compatibility: the HIP forward keeps only the per-row log-sum-exp, so there is nothing to checkpoint."""
+
+    def __init__(self, extents, dim, heads=8, dim_head=64, dropout=.0, use_checkpointing=True):
+        super().__init__()
+        self.extents = extents
+        inner = dim_head * heads
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.attend = nn.Softmax(dim=-1)
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(dim, inner, bias=False)
+        self.to_v = nn.Linear(dim, inner, bias=True)
+        if heads == 1 and dim_head == dim:
+            self.to_out = nn.Identity()                                   # quirk Q6: no to_out.* keys
+        else:
+            self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+        self.use_checkpointing = use_checkpointing
+        self.dropout = dropout
+
+    def _run(self, x, q, ln, residual):
+        if self.dropout > 0 and self.training:
+            raise NotImplementedError('dropout > 0 in training is not built into the fused HIP attention block')
+        x, q = Fw._as_compute(x), Fw._as_compute(q)
+        if isinstance(self.to_out, nn.Identity):
+            wo = bo = None
+        else:
+            wo, bo = self.to_out[0].weight, self.to_out[0].bias
+        y = Fw.attention_block(x, q, ln, self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_v.bias,
+                               wo, bo, residual, self.extents, self.heads)
+        return y.reshape(q.shape[:-1] + (y.shape[-1],))
+
+    def forward(self, x, q):
+        return self._run(x, q, None, None)
+
+    def forward_prenorm(self, x, norm, q, residual=None):
+        return self._run(x, q, (norm.weight, norm.bias), residual)
+
+    def local_attention(self, k, v, q):
+        """Attention core on already-projected tensors (reference :78-99), returned like the reference as
+        [(b s h w), heads, 1, dim_head]."""
+        from . import ops
+        k, v, q = Fw._as_compute(k), Fw._as_compute(v), Fw._as_compute(q)
+        out, _, _ = ops.local3d_attention_fwd(q, k, v, self.extents, self.heads)
+        return out.reshape(-1, self.heads, 1, out.shape[-1] // self.heads)
+
+
+class Local3dAttentionTransformer(nn.Module):
+    """Token + 3-axis position embedding followed by depth x [attention, feed-forward] with residuals and no
+    final LayerNorm (reference :121-163)."""
+
+    def __init__(self, *, data_shape, dim, num_classes, extents, depth, heads, dim_head, mlp_dim, dropout=.0):
+        super().__init__()
+        self.num_classes = num_classes
+        self.embedding = nn.Embedding(num_classes, dim)
+        self.pos_emb_s = nn.Embedding(data_shape[0], dim)
+        self.pos_emb_h = nn.Embedding(data_shape[1], dim)
+        self.pos_emb_w = nn.Embedding(data_shape[2], dim)
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(dim, Local3dAttention(extents, dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout)),
+            ]))
+
+    def get_pos_embedding(self, batch_shape):
+        """(pos_s + pos_h) + pos_w broadcast over the grid (reference :140-151); fp32, for inspection."""
+        _, s, h, w = batch_shape
+        ps = self.pos_emb_s.weight[:s].view(1, s, 1, 1, -1)
+        ph = self.pos_emb_h.weight[:h].view(1, 1, h, 1, -1)
+        pw = self.pos_emb_w.weight[:w].view(1, 1, 1, w, -1)
+        return ((ps + ph) + pw).expand(batch_shape[0], s, h, w, -1)
+
+    def forward(self, img_z):
+        if not img_z.is_cuda:
+            raise Fw.ops.L.WmzError('Local3dAttentionTransformer runs on the GPU only (no CPU fallback)')
+        _, S, H, W = img_z.shape
+        if S > self.pos_emb_s.num_embeddings or H > self.pos_emb_h.num_embeddings or W > self.pos_emb_w.num_embeddings:
+            raise IndexError('token grid larger than the position-embedding tables')
+        x = Fw.embed_tokens(img_z, self.embedding.weight, self.pos_emb_s.weight, self.pos_emb_h.weight,
+                            self.pos_emb_w.weight)
+        for attn, ff in self.layers:
+            # x = attn(x, q=x) + x ; x = ff(x) + x   with both residual adds fused into the GEMM epilogues
+            x = attn.fn.forward_prenorm(x, attn.norm, q=x, residual=x)
+            x = ff.fn.forward_prenorm(x, ff.norm, residual=x)
+        return x

@@ -1,0 +1,23 @@
+"""MI355X drop-in for the model class of vq-video-diffusion/main.py (VqVideoDiffusionModel, :25-36)."""
+import torch
+from torch import nn
+
+from . import functional as Fw
+from .local_3d_attention import Local3dAttentionTransformer
+
+
+class VqVideoDiffusionModel(nn.Module):
+    """Denoiser: tokens [B,S,H,W] (vocabulary num_classes + 1, the extra id is the mask token) ->
+    fp32 logits [B,H,W,num_classes] of the LAST frame only (reference :33-36; quirk Q5)."""
+
+    def __init__(self, *, data_shape, dim, num_classes, extents, depth, dim_head, mlp_dim, heads=1, dropout=.0):
+        super().__init__()
+        self.transformer = Local3dAttentionTransformer(data_shape=data_shape, dim=dim, num_classes=num_classes + 1,
+                                                       extents=extents, depth=depth, heads=heads, dim_head=dim_head,
+                                                       mlp_dim=mlp_dim, dropout=dropout)
+        self.logit_proj = nn.Linear(dim, num_classes)
+
+    def forward(self, x):
+        h = self.transformer(x)
+        last = h[:, -1]                       # [B,H,W,D] view: uniform row stride, no copy
+        return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)

@@ -3,6 +3,15 @@ import torch
 
 from . import _lib as L
 
+_profile_hook = None
+
+
+def set_profile_hook(fn):
+    """fn(kernel_name, is_start) is called right before / after a launch is enqueued (bench.py uses it to
+    bracket one kernel with HIP events on the launch stream)."""
+    global _profile_hook
+    _profile_hook = fn
+
 
 def _rows(t):
     """View [..., C] as rows; returns (tensor, nrows, row stride in elements). Last dim must be contiguous."""
@@ -34,12 +43,17 @@ def local3d_attention_fwd(q, k, v, extents, heads, need_lse=False, logits_dbg=Fa
     if logits_dbg:
         K = (2 * extents[0] + 1) * (2 * extents[1] + 1) * (2 * extents[2] + 1)
         dbg = torch.full((N, heads, K), -1e9, dtype=torch.float32, device=q.device)
+    if _profile_hook is not None:
+        _profile_hook('wmz_local3d_attn_fwd', True)
     L.call('wmz_local3d_attn_fwd', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dbg),
            B, S, H, W, heads, dh, int(extents[0]), int(extents[1]), int(extents[2]), ldq, ldk, ldv, I, dt, L.stream())
+    if _profile_hook is not None:
+        _profile_hook('wmz_local3d_attn_fwd', False)
     return out, lse, dbg
 
 
-def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=False, out_f32=False, out=None):
+def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=False, gelu_in=False, out_f32=False,
+               out=None):
     """act(LN?(a) @ weight^T + bias) + residual.   a: [..., K]; weight: [N, K] in a's dtype; bias / ln fp32."""
     K = a.shape[-1]
     N = weight.shape[0]
@@ -62,7 +76,8 @@ def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=F
     if bias is not None:
         assert bias.dtype == torch.float32
     L.call('wmz_linear_fwd', L.ptr(a), lda, L.ptr(weight), L.ptr(bias), L.ptr(residual), ldr, L.ptr(out), ldc,
-           M, N, K, L.ptr(g), L.ptr(b), float(ln_eps), L.WMZ_LIN_GELU if gelu else 0, 1 if out_f32 else 0, dt,
+           M, N, K, L.ptr(g), L.ptr(b), float(ln_eps),
+           (L.WMZ_LIN_GELU if gelu else 0) | (L.WMZ_LIN_GELU_IN if gelu_in else 0), 1 if out_f32 else 0, dt,
            L.stream())
     return out
 
