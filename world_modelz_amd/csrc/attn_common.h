@@ -70,22 +70,40 @@ template <int ROWB> __device__ __forceinline__ int vswz(int r) {
   else return 0;
 }
 
-// Stage `ntiles` 16-row tiles of a [HW, ld] plane (rows c0*16 ...) into an LDS image; rows >= HW and
-// columns >= dh are zero-filled.  VS selects the V swizzle.
-template <typename T, int DH, bool VS>
-__device__ __forceinline__ void attn_stage_tiles(char* dst, const T* plane, long ld, int c0, int ntiles, int HW,
-                                                 int dh, int tid, int nthreads) {
+// Stage `ntiles` (<= KC) 16-row tiles of a [HW, ld] plane (rows c0*16 ...) into an LDS image; rows >= HW and
+// columns >= dh are zero-filled.  VS selects the V swizzle.  Fixed trip count: all global loads of the slab are
+// issued before the first LDS store, so their latencies overlap.
+template <typename T, int DH, bool VS, int KC, int NTHREADS>
+__device__ __forceinline__ void attn_stage_load(i32x4 (&regs)[KC * 16 * (DH * (int)sizeof(T) / 16) / NTHREADS],
+                                                const T* plane, long ld, int c0, int ntiles, int HW, int dh, int tid) {
   constexpr int ROWB = DH * (int)sizeof(T);
   constexpr int CPR = ROWB / 16;
   constexpr int EPC = 16 / (int)sizeof(T);
-  const int total = ntiles * 16 * CPR;
-  for (int idx = tid; idx < total; idx += nthreads) {
+  constexpr int ITERS = KC * 16 * CPR / NTHREADS;
+  static_assert(KC * 16 * CPR % NTHREADS == 0, "slab must divide evenly over the workgroup");
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * NTHREADS;
     const int r = idx / CPR, c = idx - r * CPR;
     const int p = c0 * 16 + r;
-    i32x4 val = (i32x4)(0);
-    if (p < HW && c * EPC < dh) val = *reinterpret_cast<const i32x4*>(plane + (long)p * ld + c * EPC);
-    const int sw = VS ? vswz<ROWB>(r) : kswz<ROWB>(r);
-    *reinterpret_cast<i32x4*>(dst + r * ROWB + ((c << 4) ^ sw)) = val;
+    regs[it] = (i32x4)(0);
+    if (r < ntiles * 16 && p < HW && c * EPC < dh) regs[it] = *reinterpret_cast<const i32x4*>(plane + (long)p * ld + c * EPC);
+  }
+}
+template <typename T, int DH, bool VS, int KC, int NTHREADS>
+__device__ __forceinline__ void attn_stage_store(char* dst, const i32x4 (&regs)[KC * 16 * (DH * (int)sizeof(T) / 16) / NTHREADS],
+                                                 int ntiles, int tid) {
+  constexpr int ROWB = DH * (int)sizeof(T);
+  constexpr int CPR = ROWB / 16;
+  constexpr int ITERS = KC * 16 * CPR / NTHREADS;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * NTHREADS;
+    const int r = idx / CPR, c = idx - r * CPR;
+    if (r < ntiles * 16) {
+      const int sw = VS ? vswz<ROWB>(r) : kswz<ROWB>(r);
+      *reinterpret_cast<i32x4*>(dst + r * ROWB + ((c << 4) ^ sw)) = regs[it];
+    }
   }
 }
 

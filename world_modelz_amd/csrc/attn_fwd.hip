@@ -101,10 +101,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restri
     const T* vplane = V + plane_k * G.ldv + (long)head * dh;
     for (int c0 = t_lo; c0 <= t_hi; c0 += KC) {
       const int ntl = min(KC, t_hi - c0 + 1);
-      __syncthreads();
-      attn_stage_tiles<T, DH, false>(Ks, kplane, G.ldk, c0, ntl, HW, dh, tid, NTHREADS);
-      attn_stage_tiles<T, DH, true>(Vs, vplane, G.ldv, c0, ntl, HW, dh, tid, NTHREADS);
-      __syncthreads();
+      {
+        constexpr int NREG = KC * 16 * (ROWB / 16) / NTHREADS;
+        i32x4 kreg[NREG], vreg[NREG];
+        attn_stage_load<T, DH, false, KC, NTHREADS>(kreg, kplane, G.ldk, c0, ntl, HW, dh, tid);
+        attn_stage_load<T, DH, true, KC, NTHREADS>(vreg, vplane, G.ldv, c0, ntl, HW, dh, tid);
+        __syncthreads();      // every wave is done with the previous slab
+        attn_stage_store<T, DH, false, KC, NTHREADS>(Ks, kreg, ntl, tid);
+        attn_stage_store<T, DH, true, KC, NTHREADS>(Vs, vreg, ntl, tid);
+        __syncthreads();
+      }
       const int c_hi = c0 + ntl - 1;
 #pragma unroll
       for (int qi = 0; qi < QPW; ++qi) {

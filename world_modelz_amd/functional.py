@@ -29,7 +29,7 @@ class _AttentionBlock(torch.autograd.Function):
         lead = x_q.shape[:-1]
         q = ops.linear_fwd(x_q, wq_c)                                           # to_q: no bias, raw input (Q1)
         kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS)        # to_k | to_v on LN(x)
-        need_bwd = any(ctx.needs_input_grad)
+        need_bwd = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], extents, heads, need_lse=need_bwd)
         if wout is not None:
             y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual)
@@ -51,7 +51,7 @@ class _FeedForwardBlock(torch.autograd.Function):
     def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, residual):
         dt = x.dtype
         ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
-        need_bwd = any(ctx.needs_input_grad)
+        need_bwd = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         w1_c, w2_c = _cast.operand(w1, dt), _cast.operand(w2, dt)
         if need_bwd:
             # keep the pre-activation; GELU is applied while the second GEMM stages its A operand
