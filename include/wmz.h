@@ -30,7 +30,8 @@ enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
 /* epilogue / prologue flags of wmz_linear_fwd */
 enum {
   WMZ_LIN_GELU = 1,    /* exact erf GELU on (A W^T + b) */
-  WMZ_LIN_GELU_IN = 2  /* exact erf GELU applied to A while it is staged (A = saved pre-activation) */
+  WMZ_LIN_GELU_IN = 2, /* exact erf GELU applied to A while it is staged (A = saved pre-activation) */
+  WMZ_LIN_DGELU = 4    /* backward: `residual` holds the pre-activation z, C = (A W^T + b) * gelu'(z) */
 };
 
 int wmz_version(void);
@@ -46,12 +47,14 @@ int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v, void* out,
                          int B, int S, int H, int W, int heads, int dh, int eS, int eH, int eW,
                          long ldq, long ldk, long ldv, long ldo, int dtype, void* stream);
 
-/* Backward of the above given the saved lse: dq, dk, dv (same layouts / strides as q, k, v).
- * Replaces the checkpoint re-run + autograd of local_3d_attention.py:110-111. */
+/* Backward of the above given the saved lse: dq, dk, dv.  Gather form, no atomics (the window relation is
+ * symmetric): one query-owner pass (dq, and delta = rowsum(dout*out) into delta_ws, fp32 [N, heads]) and one
+ * key-owner pass (dk, dv).  Replaces the checkpoint re-run + autograd of local_3d_attention.py:110-111. */
 int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
-                         const void* dout, void* dq, void* dk, void* dv,
+                         const void* dout, void* dq, void* dk, void* dv, float* delta_ws,
                          int B, int S, int H, int W, int heads, int dh, int eS, int eH, int eW,
-                         long ldq, long ldk, long ldv, long ldo, int dtype, void* stream);
+                         long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv,
+                         int dtype, void* stream);
 
 /* ---- nn.Linear family (local_3d_attention.py:46-53 to_q/to_k/to_v/to_out, :23-29 FeedForward, main.py:31
  * logit_proj), optionally fused with the PreNorm LayerNorm in front (:14-17) and the residual add behind
@@ -64,11 +67,29 @@ int wmz_linear_fwd(const void* A, long lda, const void* Wt, const float* bias, c
                    void* C, long ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
                    float ln_eps, int flags, int out_f32, int dtype, void* stream);
 
+/* Weight / bias gradient of the family above: dW[N,K] += dC[M,N]^T . A'[M,K], dbias[N] += colsum(dC), where
+ * A' = A, LayerNorm(A) (ln_* non-NULL; mean/rstd from wmz_layernorm_stats) or GELU(A) (gelu_in).  dW / dbias are fp32
+ * and ACCUMULATED with float atomics (split over M): zero them first, or pass .grad buffers to accumulate. */
+int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N, int K,
+                     const float* ln_gamma, const float* ln_beta, const float* ln_mean, const float* ln_rstd,
+                     int gelu_in, int dtype, void* stream);
+/* nn.LayerNorm statistics (PreNorm, local_3d_attention.py:14): mean[M], rstd[M] over the K axis. */
+int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
+                        void* stream);
+/* nn.LayerNorm backward: dx = dLN(x)^T dyhat + skip (skip optional: the residual / un-normalised-q gradient),
+ * dgamma[K] += sum_m dyhat*xhat, dbeta[K] += sum_m dyhat (fp32, atomics). */
+int wmz_layernorm_bwd(const void* x, long ldx, const void* dyhat, long lddy, const void* skip, long ldskip,
+                      const float* gamma, void* dx, long lddx, float* dgamma, float* dbeta, int M, int K, float eps,
+                      int dtype, void* stream);
+
 /* ---- Local3dAttentionTransformer embedding (local_3d_attention.py:140-157):
  * x[b,s,h,w,:] = emb[z[b,s,h,w]] + ((pos_s[s] + pos_h[h]) + pos_w[w]); tables fp32, x in `dtype`. */
 int wmz_embed_pos3d_fwd(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                         const float* pos_w, void* x, int B, int S, int H, int W, int D, int num_classes,
                         int dtype, void* stream);
+/* its backward: scatter-add dx into the four fp32 tables (accumulated; zero them first). */
+int wmz_embed_pos3d_bwd(const int64_t* z, const void* dx, float* demb, float* dpos_s, float* dpos_h, float* dpos_w,
+                        int B, int S, int H, int W, int D, int num_classes, int dtype, void* stream);
 
 /* ---- VectorQuantizerEMA (vq.py) ----
  * wmz_vq_argmin: encode / codebook_distance+argmin (vq.py:77-87, :30-33).  x [N,E] fp32 (row stride ldx),

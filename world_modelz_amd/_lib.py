@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libwmz_hip.so')
 WMZ_F32, WMZ_BF16 = 0, 1
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
+WMZ_LIN_DGELU = 4
 
 _lib = None
 
@@ -22,7 +23,13 @@ c_void_p, c_int, c_long, c_float, c_double = (ctypes.c_void_p, ctypes.c_int, cty
 # name -> argtypes, mirrors include/wmz.h one to one
 SIGNATURES = {
     'wmz_local3d_attn_fwd': [c_void_p] * 6 + [c_int] * 9 + [c_long] * 4 + [c_int, c_void_p],
-    'wmz_local3d_attn_bwd': [c_void_p] * 9 + [c_int] * 9 + [c_long] * 4 + [c_int, c_void_p],
+    'wmz_local3d_attn_bwd': [c_void_p] * 10 + [c_int] * 9 + [c_long] * 8 + [c_int, c_void_p],
+    'wmz_linear_wgrad': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
+                        + [c_int, c_int, c_void_p],
+    'wmz_layernorm_stats': [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    'wmz_layernorm_bwd': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
+                          c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    'wmz_embed_pos3d_bwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],
     'wmz_linear_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
                        c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p],
     'wmz_embed_pos3d_fwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],

@@ -49,7 +49,64 @@ __global__ __launch_bounds__(256) void embed_pos3d_kernel(const int64_t* __restr
   }
 }
 
+// Backward: one workgroup per (b, s) plane, thread = channel.  pos_s gets one row add per plane, pos_h / pos_w are
+// reduced over the plane in LDS first (they would otherwise take B*S*W adds per element on a handful of rows);
+// the token table takes one atomic row add per token.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_pos3d_bwd_kernel(const int64_t* __restrict__ z, const T* __restrict__ dx,
+                                                              float* __restrict__ demb, float* __restrict__ dps,
+                                                              float* __restrict__ dph, float* __restrict__ dpw, int S,
+                                                              int H, int W, int D, int num_classes) {
+  extern __shared__ float sm[];     // [H][256] then [W][256]
+  float* sh = sm;
+  float* sw = sm + H * 256;
+  const int plane = blockIdx.x;
+  const int s = plane % S;
+  const int t = threadIdx.x;
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    const int d = d0 + t;
+    for (int i = 0; i < H; ++i) sh[i * 256 + t] = 0.f;
+    for (int i = 0; i < W; ++i) sw[i * 256 + t] = 0.f;
+    float as = 0.f;
+    if (d < D) {
+      for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+          const long tok_i = ((long)plane * H + h) * W + w;
+          const float v = Elem<T>::to_f32(dx[tok_i * D + d]);
+          long tok = z[tok_i];
+          tok = tok < 0 ? 0 : (tok >= num_classes ? num_classes - 1 : tok);
+          atomicAdd(demb + tok * D + d, v);
+          as += v;
+          sh[h * 256 + t] += v;
+          sw[w * 256 + t] += v;
+        }
+      atomicAdd(dps + (long)s * D + d, as);
+      for (int h = 0; h < H; ++h) atomicAdd(dph + (long)h * D + d, sh[h * 256 + t]);
+      for (int w = 0; w < W; ++w) atomicAdd(dpw + (long)w * D + d, sw[w * 256 + t]);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int wmz_embed_pos3d_bwd(const int64_t* z, const void* dx, float* demb, float* dpos_s, float* dpos_h,
+                                   float* dpos_w, int B, int S, int H, int W, int D, int num_classes, int dtype,
+                                   void* stream) {
+  WMZ_REQUIRE(z && dx && demb && dpos_s && dpos_h && dpos_w, "wmz_embed_pos3d_bwd: null tensor");
+  WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && D > 0 && num_classes > 0, "wmz_embed_pos3d_bwd: bad shape");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_embed_pos3d_bwd: bad dtype %d", dtype);
+  const size_t smem = (size_t)(H + W) * 256 * sizeof(float);
+  if (smem > 64 * 1024) { wmz_set_error("wmz_embed_pos3d_bwd: H + W = %d > 64 not built", H + W); return WMZ_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16)
+    hipLaunchKernelGGL(embed_pos3d_bwd_kernel<bf16_t>, dim3(B * S), dim3(256), smem, st, z, (const bf16_t*)dx, demb, dpos_s,
+                       dpos_h, dpos_w, S, H, W, D, num_classes);
+  else
+    hipLaunchKernelGGL(embed_pos3d_bwd_kernel<float>, dim3(B * S), dim3(256), smem, st, z, (const float*)dx, demb, dpos_s,
+                       dpos_h, dpos_w, S, H, W, D, num_classes);
+  WMZ_LAUNCH_CHECK("wmz_embed_pos3d_bwd");
+  return WMZ_OK;
+}
 
 extern "C" int wmz_embed_pos3d_fwd(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                    const float* pos_w, void* x, int B, int S, int H, int W, int D, int num_classes,

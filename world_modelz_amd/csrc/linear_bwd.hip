@@ -1,0 +1,374 @@
+// Backward pieces of the nn.Linear / PreNorm-LayerNorm family (the reference gets these from autograd):
+//   wmz_linear_wgrad    dW[N,K] += dC[M,N]^T . A'[M,K],  dbias[N] += colsum(dC)      A' = A | LN(A) | GELU(A)
+//   wmz_layernorm_stats mean / rstd per row
+//   wmz_layernorm_bwd   dx = LN'(x)^T dyhat (+ skip gradient),  dgamma, dbeta
+// (the data gradient dA' = dC . W is wmz_linear_fwd on the transposed weight, optionally x gelu'(z).)
+#include "wmz_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+template <typename T> __device__ __forceinline__ void unpack_chunk(const i32x4& c, float* f);
+template <> __device__ __forceinline__ void unpack_chunk<float>(const i32x4& c, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __int_as_float(c[i]);
+}
+template <> __device__ __forceinline__ void unpack_chunk<bf16_t>(const i32x4& c, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(((unsigned)c[i]) << 16);
+    f[2 * i + 1] = __uint_as_float(((unsigned)c[i]) & 0xFFFF0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ i32x4 pack_chunk(const float* f);
+template <> __device__ __forceinline__ i32x4 pack_chunk<float>(const float* f) {
+  i32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = __float_as_int(f[i]);
+  return c;
+}
+template <> __device__ __forceinline__ i32x4 pack_chunk<bf16_t>(const float* f) {
+  i32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    c[i] = (int)((unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16));
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// Output tile 128 (n) x 128 (k') per workgroup, reduction over a slice of M in steps of 32 rows.  Both operands are
+// "m-major" in memory, so both tiles are staged row = m and read as TRANSPOSED fragments (8 consecutive m of one column):
+// bf16 through ds_read_b64_tr_b16 from a 64-byte-granule swizzled image, fp32 as scalar reads.
+struct WgParams {
+  const void* dC; long ldc;
+  const void* A; long lda;
+  float* dW; float* dbias;
+  int M, N, K;
+  const float* gamma; const float* beta; const float* mean; const float* rstd;
+  int gelu_in;
+  int nbn, nbk, rows_per_wg;
+};
+
+constexpr int WG_BN = 128, WG_BK = 128, WG_MS = 32;
+
+template <typename T> __device__ __forceinline__ int wswz(int r) { return sizeof(T) == 2 ? ((r & 3) << 6) : 0; }
+
+// transposed 32x32x16 operand: element j = img[m0 + 8*(lane>>5) + j][c0 + (lane&31)]
+template <typename T>
+__device__ __forceinline__ void wg_col_frag(Frag8<T>& f, const char* img, int m0, int c0, int lane) {
+  constexpr int ROWB = WG_BN * (int)sizeof(T);
+  if constexpr (sizeof(T) == 2) {
+    const int gi = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int ra = m0 + 8 * (gi >> 1) + q, rb = ra + 4;
+    const int cb = (c0 + 16 * (gi & 1) + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + ra * ROWB + (cb ^ wswz<T>(ra))));
+    const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rb * ROWB + (cb ^ wswz<T>(rb))));
+    f.v = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+    const int h = lane >> 5, c = c0 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = *reinterpret_cast<const float*>(img + (m0 + 8 * h + j) * ROWB + c * 4);
+  }
+}
+
+template <typename T, int PRO>   // PRO: 0 raw A, 1 LN(A) from mean/rstd/gamma/beta, 2 GELU(A)
+__global__ __launch_bounds__(NT, 2) void wgrad_kernel(WgParams P) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int ROWB = WG_BN * (int)sizeof(T);
+  constexpr int CPR = ROWB / 16;                       // chunks per tile row: 16 (bf16) / 32 (f32)
+  constexpr int PER_T = WG_MS * CPR / NT;              // chunks per thread per tile: 2 / 4
+  __shared__ __attribute__((aligned(16))) char Cs[WG_MS * ROWB];
+  __shared__ __attribute__((aligned(16))) char As[WG_MS * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int bk = bid % P.nbk; bid /= P.nbk;
+  const int bn = bid % P.nbn; bid /= P.nbn;
+  const int split = bid;
+  const int n0 = bn * WG_BN, k0 = bk * WG_BK;
+  const int m_begin = split * P.rows_per_wg, m_end = min(P.M, m_begin + P.rows_per_wg);
+  const T* dC = reinterpret_cast<const T*>(P.dC);
+  const T* A = reinterpret_cast<const T*>(P.A);
+
+  i32x4 rc[PER_T], ra[PER_T];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int m = m0 + r;
+      rc[it] = (i32x4)(0);
+      ra[it] = (i32x4)(0);
+      if (m < m_end) {
+        if (n0 + c * EPC < P.N) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * EPC);
+        if (k0 + c * EPC < P.K) {
+          i32x4 v = *reinterpret_cast<const i32x4*>(A + (long)m * P.lda + k0 + c * EPC);
+          if constexpr (PRO != 0) {
+            float f[EPC];
+            unpack_chunk<T>(v, f);
+            if constexpr (PRO == 1) {
+              const float mu = P.mean[m], rs = P.rstd[m];
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k0 + c * EPC + e] + P.beta[k0 + c * EPC + e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
+            }
+            v = pack_chunk<T>(f);
+          }
+          ra[it] = v;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+  float bsum = 0.f;                                    // threads 0..127 of the bk == 0 workgroups: column sums of dC
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+
+  if (m_begin < m_end) fetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += WG_MS) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int off = r * ROWB + ((c << 4) ^ wswz<T>(r));
+      *reinterpret_cast<i32x4*>(Cs + off) = rc[it];
+      *reinterpret_cast<i32x4*>(As + off) = ra[it];
+    }
+    __syncthreads();
+    if (m0 + WG_MS < m_end) fetch(m0 + WG_MS);
+    if (P.dbias != nullptr && bk == 0 && tid < WG_BN) {
+#pragma unroll 8
+      for (int r = 0; r < WG_MS; ++r) {
+        const char* p = Cs + r * ROWB + ((tid * (int)sizeof(T)) ^ wswz<T>(r));
+        bsum += Elem<T>::to_f32(*reinterpret_cast<const T*>(p));
+      }
+    }
+#pragma unroll
+    for (int ms = 0; ms < WG_MS; ms += 16) {
+      Frag8<T> cf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wg_col_frag<T>(cf[i], Cs, ms, wn + 32 * i, lane);
+        wg_col_frag<T>(af[i], As, ms, wk + 32 * i, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32(acc[i][j], cf[i], af[j]);
+    }
+  }
+
+  // D: row (n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (k') = lane&31
+  const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = k0 + wk + 32 * j + l31;
+      if (kc >= P.K) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = n0 + wn + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (n < P.N) atomicAdd(P.dW + (long)n * P.K + kc, acc[i][j][reg]);
+      }
+    }
+  if (P.dbias != nullptr && bk == 0 && tid < WG_BN && n0 + tid < P.N) atomicAdd(P.dbias + n0 + tid, bsum);
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; lanes own interleaved 4-element column groups
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_stats_kernel(const T* __restrict__ X, long ldx, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, int M, int K, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  for (int m = row0; m < M; m += gridDim.x * (NT / 64)) {
+    const T* x = X + (long)m * ldx;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += Elem<T>::to_f32(x[k + e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)K;
+    float q = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = Elem<T>::to_f32(x[k + e]) - mu; q += d * d; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) { mean[m] = mu; rstd[m] = rsqrtf(q / (float)K + eps); }
+  }
+}
+
+// dx = rstd * (g*dy - mean_k(g*dy) - xhat * mean_k(g*dy*xhat)) + skip ;  dgamma += sum_m dy*xhat ; dbeta += sum_m dy
+// KMAX4 = K / 256 rounded up: per-lane column groups kept in registers.
+template <typename T, int KG>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY, long lddy,
+                                                    const T* __restrict__ SKIP, long ldskip, const float* __restrict__ gamma,
+                                                    T* __restrict__ DX, long lddx, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int M, int K, float eps) {
+  __shared__ float red[2][NT / 64][KG * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gsum[KG][4], bsum[KG][4], gam[KG][4];
+#pragma unroll
+  for (int c = 0; c < KG; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      gsum[c][e] = 0.f; bsum[c][e] = 0.f;
+      const int k = c * 256 + lane * 4 + e;
+      gam[c][e] = k < K ? gamma[k] : 0.f;
+    }
+  for (int m = blockIdx.x * (NT / 64) + wave; m < M; m += gridDim.x * (NT / 64)) {
+    float xv[KG][4], dy[KG][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < KG; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = c * 256 + lane * 4 + e;
+        xv[c][e] = k < K ? Elem<T>::to_f32(X[(long)m * ldx + k]) : 0.f;
+        dy[c][e] = k < K ? Elem<T>::to_f32(DY[(long)m * lddy + k]) : 0.f;
+        s += xv[c][e];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < KG; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = c * 256 + lane * 4 + e;
+        const float d = k < K ? xv[c][e] - mu : 0.f;
+        q += d * d;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rs = rsqrtf(q / (float)K + eps);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < KG; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = c * 256 + lane * 4 + e;
+        const float xh = k < K ? (xv[c][e] - mu) * rs : 0.f;
+        xv[c][e] = xh;
+        const float gd = gam[c][e] * dy[c][e];
+        c1 += gd;
+        c2 += gd * xh;
+        gsum[c][e] += dy[c][e] * xh;
+        bsum[c][e] += dy[c][e];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+    c1 /= (float)K;
+    c2 /= (float)K;
+#pragma unroll
+    for (int c = 0; c < KG; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = c * 256 + lane * 4 + e;
+        if (k < K) {
+          float v = rs * (gam[c][e] * dy[c][e] - c1 - xv[c][e] * c2);
+          if (SKIP) v += Elem<T>::to_f32(SKIP[(long)m * ldskip + k]);
+          DX[(long)m * lddx + k] = Elem<T>::from_f32(v);
+        }
+      }
+  }
+  // per-workgroup reduction over the 4 waves, then one atomic per column
+#pragma unroll
+  for (int c = 0; c < KG; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][wave][c * 256 + lane * 4 + e] = gsum[c][e];
+      red[1][wave][c * 256 + lane * 4 + e] = bsum[c][e];
+    }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += NT) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { a += red[0][w][k]; b += red[1][w][k]; }
+    atomicAdd(dgamma + k, a);
+    atomicAdd(dbeta + k, b);
+  }
+}
+
+}  // namespace
+
+extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N,
+                                int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
+                                const float* ln_rstd, int gelu_in, int dtype, void* stream) {
+  WMZ_REQUIRE(dC && A && dW, "wmz_linear_wgrad: null tensor");
+  WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_wgrad: bad shape");
+  WMZ_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0, "wmz_linear_wgrad: N, K and row strides must be multiples of 8");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_wgrad: bad dtype %d", dtype);
+  const bool ln = ln_gamma != nullptr;
+  WMZ_REQUIRE(!ln || (ln_beta && ln_mean && ln_rstd), "wmz_linear_wgrad: LayerNorm prologue needs gamma, beta, mean, rstd");
+  WMZ_REQUIRE(!(ln && gelu_in), "wmz_linear_wgrad: LayerNorm and GELU prologues are exclusive");
+  WgParams P;
+  P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
+  P.gamma = ln_gamma; P.beta = ln_beta; P.mean = ln_mean; P.rstd = ln_rstd; P.gelu_in = gelu_in;
+  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
+  const int tiles = P.nbn * P.nbk;
+  int split = wmz_cdiv(512, tiles);
+  const int max_split = wmz_cdiv(M, 4 * WG_MS);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  P.rows_per_wg = wmz_cdiv(wmz_cdiv(M, split), WG_MS) * WG_MS;
+  split = wmz_cdiv(M, P.rows_per_wg);
+  dim3 grid((unsigned)(tiles * split)), block(NT);
+  hipStream_t st = (hipStream_t)stream;
+  const int pro = ln ? 1 : (gelu_in ? 2 : 0);
+#define WMZ_WG(T, PRO) hipLaunchKernelGGL((wgrad_kernel<T, PRO>), grid, block, 0, st, P)
+  if (dtype == WMZ_BF16) { if (pro == 1) WMZ_WG(bf16_t, 1); else if (pro == 2) WMZ_WG(bf16_t, 2); else WMZ_WG(bf16_t, 0); }
+  else { if (pro == 1) WMZ_WG(float, 1); else if (pro == 2) WMZ_WG(float, 2); else WMZ_WG(float, 0); }
+#undef WMZ_WG
+  WMZ_LAUNCH_CHECK("wmz_linear_wgrad");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
+                                   void* stream) {
+  WMZ_REQUIRE(x && mean && rstd, "wmz_layernorm_stats: null tensor");
+  WMZ_REQUIRE(M > 0 && K > 0 && K % 4 == 0, "wmz_layernorm_stats: bad shape (K %% 4 == 0 required)");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_layernorm_stats: bad dtype %d", dtype);
+  const int grid = wmz_cdiv(M, 4) < 2048 ? wmz_cdiv(M, 4) : 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16) hipLaunchKernelGGL(ln_stats_kernel<bf16_t>, dim3(grid), dim3(NT), 0, st, (const bf16_t*)x, ldx, mean, rstd, M, K, eps);
+  else hipLaunchKernelGGL(ln_stats_kernel<float>, dim3(grid), dim3(NT), 0, st, (const float*)x, ldx, mean, rstd, M, K, eps);
+  WMZ_LAUNCH_CHECK("wmz_layernorm_stats");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_layernorm_bwd(const void* x, long ldx, const void* dyhat, long lddy, const void* skip, long ldskip,
+                                 const float* gamma, void* dx, long lddx, float* dgamma, float* dbeta, int M, int K,
+                                 float eps, int dtype, void* stream) {
+  WMZ_REQUIRE(x && dyhat && gamma && dx && dgamma && dbeta, "wmz_layernorm_bwd: null tensor");
+  WMZ_REQUIRE(M > 0 && K > 0 && K % 4 == 0, "wmz_layernorm_bwd: bad shape (K %% 4 == 0 required)");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_layernorm_bwd: bad dtype %d", dtype);
+  if (K > 1024) { wmz_set_error("wmz_layernorm_bwd: K=%d > 1024 not built", K); return WMZ_ERR_UNSUPPORTED; }
+  const int grid = wmz_cdiv(M, 16) < 1024 ? wmz_cdiv(M, 16) : 1024;
+  hipStream_t st = (hipStream_t)stream;
+  const int kg = wmz_cdiv(K, 256);
+#define WMZ_LNB(T, KG) hipLaunchKernelGGL((ln_bwd_kernel<T, KG>), dim3(grid), dim3(NT), 0, st, (const T*)x, ldx, (const T*)dyhat, lddy, \
+                                          (const T*)skip, ldskip, gamma, (T*)dx, lddx, dgamma, dbeta, M, K, eps)
+  if (dtype == WMZ_BF16) { if (kg == 1) WMZ_LNB(bf16_t, 1); else if (kg == 2) WMZ_LNB(bf16_t, 2); else WMZ_LNB(bf16_t, 4); }
+  else { if (kg == 1) WMZ_LNB(float, 1); else if (kg == 2) WMZ_LNB(float, 2); else WMZ_LNB(float, 4); }
+#undef WMZ_LNB
+  WMZ_LAUNCH_CHECK("wmz_layernorm_bwd");
+  return WMZ_OK;
+}

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 
   // epilogue: D col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool gelu = (P.flags & WMZ_LIN_GELU) != 0;
+  const bool dgelu = (P.flags & WMZ_LIN_DGELU) != 0;
   const T* R = reinterpret_cast<const T*>(P.res);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -216,7 +217,14 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
         if (row >= P.M) continue;
         float v = acc[i][j][reg] + bv;
         if (gelu) v = gelu_erf(v);
-        if (R) v += Elem<T>::to_f32(R[(long)row * P.ldr + col]);
+        if (R) {
+          const float rv = Elem<T>::to_f32(R[(long)row * P.ldr + col]);
+          if (dgelu) {   // rv is the saved pre-activation z: multiply by gelu'(z)
+            v *= 0.5f * (1.f + erff(rv * 0.70710678118654752440f)) + rv * 0.3989422804014327f * __expf(-0.5f * rv * rv);
+          } else {
+            v += rv;
+          }
+        }
         if (P.out_f32) reinterpret_cast<float*>(P.C)[(long)row * P.ldc + col] = v;
         else reinterpret_cast<T*>(P.C)[(long)row * P.ldc + col] = Elem<T>::from_f32(v);
       }

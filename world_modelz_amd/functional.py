@@ -19,7 +19,7 @@ LN_EPS = 1e-5
 
 class _AttentionBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, residual, extents, heads):
+    def forward(ctx, x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, residual, extents, heads, grad_on):
         dt = x_kv.dtype
         I = wq.shape[0]
         ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
@@ -29,7 +29,7 @@ class _AttentionBlock(torch.autograd.Function):
         lead = x_q.shape[:-1]
         q = ops.linear_fwd(x_q, wq_c)                                           # to_q: no bias, raw input (Q1)
         kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS)        # to_k | to_v on LN(x)
-        need_bwd = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        need_bwd = grad_on and any(ctx.needs_input_grad)     # grad mode is always off inside forward()
         o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], extents, heads, need_lse=need_bwd)
         if wout is not None:
             y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual)
@@ -38,6 +38,8 @@ class _AttentionBlock(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse)
             ctx.extents, ctx.heads, ctx.has_res = extents, heads, residual is not None
+            ctx.res_is_xkv = (residual is not None and residual.data_ptr() == x_kv.data_ptr()
+                              and residual.shape == x_kv.shape)
         return y.reshape(*lead, y.shape[-1])
 
     @staticmethod
@@ -48,10 +50,10 @@ class _AttentionBlock(torch.autograd.Function):
 
 class _FeedForwardBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, residual):
+    def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, residual, grad_on):
         dt = x.dtype
         ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
-        need_bwd = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        need_bwd = grad_on and any(ctx.needs_input_grad)
         w1_c, w2_c = _cast.operand(w1, dt), _cast.operand(w2, dt)
         if need_bwd:
             # keep the pre-activation; GELU is applied while the second GEMM stages its A operand
@@ -59,6 +61,7 @@ class _FeedForwardBlock(torch.autograd.Function):
             y = ops.linear_fwd(z, w2_c, bias=b2.detach(), residual=residual, gelu_in=True)
             ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z)
             ctx.has_res = residual is not None
+            ctx.res_is_x = residual is not None and residual.data_ptr() == x.data_ptr() and residual.shape == x.shape
         else:
             h = ops.linear_fwd(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, gelu=True)
             y = ops.linear_fwd(h, w2_c, bias=b2.detach(), residual=residual)
@@ -109,12 +112,12 @@ def _as_compute(x):
 def attention_block(x_kv, x_q, ln, wq, wk, wv, bv, wout, bout, residual, extents, heads):
     g, b = (None, None) if ln is None else ln
     return _AttentionBlock.apply(x_kv, x_q, g, b, wq, wk, wv, bv, wout, bout, residual, tuple(int(e) for e in extents),
-                                 int(heads))
+                                 int(heads), torch.is_grad_enabled())
 
 
 def feed_forward_block(x, ln, w1, b1, w2, b2, residual):
     g, b = (None, None) if ln is None else ln
-    return _FeedForwardBlock.apply(x, g, b, w1, b1, w2, b2, residual)
+    return _FeedForwardBlock.apply(x, g, b, w1, b1, w2, b2, residual, torch.is_grad_enabled())
 
 
 def embed_tokens(z, emb, pos_s, pos_h, pos_w):

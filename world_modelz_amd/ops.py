@@ -125,3 +125,88 @@ def vq_ema_update(embedding, cluster_size, activation_count, counts, dw, decay, 
     C, E = embedding.shape[-2:]
     L.call('wmz_vq_ema_update', L.ptr(embedding), L.ptr(cluster_size), L.ptr(activation_count), L.ptr(counts),
            L.ptr(dw), C, E, float(decay), float(eps), L.stream())
+
+
+# ------------------------------------------------------------------------------------------------ backward
+
+def local3d_attention_bwd(q, k, v, out, lse, dout, extents, heads):
+    """Returns (dq, dkv) with dkv = [..., 2I] holding dk | dv (the layout the fused k|v projection wants)."""
+    B, S, H, W, I = q.shape
+    dh = I // heads
+    dt = L.dtype_code(q.dtype)
+    q, _, ldq = _rows(q)
+    k, _, ldk = _rows(k)
+    v, _, ldv = _rows(v)
+    out, _, ldo = _rows(out)
+    dout, _, lddo = _rows(dout)
+    dq = torch.empty((B, S, H, W, I), dtype=q.dtype, device=q.device)
+    dkv = torch.empty((B, S, H, W, 2 * I), dtype=q.dtype, device=q.device)
+    delta = torch.empty((B * S * H * W, heads), dtype=torch.float32, device=q.device)
+    dk, dv = dkv[..., :I], dkv[..., I:]
+    L.call('wmz_local3d_attn_bwd', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dout), L.ptr(dq),
+           L.ptr(dk), L.ptr(dv), L.ptr(delta), B, S, H, W, heads, dh, int(extents[0]), int(extents[1]),
+           int(extents[2]), ldq, ldk, ldv, ldo, lddo, I, 2 * I, 2 * I, dt, L.stream())
+    return dq, dkv
+
+
+def linear_dgrad(dc, weight_t, dgelu_z=None):
+    """dA' = dC @ W (weight_t = W^T contiguous [K, N] in dC's dtype), optionally times gelu'(z)."""
+    K = weight_t.shape[0]
+    dt = L.dtype_code(dc.dtype)
+    dc, M, ldc = _rows(dc)
+    N = dc.shape[-1]
+    out = torch.empty(dc.shape[:-1] + (K,), dtype=dc.dtype, device=dc.device)
+    ldz = 0
+    if dgelu_z is not None:
+        dgelu_z, Mz, ldz = _rows(dgelu_z)
+        assert Mz == M
+    L.call('wmz_linear_fwd', L.ptr(dc), ldc, L.ptr(weight_t), None, L.ptr(dgelu_z), ldz, L.ptr(out), K, M, K, N,
+           None, None, 0.0, L.WMZ_LIN_DGELU if dgelu_z is not None else 0, 0, dt, L.stream())
+    return out
+
+
+def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False):
+    """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc).  dw / dbias fp32, accumulated."""
+    dt = L.dtype_code(dc.dtype)
+    dc, M, ldc = _rows(dc)
+    a, Ma, lda = _rows(a)
+    assert Ma == M and a.dtype == dc.dtype and dw.dtype == torch.float32 and dw.is_contiguous()
+    N, K = dw.shape
+    g = b = mean = rstd = None
+    if ln is not None:
+        g, b = ln
+        mean, rstd = ln_stats
+    L.call('wmz_linear_wgrad', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
+           L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, dt, L.stream())
+
+
+def layernorm_stats(x, eps=1e-5):
+    x, M, ldx = _rows(x)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    L.call('wmz_layernorm_stats', L.ptr(x), ldx, L.ptr(mean), L.ptr(rstd), M, x.shape[-1], float(eps),
+           L.dtype_code(x.dtype), L.stream())
+    return mean, rstd
+
+
+def layernorm_bwd(x, dyhat, gamma, dgamma, dbeta, skip=None, eps=1e-5):
+    x, M, ldx = _rows(x)
+    dyhat, _, lddy = _rows(dyhat)
+    lds = 0
+    if skip is not None:
+        skip, _, lds = _rows(skip)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    K = x.shape[-1]
+    L.call('wmz_layernorm_bwd', L.ptr(x), ldx, L.ptr(dyhat), lddy, L.ptr(skip), lds, L.ptr(gamma), L.ptr(dx), K,
+           L.ptr(dgamma), L.ptr(dbeta), M, K, float(eps), L.dtype_code(x.dtype), L.stream())
+    return dx
+
+
+def embed_pos3d_bwd(z, dx, shapes):
+    B, S, H, W = z.shape
+    D = dx.shape[-1]
+    dx = dx.contiguous()
+    tabs = [torch.zeros(s, dtype=torch.float32, device=dx.device) for s in shapes]
+    L.call('wmz_embed_pos3d_bwd', L.ptr(z.contiguous()), L.ptr(dx), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]),
+           L.ptr(tabs[3]), B, S, H, W, D, shapes[0][0], L.dtype_code(dx.dtype), L.stream())
+    return tabs
