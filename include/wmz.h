@@ -110,6 +110,14 @@ int wmz_vq_ema_stats(const float* x, long ldx, const int64_t* idx, const float* 
 int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_count, const float* counts,
                       const float* dw, int C, int E, double decay, double eps, void* stream);
 
+/* ---- training-step tail over flat fp32 arenas (one launch each) ----
+ * grad_norm (main.py:188-193): out[0] += scale^2 * sum g^2 (caller zeroes out[0]; no host sync). */
+int wmz_grad_sqnorm(const float* g, long n, float scale, float* out, void* stream);
+/* torch.optim.AdamW step as configured at main.py:433 (decoupled weight decay, amsgrad off), gradients read as
+ * grad_scale * g (1/world after a SUM all-reduce); `step` is the 1-based step count for the bias corrections. */
+int wmz_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, long step, double grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

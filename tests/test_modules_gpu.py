@@ -101,3 +101,47 @@ def test_cpu_input_is_refused(wmz):
                                           dim_head=8, mlp_dim=16, heads=2).cuda()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 2, 4, 4, dtype=torch.long))
+
+
+def test_vq_module_sequence_vs_golden():
+    """VectorQuantizerEMA.forward x3 (train) + eval + reuse_inactive + reset_stats: every output and buffer
+    against the reference capture (quirk Q4), plus the straight-through / commitment gradients."""
+    from world_modelz_amd.vq import VectorQuantizerEMA
+    g = load_golden('vq_forward_train')
+    m = VectorQuantizerEMA(8, 32)
+    assert set(m.state_dict().keys()) == {'embedding', 'cluster_size'}        # non-persistent buffers stay out
+    m.load_state_dict({'embedding': g['embedding0'], 'cluster_size': g['cluster_size0']})
+    m = m.cuda()
+    m.train()
+    for tag in ['t0', 't1', 't2', 'e']:
+        if tag == 'e':
+            m.eval()
+        x = g[f'{tag}/x'].cuda().requires_grad_(tag != 'e')
+        qz, enc, loss, ppl = m(x)
+        assert torch.equal(enc.argmax(-1).cpu(), g[f'{tag}/encodings_argmax'])
+        assert enc.shape == (96, 1, 32) and float(enc.sum()) == 96
+        assert torch.allclose(qz.detach().cpu(), g[f'{tag}/quantized'], rtol=0, atol=1e-6)
+        assert torch.allclose(loss.detach().cpu(), g[f'{tag}/loss'], rtol=1e-5)
+        assert torch.allclose(ppl.detach().cpu(), g[f'{tag}/perplexity'], rtol=1e-5)
+        if tag != 'e':
+            (qz.square().sum() + 3.0 * loss).backward()
+            assert torch.allclose(x.grad.cpu(), g[f'{tag}/dx'], rtol=1e-5, atol=1e-6)
+        for b in ('embedding', 'cluster_size', 'activation_count', 'accumulated_error'):
+            assert torch.allclose(getattr(m, b).cpu(), g[f'{tag}/{b}'], rtol=1e-5, atol=1e-6), (tag, b)
+    assert m.reuse_inactive() == int(g['reused'])
+    assert torch.allclose(m.embedding.cpu(), g['reuse/embedding'], rtol=1e-5, atol=1e-6)
+    m.reset_stats()
+    assert float(m.activation_count.abs().sum()) == 0 and float(m.accumulated_error.abs().sum()) == 0
+
+
+def test_vq_module_encode_decode_vs_golden():
+    from world_modelz_amd.vq import VectorQuantizerEMA
+    g = load_golden('vq_encode_1024')
+    m = VectorQuantizerEMA(64, 1024)
+    m.embedding.copy_(g['embedding'])
+    m = m.cuda()
+    idx = m.encode(g['x'].cuda())
+    assert idx.shape == (257, 1) and torch.equal(idx.cpu(), g['idx'])
+    assert torch.equal(m.decode(idx).cpu(), g['decoded'])
+    d = m.codebook_distance(g['x'].cuda()[:8], normalize=False)
+    assert torch.allclose(d[:, 0].cpu(), g['dist_rows'], rtol=1e-5)

@@ -1,0 +1,126 @@
+"""CPU (gloo, world_size 2): the flat-arena bucketed gradient all-reduce of world_modelz_amd/parallel.py.
+The reducer is device-agnostic; on the GPU box the same code runs over RCCL with the side-stream overlap."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.GELU(), torch.nn.Linear(40, 24), torch.nn.LayerNorm(24),
+                               torch.nn.Linear(24, 5))
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from world_modelz_amd.parallel import BucketedAllReduce, FlatArena, broadcast_parameters
+    torch.set_num_threads(1)
+    model = _model()
+    if rank == 1:                                       # perturb: broadcast must restore rank 0's weights
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    arena = FlatArena(model)
+    broadcast_parameters(arena)
+    red = BucketedAllReduce(arena, bucket_bytes=1024)   # tiny buckets -> several collectives per step
+    assert len(red.buckets) >= 3
+    torch.manual_seed(100)
+    x = torch.randn(8, 12)
+    y = torch.randint(0, 5, (8,))
+    for it in range(2):                                 # two steps: state resets between them
+        arena.zero_grad()
+        xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        torch.nn.functional.cross_entropy(model(xs), ys).backward()
+        scale = red.finish()
+        g = (arena.flat_grad * scale).clone()
+    ret[rank] = (g, arena.flat_param.clone(), [b[:2] for b in red.buckets])
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+        g0, p0, buckets = ret[0]
+        g1, p1, _ = ret[1]
+    assert torch.equal(p0, p1)                          # broadcast made the replicas identical
+    assert torch.equal(g0, g1)                          # and every rank holds the same reduced gradient
+    # single-process reference: mean loss over the union of both ranks' shards
+    from world_modelz_amd.parallel import FlatArena
+    model = _model()
+    arena = FlatArena(model)
+    torch.manual_seed(100)
+    x = torch.randn(8, 12)
+    y = torch.randint(0, 5, (8,))
+    loss = 0.5 * (torch.nn.functional.cross_entropy(model(x[:4]), y[:4]) + torch.nn.functional.cross_entropy(model(x[4:]), y[4:]))
+    loss.backward()
+    assert torch.allclose(g0, arena.flat_grad, rtol=1e-5, atol=1e-7)
+    assert buckets[0][0] == 0 and buckets[-1][1] == arena.numel
+
+
+def test_flat_arena_views_and_zero_grad():
+    from world_modelz_amd.parallel import FlatArena
+    model = _model()
+    ref = [p.detach().clone() for p in model.parameters()]
+    arena = FlatArena(model)
+    for p, r in zip(model.parameters(), ref):
+        assert torch.equal(p, r)
+        assert p.data_ptr() >= arena.flat_param.data_ptr()
+        assert p.grad is not None and p.grad.data_ptr() >= arena.flat_grad.data_ptr()
+    model(torch.randn(3, 12)).sum().backward()
+    assert float(arena.flat_grad.abs().sum()) > 0
+    arena.zero_grad()
+    assert float(arena.flat_grad.abs().sum()) == 0
+    with torch.no_grad():
+        arena.flat_param.add_(1.0)                      # arena writes are visible through the parameters
+    for p, r in zip(model.parameters(), ref):
+        assert torch.allclose(p, r + 1.0)
+
+
+def test_lr_schedule_and_sampler_match_golden():
+    import math
+    from conftest import load_golden
+    from world_modelz_amd.train import LossAwareSamplerEma, lr_at
+    g = load_golden('step_tiny')
+    traj = g['lr_trajectory'].tolist()
+    mine = [lr_at(s, float(g['base_lr']), int(g['warmup']), int(g['max_steps'])) for s in range(1, len(traj) + 1)]
+    assert all(math.isclose(a, b, rel_tol=1e-6, abs_tol=1e-12) for a, b in zip(mine, traj))
+    s = LossAwareSamplerEma(num_histogram_buckets=10, uniform_p=0.01, alpha=0.9, warmup=2)
+    s.update_with_losses(g['sampler/ts'], g['sampler/losses'])
+    assert torch.equal(s._counts, g['sampler/counts'])
+    assert torch.allclose(s._weights, g['sampler/weights_raw'], rtol=1e-6)
+    assert torch.allclose(s.weights(), g['sampler/weights'], rtol=1e-6)
+    r = s.sample(16)
+    assert r.shape == (16,) and float(r.min()) >= 0 and float(r.max()) < 1
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/wmz.h <-> libwmz_hip.so: the library loads on a CPU-only host and exports every entry point."""
+    import re
+    from world_modelz_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'wmz.h')).read()
+    declared = set(re.findall(r'\b(wmz_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 15
+    lib = _lib.lib()
+    assert lib.wmz_version() >= 100
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    for n in declared - {'wmz_version', 'wmz_last_error'}:
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'

@@ -1,0 +1,80 @@
+"""GPU: the training-step driver (world_modelz_amd/train.py) against the reference captures."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden, sub
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def wmz():
+    assert torch.cuda.is_available()
+    from world_modelz_amd import config, main, train
+    return dict(config=config, main=main, train=train)
+
+
+def _tiny_model(wmz, g):
+    sd0 = sub(g, 'sd0/')
+    ext = tuple(int(e) for e in g['extents'])
+    C = g['logits'].shape[-1]
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 4, 4), dim=16, num_classes=C, extents=ext, depth=2, dim_head=8,
+                                          mlp_dim=24, heads=int(g['heads']))
+    m.load_state_dict(sd0, strict=True)
+    return m.cuda(), C
+
+
+def test_one_adamw_step_matches_reference(wmz):
+    """forward/backward + flat-arena grad-norm + AdamW kernel == torch.optim.AdamW on the reference model."""
+    g = load_golden('step_tiny')
+    m, C = _tiny_model(wmz, g)
+    with wmz['config'].compute_dtype(torch.float32):
+        tr = wmz['train'].DenoiserTrainer(m, C, lr=float(g['adamw_lr']), warmup=0, max_steps=1000, distributed=False)
+        tr.arena.zero_grad()
+        per_sample, mean = tr.forward_backward(g['corrupted'].cuda(), g['target'].cuda())
+        sq = tr.optimizer_step(lr=float(g['adamw_lr']))
+    assert torch.allclose(per_sample.cpu(), g['per_sample_loss'], rtol=1e-5)
+    assert math.isclose(math.sqrt(float(sq)), float(g['grad_norm']), rel_tol=1e-4)
+    sd1 = sub(g, 'sd1/')
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.detach().cpu(), sd1[n], rtol=2e-5, atol=2e-7), n
+    # the operand caches were invalidated: a second forward sees the updated weights
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        y2 = m(g['corrupted'].cuda())
+    assert not torch.allclose(y2.cpu(), g['logits'], rtol=1e-4)
+
+
+def test_corruption_matches_reference_law(wmz):
+    """Closed-form corruption == multinomial(lerp(one_hot, 1/C, 0.1 r)) + mask (main.py:246-259) in distribution."""
+    torch.manual_seed(0)
+    C, B, HW = 8, 2, 4096
+    z = torch.full((B, 2, 64, 64), 3, device='cuda')
+    r = torch.tensor([0.6, 1.0])
+    zc, target = wmz['train'].corrupt_last_frame(z, r, C)
+    assert torch.equal(target, z[:, -1]) and torch.equal(zc[:, 0], z[:, 0])
+    for b in range(B):
+        cnt = torch.bincount(zc[b, -1].reshape(-1).cpu(), minlength=C + 1).float() / HW
+        a, rb = 0.1 * float(r[b]), float(r[b])
+        expect = torch.full((C + 1,), (1 - rb) * a / C)
+        expect[3] = (1 - rb) * (1 - a + a / C)
+        expect[C] = rb
+        assert torch.allclose(cnt, expect, atol=0.02), (cnt, expect)
+
+
+def test_training_reduces_loss(wmz):
+    """A few full train_step() calls (corrupt -> fwd/bwd -> grad-norm -> AdamW) on a learnable toy task, bf16."""
+    torch.manual_seed(1)
+    C = 16
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 8, 8), dim=64, num_classes=C, extents=(1, 1, 1), depth=2, dim_head=32,
+                                          mlp_dim=64, heads=2).cuda()
+    tr = wmz['train'].DenoiserTrainer(m, C, lr=3e-3, warmup=1, max_steps=1000, distributed=False)
+    z = torch.randint(0, C, (1, 1, 8, 8), device='cuda').expand(8, 3, 8, 8).contiguous()   # same frame repeated
+    losses = []
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        for _ in range(30):
+            loss, gn = tr.train_step(z, r=torch.full((8,), 0.9))
+            assert math.isfinite(loss) and math.isfinite(gn)
+            losses.append(loss)
+    assert losses[-1] < 0.5 * losses[0], losses

@@ -2,6 +2,7 @@
 import torch
 
 _cache = {}
+_epoch = 0      # bumped when parameters are rewritten behind torch's version counters (arena optimizer step)
 
 
 def _key(ts, dtype, tag):
@@ -16,7 +17,7 @@ def operand(params, dtype, tag='w', build=None):
     if build is None and len(params) == 1 and params[0].dtype == dtype and params[0].is_contiguous():
         return params[0].detach()
     key = _key(params, dtype, tag)
-    ver = tuple((p._version, p.data_ptr()) for p in params)
+    ver = (_epoch,) + tuple((p._version, p.data_ptr()) for p in params)
     hit = _cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -25,6 +26,12 @@ def operand(params, dtype, tag='w', build=None):
         val = src.detach().to(dtype).contiguous()
     _cache[key] = (ver, val)
     return val
+
+
+def invalidate():
+    """Parameters changed in place without torch noticing (wmz_adamw_step on the flat arena)."""
+    global _epoch
+    _epoch += 1
 
 
 def clear():

@@ -33,6 +33,8 @@ SIGNATURES = {
     'wmz_linear_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
                        c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p],
     'wmz_embed_pos3d_fwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],
+    'wmz_grad_sqnorm': [c_void_p, c_long, c_float, c_void_p, c_void_p],
+    'wmz_adamw_step': [c_void_p] * 4 + [c_long] + [c_double] * 5 + [c_long, c_double, c_void_p],
     'wmz_vq_argmin': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'wmz_vq_gather': [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_vq_ema_stats': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -1,0 +1,66 @@
+// Flat-arena optimizer kernels for the denoiser training step (reference: grad_norm main.py:188-193, which costs
+// one .item() sync per parameter tensor, and torch.optim.AdamW as configured at main.py:433).  All parameters,
+// gradients and moments live in contiguous fp32 arenas, so each of these is ONE launch over n elements.
+#include "wmz_common.h"
+
+namespace {
+
+// out[0] += scale^2 * sum g^2   (caller zeroes out; sqrt on the host or in the consumer)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; acc += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale * scale);
+}
+
+// torch.optim.AdamW (amsgrad=False, maximize=False), decoupled weight decay, bias corrections passed in:
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// g is read as grad_scale * g (1/world_size after a SUM all-reduce).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float sqrt_bc2, float grad_scale) {
+  const float step = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    pi -= step * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+}  // namespace
+
+extern "C" int wmz_grad_sqnorm(const float* g, long n, float scale, float* out, void* stream) {
+  WMZ_REQUIRE(g && out && n > 0, "wmz_grad_sqnorm: bad arguments");
+  WMZ_REQUIRE(((uintptr_t)g & 15) == 0, "wmz_grad_sqnorm: arena must be 16-byte aligned");
+  const long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)(blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024)), dim3(256), 0,
+                     (hipStream_t)stream, g, n, scale, out);
+  WMZ_LAUNCH_CHECK("wmz_grad_sqnorm");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                              double eps, double weight_decay, long step, double grad_scale, void* stream) {
+  WMZ_REQUIRE(p && g && m && v && n > 0 && step > 0, "wmz_adamw_step: bad arguments");
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, p, g,
+                     m, v, n, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1,
+                     (float)sqrt(bc2), (float)grad_scale);
+  WMZ_LAUNCH_CHECK("wmz_adamw_step");
+  return WMZ_OK;
+}

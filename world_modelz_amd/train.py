@@ -1,0 +1,138 @@
+"""Build-owned counterpart of the step body of vq-video-diffusion/main.py:train (:216-287) for the MI355X path.
+
+The reference's Python never travels; this restates the step with the same semantics:
+token corruption (:246-259), CrossEntropyLoss(reduction='none') on the last frame (:266-274), loss-aware noise-level
+sampler update (:271-272), grad_norm (:188-193), AdamW + warm-up/cosine schedule (:432-442) -- with the host syncs
+removed: one flat fp32 arena for parameters / gradients / moments, ONE grad-norm launch, ONE AdamW launch, and the
+gradient all-reduce of parallel.py overlapped with the backward.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _cast
+from . import _lib as L
+from .parallel import BucketedAllReduce, FlatArena, broadcast_parameters
+
+P_MAX_UNIFORM = 0.1     # main.py:208
+
+
+def corrupt_last_frame(batch_z, r, num_embeddings, generator=None):
+    """main.py:240-259 on the GPU without the [B,HW,C] one-hot / lerp / multinomial temporaries.
+
+    multinomial(lerp(one_hot(z), 1/C, a)) with a = 0.1 r has the closed form "with probability a redraw uniformly
+    over all C codes, else keep z" (checked against the reference's categorical law in tests); then positions with
+    rand < r become the mask token C.  Same distribution as the reference, not the same RNG stream."""
+    B = batch_z.shape[0]
+    last = batch_z[:, -1]
+    target = last.clone()
+    flat = last.reshape(B, -1)
+    dev = batch_z.device
+    r = r.to(dev).view(B, 1)
+    u = torch.rand((3,) + flat.shape, device=dev, generator=generator)
+    uni = torch.clamp((u[1] * num_embeddings).long(), max=num_embeddings - 1)
+    draw = torch.where(u[0] < r * P_MAX_UNIFORM, uni, flat)
+    draw = torch.where(u[2] < r, torch.full_like(draw, num_embeddings), draw)
+    out = batch_z.clone()
+    out[:, -1] = draw.view(last.shape)
+    return out, target
+
+
+class LossAwareSamplerEma:
+    """importance_sampling.py:5-47 (100-bucket EMA-of-loss histogram over the noise level), host side."""
+
+    def __init__(self, num_histogram_buckets=100, uniform_p=0.01, alpha=0.9, warmup=10, jitter=True):
+        assert num_histogram_buckets > 1
+        self.n, self.uniform_p, self.alpha, self.warmup, self.jitter = num_histogram_buckets, uniform_p, alpha, warmup, jitter
+        self._weights = torch.ones(self.n)
+        self._counts = torch.zeros(self.n, dtype=torch.long)
+
+    def warmed_up(self):
+        return bool((self._counts > self.warmup).all())
+
+    def weights(self):
+        if not self.warmed_up():
+            return torch.ones(self.n)
+        w = self._weights / self._weights.sum()
+        return (1 - self.uniform_p) * w + self.uniform_p / self.n
+
+    def sample(self, batch_size, generator=None):
+        w = torch.multinomial(self.weights(), batch_size, replacement=True, generator=generator).float()
+        if self.jitter:
+            return (w + torch.rand(w.shape, generator=generator)) / self.n
+        return w / (self.n - 1)
+
+    def update_with_losses(self, ts, losses):
+        ts, losses = ts.detach().view(-1).cpu(), losses.detach().view(-1).float().cpu()
+        idx = (ts * self.n).long().clamp(0, self.n - 1)
+        self._counts.scatter_add_(0, idx, torch.ones_like(idx))
+        for i, j in enumerate(idx.tolist()):
+            self._weights[j] = self._weights[j] * self.alpha + float(losses[i]) * (1 - self.alpha)
+
+
+def lr_at(step, base_lr, warmup, max_steps):
+    """Learning rate of optimizer step `step` (1-based) under GradualWarmupScheduler(multiplier 1, total_epoch=warmup)
+    handing over to CosineAnnealingLR(T_max=max_steps) (main.py:441-442)."""
+    e = step - 1
+    if e <= warmup:
+        return base_lr * (float(e) / warmup) if warmup > 0 else base_lr
+    return 0.5 * base_lr * (1 + math.cos(math.pi * max(e - warmup - 1, 0) / max_steps))
+
+
+class DenoiserTrainer:
+    """One object = model + flat arenas + AdamW state + (optional) data-parallel reducer."""
+
+    def __init__(self, model, num_embeddings, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, warmup=500,
+                 max_steps=200 * 1000, distributed=None, bucket_bytes=4 << 20):
+        self.model = model
+        self.C = num_embeddings
+        self.arena = FlatArena(model)
+        self.m = torch.zeros_like(self.arena.flat_param)
+        self.v = torch.zeros_like(self.arena.flat_param)
+        self.sq = torch.zeros(1, dtype=torch.float32, device=self.arena.flat_param.device)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.warmup, self.max_steps = warmup, max_steps
+        self.step_count = 0
+        if distributed is None:
+            distributed = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes) if distributed else None
+        if distributed:
+            broadcast_parameters(self.arena)
+        self.sampler = LossAwareSamplerEma(num_histogram_buckets=100, uniform_p=0.01, alpha=0.9, warmup=10)
+
+    def forward_backward(self, batch_z, target):
+        """Forward, per-sample CE over the last frame, backward.  Returns (per_sample_loss[B], mean loss) on device."""
+        y = self.model(batch_z)
+        loss = F.cross_entropy(y.reshape(-1, self.C), target.reshape(-1), reduction='none')
+        per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
+        mean = loss.mean()
+        mean.backward()
+        return per_sample.detach(), mean.detach()
+
+    def optimizer_step(self, lr=None):
+        """Finish the all-reduce, grad-norm (device scalar, no sync), AdamW.  Returns the squared grad-norm tensor."""
+        scale = self.reducer.finish() if self.reducer is not None else 1.0
+        self.step_count += 1
+        if lr is None:
+            lr = lr_at(self.step_count, self.lr, self.warmup, self.max_steps)
+        a = self.arena
+        st = L.stream()
+        self.sq.zero_()
+        L.call('wmz_grad_sqnorm', L.ptr(a.flat_grad), a.numel, float(scale), L.ptr(self.sq), st)
+        L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
+               float(lr), self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), st)
+        _cast.invalidate()            # the kernel rewrote the arena behind torch's version counters
+        return self.sq
+
+    def train_step(self, batch_z, r=None, generator=None):
+        """corrupt -> forward/backward (all-reduce overlapped) -> grad-norm -> AdamW; sampler update on the host."""
+        B = batch_z.shape[0]
+        if r is None:
+            r = self.sampler.sample(B)
+        self.arena.zero_grad()
+        zc, target = corrupt_last_frame(batch_z, r, self.C, generator)
+        per_sample, mean = self.forward_backward(zc, target)
+        sq = self.optimizer_step()
+        self.sampler.update_with_losses(r, per_sample)        # the step's one host sync (reference: ~50)
+        return float(mean), math.sqrt(float(sq))

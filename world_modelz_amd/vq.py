@@ -1,0 +1,98 @@
+"""MI355X drop-in for vq-video-diffusion/vq.py::VectorQuantizerEMA (:6-111).
+
+Same constructor, buffers (embedding / cluster_size persistent; latent_offsets / activation_count /
+accumulated_error non-persistent) and methods.  Nearest-neighbour search, row gather, EMA statistics and the EMA
+update are HIP kernels; the argmin reproduces the reference's fp32 summation order, so indices are bit-identical.
+`VectorQuantizerEMA1` of the reference is dead code (never instantiated) and is not provided.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import WmzError
+
+
+class VectorQuantizerEMA(nn.Module):
+    def __init__(self, embedding_dim, num_embeddings, num_latents=1, decay=0.99, eps=1e-5):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.num_embeddings = num_embeddings
+        self.num_latents = num_latents
+        self.decay = decay
+        self.eps = eps
+        self.register_buffer('embedding', torch.randn(num_latents, num_embeddings, embedding_dim))
+        self.register_buffer('cluster_size', torch.ones(num_latents, num_embeddings))
+        self.register_buffer('latent_offsets', torch.arange(num_latents).mul(num_embeddings).unsqueeze(0), persistent=False)
+        self.register_buffer('activation_count', torch.zeros(num_latents, num_embeddings), persistent=False)
+        self.register_buffer('accumulated_error', torch.zeros(num_latents, num_embeddings), persistent=False)
+        self.simple_update = False
+        self.laplace_smoothing = True
+        # data-parallel training: set to a process group (or True for the default group) to all-reduce the EMA
+        # statistics before the update, otherwise codebooks diverge across ranks (comm backend row)
+        self.sync_stats = None
+
+    # ---- helpers
+    def _flat(self, x):
+        if self.num_latents != 1:
+            raise WmzError('the HIP VectorQuantizerEMA is built for num_latents == 1 (every caller in scope, '
+                           'train_vqae.py:31)')
+        if not x.is_cuda:
+            raise WmzError('VectorQuantizerEMA runs on the GPU only (no CPU fallback)')
+        return x.reshape(-1, self.embedding_dim).float()
+
+    def codebook_distance(self, input, normalize=True):
+        """[N, 1, C] distances (reference :77-82).  Diagnostic API: materialises N*C floats, chunked over N."""
+        flat = self._flat(input)
+        cb = self.embedding[0]
+        outs = [(flat[i:i + 8192, None, :] - cb[None]).pow(2).sum(-1) for i in range(0, flat.shape[0], 8192)]
+        d = torch.cat(outs, 0).unsqueeze(1)
+        return d / self.embedding_dim if normalize else d
+
+    def encode(self, input):
+        """int64 [N, 1] nearest-code indices (reference :84-87)."""
+        return ops.vq_argmin(self._flat(input), self.embedding[0]).unsqueeze(1)
+
+    def decode(self, indices):
+        """codebook rows, [*indices.shape, E] (reference :89-94)."""
+        idx = indices.reshape(-1)
+        return ops.vq_gather(idx, self.embedding[0]).reshape(*indices.shape, self.embedding_dim)
+
+    def forward(self, input):
+        flat = self._flat(input)
+        N, C = flat.shape[0], self.num_embeddings
+        cb = self.embedding[0]
+        idx = ops.vq_argmin(flat.detach(), cb)
+        quantized = ops.vq_gather(idx, cb)                                    # before the EMA update, like :34
+        counts = torch.zeros(C, device=flat.device)
+        dw = torch.zeros(C, self.embedding_dim, device=flat.device) if self.training else None
+        ops.vq_ema_stats(flat.detach(), idx, cb, counts, dw, self.accumulated_error[0])   # :35-36 always, :43-46
+        encodings = torch.zeros(N, 1, C, device=flat.device).scatter_(-1, idx.view(N, 1, 1), 1.0)   # returned (:39)
+        if self.training:
+            if self.sync_stats is not None and torch.distributed.is_initialized():
+                group = None if self.sync_stats is True else self.sync_stats
+                torch.distributed.all_reduce(counts, group=group)
+                torch.distributed.all_reduce(dw, group=group)
+            ops.vq_ema_update(self.embedding, self.cluster_size, self.activation_count, counts, dw, self.decay, self.eps)
+        quantized = quantized.view_as(input).to(input.dtype)
+        commitment_loss = F.mse_loss(quantized.detach(), input)               # :67
+        quantized = input + (quantized - input).detach()                      # straight-through (:70)
+        avg_probs = counts / N if self.sync_stats is None else encodings.mean(dim=0)[0]
+        perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10) / self.num_latents))
+        return quantized, encodings, commitment_loss, perplexity
+
+    def reuse_inactive(self):
+        """Host-driven, rare (every 500 steps, train_vqae.py:160-164): kept in torch (reference :96-107)."""
+        total = 0
+        for i in range(self.num_latents):
+            dead = self.activation_count[i] == 0
+            nd = int(dead.count_nonzero().item())
+            if nd > 0:
+                _, j = self.activation_count[i].topk(nd)
+                self.embedding[i][dead] = self.embedding[i][dead] * 0.1 + self.embedding[i][j] * 0.9
+                total += nd
+        return total
+
+    def reset_stats(self):
+        self.activation_count.zero_()
+        self.accumulated_error.zero_()
