@@ -110,6 +110,28 @@ int wmz_vq_ema_stats(const float* x, long ldx, const int64_t* idx, const float* 
 int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_count, const float* counts,
                       const float* dw, int C, int E, double decay, double eps, void* stream);
 
+/* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
+ * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]
+ * (nn.Conv2d weight permuted (0,2,3,1)), Cin % 8 == 0 (zero-pad), act = LeakyReLU(slope) if leaky.  scale/shift carry a
+ * folded eval-mode BatchNorm (autoencoder.py:21-25).  stat_sum / stat_sq (optional, fp32 [Cout], accumulated) receive
+ * per-channel sum and sum of squares of the stored output: the batch statistics of a training-mode BatchNorm. */
+int wmz_conv2d_nhwc_fwd(const void* x, const void* w, void* out, const float* bias, const float* scale,
+                        const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int Hi, int Wi,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, int dtype,
+                        void* stream);
+/* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [C]). */
+int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream);
+/* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq, count), running stats updated with
+ * `momentum` and the unbiased variance; training == 0: running stats.  Emits scale = gamma*rstd, shift = beta - mean*scale. */
+int wmz_bn_finalize(const float* sum, const float* sq, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, double momentum, double eps, int training, float* scale,
+                    float* shift, int C, void* stream);
+/* y = act(a*sa + ta (+ b*sb + tb)) per channel on NHWC [M, C] (BatchNorm apply, skip add, LeakyReLU). */
+int wmz_affine_act_nhwc(const void* a, const float* sa, const float* ta, const void* b, const float* sb, const float* tb,
+                        void* y, long M, int C, int leaky, float slope, int dtype, void* stream);
+/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (autoencoder.py:138) on NHWC. */
+int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+
 /* ---- training-step tail over flat fp32 arenas (one launch each) ----
  * grad_norm (main.py:188-193): out[0] += scale^2 * sum g^2 (caller zeroes out[0]; no host sync). */
 int wmz_grad_sqnorm(const float* g, long n, float scale, float* out, void* stream);

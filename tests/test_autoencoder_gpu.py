@@ -1,0 +1,137 @@
+"""GPU parity of the conv encoder / decoder / VqAutoEncoder drop-ins against the reference captures
+(tests/golden/ae_roundtrip.npz, ae_cfg1_meta.npz) and the oracle."""
+import pytest
+import torch
+
+from conftest import load_golden, sub
+
+pytestmark = pytest.mark.gpu
+
+from oracle import autoencoder as oae        # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def wmz():
+    assert torch.cuda.is_available()
+    from world_modelz_amd import config, ops, train_vqae
+    return dict(config=config, ops=ops, tv=train_vqae)
+
+
+def _model(wmz, sd):
+    m = wmz['tv'].VqAutoEncoder(embedding_dim=16, num_embeddings=32, downscale_steps=2, hidden_planes=24, in_channels=3)
+    m.load_state_dict(sd, strict=True)                        # reference state_dict loads key-for-key
+    return m.cuda()
+
+
+def test_conv_kernel_vs_torch(wmz):
+    ops = wmz['ops']
+    torch.manual_seed(0)
+    for (B, H, W, Ci, Co, k, s, p) in [(2, 9, 11, 8, 40, 3, 1, 1), (1, 16, 16, 24, 16, 3, 2, 1), (3, 8, 8, 16, 130, 1, 1, 0),
+                                       (2, 10, 6, 8, 8, 2, 2, 0)]:
+        x = torch.randn(B, Ci, H, W)
+        w = torch.randn(Co, Ci, k, k) / (Ci * k * k) ** 0.5
+        b = torch.randn(Co)
+        ref = torch.nn.functional.conv2d(x, w, b, stride=s, padding=p)
+        xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+        wop = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().cuda()
+        out, s1, s2 = ops.conv2d_nhwc(xn, wop, k, k, s, p, bias=b.cuda(), stats=True)
+        assert rel(out.permute(0, 3, 1, 2), ref) < 2e-6
+        assert torch.allclose(s1.cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(s2.cpu(), (ref ** 2).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4)
+        outb = ops.conv2d_nhwc(xn.bfloat16(), wop.bfloat16(), k, k, s, p, bias=b.cuda(), leaky=True)
+        refb = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.bfloat16().float(), w.bfloat16().float(), b,
+                                                                         stride=s, padding=p), 0.01)
+        assert rel(outb.permute(0, 3, 1, 2), refb) < 6e-3
+
+
+def test_bilinear_and_affine(wmz):
+    ops = wmz['ops']
+    torch.manual_seed(1)
+    x = torch.randn(2, 8, 5, 7)
+    ref = torch.nn.functional.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    y = ops.bilinear2x_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda())
+    assert rel(y.permute(0, 3, 1, 2), ref) < 1e-6
+    a, b = torch.randn(3, 4, 4, 8), torch.randn(3, 4, 4, 8)
+    sa, ta, sb, tb = (torch.randn(8) for _ in range(4))
+    ref = torch.nn.functional.leaky_relu(a * sa + ta + b * sb + tb, 0.01)
+    y = ops.affine_act_nhwc(a.cuda(), sa.cuda(), ta.cuda(), b.cuda(), sb.cuda(), tb.cuda(), leaky=True)
+    assert rel(y, ref) < 1e-6
+
+
+def test_autoencoder_eval_vs_golden(wmz):
+    g = load_golden('ae_roundtrip')
+    m = _model(wmz, sub(g, 'sd0/'))
+    m.eval()
+    x = g['x'].cuda()
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        h = m.encoder(x)
+        idx = m.encode(x)
+        rec = m.decode(g['eval/idx'].cuda())
+        out, ll, ppl = m(x)
+    assert h.shape == g['eval/enc_out'].shape and rel(h, g['eval/enc_out']) < 1e-5
+    assert idx.dtype == torch.int64 and idx.shape == g['eval/idx'].shape
+    assert (idx.cpu() == g['eval/idx']).float().mean() >= 0.98      # argmin on fp32 latents that differ in the last bits
+    assert rel(rec, g['eval/decoded']) < 1e-5
+    if torch.equal(idx.cpu(), g['eval/idx']):
+        assert rel(out, g['eval/recon']) < 1e-5
+        assert torch.allclose(ll.cpu(), g['eval/latent_loss'], rtol=1e-4)
+        assert torch.allclose(ppl.cpu(), g['eval/perplexity'], rtol=1e-4)
+
+
+def test_autoencoder_train_mode_bn_vs_golden(wmz):
+    """Quirk Q3: the frozen AE is never .eval()-ed in main.py, so BatchNorm uses batch statistics and updates its
+    running statistics even under no_grad.  Indices and the mutated state_dict against the reference capture."""
+    g = load_golden('ae_roundtrip')
+    m = _model(wmz, sub(g, 'sd0/'))
+    m.train()
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        idx = m.encode(g['x'].cuda())
+    assert (idx.cpu() == g['train/idx']).float().mean() >= 0.98
+    assert not torch.equal(idx.cpu(), g['eval/idx'])
+    sd1 = sub(g, 'sd1/')
+    for k, v in m.state_dict().items():
+        if k.startswith('encoder.') and v.dtype.is_floating_point:
+            assert torch.allclose(v.cpu(), sd1[k], rtol=1e-4, atol=1e-5), k
+        elif k.startswith('encoder.'):
+            assert torch.equal(v.cpu(), sd1[k]), k
+    # full forward in train mode: recon against the oracle fed with the SAME state (decoder BN batch statistics)
+    m2 = _model(wmz, sub(g, 'sd1/'))
+    m2.train()
+    p = oae.with_vq_stats({k: v.clone() for k, v in sub(g, 'sd1/').items()})
+    rec_ref, ll_ref, _ = oae.vqae_forward(p, g['x'], training=True)
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        rec, ll, _ = m2(g['x'].cuda())
+    assert rel(rec, rec_ref) < 2e-3          # a flipped index moves one 4x4 patch; most runs are ~1e-6
+    assert abs(float(ll) - float(ll_ref)) < 1e-3
+
+
+def test_config1_frame_roundtrip(wmz):
+    """BASELINE.json configs[0]: encode -> quantize -> decode one 64x64 RGB frame, codebook 512, default sizes.
+    The model is re-created from the reference's seed: same construction order => same initial weights."""
+    g = load_golden('ae_cfg1_meta')
+    torch.manual_seed(int(g['seed']))
+    m = wmz['tv'].VqAutoEncoder(embedding_dim=64, num_embeddings=512, downscale_steps=3, hidden_planes=128, in_channels=3)
+    m = m.cuda().eval()
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        idx = m.encode(g['x'].cuda())
+        rec = m.decode(g['idx'].cuda())
+    assert idx.shape == (1, 8, 8)
+    assert (idx.cpu() == g['idx']).float().mean() >= 0.95
+    assert rec.shape == (1, 3, 64, 64)
+    assert torch.allclose(rec[0, :, :4, :4].cpu(), g['recon_corner'], rtol=1e-4, atol=1e-5)
+    assert abs(float(rec.mean()) - float(g['recon_mean'])) < 1e-5
+    with wmz['config'].compute_dtype(torch.bfloat16), torch.no_grad():
+        rec16 = m.decode(g['idx'].cuda())
+    assert rel(rec16, rec) < 3e-2
+
+
+def test_backward_not_silently_wrong(wmz):
+    g = load_golden('ae_roundtrip')
+    m = _model(wmz, sub(g, 'sd0/'))
+    with pytest.raises(NotImplementedError):
+        m(g['x'].cuda())

@@ -1,0 +1,340 @@
+// Conv encoder / decoder tiles of the VQ auto-encoder (vq-video-diffusion/autoencoder.py): NHWC implicit-GEMM
+// convolution on MFMA plus the BatchNorm / LeakyReLU / bilinear pieces around it.
+//
+//   conv:  out[b,ho,wo,co] = sum_{kh,kw,ci} x[b, ho*s+kh-p, wo*s+kw-p, ci] * w[co,kh,kw,ci]   (+bias)
+//          as C[M = B*Ho*Wo, N = Cout] = A_im2col[M, K = kh*kw*Cin] . Wt[N, K]^T; the im2col row is never built:
+//          the A-slab fetch computes the source address per 16-byte chunk (Cin % 8 == 0 keeps a chunk in one tap).
+//          Epilogue: bias, per-channel affine (folded eval-mode BatchNorm), residual add, LeakyReLU, and optionally
+//          per-channel sum / sum-of-squares of the stored output (training-mode BatchNorm statistics).
+//   channel_stats / bn_finalize / affine_act / bilinear2x: the memory-bound companions.
+#include "wmz_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128, CPR = 8, NT = 256;
+
+struct ConvParams {
+  const void* x; const void* w; void* out;
+  const float* bias; const float* scale; const float* shift;
+  const void* res;
+  float* stat_sum; float* stat_sq;
+  int B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+  int M, K, nbn;
+  float slope; int leaky;
+};
+
+__device__ __forceinline__ int swz128(int r) { return ((r >> 1) << 4) & 112; }
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = CPR * EPC;
+  constexpr int KSTEPS = BK / 16;
+  __shared__ __attribute__((aligned(16))) char As[BM * ROWB];
+  __shared__ __attribute__((aligned(16))) char Bs[BN * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bm = lid / P.nbn, bn = lid - bm * P.nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const T* X = reinterpret_cast<const T*>(P.x);
+  const T* Wt = reinterpret_cast<const T*>(P.w);
+  const int K = P.K;
+
+  // the 4 output pixels this thread stages (rows rr + 32 i): decompose once
+  const int cc = tid & 7, rr = tid >> 3;
+  int pb[4], ph[4], pw[4];
+  bool pok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + rr + 32 * i;
+    pok[i] = m < P.M;
+    const int mm = pok[i] ? m : 0;
+    const int wo = mm % P.Wo, t = mm / P.Wo;
+    pw[i] = wo * P.stride - P.pad;
+    ph[i] = (t % P.Ho) * P.stride - P.pad;
+    pb[i] = t / P.Ho;
+  }
+
+  i32x4 ra[4], rb[4];
+  auto fetch = [&](int k0) {
+    const int k = k0 + cc * EPC;
+    const int tap = k / P.Cin, ci = k - tap * P.Cin;
+    const int kh = tap / P.KW, kw = tap - kh * P.KW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = (i32x4)(0);
+      rb[i] = (i32x4)(0);
+      if (k < K) {
+        const int hi = ph[i] + kh, wi = pw[i] + kw;
+        if (pok[i] && hi >= 0 && hi < P.Hi && wi >= 0 && wi < P.Wi)
+          ra[i] = *reinterpret_cast<const i32x4*>(X + (((long)pb[i] * P.Hi + hi) * P.Wi + wi) * P.Cin + ci);
+        const int r = rr + 32 * i;
+        if (n0 + r < P.Cout) rb[i] = *reinterpret_cast<const i32x4*>(Wt + (long)(n0 + r) * K + k);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 32 * i;
+      const int off = r * ROWB + ((cc << 4) ^ swz128(r));
+      *reinterpret_cast<i32x4*>(As + off) = ra[i];
+      *reinterpret_cast<i32x4*>(Bs + off) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      Frag8<T> af[2], bf[2];
+      const int b0 = (kk * 16 + hh * 8) * (int)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wr + 32 * i + l31, rn = wc + 32 * i + l31;
+        const char* rowa = As + r * ROWB;
+        const char* rowb = Bs + rn * ROWB;
+        const int sa = swz128(r), sb = swz128(rn);
+        if constexpr (sizeof(T) == 2) {
+          af[i].v = *reinterpret_cast<const s16x8*>(rowa + (b0 ^ sa));
+          bf[i].v = *reinterpret_cast<const s16x8*>(rowb + (b0 ^ sb));
+        } else {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(rowa + (b0 ^ sa));
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(rowa + ((b0 + 16) ^ sa));
+          const f32x4 y0 = *reinterpret_cast<const f32x4*>(rowb + (b0 ^ sb));
+          const f32x4 y1 = *reinterpret_cast<const f32x4*>(rowb + ((b0 + 16) ^ sb));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { af[i].v[e] = x0[e]; af[i].v[4 + e] = x1[e]; bf[i].v[e] = y0[e]; bf[i].v[4 + e] = y1[e]; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32(acc[i][j], af[i], bf[j]);
+    }
+  }
+
+  const T* R = reinterpret_cast<const T*>(P.res);
+  T* O = reinterpret_cast<T*>(P.out);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc + 32 * j + l31;
+    const bool cok = col < P.Cout;
+    const float bv = (cok && P.bias) ? P.bias[col] : 0.f;
+    const float sc = (cok && P.scale) ? P.scale[col] : 1.f;
+    const float sh = (cok && P.shift) ? P.shift[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + wr + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (!cok || row >= P.M) continue;
+        float v = (acc[i][j][reg] + bv) * sc + sh;
+        if (R) v += Elem<T>::to_f32(R[(long)row * P.Cout + col]);
+        if (P.leaky) v = v > 0.f ? v : v * P.slope;
+        const T tv = Elem<T>::from_f32(v);
+        O[(long)row * P.Cout + col] = tv;
+        const float q = Elem<T>::to_f32(tv);       // statistics of what the next stage will read
+        s1 += q;
+        s2 += q * q;
+      }
+    if (P.stat_sum != nullptr) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (hh == 0 && cok) { atomicAdd(P.stat_sum + col, s1); atomicAdd(P.stat_sq + col, s2); }
+    }
+  }
+}
+
+// per-channel sum / sumsq of an NHWC tensor [M, C]: a wave sweeps 64 channels x a slice of rows
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ sum,
+                                                            float* __restrict__ sq) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (long m = (long)blockIdx.x * 4 + sub; m < M; m += (long)gridDim.x * 4) {
+      const float v = Elem<T>::to_f32(x[m * C + c]);
+      s1 += v;
+      s2 += v * v;
+    }
+  __shared__ float r1[4][64], r2[4][64];
+  r1[sub][threadIdx.x & 63] = s1;
+  r2[sub][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (sub == 0 && c < C) {
+    const int l = threadIdx.x;
+    atomicAdd(sum + c, r1[0][l] + r1[1][l] + r1[2][l] + r1[3][l]);
+    atomicAdd(sq + c, r2[0][l] + r2[1][l] + r2[2][l] + r2[3][l]);
+  }
+}
+
+// nn.BatchNorm2d bookkeeping for one layer: batch mean / biased var -> (scale, shift); running stats with momentum and
+// the unbiased variance; training==0 folds the running statistics instead.
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, int training, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    mean = sum[c] / count;
+    var = fmaxf(sq[c] / count - mean * mean, 0.f);
+    const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float rs = rsqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * rs;
+  shift[c] = b - mean * g * rs;
+}
+
+// y = act( a*sa[c] + ta[c]  (+ b*sb[c] + tb[c]) ),  act = LeakyReLU(slope) or identity; NHWC [M, C], C % 4 == 0
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ a, const float* __restrict__ sa,
+                                                         const float* __restrict__ ta, const T* __restrict__ b,
+                                                         const float* __restrict__ sb, const float* __restrict__ tb,
+                                                         T* __restrict__ y, long total, int C, int leaky, float slope) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (long)gridDim.x * blockDim.x * 4) {
+    const int c = (int)(i % C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = Elem<T>::to_f32(a[i + e]);
+      if (sa) v = v * sa[c + e] + ta[c + e];
+      if (b) {
+        float u = Elem<T>::to_f32(b[i + e]);
+        if (sb) u = u * sb[c + e] + tb[c + e];
+        v += u;
+      }
+      if (leaky) v = v > 0.f ? v : v * slope;
+      y[i + e] = Elem<T>::from_f32(v);
+    }
+  }
+}
+
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on NHWC
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float sh = fmaxf((ho + 0.5f) * 0.5f - 0.5f, 0.f), sw = fmaxf((wo + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int h0 = (int)sh, w0 = (int)sw;
+    const int h1 = min(h0 + 1, H - 1), w1 = min(w0 + 1, W - 1);
+    const float lh = sh - h0, lw = sw - w0;
+    const T* p = x + (long)b * H * W * C + c;
+    const float v00 = Elem<T>::to_f32(p[((long)h0 * W + w0) * C]), v01 = Elem<T>::to_f32(p[((long)h0 * W + w1) * C]);
+    const float v10 = Elem<T>::to_f32(p[((long)h1 * W + w0) * C]), v11 = Elem<T>::to_f32(p[((long)h1 * W + w1) * C]);
+    // ATen's upsample_bilinear2d order: interpolate along w inside each row, then along h
+    const float top = (1.f - lw) * v00 + lw * v01, bot = (1.f - lw) * v10 + lw * v11;
+    y[i] = Elem<T>::from_f32((1.f - lh) * top + lh * bot);
+  }
+}
+
+int grid_for(long total, int per_block, int cap) {
+  long b = (total + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int wmz_conv2d_nhwc_fwd(const void* x, const void* w, void* out, const float* bias, const float* scale,
+                                   const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B,
+                                   int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky,
+                                   float slope, int dtype, void* stream) {
+  WMZ_REQUIRE(x && w && out, "wmz_conv2d_nhwc_fwd: null tensor");
+  WMZ_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+              "wmz_conv2d_nhwc_fwd: bad shape");
+  WMZ_REQUIRE(Cin % 8 == 0, "wmz_conv2d_nhwc_fwd: Cin must be a multiple of 8 (zero-pad the input channels), got %d", Cin);
+  WMZ_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "wmz_conv2d_nhwc_fwd: stat_sum and stat_sq go together");
+  WMZ_REQUIRE((scale == nullptr) == (shift == nullptr), "wmz_conv2d_nhwc_fwd: scale and shift go together");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_conv2d_nhwc_fwd: bad dtype %d", dtype);
+  ConvParams P;
+  P.x = x; P.w = w; P.out = out; P.bias = bias; P.scale = scale; P.shift = shift; P.res = residual;
+  P.stat_sum = stat_sum; P.stat_sq = stat_sq;
+  P.B = B; P.Hi = Hi; P.Wi = Wi; P.Cin = Cin; P.Cout = Cout; P.KH = KH; P.KW = KW; P.stride = stride; P.pad = pad;
+  P.Ho = (Hi + 2 * pad - KH) / stride + 1;
+  P.Wo = (Wi + 2 * pad - KW) / stride + 1;
+  WMZ_REQUIRE(P.Ho > 0 && P.Wo > 0, "wmz_conv2d_nhwc_fwd: empty output");
+  P.M = B * P.Ho * P.Wo; P.K = KH * KW * Cin; P.nbn = wmz_cdiv(Cout, BN);
+  P.leaky = leaky; P.slope = slope;
+  dim3 grid((unsigned)(wmz_cdiv(P.M, BM) * P.nbn)), block(NT);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16) hipLaunchKernelGGL(conv2d_kernel<bf16_t>, grid, block, 0, st, P);
+  else hipLaunchKernelGGL(conv2d_kernel<float>, grid, block, 0, st, P);
+  WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_fwd");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream) {
+  WMZ_REQUIRE(x && sum && sq && M > 0 && C > 0, "wmz_channel_stats_nhwc: bad arguments");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_channel_stats_nhwc: bad dtype %d", dtype);
+  dim3 grid((unsigned)grid_for(M, 64, 512), (unsigned)wmz_cdiv(C, 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16) hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, C, sum, sq);
+  else hipLaunchKernelGGL(channel_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, M, C, sum, sq);
+  WMZ_LAUNCH_CHECK("wmz_channel_stats_nhwc");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_bn_finalize(const float* sum, const float* sq, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, double momentum, double eps, int training,
+                               float* scale, float* shift, int C, void* stream) {
+  WMZ_REQUIRE(running_mean && running_var && scale && shift && C > 0, "wmz_bn_finalize: bad arguments");
+  WMZ_REQUIRE(!training || (sum && sq && count > 0), "wmz_bn_finalize: training mode needs the batch statistics");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(wmz_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sum, sq, (float)count,
+                     gamma, beta, running_mean, running_var, (float)momentum, (float)eps, training, scale, shift, C);
+  WMZ_LAUNCH_CHECK("wmz_bn_finalize");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* ta, const void* b, const float* sb,
+                                   const float* tb, void* y, long M, int C, int leaky, float slope, int dtype,
+                                   void* stream) {
+  WMZ_REQUIRE(a && y && M > 0 && C > 0 && C % 4 == 0, "wmz_affine_act_nhwc: bad arguments (C %% 4 == 0 required)");
+  WMZ_REQUIRE((sa == nullptr) == (ta == nullptr) && (sb == nullptr) == (tb == nullptr), "wmz_affine_act_nhwc: scale/shift pairs");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_affine_act_nhwc: bad dtype %d", dtype);
+  const long total = M * C;
+  const int grid = grid_for(total, 1024, 4096);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16)
+    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)a, sa, ta, (const bf16_t*)b, sb, tb, (bf16_t*)y, total, C, leaky, slope);
+  else
+    hipLaunchKernelGGL(affine_act_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a, sa, ta, (const float*)b, sb, tb, (float*)y, total, C, leaky, slope);
+  WMZ_LAUNCH_CHECK("wmz_affine_act_nhwc");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+  WMZ_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "wmz_bilinear2x_nhwc: bad arguments");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bilinear2x_nhwc: bad dtype %d", dtype);
+  const long total = (long)B * 4 * H * W * C;
+  const int grid = grid_for(total, 256, 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16) hipLaunchKernelGGL(bilinear2x_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+  else hipLaunchKernelGGL(bilinear2x_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
+  WMZ_LAUNCH_CHECK("wmz_bilinear2x_nhwc");
+  return WMZ_OK;
+}

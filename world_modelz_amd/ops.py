@@ -210,3 +210,67 @@ def embed_pos3d_bwd(z, dx, shapes):
     L.call('wmz_embed_pos3d_bwd', L.ptr(z.contiguous()), L.ptr(dx), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]),
            L.ptr(tabs[3]), B, S, H, W, D, shapes[0][0], L.dtype_code(dx.dtype), L.stream())
     return tabs
+
+
+# ------------------------------------------------------------------------------------------------ conv AE (NHWC)
+
+def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None, residual=None, leaky=False,
+                slope=0.01, stats=False):
+    """x: [B,H,W,Cin] contiguous (Cin % 8 == 0), w_op: [Cout, KH*KW*Cin] in x's dtype -> [B,Ho,Wo,Cout] (+ sum, sq)."""
+    B, Hi, Wi, Cin = x.shape
+    Cout = w_op.shape[0]
+    assert x.is_contiguous() and w_op.is_contiguous() and w_op.shape[1] == KH * KW * Cin and w_op.dtype == x.dtype
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    s = q = None
+    if stats:
+        s = torch.zeros(Cout, dtype=torch.float32, device=x.device)
+        q = torch.zeros(Cout, dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
+    L.call('wmz_conv2d_nhwc_fwd', L.ptr(x), L.ptr(w_op), L.ptr(out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+           L.ptr(residual), L.ptr(s), L.ptr(q), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 1 if leaky else 0,
+           float(slope), L.dtype_code(x.dtype), L.stream())
+    return (out, s, q) if stats else out
+
+
+def channel_stats_nhwc(x):
+    C = x.shape[-1]
+    M = x.numel() // C
+    s = torch.zeros(C, dtype=torch.float32, device=x.device)
+    q = torch.zeros(C, dtype=torch.float32, device=x.device)
+    L.call('wmz_channel_stats_nhwc', L.ptr(x), M, C, L.ptr(s), L.ptr(q), L.dtype_code(x.dtype), L.stream())
+    return s, q
+
+
+def bn_finalize(bn, s, q, count):
+    """(scale, shift) of an nn.BatchNorm2d; in training mode also updates its running statistics."""
+    C = bn.num_features
+    dev = bn.running_mean.device
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    shift = torch.empty(C, dtype=torch.float32, device=dev)
+    training = bn.training or bn.running_mean is None
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    L.call('wmz_bn_finalize', L.ptr(s), L.ptr(q), float(count), L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()),
+           L.ptr(bn.running_mean), L.ptr(bn.running_var), float(mom), float(bn.eps), 1 if training else 0,
+           L.ptr(scale), L.ptr(shift), C, L.stream())
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return scale, shift
+
+
+def affine_act_nhwc(a, sa=None, ta=None, b=None, sb=None, tb=None, leaky=False, slope=0.01):
+    C = a.shape[-1]
+    M = a.numel() // C
+    y = torch.empty_like(a)
+    L.call('wmz_affine_act_nhwc', L.ptr(a), L.ptr(sa), L.ptr(ta), L.ptr(b), L.ptr(sb), L.ptr(tb), L.ptr(y), M, C,
+           1 if leaky else 0, float(slope), L.dtype_code(a.dtype), L.stream())
+    return y
+
+
+def bilinear2x_nhwc(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+    L.call('wmz_bilinear2x_nhwc', L.ptr(x), L.ptr(y), B, H, W, C, L.dtype_code(x.dtype), L.stream())
+    return y
