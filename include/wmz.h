@@ -110,6 +110,20 @@ int wmz_vq_ema_stats(const float* x, long ldx, const int64_t* idx, const float* 
 int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_count, const float* counts,
                       const float* dw, int C, int E, double decay, double eps, void* stream);
 
+/* ---- everything per-token of a transformer layer boundary in ONE launch (bf16 speed path):
+ * head (has_head): x1 = o Wout^T + bout + x ; x_out = W2 GELU(W1 LN2(x1) + b1) + b2 + x1
+ *                  (to_out + residual, PreNorm(FeedForward) + residual: local_3d_attention.py:50-53, :20-31, :160-161)
+ * tail (has_tail): q = Wq' x_out ; k|v = Wkv' LN1'(x_out) + bkv'   (the NEXT layer's to_q / to_k / to_v, :46-48, :106-108;
+ *                  without a head the tail reads x directly: the first layer after the embedding)
+ * o [ntok, I], x / x_out [ntok, D], q [ntok, I], kv [ntok, 2I], all bf16 contiguous.  wpack: the stage weights as bf16,
+ * pre-packed in consumption order (Wout, W1 rows 0..127, W1 rows 128..255, W2, Wq', Wk', Wv'; each as [K/16][N][16] with the two 8-element halves of row n
+ * swapped when (n>>3)&1) followed by 32 KB of padding; vec: fp32 bout[D] g2[D] be2[D] b1[M] b2[D] g1'[D] be1'[D] bkv'[2I]
+ * (world_modelz_amd/fused.py builds both).  Built for D = 256, I = 128, M = 256; other widths return
+ * WMZ_ERR_UNSUPPORTED and callers use the per-op entry points above. */
+int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                        const float* vec, int ntok, int D, int I, int M, int has_head, int has_tail, float eps,
+                        void* stream);
+
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]
  * (nn.Conv2d weight permuted (0,2,3,1)), Cin % 8 == 0 (zero-pad), act = LeakyReLU(slope) if leaky.  scale/shift carry a

@@ -145,3 +145,31 @@ def test_vq_module_encode_decode_vs_golden():
     assert torch.equal(m.decode(idx).cpu(), g['decoded'])
     d = m.codebook_distance(g['x'].cuda()[:8], normalize=False)
     assert torch.allclose(d[:, 0].cpu(), g['dist_rows'], rtol=1e-5)
+
+
+def test_fused_layer_path_matches_unfused_and_oracle(wmz):
+    """Inference in bf16 with the default widths takes the fused per-token kernel (wmz_layer_fused_fwd): compare with
+    the per-op path (grad-enabled forward uses it) and with the fp32 oracle."""
+    from world_modelz_amd import fused
+    torch.manual_seed(5)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(5, 16, 16), dim=256, num_classes=300, extents=(3, 3, 3), depth=3,
+                                          dim_head=128, mlp_dim=256, heads=1)
+    # non-trivial LayerNorm affine and biases so every packed vector matters
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'norm' in n or n.endswith('bias'):
+                p.add_(0.3 * torch.randn_like(p))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    z = torch.randint(0, 301, (3, 5, 16, 16))          # 3840 tokens: a ragged last 128-token workgroup
+    ref = oden.transformer_forward(sd, z, (3, 3, 3), 1)
+    m = m.cuda()
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        assert fused.supported(m.transformer, torch.bfloat16)
+        with torch.no_grad():
+            x_fused = m.transformer(z.cuda())
+        x_unfused = m.transformer(z.cuda())              # grad mode on -> per-op path
+    e_f, e_u = rel(x_fused, ref), rel(x_unfused, ref)
+    print(f'fused vs oracle {e_f:.3e}, per-op vs oracle {e_u:.3e}, fused vs per-op {rel(x_fused, x_unfused):.3e}')
+    assert e_f < 2e-2 and e_u < 2e-2
+    assert rel(x_fused, x_unfused) < 1.5e-2
+    assert e_f < 1.5 * e_u + 1e-3                        # keeping the residual stream in fp32 registers must not hurt

@@ -1,0 +1,97 @@
+"""Host side of wmz_layer_fused_fwd: weight / vector packing (cached per parameter version) and the fused
+inference forward of Local3dAttentionTransformer (bf16, default widths)."""
+import torch
+
+from . import _cast, ops
+from . import _lib as L
+
+D_, I_, M_ = 256, 128, 256
+_PAD = 2 * 16384
+
+
+def _pack_w(w):
+    """[N, K] -> [K/16][N][2 halves][8], halves of row n swapped when (n>>3)&1 (LDS bank-conflict swizzle)."""
+    N, K = w.shape
+    v = w.reshape(N, K // 16, 2, 8)
+    odd = ((torch.arange(N, device=w.device) >> 3) & 1).bool()
+    v = torch.where(odd[:, None, None, None], v.flip(2), v)
+    return v.permute(1, 0, 2, 3).reshape(-1)
+
+
+def supported(transformer, x_dtype):
+    if x_dtype != torch.bfloat16 or len(transformer.layers) == 0:
+        return False
+    for attn, ff in transformer.layers:
+        a, f = attn.fn, ff.fn
+        if isinstance(a.to_out, torch.nn.Identity) or a.dropout > 0 or f.dropout > 0:
+            return False
+        if a.to_q.weight.shape != (I_, D_) or f.net[0].weight.shape != (M_, D_):
+            return False
+    return True
+
+
+def _layer_pack(head, tail):
+    """head / tail: (attn PreNorm, ff PreNorm) of the layer whose to_out+FF run, and of the layer whose q|k|v run."""
+    params, parts = [], []
+    if head is not None:
+        attn, ff = head
+        params += [attn.fn.to_out[0].weight, ff.fn.net[0].weight, ff.fn.net[3].weight]
+    if tail is not None:
+        attn_n = tail[0]
+        params += [attn_n.fn.to_q.weight, attn_n.fn.to_k.weight, attn_n.fn.to_v.weight]
+
+    def build_w(*ws):
+        ws = [w.detach().to(torch.bfloat16) for w in ws]
+        out, i = [], 0
+        if head is not None:
+            out += [_pack_w(ws[0]), _pack_w(ws[1][:M_ // 2]), _pack_w(ws[1][M_ // 2:]), _pack_w(ws[2])]
+            i = 3
+        if tail is not None:
+            out += [_pack_w(ws[i]), _pack_w(ws[i + 1]), _pack_w(ws[i + 2])]
+        out.append(torch.zeros(_PAD // 2, dtype=torch.bfloat16, device=ws[0].device))
+        return torch.cat(out)
+    wpack = _cast.operand(tuple(params), torch.bfloat16, 'fusedw', build_w)
+
+    vparams = []
+    if head is not None:
+        attn, ff = head
+        vparams += [attn.fn.to_out[0].bias, ff.norm.weight, ff.norm.bias, ff.fn.net[0].bias, ff.fn.net[3].bias]
+    if tail is not None:
+        attn_n = tail[0]
+        vparams += [attn_n.norm.weight, attn_n.norm.bias, attn_n.fn.to_v.bias]
+
+    def build_v(*vs):
+        dev = vs[0].device
+        z = lambda n: torch.zeros(n, device=dev)  # noqa: E731
+        vs = [v.detach().float() for v in vs]
+        if head is not None:
+            hv, rest = vs[:5], vs[5:]
+        else:
+            hv, rest = [z(D_), z(D_), z(D_), z(M_), z(D_)], vs
+        tv = [rest[0], rest[1], torch.cat([z(I_), rest[2]])] if tail is not None else [z(D_), z(D_), z(2 * I_)]
+        return torch.cat(hv + tv)
+    vec = _cast.operand(tuple(vparams), torch.float32, 'fusedv', build_v)
+    return wpack, vec
+
+
+def layer_fused(o, x, head, tail, eps=1e-5):
+    """Returns (x_out | None, q | None, kv | None)."""
+    ntok = x.numel() // D_
+    wpack, vec = _layer_pack(head, tail)
+    lead = x.shape[:-1]
+    xo = torch.empty_like(x) if head is not None else None
+    q = torch.empty(lead + (I_,), dtype=x.dtype, device=x.device) if tail is not None else None
+    kv = torch.empty(lead + (2 * I_,), dtype=x.dtype, device=x.device) if tail is not None else None
+    L.call('wmz_layer_fused_fwd', L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), ntok,
+           D_, I_, M_, 1 if head is not None else 0, 1 if tail is not None else 0, float(eps), L.stream())
+    return xo, q, kv
+
+
+def transformer_forward(tr, x):
+    """depth x [attention, feed-forward] on the fused kernels: per layer ONE attention launch + ONE per-token launch."""
+    layers = list(tr.layers)
+    _, q, kv = layer_fused(None, x, None, layers[0])
+    for l, (attn, ff) in enumerate(layers):
+        o, _, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads)
+        x, q, kv = layer_fused(o, x, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None)
+    return x
