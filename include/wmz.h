@@ -116,8 +116,9 @@ int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_c
  * tail (has_tail): q = Wq' x_out ; k|v = Wkv' LN1'(x_out) + bkv'   (the NEXT layer's to_q / to_k / to_v, :46-48, :106-108;
  *                  without a head the tail reads x directly: the first layer after the embedding)
  * o [ntok, I], x / x_out [ntok, D], q [ntok, I], kv [ntok, 2I], all bf16 contiguous.  wpack: the stage weights as bf16,
- * pre-packed in consumption order (Wout, W1 rows 0..127, W1 rows 128..255, W2, Wq', Wk', Wv'; each as [K/16][N][16] with the two 8-element halves of row n
- * swapped when (n>>3)&1) followed by 32 KB of padding; vec: fp32 bout[D] g2[D] be2[D] b1[M] b2[D] g1'[D] be1'[D] bkv'[2I]
+ * pre-packed in consumption order (Wout, then for c = 0..3: W1 rows 64c..64c+63, W2 columns 64c..64c+63, then Wq', Wk', Wv';
+ * each as [K/32][N][32] with the four 8-element chunks of row n
+ * XOR-permuted by (-(n>>2))&3) followed by 64 KB of padding; vec: fp32 bout[D] g2[D] be2[D] b1[M] b2[D] g1'[D] be1'[D] bkv'[2I]
  * (world_modelz_amd/fused.py builds both).  Built for D = 256, I = 128, M = 256; other widths return
  * WMZ_ERR_UNSUPPORTED and callers use the per-op entry points above. */
 int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,

@@ -1,0 +1,23 @@
+"""Micro-driver for profiling single kernels under rocprofv3 (not part of the product)."""
+import sys
+import torch
+sys.path.insert(0, '.')
+from world_modelz_amd import config, fused, ops
+from world_modelz_amd.main import VqVideoDiffusionModel
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'fused'
+torch.manual_seed(0)
+m = VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=256, num_classes=1024, extents=(3, 3, 3), depth=4, dim_head=128,
+                          mlp_dim=256, heads=1).cuda()
+config.set_compute_dtype(torch.bfloat16)
+N = 65536
+x = torch.randn(8, 32, 16, 16, 256, device='cuda').bfloat16()
+o = torch.randn(8, 32, 16, 16, 128, device='cuda').bfloat16()
+layers = list(m.transformer.layers)
+qkv = torch.randn(8, 32, 16, 16, 384, device='cuda').bfloat16()
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):
+    if which == 'fused':
+        fused.layer_fused(o, x, layers[0], layers[1])
+    elif which == 'attn':
+        ops.local3d_attention_fwd(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], (3, 3, 3), 1)
+torch.cuda.synchronize()

@@ -5,25 +5,31 @@
 //   TAIL:  q' = Wq' x2 ,  k'|v' = Wkv' LN1'(x2) + bkv'    (NEXT layer's to_q on the raw stream and to_k|to_v on
 //                                                          LayerNorm(x): quirk Q1, :16-17, :46-48, :106-108)
 //
-// Design (MI355X): a workgroup = 4 waves = 128 tokens; each wave owns 32 tokens end to end, so the only thing the waves
-// share is the weight stream.  Every GEMM is computed TRANSPOSED, D^T[features x 32 tokens] = W[features x K] . act^T, with
-// MFMA 32x32x16 bf16: A = weight rows, B = the wave's activation rows -- both K-contiguous row fragments, no transposes --
+// Design (MI355X): a workgroup = 8 waves = 128 tokens; each wave owns 16 tokens end to end, so the only thing the waves
+// share is the weight stream.  Every GEMM is computed TRANSPOSED, D^T[features x 16 tokens] = W[features x K] . act^T, with
+// MFMA 16x16x32 bf16: A = weight rows, B = the wave's activation rows -- both K-contiguous row fragments, no transposes --
 // and the token on the lane.  Consequences: the residual stream x1/x2 stays in fp32 REGISTERS across the whole chain
-// (128 accumulator VGPRs, one wave per SIMD, 512-register budget); LayerNorm statistics are lane-local sums plus one
-// cross-half shuffle; each lane holds 4 consecutive features per register quad, so activations are exchanged through two
-// per-wave 16 KB LDS buffers with 8-byte accesses (no workgroup barrier), and every HBM store is a whole 512-byte row.
+// (64 VGPRs; two waves per SIMD, so one wave's VALU epilogue (LayerNorm, GELU, packing) overlaps the other's MFMAs);
+// LayerNorm statistics are lane-local sums plus two shuffles; each lane holds 4 consecutive features per accumulator
+// block, so activations are exchanged through a per-wave 8 KB LDS buffer with 8-byte accesses (no workgroup barrier),
+// and every HBM store is a whole row.
 // The layer's 512 KB of weights are pre-packed on the host in exactly the order the kernel consumes them (16 KB slabs of
-// [k-step][feature][16 k], half-swizzled against bank conflicts) and streamed global -> registers -> 2-slab LDS ring, one
-// barrier per slab (= 16 MFMAs per wave).
+// [32-deep k-step][feature][32 k], 16-byte chunks swizzled against bank conflicts) and streamed by LDS-DMA (global_load_lds) into a 5-slot
+// LDS ring with 4 slabs in flight: counted vmcnt + ONE raw s_barrier per slab (= 16 MFMAs per wave).  The feed-forward is
+// walked 64 hidden units at a time (W1 rows -> GELU -> W2 columns), so its activation never exists in full.
 #include "wmz_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int FT = 32;          // tokens per wave
-constexpr int FW = 4;           // waves per workgroup
+constexpr int FT = 16;          // tokens per wave
+constexpr int FW = 8;           // waves per workgroup (two per SIMD: one's epilogue overlaps the other's MFMAs)
 constexpr int NTHR = FW * 64;
 constexpr int SLAB = 16384;     // bytes per weight slab
-constexpr int ACTB = 16384;     // bytes per per-wave activation buffer (32 tokens x 256 features bf16)
+constexpr int RING = 5;         // LDS ring slots: 4 slabs (64 KB) of the weight stream stay in flight
+constexpr int ACTB = 8192;      // per-wave activation buffer (16 tokens x 256 features bf16)
+constexpr int ZCB = 2048;       // per-wave feed-forward chunk buffer (16 tokens x 64 features bf16)
+constexpr int MC = 64;          // feed-forward hidden chunk: W1 rows / W2 columns streamed MC at a time
 
 struct FusedParams {
   const bf16_t* o;      // [ntok, I]   attention output               (HEAD)
@@ -31,146 +37,166 @@ struct FusedParams {
   bf16_t* xo;           // [ntok, D]   residual stream out            (HEAD)
   bf16_t* q;            // [ntok, I]                                   (TAIL)
   bf16_t* kv;           // [ntok, 2I]                                  (TAIL)
-  const char* wpack;    // packed bf16 weights in streaming order (+ 2 slabs of padding)
+  const char* wpack;    // packed bf16 weights in streaming order (+ RING-1 slabs of padding)
   const float* vec;     // packed fp32 vectors: bout[D] g2[D] be2[D] b1[M] b2[D] g1n[D] be1n[D] bkv[2I]
   int ntok;
   float eps;
+  int dbg;              // ablation switches (timing experiments only): 1 = skip MFMA loop, 2 = skip weight DMA + waits
 };
 
-__device__ __forceinline__ int aswz(int token) { return (token & 15) << 4; }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+// 16-byte-chunk XOR swizzle of an activation row: conflict-free ds_read_b128 of 32 token rows at one k-chunk
+template <int ROWB> __device__ __forceinline__ int aswz(int token) {
+  if constexpr (ROWB >= 256) return (token & 15) << 4;
+  else return ((token >> 1) & 7) << 4;          // 128-byte rows: two rows per 256-byte bank line
+}
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below bf16 resolution by 4 orders):
+// a third of libm erff's instruction count, and this kernel's epilogues are VALU-bound
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.f - p * t * __expf(-x * x);
+  return 0.5f * v * (1.f + copysignf(e, v));
+}
 
-// weight stream: ring of two 16 KB slabs; `pre` holds the slab after the one being multiplied
+// ---- weight stream: RING-slot LDS ring filled by LDS-DMA (global_load_lds), RING-1 slabs in flight.
 struct WStream {
-  const char* src;     // next global slab to fetch
-  char* ring;          // LDS, 2 * SLAB
-  int cur;             // ring index holding the current slab
+  int dbg;
+  const char* src;     // global address of the next slab to ISSUE (this lane's 16 bytes of piece 0 of its wave)
+  char* ring;          // LDS ring base + this wave's 4 KB quarter
+  int issue_slot;      // ring slot the next issued slab goes to
+  int cur;             // ring slot of the slab being multiplied
 };
 
-__device__ __forceinline__ void ws_fetch(i32x4 (&pre)[4], const char* src, int tid) {
+__device__ __forceinline__ void ws_issue(WStream& ws) {
+  if (ws.dbg & 2) return;
+  char* dst = ws.ring + ws.issue_slot * SLAB;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pre[i] = *reinterpret_cast<const i32x4*>(src + (tid + NTHR * i) * 16);
-}
-__device__ __forceinline__ void ws_put(char* dst, const i32x4 (&pre)[4], int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(dst + (tid + NTHR * i) * 16) = pre[i];
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws.src + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  ws.src += SLAB;
+  ws.issue_slot = ws.issue_slot == RING - 1 ? 0 : ws.issue_slot + 1;
 }
 
-// acc^T[N x 32 tokens] += W[N x K] . act^T, consuming K/16 k-steps of the stream.  act: this wave's LDS buffer,
-// rows = tokens, ROWB = K*2 bytes, 16-byte chunks XOR-swizzled by aswz(token).
-template <int N, int K>
-__device__ __forceinline__ void gemm_stage(f32x16 (&acc)[N / 32], const char* act, WStream& ws, i32x4 (&pre)[4], int tid,
-                                           int l31, int hh) {
-  constexpr int NB = N / 32;
-  constexpr int KPS = SLAB / (N * 32);          // k-steps per slab
-  constexpr int NSLAB = (K / 16) / KPS;
-  constexpr int ROWB = K * 2;
-  const char* arow = act + l31 * ROWB;
-  const int asw = aswz(l31);
-  const int whalf = (hh ^ ((l31 >> 3) & 1)) * 16; // physical half of this lane's weight row (pre-swizzled on the host)
+// Before multiplying a slab: this wave's eighth of it has landed (all but the 2*(RING-2) youngest VMEM ops done), then
+// one barrier: every piece landed, and every wave is done with the previous slab, whose slot is refilled right away.
+__device__ __forceinline__ void ws_acquire(WStream& ws) {
+  if (!(ws.dbg & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  static_assert(2 * (RING - 2) == 6, "vmcnt literal above follows RING (2 LDS-DMA pieces per wave per slab)");
+  __builtin_amdgcn_s_barrier();
+  ws_issue(ws);
+}
+__device__ __forceinline__ void ws_release(WStream& ws) { ws.cur = ws.cur == RING - 1 ? 0 : ws.cur + 1; }
+
+// acc^T[N x 16 tokens] += W[N x K] . act^T over K/32 k-steps of the stream (MFMA 16x16x32: A = weight rows, B = the
+// wave's token rows).  act: this wave's LDS buffer, rows = tokens, AROWB bytes per row.
+template <int N, int K, int AROWB>
+__device__ __forceinline__ void gemm_stage(f32x4 (&acc)[N / 16], const char* act, const char* ring0, WStream& ws, int li,
+                                           int g) {
+  constexpr int NB = N / 16;
+  constexpr int KPS = SLAB / (N * 64);          // 32-deep k-steps per slab
+  constexpr int NSLAB = (K / 32) / KPS;
+  static_assert(KPS >= 1 && NSLAB * KPS * 32 == K, "stage depth must be a whole number of slabs");
+  const char* arow = act + li * AROWB;
+  const int asw = aswz<AROWB>(li);
+  const int wchunk = (g ^ ((0 - (li >> 2)) & 3)) * 16;   // physical 16-byte chunk of this lane's weight row (host swizzle)
 #pragma unroll 1
   for (int s = 0; s < NSLAB; ++s) {
-    const char* slab = ws.ring + ws.cur * SLAB;
+    ws_acquire(ws);
+    const char* slab = ring0 + ws.cur * SLAB;
+    if (ws.dbg & 1) { ws_release(ws); continue; }
 #pragma unroll
     for (int t = 0; t < KPS; ++t) {
       const int ks = s * KPS + t;
       Frag8<bf16_t> bf;
-      bf.v = *reinterpret_cast<const s16x8*>(arow + (((ks * 2 + hh) << 4) ^ asw));
+      bf.v = *reinterpret_cast<const s16x8*>(arow + (((ks * 4 + g) << 4) ^ asw));
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         Frag8<bf16_t> af;
-        af.v = *reinterpret_cast<const s16x8*>(slab + t * (N * 32) + (32 * b + l31) * 32 + whalf);
-        mma32(acc[b], af, bf);
+        af.v = *reinterpret_cast<const s16x8*>(slab + t * (N * 64) + (16 * b + li) * 64 + wchunk);
+        mma16(acc[b], af, bf);
       }
     }
-    // hand-over: the prefetched slab goes into the other ring slot (everyone left it one barrier ago), the fetch after
-    // next is issued, and one barrier publishes the new slab and retires the current one
-    ws_put(ws.ring + (ws.cur ^ 1) * SLAB, pre, tid);
-    ws.src += SLAB;
-    ws_fetch(pre, ws.src, tid);
-    __syncthreads();
-    ws.cur ^= 1;
+    ws_release(ws);
   }
 }
 
-// feature quad of accumulator block b, register group g4 (regs 4g4..4g4+3): n0 .. n0+3
-__device__ __forceinline__ int quad_n0(int b, int g4, int hh) { return 32 * b + 8 * g4 + 4 * hh; }
+// accumulator block b of lane group g holds features n0 .. n0+3 of the lane's token
+__device__ __forceinline__ int quad_n0(int b, int g) { return 16 * b + 4 * g; }
 
 template <int NB>
-__device__ __forceinline__ void add_vec(f32x16 (&acc)[NB], const float* vec, int hh) {   // vec already offset to feature 0 of acc
+__device__ __forceinline__ void add_vec(f32x4 (&acc)[NB], const float* vec, int g) {   // vec offset to feature 0 of acc
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(vec + quad_n0(b, g4, hh));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[b][4 * g4 + r] += v[r];
-      if (g4 == 3) __builtin_amdgcn_sched_barrier(0);   // keep the loads of later blocks from piling up in VGPRs
-    }
+  for (int b = 0; b < NB; ++b) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(vec + quad_n0(b, g));
+    acc[b] += v;
+  }
 }
 
-// write the wave's [32 tokens x NB*32 features] tile (bf16) into columns n_off.. of its LDS buffer (rows of ROWF
-// features, row-major, swizzled)
+// acc += the lane's token row of a global [ntok, NB*16] bf16 tensor (8-byte loads in the accumulator layout)
+template <int NB>
+__device__ __forceinline__ void add_row_global(f32x4 (&acc)[NB], const bf16_t* src, long tok, bool ok, int g) {
+  const bf16_t* row = src + tok * (NB * 16);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    s16x4 pk = (s16x4)(0);
+    if (ok) pk = *reinterpret_cast<const s16x4*>(row + quad_n0(b, g));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[b][r] += bf16_bits_to_f32((unsigned short)pk[r]);
+  }
+}
+
+// write the wave's [16 tokens x NB*16 features] tile (bf16) into columns n_off.. of an LDS buffer with ROWF-feature rows
 template <int NB, int ROWF, typename F>
-__device__ __forceinline__ void tile_to_lds(char* act, const f32x16 (&acc)[NB], int n_off, int l31, int hh, F f) {
+__device__ __forceinline__ void tile_to_lds(char* act, const f32x4 (&acc)[NB], int n_off, int li, int g, F f) {
   constexpr int ROWB = ROWF * 2;
-  char* row = act + l31 * ROWB;
-  const int sw = aswz(l31);
+  char* row = act + li * ROWB;
+  const int sw = aswz<ROWB>(li);
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int b = 0; b < NB; ++b) {
+    const int n0 = n_off + quad_n0(b, g);
+    s16x4 pk;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int n0 = n_off + quad_n0(b, g4, hh);
-      s16x4 pk;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(f(acc[b][4 * g4 + r], n0 + r));
-      *reinterpret_cast<s16x4*>(row + ((n0 * 2) ^ sw)) = pk;
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(f(acc[b][r]));
+    *reinterpret_cast<s16x4*>(row + ((n0 * 2) ^ sw)) = pk;
+  }
 }
 
-// LayerNorm of the token held by this lane pair (features split over hh): returns mean, rstd
+// LayerNorm of the token held by this lane quartet (features split over the 4 lane groups) -> bf16 -> LDS buffer
 template <int NB>
-__device__ __forceinline__ void ln_stats(const f32x16 (&acc)[NB], float eps, float& mean, float& rstd) {
-  constexpr int NF = NB * 32;
+__device__ __forceinline__ void ln_to_lds(char* act, const f32x4 (&acc)[NB], const float* gamma, const float* beta,
+                                          float eps, int li, int g) {
+  constexpr int NF = NB * 16, ROWB = NF * 2;
   float s = 0.f;
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += acc[b][r];
+  for (int b = 0; b < NB; ++b) s += (acc[b][0] + acc[b][1]) + (acc[b][2] + acc[b][3]);
+  s += __shfl_xor(s, 16);
   s += __shfl_xor(s, 32);
-  mean = s / (float)NF;
+  const float mean = s / (float)NF;
   float q = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float d = acc[b][r] - mean; q += d * d; }
+    for (int r = 0; r < 4; ++r) { const float d = acc[b][r] - mean; q = fmaf(d, d, q); }
+  q += __shfl_xor(q, 16);
   q += __shfl_xor(q, 32);
-  rstd = rsqrtf(q / (float)NF + eps);
-}
-
-// LN(acc) -> bf16 -> LDS buffer
-template <int NB>
-__device__ __forceinline__ void ln_to_lds(char* act, const f32x16 (&acc)[NB], const float* gamma, const float* beta,
-                                          float eps, int l31, int hh) {
-  float mean, rstd;
-  ln_stats<NB>(acc, eps, mean, rstd);
-  constexpr int ROWB = NB * 32 * 2;
-  char* row = act + l31 * ROWB;
-  const int sw = aswz(l31);
+  const float rstd = rsqrtf(q / (float)NF + eps);
+  char* row = act + li * ROWB;
+  const int sw = aswz<ROWB>(li);
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int b = 0; b < NB; ++b) {
+    const int n0 = quad_n0(b, g);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + n0);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + n0);
+    s16x4 pk;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int n0 = quad_n0(b, g4, hh);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n0);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(beta + n0);
-      s16x4 pk;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits((acc[b][4 * g4 + r] - mean) * rstd * g[r] + be[r]);
-      *reinterpret_cast<s16x4*>(row + ((n0 * 2) ^ sw)) = pk;
-      if (g4 == 3) __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits((acc[b][r] - mean) * rstd * gm[r] + be[r]);
+    *reinterpret_cast<s16x4*>(row + ((n0 * 2) ^ sw)) = pk;
+  }
 }
 
 // global [tok0.., F] bf16 rows -> the wave's LDS buffer (coalesced 16-byte chunks); rows >= ntok are zero
@@ -183,7 +209,29 @@ __device__ __forceinline__ void rows_to_lds(char* act, const bf16_t* src, long t
     const int r = idx / CPR, c = idx - r * CPR;
     i32x4 v = (i32x4)(0);
     if (tok0 + r < ntok) v = *reinterpret_cast<const i32x4*>(src + (tok0 + r) * F + c * 8);
-    *reinterpret_cast<i32x4*>(act + r * ROWB + ((c << 4) ^ aswz(r))) = v;
+    *reinterpret_cast<i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r))) = v;
+  }
+}
+// same, split: issue the global loads early (registers), write them to LDS late (T14: the GEMM in between hides them)
+template <int F>
+__device__ __forceinline__ void rows_fetch(i32x4 (&regs)[FT * (F * 2 / 16) / 64], const bf16_t* src, long tok0, int ntok, int lane) {
+  constexpr int CPR = F * 2 / 16, TOT = FT * CPR;
+#pragma unroll
+  for (int i = 0; i < TOT / 64; ++i) {
+    const int idx = lane + 64 * i;
+    const int r = idx / CPR, c = idx - r * CPR;
+    regs[i] = (i32x4)(0);
+    if (tok0 + r < ntok) regs[i] = *reinterpret_cast<const i32x4*>(src + (tok0 + r) * F + c * 8);
+  }
+}
+template <int F>
+__device__ __forceinline__ void rows_put(char* act, const i32x4 (&regs)[FT * (F * 2 / 16) / 64], int lane) {
+  constexpr int ROWB = F * 2, CPR = ROWB / 16, TOT = FT * CPR;
+#pragma unroll
+  for (int i = 0; i < TOT / 64; ++i) {
+    const int idx = lane + 64 * i;
+    const int r = idx / CPR, c = idx - r * CPR;
+    *reinterpret_cast<i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r))) = regs[i];
   }
 }
 // the wave's LDS buffer -> global rows, whole rows per store instruction
@@ -194,43 +242,47 @@ __device__ __forceinline__ void lds_to_rows(bf16_t* dst, const char* act, long t
   for (int i = 0; i < TOT / 64; ++i) {
     const int idx = lane + 64 * i;
     const int r = idx / CPR, c = idx - r * CPR;
-    const i32x4 v = *reinterpret_cast<const i32x4*>(act + r * ROWB + ((c << 4) ^ aswz(r)));
+    const i32x4 v = *reinterpret_cast<const i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r)));
     if (tok0 + r < ntok) *reinterpret_cast<i32x4*>(dst + (tok0 + r) * F + c * 8) = v;
   }
 }
 // read the lane's token row back from LDS into the accumulator layout (fp32)
-template <int NB>
-__device__ __forceinline__ void lds_to_acc(f32x16 (&acc)[NB], const char* act, int l31, int hh, bool add) {
-  constexpr int ROWB = NB * 32 * 2;
-  const char* row = act + l31 * ROWB;
-  const int sw = aswz(l31);
+template <int NB, bool ADD>
+__device__ __forceinline__ void lds_to_acc(f32x4 (&acc)[NB], const char* act, int li, int g) {
+  constexpr int ROWB = NB * 16 * 2;
+  const char* row = act + li * ROWB;
+  const int sw = aswz<ROWB>(li);
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int b = 0; b < NB; ++b) {
+    const s16x4 pk = *reinterpret_cast<const s16x4*>(row + ((quad_n0(b, g) * 2) ^ sw));
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const s16x4 pk = *reinterpret_cast<const s16x4*>(row + ((quad_n0(b, g4, hh) * 2) ^ sw));
+    for (int r = 0; r < 4; ++r) acc[b][r] = (ADD ? acc[b][r] : 0.f) + bf16_bits_to_f32((unsigned short)pk[r]);
+  }
+}
+
+template <int N> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[N]) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = bf16_bits_to_f32((unsigned short)pk[r]);
-        acc[b][4 * g4 + r] = add ? acc[b][4 * g4 + r] + v : v;
-      }
-      if (g4 == 3) __builtin_amdgcn_sched_barrier(0);
-    }
+  for (int b = 0; b < N; ++b) acc[b] = (f32x4)(0.f);
 }
 
 template <int D, int I, int M, bool HEAD, bool TAIL>
-__global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
+__global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
   static_assert(D == 256 && M == 256 && I == 128, "built for the default denoiser widths");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
   char* actA = smem + wave * ACTB;
-  char* actB = smem + FW * ACTB + wave * ACTB;
+  char* zc = smem + FW * ACTB + wave * ZCB;
+  const char* ring0 = smem + FW * (ACTB + ZCB);
   WStream ws;
-  ws.ring = smem + 2 * FW * ACTB;
-  ws.src = P.wpack;
+  ws.ring = smem + FW * (ACTB + ZCB) + wave * 2048;
+  ws.src = P.wpack + wave * 2048 + lane * 16;
+  ws.issue_slot = 0;
   ws.cur = 0;
+  ws.dbg = P.dbg;
   const long tok0 = (long)blockIdx.x * (FT * FW) + wave * FT;
+  const bool tok_ok = tok0 + li < P.ntok;
   const float* v_bout = P.vec;
   const float* v_g2 = v_bout + D;
   const float* v_be2 = v_g2 + D;
@@ -240,64 +292,57 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   const float* v_be1n = v_g1n + D;
   const float* v_bkv = v_be1n + D;
 
-  // prime the weight ring: slab 0 -> ring[0], slab 1 in flight
-  i32x4 pre[4];
-  ws_fetch(pre, ws.src, tid);
-  ws_put(ws.ring, pre, tid);
-  ws.src += SLAB;
-  ws_fetch(pre, ws.src, tid);
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) ws_issue(ws);   // prime: RING-1 slabs in flight
 
-  f32x16 xr[D / 32];                         // the residual stream of this lane's token, fp32, lives here
+  f32x4 xr[D / 16];                          // the residual stream of this lane's token (1/4 of its features), fp32
   if constexpr (HEAD) {
     rows_to_lds<I>(actA, P.o, tok0, P.ntok, lane);
-    rows_to_lds<D>(actB, P.x, tok0, P.ntok, lane);
-    __syncthreads();                         // ring[0] visible (the act buffers are wave-private)
-#pragma unroll
-    for (int b = 0; b < D / 32; ++b) xr[b] = (f32x16)(0.f);
-    gemm_stage<D, I>(xr, actA, ws, pre, tid, l31, hh);            // o Wout^T
-    add_vec<D / 32>(xr, v_bout, hh);
-    lds_to_acc<D / 32>(xr, actB, l31, hh, true);                   // + x            -> x1
-    ln_to_lds<D / 32>(actA, xr, v_g2, v_be2, P.eps, l31, hh);      // LN2(x1) -> actA
+    i32x4 xpre[FT * (D * 2 / 16) / 64];
+    rows_fetch<D>(xpre, P.x, tok0, P.ntok, lane);                      // residual rows: in flight under the first GEMM
+    zero_acc(xr);
+    gemm_stage<D, I, I * 2>(xr, actA, ring0, ws, li, g);               // o Wout^T
+    add_vec<D / 16>(xr, v_bout, g);
+    rows_put<D>(actA, xpre, lane);                                     // (o tile is dead) x rows -> LDS, coalesced
+    lds_to_acc<D / 16, true>(xr, actA, li, g);                         // + x            -> x1
+    ln_to_lds<D / 16>(actA, xr, v_g2, v_be2, P.eps, li, g);            // LN2(x1) -> actA
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {                          // W1 LN2(x1) in two 128-feature halves
-      f32x16 z[M / 64];
-#pragma unroll
-      for (int b = 0; b < M / 64; ++b) z[b] = (f32x16)(0.f);
-      gemm_stage<M / 2, D>(z, actA, ws, pre, tid, l31, hh);
-      add_vec<M / 64>(z, v_b1 + half * (M / 2), hh);
-      tile_to_lds<M / 64, M>(actB, z, half * (M / 2), l31, hh, [](float v, int) { return gelu_erf(v); });
+    for (int c = 0; c < M / MC; ++c) {                                 // feed-forward, MC hidden units at a time
+      f32x4 z[MC / 16];
+      zero_acc(z);
+      gemm_stage<MC, D, D * 2>(z, actA, ring0, ws, li, g);             // W1[c] LN2(x1)
+      add_vec<MC / 16>(z, v_b1 + c * MC, g);
+      tile_to_lds<MC / 16, MC>(zc, z, 0, li, g, [](float v) { return gelu_erf(v); });
+      gemm_stage<D, MC, MC * 2>(xr, zc, ring0, ws, li, g);             // x1 += W2[:, c] GELU(.)
     }
-    gemm_stage<D, M>(xr, actB, ws, pre, tid, l31, hh);             // x1 += W2 GELU(.)
-    add_vec<D / 32>(xr, v_b2, hh);                                 //                 -> x2
-    tile_to_lds<D / 32, D>(actA, xr, 0, l31, hh, [](float v, int) { return v; });
+    add_vec<D / 16>(xr, v_b2, g);                                      //                 -> x2
+    tile_to_lds<D / 16, D>(actA, xr, 0, li, g, [](float v) { return v; });
     lds_to_rows<D>(P.xo, actA, tok0, P.ntok, lane);
   } else {
     rows_to_lds<D>(actA, P.x, tok0, P.ntok, lane);
-    __syncthreads();
-    lds_to_acc<D / 32>(xr, actA, l31, hh, false);
+    lds_to_acc<D / 16, false>(xr, actA, li, g);
   }
   if constexpr (TAIL) {
-    // actA holds x2 (bf16): to_q on the raw stream; LN1'(x2) -> actB for to_k | to_v
-    ln_to_lds<D / 32>(actB, xr, v_g1n, v_be1n, P.eps, l31, hh);
-    {
-      f32x16 qa[I / 32];
-#pragma unroll
-      for (int b = 0; b < I / 32; ++b) qa[b] = (f32x16)(0.f);
-      gemm_stage<I, D>(qa, actA, ws, pre, tid, l31, hh);
-      tile_to_lds<I / 32, I>(actA, qa, 0, l31, hh, [](float v, int) { return v; });
+    {                                                                  // to_q on the raw stream (actA = x2, bf16)
+      f32x4 qa[I / 16];
+      zero_acc(qa);
+      gemm_stage<I, D, D * 2>(qa, actA, ring0, ws, li, g);
+      tile_to_lds<I / 16, I>(actA, qa, 0, li, g, [](float v) { return v; });
       lds_to_rows<I>(P.q, actA, tok0, P.ntok, lane);
     }
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {                          // to_k, then to_v, into the two column halves
-      f32x16 ka[I / 32];
-#pragma unroll
-      for (int b = 0; b < I / 32; ++b) ka[b] = (f32x16)(0.f);
-      gemm_stage<I, D>(ka, actB, ws, pre, tid, l31, hh);
-      add_vec<I / 32>(ka, v_bkv + half * I, hh);
-      tile_to_lds<I / 32, 2 * I>(actA, ka, half * I, l31, hh, [](float v, int) { return v; });
-    }
+    ln_to_lds<D / 16>(actA, xr, v_g1n, v_be1n, P.eps, li, g);          // LN1'(x2) -> actA
+    f32x4 ka[I / 16], va[I / 16];
+    zero_acc(ka);
+    zero_acc(va);
+    gemm_stage<I, D, D * 2>(ka, actA, ring0, ws, li, g);               // to_k
+    gemm_stage<I, D, D * 2>(va, actA, ring0, ws, li, g);               // to_v
+    add_vec<I / 16>(ka, v_bkv, g);
+    add_vec<I / 16>(va, v_bkv + I, g);
+    tile_to_lds<I / 16, 2 * I>(actA, ka, 0, li, g, [](float v) { return v; });
+    tile_to_lds<I / 16, 2 * I>(actA, va, I, li, g, [](float v) { return v; });
     lds_to_rows<2 * I>(P.kv, actA, tok0, P.ntok, lane);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the padding slabs still in flight target this workgroup's LDS
 }
 
 }  // namespace
@@ -316,7 +361,9 @@ extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, vo
   FusedParams P;
   P.o = (const bf16_t*)o; P.x = (const bf16_t*)x; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
   P.wpack = (const char*)wpack; P.vec = vec; P.ntok = ntok; P.eps = eps;
-  const size_t smem = 2 * FW * ACTB + 2 * SLAB;
+  static const int dbg_env = getenv("WMZ_FUSED_DBG") ? atoi(getenv("WMZ_FUSED_DBG")) : 0;
+  P.dbg = dbg_env;
+  const size_t smem = FW * (ACTB + ZCB) + RING * SLAB;
   dim3 grid((unsigned)wmz_cdiv(ntok, FT * FW)), block(NTHR);
   hipStream_t st = (hipStream_t)stream;
 #define WMZ_FUSED(H, T)                                                                                            \

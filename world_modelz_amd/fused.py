@@ -6,15 +6,19 @@ from . import _cast, ops
 from . import _lib as L
 
 D_, I_, M_ = 256, 128, 256
-_PAD = 2 * 16384
+_PAD = 4 * 16384        # RING-1 slabs the kernel's LDS-DMA prefetch runs past the last real slab
+MC_ = 64
 
 
 def _pack_w(w):
-    """[N, K] -> [K/16][N][2 halves][8], halves of row n swapped when (n>>3)&1 (LDS bank-conflict swizzle)."""
+    """[N, K] -> [K/32][N][4 chunks][8]: the MFMA 16x16x32 A-operand rows of one 32-deep k-step, with the 16-byte chunk
+    index of row n XOR-ed by (-(n>>2)) & 3 (conflict-free ds_read_b128 in the kernel)."""
     N, K = w.shape
-    v = w.reshape(N, K // 16, 2, 8)
-    odd = ((torch.arange(N, device=w.device) >> 3) & 1).bool()
-    v = torch.where(odd[:, None, None, None], v.flip(2), v)
+    v = w.reshape(N, K // 32, 4, 8)
+    n = torch.arange(N, device=w.device)
+    f = (-(n >> 2)) & 3                                       # [N]
+    src = torch.arange(4, device=w.device)[None, :] ^ f[:, None]   # physical chunk c' holds logical chunk c'^f
+    v = torch.gather(v, 2, src[:, None, :, None].expand(N, K // 32, 4, 8))
     return v.permute(1, 0, 2, 3).reshape(-1)
 
 
@@ -44,7 +48,9 @@ def _layer_pack(head, tail):
         ws = [w.detach().to(torch.bfloat16) for w in ws]
         out, i = [], 0
         if head is not None:
-            out += [_pack_w(ws[0]), _pack_w(ws[1][:M_ // 2]), _pack_w(ws[1][M_ // 2:]), _pack_w(ws[2])]
+            out.append(_pack_w(ws[0]))
+            for c in range(M_ // MC_):          # feed-forward streamed MC hidden units at a time: W1 rows, then W2 columns
+                out += [_pack_w(ws[1][c * MC_:(c + 1) * MC_]), _pack_w(ws[2][:, c * MC_:(c + 1) * MC_])]
             i = 3
         if tail is not None:
             out += [_pack_w(ws[i]), _pack_w(ws[i + 1]), _pack_w(ws[i + 2])]
