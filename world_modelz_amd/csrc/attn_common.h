@@ -107,6 +107,33 @@ __device__ __forceinline__ void attn_stage_store(char* dst, const i32x4 (&regs)[
   }
 }
 
+// LDS-DMA staging of `KC` tiles (rows c0*16 ...) of a [HW, ld] plane into a swizzled LDS image.  global_load_lds writes
+// lane-linear (1 KB per wave instruction), so the swizzle is applied on the SOURCE side: the lane that lands on physical
+// chunk pc of row r fetches logical chunk pc ^ (swz(r) >> 4).  Rows past the staged range / the plane and columns past dh
+// are redirected to valid addresses (finite data; the window mask or Q's zero padding nullifies them).  Each of the NW
+// waves issues IMG/1024/NW pieces; completion is the issuing wave's vmcnt.
+template <typename T, int DH, bool VS, int KC, int NW>
+__device__ __forceinline__ void attn_stage_dma(char* dst, const T* plane, long ld, int c0, int ntiles, int HW, int dh,
+                                               int wave, int lane) {
+  constexpr int ROWB = DH * (int)sizeof(T);
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int PIECES = KC * 16 * ROWB / 1024;
+  static_assert(PIECES % NW == 0 && PIECES >= NW, "image must split into whole 1 KB pieces per wave");
+  const int last_row = min(ntiles * 16, HW - c0 * 16) - 1;
+  const int cmax = dh / EPC - 1;
+#pragma unroll
+  for (int i = 0; i < PIECES / NW; ++i) {
+    const int piece = wave + NW * i;
+    const int off = piece * 1024 + lane * 16;
+    const int r = off / ROWB, pc = (off - r * ROWB) >> 4;
+    const int sw = VS ? vswz<ROWB>(r) : kswz<ROWB>(r);
+    const int c = min(pc ^ (sw >> 4), cmax);
+    const int rr = min(r, last_row);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plane + (long)(c0 * 16 + rr) * ld + c * EPC),
+                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+  }
+}
+
 // Row fragment (8 consecutive elements starting at element e0, e0 % 8 == 0) of image row r.
 template <typename T, int DH, bool VS>
 __device__ __forceinline__ void lds_row_frag(Frag8<T>& f, const char* img, int r, int e0) {

@@ -1,9 +1,12 @@
 // Local windowed 3D attention, forward (replaces Local3dAttention.local_attention,
 // vq-video-diffusion/local_3d_attention.py:78-99, without materialising the unfolded K/V).
 //
-// Work split: a workgroup (4 waves) owns 4*QPW consecutive 16-query tiles of one (b, head, s) plane.  For every
-// in-range key plane s+ds it stages KC key tiles of K and V into LDS (swizzled images), and each wave walks the
-// key tiles its query tiles can see, two at a time:
+// Work split: a workgroup (8 waves, two per SIMD) owns 8*QPW consecutive 16-query tiles of one (b, head, s) plane -- a
+// whole 16x16 plane at the BASELINE shapes, so every K/V row is staged once per neighbouring plane (7x) instead of once
+// per half plane with its halo (12x).  For every in-range key plane s+ds, slabs of KC key tiles of K and V are brought
+// into a DOUBLE-BUFFERED pair of swizzled LDS images by LDS-DMA (global_load_lds, swizzle applied on the source address):
+// the slab after the one being processed is always in flight.  Each wave walks the key tiles its query tiles can see,
+// two at a time:
 //   S^T[32 keys x 16 queries] = K . Q^T          (MFMA 16x16x32, A = K rows from LDS, B = Q rows in registers)
 //   window mask (packed u16 coordinate test), online softmax (row max via two wave shuffles)
 //   O^T[dh x 16 queries]    += V^T . P^T          (A = V^T by ds_read_b64_tr_b16, B = P straight from S^T's
@@ -13,7 +16,7 @@
 
 namespace {
 
-constexpr int NWAVES = 4;
+constexpr int NWAVES = 8;
 constexpr int NTHREADS = NWAVES * 64;
 
 template <typename T, int DH, int QPW, int KC>
@@ -26,9 +29,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restri
   constexpr int KS = DH / 32;   // k-steps of QK^T
   constexpr int MT = DH / 16;   // 16-row blocks of O^T
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vs = smem + IMG;
-  int* coords = reinterpret_cast<int*>(smem + 2 * IMG);
+  int* coords = reinterpret_cast<int*>(smem + 4 * IMG);      // [buf0: K | V][buf1: K | V][tables]
   TileInfo* tinfo = reinterpret_cast<TileInfo*>(coords + G.tiles * 16);
 
   const int tid = threadIdx.x;
@@ -93,24 +94,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restri
   const int t_lo = (max(wg_hlo - G.eH, 0) * G.W) >> 4;
   const int t_hi = (min(wg_hhi + G.eH, G.H - 1) * G.W + G.W - 1) >> 4;
 
-  for (int ds = -G.eS; ds <= G.eS; ++ds) {
-    const int sk = s + ds;
-    if (sk < 0 || sk >= G.S) continue;
-    const long plane_k = ((long)b * G.S + sk) * HW;
-    const T* kplane = K + plane_k * G.ldk + (long)head * dh;
-    const T* vplane = V + plane_k * G.ldv + (long)head * dh;
-    for (int c0 = t_lo; c0 <= t_hi; c0 += KC) {
-      const int ntl = min(KC, t_hi - c0 + 1);
-      {
-        constexpr int NREG = KC * 16 * (ROWB / 16) / NTHREADS;
-        i32x4 kreg[NREG], vreg[NREG];
-        attn_stage_load<T, DH, false, KC, NTHREADS>(kreg, kplane, G.ldk, c0, ntl, HW, dh, tid);
-        attn_stage_load<T, DH, true, KC, NTHREADS>(vreg, vplane, G.ldv, c0, ntl, HW, dh, tid);
-        __syncthreads();      // every wave is done with the previous slab
-        attn_stage_store<T, DH, false, KC, NTHREADS>(Ks, kreg, ntl, tid);
-        attn_stage_store<T, DH, true, KC, NTHREADS>(Vs, vreg, ntl, tid);
-        __syncthreads();
-      }
+  // slab schedule: planes sk_lo..sk_hi x nch slabs of KC tiles; slab j+1 is in flight while slab j is processed
+  const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
+  const int nch = (t_hi - t_lo + KC) / KC;
+  const int nslab = (sk_hi - sk_lo + 1) * nch;
+  auto issue = [&](int j) {
+    const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
+    const long plane_k = ((long)b * G.S + (sk_lo + pl)) * HW;
+    const int ntl = min(KC, t_hi - c0 + 1);
+    char* buf = smem + (j & 1) * 2 * IMG;
+    attn_stage_dma<T, DH, false, KC, NWAVES>(buf, K + plane_k * G.ldk + (long)head * dh, G.ldk, c0, ntl, HW, dh, wave, lane);
+    attn_stage_dma<T, DH, true, KC, NWAVES>(buf + IMG, V + plane_k * G.ldv + (long)head * dh, G.ldv, c0, ntl, HW, dh, wave, lane);
+  };
+  issue(0);
+  for (int j = 0; j < nslab; ++j) {
+    const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
+    const int ds = sk_lo + pl - s;
+    const int ntl = min(KC, t_hi - c0 + 1);
+    const char* Ks = smem + (j & 1) * 2 * IMG;
+    const char* Vs = Ks + IMG;
+    // this wave's pieces of slab j have landed; the barrier makes every wave's pieces visible and retires slab j-1,
+    // whose buffer is refilled right away
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + 1 < nslab) issue(j + 1);
+    {
       const int c_hi = c0 + ntl - 1;
 #pragma unroll
       for (int qi = 0; qi < QPW; ++qi) {
@@ -222,7 +230,7 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
            hipStream_t st) {
   G.qgroups = wmz_cdiv(G.tiles, NWAVES * QPW);
   const long nwg = (long)G.B * G.heads * G.S * G.qgroups;
-  const size_t smem = 2 * (size_t)KC * 16 * DH * sizeof(T) + (size_t)G.tiles * 16 * 4 + (size_t)G.tiles * sizeof(TileInfo);
+  const size_t smem = 4 * (size_t)KC * 16 * DH * sizeof(T) + (size_t)G.tiles * 16 * 4 + (size_t)G.tiles * sizeof(TileInfo);
   if (smem > 160 * 1024) { wmz_set_error("wmz_local3d_attn_fwd: plane too large for the LDS tables (H*W=%d)", G.HW); return WMZ_ERR_UNSUPPORTED; }
   auto kern = attn_fwd_kernel<T, DH, QPW, KC>;
   static bool attr_done = false;   // per instantiation
