@@ -242,3 +242,47 @@ def test_library_refuses_cpu_tensors(ops):
     from world_modelz_amd._lib import WmzError
     with pytest.raises(WmzError):
         ops.vq_argmin(torch.randn(4, 8), torch.randn(3, 8))
+
+
+@pytest.mark.parametrize('shape,heads,dh,ext', [
+    ((2, 5, 16, 16), 1, 128, (3, 3, 3)),       # BASELINE plane shape
+    ((1, 9, 16, 16), 1, 128, (3, 1, 1)),       # published run-03 window (7,3,3)
+    ((1, 4, 16, 16), 2, 64, (1, 2, 3)),
+    ((1, 3, 40, 16), 1, 32, (2, 2, 2)),        # H > 16: several workgroups per plane
+    ((1, 2, 5, 16), 4, 32, (0, 1, 0)),         # H < 16: idle waves
+    ((1, 6, 16, 16), 1, 128, (5, 0, 7)),       # wide column window, single row
+])
+def test_attention_row16_fast_path(ops, shape, heads, dh, ext):
+    """bf16, W == 16 takes attn_fwd_row16.hip (padded LDS rows, bias masks, deferred max): against the oracle and
+    against the general kernel (forced by asking for the logits probe).  out within 1e-2 rel of the fp32 oracle
+    (P is bf16 for the PV MFMA), the two kernels within 4e-3 of each other, lse within 1e-4."""
+    torch.manual_seed(21)
+    B, S, H, W = shape
+    I = heads * dh
+    q, k, v = (torch.randn(B, S, H, W, I).bfloat16() for _ in range(3))
+    ref, ref_logits = oat.local_attention(k.float(), v.float(), q.float(), ext, heads, return_logits=True)
+    fast, lse_f, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True)
+    gen, lse_g, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True, logits_dbg=True)
+    assert rel(fast, ref) < 1e-2
+    assert rel(fast, gen) < 4e-3
+    lse_ref = torch.logsumexp(ref_logits, -1).reshape(-1, heads)
+    assert torch.allclose(lse_f.cpu(), lse_ref, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(lse_f.cpu(), lse_g.cpu(), rtol=1e-5, atol=1e-5)
+
+
+def test_attention_row16_deferred_max_branch(ops):
+    """Force both sides of the deferred-rescale decision: a key far above the running max late in the walk (rescale
+    must fire) and logits that creep up by < 2^8 per step (rescale deferred; P may exceed 1)."""
+    torch.manual_seed(22)
+    B, S, H, W, I = 1, 7, 16, 16, 128
+    q, k, v = (torch.randn(B, S, H, W, I) * 0.5 for _ in range(3))
+    k[0, 6, 15, 15] = 60.0 * q[0, 4, 13, 13] / q[0, 4, 13, 13].norm()     # visited last for that query: big jump
+    for i in range(7):                                                     # slowly growing logits for query (3,8,8)
+        k[0, i, 8, 8] = (2.0 + 2.5 * i) * q[0, 3, 8, 8] / q[0, 3, 8, 8].norm() * (128 ** 0.5) / q[0, 3, 8, 8].norm()
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    ref = oat.local_attention(k.float(), v.float(), q.float(), (3, 3, 3), 1)
+    out, _, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), (3, 3, 3), 1)
+    assert torch.isfinite(out).all()
+    assert rel(out, ref) < 1e-2
+    for pos in [(0, 4, 13, 13), (0, 3, 8, 8)]:
+        assert rel(out[pos], ref[pos]) < 2e-2

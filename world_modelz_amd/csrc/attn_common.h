@@ -17,6 +17,7 @@ struct AttnGeom {
   int tiles;     // ceil(HW/16)
   int qgroups;   // workgroups per (b, head, s) plane
   float scale;   // dh^-0.5
+  int dbg;       // ablation switches for timing experiments: 1 = skip the per-tile compute, 2 = skip the K/V staging
 };
 
 struct TileInfo { int hlo, hhi, wlo, whi; };
@@ -118,12 +119,12 @@ __device__ __forceinline__ void attn_stage_dma(char* dst, const T* plane, long l
   constexpr int ROWB = DH * (int)sizeof(T);
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int PIECES = KC * 16 * ROWB / 1024;
-  static_assert(PIECES % NW == 0 && PIECES >= NW, "image must split into whole 1 KB pieces per wave");
   const int last_row = min(ntiles * 16, HW - c0 * 16) - 1;
   const int cmax = dh / EPC - 1;
 #pragma unroll
-  for (int i = 0; i < PIECES / NW; ++i) {
+  for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
     const int piece = wave + NW * i;
+    if (PIECES % NW != 0 && piece >= PIECES) break;      // wave-uniform
     const int off = piece * 1024 + lane * 16;
     const int r = off / ROWB, pc = (off - r * ROWB) >> 4;
     const int sw = VS ? vswz<ROWB>(r) : kswz<ROWB>(r);

@@ -1,7 +1,8 @@
 // Local windowed 3D attention, forward (replaces Local3dAttention.local_attention,
 // vq-video-diffusion/local_3d_attention.py:78-99, without materialising the unfolded K/V).
 //
-// Work split: a workgroup (8 waves, two per SIMD) owns 8*QPW consecutive 16-query tiles of one (b, head, s) plane -- a
+// Work split: a workgroup (bf16: 16 waves = four per SIMD, one 16-query tile each; the per-tile dependency chain
+// S -> max -> exp -> PV is latency-bound, so occupancy is what hides it) owns NWAVES*QPW consecutive 16-query tiles of one (b, head, s) plane -- a
 // whole 16x16 plane at the BASELINE shapes, so every K/V row is staged once per neighbouring plane (7x) instead of once
 // per half plane with its halo (12x).  For every in-range key plane s+ds, slabs of KC key tiles of K and V are brought
 // into a DOUBLE-BUFFERED pair of swizzled LDS images by LDS-DMA (global_load_lds, swizzle applied on the source address):
@@ -13,17 +14,17 @@
 //                                                  accumulator layout: no cross-lane movement)
 // The reference's zero-padded, -1e9-masked slots have probability exactly 0, so they are simply not visited.
 #include "attn_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int NWAVES = 8;
-constexpr int NTHREADS = NWAVES * 64;
 
-template <typename T, int DH, int QPW, int KC>
-__global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+template <typename T, int DH, int QPW, int KC, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                const T* __restrict__ V, T* __restrict__ O,
                                                                float* __restrict__ LSE, float* __restrict__ DBG,
                                                                AttnGeom G) {
+  constexpr int NTHREADS = NWAVES * 64;
   constexpr int ROWB = DH * (int)sizeof(T);
   constexpr int IMG = KC * 16 * ROWB;
   constexpr int KS = DH / 32;   // k-steps of QK^T
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restri
   const int nch = (t_hi - t_lo + KC) / KC;
   const int nslab = (sk_hi - sk_lo + 1) * nch;
   auto issue = [&](int j) {
+    if (G.dbg & 2) return;
     const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
     const long plane_k = ((long)b * G.S + (sk_lo + pl)) * HW;
     const int ntl = min(KC, t_hi - c0 + 1);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restri
       const int c_hi = c0 + ntl - 1;
 #pragma unroll
       for (int qi = 0; qi < QPW; ++qi) {
-        if (!active[qi]) continue;
+        if (!active[qi] || (G.dbg & 1)) continue;
         const int lo = max(c0, need_lo[qi]), hi = min(c_hi, need_hi[qi]);
         for (int t0 = lo; t0 <= hi; t0 += 2) {
           const bool has1 = t0 + 1 <= hi;
@@ -225,14 +227,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void attn_fwd_kernel(const T* __restri
   }
 }
 
-template <typename T, int DH, int QPW, int KC>
+template <typename T, int DH, int QPW, int KC, int NWAVES>
 int launch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg, AttnGeom G,
            hipStream_t st) {
   G.qgroups = wmz_cdiv(G.tiles, NWAVES * QPW);
   const long nwg = (long)G.B * G.heads * G.S * G.qgroups;
   const size_t smem = 4 * (size_t)KC * 16 * DH * sizeof(T) + (size_t)G.tiles * 16 * 4 + (size_t)G.tiles * sizeof(TileInfo);
   if (smem > 160 * 1024) { wmz_set_error("wmz_local3d_attn_fwd: plane too large for the LDS tables (H*W=%d)", G.HW); return WMZ_ERR_UNSUPPORTED; }
-  auto kern = attn_fwd_kernel<T, DH, QPW, KC>;
+  constexpr int NTHREADS = NWAVES * 64;
+  auto kern = attn_fwd_kernel<T, DH, QPW, KC, NWAVES>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -245,6 +248,10 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
 }
 
 }  // namespace
+
+// fast path for 16-wide planes (attn_fwd_row16.hip)
+int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, const AttnGeom& G,
+                                hipStream_t st);
 
 extern "C" int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                                     float* logits_dbg, int B, int S, int H, int W, int heads, int dh, int eS, int eH,
@@ -262,14 +269,19 @@ extern "C" int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v,
   G.ldq = ldq; G.ldk = ldk; G.ldv = ldv; G.ldo = ldo;
   G.HW = H * W; G.tiles = (G.HW + 15) / 16; G.qgroups = 0;
   G.scale = 1.0f / sqrtf((float)dh);
+  static const int dbg_env = getenv("WMZ_ATTN_DBG") ? atoi(getenv("WMZ_ATTN_DBG")) : 0;
+  G.dbg = dbg_env;
   hipStream_t st = (hipStream_t)stream;
+  static const bool no_fast = getenv("WMZ_ATTN_GENERAL") != nullptr;   // force the general kernel (A/B timing, tests)
+  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && logits_dbg == nullptr && !no_fast)
+    return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, G, st);
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {
-    if (DHp == 32) return launch<bf16_t, 32, 2, 8>(q, k, v, out, lse, logits_dbg, G, st);
-    if (DHp == 64) return launch<bf16_t, 64, 2, 8>(q, k, v, out, lse, logits_dbg, G, st);
-    return launch<bf16_t, 128, 2, 8>(q, k, v, out, lse, logits_dbg, G, st);
+    if (DHp == 32) return launch<bf16_t, 32, 1, 8, 16>(q, k, v, out, lse, logits_dbg, G, st);
+    if (DHp == 64) return launch<bf16_t, 64, 1, 8, 16>(q, k, v, out, lse, logits_dbg, G, st);
+    return launch<bf16_t, 128, 1, 8, 16>(q, k, v, out, lse, logits_dbg, G, st);
   }
-  if (DHp == 32) return launch<float, 32, 1, 8>(q, k, v, out, lse, logits_dbg, G, st);
-  if (DHp == 64) return launch<float, 64, 1, 8>(q, k, v, out, lse, logits_dbg, G, st);
-  return launch<float, 128, 1, 4>(q, k, v, out, lse, logits_dbg, G, st);
+  if (DHp == 32) return launch<float, 32, 1, 8, 8>(q, k, v, out, lse, logits_dbg, G, st);
+  if (DHp == 64) return launch<float, 64, 1, 8, 8>(q, k, v, out, lse, logits_dbg, G, st);
+  return launch<float, 128, 1, 4, 8>(q, k, v, out, lse, logits_dbg, G, st);
 }
