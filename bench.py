@@ -153,34 +153,78 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(y).all()
 
-    # Dominant kernel (local-3D-attention forward): per-launch duration with HIP events on the launch stream
-    # (torch's current stream).  Launches are enqueued back to back behind a primer so the host stays ahead of
-    # the GPU and the events bracket kernel time only (inside a captured graph single nodes cannot be timed).
-    N = cfg['B'] * cfg['S'] * cfg['H'] * cfg['W']
+    # Per-launch durations of the two kernels that carry the step (the fused per-token layer kernel and the local-3D
+    # attention forward), measured live with HIP events on the launch stream (torch's current stream);
+    # rocprofv3's averages for the same kernels are in profiles/.
+    from world_modelz_amd import fused
     I = cfg['dim_head'] * cfg['heads']
+    D = cfg['dim']
     qkv = torch.randn(cfg['B'], cfg['S'], cfg['H'], cfg['W'], 3 * I, device=dev).to(dtype)
     qa, ka, va = qkv[..., :I], qkv[..., I:2 * I], qkv[..., 2 * I:]
-    reps = max(10, min(4 * a.steps, 200))
-    for _ in range(5):
+    xa = torch.randn(cfg['B'], cfg['S'], cfg['H'], cfg['W'], D, device=dev).to(dtype)
+    oa = torch.randn(cfg['B'], cfg['S'], cfg['H'], cfg['W'], I, device=dev).to(dtype)
+    layers = list(model.transformer.layers)
+    use_fused = dtype == torch.bfloat16 and fused.supported(model.transformer, dtype)
+
+    def run_attn():
         ops.local3d_attention_fwd(qa, ka, va, cfg['extents'], cfg['heads'])
-    torch.cuda.synchronize()
-    ev = []
-    for _ in range(3):                                   # primer: keeps the queue non-empty
-        ops.local3d_attention_fwd(qa, ka, va, cfg['extents'], cfg['heads'])
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ops.local3d_attention_fwd(qa, ka, va, cfg['extents'], cfg['heads'])
-        e1.record()
-        ev.append((e0, e1))
-    torch.cuda.synchronize()
+
+    def run_fused():
+        fused.layer_fused(oa, xa, layers[0], layers[1])
+
+    def time_kernel(fn, reps):
+        """Average duration of `reps` back-to-back launches: the launches are captured into one hipGraph (so no host
+        gap can sit between them) and the replay is bracketed by one HIP-event pair on the launch stream."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / reps)
+        return sorted(times)[1]
+
+    reps = 50
+    with torch.no_grad():
+        attn_ms = time_kernel(run_attn, reps)
+        fused_ms = time_kernel(run_fused, reps) if use_fused else None
 
     frames = cfg['B'] * cfg['S'] * world * a.steps
     ms_per_step = elapsed / a.steps * 1e3
     elt = 2 if dtype == torch.bfloat16 else 4
     step_bytes, attn_bytes = algorithmic_bytes(cfg, elt)
-    attn_ms = sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev))
-    attn_gbs = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
+    N = cfg['B'] * cfg['S'] * cfg['H'] * cfg['W']
+    attn_gbs = attn_bytes / (attn_ms * 1e-3) / 1e9
+    attn_roof = {'bound': 'hbm', 'kernel': 'attn_fwd_row16_kernel (local 3D attention forward)', 'achieved': attn_gbs,
+                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': attn_gbs / HBM_PEAK_GBS, 'traffic': None,
+                 'algorithmic_bytes_per_launch': attn_bytes, 'avg_launch_ms': attn_ms, 'launches_per_step': cfg['depth'],
+                 'launches_timed': reps}
+    if fused_ms is not None:
+        # per launch: read o [N,I] + x [N,D], write x [N,D] + q [N,I] + k|v [N,2I]  (SURVEY 8d stages K3+K4+K1 of two layers)
+        fused_bytes = N * (2 * D + 4 * I) * elt
+        fused_gbs = fused_bytes / (fused_ms * 1e-3) / 1e9
+        fused_roof = {'bound': 'hbm', 'kernel': 'layer_fused_kernel<head,tail> (to_out+res -> LN -> FF -> res -> next q|k|v)',
+                      'achieved': fused_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': fused_gbs / HBM_PEAK_GBS,
+                      'traffic': None, 'algorithmic_bytes_per_launch': fused_bytes, 'avg_launch_ms': fused_ms,
+                      'launches_per_step': cfg['depth'] - 1, 'launches_timed': reps}
+    else:
+        fused_roof = None
+    # `roofline` = the kernel with the larger share of the step
+    dominant_fused = fused_roof is not None and fused_ms * (cfg['depth'] - 1) > attn_ms * cfg['depth']
     out = {
         'metric': 'denoise-step latent-frames/sec (forward, 32x16x16 latent clips)',
         'value': frames / elapsed, 'unit': 'latent-frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -191,10 +235,8 @@ def main():
                                'depth 4, mlp 256',
                    'clips_per_gpu': cfg['B'], 'latent_shape': [cfg['S'], cfg['H'], cfg['W']], 'codebook': cfg['C'],
                    'parallelism': f'clips sharded over {world} rank(s), no data-path collective'},
-        'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_kernel (local 3D attention forward)',
-                     'achieved': attn_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': attn_gbs / HBM_PEAK_GBS,
-                     'traffic': None, 'algorithmic_bytes_per_launch': attn_bytes, 'avg_launch_ms': attn_ms,
-                     'launches_timed': len(ev)},
+        'roofline': fused_roof if dominant_fused else attn_roof,
+        'roofline_other': attn_roof if dominant_fused else fused_roof,
         'launch_mode': 'eager' if a.eager else 'hipGraph replay (1 graph = 1 forward step)',
         'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
                           'achieved_GBs': step_bytes / (ms_per_step * 1e-3) / 1e9,

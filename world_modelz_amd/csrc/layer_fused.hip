@@ -14,8 +14,8 @@
 // block, so activations are exchanged through a per-wave 8 KB LDS buffer with 8-byte accesses (no workgroup barrier),
 // and every HBM store is a whole row.
 // The layer's 512 KB of weights are pre-packed on the host in exactly the order the kernel consumes them (16 KB slabs of
-// [32-deep k-step][feature][32 k], 16-byte chunks swizzled against bank conflicts) and streamed by LDS-DMA (global_load_lds) into a 5-slot
-// LDS ring with 4 slabs in flight: counted vmcnt + ONE raw s_barrier per slab (= 16 MFMAs per wave).  The feed-forward is
+// [32-deep k-step][feature][32 k], 16-byte chunks swizzled against bank conflicts) and streamed by LDS-DMA (global_load_lds) into a 4-slot
+// LDS ring with 3 slabs in flight: counted vmcnt + ONE raw s_barrier per slab (= 16 MFMAs per wave).  The feed-forward is
 // walked 64 hidden units at a time (W1 rows -> GELU -> W2 columns), so its activation never exists in full.
 #include "wmz_common.h"
 #include <stdlib.h>
@@ -26,7 +26,8 @@ constexpr int FT = 16;          // tokens per wave
 constexpr int FW = 8;           // waves per workgroup (two per SIMD: one's epilogue overlaps the other's MFMAs)
 constexpr int NTHR = FW * 64;
 constexpr int SLAB = 16384;     // bytes per weight slab
-constexpr int RING = 5;         // LDS ring slots: 4 slabs (64 KB) of the weight stream stay in flight
+constexpr int RING = 4;         // LDS ring slots: 3 slabs (48 KB) of the weight stream stay in flight
+constexpr int VECB = 8192;      // the layer's bias / LayerNorm vectors (2048 fp32), staged once per workgroup
 constexpr int ACTB = 8192;      // per-wave activation buffer (16 tokens x 256 features bf16)
 constexpr int ZCB = 2048;       // per-wave feed-forward chunk buffer (16 tokens x 64 features bf16)
 constexpr int MC = 64;          // feed-forward hidden chunk: W1 rows / W2 columns streamed MC at a time
@@ -85,8 +86,8 @@ __device__ __forceinline__ void ws_issue(WStream& ws) {
 // Before multiplying a slab: this wave's eighth of it has landed (all but the 2*(RING-2) youngest VMEM ops done), then
 // one barrier: every piece landed, and every wave is done with the previous slab, whose slot is refilled right away.
 __device__ __forceinline__ void ws_acquire(WStream& ws) {
-  if (!(ws.dbg & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  static_assert(2 * (RING - 2) == 6, "vmcnt literal above follows RING (2 LDS-DMA pieces per wave per slab)");
+  if (!(ws.dbg & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  static_assert(2 * (RING - 2) == 4, "vmcnt literal above follows RING (2 LDS-DMA pieces per wave per slab)");
   __builtin_amdgcn_s_barrier();
   ws_issue(ws);
 }
@@ -274,16 +275,21 @@ __global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
   const int li = lane & 15, g = lane >> 4;
   char* actA = smem + wave * ACTB;
   char* zc = smem + FW * ACTB + wave * ZCB;
-  const char* ring0 = smem + FW * (ACTB + ZCB);
+  float* vecs = reinterpret_cast<float*>(smem + FW * (ACTB + ZCB));
+  const char* ring0 = smem + FW * (ACTB + ZCB) + VECB;
   WStream ws;
-  ws.ring = smem + FW * (ACTB + ZCB) + wave * 2048;
+  ws.ring = smem + FW * (ACTB + ZCB) + VECB + wave * 2048;
   ws.src = P.wpack + wave * 2048 + lane * 16;
   ws.issue_slot = 0;
   ws.cur = 0;
   ws.dbg = P.dbg;
   const long tok0 = (long)blockIdx.x * (FT * FW) + wave * FT;
   const bool tok_ok = tok0 + li < P.ntok;
-  const float* v_bout = P.vec;
+  // per-feature vectors: one coalesced copy into LDS (reading them from L2 inside the epilogues exposed ~150 dependent
+  // load latencies per wave)
+  *reinterpret_cast<f32x4*>(vecs + tid * 4) = *reinterpret_cast<const f32x4*>(P.vec + tid * 4);
+  static_assert(NTHR * 4 == 7 * 256 + 256, "vector block is 2048 floats");
+  const float* v_bout = vecs;
   const float* v_g2 = v_bout + D;
   const float* v_be2 = v_g2 + D;
   const float* v_b1 = v_be2 + D;
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
   const float* v_be1n = v_g1n + D;
   const float* v_bkv = v_be1n + D;
 
+  __syncthreads();                                   // vectors visible
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) ws_issue(ws);   // prime: RING-1 slabs in flight
 
@@ -363,7 +370,7 @@ extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, vo
   P.wpack = (const char*)wpack; P.vec = vec; P.ntok = ntok; P.eps = eps;
   static const int dbg_env = getenv("WMZ_FUSED_DBG") ? atoi(getenv("WMZ_FUSED_DBG")) : 0;
   P.dbg = dbg_env;
-  const size_t smem = FW * (ACTB + ZCB) + RING * SLAB;
+  const size_t smem = FW * (ACTB + ZCB) + VECB + RING * SLAB;
   dim3 grid((unsigned)wmz_cdiv(ntok, FT * FW)), block(NTHR);
   hipStream_t st = (hipStream_t)stream;
 #define WMZ_FUSED(H, T)                                                                                            \

@@ -6,7 +6,7 @@ from . import _cast, ops
 from . import _lib as L
 
 D_, I_, M_ = 256, 128, 256
-_PAD = 4 * 16384        # RING-1 slabs the kernel's LDS-DMA prefetch runs past the last real slab
+_PAD = 4 * 16384        # >= RING-1 slabs the kernel's LDS-DMA prefetch runs past the last real slab
 MC_ = 64
 
 
