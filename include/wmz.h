@@ -91,6 +91,15 @@ int wmz_embed_pos3d_fwd(const int64_t* z, const float* emb, const float* pos_s, 
 int wmz_embed_pos3d_bwd(const int64_t* z, const void* dx, float* demb, float* dpos_s, float* dpos_h, float* dpos_w,
                         int B, int S, int H, int W, int D, int num_classes, int dtype, void* stream);
 
+/* config 5, VqSparseDiffusionModel (minecraft/sparse_diffusion.py:91-111): ntok tokens at arbitrary flat grid positions:
+ * x[t,:] = emb[tok[t]] + ((pos_s[p/(H*W)] + pos_h[(p/W)%H]) + pos_w[p%W]), p = pos[t]; and its backward (atomics, fp32). */
+int wmz_embed_indexed_fwd(const int64_t* tok, const int64_t* pos, const float* emb, const float* pos_s,
+                          const float* pos_h, const float* pos_w, void* x, long ntok, int S, int H, int W, int D,
+                          int num_classes, int dtype, void* stream);
+int wmz_embed_indexed_bwd(const int64_t* tok, const int64_t* pos, const void* dx, float* demb, float* dpos_s,
+                          float* dpos_h, float* dpos_w, long ntok, int S, int H, int W, int D, int num_classes, int dtype,
+                          void* stream);
+
 /* ---- VectorQuantizerEMA (vq.py) ----
  * wmz_vq_argmin: encode / codebook_distance+argmin (vq.py:77-87, :30-33).  x [N,E] fp32 (row stride ldx),
  * codebook [C,E] fp32.  dist = sum_e (x-e)^2 evaluated in the exact fp32 order ATen uses on x86

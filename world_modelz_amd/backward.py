@@ -113,3 +113,41 @@ def linear_backward(ctx, dy):
     ops.linear_wgrad(dyc, xc, dw, db)
     dx = ops.linear_dgrad(dyc, _wt(w, dt, 'wT'))
     return dx.reshape(x.shape), dw, db, None
+
+
+def dense_attention_block_backward(ctx, dy):
+    from .functional import _dense_grid
+    x, ln_g, ln_b, wqkv, wout, bout, qkv, o, lse = ctx.saved_tensors
+    dt = x.dtype
+    B, n, _ = x.shape
+    I = wqkv.shape[0] // 3
+    dy = dy.contiguous()
+    d_res = dy if ctx.has_res else None
+    dwout = dbout = None
+    if wout is not None:
+        do = ops.linear_dgrad(dy, _wt(wout, dt, 'woutT'))
+        dwout = torch.zeros_like(wout, dtype=torch.float32)
+        dbout = torch.zeros_like(bout, dtype=torch.float32)
+        ops.linear_wgrad(dy, o, dwout, dbout)
+    else:
+        do = dy
+    (S, H, W), ext = _dense_grid(n)
+    g = qkv.view(B, S, H, W, 3 * I)
+    dqkv = torch.empty_like(qkv)
+    ops.local3d_attention_bwd(g[..., :I], g[..., I:2 * I], g[..., 2 * I:], o.view(B, S, H, W, I), lse,
+                              do.view(B, S, H, W, I), ext, ctx.heads, dqkv=dqkv.view(B, S, H, W, 3 * I))
+    dwqkv = torch.zeros_like(wqkv, dtype=torch.float32)
+    dxhat = ops.linear_dgrad(dqkv, _wt(wqkv, dt, 'wqkvT'))
+    dg = db = None
+    fold = ctx.has_res and ctx.res_is_x
+    if ln_g is not None:
+        stats = ops.layernorm_stats(x, LN_EPS)
+        ops.linear_wgrad(dqkv, x, dwqkv, None, ln=(ln_g.detach(), ln_b.detach()), ln_stats=stats)
+        dg = torch.zeros_like(ln_g, dtype=torch.float32)
+        db = torch.zeros_like(ln_b, dtype=torch.float32)
+        dx = ops.layernorm_bwd(x, dxhat, ln_g.detach(), dg, db, skip=d_res if fold else None, eps=LN_EPS)
+    else:
+        ops.linear_wgrad(dqkv, x, dwqkv, None)
+        dx = dxhat + d_res if fold else dxhat
+    g_res = None if (not ctx.has_res or fold) else d_res
+    return dx.reshape(x.shape), dg, db, dwqkv, dwout, dbout, g_res, None, None

@@ -87,7 +87,98 @@ __global__ __launch_bounds__(256) void embed_pos3d_bwd_kernel(const int64_t* __r
   }
 }
 
+// config 5 (minecraft/sparse_diffusion.py:91-111): tokens at ARBITRARY flat grid positions `pos` (one per token):
+// x[t,:] = emb[tok[t]] + ((pos_s[p / (H*W)] + pos_h[(p / W) % H]) + pos_w[p % W])
+template <typename T>
+__global__ __launch_bounds__(256) void embed_indexed_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ pos,
+                                                            const float* __restrict__ emb, const float* __restrict__ ps,
+                                                            const float* __restrict__ ph, const float* __restrict__ pw,
+                                                            T* __restrict__ x, long ntok, int S, int H, int W, int D,
+                                                            int num_classes) {
+  const int d4 = D >> 2;
+  const long total = ntok * d4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i / d4;
+    const int c = (int)(i - t * d4) * 4;
+    long p = pos[t];
+    p = p < 0 ? 0 : (p >= (long)S * H * W ? (long)S * H * W - 1 : p);
+    const int w = (int)(p % W), h = (int)((p / W) % H), s = (int)(p / ((long)W * H));
+    long tk = tok[t];
+    tk = tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : tk);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(emb + tk * D + c);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ps + (long)s * D + c);
+    const f32x4 bq = *reinterpret_cast<const f32x4*>(ph + (long)h * D + c);
+    const f32x4 cw = *reinterpret_cast<const f32x4*>(pw + (long)w * D + c);
+    const f32x4 v = e + ((a + bq) + cw);
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<f32x4*>(x + t * D + c) = v;
+    } else {
+      s16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (short)f32_to_bf16_bits(v[k]);
+      *reinterpret_cast<s16x4*>(x + t * D + c) = o;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_indexed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ pos,
+                                                                const T* __restrict__ dx, float* __restrict__ demb,
+                                                                float* __restrict__ dps, float* __restrict__ dph,
+                                                                float* __restrict__ dpw, long ntok, int S, int H, int W,
+                                                                int D, int num_classes) {
+  const long total = ntok * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i / D;
+    const int d = (int)(i - t * D);
+    long p = pos[t];
+    p = p < 0 ? 0 : (p >= (long)S * H * W ? (long)S * H * W - 1 : p);
+    const int w = (int)(p % W), h = (int)((p / W) % H), s = (int)(p / ((long)W * H));
+    long tk = tok[t];
+    tk = tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : tk);
+    const float v = Elem<T>::to_f32(dx[i]);
+    atomicAdd(demb + tk * D + d, v);
+    atomicAdd(dps + (long)s * D + d, v);
+    atomicAdd(dph + (long)h * D + d, v);
+    atomicAdd(dpw + (long)w * D + d, v);
+  }
+}
+
 }  // namespace
+
+extern "C" int wmz_embed_indexed_fwd(const int64_t* tok, const int64_t* pos, const float* emb, const float* pos_s,
+                                     const float* pos_h, const float* pos_w, void* x, long ntok, int S, int H, int W,
+                                     int D, int num_classes, int dtype, void* stream) {
+  WMZ_REQUIRE(tok && pos && emb && pos_s && pos_h && pos_w && x, "wmz_embed_indexed_fwd: null tensor");
+  WMZ_REQUIRE(ntok > 0 && S > 0 && H > 0 && W > 0 && D > 0 && D % 4 == 0 && num_classes > 0, "wmz_embed_indexed_fwd: bad shape");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_embed_indexed_fwd: bad dtype %d", dtype);
+  const long total = ntok * (D / 4);
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16)
+    hipLaunchKernelGGL(embed_indexed_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, tok, pos, emb, pos_s, pos_h, pos_w, (bf16_t*)x, ntok, S, H, W, D, num_classes);
+  else
+    hipLaunchKernelGGL(embed_indexed_kernel<float>, dim3(grid), dim3(256), 0, st, tok, pos, emb, pos_s, pos_h, pos_w, (float*)x, ntok, S, H, W, D, num_classes);
+  WMZ_LAUNCH_CHECK("wmz_embed_indexed_fwd");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_embed_indexed_bwd(const int64_t* tok, const int64_t* pos, const void* dx, float* demb, float* dpos_s,
+                                     float* dpos_h, float* dpos_w, long ntok, int S, int H, int W, int D, int num_classes,
+                                     int dtype, void* stream) {
+  WMZ_REQUIRE(tok && pos && dx && demb && dpos_s && dpos_h && dpos_w, "wmz_embed_indexed_bwd: null tensor");
+  WMZ_REQUIRE(ntok > 0 && S > 0 && H > 0 && W > 0 && D > 0 && num_classes > 0, "wmz_embed_indexed_bwd: bad shape");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_embed_indexed_bwd: bad dtype %d", dtype);
+  const long total = ntok * D;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16)
+    hipLaunchKernelGGL(embed_indexed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, tok, pos, (const bf16_t*)dx, demb, dpos_s, dpos_h, dpos_w, ntok, S, H, W, D, num_classes);
+  else
+    hipLaunchKernelGGL(embed_indexed_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, tok, pos, (const float*)dx, demb, dpos_s, dpos_h, dpos_w, ntok, S, H, W, D, num_classes);
+  WMZ_LAUNCH_CHECK("wmz_embed_indexed_bwd");
+  return WMZ_OK;
+}
 
 extern "C" int wmz_embed_pos3d_bwd(const int64_t* z, const void* dx, float* demb, float* dpos_s, float* dpos_h,
                                    float* dpos_w, int B, int S, int H, int W, int D, int num_classes, int dtype,

@@ -126,3 +126,69 @@ def embed_tokens(z, emb, pos_s, pos_h, pos_w):
 
 def linear(x, w, b=None, out_f32=False):
     return _Linear.apply(x, w, b, out_f32)
+
+
+# ------------------------------------------------------------------------------------------------ config 5 (dense ViT)
+
+def _dense_grid(n):
+    """A length-n sequence as a token grid whose window covers everything: dense attention IS local attention with
+    unbounded extents, so the same kernels serve it (16-wide planes take the fast path)."""
+    if n % 16 == 0:
+        return (1, n // 16, 16), (0, n // 16, 16)
+    return (1, 1, n), (0, 0, n)
+
+
+class _DenseAttentionBlock(torch.autograd.Function):
+    """to_out(softmax(q k^T * scale) v) + residual with q|k|v = to_qkv(LN(x)) (no bias): PreNorm(Attention) of
+    minecraft/transformer.py:11-63 plus the `+ x` of :77."""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, wqkv, wout, bout, residual, heads, grad_on):
+        dt = x.dtype
+        B, n, _ = x.shape
+        I = wqkv.shape[0] // 3
+        ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
+        qkv = ops.linear_fwd(x, _cast.operand(wqkv, dt), ln=ln, ln_eps=LN_EPS)                    # [B, n, 3I]
+        (S, H, W), ext = _dense_grid(n)
+        g = qkv.view(B, S, H, W, 3 * I)
+        need_bwd = grad_on and any(ctx.needs_input_grad)
+        o, lse, _ = ops.local3d_attention_fwd(g[..., :I], g[..., I:2 * I], g[..., 2 * I:], ext, heads, need_lse=need_bwd)
+        o = o.view(B, n, I)
+        if wout is not None:
+            y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual)
+        else:
+            y = o if residual is None else o + residual
+        if need_bwd:
+            ctx.save_for_backward(x, ln_g, ln_b, wqkv, wout, bout, qkv, o, lse)
+            ctx.heads, ctx.has_res = heads, residual is not None
+            ctx.res_is_x = residual is not None and residual.data_ptr() == x.data_ptr() and residual.shape == x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import backward as Bk
+        return Bk.dense_attention_block_backward(ctx, dy)
+
+
+class _EmbedIndexed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, pos, emb, pos_s, pos_h, pos_w, shape, dtype):
+        x = ops.embed_indexed_fwd(tok, pos, emb.detach(), pos_s.detach(), pos_h.detach(), pos_w.detach(), shape, dtype)
+        ctx.save_for_backward(tok, pos)
+        ctx.shape3, ctx.shapes = shape, (emb.shape, pos_s.shape, pos_h.shape, pos_w.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        tok, pos = ctx.saved_tensors
+        demb, dps, dph, dpw = ops.embed_indexed_bwd(tok, pos, dx, ctx.shape3, ctx.shapes)
+        return None, None, demb, dps, dph, dpw, None, None
+
+
+def dense_attention_block(x, ln, wqkv, wout, bout, residual, heads):
+    g, b = (None, None) if ln is None else ln
+    return _DenseAttentionBlock.apply(x, g, b, wqkv, wout, bout, residual, int(heads), torch.is_grad_enabled())
+
+
+def embed_tokens_indexed(tok, pos, emb, pos_s, pos_h, pos_w, shape):
+    return _EmbedIndexed.apply(tok, pos, emb, pos_s, pos_h, pos_w, tuple(int(s) for s in shape), get_compute_dtype())

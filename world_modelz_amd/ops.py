@@ -129,8 +129,9 @@ def vq_ema_update(embedding, cluster_size, activation_count, counts, dw, decay, 
 
 # ------------------------------------------------------------------------------------------------ backward
 
-def local3d_attention_bwd(q, k, v, out, lse, dout, extents, heads):
-    """Returns (dq, dkv) with dkv = [..., 2I] holding dk | dv (the layout the fused k|v projection wants)."""
+def local3d_attention_bwd(q, k, v, out, lse, dout, extents, heads, dqkv=None):
+    """Returns (dq, dkv) with dkv = [..., 2I] holding dk | dv (the layout the fused k|v projection wants).
+    dqkv (optional, [..., 3I]): write dq | dk | dv into its column thirds instead (fused to_qkv of config 5)."""
     B, S, H, W, I = q.shape
     dh = I // heads
     dt = L.dtype_code(q.dtype)
@@ -139,13 +140,20 @@ def local3d_attention_bwd(q, k, v, out, lse, dout, extents, heads):
     v, _, ldv = _rows(v)
     out, _, ldo = _rows(out)
     dout, _, lddo = _rows(dout)
-    dq = torch.empty((B, S, H, W, I), dtype=q.dtype, device=q.device)
-    dkv = torch.empty((B, S, H, W, 2 * I), dtype=q.dtype, device=q.device)
     delta = torch.empty((B * S * H * W, heads), dtype=torch.float32, device=q.device)
-    dk, dv = dkv[..., :I], dkv[..., I:]
+    if dqkv is None:
+        dq = torch.empty((B, S, H, W, I), dtype=q.dtype, device=q.device)
+        dkv = torch.empty((B, S, H, W, 2 * I), dtype=q.dtype, device=q.device)
+        dk, dv = dkv[..., :I], dkv[..., I:]
+        lddq, lddkv = I, 2 * I
+    else:
+        assert dqkv.is_contiguous() and dqkv.shape[-1] == 3 * I and dqkv.dtype == q.dtype
+        dq, dk, dv = dqkv[..., :I], dqkv[..., I:2 * I], dqkv[..., 2 * I:]
+        dkv = dqkv[..., I:]
+        lddq = lddkv = 3 * I
     L.call('wmz_local3d_attn_bwd', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dout), L.ptr(dq),
            L.ptr(dk), L.ptr(dv), L.ptr(delta), B, S, H, W, heads, dh, int(extents[0]), int(extents[1]),
-           int(extents[2]), ldq, ldk, ldv, ldo, lddo, I, 2 * I, 2 * I, dt, L.stream())
+           int(extents[2]), ldq, ldk, ldv, ldo, lddo, lddq, lddkv, lddkv, dt, L.stream())
     return dq, dkv
 
 
@@ -274,3 +282,25 @@ def bilinear2x_nhwc(x):
     y = torch.empty((B, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
     L.call('wmz_bilinear2x_nhwc', L.ptr(x), L.ptr(y), B, H, W, C, L.dtype_code(x.dtype), L.stream())
     return y
+
+
+def embed_indexed_fwd(tok, pos, emb, pos_s, pos_h, pos_w, shape, dtype):
+    """tok, pos: int64 [..]; tables fp32 -> x [.., D]."""
+    S, H, W = shape
+    D = emb.shape[1]
+    tok, pos = tok.contiguous(), pos.contiguous()
+    x = torch.empty(tok.shape + (D,), dtype=dtype, device=tok.device)
+    L.call('wmz_embed_indexed_fwd', L.ptr(tok), L.ptr(pos), L.ptr(emb), L.ptr(pos_s), L.ptr(pos_h), L.ptr(pos_w),
+           L.ptr(x), tok.numel(), S, H, W, D, emb.shape[0], L.dtype_code(dtype), L.stream())
+    return x
+
+
+def embed_indexed_bwd(tok, pos, dx, shape, table_shapes):
+    S, H, W = shape
+    dx = dx.contiguous()
+    D = dx.shape[-1]
+    tabs = [torch.zeros(s, dtype=torch.float32, device=dx.device) for s in table_shapes]
+    L.call('wmz_embed_indexed_bwd', L.ptr(tok.contiguous()), L.ptr(pos.contiguous()), L.ptr(dx), L.ptr(tabs[0]),
+           L.ptr(tabs[1]), L.ptr(tabs[2]), L.ptr(tabs[3]), tok.numel(), S, H, W, D, table_shapes[0][0],
+           L.dtype_code(dx.dtype), L.stream())
+    return tabs

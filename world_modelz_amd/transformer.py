@@ -1,0 +1,59 @@
+"""MI355X drop-in for minecraft/transformer.py (lucidrains ViT blocks used by config 5): PreNorm :11-17,
+FeedForward :19-31, Attention :33-63, Transformer :66-80.  Same constructors and state_dict keys.
+
+Dense softmax attention over n tokens is local 3D attention whose window covers the whole grid, so it runs on the
+same HIP attention kernels (n % 16 == 0 takes the 16-wide-plane fast path); the fused to_qkv GEMM carries the PreNorm
+LayerNorm in its prologue and to_out carries the residual add in its epilogue.
+"""
+import torch
+from torch import nn
+
+from . import functional as Fw
+from .local_3d_attention import FeedForward, PreNorm  # same modules as the local-attention stack  # noqa: F401
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.attend = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        if heads == 1 and dim_head == dim:
+            self.to_out = nn.Identity()
+        else:
+            self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
+        self.p_drop = dropout
+
+    def _run(self, x, ln, residual):
+        if self.p_drop > 0 and self.training:
+            raise NotImplementedError('dropout > 0 in training is not built into the fused HIP attention block')
+        x = Fw._as_compute(x)
+        wo, bo = (None, None) if isinstance(self.to_out, nn.Identity) else (self.to_out[0].weight, self.to_out[0].bias)
+        return Fw.dense_attention_block(x, ln, self.to_qkv.weight, wo, bo, residual, self.heads)
+
+    def forward(self, x):
+        return self._run(x, None, None)
+
+    def forward_prenorm(self, x, norm, residual=None):
+        return self._run(x, (norm.weight, norm.bias), residual)
+
+
+class Transformer(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout)),
+            ]))
+
+    def forward(self, x):
+        x = Fw._as_compute(x)
+        for attn, ff in self.layers:
+            x = attn.fn.forward_prenorm(x, attn.norm, residual=x)     # attn(x) + x
+            x = ff.fn.forward_prenorm(x, ff.norm, residual=x)         # ff(x) + x
+        return x
