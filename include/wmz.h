@@ -149,12 +149,26 @@ int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, 
  * `momentum` and the unbiased variance; training == 0: running stats.  Emits scale = gamma*rstd, shift = beta - mean*scale. */
 int wmz_bn_finalize(const float* sum, const float* sq, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, double momentum, double eps, int training, float* scale,
-                    float* shift, int C, void* stream);
+                    float* shift, float* mean_out, float* rstd_out, int C, void* stream);
 /* y = act(a*sa + ta (+ b*sb + tb)) per channel on NHWC [M, C] (BatchNorm apply, skip add, LeakyReLU). */
 int wmz_affine_act_nhwc(const void* a, const float* sa, const float* ta, const void* b, const float* sb, const float* tb,
                         void* y, long M, int C, int leaky, float slope, int dtype, void* stream);
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (autoencoder.py:138) on NHWC. */
 int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+
+/* ---- backward of the conv path (VQ-AE training, train_vqae.py:125-192; the reference gets these from autograd) ----
+ * data gradient: wmz_conv2d_nhwc_fwd on the (zero-dilated for stride 2) output gradient with flipped, transposed weights.
+ * weight gradient: dW[Cout, KH*KW*Cin] += dy^T . im2col(x) (implicit), dbias[Cout] += colsum(dy); fp32, accumulated. */
+int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad, int dtype, void* stream);
+/* training-mode BatchNorm + LeakyReLU backward, pass 1: g = dy * act'(y) (optional g_out), sum_g[C] += g,
+ * sum_gx[C] += g * (x - mean) * rstd;  pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)  (dgamma = sum_gx, dbeta = sum_g). */
+int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, void* g_out,
+                          float* sum_g, float* sum_gx, long M, int C, int leaky, float slope, int dtype, void* stream);
+int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean, const float* rstd, const float* gamma,
+                     const float* sum_g, const float* sum_gx, void* dx, long M, int C, int dtype, void* stream);
+/* adjoint of wmz_bilinear2x_nhwc (gather form, deterministic): dy [B,2H,2W,C] -> dx [B,H,W,C]. */
+int wmz_bilinear2x_nhwc_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 
 /* ---- training-step tail over flat fp32 arenas (one launch each) ----
  * grad_norm (main.py:188-193): out[0] += scale^2 * sum g^2 (caller zeroes out[0]; no host sync). */

@@ -7,7 +7,10 @@ forward passes run NHWC implicit-GEMM convolutions on MFMA with BatchNorm / Leak
 epilogues (eval mode) or applied by one elementwise kernel after the batch statistics are known (training mode,
 which is what the frozen AE runs in inside main.py -- quirk Q3: running statistics are updated even under no_grad).
 Tensors cross the module boundary as logical NCHW in channels_last memory format: no layout copies inside.
-Forward only this round: the conv backward (VQ-AE training) is not built yet and raises.
+With gradients enabled (VQ-AE training, train_vqae.py:125-192) the blocks run op by op through autograd Functions over
+the HIP kernels: data gradient = the same implicit-GEMM conv on the (zero-dilated for stride 2) output gradient with
+flipped, transposed weights; weight gradient = split-M MFMA GEMM with an implicit-im2col operand; training-mode
+BatchNorm + LeakyReLU backward in two passes; bilinear x2 adjoint in gather form.
 """
 import functools
 
@@ -62,10 +65,109 @@ def _to_nchw_view(y):
     return y.permute(0, 3, 1, 2)
 
 
-def _check_no_grad(*mods):
-    if torch.is_grad_enabled() and any(p.requires_grad for m in mods for p in m.parameters()):
-        raise NotImplementedError('conv encoder/decoder backward is not built yet on the HIP path: run the '
-                                  'auto-encoder under torch.no_grad() (the denoiser trains against a frozen AE)')
+def _grad_path(*mods):
+    """True when this forward must be differentiable (training through the HIP autograd Functions)."""
+    if not torch.is_grad_enabled() or not any(p.requires_grad for m in mods for p in m.parameters()):
+        return False
+    for m in mods:
+        for sub in m.modules():
+            if isinstance(sub, nn.BatchNorm2d) and not sub.training:
+                raise NotImplementedError('backward through eval-mode BatchNorm is not built on the HIP path '
+                                          '(train the VQ-AE in .train() mode, run the frozen AE under no_grad)')
+    return True
+
+
+def _wT_op(weight, dtype):
+    """Operand of the data-gradient conv: w'[ci, kh', kw', co] = w[co, ci, K-1-kh', K-1-kw'] as [Ci8, K*K*Co8]."""
+    def build(w):
+        co, ci, kh, kw = w.shape
+        wt = w.flip(2, 3).permute(1, 2, 3, 0)                     # [ci, kh', kw', co]
+        wt = F.pad(wt, (0, _pad8(co) - co, 0, 0, 0, 0, 0, _pad8(ci) - ci))
+        return wt.reshape(_pad8(ci), -1)
+    return _cast.operand((weight,), dtype, 'convT', build)
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        k = weight.shape[2]
+        dt = x.dtype
+
+        def build(w):
+            co, ci, kh, kw = w.shape
+            w = w.permute(0, 2, 3, 1)
+            if _pad8(ci) != ci:
+                w = F.pad(w, (0, _pad8(ci) - ci))
+            return w.reshape(co, -1)
+        y = ops.conv2d_nhwc(x, _cast.operand((weight,), dt, 'conv', build), k, k, stride, pad,
+                            bias=None if bias is None else bias.detach())
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (k, stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        k, stride, pad, has_bias = ctx.geom
+        co, ci = weight.shape[:2]
+        cop, cip = _pad8(co), x.shape[-1]
+        dy = dy.contiguous()
+        if cop != co:
+            dy = F.pad(dy, (0, cop - co))
+        dwf, dbf = ops.conv2d_nhwc_wgrad(x, dy, k, k, stride, pad, has_bias)
+        dw = dwf.view(cop, k, k, cip)[:co, :, :, :ci].permute(0, 3, 1, 2).contiguous()
+        db = dbf[:co].contiguous() if has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            B, Hi, Wi, _ = x.shape
+            Ho, Wo = dy.shape[1:3]
+            if stride == 1:
+                dz = dy
+            else:
+                op_h = Hi - ((Ho - 1) * stride - 2 * pad + k)
+                op_w = Wi - ((Wo - 1) * stride - 2 * pad + k)
+                dz = torch.zeros((B, (Ho - 1) * stride + 1 + op_h, (Wo - 1) * stride + 1 + op_w, cop), dtype=dy.dtype,
+                                 device=dy.device)
+                dz[:, 0:(Ho - 1) * stride + 1:stride, 0:(Wo - 1) * stride + 1:stride] = dy
+            dx = ops.conv2d_nhwc(dz, _wT_op(weight, dy.dtype), k, k, 1, k - 1 - pad)
+        return dx, dw, db, None, None
+
+
+class _BnActFn(torch.autograd.Function):
+    """y = act(BatchNorm_train(x) [+ r]); updates the module's running statistics like nn.BatchNorm2d."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, r, bn, leaky):
+        s, q = ops.channel_stats_nhwc(x)
+        scale, shift, mean, rstd = ops.bn_finalize(bn, s, q, _count(x), want_stats=True)
+        y = ops.affine_act_nhwc(x, scale, shift, b=r, leaky=leaky, slope=LEAKY)
+        ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.leaky, ctx.has_r = leaky, r is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY)
+        return dx, dgamma, dbeta, (g if ctx.has_r else None), None, None
+
+
+class _Bilinear2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.bilinear2x_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bilinear2x_nhwc_bwd(dy)
+
+
+def _conv_g(x, conv):
+    return _Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+
+
+def _bnact_g(x, bn, r=None, leaky=True):
+    return _BnActFn.apply(x, bn.weight, bn.bias, r, bn, leaky)
 
 
 def _conv(x, conv, dtype, **kw):
@@ -91,6 +193,14 @@ class Residual(nn.Module):
 
     def forward_nhwc(self, x, dtype):
         c1, bn1, c2, bn2 = self._block[0], self._block[1], self._block[3], self._block[4]
+        if _grad_path(self):
+            h = _bnact_g(_conv_g(x, c1), bn1)
+            h = _conv_g(h, c2)
+            if self.downsample is not None:
+                r = _bnact_g(_conv_g(x, self.downsample[0]), self.downsample[1], leaky=False)
+            else:
+                r = x
+            return _bnact_g(h, bn2, r=r)
         if bn1.training:
             h, s, q = _conv(x, c1, dtype, stats=True)
             sc, sh = ops.bn_finalize(bn1, s, q, _count(h))
@@ -114,7 +224,6 @@ class Residual(nn.Module):
         return _conv(h, c2, dtype, scale=sc2, shift=sh2, residual=r, leaky=True, slope=LEAKY)
 
     def forward(self, x):
-        _check_no_grad(self)
         dt = get_compute_dtype()
         return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt))
 
@@ -135,7 +244,6 @@ class ResidualStack(nn.Module):
         return x
 
     def forward(self, x):
-        _check_no_grad(self)
         dt = get_compute_dtype()
         return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt))
 
@@ -152,9 +260,11 @@ class SimpleResidualEncoder(nn.Module):
 
     def forward_nhwc(self, x):
         """NCHW frames -> [B,h,w,E] latents (what VectorQuantizerEMA wants: no NCHW<->NHWC flips)."""
-        _check_no_grad(self)
         dt = get_compute_dtype()
-        h = _conv(_to_nhwc(x, dt), self._conv_1, dt, leaky=True, slope=LEAKY)
+        if _grad_path(self):
+            h = F.leaky_relu(_conv_g(_to_nhwc(x, dt), self._conv_1), LEAKY)
+        else:
+            h = _conv(_to_nhwc(x, dt), self._conv_1, dt, leaky=True, slope=LEAKY)
         return self._residual_stack.forward_nhwc(h, dt)
 
     def forward(self, x):
@@ -180,6 +290,16 @@ class UpscaleResidual(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward_nhwc(self, x, dtype):
+        if _grad_path(self):
+            h = _bnact_g(x, self.bn1)
+            if self.upsample:
+                h = _Bilinear2xFn.apply(h)
+                x = _Bilinear2xFn.apply(x)
+            h = _bnact_g(_conv_g(h, self.conv1), self.bn2)
+            h = _conv_g(h, self.conv2)
+            if self.learn_conv_residual:
+                x = _conv_g(x, self.conv_residual)
+            return h + x
         if self.bn1.training:
             s, q = ops.channel_stats_nhwc(x)
             sc, sh = ops.bn_finalize(self.bn1, s, q, _count(x))
@@ -201,7 +321,6 @@ class UpscaleResidual(nn.Module):
         return _conv(h, self.conv2, dtype, residual=x)
 
     def forward(self, x):
-        _check_no_grad(self)
         dt = get_compute_dtype()
         return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt))
 
@@ -219,13 +338,13 @@ class SimpleResidualDecoder(nn.Module):
 
     def forward_nhwc(self, h):
         """[B,h,w,E] latents (NHWC, C % 8 == 0) -> logical NCHW image."""
-        _check_no_grad(self)
         dt = get_compute_dtype()
         mods = list(self.decoder_stack)
-        h = _conv(h, mods[0], dt)
+        grad = _grad_path(self)
+        h = _conv_g(h, mods[0]) if grad else _conv(h, mods[0], dt)
         for m in mods[1:-1]:
             h = m.forward_nhwc(h, dt)
-        return _to_nchw_view(_conv(h, mods[-1], dt))
+        return _to_nchw_view(_conv_g(h, mods[-1]) if grad else _conv(h, mods[-1], dt))
 
     def forward(self, x):
         return self.forward_nhwc(_to_nhwc(x, get_compute_dtype()))

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
 __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, int training, float* __restrict__ scale, float* __restrict__ shift, int C) {
+                                   float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float mean, var;
@@ -204,6 +205,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   scale[c] = g * rs;
   shift[c] = b - mean * g * rs;
+  if (mean_out) { mean_out[c] = mean; rstd_out[c] = rs; }
 }
 
 // y = act( a*sa[c] + ta[c]  (+ b*sb[c] + tb[c]) ),  act = LeakyReLU(slope) or identity; NHWC [M, C], C % 4 == 0
@@ -250,6 +252,88 @@ __global__ __launch_bounds__(256) void bilinear2x_kernel(const T* __restrict__ x
     // ATen's upsample_bilinear2d order: interpolate along w inside each row, then along h
     const float top = (1.f - lw) * v00 + lw * v01, bot = (1.f - lw) * v10 + lw * v11;
     y[i] = Elem<T>::from_f32((1.f - lh) * top + lh * bot);
+  }
+}
+
+// ---- backward companions (training-mode BatchNorm + LeakyReLU, bilinear x2)
+// g = dy * act'(y)  (act' from the sign of the stored post-activation y); per channel: sum_g += g, sum_gx += g * xhat
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                const T* __restrict__ dy, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, T* __restrict__ g_out,
+                                                                float* __restrict__ sum_g, float* __restrict__ sum_gx,
+                                                                long M, int C, int leaky, float slope) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean ? mean[c] : 0.f, rs = rstd ? rstd[c] : 1.f;
+    for (long m = (long)blockIdx.x * 4 + sub; m < M; m += (long)gridDim.x * 4) {
+      float g = Elem<T>::to_f32(dy[m * C + c]);
+      if (leaky && Elem<T>::to_f32(y[m * C + c]) <= 0.f) g *= slope;
+      if (g_out) g_out[m * C + c] = Elem<T>::from_f32(g);
+      s1 += g;
+      if (x) s2 += g * (Elem<T>::to_f32(x[m * C + c]) - mu) * rs;
+    }
+  }
+  __shared__ float r1[4][64], r2[4][64];
+  r1[sub][threadIdx.x & 63] = s1;
+  r2[sub][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (sub == 0 && c < C && sum_g) {
+    const int l = threadIdx.x;
+    atomicAdd(sum_g + c, r1[0][l] + r1[1][l] + r1[2][l] + r1[3][l]);
+    atomicAdd(sum_gx + c, r2[0][l] + r2[1][l] + r2[2][l] + r2[3][l]);
+  }
+}
+
+// dx = gamma * rstd * (g - sum_g/M - xhat * sum_gx/M)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sum_g,
+                                                           const float* __restrict__ sum_gx, T* __restrict__ dx, long M,
+                                                           int C) {
+  const long total = M * C;
+  const float invM = 1.f / (float)M;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float rs = rstd[c];
+    const float xh = (Elem<T>::to_f32(x[i]) - mean[c]) * rs;
+    const float v = gamma[c] * rs * (Elem<T>::to_f32(g[i]) - sum_g[c] * invM - xh * sum_gx[c] * invM);
+    dx[i] = Elem<T>::from_f32(v);
+  }
+}
+
+// adjoint of bilinear2x_kernel, gather form (deterministic): each source pixel collects from the <= 6x6 destination
+// pixels that could reference it, recomputing the forward's indices and weights
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
+                                                             int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc = 0.f;
+    for (int ho = max(2 * h - 2, 0); ho <= min(2 * h + 3, Ho - 1); ++ho) {
+      const float sh = fmaxf((ho + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int h0 = (int)sh, h1 = min(h0 + 1, H - 1);
+      const float lh = sh - h0;
+      const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+      if (wh == 0.f) continue;
+      for (int wo = max(2 * w - 2, 0); wo <= min(2 * w + 3, Wo - 1); ++wo) {
+        const float sw = fmaxf((wo + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int w0 = (int)sw, w1 = min(w0 + 1, W - 1);
+        const float lw = sw - w0;
+        const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+        if (ww != 0.f) acc += wh * ww * Elem<T>::to_f32(dy[(((long)b * Ho + ho) * Wo + wo) * C + c]);
+      }
+    }
+    dx[i] = Elem<T>::from_f32(acc);
   }
 }
 
@@ -301,11 +385,11 @@ extern "C" int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, 
 
 extern "C" int wmz_bn_finalize(const float* sum, const float* sq, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, double momentum, double eps, int training,
-                               float* scale, float* shift, int C, void* stream) {
+                               float* scale, float* shift, float* mean_out, float* rstd_out, int C, void* stream) {
   WMZ_REQUIRE(running_mean && running_var && scale && shift && C > 0, "wmz_bn_finalize: bad arguments");
   WMZ_REQUIRE(!training || (sum && sq && count > 0), "wmz_bn_finalize: training mode needs the batch statistics");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(wmz_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sum, sq, (float)count,
-                     gamma, beta, running_mean, running_var, (float)momentum, (float)eps, training, scale, shift, C);
+                     gamma, beta, running_mean, running_var, (float)momentum, (float)eps, training, scale, shift, mean_out, rstd_out, C);
   WMZ_LAUNCH_CHECK("wmz_bn_finalize");
   return WMZ_OK;
 }
@@ -336,5 +420,48 @@ extern "C" int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, 
   if (dtype == WMZ_BF16) hipLaunchKernelGGL(bilinear2x_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
   else hipLaunchKernelGGL(bilinear2x_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
   WMZ_LAUNCH_CHECK("wmz_bilinear2x_nhwc");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* dy, const float* mean, const float* rstd,
+                                     void* g_out, float* sum_g, float* sum_gx, long M, int C, int leaky, float slope,
+                                     int dtype, void* stream) {
+  WMZ_REQUIRE(dy && M > 0 && C > 0, "wmz_bn_act_bwd_reduce: bad arguments");
+  WMZ_REQUIRE(!leaky || y, "wmz_bn_act_bwd_reduce: LeakyReLU backward needs the stored output y");
+  WMZ_REQUIRE((sum_g == nullptr) == (sum_gx == nullptr), "wmz_bn_act_bwd_reduce: sum_g and sum_gx go together");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bn_act_bwd_reduce: bad dtype %d", dtype);
+  dim3 grid((unsigned)grid_for(M, 64, 512), (unsigned)wmz_cdiv(C, 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, (bf16_t*)g_out, sum_g, sum_gx, M, C, leaky, slope);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, (float*)g_out, sum_g, sum_gx, M, C, leaky, slope);
+  WMZ_LAUNCH_CHECK("wmz_bn_act_bwd_reduce");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean, const float* rstd, const float* gamma,
+                                const float* sum_g, const float* sum_gx, void* dx, long M, int C, int dtype, void* stream) {
+  WMZ_REQUIRE(x && g && mean && rstd && gamma && sum_g && sum_gx && dx && M > 0 && C > 0, "wmz_bn_bwd_apply: bad arguments");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bn_bwd_apply: bad dtype %d", dtype);
+  const int grid = grid_for(M * C, 256, 4096);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, M, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, M, C);
+  WMZ_LAUNCH_CHECK("wmz_bn_bwd_apply");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_bilinear2x_nhwc_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+  WMZ_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "wmz_bilinear2x_nhwc_bwd: bad arguments");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bilinear2x_nhwc_bwd: bad dtype %d", dtype);
+  const long total = (long)B * H * W * C;
+  const int grid = grid_for(total, 256, 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16) hipLaunchKernelGGL(bilinear2x_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
+  else hipLaunchKernelGGL(bilinear2x_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (float*)dx, B, H, W, C);
+  WMZ_LAUNCH_CHECK("wmz_bilinear2x_nhwc_bwd");
   return WMZ_OK;
 }

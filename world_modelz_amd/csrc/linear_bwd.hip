@@ -50,6 +50,8 @@ struct WgParams {
   const float* gamma; const float* beta; const float* mean; const float* rstd;
   int gelu_in;
   int nbn, nbk, rows_per_wg;
+  // PRO == 3: A is the implicit im2col of an NHWC tensor x[B,Hi,Wi,Cin] (row m = output pixel, k = (kh, kw, ci))
+  int Hi, Wi, Cin, Ho, Wo, KW, cstride, cpad;
 };
 
 constexpr int WG_BN = 128, WG_BK = 128, WG_MS = 32;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void wg_col_frag(Frag8<T>& f, const char* img, int m0
   }
 }
 
-template <typename T, int PRO>   // PRO: 0 raw A, 1 LN(A) from mean/rstd/gamma/beta, 2 GELU(A)
+template <typename T, int PRO>   // PRO: 0 raw A, 1 LN(A) from mean/rstd/gamma/beta, 2 GELU(A), 3 implicit im2col of NHWC x
 __global__ __launch_bounds__(NT, 2) void wgrad_kernel(WgParams P) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int ROWB = WG_BN * (int)sizeof(T);
@@ -105,9 +107,20 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(WgParams P) {
       ra[it] = (i32x4)(0);
       if (m < m_end) {
         if (n0 + c * EPC < P.N) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * EPC);
-        if (k0 + c * EPC < P.K) {
+        if constexpr (PRO == 3) {
+          const int k = k0 + c * EPC;
+          if (k < P.K) {
+            const int tap = k / P.Cin, ci = k - tap * P.Cin;
+            const int kh = tap / P.KW, kw = tap - kh * P.KW;
+            const int wo = m % P.Wo, t = m / P.Wo;
+            const int ho = t % P.Ho, b = t / P.Ho;
+            const int hi = ho * P.cstride - P.cpad + kh, wi = wo * P.cstride - P.cpad + kw;
+            if (hi >= 0 && hi < P.Hi && wi >= 0 && wi < P.Wi)
+              ra[it] = *reinterpret_cast<const i32x4*>(A + (((long)b * P.Hi + hi) * P.Wi + wi) * P.Cin + ci);
+          }
+        } else if (k0 + c * EPC < P.K) {
           i32x4 v = *reinterpret_cast<const i32x4*>(A + (long)m * P.lda + k0 + c * EPC);
-          if constexpr (PRO != 0) {
+          if constexpr (PRO == 1 || PRO == 2) {
             float f[EPC];
             unpack_chunk<T>(v, f);
             if constexpr (PRO == 1) {
@@ -322,6 +335,7 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   WgParams P;
   P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
   P.gamma = ln_gamma; P.beta = ln_beta; P.mean = ln_mean; P.rstd = ln_rstd; P.gelu_in = gelu_in;
+  P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
   P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
   const int tiles = P.nbn * P.nbk;
   int split = wmz_cdiv(512, tiles);
@@ -338,6 +352,36 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   else { if (pro == 1) WMZ_WG(float, 1); else if (pro == 2) WMZ_WG(float, 2); else WMZ_WG(float, 0); }
 #undef WMZ_WG
   WMZ_LAUNCH_CHECK("wmz_linear_wgrad");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin,
+                                     int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+  WMZ_REQUIRE(x && dy && dW, "wmz_conv2d_nhwc_wgrad: null tensor");
+  WMZ_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "wmz_conv2d_nhwc_wgrad: bad shape");
+  WMZ_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "wmz_conv2d_nhwc_wgrad: Cin and Cout must be multiples of 8 (zero-pad)");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_conv2d_nhwc_wgrad: bad dtype %d", dtype);
+  WgParams P;
+  P.Hi = Hi; P.Wi = Wi; P.Cin = Cin; P.KW = KW; P.cstride = stride; P.cpad = pad;
+  P.Ho = (Hi + 2 * pad - KH) / stride + 1;
+  P.Wo = (Wi + 2 * pad - KW) / stride + 1;
+  WMZ_REQUIRE(P.Ho > 0 && P.Wo > 0, "wmz_conv2d_nhwc_wgrad: empty output");
+  P.dC = dy; P.ldc = Cout; P.A = x; P.lda = 0; P.dW = dW; P.dbias = dbias;
+  P.M = B * P.Ho * P.Wo; P.N = Cout; P.K = KH * KW * Cin;
+  P.gamma = P.beta = P.mean = P.rstd = nullptr; P.gelu_in = 0;
+  P.nbn = wmz_cdiv(P.N, WG_BN); P.nbk = wmz_cdiv(P.K, WG_BK);
+  const int tiles = P.nbn * P.nbk;
+  int split = wmz_cdiv(512, tiles);
+  const int max_split = wmz_cdiv(P.M, 4 * WG_MS);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  P.rows_per_wg = wmz_cdiv(wmz_cdiv(P.M, split), WG_MS) * WG_MS;
+  split = wmz_cdiv(P.M, P.rows_per_wg);
+  dim3 grid((unsigned)(tiles * split)), block(NT);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3>), grid, block, 0, st, P);
+  else hipLaunchKernelGGL((wgrad_kernel<float, 3>), grid, block, 0, st, P);
+  WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_wgrad");
   return WMZ_OK;
 }
 

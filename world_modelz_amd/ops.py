@@ -252,20 +252,22 @@ def channel_stats_nhwc(x):
     return s, q
 
 
-def bn_finalize(bn, s, q, count):
-    """(scale, shift) of an nn.BatchNorm2d; in training mode also updates its running statistics."""
+def bn_finalize(bn, s, q, count, want_stats=False):
+    """(scale, shift[, mean, rstd]) of an nn.BatchNorm2d; in training mode also updates its running statistics."""
     C = bn.num_features
     dev = bn.running_mean.device
     scale = torch.empty(C, dtype=torch.float32, device=dev)
     shift = torch.empty(C, dtype=torch.float32, device=dev)
     training = bn.training or bn.running_mean is None
     mom = bn.momentum if bn.momentum is not None else 0.1
+    mean = torch.empty(C, dtype=torch.float32, device=dev) if want_stats else None
+    rstd = torch.empty(C, dtype=torch.float32, device=dev) if want_stats else None
     L.call('wmz_bn_finalize', L.ptr(s), L.ptr(q), float(count), L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()),
            L.ptr(bn.running_mean), L.ptr(bn.running_var), float(mom), float(bn.eps), 1 if training else 0,
-           L.ptr(scale), L.ptr(shift), C, L.stream())
+           L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(rstd), C, L.stream())
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
-    return scale, shift
+    return (scale, shift, mean, rstd) if want_stats else (scale, shift)
 
 
 def affine_act_nhwc(a, sa=None, ta=None, b=None, sb=None, tb=None, leaky=False, slope=0.01):
@@ -304,3 +306,50 @@ def embed_indexed_bwd(tok, pos, dx, shape, table_shapes):
            L.ptr(tabs[1]), L.ptr(tabs[2]), L.ptr(tabs[3]), tok.numel(), S, H, W, D, table_shapes[0][0],
            L.dtype_code(dx.dtype), L.stream())
     return tabs
+
+
+def conv2d_nhwc_wgrad(x, dy, KH, KW, stride, pad, want_bias):
+    """x [B,Hi,Wi,Cin8], dy [B,Ho,Wo,Cout8] -> dW fp32 [Cout8, KH*KW*Cin8] (+ dbias fp32 [Cout8])."""
+    B, Hi, Wi, Cin = x.shape
+    Cout = dy.shape[-1]
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
+    dw = torch.zeros((Cout, KH * KW * Cin), dtype=torch.float32, device=x.device)
+    db = torch.zeros((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    L.call('wmz_conv2d_nhwc_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad,
+           L.dtype_code(x.dtype), L.stream())
+    return dw, db
+
+
+def bn_act_bwd(x, y, dy, mean, rstd, gamma, leaky, slope=0.01):
+    """Training-mode BatchNorm (+ LeakyReLU) backward -> (dx, dgamma, dbeta, g) ; g = dy * act'(y)."""
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    dy = dy.contiguous()
+    g = torch.empty_like(dy)
+    sg = torch.zeros(C, dtype=torch.float32, device=dy.device)
+    sgx = torch.zeros(C, dtype=torch.float32, device=dy.device)
+    L.call('wmz_bn_act_bwd_reduce', L.ptr(x), L.ptr(y), L.ptr(dy), L.ptr(mean), L.ptr(rstd), L.ptr(g), L.ptr(sg),
+           L.ptr(sgx), M, C, 1 if leaky else 0, float(slope), L.dtype_code(dy.dtype), L.stream())
+    dx = torch.empty_like(dy)
+    L.call('wmz_bn_bwd_apply', L.ptr(x), L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(sg), L.ptr(sgx), L.ptr(dx),
+           M, C, L.dtype_code(dy.dtype), L.stream())
+    return dx, sgx, sg, g
+
+
+def leaky_bwd(y, dy, slope=0.01):
+    """g = dy * LeakyReLU'(y) from the stored output."""
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    dy = dy.contiguous()
+    g = torch.empty_like(dy)
+    L.call('wmz_bn_act_bwd_reduce', None, L.ptr(y), L.ptr(dy), None, None, L.ptr(g), None, None, M, C, 1, float(slope),
+           L.dtype_code(dy.dtype), L.stream())
+    return g
+
+
+def bilinear2x_nhwc_bwd(dy):
+    B, Ho, Wo, C = dy.shape
+    dy = dy.contiguous()
+    dx = torch.empty((B, Ho // 2, Wo // 2, C), dtype=dy.dtype, device=dy.device)
+    L.call('wmz_bilinear2x_nhwc_bwd', L.ptr(dy), L.ptr(dx), B, Ho // 2, Wo // 2, C, L.dtype_code(dy.dtype), L.stream())
+    return dx
