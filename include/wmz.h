@@ -170,6 +170,19 @@ int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean, const floa
 /* adjoint of wmz_bilinear2x_nhwc (gather form, deterministic): dy [B,2H,2W,C] -> dx [B,H,W,C]. */
 int wmz_bilinear2x_nhwc_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 
+/* ---- the steps either side of the model in the training loop (main.py:246-274) ----
+ * corruption of the last latent frame: out[b, p] = C (mask token) with probability r[b]; else a uniformly redrawn code with
+ * probability 0.1 r[b]; else z_last[b, p]  (== multinomial(lerp(one_hot, 1/C, 0.1 r)) then mask: same law, in-kernel
+ * Philox4x32-10 keyed by (seed, stream_id)).  z_last / out: int64, clip strides in elements; target (optional) = z_last copy. */
+int wmz_corrupt_tokens(const int64_t* z_last, long clip_stride, const float* r, int64_t* out, long out_stride,
+                       int64_t* target, int B, int HW, int C, unsigned long long seed, unsigned long long stream_id,
+                       void* stream);
+/* CrossEntropyLoss(reduction='none') over fp32 logits [R, C] (row stride ld): loss[R], lse[R]; and its gradient
+ * dlogits[r,c] = (softmax - one_hot) * grad_rows[r], written in `dtype` (the GEMM operand type of the backward). */
+int wmz_ce_fwd(const float* logits, long ld, const int64_t* target, float* loss, float* lse, long R, int C, void* stream);
+int wmz_ce_bwd(const float* logits, long ld, const int64_t* target, const float* lse, const float* grad_rows, void* dlogits,
+               long R, int C, int dtype, void* stream);
+
 /* ---- training-step tail over flat fp32 arenas (one launch each) ----
  * grad_norm (main.py:188-193): out[0] += scale^2 * sum g^2 (caller zeroes out[0]; no host sync). */
 int wmz_grad_sqnorm(const float* g, long n, float scale, float* out, void* stream);

@@ -46,6 +46,10 @@ SIGNATURES = {
     'wmz_bilinear2x_nhwc': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_embed_indexed_fwd': [c_void_p] * 7 + [c_long] + [c_int] * 6 + [c_void_p],
     'wmz_embed_indexed_bwd': [c_void_p] * 7 + [c_long] + [c_int] * 6 + [c_void_p],
+    'wmz_corrupt_tokens': [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
+                           ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p],
+    'wmz_ce_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
+    'wmz_ce_bwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     'wmz_grad_sqnorm': [c_void_p, c_long, c_float, c_void_p, c_void_p],
     'wmz_adamw_step': [c_void_p] * 4 + [c_long] + [c_double] * 5 + [c_long, c_double, c_void_p],
     'wmz_vq_argmin': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -106,7 +106,7 @@ def embed_backward(ctx, dx):
 def linear_backward(ctx, dy):
     x, w, b = ctx.saved_tensors
     dt = x.dtype
-    dyc = dy.to(dt).contiguous()                                   # logits gradient arrives in fp32
+    dyc = dy.to(dt).contiguous()                                   # fused CE hands it over in dt already; torch's CE in fp32
     dw = torch.zeros_like(w, dtype=torch.float32)
     db = torch.zeros_like(b, dtype=torch.float32) if b is not None else None
     xc = x.contiguous()

@@ -1,0 +1,53 @@
+"""Iterative-unmasking sampler (the inference caller of the denoiser): build-owned counterpart of
+vq-video-diffusion/main.py:evaluate_model (:50-117) -- SURVEY 8f N2.
+
+Per generated frame: the last latent frame starts fully masked; 30 denoise iterations of
+{top-k filter -> softmax -> multinomial -> re-mask a (1 - frac) share -> write into the last frame -> model.forward};
+then the frames shift by one.  Everything stays on the GPU: the forward is ONE hipGraph launch per iteration
+(GraphedForward), sampling uses device RNG, and there is no host sync inside a frame.
+"""
+import torch
+import torch.nn.functional as F
+
+from .graph import GraphedForward
+
+
+def top_k_logits(logits, k):
+    """Keep the k largest logits per row, -inf elsewhere (main.py:39-43)."""
+    v, _ = torch.topk(logits, k, largest=True, sorted=True)
+    return logits.masked_fill(logits < v[:, [-1]], -float('inf'))
+
+
+@torch.no_grad()
+def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iterations=30, sample_topk=-1, noise_schedule=None,
+                  consistent_masking=False, generator=None, use_graph=True):
+    """batch_z: int64 [B,S,H,W] context tokens on the GPU (the last frame is overwritten).  Returns the list of generated
+    latent frames [B,H,W] (decode them with VqAutoEncoder.decode) and the final batch_z."""
+    assert batch_z.is_cuda
+    B, S, H, W = batch_z.shape
+    mask_token = num_embeddings
+    batch_z = batch_z.clone()
+    batch_z[:, -1] = mask_token                                   # destroy all information in the last frame (:62)
+    fwd = GraphedForward(model, batch_z) if use_graph else None
+    dev = batch_z.device
+    out = []
+    for _ in range(num_frames):
+        logits = torch.zeros(B * H * W, num_embeddings, device=dev)      # flat start (:71)
+        last_mask = torch.ones(B, H * W, dtype=torch.bool, device=dev)
+        for i in range(num_eval_iterations):
+            if sample_topk > 0:
+                logits = top_k_logits(logits, sample_topk)
+            p = F.softmax(logits, dim=-1)
+            denoised = torch.multinomial(p, 1, True, generator=generator).view(B, H * W)
+            frac = (i + 1) / num_eval_iterations
+            alpha = min(max(noise_schedule(frac) if noise_schedule is not None else frac, 0.0), 1.0)
+            mask = torch.rand(B, H * W, device=dev, generator=generator) > alpha
+            if consistent_masking:
+                mask = last_mask & mask
+                last_mask = mask
+            frame = torch.where(mask, torch.full_like(denoised, mask_token), denoised)
+            batch_z[:, -1] = frame.view(B, H, W)
+            logits = (fwd(batch_z) if fwd is not None else model(batch_z)).reshape(B * H * W, num_embeddings).float()
+        out.append(denoised.view(B, H, W).clone())
+        batch_z[:, :-1] = batch_z[:, 1:].clone()                  # shift frames (:115)
+    return out, batch_z

@@ -18,25 +18,61 @@ from .parallel import BucketedAllReduce, FlatArena, broadcast_parameters
 P_MAX_UNIFORM = 0.1     # main.py:208
 
 
-def corrupt_last_frame(batch_z, r, num_embeddings, generator=None):
-    """main.py:240-259 on the GPU without the [B,HW,C] one-hot / lerp / multinomial temporaries.
+_corrupt_calls = 0
+
+
+def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None):
+    """main.py:240-259 on the GPU without the [B,HW,C] one-hot / lerp / multinomial temporaries: ONE kernel.
 
     multinomial(lerp(one_hot(z), 1/C, a)) with a = 0.1 r has the closed form "with probability a redraw uniformly
     over all C codes, else keep z" (checked against the reference's categorical law in tests); then positions with
-    rand < r become the mask token C.  Same distribution as the reference, not the same RNG stream."""
-    B = batch_z.shape[0]
-    last = batch_z[:, -1]
-    target = last.clone()
-    flat = last.reshape(B, -1)
-    dev = batch_z.device
-    r = r.to(dev).view(B, 1)
-    u = torch.rand((3,) + flat.shape, device=dev, generator=generator)
-    uni = torch.clamp((u[1] * num_embeddings).long(), max=num_embeddings - 1)
-    draw = torch.where(u[0] < r * P_MAX_UNIFORM, uni, flat)
-    draw = torch.where(u[2] < r, torch.full_like(draw, num_embeddings), draw)
+    rand < r become the mask token C.  Same distribution as the reference, not the same RNG stream (in-kernel
+    Philox keyed by `seed` -- default torch's initial seed -- and a per-call stream id)."""
+    global _corrupt_calls
+    assert batch_z.is_cuda and batch_z.dtype == torch.int64
+    B, S = batch_z.shape[:2]
+    HW = batch_z[0, 0].numel()
     out = batch_z.clone()
-    out[:, -1] = draw.view(last.shape)
+    target = torch.empty_like(batch_z[:, -1]).contiguous()
+    r = r.to(batch_z.device, torch.float32).contiguous()
+    if seed is None:
+        seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+    _corrupt_calls += 1
+    src = batch_z.contiguous()
+    L.call('wmz_corrupt_tokens', src.data_ptr() + (S - 1) * HW * 8, S * HW, L.ptr(r), out.data_ptr() + (S - 1) * HW * 8,
+           S * HW, L.ptr(target), B, HW, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, _corrupt_calls, L.stream())
     return out, target
+
+
+class _CrossEntropyRows(torch.autograd.Function):
+    """CrossEntropyLoss(reduction='none') (main.py:268, :444) on fp32 logits; the gradient leaves in the GEMM dtype."""
+
+    @staticmethod
+    def forward(ctx, logits, target, grad_dtype):
+        R, C = logits.shape
+        assert logits.dtype == torch.float32 and logits.stride(1) == 1
+        loss = torch.empty(R, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(R, dtype=torch.float32, device=logits.device)
+        target = target.contiguous()
+        L.call('wmz_ce_fwd', L.ptr(logits), logits.stride(0), L.ptr(target), L.ptr(loss), L.ptr(lse), R, C, L.stream())
+        ctx.save_for_backward(logits, target, lse)
+        ctx.grad_dtype = grad_dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target, lse = ctx.saved_tensors
+        R, C = logits.shape
+        d = torch.empty((R, C), dtype=ctx.grad_dtype, device=logits.device)
+        L.call('wmz_ce_bwd', L.ptr(logits), logits.stride(0), L.ptr(target), L.ptr(lse), L.ptr(dloss.float().contiguous()),
+               L.ptr(d), R, C, L.dtype_code(ctx.grad_dtype), L.stream())
+        return d, None, None
+
+
+def cross_entropy_rows(logits, target):
+    """Per-row CE on fp32 logits.  (autograd hands a gradient back in the dtype of `logits`, so the fused backward
+    writes fp32 here; wmz_ce_bwd can emit bf16 for callers that fuse it with the projection's backward.)"""
+    return _CrossEntropyRows.apply(logits, target, torch.float32)
 
 
 class LossAwareSamplerEma:
@@ -104,7 +140,7 @@ class DenoiserTrainer:
     def forward_backward(self, batch_z, target):
         """Forward, per-sample CE over the last frame, backward.  Returns (per_sample_loss[B], mean loss) on device."""
         y = self.model(batch_z)
-        loss = F.cross_entropy(y.reshape(-1, self.C), target.reshape(-1), reduction='none')
+        loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
         per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
         mean = loss.mean()
         mean.backward()
