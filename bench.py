@@ -92,6 +92,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='replay the Python launch path instead of the hipGraph')
+    ap.add_argument('--train-steps', type=int, default=8, help='timed full training steps reported as train_step (0 = skip)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -242,6 +243,40 @@ def main():
                           'achieved_GBs': step_bytes / (ms_per_step * 1e-3) / 1e9,
                           'frac_of_8TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> gradient all-reduce overlapped
+    # on a side stream when n_gpus > 1 -> grad-norm -> AdamW), same shapes, same rules (barrier + sync both sides, max over
+    # ranks).  Eager launches: the backward is not graph-captured yet.
+    train = None
+    if a.train_steps > 0:
+        from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame
+        model.train()
+        tr = DenoiserTrainer(model, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=world > 1)
+        rfix = torch.full((cfg['B'],), 0.5)
+
+        def tstep():
+            tr.arena.zero_grad()
+            zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
+            tr.forward_backward(zc, tgt)
+            tr.optimizer_step()
+        for _ in range(3):
+            tstep()
+        barrier()
+        tt0 = time.perf_counter()
+        for _ in range(a.train_steps):
+            tstep()
+        torch.cuda.synchronize()
+        barrier()
+        tel = time.perf_counter() - tt0
+        if world > 1:
+            t = torch.tensor([tel], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            tel = float(t.item())
+        train = {'value': cfg['B'] * cfg['S'] * world * a.train_steps / tel, 'unit': 'latent-frames/s',
+                 'ms_per_step': tel / a.train_steps * 1e3, 'steps': a.train_steps,
+                 'what': 'corrupt + forward + CE + backward + (overlapped RCCL gradient all-reduce) + grad-norm + AdamW, '
+                         'eager launches', 'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0}
+        log(f'train step {train["ms_per_step"]:.2f} ms')
+    out['train_step'] = train
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             log(f'cpu baseline on {usable_cores()} threads')
