@@ -15,31 +15,64 @@ def _flat(t):
     return t.reshape(-1, t.shape[-1])
 
 
+def _emit(param, fill):
+    """Produce the gradient of `param` with `fill(buffer)` (every wgrad-type kernel ACCUMULATES into its output).
+
+    Under a FlatArena (parallel.py) the parameter carries `_wmz_grad`, its slice of the flat gradient arena: the kernel
+    accumulates straight into it, the data-parallel reducer is told (`_wmz_ready`) and autograd gets None -- no zeros
+    allocation, no `grad += g` pass, no extra launches.  Otherwise a fresh fp32 tensor is returned for autograd."""
+    if param is None:
+        return None
+    buf = getattr(param, '_wmz_grad', None)
+    if buf is not None:
+        fill(buf)
+        ready = getattr(param, '_wmz_ready', None)
+        if ready is not None:
+            ready()
+        return None
+    t = torch.zeros(param.shape, dtype=torch.float32, device=param.device)
+    fill(t)
+    return t
+
+
+def _emit2(p1, p2, fill):
+    """Two parameters filled by ONE kernel call (weight + bias, gamma + beta)."""
+    b1 = getattr(p1, '_wmz_grad', None)
+    b2 = getattr(p2, '_wmz_grad', None) if p2 is not None else None
+    direct = b1 is not None and (p2 is None or b2 is not None)
+    if not direct:
+        b1 = torch.zeros(p1.shape, dtype=torch.float32, device=p1.device)
+        b2 = torch.zeros(p2.shape, dtype=torch.float32, device=p2.device) if p2 is not None else None
+    fill(b1, b2)
+    if direct:
+        for p in (p1, p2):
+            ready = getattr(p, '_wmz_ready', None) if p is not None else None
+            if ready is not None:
+                ready()
+        return None, None
+    return b1, b2
+
+
 def attention_block_backward(ctx, dy):
     x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse = ctx.saved_tensors
     dt = x_kv.dtype
     I = wq.shape[0]
     dy = dy.contiguous()
     same_src = x_kv.data_ptr() == x_q.data_ptr() and x_kv.shape == x_q.shape
-    grads = {}
     # ---- to_out (+ residual): y = o Wout^T + bout + residual
     d_res = dy if ctx.has_res else None
+    g_wout = g_bout = None
     if wout is not None:
         do = ops.linear_dgrad(dy, _wt(wout, dt, 'woutT'))
-        grads['wout'] = torch.zeros_like(wout, dtype=torch.float32)
-        grads['bout'] = torch.zeros_like(bout, dtype=torch.float32)
-        ops.linear_wgrad(dy, o, grads['wout'], grads['bout'])
+        g_wout, g_bout = _emit2(wout, bout, lambda w, b: ops.linear_wgrad(dy, o, w, b))
     else:
         do = dy
     # ---- attention core
     dq, dkv = ops.local3d_attention_bwd(q, kv[..., :I], kv[..., I:], o, lse, do, ctx.extents, ctx.heads)
     # ---- to_q on the raw input
-    grads['wq'] = torch.zeros_like(wq, dtype=torch.float32)
-    ops.linear_wgrad(dq, x_q, grads['wq'])
+    g_wq = _emit(wq, lambda w: ops.linear_wgrad(dq, x_q, w))
     dxq = ops.linear_dgrad(dq, _wt(wq, dt, 'wqT'))
     # ---- to_k | to_v on LN(x_kv)
-    dwkv = torch.zeros((2 * I, wk.shape[1]), dtype=torch.float32, device=dy.device)
-    dbkv = torch.zeros((2 * I,), dtype=torch.float32, device=dy.device)
     wkvT = _cast.operand((wk, wv), dt, 'kvT', lambda a, b: torch.cat([a, b], dim=0).t())
     dxhat = ops.linear_dgrad(dkv, wkvT)                      # gradient w.r.t. LN(x_kv) (or x_kv without a norm)
     fold_q = same_src                                        # attn(x, q=x): the q path lands on the same tensor
@@ -49,21 +82,27 @@ def attention_block_backward(ctx, dy):
         skip = dxq
     if fold_res:
         skip = d_res if skip is None else skip + d_res
+    g_ln_g = g_ln_b = None
+    dk, dv = dkv[..., :I], dkv[..., I:]
     if ln_g is not None:
         stats = ops.layernorm_stats(x_kv, LN_EPS)
-        ops.linear_wgrad(dkv, x_kv, dwkv, dbkv, ln=(ln_g.detach(), ln_b.detach()), ln_stats=stats)
-        grads['ln_g'] = torch.zeros_like(ln_g, dtype=torch.float32)
-        grads['ln_b'] = torch.zeros_like(ln_b, dtype=torch.float32)
-        dx_kv = ops.layernorm_bwd(x_kv, dxhat, ln_g.detach(), grads['ln_g'], grads['ln_b'], skip=skip, eps=LN_EPS)
+        lnp = (ln_g.detach(), ln_b.detach())
+        g_wk = _emit(wk, lambda w: ops.linear_wgrad(dk, x_kv, w, None, ln=lnp, ln_stats=stats))
+        g_wv, g_bv = _emit2(wv, bv, lambda w, b: ops.linear_wgrad(dv, x_kv, w, b, ln=lnp, ln_stats=stats))
+        holder = {}
+
+        def fill_ln(gg, gb):
+            holder['dx'] = ops.layernorm_bwd(x_kv, dxhat, ln_g.detach(), gg, gb, skip=skip, eps=LN_EPS)
+        g_ln_g, g_ln_b = _emit2(ln_g, ln_b, fill_ln)
+        dx_kv = holder['dx']
     else:
-        ops.linear_wgrad(dkv, x_kv, dwkv, dbkv)
+        g_wk = _emit(wk, lambda w: ops.linear_wgrad(dk, x_kv, w))
+        g_wv, g_bv = _emit2(wv, bv, lambda w, b: ops.linear_wgrad(dv, x_kv, w, b))
         dx_kv = dxhat if skip is None else dxhat + skip.reshape(dxhat.shape)
-    grads['wk'], grads['wv'], grads['bv'] = dwkv[:I], dwkv[I:], dbkv[I:]
     g_xkv = dx_kv.reshape(x_kv.shape)
     g_xq = None if fold_q else dxq.reshape(x_q.shape)
     g_res = None if (not ctx.has_res or fold_res) else d_res
-    return (g_xkv, g_xq, grads.get('ln_g'), grads.get('ln_b'), grads['wq'], grads['wk'], grads['wv'], grads['bv'],
-            grads.get('wout'), grads.get('bout'), g_res, None, None, None)
+    return (g_xkv, g_xq, g_ln_g, g_ln_b, g_wq, g_wk, g_wv, g_bv, g_wout, g_bout, g_res, None, None, None)
 
 
 def feed_forward_block_backward(ctx, dy):
@@ -72,26 +111,26 @@ def feed_forward_block_backward(ctx, dy):
     dy = dy.contiguous()
     d_res = dy if ctx.has_res else None
     # y = GELU(z) W2^T + b2 (+ residual)
-    dw2 = torch.zeros_like(w2, dtype=torch.float32)
-    db2 = torch.zeros_like(b2, dtype=torch.float32)
-    ops.linear_wgrad(dy, z, dw2, db2, gelu_in=True)
+    dw2, db2 = _emit2(w2, b2, lambda w, b: ops.linear_wgrad(dy, z, w, b, gelu_in=True))
     dz = ops.linear_dgrad(dy, _wt(w2, dt, 'w2T'), dgelu_z=z)        # (dy W2) * gelu'(z)
     # z = LN(x) W1^T + b1
-    dw1 = torch.zeros_like(w1, dtype=torch.float32)
-    db1 = torch.zeros_like(b1, dtype=torch.float32)
     dxhat = ops.linear_dgrad(dz, _wt(w1, dt, 'w1T'))
     dg = db = None
     if ln_g is not None:
         stats = ops.layernorm_stats(x, LN_EPS)
-        ops.linear_wgrad(dz, x, dw1, db1, ln=(ln_g.detach(), ln_b.detach()), ln_stats=stats)
-        dg = torch.zeros_like(ln_g, dtype=torch.float32)
-        db = torch.zeros_like(ln_b, dtype=torch.float32)
+        lnp = (ln_g.detach(), ln_b.detach())
+        dw1, db1 = _emit2(w1, b1, lambda w, b: ops.linear_wgrad(dz, x, w, b, ln=lnp, ln_stats=stats))
         # the transformer passes residual = x: fold the skip gradient into the LayerNorm backward
         fold = ctx.has_res and ctx.res_is_x
-        dx = ops.layernorm_bwd(x, dxhat, ln_g.detach(), dg, db, skip=d_res if fold else None, eps=LN_EPS)
+        holder = {}
+
+        def fill_ln(gg, gb):
+            holder['dx'] = ops.layernorm_bwd(x, dxhat, ln_g.detach(), gg, gb, skip=d_res if fold else None, eps=LN_EPS)
+        dg, db = _emit2(ln_g, ln_b, fill_ln)
+        dx = holder['dx']
         g_res = None if fold else d_res
     else:
-        ops.linear_wgrad(dz, x, dw1, db1)
+        dw1, db1 = _emit2(w1, b1, lambda w, b: ops.linear_wgrad(dz, x, w, b))
         dx = dxhat
         g_res = d_res
     return dx.reshape(x.shape), dg, db, dw1, db1, dw2, db2, g_res, None
@@ -99,18 +138,30 @@ def feed_forward_block_backward(ctx, dy):
 
 def embed_backward(ctx, dx):
     (z,) = ctx.saved_tensors
-    demb, dps, dph, dpw = ops.embed_pos3d_bwd(z, dx, ctx.shapes)
-    return None, demb, dps, dph, dpw, None
+    params = ctx.params                       # (emb, pos_s, pos_h, pos_w) Parameters
+    bufs = [getattr(p, '_wmz_grad', None) for p in params]
+    direct = all(b is not None for b in bufs)
+    if not direct:
+        bufs = [torch.zeros(p.shape, dtype=torch.float32, device=dx.device) for p in params]
+    ops.embed_pos3d_bwd(z, dx, bufs)
+    if direct:
+        for p in params:
+            ready = getattr(p, '_wmz_ready', None)
+            if ready is not None:
+                ready()
+        return None, None, None, None, None, None
+    return None, bufs[0], bufs[1], bufs[2], bufs[3], None
 
 
 def linear_backward(ctx, dy):
     x, w, b = ctx.saved_tensors
     dt = x.dtype
     dyc = dy.to(dt).contiguous()                                   # fused CE hands it over in dt already; torch's CE in fp32
-    dw = torch.zeros_like(w, dtype=torch.float32)
-    db = torch.zeros_like(b, dtype=torch.float32) if b is not None else None
     xc = x.contiguous()
-    ops.linear_wgrad(dyc, xc, dw, db)
+    if b is not None:
+        dw, db = _emit2(w, b, lambda gw, gb: ops.linear_wgrad(dyc, xc, gw, gb))
+    else:
+        dw, db = _emit(w, lambda gw: ops.linear_wgrad(dyc, xc, gw)), None
     dx = ops.linear_dgrad(dyc, _wt(w, dt, 'wT'))
     return dx.reshape(x.shape), dw, db, None
 

@@ -200,6 +200,31 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(WgParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&f)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&f)[4]) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = v[e];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&f)[4]) {
+  const s16x4 v = *reinterpret_cast<const s16x4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = bf16_bits_to_f32((unsigned short)v[e]);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&f)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&f)[4]) {
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = f[e];
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&f)[4]) {
+  s16x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (short)f32_to_bf16_bits(f[e]);
+  *reinterpret_cast<s16x4*>(p) = v;
+}
+
 // one wave per row; lanes own interleaved 4-element column groups
 template <typename T>
 __global__ __launch_bounds__(NT) void ln_stats_kernel(const T* __restrict__ X, long ldx, float* __restrict__ mean,
@@ -210,16 +235,19 @@ __global__ __launch_bounds__(NT) void ln_stats_kernel(const T* __restrict__ X, l
     const T* x = X + (long)m * ldx;
     float s = 0.f;
     for (int k = lane * 4; k < K; k += 256) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s += Elem<T>::to_f32(x[k + e]);
+      float f[4];
+      load4<T>(x + k, f);
+      s += (f[0] + f[1]) + (f[2] + f[3]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mu = s / (float)K;
     float q = 0.f;
     for (int k = lane * 4; k < K; k += 256) {
+      float f[4];
+      load4<T>(x + k, f);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = Elem<T>::to_f32(x[k + e]) - mu; q += d * d; }
+      for (int e = 0; e < 4; ++e) { const float d = f[e] - mu; q += d * d; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
@@ -249,14 +277,17 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, lon
     float xv[KG][4], dy[KG][4];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < KG; ++c)
+    for (int c = 0; c < KG; ++c) {
+      const int k0 = c * 256 + lane * 4;
+      if (k0 < K) {
+        load4<T>(X + (long)m * ldx + k0, xv[c]);
+        load4<T>(DY + (long)m * lddy + k0, dy[c]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = c * 256 + lane * 4 + e;
-        xv[c][e] = k < K ? Elem<T>::to_f32(X[(long)m * ldx + k]) : 0.f;
-        dy[c][e] = k < K ? Elem<T>::to_f32(DY[(long)m * lddy + k]) : 0.f;
-        s += xv[c][e];
+        for (int e = 0; e < 4; ++e) { xv[c][e] = 0.f; dy[c][e] = 0.f; }
       }
+      s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mu = s / (float)K;
@@ -291,16 +322,16 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, lon
     c1 /= (float)K;
     c2 /= (float)K;
 #pragma unroll
-    for (int c = 0; c < KG; ++c)
+    for (int c = 0; c < KG; ++c) {
+      const int k0 = c * 256 + lane * 4;
+      if (k0 < K) {
+        float sk[4] = {0.f, 0.f, 0.f, 0.f}, out[4];
+        if (SKIP) load4<T>(SKIP + (long)m * ldskip + k0, sk);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = c * 256 + lane * 4 + e;
-        if (k < K) {
-          float v = rs * (gam[c][e] * dy[c][e] - c1 - xv[c][e] * c2);
-          if (SKIP) v += Elem<T>::to_f32(SKIP[(long)m * ldskip + k]);
-          DX[(long)m * lddx + k] = Elem<T>::from_f32(v);
-        }
+        for (int e = 0; e < 4; ++e) out[e] = rs * (gam[c][e] * dy[c][e] - c1 - xv[c][e] * c2) + sk[e];
+        store4<T>(DX + (long)m * lddx + k0, out);
       }
+    }
   }
   // per-workgroup reduction over the 4 waves, then one atomic per column
 #pragma unroll

@@ -64,8 +64,9 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = CPR * EPC;              // 64 (bf16) / 32 (f32)
   constexpr int KSTEPS = BK / 16;
-  __shared__ __attribute__((aligned(16))) char As[BM * ROWB];
-  __shared__ __attribute__((aligned(16))) char Bs[BN * ROWB];
+  __shared__ __attribute__((aligned(16))) char tiles[(BM + BN) * ROWB];   // A slab | B slab; reused by the epilogue
+  char* As = tiles;
+  char* Bs = tiles + BM * ROWB;
   __shared__ float mean_s[BM], rstd_s[BM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,6 +205,71 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   const bool gelu = (P.flags & WMZ_LIN_GELU) != 0;
   const bool dgelu = (P.flags & WMZ_LIN_DGELU) != 0;
   const T* R = reinterpret_cast<const T*>(P.res);
+  if constexpr (sizeof(T) == 2) {
+    if (!P.out_f32 && (P.ldc % 8) == 0 && (R == nullptr || (P.ldr % 8) == 0)) {
+      // 16-bit outputs: a lane owns ONE column, so direct stores would be 2 bytes each.  Stage the fp32 tile through LDS
+      // (64 rows per round = the 32 KB the slabs occupied) and leave as whole 16-byte row chunks; the residual / gelu'
+      // operand is read the same way and applied in fp32 before the single rounding.
+      float* stage = reinterpret_cast<float*>(tiles);                 // [64][128] fp32
+#pragma unroll 1
+      for (int round = 0; round < 2; ++round) {
+        __syncthreads();
+        if ((wave >> 1) == round) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int cl = wc + 32 * j + l31;
+              const int col = n0 + cl;
+              const float bv = (P.bias && col < P.N) ? P.bias[col] : 0.f;
+#pragma unroll
+              for (int reg = 0; reg < 16; ++reg) {
+                const int rl = 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                float v = acc[i][j][reg] + bv;
+                if (gelu) v = gelu_erf(v);
+                stage[rl * BN + cl] = v;
+              }
+            }
+        }
+        __syncthreads();
+        // 64 rows x 16 chunks of 8 columns = 1024 chunks, 4 per thread
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = tid + it * NT;
+          const int rl = idx >> 4, ch = idx & 15;
+          const int row = m0 + round * 64 + rl, col = n0 + ch * 8;
+          if (row >= P.M || col >= P.N) continue;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * BN + ch * 8);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(stage + rl * BN + ch * 8 + 4);
+          float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+          T* dst = reinterpret_cast<T*>(P.C) + (long)row * P.ldc + col;
+          if (col + 8 <= P.N) {
+            if (R) {
+              float r8[8];
+              chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(R + (long)row * P.ldr + col), r8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                if (dgelu) f[e] *= 0.5f * (1.f + erff(r8[e] * 0.70710678118654752440f)) + r8[e] * 0.3989422804014327f * __expf(-0.5f * r8[e] * r8[e]);
+                else f[e] += r8[e];
+              }
+            }
+            *reinterpret_cast<i32x4*>(dst) = f32_to_chunk<T>(f);
+          } else {
+            for (int e = 0; e < 8 && col + e < P.N; ++e) {
+              float v = f[e];
+              if (R) {
+                const float rv = Elem<T>::to_f32(R[(long)row * P.ldr + col + e]);
+                if (dgelu) v *= 0.5f * (1.f + erff(rv * 0.70710678118654752440f)) + rv * 0.3989422804014327f * __expf(-0.5f * rv * rv);
+                else v += rv;
+              }
+              dst[e] = Elem<T>::from_f32(v);
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

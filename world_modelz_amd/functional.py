@@ -78,7 +78,7 @@ class _Embed(torch.autograd.Function):
     def forward(ctx, z, emb, pos_s, pos_h, pos_w, dtype):
         x = ops.embed_pos3d_fwd(z, emb.detach(), pos_s.detach(), pos_h.detach(), pos_w.detach(), dtype)
         ctx.save_for_backward(z)
-        ctx.shapes = (emb.shape, pos_s.shape, pos_h.shape, pos_w.shape)
+        ctx.params = (emb, pos_s, pos_h, pos_w)
         return x
 
     @staticmethod

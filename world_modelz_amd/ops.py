@@ -210,13 +210,13 @@ def layernorm_bwd(x, dyhat, gamma, dgamma, dbeta, skip=None, eps=1e-5):
     return dx
 
 
-def embed_pos3d_bwd(z, dx, shapes):
+def embed_pos3d_bwd(z, dx, tabs):
+    """Accumulates into tabs = [demb, dpos_s, dpos_h, dpos_w] (fp32)."""
     B, S, H, W = z.shape
     D = dx.shape[-1]
     dx = dx.contiguous()
-    tabs = [torch.zeros(s, dtype=torch.float32, device=dx.device) for s in shapes]
     L.call('wmz_embed_pos3d_bwd', L.ptr(z.contiguous()), L.ptr(dx), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]),
-           L.ptr(tabs[3]), B, S, H, W, D, shapes[0][0], L.dtype_code(dx.dtype), L.stream())
+           L.ptr(tabs[3]), B, S, H, W, D, tabs[0].shape[0], L.dtype_code(dx.dtype), L.stream())
     return tabs
 
 

@@ -35,12 +35,14 @@ class FlatArena:
                 self.flat_param[o:o + p.numel()].view_as(p).copy_(p)
                 p.data = self.flat_param[o:o + p.numel()].view_as(p)
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                p._wmz_grad = p.grad          # backward kernels accumulate straight into the arena (backward._emit)
 
     def zero_grad(self):
         self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):          # keep .grad pointing into the arena
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                p._wmz_grad = p.grad
 
 
 class BucketedAllReduce:
@@ -73,7 +75,9 @@ class BucketedAllReduce:
         self._hooks = []
         if self.world > 1:
             for i, p in enumerate(arena.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                hook = self._make_hook(i)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))     # gradients arriving through autograd
+                p._wmz_ready = (lambda h=hook, q=p: h(q))                          # ... and those written in place
         self.reset()
 
     def reset(self):
@@ -119,6 +123,9 @@ class BucketedAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.arena.params:
+            if hasattr(p, '_wmz_ready'):
+                del p._wmz_ready
 
 
 def broadcast_parameters(arena, src=0, process_group=None):
