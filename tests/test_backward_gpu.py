@@ -121,3 +121,28 @@ def test_default_model_backward_bf16_vs_oracle(wmz):
         worst = max((rel(p.grad, grads_ref[n]), n) for n, p in m.named_parameters())
         print(f'{dtype}: worst relative gradient error {worst[0]:.3e} at {worst[1]}')
         assert worst[0] < tol, worst
+
+
+@pytest.mark.parametrize('shape,heads,dh,ext', [
+    ((2, 5, 16, 16), 1, 128, (3, 3, 3)),
+    ((1, 9, 16, 16), 1, 128, (3, 1, 1)),
+    ((1, 4, 16, 16), 2, 64, (1, 2, 3)),
+    ((1, 3, 40, 16), 1, 32, (2, 2, 2)),        # H > 16: several workgroups per plane, both roles
+    ((1, 2, 5, 16), 4, 32, (0, 1, 0)),
+])
+def test_attention_backward_row16_fast_path(wmz, shape, heads, dh, ext):
+    """bf16, W == 16: attn_bwd_row16.hip against torch.autograd over the oracle (2e-2 rel: P and dS are bf16 MFMA
+    operands) -- dq, dk, dv."""
+    torch.manual_seed(31)
+    ops = wmz['ops']
+    B, S, H, W = shape
+    I = heads * dh
+    q, k, v, do = (torch.randn(B, S, H, W, I).bfloat16() for _ in range(4))
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    oat.local_attention(kr, vr, qr, ext, heads).backward(do.float())
+    qd, kd, vd, dod = (t.cuda() for t in (q, k, v, do))
+    out, lse, _ = ops.local3d_attention_fwd(qd, kd, vd, ext, heads, need_lse=True)
+    dq, dkv = ops.local3d_attention_bwd(qd, kd, vd, out, lse, dod, ext, heads)
+    assert rel(dq, qr.grad) < 2e-2
+    assert rel(dkv[..., :I], kr.grad) < 2e-2
+    assert rel(dkv[..., I:], vr.grad) < 2e-2

@@ -11,6 +11,7 @@
 //   S^T [32 visitors x 16 owners] = Y1 . X1^T          dP^T = Y2 . X2^T          (row fragments, MFMA 16x16x32)
 //   acc1^T[dh x 16 owners] += Y1^T . dS^T               (MODE 1 also: acc2^T += Y2^T . P^T)   (transposed LDS reads)
 #include "attn_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -302,6 +303,11 @@ int launch_both(const BwdPtrs& PQ, const BwdPtrs& PK, const AttnGeom& G, hipStre
 
 }  // namespace
 
+// fast path for 16-wide planes (attn_bwd_row16.hip)
+int wmz_attn_bwd_row16_dispatch(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                                const void* dout, void* dq, void* dk, void* dv, float* delta, const AttnGeom& G, long lddo,
+                                long lddq, long lddk, long lddv, hipStream_t st);
+
 extern "C" int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                                     const void* dout, void* dq, void* dk, void* dv, float* delta_ws, int B, int S, int H,
                                     int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv,
@@ -326,6 +332,9 @@ extern "C" int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v,
   PK.x1 = k; PK.x2 = v; PK.y1 = q; PK.y2 = dout; PK.o = nullptr; PK.lse = lse; PK.delta = delta_ws; PK.g1 = dk; PK.g2 = dv;
   PK.ldx1 = ldk; PK.ldx2 = ldv; PK.ldy1 = ldq; PK.ldy2 = lddo; PK.ldo = 0; PK.ldg1 = lddk; PK.ldg2 = lddv;
   hipStream_t st = (hipStream_t)stream;
+  static const bool no_fast = getenv("WMZ_ATTN_GENERAL") != nullptr;
+  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !no_fast)
+    return wmz_attn_bwd_row16_dispatch(q, k, v, out, lse, dout, dq, dk, dv, delta_ws, G, lddo, lddq, lddk, lddv, st);
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {
     if (DHp == 32) return launch_both<bf16_t, 32, 8>(PQ, PK, G, st);
