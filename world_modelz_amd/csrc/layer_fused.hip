@@ -50,18 +50,7 @@ template <int ROWB> __device__ __forceinline__ int aswz(int token) {
   if constexpr (ROWB >= 256) return (token & 15) << 4;
   else return ((token >> 1) & 7) << 4;          // 128-byte rows: two rows per 256-byte bank line
 }
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below bf16 resolution by 4 orders):
-// a third of libm erff's instruction count, and this kernel's epilogues are VALU-bound
-__device__ __forceinline__ float gelu_erf(float v) {
-  const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.f - p * t * __expf(-x * x);
-  return 0.5f * v * (1.f + copysignf(e, v));
-}
+__device__ __forceinline__ float gelu_erf(float v) { return wmz_gelu(v); }
 
 // ---- weight stream: RING-slot LDS ring filled by LDS-DMA (global_load_lds), RING-1 slabs in flight.
 struct WStream {

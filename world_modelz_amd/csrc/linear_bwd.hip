@@ -9,7 +9,7 @@ namespace {
 
 constexpr int NT = 256;
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float v) { return wmz_gelu(v); }
 
 template <typename T> __device__ __forceinline__ void unpack_chunk(const i32x4& c, float* f);
 template <> __device__ __forceinline__ void unpack_chunk<float>(const i32x4& c, float* f) {
@@ -369,7 +369,7 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
   P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
   const int tiles = P.nbn * P.nbk;
-  int split = wmz_cdiv(512, tiles);
+  int split = wmz_cdiv(256, tiles);          // ~one workgroup per CU: every extra split is another 64 KB of float atomics
   const int max_split = wmz_cdiv(M, 4 * WG_MS);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -402,7 +402,7 @@ extern "C" int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, f
   P.gamma = P.beta = P.mean = P.rstd = nullptr; P.gelu_in = 0;
   P.nbn = wmz_cdiv(P.N, WG_BN); P.nbk = wmz_cdiv(P.K, WG_BK);
   const int tiles = P.nbn * P.nbk;
-  int split = wmz_cdiv(512, tiles);
+  int split = wmz_cdiv(256, tiles);
   const int max_split = wmz_cdiv(P.M, 4 * WG_MS);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;

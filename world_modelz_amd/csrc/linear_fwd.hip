@@ -28,7 +28,7 @@ struct LinParams {
 
 __device__ __forceinline__ int swz128(int r) { return ((r >> 1) << 4) & 112; }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float v) { return wmz_gelu(v); }
 
 template <typename T> __device__ __forceinline__ void chunk_to_f32(const i32x4& c, float* f);
 template <> __device__ __forceinline__ void chunk_to_f32<float>(const i32x4& c, float* f) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
               chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(R + (long)row * P.ldr + col), r8);
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
-                if (dgelu) f[e] *= 0.5f * (1.f + erff(r8[e] * 0.70710678118654752440f)) + r8[e] * 0.3989422804014327f * __expf(-0.5f * r8[e] * r8[e]);
+                if (dgelu) f[e] *= wmz_dgelu(r8[e]);
                 else f[e] += r8[e];
               }
             }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
               float v = f[e];
               if (R) {
                 const float rv = Elem<T>::to_f32(R[(long)row * P.ldr + col + e]);
-                if (dgelu) v *= 0.5f * (1.f + erff(rv * 0.70710678118654752440f)) + rv * 0.3989422804014327f * __expf(-0.5f * rv * rv);
+                if (dgelu) v *= wmz_dgelu(rv);
                 else v += rv;
               }
               dst[e] = Elem<T>::from_f32(v);
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
         if (R) {
           const float rv = Elem<T>::to_f32(R[(long)row * P.ldr + col]);
           if (dgelu) {   // rv is the saved pre-activation z: multiply by gelu'(z)
-            v *= 0.5f * (1.f + erff(rv * 0.70710678118654752440f)) + rv * 0.3989422804014327f * __expf(-0.5f * rv * rv);
+            v *= wmz_dgelu(rv);
           } else {
             v += rv;
           }

@@ -104,6 +104,24 @@ __device__ __forceinline__ void mma32(f32x16& acc, const Frag8<float>& a, const 
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
 
+// exact-erf GELU (nn.GELU default) with erf from Abramowitz-Stegun 7.1.26: |erf error| <= 1.5e-7 (fp32 round-off level,
+// 4 orders below bf16 resolution) at about a third of libm erff's instruction count.  Shared by every kernel that
+// applies GELU or its derivative.
+__device__ __forceinline__ float wmz_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return copysignf(1.f - p * t * __expf(-ax * ax), x);
+}
+__device__ __forceinline__ float wmz_gelu(float v) { return 0.5f * v * (1.f + wmz_erf(v * 0.70710678118654752440f)); }
+// d/dv GELU(v) = Phi(v) + v * phi(v)
+__device__ __forceinline__ float wmz_dgelu(float v) {
+  return 0.5f * (1.f + wmz_erf(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
+
 // wave64 butterfly helpers
 __device__ __forceinline__ float wave_xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask)); }
 __device__ __forceinline__ float wave_xor_add(float v, int mask) { return v + __shfl_xor(v, mask); }
