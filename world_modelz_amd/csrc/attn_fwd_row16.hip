@@ -30,8 +30,10 @@ template <int DH> struct Img {
 
 // LDS-DMA one padded image: lane landing on (row, 16-byte chunk) fetches that chunk of global row c0*16+row; pad chunks and
 // rows past the valid range fetch a valid dummy (never read / masked).
+// A slab holds every OTHER row of a 16-row chunk of the plane (plane row = base + 2 * slab row): whatever its own row, a
+// wave finds about half of its +-eH key rows in each slab, so all waves of the workgroup are busy between two barriers.
 template <int DH, int ROWP, int IMGB>
-__device__ __forceinline__ void stage_padded(char* dst, const bf16_t* plane, long ld, int row0, int last_row, int wave,
+__device__ __forceinline__ void stage_padded(char* dst, const bf16_t* plane, long ld, int base, int H, int wave,
                                              int lane) {
   constexpr int PIECES = IMGB / 1024;
 #pragma unroll
@@ -42,8 +44,9 @@ __device__ __forceinline__ void stage_padded(char* dst, const bf16_t* plane, lon
     const int r = off / ROWP;
     int c = (off - r * ROWP) >> 4;
     c = c < DH / 8 ? c : 0;
-    const int rr = min(r, last_row);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plane + (long)(row0 + rr) * ld + c * 8),
+    const int prow = min(base + 2 * (r >> 4), H - 1);         // rows past the plane: any valid row (never read)
+    const int grow = (prow << 4) + (r & 15);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plane + (long)grow * ld + c * 8),
                                      (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
   }
 }
@@ -99,16 +102,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_row16_kernel(const b
   const int h0 = og * NW;
   const int t_lo = max(h0 - G.eH, 0), t_hi = min(min(h0 + NW - 1, H - 1) + G.eH, H - 1);
   const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
-  const int nch = (t_hi - t_lo + KC) / KC;
+  const int c_first = t_lo >> 4, c_last = t_hi >> 4;
+  const int nch = (c_last - c_first + 1) * 2;               // slabs per key plane: (16-row chunk) x (row parity)
   const int nslab = (sk_hi - sk_lo + 1) * nch;
 
   auto issue = [&](int j) {
-    const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
+    if (G.dbg & 2) return;
+    const int pl = j / nch, rem = j - pl * nch;
+    const int base = ((c_first + (rem >> 1)) << 4) + (rem & 1);
     const long plane_k = ((long)b * G.S + (sk_lo + pl)) * HW;
-    const int last_row = (min(KC, t_hi - c0 + 1)) * 16 - 1;
     char* buf = smem + (j % NBUF) * I::BUF;
-    stage_padded<DH, I::KROW, I::KIMG>(buf, K + plane_k * G.ldk + (long)head * DH, G.ldk, c0 * 16, last_row, wave, lane);
-    stage_padded<DH, I::VROW, I::VIMG>(buf + I::KIMG, V + plane_k * G.ldv + (long)head * DH, G.ldv, c0 * 16, last_row, wave, lane);
+    stage_padded<DH, I::KROW, I::KIMG>(buf, K + plane_k * G.ldk + (long)head * DH, G.ldk, base, H, wave, lane);
+    stage_padded<DH, I::VROW, I::VIMG>(buf + I::KIMG, V + plane_k * G.ldv + (long)head * DH, G.ldv, base, H, wave, lane);
   };
   // pieces this wave issues per slab (K image + V image): the counted vmcnt below depends on it
   constexpr int KP = I::KIMG / 1024, VP = I::VIMG / 1024;
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_row16_kernel(const b
   for (int j = 0; j < NBUF - 1; ++j)
     if (j < nslab) issue(j);
   for (int j = 0; j < nslab; ++j) {
-    const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
-    const int c_hi = min(c0 + KC - 1, t_hi);
+    const int pl = j / nch, rem = j - pl * nch;
+    const int base = ((c_first + (rem >> 1)) << 4) + (rem & 1);   // plane row of slab row 0; slab row r <-> base + 2r
     const char* Ks = smem + (j % NBUF) * I::BUF;
     const char* Vs = Ks + I::KIMG;
     // this wave's pieces of slab j landed: all but the pieces of the (up to NBUF-2) younger slabs in flight
@@ -132,12 +137,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_row16_kernel(const b
     }
     __builtin_amdgcn_s_barrier();                        // ... everyone's did, and slab j-1 is retired: refill its slot
     if (j + NBUF - 1 < nslab) issue(j + NBUF - 1);
-    if (!active) continue;
-    const int lo = max(c0, my_lo), hi = min(c_hi, my_hi);
+    if (!active || (G.dbg & 1)) continue;
+    const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
     for (int t0 = lo; t0 <= hi; t0 += 2) {
       const bool has1 = t0 + 1 <= hi;
-      const int ko0 = kbase + (t0 - c0) * 16 * I::KROW, ko1 = has1 ? ko0 + 16 * I::KROW : ko0;
-      const int vo0 = vbase + (t0 - c0) * 16 * I::VROW, vo1 = has1 ? vo0 + 16 * I::VROW : vo0;
+      const int ko0 = kbase + t0 * 16 * I::KROW, ko1 = has1 ? ko0 + 16 * I::KROW : ko0;
+      const int vo0 = vbase + t0 * 16 * I::VROW, vo1 = has1 ? vo0 + 16 * I::VROW : vo0;
       // ---- S^T = K Q^T, two key rows
       f32x4 s0 = (f32x4)(0.f), s1 = (f32x4)(0.f);
 #pragma unroll
