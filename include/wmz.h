@@ -134,6 +134,13 @@ int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, 
                         const float* vec, int ntok, int D, int I, int M, int has_head, int has_tail, float eps,
                         void* stream);
 
+/* First layer: the token + 3-axis position embedding (local_3d_attention.py:140-157) fused with the tail above:
+ * x_out = embedding (bf16), q / k|v of layer 0 from it.  wpack / vec as for a tail-only call. */
+int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+                            const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                            const float* vec, int B, int S, int H, int W, int D, int I, int M, int num_classes, float eps,
+                            void* stream);
+
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]
  * (nn.Conv2d weight permuted (0,2,3,1)), Cin % 8 == 0 (zero-pad), act = LeakyReLU(slope) if leaky.  scale/shift carry a

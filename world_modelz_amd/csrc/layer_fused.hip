@@ -42,6 +42,8 @@ struct FusedParams {
   const float* vec;     // packed fp32 vectors: bout[D] g2[D] be2[D] b1[M] b2[D] g1n[D] be1n[D] bkv[2I]
   int ntok;
   float eps;
+  // EMBED variant (first layer): x is produced in-kernel from the token grid (local_3d_attention.py:140-157)
+  const int64_t* z; const float *emb, *pos_s, *pos_h, *pos_w; int S, H, W, num_classes;
   int dbg;              // ablation switches (timing experiments only): 1 = skip MFMA loop, 2 = skip weight DMA + waits
 };
 
@@ -255,6 +257,41 @@ template <int N> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[N]) {
   for (int b = 0; b < N; ++b) acc[b] = (f32x4)(0.f);
 }
 
+// token + 3-axis position embedding of the wave's 16 tokens -> LDS buffer (bf16, the tail's operand) and x_out (bf16)
+template <int F>
+__device__ __forceinline__ void embed_rows(char* act, const FusedParams& P, long tok0, int lane) {
+  constexpr int ROWB = F * 2, CPR = ROWB / 16, TOT = FT * CPR;
+#pragma unroll
+  for (int i = 0; i < TOT / 64; ++i) {
+    const int idx = lane + 64 * i;
+    const int r = idx / CPR, c = idx - r * CPR;
+    const long t = tok0 + r;
+    i32x4 v = (i32x4)(0);
+    if (t < P.ntok) {
+      const int w = (int)(t % P.W), h = (int)((t / P.W) % P.H), s = (int)((t / ((long)P.W * P.H)) % P.S);
+      long tk = P.z[t];
+      tk = tk < 0 ? 0 : (tk >= P.num_classes ? P.num_classes - 1 : tk);
+      float f[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int col = c * 8 + 4 * q;
+        const f32x4 e = *reinterpret_cast<const f32x4*>(P.emb + tk * F + col);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(P.pos_s + (long)s * F + col);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(P.pos_h + (long)h * F + col);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(P.pos_w + (long)w * F + col);
+        const f32x4 y = e + ((a + b) + d);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[4 * q + k] = y[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        v[k] = (int)((unsigned)f32_to_bf16_bits(f[2 * k]) | ((unsigned)f32_to_bf16_bits(f[2 * k + 1]) << 16));
+      *reinterpret_cast<i32x4*>(P.xo + t * F + c * 8) = v;
+    }
+    *reinterpret_cast<i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r))) = v;
+  }
+}
+
 template <int D, int I, int M, bool HEAD, bool TAIL>
 __global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
   static_assert(D == 256 && M == 256 && I == 128, "built for the default denoiser widths");
@@ -315,7 +352,8 @@ __global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
     tile_to_lds<D / 16, D>(actA, xr, 0, li, g, [](float v) { return v; });
     lds_to_rows<D>(P.xo, actA, tok0, P.ntok, lane);
   } else {
-    rows_to_lds<D>(actA, P.x, tok0, P.ntok, lane);
+    if (P.z != nullptr) embed_rows<D>(actA, P, tok0, lane);          // first layer: x = embedding, also written to x_out
+    else rows_to_lds<D>(actA, P.x, tok0, P.ntok, lane);
     lds_to_acc<D / 16, false>(xr, actA, li, g);
   }
   if constexpr (TAIL) {
@@ -343,6 +381,8 @@ __global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
 
 }  // namespace
 
+static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_head, int has_tail, void* stream);
+
 extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
                                    const void* wpack, const float* vec, int ntok, int D, int I, int M, int has_head,
                                    int has_tail, float eps, void* stream) {
@@ -350,13 +390,31 @@ extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, vo
   WMZ_REQUIRE(has_head || has_tail, "wmz_layer_fused_fwd: nothing to do");
   WMZ_REQUIRE(!has_head || (o && x_out), "wmz_layer_fused_fwd: head needs o and x_out");
   WMZ_REQUIRE(!has_tail || (q_out && kv_out), "wmz_layer_fused_fwd: tail needs q_out and kv_out");
+  FusedParams P;
+  P.o = (const bf16_t*)o; P.x = (const bf16_t*)x; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
+  P.wpack = (const char*)wpack; P.vec = vec; P.ntok = ntok; P.eps = eps;
+  P.z = nullptr; P.emb = P.pos_s = P.pos_h = P.pos_w = nullptr; P.S = P.H = P.W = P.num_classes = 0;
+  return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
+}
+
+extern "C" int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+                                       const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                                       const float* vec, int B, int S, int H, int W, int D, int I, int M, int num_classes,
+                                       float eps, void* stream) {
+  WMZ_REQUIRE(z && emb && pos_s && pos_h && pos_w && x_out && q_out && kv_out && wpack && vec, "wmz_embed_qkv_fused_fwd: null tensor");
+  WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && num_classes > 0, "wmz_embed_qkv_fused_fwd: bad shape");
+  FusedParams P;
+  P.o = nullptr; P.x = nullptr; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
+  P.wpack = (const char*)wpack; P.vec = vec; P.ntok = B * S * H * W; P.eps = eps;
+  P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
+  return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
+}
+
+static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_head, int has_tail, void* stream) {
   if (!(D == 256 && I == 128 && M == 256)) {
     wmz_set_error("wmz_layer_fused_fwd: built for dim 256 / inner 128 / mlp 256 (got %d/%d/%d); use the unfused path", D, I, M);
     return WMZ_ERR_UNSUPPORTED;
   }
-  FusedParams P;
-  P.o = (const bf16_t*)o; P.x = (const bf16_t*)x; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
-  P.wpack = (const char*)wpack; P.vec = vec; P.ntok = ntok; P.eps = eps;
   static const int dbg_env = getenv("WMZ_FUSED_DBG") ? atoi(getenv("WMZ_FUSED_DBG")) : 0;
   P.dbg = dbg_env;
   const size_t smem = FW * (ACTB + ZCB) + VECB + RING * SLAB;

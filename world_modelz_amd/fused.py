@@ -93,10 +93,29 @@ def layer_fused(o, x, head, tail, eps=1e-5):
     return xo, q, kv
 
 
-def transformer_forward(tr, x):
-    """depth x [attention, feed-forward] on the fused kernels: per layer ONE attention launch + ONE per-token launch."""
+def embed_qkv_fused(tr, z, eps=1e-5):
+    """Embedding + layer 0's q | k|v in one launch.  Returns (x, q, kv)."""
+    B, S, H, W = z.shape
+    wpack, vec = _layer_pack(None, tr.layers[0])
+    dev = z.device
+    x = torch.empty((B, S, H, W, D_), dtype=torch.bfloat16, device=dev)
+    q = torch.empty((B, S, H, W, I_), dtype=torch.bfloat16, device=dev)
+    kv = torch.empty((B, S, H, W, 2 * I_), dtype=torch.bfloat16, device=dev)
+    L.call('wmz_embed_qkv_fused_fwd', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
+           L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
+           L.ptr(x), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), B, S, H, W, D_, I_, M_, tr.embedding.num_embeddings,
+           float(eps), L.stream())
+    return x, q, kv
+
+
+def transformer_forward(tr, x=None, z=None):
+    """depth x [attention, feed-forward] on the fused kernels: per layer ONE attention launch + ONE per-token launch;
+    with `z` (token grid) the embedding rides in the first per-token launch."""
     layers = list(tr.layers)
-    _, q, kv = layer_fused(None, x, None, layers[0])
+    if z is not None:
+        x, q, kv = embed_qkv_fused(tr, z)
+    else:
+        _, q, kv = layer_fused(None, x, None, layers[0])
     for l, (attn, ff) in enumerate(layers):
         o, _, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads)
         x, q, kv = layer_fused(o, x, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None)

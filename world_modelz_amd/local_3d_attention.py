@@ -136,13 +136,15 @@ class Local3dAttentionTransformer(nn.Module):
         _, S, H, W = img_z.shape
         if S > self.pos_emb_s.num_embeddings or H > self.pos_emb_h.num_embeddings or W > self.pos_emb_w.num_embeddings:
             raise IndexError('token grid larger than the position-embedding tables')
-        x = Fw.embed_tokens(img_z, self.embedding.weight, self.pos_emb_s.weight, self.pos_emb_h.weight,
-                            self.pos_emb_w.weight)
         if not torch.is_grad_enabled():
             from . import fused
-            if fused.supported(self, x.dtype):
-                # inference, bf16, default widths: one attention launch + one per-token launch per layer
-                return fused.transformer_forward(self, x)
+            from .config import get_compute_dtype
+            if fused.supported(self, get_compute_dtype()):
+                # inference, bf16, default widths: one attention launch + one per-token launch per layer, the
+                # embedding fused into the first one
+                return fused.transformer_forward(self, z=img_z)
+        x = Fw.embed_tokens(img_z, self.embedding.weight, self.pos_emb_s.weight, self.pos_emb_h.weight,
+                            self.pos_emb_w.weight)
         for attn, ff in self.layers:
             # x = attn(x, q=x) + x ; x = ff(x) + x   with both residual adds fused into the GEMM epilogues
             x = attn.fn.forward_prenorm(x, attn.norm, q=x, residual=x)
