@@ -99,12 +99,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)      # one rank per GPU on a full node; rehearsals may stack ranks on one card
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('WMZ_DIST_BACKEND', 'nccl')       # 'nccl' IS RCCL on ROCm; gloo only for rehearsals
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from world_modelz_amd import config, ops
     from world_modelz_amd.main import VqVideoDiffusionModel
