@@ -141,6 +141,25 @@ int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const float* pos
                             const float* vec, int B, int S, int H, int W, int D, int I, int M, int num_classes, float eps,
                             void* stream);
 
+/* ---- trailing-planes variants (inference).  main.py:37 keeps only the LAST frame's logits (x[:, -1]), so layer l of a
+ * depth-L stack only has to produce the last min(S, 1 + (L-1-l) * eS) planes -- the dependence cone of the last frame
+ * through the temporal windows (local_3d_attention.py:95-104).  Same arithmetic per token as the full-grid calls (results
+ * are bit-identical on the planes that are computed); the dead planes are simply never launched.
+ *   attention: q / k / v cover all S planes, queries are taken from planes [q_plane0, q_plane0 + q_planes) only and
+ *              out / lse are compact [B, q_planes, H, W, ..];
+ *   fused layer: x holds planes_in planes per clip, o and the outputs hold its last planes_out planes;
+ *   embedding:  z is the full [B, S, H, W] token grid, the outputs hold the last planes_out planes of each clip. */
+int wmz_local3d_attn_fwd_planes(const void* q, const void* k, const void* v, void* out, float* lse, int B, int S, int H,
+                                int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
+                                int q_plane0, int q_planes, int dtype, void* stream);
+int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                               const float* vec, int B, int planes_out, int planes_in, int HW, int D, int I, int M,
+                               int has_head, int has_tail, float eps, void* stream);
+int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+                                   const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                                   const float* vec, int B, int S, int H, int W, int planes_out, int D, int I, int M,
+                                   int num_classes, float eps, void* stream);
+
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]
  * (nn.Conv2d weight permuted (0,2,3,1)), Cin % 8 == 0 (zero-pad), act = LeakyReLU(slope) if leaky.  scale/shift carry a

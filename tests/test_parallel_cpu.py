@@ -124,3 +124,17 @@ def test_c_abi_exports_every_declared_symbol():
     assert not missing, missing
     for n in declared - {'wmz_version', 'wmz_last_error'}:
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
+
+
+def test_cone_planes_schedule():
+    """Host logic of the last-frame dependence cone: brute-force reachability over the temporal windows."""
+    from world_modelz_amd.fused import cone_planes
+    for S in (1, 2, 5, 9, 32):
+        for eS in (0, 1, 3):
+            for depth in (1, 2, 4, 6):
+                need, src = cone_planes(S, eS, depth)
+                live = {S - 1}                                   # planes of layer `depth-1` output that matter
+                for l in range(depth - 1, -1, -1):
+                    assert need[l] == S - min(live), (S, eS, depth, l)
+                    live = {k for s in live for k in range(max(0, s - eS), min(S - 1, s + eS) + 1)}
+                    assert src[l] == S - min(live)

@@ -1,3 +1,5 @@
+"""Per-launch time of the fused per-token kernel at several token counts (graph of 50 launches, one event pair).
+WMZ_FUSED_DBG=1 skips the MFMA loops, =2 the weight DMA + waits (timing ablations only)."""
 import sys, torch
 sys.path.insert(0, '.')
 from world_modelz_amd import config, fused
@@ -5,13 +7,27 @@ from world_modelz_amd.main import VqVideoDiffusionModel
 torch.manual_seed(0)
 m = VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=256, num_classes=1024, extents=(3, 3, 3), depth=4, dim_head=128, mlp_dim=256, heads=1).cuda()
 config.set_compute_dtype(torch.bfloat16)
-x = torch.randn(8, 32, 16, 16, 256, device='cuda').bfloat16()
-o = torch.randn(8, 32, 16, 16, 128, device='cuda').bfloat16()
 L = list(m.transformer.layers)
-for _ in range(5): fused.layer_fused(o, x, L[0], L[1])
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(50): fused.layer_fused(o, x, L[0], L[1])
-e1.record(); torch.cuda.synchronize()
-print('fused head+tail us:', e0.elapsed_time(e1) * 1000 / 50)
+def timeit(fn, reps=50):
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1000 / reps)
+    return sorted(ts)[1]
+for planes in (1, 4, 8, 16, 32, 64, 128, 256, 512):
+    x = torch.randn(planes, 16, 16, 256, device='cuda').bfloat16()
+    o = torch.randn(planes, 16, 16, 128, device='cuda').bfloat16()
+    with torch.no_grad():
+        ht = timeit(lambda: fused.layer_fused(o, x, L[0], L[1]))
+        h = timeit(lambda: fused.layer_fused(o, x, L[0], None))
+        t = timeit(lambda: fused.layer_fused(None, x, None, L[1]))
+    print(f'planes {planes:4d} tokens {planes*256:7d} wgs {planes*2:5d}: head+tail {ht:7.1f} us  head {h:7.1f}  tail {t:7.1f}', flush=True)

@@ -1,4 +1,6 @@
 """Operand-dtype copies of fp32 parameters, cached per (parameter version, dtype)."""
+import weakref
+
 import torch
 
 _cache = {}
@@ -19,12 +21,17 @@ def operand(params, dtype, tag='w', build=None):
     key = _key(params, dtype, tag)
     ver = (_epoch,) + tuple((p._version, p.data_ptr()) for p in params)
     hit = _cache.get(key)
-    if hit is not None and hit[0] == ver:
+    # the key is made of id()s: a freed parameter's id (and storage address, and version) can come back with another
+    # model's parameter, so an entry only counts while its weak references still point at these very objects
+    if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     with torch.no_grad():
         src = build(*params) if build is not None else params[0]
         val = src.detach().to(dtype).contiguous()
-    _cache[key] = (ver, val)
+    if len(_cache) > 2048:
+        for k in [k for k, h in _cache.items() if any(r() is None for r in h[2])]:
+            del _cache[k]
+    _cache[key] = (ver, val, tuple(weakref.ref(p) for p in params))
     return val
 
 

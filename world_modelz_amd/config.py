@@ -33,3 +33,29 @@ def compute_dtype(dt):
         yield
     finally:
         set_compute_dtype(prev)
+
+
+# Inference only: the denoiser returns the last frame's logits (reference main.py:33-36), so the planes outside the
+# last frame's dependence cone are dead work.  With the cone on (default) they are not launched; the logits are
+# bit-identical either way (tests/test_modules_gpu.py).  bench.py's headline figure runs with the cone OFF: it times
+# the full grid, i.e. the same work the reference's forward does.
+_last_frame_cone = os.environ.get('WMZ_LAST_FRAME_CONE', '1') != '0'
+
+
+def get_last_frame_cone():
+    return _last_frame_cone
+
+
+def set_last_frame_cone(on):
+    global _last_frame_cone
+    _last_frame_cone = bool(on)
+
+
+@contextlib.contextmanager
+def last_frame_cone(on):
+    prev = get_last_frame_cone()
+    set_last_frame_cone(on)
+    try:
+        yield
+    finally:
+        set_last_frame_cone(prev)

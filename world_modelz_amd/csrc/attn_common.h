@@ -17,6 +17,7 @@ struct AttnGeom {
   int tiles;     // ceil(HW/16)
   int qgroups;   // workgroups per (b, head, s) plane
   float scale;   // dh^-0.5
+  int qs0, Sq;   // query planes [qs0, qs0+Sq) only; out / lse are compact [B, Sq, H, W, ..] (forward; full grid: 0, S)
   int dbg;       // ablation switches for timing experiments: 1 = skip the per-tile compute, 2 = skip the K/V staging
 };
 

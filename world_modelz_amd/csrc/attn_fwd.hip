@@ -40,7 +40,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void attn_fwd_kernel(const
 
   int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int qg = lid % G.qgroups; lid /= G.qgroups;
-  const int s = lid % G.S; lid /= G.S;
+  const int sq = lid % G.Sq; lid /= G.Sq;
+  const int s = G.qs0 + sq;
   const int head = lid % G.heads;
   const int b = lid / G.heads;
 
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void attn_fwd_kernel(const
 
   const int HW = G.HW, dh = G.dh;
   const long plane_q = ((long)b * G.S + s) * HW;
+  const long plane_o = ((long)b * G.Sq + sq) * HW;
   const float c2 = G.scale * 1.4426950408889634f;   // logits -> log2 domain
   const unsigned lim = ((unsigned)(2 * G.eH) << 16) | (unsigned)(2 * G.eW);
   const int KHW = (2 * G.eH + 1) * (2 * G.eW + 1), KW = 2 * G.eW + 1;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void attn_fwd_kernel(const
     l = wave_xor_add(l, 32);
     if (pq >= HW) continue;
     const float inv = 1.f / l;
-    T* orow = O + (plane_q + pq) * G.ldo + (long)head * dh;
+    T* orow = O + (plane_o + pq) * G.ldo + (long)head * dh;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int ch = mt * 16 + 4 * g;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void attn_fwd_kernel(const
         }
       }
     }
-    if (LSE != nullptr && g == 0) LSE[(plane_q + pq) * G.heads + head] = m_run[qi] * G.scale + logf(l);
+    if (LSE != nullptr && g == 0) LSE[(plane_o + pq) * G.heads + head] = m_run[qi] * G.scale + logf(l);
   }
 }
 
@@ -231,7 +233,7 @@ template <typename T, int DH, int QPW, int KC, int NWAVES>
 int launch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg, AttnGeom G,
            hipStream_t st) {
   G.qgroups = wmz_cdiv(G.tiles, NWAVES * QPW);
-  const long nwg = (long)G.B * G.heads * G.S * G.qgroups;
+  const long nwg = (long)G.B * G.heads * G.Sq * G.qgroups;
   const size_t smem = 4 * (size_t)KC * 16 * DH * sizeof(T) + (size_t)G.tiles * 16 * 4 + (size_t)G.tiles * sizeof(TileInfo);
   if (smem > 160 * 1024) { wmz_set_error("wmz_local3d_attn_fwd: plane too large for the LDS tables (H*W=%d)", G.HW); return WMZ_ERR_UNSUPPORTED; }
   constexpr int NTHREADS = NWAVES * 64;
@@ -253,10 +255,29 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
 int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, const AttnGeom& G,
                                 hipStream_t st);
 
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse, float* logits_dbg, int B, int S,
+                         int H, int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
+                         int q_plane0, int q_planes, int dtype, void* stream);
+
 extern "C" int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                                     float* logits_dbg, int B, int S, int H, int W, int heads, int dh, int eS, int eH,
                                     int eW, long ldq, long ldk, long ldv, long ldo, int dtype, void* stream) {
+  return attn_fwd_impl(q, k, v, out, lse, logits_dbg, B, S, H, W, heads, dh, eS, eH, eW, ldq, ldk, ldv, ldo, 0, S, dtype, stream);
+}
+
+extern "C" int wmz_local3d_attn_fwd_planes(const void* q, const void* k, const void* v, void* out, float* lse, int B, int S,
+                                           int H, int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk,
+                                           long ldv, long ldo, int q_plane0, int q_planes, int dtype, void* stream) {
+  return attn_fwd_impl(q, k, v, out, lse, nullptr, B, S, H, W, heads, dh, eS, eH, eW, ldq, ldk, ldv, ldo, q_plane0, q_planes,
+                       dtype, stream);
+}
+
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse, float* logits_dbg, int B, int S,
+                         int H, int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
+                         int q_plane0, int q_planes, int dtype, void* stream) {
   WMZ_REQUIRE(q && k && v && out, "wmz_local3d_attn_fwd: null tensor");
+  WMZ_REQUIRE(q_plane0 >= 0 && q_planes > 0 && q_plane0 + q_planes <= S, "wmz_local3d_attn_fwd: query planes [%d, %d) outside [0, %d)", q_plane0, q_plane0 + q_planes, S);
+  WMZ_REQUIRE(logits_dbg == nullptr || q_planes == S, "wmz_local3d_attn_fwd: the logits probe needs the full grid");
   WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && heads > 0 && dh > 0, "wmz_local3d_attn_fwd: bad shape");
   WMZ_REQUIRE(eS >= 0 && eH >= 0 && eW >= 0, "wmz_local3d_attn_fwd: negative extent");
   WMZ_REQUIRE(H <= 16384 && W <= 16384, "wmz_local3d_attn_fwd: H, W must be <= 16384");
@@ -268,6 +289,7 @@ extern "C" int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v,
   G.B = B; G.S = S; G.H = H; G.W = W; G.heads = heads; G.dh = dh; G.eS = eS; G.eH = eH; G.eW = eW;
   G.ldq = ldq; G.ldk = ldk; G.ldv = ldv; G.ldo = ldo;
   G.HW = H * W; G.tiles = (G.HW + 15) / 16; G.qgroups = 0;
+  G.qs0 = q_plane0; G.Sq = q_planes;
   G.scale = 1.0f / sqrtf((float)dh);
   static const int dbg_env = getenv("WMZ_ATTN_DBG") ? atoi(getenv("WMZ_ATTN_DBG")) : 0;
   G.dbg = dbg_env;

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_row16_kernel(const b
 
   int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int og = lid % G.qgroups; lid /= G.qgroups;
-  const int s = lid % G.S; lid /= G.S;
+  const int sq = lid % G.Sq; lid /= G.Sq;
+  const int s = G.qs0 + sq;
   const int head = lid % G.heads;
   const int b = lid / G.heads;
 
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_row16_kernel(const b
   const int h = og * NW + wave;                       // this wave's query row
   const bool active = h < H;
   const long plane_q = ((long)b * G.S + s) * HW;
+  const long plane_o = ((long)b * G.Sq + sq) * HW;
   const float c2 = G.scale * 1.4426950408889634f;
 
   // column-window biases of this lane's 4 keys (w = 4g + r) against its query (w = li)
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_row16_kernel(const b
   l = wave_xor_add(l, 16);
   l = wave_xor_add(l, 32);
   const float inv = 1.f / l;
-  bf16_t* orow = O + (plane_q + h * 16 + li) * G.ldo + (long)head * DH;
+  bf16_t* orow = O + (plane_o + h * 16 + li) * G.ldo + (long)head * DH;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     s16x4 pk;
@@ -209,13 +211,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_row16_kernel(const b
     for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(o[mt][r] * inv);
     *reinterpret_cast<s16x4*>(orow + mt * 16 + 4 * g) = pk;
   }
-  if (LSE != nullptr && g == 0) LSE[(plane_q + h * 16 + li) * G.heads + head] = m_run * 0.6931471805599453f + logf(l);
+  if (LSE != nullptr && g == 0) LSE[(plane_o + h * 16 + li) * G.heads + head] = m_run * 0.6931471805599453f + logf(l);
 }
 
 template <int DH>
 int launch_row16(const void* q, const void* k, const void* v, void* out, float* lse, AttnGeom G, hipStream_t st) {
   G.qgroups = wmz_cdiv(G.H, NW);
-  const long nwg = (long)G.B * G.heads * G.S * G.qgroups;
+  const long nwg = (long)G.B * G.heads * G.Sq * G.qgroups;
   const size_t smem = NBUF * (size_t)Img<DH>::BUF;
   auto kern = attn_fwd_row16_kernel<DH>;
   static bool attr_done = false;

@@ -45,7 +45,15 @@ struct FusedParams {
   // EMBED variant (first layer): x is produced in-kernel from the token grid (local_3d_attention.py:140-157)
   const int64_t* z; const float *emb, *pos_s, *pos_h, *pos_w; int S, H, W, num_classes;
   int dbg;              // ablation switches (timing experiments only): 1 = skip MFMA loop, 2 = skip weight DMA + waits
+  // trailing-planes variant: token t of the compact output grid reads row (t / rows_out) * rows_in + row0 + t % rows_out
+  // of x (or of the token grid z); rows_out == 0: identity
+  int rows_out, rows_in, row0;
 };
+__device__ __forceinline__ long src_row(const FusedParams& P, long t) {
+  if (P.rows_out == 0) return t;
+  const int c = (int)t / P.rows_out;
+  return (long)c * P.rows_in + P.row0 + ((int)t - c * P.rows_out);
+}
 
 // 16-byte-chunk XOR swizzle of an activation row: conflict-free ds_read_b128 of 32 token rows at one k-chunk
 template <int ROWB> __device__ __forceinline__ int aswz(int token) {
@@ -206,14 +214,15 @@ __device__ __forceinline__ void rows_to_lds(char* act, const bf16_t* src, long t
 }
 // same, split: issue the global loads early (registers), write them to LDS late (T14: the GEMM in between hides them)
 template <int F>
-__device__ __forceinline__ void rows_fetch(i32x4 (&regs)[FT * (F * 2 / 16) / 64], const bf16_t* src, long tok0, int ntok, int lane) {
+__device__ __forceinline__ void rows_fetch(i32x4 (&regs)[FT * (F * 2 / 16) / 64], const bf16_t* src, long tok0, int ntok, int lane,
+                                           const FusedParams& P) {
   constexpr int CPR = F * 2 / 16, TOT = FT * CPR;
 #pragma unroll
   for (int i = 0; i < TOT / 64; ++i) {
     const int idx = lane + 64 * i;
     const int r = idx / CPR, c = idx - r * CPR;
     regs[i] = (i32x4)(0);
-    if (tok0 + r < ntok) regs[i] = *reinterpret_cast<const i32x4*>(src + (tok0 + r) * F + c * 8);
+    if (tok0 + r < ntok) regs[i] = *reinterpret_cast<const i32x4*>(src + src_row(P, tok0 + r) * F + c * 8);
   }
 }
 template <int F>
@@ -268,8 +277,9 @@ __device__ __forceinline__ void embed_rows(char* act, const FusedParams& P, long
     const long t = tok0 + r;
     i32x4 v = (i32x4)(0);
     if (t < P.ntok) {
-      const int w = (int)(t % P.W), h = (int)((t / P.W) % P.H), s = (int)((t / ((long)P.W * P.H)) % P.S);
-      long tk = P.z[t];
+      const long ts = src_row(P, t);
+      const int w = (int)(ts % P.W), h = (int)((ts / P.W) % P.H), s = (int)((ts / ((long)P.W * P.H)) % P.S);
+      long tk = P.z[ts];
       tk = tk < 0 ? 0 : (tk >= P.num_classes ? P.num_classes - 1 : tk);
       float f[8];
 #pragma unroll
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
   if constexpr (HEAD) {
     rows_to_lds<I>(actA, P.o, tok0, P.ntok, lane);
     i32x4 xpre[FT * (D * 2 / 16) / 64];
-    rows_fetch<D>(xpre, P.x, tok0, P.ntok, lane);                      // residual rows: in flight under the first GEMM
+    rows_fetch<D>(xpre, P.x, tok0, P.ntok, lane, P);                      // residual rows: in flight under the first GEMM
     zero_acc(xr);
     gemm_stage<D, I, I * 2>(xr, actA, ring0, ws, li, g);               // o Wout^T
     add_vec<D / 16>(xr, v_bout, g);
@@ -353,7 +363,11 @@ __global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
     lds_to_rows<D>(P.xo, actA, tok0, P.ntok, lane);
   } else {
     if (P.z != nullptr) embed_rows<D>(actA, P, tok0, lane);          // first layer: x = embedding, also written to x_out
-    else rows_to_lds<D>(actA, P.x, tok0, P.ntok, lane);
+    else {
+      i32x4 xpre[FT * (D * 2 / 16) / 64];
+      rows_fetch<D>(xpre, P.x, tok0, P.ntok, lane, P);
+      rows_put<D>(actA, xpre, lane);
+    }
     lds_to_acc<D / 16, false>(xr, actA, li, g);
   }
   if constexpr (TAIL) {
@@ -386,6 +400,16 @@ static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_h
 extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
                                    const void* wpack, const float* vec, int ntok, int D, int I, int M, int has_head,
                                    int has_tail, float eps, void* stream) {
+  return wmz_layer_fused_fwd_planes(o, x, x_out, q_out, kv_out, wpack, vec, 1, 1, 1, ntok, D, I, M, has_head, has_tail, eps,
+                                    stream);
+}
+
+extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
+                                          const void* wpack, const float* vec, int B, int planes_out, int planes_in, int HW,
+                                          int D, int I, int M, int has_head, int has_tail, float eps, void* stream) {
+  WMZ_REQUIRE(B > 0 && HW > 0 && planes_out > 0 && planes_out <= planes_in, "wmz_layer_fused_fwd: bad plane counts");
+  WMZ_REQUIRE((long)B * planes_in * HW < (1L << 31), "wmz_layer_fused_fwd: token count overflows int");
+  const int ntok = B * planes_out * HW;
   WMZ_REQUIRE(x && wpack && vec && ntok > 0, "wmz_layer_fused_fwd: bad arguments");
   WMZ_REQUIRE(has_head || has_tail, "wmz_layer_fused_fwd: nothing to do");
   WMZ_REQUIRE(!has_head || (o && x_out), "wmz_layer_fused_fwd: head needs o and x_out");
@@ -394,6 +418,8 @@ extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, vo
   P.o = (const bf16_t*)o; P.x = (const bf16_t*)x; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
   P.wpack = (const char*)wpack; P.vec = vec; P.ntok = ntok; P.eps = eps;
   P.z = nullptr; P.emb = P.pos_s = P.pos_h = P.pos_w = nullptr; P.S = P.H = P.W = P.num_classes = 0;
+  P.rows_out = P.rows_in = P.row0 = 0;
+  if (planes_out != planes_in) { P.rows_out = planes_out * HW; P.rows_in = planes_in * HW; P.row0 = (planes_in - planes_out) * HW; }
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
@@ -401,11 +427,23 @@ extern "C" int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const
                                        const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                        const float* vec, int B, int S, int H, int W, int D, int I, int M, int num_classes,
                                        float eps, void* stream) {
+  return wmz_embed_qkv_fused_fwd_planes(z, emb, pos_s, pos_h, pos_w, x_out, q_out, kv_out, wpack, vec, B, S, H, W, S, D, I, M,
+                                        num_classes, eps, stream);
+}
+
+extern "C" int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+                                              const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                                              const float* vec, int B, int S, int H, int W, int planes_out, int D, int I,
+                                              int M, int num_classes, float eps, void* stream) {
+  WMZ_REQUIRE(planes_out > 0 && planes_out <= S, "wmz_embed_qkv_fused_fwd: bad plane count");
+  WMZ_REQUIRE((long)B * S * H * W < (1L << 31), "wmz_embed_qkv_fused_fwd: token count overflows int");
   WMZ_REQUIRE(z && emb && pos_s && pos_h && pos_w && x_out && q_out && kv_out && wpack && vec, "wmz_embed_qkv_fused_fwd: null tensor");
   WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && num_classes > 0, "wmz_embed_qkv_fused_fwd: bad shape");
   FusedParams P;
   P.o = nullptr; P.x = nullptr; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
-  P.wpack = (const char*)wpack; P.vec = vec; P.ntok = B * S * H * W; P.eps = eps;
+  P.wpack = (const char*)wpack; P.vec = vec; P.ntok = B * planes_out * H * W; P.eps = eps;
+  P.rows_out = P.rows_in = P.row0 = 0;
+  if (planes_out != S) { P.rows_out = planes_out * H * W; P.rows_in = S * H * W; P.row0 = (S - planes_out) * H * W; }
   P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }

@@ -120,3 +120,57 @@ def transformer_forward(tr, x=None, z=None):
         o, _, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads)
         x, q, kv = layer_fused(o, x, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None)
     return x
+
+
+def cone_planes(S, eS, depth):
+    """Planes each layer has to produce so that the LAST plane of the last layer is exact: need[l] = planes of queries
+    at layer l, src[l] = planes of that layer's input stream (= its key/value planes).  main.py:37 reads x[:, -1] only and
+    a query at plane s sees planes s-eS..s+eS (local_3d_attention.py:95-104), so need[L-1] = 1, need[l] = need[l+1] + eS,
+    capped at S."""
+    need = [0] * depth
+    need[depth - 1] = 1
+    for l in range(depth - 2, -1, -1):
+        need[l] = min(S, need[l + 1] + eS)
+    src = [min(S, need[l] + eS) for l in range(depth)]
+    return need, src
+
+
+def transformer_forward_last(tr, z):
+    """The last plane of transformer_forward(tr, z=z) ([B, H, W, D]) computing only its dependence cone: identical
+    arithmetic per token (bit-identical result), the planes that cannot reach the last frame are never launched."""
+    layers = list(tr.layers)
+    depth = len(layers)
+    B, S, H, W = z.shape
+    HW = H * W
+    eS = int(layers[0][0].fn.extents[0])
+    if any(int(a.fn.extents[0]) != eS for a, _ in layers):
+        return transformer_forward(tr, z=z)[:, -1]
+    need, src = cone_planes(S, eS, depth)
+    dev = z.device
+    bf = torch.bfloat16
+    n0 = src[0]
+    wpack, vec = _layer_pack(None, layers[0])
+    x = torch.empty((B, n0, H, W, D_), dtype=bf, device=dev)
+    q = torch.empty((B, n0, H, W, I_), dtype=bf, device=dev)
+    kv = torch.empty((B, n0, H, W, 2 * I_), dtype=bf, device=dev)
+    L.call('wmz_embed_qkv_fused_fwd_planes', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
+           L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
+           L.ptr(x), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), B, S, H, W, n0, D_, I_, M_,
+           tr.embedding.num_embeddings, 1e-5, L.stream())
+    for l, (attn, ff) in enumerate(layers):
+        n_in, n_q = src[l], need[l]
+        heads = attn.fn.heads
+        ext = attn.fn.extents
+        o = torch.empty((B, n_q, H, W, I_), dtype=bf, device=dev)
+        L.call('wmz_local3d_attn_fwd_planes', L.ptr(q), L.ptr(kv), L.ptr(kv[..., I_:]), L.ptr(o), None,
+               B, n_in, H, W, heads, I_ // heads, int(ext[0]), int(ext[1]), int(ext[2]), I_, 2 * I_, 2 * I_, I_,
+               n_in - n_q, n_q, L.dtype_code(bf), L.stream())
+        tail = layers[l + 1] if l + 1 < depth else None
+        wpack, vec = _layer_pack((attn, ff), tail)
+        xo = torch.empty((B, n_q, H, W, D_), dtype=bf, device=dev)
+        q = torch.empty((B, n_q, H, W, I_), dtype=bf, device=dev) if tail is not None else None
+        kv = torch.empty((B, n_q, H, W, 2 * I_), dtype=bf, device=dev) if tail is not None else None
+        L.call('wmz_layer_fused_fwd_planes', L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
+               B, n_q, n_in, HW, D_, I_, M_, 1, 1 if tail is not None else 0, 1e-5, L.stream())
+        x = xo
+    return x[:, 0]

@@ -18,6 +18,15 @@ class VqVideoDiffusionModel(nn.Module):
         self.logit_proj = nn.Linear(dim, num_classes)
 
     def forward(self, x):
+        if not torch.is_grad_enabled() and x.is_cuda:
+            from . import config, fused
+            if config.get_last_frame_cone() and fused.supported(self.transformer, config.get_compute_dtype()):
+                tr = self.transformer
+                _, S, H, W = x.shape
+                if S > tr.pos_emb_s.num_embeddings or H > tr.pos_emb_h.num_embeddings or W > tr.pos_emb_w.num_embeddings:
+                    raise IndexError('token grid larger than the position-embedding tables')
+                last = fused.transformer_forward_last(tr, x)      # only the planes the last frame depends on
+                return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)
         h = self.transformer(x)
         last = h[:, -1]                       # [B,H,W,D] view: uniform row stride, no copy
         return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)
