@@ -181,7 +181,7 @@ def main():
         ops.local3d_attention_fwd(qa, ka, va, cfg['extents'], cfg['heads'])
 
     def run_fused():
-        fused.layer_fused(oa, xa, layers[0], layers[1])
+        fused.layer_fused(oa, xa, layers[0], layers[1], xflags=3)      # the tiled stream layout, as inside the step
 
     def time_kernel(fn, reps):
         """Average duration of `reps` back-to-back launches: the launches are captured into one hipGraph (so no host

@@ -124,12 +124,13 @@ int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_c
  *                  (to_out + residual, PreNorm(FeedForward) + residual: local_3d_attention.py:50-53, :20-31, :160-161)
  * tail (has_tail): q = Wq' x_out ; k|v = Wkv' LN1'(x_out) + bkv'   (the NEXT layer's to_q / to_k / to_v, :46-48, :106-108;
  *                  without a head the tail reads x directly: the first layer after the embedding)
- * o [ntok, I], x / x_out [ntok, D], q [ntok, I], kv [ntok, 2I], all bf16 contiguous.  wpack: the stage weights as bf16,
- * pre-packed in consumption order (Wout, then for c = 0..3: W1 rows 64c..64c+63, W2 columns 64c..64c+63, then Wq', Wk', Wv';
- * each as [K/32][N][32] with the four 8-element chunks of row n
- * XOR-permuted by (-(n>>2))&3) followed by 64 KB of padding; vec: fp32 bout[D] g2[D] be2[D] b1[M] b2[D] g1'[D] be1'[D] bkv'[2I]
- * (world_modelz_amd/fused.py builds both).  Built for D = 256, I = 128, M = 256; other widths return
- * WMZ_ERR_UNSUPPORTED and callers use the per-op entry points above. */
+ * o [ntok, I], x / x_out [ntok, D], q [ntok, I], kv [2, ntok, I] (the k rows, then the v rows), all bf16 contiguous.
+ * wpack: the stage weights as bf16, pre-packed in consumption order -- Wout, then for c = 0..7: W1' rows 32c..32c+31,
+ * W2 columns 32c..32c+31, then Wq, Wk', Wv' -- as 1 KB MFMA 32x32x16 A operands in (16-deep k-step, 32-feature block)
+ * order, followed by 64 KB of padding; the LayerNorm affines are folded in (W1' = W1 diag(g2), Wk' = Wk diag(g1), ..).
+ * vec: 2048 fp32: bout[D] b1'[M] b2[D] bk'[I] bv'[I] (b1' = b1 + W1 be2, bk' = Wk be1, bv' = bv + Wv be1), zero padded.
+ * world_modelz_amd/fused.py (_pack_w, _layer_pack) builds both and documents the exact element order.  Built for
+ * D = 256, I = 128, M = 256; other widths return WMZ_ERR_UNSUPPORTED and callers use the per-op entry points above. */
 int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
                         const float* vec, int ntok, int D, int I, int M, int has_head, int has_tail, float eps,
                         void* stream);
@@ -148,17 +149,27 @@ int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const float* pos
  *   attention: q / k / v cover all S planes, queries are taken from planes [q_plane0, q_plane0 + q_planes) only and
  *              out / lse are compact [B, q_planes, H, W, ..];
  *   fused layer: x holds planes_in planes per clip, o and the outputs hold its last planes_out planes;
- *   embedding:  z is the full [B, S, H, W] token grid, the outputs hold the last planes_out planes of each clip. */
+ *   embedding:  z is the full [B, S, H, W] token grid, the outputs hold the last planes_out planes of each clip;
+ *   xflags:     WMZ_FUSED_X_IN_TILED / WMZ_FUSED_X_OUT_TILED -- x / x_out in the fused path's private stream layout (per
+ *               32-token tile: [16 chunks][2 halves][32 tokens][8 features], every access of the kernel one contiguous
+ *               KB) instead of row-major; needs whole 32-token tiles per clip.  Layer -> layer only: the last layer
+ *               writes row-major. */
+#define WMZ_FUSED_X_IN_TILED 1
+#define WMZ_FUSED_X_OUT_TILED 2
 int wmz_local3d_attn_fwd_planes(const void* q, const void* k, const void* v, void* out, float* lse, int B, int S, int H,
                                 int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
                                 int q_plane0, int q_planes, int dtype, void* stream);
 int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                const float* vec, int B, int planes_out, int planes_in, int HW, int D, int I, int M,
-                               int has_head, int has_tail, float eps, void* stream);
+                               int has_head, int has_tail, int xflags, float eps, void* stream);
 int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                    const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                    const float* vec, int B, int S, int H, int W, int planes_out, int D, int I, int M,
-                                   int num_classes, float eps, void* stream);
+                                   int num_classes, int xflags, float eps, void* stream);
+
+/* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
+ * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */
+int wmz_debug_fused_timestamps(void* buf);
 
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]

@@ -23,11 +23,13 @@ def timeit(fn, reps=50):
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1000 / reps)
     return sorted(ts)[1]
+import os
+XF = int(os.environ.get('XF', '3'))
 for planes in (1, 4, 8, 16, 32, 64, 128, 256, 512):
     x = torch.randn(planes, 16, 16, 256, device='cuda').bfloat16()
     o = torch.randn(planes, 16, 16, 128, device='cuda').bfloat16()
     with torch.no_grad():
-        ht = timeit(lambda: fused.layer_fused(o, x, L[0], L[1]))
-        h = timeit(lambda: fused.layer_fused(o, x, L[0], None))
+        ht = timeit(lambda: fused.layer_fused(o, x, L[0], L[1], xflags=XF))
+        h = timeit(lambda: fused.layer_fused(o, x, L[0], None, xflags=XF & 1))
         t = timeit(lambda: fused.layer_fused(None, x, None, L[1]))
     print(f'planes {planes:4d} tokens {planes*256:7d} wgs {planes*2:5d}: head+tail {ht:7.1f} us  head {h:7.1f}  tail {t:7.1f}', flush=True)

@@ -5,41 +5,52 @@
 //   TAIL:  q' = Wq' x2 ,  k'|v' = Wkv' LN1'(x2) + bkv'    (NEXT layer's to_q on the raw stream and to_k|to_v on
 //                                                          LayerNorm(x): quirk Q1, :16-17, :46-48, :106-108)
 //
-// Design (MI355X): a workgroup = 8 waves = 128 tokens; each wave owns 16 tokens end to end, so the only thing the waves
-// share is the weight stream.  Every GEMM is computed TRANSPOSED, D^T[features x 16 tokens] = W[features x K] . act^T, with
-// MFMA 16x16x32 bf16: A = weight rows, B = the wave's activation rows -- both K-contiguous row fragments, no transposes --
-// and the token on the lane.  Consequences: the residual stream x1/x2 stays in fp32 REGISTERS across the whole chain
-// (64 VGPRs; two waves per SIMD, so one wave's VALU epilogue (LayerNorm, GELU, packing) overlaps the other's MFMAs);
-// LayerNorm statistics are lane-local sums plus two shuffles; each lane holds 4 consecutive features per accumulator
-// block, so activations are exchanged through a per-wave 8 KB LDS buffer with 8-byte accesses (no workgroup barrier),
-// and every HBM store is a whole row.
-// The layer's 512 KB of weights are pre-packed on the host in exactly the order the kernel consumes them (16 KB slabs of
-// [32-deep k-step][feature][32 k], 16-byte chunks swizzled against bank conflicts) and streamed by LDS-DMA (global_load_lds) into a 4-slot
-// LDS ring with 3 slabs in flight: counted vmcnt + ONE raw s_barrier per slab (= 16 MFMAs per wave).  The feed-forward is
-// walked 64 hidden units at a time (W1 rows -> GELU -> W2 columns), so its activation never exists in full.
+// Design (MI355X): a workgroup = 8 waves = 256 tokens, one workgroup per CU; each wave owns 32 tokens end to end, so the
+// only thing the waves share is the weight stream.  Every GEMM is computed TRANSPOSED with MFMA 32x32x16 bf16,
+// D[32 features x 32 tokens] += W[32 features x 16 k] . act^T[16 k x 32 tokens]: the token sits on the lane, and
+//   * the accumulator of one GEMM IS the B operand of the next (after bf16 packing): the order in which a GEMM walks its
+//     k axis and the order of its output features are free, so the host packs the weights such that lane (token t,
+//     half h) owns the CONTIGUOUS features h*N/2 .. h*N/2+N/2-1 of every activation, in accumulator registers and in
+//     operand registers alike.  Activations never touch LDS; the residual stream stays in fp32 registers across the
+//     whole chain; LayerNorm is lane-local sums plus one cross-half exchange; global loads / stores are 16-byte pieces
+//     of one token row per lane.
+//   * the layer's 512 KB of weights are pre-packed in exactly the order the kernel consumes them -- 1 KB pieces, one
+//     MFMA A operand each (lane l's 16 bytes at l*16: conflict-free ds_read_b128 without a swizzle) -- and streamed by
+//     LDS-DMA into a 4-slot ring of 16 KB slabs, 3 slabs in flight: counted vmcnt + ONE raw s_barrier per slab
+//     (= 16 MFMAs of 32 cycles per wave).  Each A fragment read from LDS feeds 32 tokens: the LDS array runs at half the
+//     rate that would bound the MFMAs (16-token waves with 16x16x32 sit exactly on that bound).
+//   * the feed-forward is walked 32 hidden units at a time (W1 rows -> GELU -> W2 columns), so its activation never
+//     exists in full and the chunk's accumulator (16 registers) is converted in place to the next operand.
 #include "wmz_common.h"
 #include <stdlib.h>
 
+// Compiler + scheduler fence: neither IR passes (memory clobber) nor the machine scheduler (sched_barrier) may move
+// loads across it.  Used to cap how many operand loads are in flight: the register file is the scarce resource here.
+#define WMZ_FENCE()                        \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+
 namespace {
 
-constexpr int FT = 16;          // tokens per wave
+constexpr int TW = 32;          // tokens per wave
 constexpr int FW = 8;           // waves per workgroup (two per SIMD: one's epilogue overlaps the other's MFMAs)
 constexpr int NTHR = FW * 64;
 constexpr int SLAB = 16384;     // bytes per weight slab
+constexpr int PIECES = SLAB / 1024;   // MFMA A operands per slab
 constexpr int RING = 4;         // LDS ring slots: 3 slabs (48 KB) of the weight stream stay in flight
 constexpr int VECB = 8192;      // the layer's bias / LayerNorm vectors (2048 fp32), staged once per workgroup
-constexpr int ACTB = 8192;      // per-wave activation buffer (16 tokens x 256 features bf16)
-constexpr int ZCB = 2048;       // per-wave feed-forward chunk buffer (16 tokens x 64 features bf16)
-constexpr int MC = 64;          // feed-forward hidden chunk: W1 rows / W2 columns streamed MC at a time
+constexpr int MC = 32;          // feed-forward hidden chunk: W1 rows / W2 columns streamed MC at a time
 
 struct FusedParams {
   const bf16_t* o;      // [ntok, I]   attention output               (HEAD)
   const bf16_t* x;      // [ntok, D]   residual stream in
   bf16_t* xo;           // [ntok, D]   residual stream out            (HEAD)
   bf16_t* q;            // [ntok, I]                                   (TAIL)
-  bf16_t* kv;           // [ntok, 2I]                                  (TAIL)
+  bf16_t* kv;           // [2, ntok, I]  k rows, then v rows            (TAIL)
   const char* wpack;    // packed bf16 weights in streaming order (+ RING-1 slabs of padding)
-  const float* vec;     // packed fp32 vectors: bout[D] g2[D] be2[D] b1[M] b2[D] g1n[D] be1n[D] bkv[2I]
+  const float* vec;     // packed fp32 vectors (2048 floats): bout[D] b1'[M] b2[D] bk'[I] bv'[I], LayerNorm affines folded in
   int ntok;
   float eps;
   // EMBED variant (first layer): x is produced in-kernel from the token grid (local_3d_attention.py:140-157)
@@ -48,27 +59,32 @@ struct FusedParams {
   // trailing-planes variant: token t of the compact output grid reads row (t / rows_out) * rows_in + row0 + t % rows_out
   // of x (or of the token grid z); rows_out == 0: identity
   int rows_out, rows_in, row0;
+  // x / x_out in the TILED stream layout (WMZ_FUSED_X_IN_TILED / _OUT_TILED): per 32-token tile [16 chunks][2 halves]
+  // [32 tokens][8 features], i.e. lane (t, h)'s k-step s at ((2 s + h) * 32 + t) * 16 bytes -- every load / store
+  // instruction of the kernel is then one contiguous KB.  Private to the fused path (layer -> layer); the last layer
+  // writes row-major.
+  int xflags;
+  long long* ts;        // timing probe (wmz_debug_fused_timestamps): workgroup 0 writes s_memtime at stage boundaries
 };
+// stage-boundary probe: wave w of workgroup 0 stores the shader clock into ts[w * 64 + slot]
+#define WMZ_TS(slot)                                                                                      \
+  do {                                                                                                    \
+    if (P.ts != nullptr && blockIdx.x == 0 && lane == 0) P.ts[wave * 64 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
 __device__ __forceinline__ long src_row(const FusedParams& P, long t) {
   if (P.rows_out == 0) return t;
   const int c = (int)t / P.rows_out;
   return (long)c * P.rows_in + P.row0 + ((int)t - c * P.rows_out);
 }
 
-// 16-byte-chunk XOR swizzle of an activation row: conflict-free ds_read_b128 of 32 token rows at one k-chunk
-template <int ROWB> __device__ __forceinline__ int aswz(int token) {
-  if constexpr (ROWB >= 256) return (token & 15) << 4;
-  else return ((token >> 1) & 7) << 4;          // 128-byte rows: two rows per 256-byte bank line
-}
-__device__ __forceinline__ float gelu_erf(float v) { return wmz_gelu(v); }
-
 // ---- weight stream: RING-slot LDS ring filled by LDS-DMA (global_load_lds), RING-1 slabs in flight.
 struct WStream {
   int dbg;
   const char* src;     // global address of the next slab to ISSUE (this lane's 16 bytes of piece 0 of its wave)
-  char* ring;          // LDS ring base + this wave's 4 KB quarter
+  char* ring;          // LDS ring base + this wave's 2 KB eighth
   int issue_slot;      // ring slot the next issued slab goes to
   int cur;             // ring slot of the slab being multiplied
+  int extra, extra_n;  // `extra` ordinary stores were issued behind the slabs in flight: the next extra_n waits allow for them
 };
 
 __device__ __forceinline__ void ws_issue(WStream& ws) {
@@ -82,331 +98,492 @@ __device__ __forceinline__ void ws_issue(WStream& ws) {
   ws.issue_slot = ws.issue_slot == RING - 1 ? 0 : ws.issue_slot + 1;
 }
 
-// Before multiplying a slab: this wave's eighth of it has landed (all but the 2*(RING-2) youngest VMEM ops done), then
-// one barrier: every piece landed, and every wave is done with the previous slab, whose slot is refilled right away.
+// Before multiplying a slab: this wave's eighth of it has landed, then one barrier: every piece landed, and every wave is
+// done with the previous slab, whose slot is refilled right away.  vmcnt counts loads, stores and LDS-DMA together in issue
+// order: "landed" = all but the 2*(RING-2) pieces of the two younger slabs are done -- plus, for the three waits that
+// follow a burst of row stores, those stores (they sit between the slabs in flight and must not be waited for).
 __device__ __forceinline__ void ws_acquire(WStream& ws) {
-  if (!(ws.dbg & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  static_assert(2 * (RING - 2) == 4, "vmcnt literal above follows RING (2 LDS-DMA pieces per wave per slab)");
+  static_assert(2 * (RING - 2) == 4, "vmcnt literals below follow RING (2 LDS-DMA pieces per wave per slab)");
+  if (!(ws.dbg & 2)) {
+    if (ws.extra_n > 0) {
+      if (ws.extra == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if (ws.extra == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      --ws.extra_n;
+    } else {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+  }
   __builtin_amdgcn_s_barrier();
   ws_issue(ws);
 }
 __device__ __forceinline__ void ws_release(WStream& ws) { ws.cur = ws.cur == RING - 1 ? 0 : ws.cur + 1; }
+__device__ __forceinline__ void ws_stores(WStream& ws, int n) { ws.extra = n; ws.extra_n = 3; }
 
-// acc^T[N x 16 tokens] += W[N x K] . act^T over K/32 k-steps of the stream (MFMA 16x16x32: A = weight rows, B = the
-// wave's token rows).  act: this wave's LDS buffer, rows = tokens, AROWB bytes per row.
-template <int N, int K, int AROWB>
-__device__ __forceinline__ void gemm_stage(f32x4 (&acc)[N / 16], const char* act, const char* ring0, WStream& ws, int li,
-                                           int g) {
-  constexpr int NB = N / 16;
-  constexpr int KPS = SLAB / (N * 64);          // 32-deep k-steps per slab
-  constexpr int NSLAB = (K / 32) / KPS;
-  static_assert(KPS >= 1 && NSLAB * KPS * 32 == K, "stage depth must be a whole number of slabs");
-  const char* arow = act + li * AROWB;
-  const int asw = aswz<AROWB>(li);
-  const int wchunk = (g ^ ((0 - (li >> 2)) & 3)) * 16;   // physical 16-byte chunk of this lane's weight row (host swizzle)
-#pragma unroll 1
-  for (int s = 0; s < NSLAB; ++s) {
+// acc[NB blocks of 32 features x 32 tokens] += W . act^T over KS 16-deep k-steps; the stream holds the pieces in
+// (k-step, block) order, so a k-step's operand is used by NB independent accumulators.  bget(s) yields the B operand
+// of k-step s (a register array, or an LDS read issued one k-step ahead).
+template <int NB, int KS, typename BGet>
+__device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const char* ring0, WStream& ws, int lane) {
+  constexpr int NP = NB * KS;
+  static_assert(NP % PIECES == 0, "a stage is a whole number of slabs");
+  Frag8<bf16_t> bcur, bnext = bget(0);
+  bcur = bnext;
+#pragma unroll
+  for (int sl = 0; sl < NP / PIECES; ++sl) {
     ws_acquire(ws);
-    const char* slab = ring0 + ws.cur * SLAB;
-    if (ws.dbg & 1) { ws_release(ws); continue; }
+    const char* slab = ring0 + ws.cur * SLAB + lane * 16;
+    if (!(ws.dbg & 1)) {
+      // A operands: groups of AG, the next group's ds_reads in flight under this group's MFMAs (8 fragments live, no more:
+      // the scheduler is fenced so that it cannot hoist the whole slab's reads into registers the chain needs)
+      constexpr int AG = 4;
+      Frag8<bf16_t> af[2][AG];
 #pragma unroll
-    for (int t = 0; t < KPS; ++t) {
-      const int ks = s * KPS + t;
-      Frag8<bf16_t> bf;
-      bf.v = *reinterpret_cast<const s16x8*>(arow + (((ks * 4 + g) << 4) ^ asw));
+      for (int j = 0; j < AG; ++j) af[0][j].v = *reinterpret_cast<const s16x8*>(slab + j * 1024);
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        Frag8<bf16_t> af;
-        af.v = *reinterpret_cast<const s16x8*>(slab + t * (N * 64) + (16 * b + li) * 64 + wchunk);
-        mma16(acc[b], af, bf);
+      for (int gq = 0; gq < PIECES / AG; ++gq) {
+        if (gq + 1 < PIECES / AG) {
+#pragma unroll
+          for (int j = 0; j < AG; ++j)
+            af[(gq + 1) & 1][j].v = *reinterpret_cast<const s16x8*>(slab + ((gq + 1) * AG + j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < AG; ++j) {
+          const int idx = sl * PIECES + gq * AG + j;
+          if (idx % NB == 0) {
+            bcur = bnext;
+            if (idx / NB + 1 < KS) bnext = bget(idx / NB + 1);
+          }
+          mma32(acc[idx % NB], af[gq & 1][j], bcur);
+        }
+        WMZ_FENCE();
       }
     }
     ws_release(ws);
   }
 }
-
-// accumulator block b of lane group g holds features n0 .. n0+3 of the lane's token
-__device__ __forceinline__ int quad_n0(int b, int g) { return 16 * b + 4 * g; }
-
-template <int NB>
-__device__ __forceinline__ void add_vec(f32x4 (&acc)[NB], const float* vec, int g) {   // vec offset to feature 0 of acc
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(vec + quad_n0(b, g));
-    acc[b] += v;
-  }
+template <int NB, int KS>
+__device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[KS], const char* ring0, WStream& ws,
+                                           int lane) {
+  gemm_stage_b<NB, KS>(acc, [&](int s) { return bop[s]; }, ring0, ws, lane);
 }
 
-// acc += the lane's token row of a global [ntok, NB*16] bf16 tensor (8-byte loads in the accumulator layout)
+__device__ __forceinline__ f32x16 lds_vec16(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  const f32x4 c = *reinterpret_cast<const f32x4*>(p + 8), d = *reinterpret_cast<const f32x4*>(p + 12);
+  f32x16 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; v[8 + i] = c[i]; v[12 + i] = d[i]; }
+  return v;
+}
 template <int NB>
-__device__ __forceinline__ void add_row_global(f32x4 (&acc)[NB], const bf16_t* src, long tok, bool ok, int g) {
-  const bf16_t* row = src + tok * (NB * 16);
+__device__ __forceinline__ void add_vec(f32x16 (&acc)[NB], const float* vec /* + h*16*NB */) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    s16x4 pk = (s16x4)(0);
-    if (ok) pk = *reinterpret_cast<const s16x4*>(row + quad_n0(b, g));
+  for (int b = 0; b < NB; ++b) acc[b] += lds_vec16(vec + 16 * b);
+}
+// accumulators that start at the bias: the add rides in the MFMA chain
+template <int NB>
+__device__ __forceinline__ void init_vec(f32x16 (&acc)[NB], const float* vec) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[b][r] += bf16_bits_to_f32((unsigned short)pk[r]);
-  }
+  for (int b = 0; b < NB; ++b) acc[b] = lds_vec16(vec + 16 * b);
 }
 
-// write the wave's [16 tokens x NB*16 features] tile (bf16) into columns n_off.. of an LDS buffer with ROWF-feature rows
-template <int NB, int ROWF, typename F>
-__device__ __forceinline__ void tile_to_lds(char* act, const f32x4 (&acc)[NB], int n_off, int li, int g, F f) {
-  constexpr int ROWB = ROWF * 2;
-  char* row = act + li * ROWB;
-  const int sw = aswz<ROWB>(li);
+// The empty asm pins the packed operand HERE: without it the compiler sinks the conversion arithmetic down to the MFMA
+// that consumes it and keeps the fp32 sources (and every gamma / beta / bias fetched for them) alive until then.
+__device__ __forceinline__ void pack8(Frag8<bf16_t>& f, const float (&y)[8]) {
+  s16x8 v;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int n0 = n_off + quad_n0(b, g);
-    s16x4 pk;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(f(acc[b][r]));
-    *reinterpret_cast<s16x4*>(row + ((n0 * 2) ^ sw)) = pk;
-  }
+  for (int j = 0; j < 8; ++j) v[j] = (short)f32_to_bf16_bits(y[j]);
+  asm volatile("" : "+v"(v));
+  f.v = v;
 }
 
-// LayerNorm of the token held by this lane quartet (features split over the 4 lane groups) -> bf16 -> LDS buffer
-template <int NB>
-__device__ __forceinline__ void ln_to_lds(char* act, const f32x4 (&acc)[NB], const float* gamma, const float* beta,
-                                          float eps, int li, int g) {
-  constexpr int NF = NB * 16, ROWB = NF * 2;
-  float s = 0.f;
+// operand k-step s of a K-feature activation = features h*K/2 + 8*s .. +7 of the lane's token: the lane's half row.
+// Unconditional loads (rows past ntok are clamped by the caller to a valid row; their results are never stored): a
+// predicated load makes hipcc branch around it and wait for each one in turn -- one L2 round trip per 16 bytes.
+template <int KS>
+__device__ __forceinline__ void load_bop(Frag8<bf16_t> (&bop)[KS], const bf16_t* half_row) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) s += (acc[b][0] + acc[b][1]) + (acc[b][2] + acc[b][3]);
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
-  const float mean = s / (float)NF;
-  float q = 0.f;
+  for (int s = 0; s < KS; ++s) bop[s].v = *reinterpret_cast<const s16x8*>(half_row + 8 * s);
+}
+
+// A load the compiler does not know about: no automatic s_waitcnt (which, with LDS-DMA in flight, is always vmcnt(0)).
+// Its result may only be used behind wait_untracked().
+__device__ __forceinline__ s16x8 gload_untracked(const bf16_t* p) {
+  s16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// vmcnt is in issue order: once at most the ring's 2*(RING-1) youngest pieces are outstanding, every older load is done.
+template <int KS>
+__device__ __forceinline__ void wait_untracked(Frag8<bf16_t> (&b)[KS]) {
+  static_assert(2 * (RING - 1) == 6, "literal below");
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(b[s].v));       // uses stay behind the wait
+}
+// the 8 KB vector block by LDS-DMA: wave w moves KB w
+__device__ __forceinline__ void vec_dma(float* vecs, const float* src, int wave, int lane) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wave * 256 + lane * 4),
+                                   (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(vecs) + wave * 1024), 16, 0, 0);
+}
+template <int NB>
+__device__ __forceinline__ void add_bop(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[2 * NB]) {
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const float d = acc[b][r] - mean; q = fmaf(d, d, q); }
-  q += __shfl_xor(q, 16);
-  q += __shfl_xor(q, 32);
-  const float rstd = rsqrtf(q / (float)NF + eps);
-  char* row = act + li * ROWB;
-  const int sw = aswz<ROWB>(li);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int n0 = quad_n0(b, g);
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + n0);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + n0);
-    s16x4 pk;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits((acc[b][r] - mean) * rstd * gm[r] + be[r]);
-    *reinterpret_cast<s16x4*>(row + ((n0 * 2) ^ sw)) = pk;
-  }
+    for (int i = 0; i < 16; ++i) acc[b][i] += bf16_bits_to_f32((unsigned short)bop[2 * b + (i >> 3)].v[i & 7]);
 }
 
-// global [tok0.., F] bf16 rows -> the wave's LDS buffer (coalesced 16-byte chunks); rows >= ntok are zero
-template <int F>
-__device__ __forceinline__ void rows_to_lds(char* act, const bf16_t* src, long tok0, int ntok, int lane) {
-  constexpr int ROWB = F * 2, CPR = ROWB / 16, TOT = FT * CPR;
+template <int KS>
+__device__ __forceinline__ void load_bop_tiled(Frag8<bf16_t> (&bop)[KS], const bf16_t* tile, int lane) {
 #pragma unroll
-  for (int i = 0; i < TOT / 64; ++i) {
-    const int idx = lane + 64 * i;
-    const int r = idx / CPR, c = idx - r * CPR;
-    i32x4 v = (i32x4)(0);
-    if (tok0 + r < ntok) v = *reinterpret_cast<const i32x4*>(src + (tok0 + r) * F + c * 8);
-    *reinterpret_cast<i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r))) = v;
-  }
+  for (int s = 0; s < KS; ++s) bop[s].v = *reinterpret_cast<const s16x8*>(tile + (s * 64 + lane) * 8);   // (2s+h)*32+t = 64s+lane
 }
-// same, split: issue the global loads early (registers), write them to LDS late (T14: the GEMM in between hides them)
-template <int F>
-__device__ __forceinline__ void rows_fetch(i32x4 (&regs)[FT * (F * 2 / 16) / 64], const bf16_t* src, long tok0, int ntok, int lane,
-                                           const FusedParams& P) {
-  constexpr int CPR = F * 2 / 16, TOT = FT * CPR;
+template <int KS>
+__device__ __forceinline__ void store_bop_tiled(bf16_t* tile, const Frag8<bf16_t> (&bop)[KS], int lane) {
 #pragma unroll
-  for (int i = 0; i < TOT / 64; ++i) {
-    const int idx = lane + 64 * i;
-    const int r = idx / CPR, c = idx - r * CPR;
-    regs[i] = (i32x4)(0);
-    if (tok0 + r < ntok) regs[i] = *reinterpret_cast<const i32x4*>(src + src_row(P, tok0 + r) * F + c * 8);
-  }
-}
-template <int F>
-__device__ __forceinline__ void rows_put(char* act, const i32x4 (&regs)[FT * (F * 2 / 16) / 64], int lane) {
-  constexpr int ROWB = F * 2, CPR = ROWB / 16, TOT = FT * CPR;
-#pragma unroll
-  for (int i = 0; i < TOT / 64; ++i) {
-    const int idx = lane + 64 * i;
-    const int r = idx / CPR, c = idx - r * CPR;
-    *reinterpret_cast<i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r))) = regs[i];
-  }
-}
-// the wave's LDS buffer -> global rows, whole rows per store instruction
-template <int F>
-__device__ __forceinline__ void lds_to_rows(bf16_t* dst, const char* act, long tok0, int ntok, int lane) {
-  constexpr int ROWB = F * 2, CPR = ROWB / 16, TOT = FT * CPR;
-#pragma unroll
-  for (int i = 0; i < TOT / 64; ++i) {
-    const int idx = lane + 64 * i;
-    const int r = idx / CPR, c = idx - r * CPR;
-    const i32x4 v = *reinterpret_cast<const i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r)));
-    if (tok0 + r < ntok) *reinterpret_cast<i32x4*>(dst + (tok0 + r) * F + c * 8) = v;
-  }
-}
-// read the lane's token row back from LDS into the accumulator layout (fp32)
-template <int NB, bool ADD>
-__device__ __forceinline__ void lds_to_acc(f32x4 (&acc)[NB], const char* act, int li, int g) {
-  constexpr int ROWB = NB * 16 * 2;
-  const char* row = act + li * ROWB;
-  const int sw = aswz<ROWB>(li);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const s16x4 pk = *reinterpret_cast<const s16x4*>(row + ((quad_n0(b, g) * 2) ^ sw));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[b][r] = (ADD ? acc[b][r] : 0.f) + bf16_bits_to_f32((unsigned short)pk[r]);
-  }
+  for (int s = 0; s < KS; ++s) *reinterpret_cast<s16x8*>(tile + (s * 64 + lane) * 8) = bop[s].v;
 }
 
-template <int N> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[N]) {
+// Row stores through the wave's private 8 KB LDS buffer: a lane owns HALF A ROW of its token, so direct 16-byte stores
+// would scatter 64 pieces per instruction over 32 rows (measured: ~570 cycles per store instruction, and the LDS-DMA
+// weight stream queues behind them).  Instead: the lanes write their pieces into a [32 rows x 256 B] image (16-byte
+// chunk c of row r at chunk c ^ (r & 15): conflict-free both ways), then the wave copies the image out 1 KB per
+// instruction, whole 256-byte runs per row.
+// LDS-DMA a [32 tokens x 128 features] tile (rows of ROWF features, 256 B of each from column col0) into the wave's image,
+// same chunk swizzle as the store path (applied on the source address: the DMA writes lane-linear).
+__device__ __forceinline__ void stage_dma128(char* stg, const bf16_t* src, int rowf, long tok0, int ntok, int lane) {
 #pragma unroll
-  for (int b = 0; b < N; ++b) acc[b] = (f32x4)(0.f);
+  for (int p = 0; p < 8; ++p) {
+    const int r = p * 4 + (lane >> 4), pc = lane & 15;
+    const long row = tok0 + r < ntok ? tok0 + r : ntok - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * rowf + ((pc ^ (r & 15)) << 3)),
+                                     (__attribute__((address_space(3))) void*)(stg + p * 1024), 16, 0, 0);
+  }
 }
-
-// token + 3-axis position embedding of the wave's 16 tokens -> LDS buffer (bf16, the tail's operand) and x_out (bf16)
-template <int F>
-__device__ __forceinline__ void embed_rows(char* act, const FusedParams& P, long tok0, int lane) {
-  constexpr int ROWB = F * 2, CPR = ROWB / 16, TOT = FT * CPR;
+__device__ __forceinline__ Frag8<bf16_t> stage_get(const char* stg, int t, int c) {
+  Frag8<bf16_t> f;
+  f.v = *reinterpret_cast<const s16x8*>(stg + t * 256 + ((c ^ (t & 15)) << 4));
+  return f;
+}
+__device__ __forceinline__ void stage_put(char* stg, const s16x8& v, int t, int c) {
+  *reinterpret_cast<s16x8*>(stg + t * 256 + ((c ^ (t & 15)) << 4)) = v;
+}
+// copy the 8 KB image out: row r of the image -> dst + (tok0 + r) * ROWF + col0, 128 features (256 B) per row
+template <int ROWF>
+__device__ __forceinline__ void stage_flush(const char* stg, bf16_t* dst, long tok0, int ntok, int col0, int lane) {
+  asm volatile("" : "+s"(tok0), "+v"(lane));   // compute the store addresses HERE (hoisted / shared with the prologue's
+                                               // index math they only get spilled)
 #pragma unroll
-  for (int i = 0; i < TOT / 64; ++i) {
-    const int idx = lane + 64 * i;
-    const int r = idx / CPR, c = idx - r * CPR;
-    const long t = tok0 + r;
-    i32x4 v = (i32x4)(0);
-    if (t < P.ntok) {
-      const long ts = src_row(P, t);
-      const int w = (int)(ts % P.W), h = (int)((ts / P.W) % P.H), s = (int)((ts / ((long)P.W * P.H)) % P.S);
-      long tk = P.z[ts];
-      tk = tk < 0 ? 0 : (tk >= P.num_classes ? P.num_classes - 1 : tk);
-      float f[8];
+  for (int p = 0; p < 8; ++p) {
+    const int r = p * 4 + (lane >> 4), pc = lane & 15;
+    const s16x8 v = *reinterpret_cast<const s16x8*>(stg + p * 1024 + lane * 16);
+    const int c = pc ^ (r & 15);
+    if (tok0 + r < ntok) *reinterpret_cast<s16x8*>(dst + (tok0 + r) * ROWF + col0 + c * 8) = v;
+  }
+}
+// an I-feature tile (q, k, v: 128 features, every lane holds 8 chunks of its row): one pass
+__device__ __forceinline__ void store_tile128(char* stg, bf16_t* dst, int rowf, long tok0, int ntok, int col0,
+                                              const Frag8<bf16_t> (&b)[8], int lane) {
+  const int t = lane & 31, h = lane >> 5;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int col = c * 8 + 4 * q;
-        const f32x4 e = *reinterpret_cast<const f32x4*>(P.emb + tk * F + col);
-        const f32x4 a = *reinterpret_cast<const f32x4*>(P.pos_s + (long)s * F + col);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(P.pos_h + (long)h * F + col);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(P.pos_w + (long)w * F + col);
-        const f32x4 y = e + ((a + b) + d);
+  for (int s = 0; s < 8; ++s) stage_put(stg, b[s].v, t, h * 8 + s);
+  if (rowf == 128) stage_flush<128>(stg, dst, tok0, ntok, col0, lane);
+  else stage_flush<256>(stg, dst, tok0, ntok, col0, lane);
+}
+// the D-feature stream (256 features, a lane holds 16 chunks = its whole 256-byte half row): one pass per lane half
+__device__ __forceinline__ void store_tile256(char* stg, bf16_t* dst, long tok0, int ntok, const Frag8<bf16_t> (&b)[16],
+                                              int lane) {
+  const int t = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f[4 * q + k] = y[k];
-      }
+  for (int hh = 0; hh < 2; ++hh) {
+    if (h == hh) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        v[k] = (int)((unsigned)f32_to_bf16_bits(f[2 * k]) | ((unsigned)f32_to_bf16_bits(f[2 * k + 1]) << 16));
-      *reinterpret_cast<i32x4*>(P.xo + t * F + c * 8) = v;
+      for (int s = 0; s < 16; ++s) stage_put(stg, b[s].v, t, s);
     }
-    *reinterpret_cast<i32x4*>(act + r * ROWB + ((c << 4) ^ aswz<ROWB>(r))) = v;
+    stage_flush<256>(stg, dst, tok0, ntok, hh * 128, lane);
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void acc_from_bop(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[2 * NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[b][i] = bf16_bits_to_f32((unsigned short)bop[2 * b + (i >> 3)].v[i & 7]);
+}
+template <int NB>
+__device__ __forceinline__ void bop_from_acc(Frag8<bf16_t> (&bop)[2 * NB], const f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = acc[b][8 * m + j];
+      pack8(bop[2 * b + m], y);
+    }
+}
+
+// LayerNorm statistics of the lane pair's token (features split over the two lane halves): rstd and -mean*rstd
+template <int NB>
+__device__ __forceinline__ void ln_stats(const f32x16 (&acc)[NB], float eps, float& rstd, float& mr) {
+  constexpr int NF = NB * 32;
+  f32x16 sv = acc[0];
+#pragma unroll
+  for (int b = 1; b < NB; ++b) sv += acc[b];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += sv[i];
+  s += __shfl_xor(s, 32);
+  const float mean = s / (float)NF;
+  f32x16 qv = (f32x16)(0.f);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { const f32x16 d = acc[b] - mean; qv += d * d; }
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) q += qv[i];
+  q += __shfl_xor(q, 32);
+  rstd = rsqrtf(q / (float)NF + eps);
+  mr = -mean * rstd;
+}
+// one block: x*rstd - mean*rstd -> two bf16 operands (the LayerNorm affine lives in the weights that consume it).
+// Not (x - mean)*rstd: the variance pass used x - mean, and reusing it would keep a second copy of the row alive.
+__device__ __forceinline__ void ln_block(Frag8<bf16_t>& lo, Frag8<bf16_t>& hi, const f32x16& x, float rstd, float mr) {
+  const f32x16 y = x * rstd + mr;
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = y[j]; b[j] = y[8 + j]; }
+  pack8(lo, a);
+  pack8(hi, b);
+}
+template <int NB>
+__device__ __forceinline__ void ln_to_bop(Frag8<bf16_t> (&bop)[2 * NB], const f32x16 (&acc)[NB], float eps) {
+  float rstd, mr;
+  ln_stats<NB>(acc, eps, rstd, mr);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) ln_block(bop[2 * b], bop[2 * b + 1], acc[b], rstd, mr);
+}
+// x2 (fp32) -> normalised operand and x2 itself as bf16, block by block (each block of xr dies as its operands appear)
+template <int NB>
+__device__ __forceinline__ void ln_and_pack(Frag8<bf16_t> (&lnb)[2 * NB], Frag8<bf16_t> (&xb)[2 * NB], const f32x16 (&acc)[NB],
+                                            float eps) {
+  float rstd, mr;
+  ln_stats<NB>(acc, eps, rstd, mr);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    ln_block(lnb[2 * b], lnb[2 * b + 1], acc[b], rstd, mr);
+    float a[8], c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = acc[b][j]; c[j] = acc[b][8 + j]; }
+    pack8(xb[2 * b], a);
+    pack8(xb[2 * b + 1], c);
+  }
+}
+
+template <int N> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
+#pragma unroll
+  for (int b = 0; b < N; ++b) acc[b] = (f32x16)(0.f);
+}
+
+// token + 3-axis position embedding of the lane's half row, rounded to bf16 (the value the stream carries)
+template <int F>
+__device__ __forceinline__ void embed_bop(Frag8<bf16_t> (&bop)[F / 16], const FusedParams& P, long t, bool ok, int h) {
+  (void)ok;                                              // t is already clamped to a valid token
+  const long ts = src_row(P, t);
+  const int w = (int)(ts % P.W), hh = (int)((ts / P.W) % P.H), s = (int)((ts / ((long)P.W * P.H)) % P.S);
+  long tk = P.z[ts];
+  tk = tk < 0 ? 0 : (tk >= P.num_classes ? P.num_classes - 1 : tk);
+  const float* e = P.emb + tk * F + h * (F / 2);
+  const float* a = P.pos_s + (long)s * F + h * (F / 2);
+  const float* b = P.pos_h + (long)hh * F + h * (F / 2);
+  const float* d = P.pos_w + (long)w * F + h * (F / 2);
+#pragma unroll
+  for (int c = 0; c < F / 16; ++c) {
+    float y[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 ev = *reinterpret_cast<const f32x4*>(e + 8 * c + 4 * q);
+      const f32x4 av = *reinterpret_cast<const f32x4*>(a + 8 * c + 4 * q);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b + 8 * c + 4 * q);
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(d + 8 * c + 4 * q);
+      const f32x4 yv = ev + ((av + bv) + dv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[4 * q + r] = yv[r];
+    }
+    pack8(bop[c], y);
+    if ((c & 1) == 1) WMZ_FENCE();     // 32 loads in flight, not 128
   }
 }
 
 template <int D, int I, int M, bool HEAD, bool TAIL>
-__global__ __launch_bounds__(NTHR, 2) void layer_fused_kernel(FusedParams P) {
+__global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   static_assert(D == 256 && M == 256 && I == 128, "built for the default denoiser widths");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, g = lane >> 4;
-  char* actA = smem + wave * ACTB;
-  char* zc = smem + FW * ACTB + wave * ZCB;
-  float* vecs = reinterpret_cast<float*>(smem + FW * (ACTB + ZCB));
-  const char* ring0 = smem + FW * (ACTB + ZCB) + VECB;
+  const int h = lane >> 5;
+  float* vecs = reinterpret_cast<float*>(smem);
+  const char* ring0 = smem + VECB;
   WStream ws;
-  ws.ring = smem + FW * (ACTB + ZCB) + VECB + wave * 2048;
+  ws.ring = smem + VECB + wave * 2048;
   ws.src = P.wpack + wave * 2048 + lane * 16;
   ws.issue_slot = 0;
   ws.cur = 0;
   ws.dbg = P.dbg;
-  const long tok0 = (long)blockIdx.x * (FT * FW) + wave * FT;
-  const bool tok_ok = tok0 + li < P.ntok;
-  // per-feature vectors: one coalesced copy into LDS (reading them from L2 inside the epilogues exposed ~150 dependent
-  // load latencies per wave)
-  *reinterpret_cast<f32x4*>(vecs + tid * 4) = *reinterpret_cast<const f32x4*>(P.vec + tid * 4);
-  static_assert(NTHR * 4 == 7 * 256 + 256, "vector block is 2048 floats");
-  const float* v_bout = vecs;
-  const float* v_g2 = v_bout + D;
-  const float* v_be2 = v_g2 + D;
-  const float* v_b1 = v_be2 + D;
-  const float* v_b2 = v_b1 + M;
-  const float* v_g1n = v_b2 + D;
-  const float* v_be1n = v_g1n + D;
-  const float* v_bkv = v_be1n + D;
+  ws.extra = 0; ws.extra_n = 0;
+  WMZ_TS(0);
+  const long tok0 = (long)blockIdx.x * (TW * FW) + wave * TW;        // first token of this wave
+  const long tok = tok0 + (lane & 31);
+  const long tokc = tok < P.ntok ? tok : P.ntok - 1;                  // clamped: loads are unconditional
+  char* stg = smem + VECB + RING * SLAB + wave * 8192;                // this wave's store-staging image
+  static_assert(NTHR * 4 == 2048 && FW * 1024 == VECB, "vector block is 2048 floats, one KB per wave");
+  const float* v_bout = vecs + h * (D / 2);                            // bout[D] b1'[M] b2[D] bk'[I] bv'[I]
+  const float* v_b1 = vecs + D + h * (MC / 2);
+  const float* v_b2 = vecs + D + M + h * (D / 2);
+  const float* v_bk = vecs + 2 * D + M + h * (I / 2);
+  const float* v_bv = v_bk + I;
 
-  __syncthreads();                                   // vectors visible
-#pragma unroll
-  for (int i = 0; i < RING - 1; ++i) ws_issue(ws);   // prime: RING-1 slabs in flight
-
-  f32x4 xr[D / 16];                          // the residual stream of this lane's token (1/4 of its features), fp32
+  f32x16 xr[D / 32];                         // the residual stream of this lane's token (its half of the features), fp32
+  Frag8<bf16_t> xb[D / 16];                  // a D-feature bf16 operand: LN output / the stream as stored
   if constexpr (HEAD) {
-    rows_to_lds<I>(actA, P.o, tok0, P.ntok, lane);
-    i32x4 xpre[FT * (D * 2 / 16) / 64];
-    rows_fetch<D>(xpre, P.x, tok0, P.ntok, lane, P);                      // residual rows: in flight under the first GEMM
-    zero_acc(xr);
-    gemm_stage<D, I, I * 2>(xr, actA, ring0, ws, li, g);               // o Wout^T
-    add_vec<D / 16>(xr, v_bout, g);
-    rows_put<D>(actA, xpre, lane);                                     // (o tile is dead) x rows -> LDS, coalesced
-    lds_to_acc<D / 16, true>(xr, actA, li, g);                         // + x            -> x1
-    ln_to_lds<D / 16>(actA, xr, v_g2, v_be2, P.eps, li, g);            // LN2(x1) -> actA
+    // Everything the chain needs is requested up front, most urgent first, and nothing is waited for as a whole: the o
+    // tile and the vectors by LDS-DMA, three weight slabs, then the residual rows (needed only after the first GEMM) by
+    // loads the compiler does not track (it would drain the whole queue, weight ring included, at their first use).
+    stage_dma128(stg, P.o, I, tok0, P.ntok, lane);                     // o tile -> the wave's LDS image (coalesced)
+    vec_dma(vecs, P.vec, wave, lane);
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) ws_issue(ws);                   // prime: RING-1 slabs in flight
+    const bool xt = (P.xflags & WMZ_FUSED_X_IN_TILED) != 0;
+    {
+      const bf16_t* xp = xt ? P.x + src_row(P, tok0) * D + lane * 8 : P.x + src_row(P, tokc) * D + h * (D / 2);
+      const int xs = xt ? 64 * 8 : 8;                                  // elements between consecutive k-steps
+#pragma unroll
+      for (int s = 0; s < D / 16; ++s) xb[s].v = gload_untracked(xp + s * xs);
+    }
+    ws_stores(ws, D / 16);                                             // 16 younger loads sit behind the primed slabs
+    WMZ_TS(1);
+    asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                  // o tile + vectors landed (6 slab pieces + 16 loads may fly)
+    __builtin_amdgcn_s_barrier();                                      // everyone's share of the vectors did
+    WMZ_TS(44);
+    init_vec<D / 32>(xr, v_bout);
+    WMZ_TS(2);
+    {
+      const int t = lane & 31;
+      gemm_stage_b<D / 32, I / 16>(xr, [&](int ks) { return stage_get(stg, t, h * (I / 16) + ks); }, ring0, ws, lane);
+    }                                                                  // o Wout^T + bout
+    wait_untracked<D / 16>(xb);                                        // the residual rows are older than the ring's 6 pieces
+    WMZ_TS(45);
+    add_bop<D / 32>(xr, xb);                                           // + x  -> x1
+    WMZ_TS(3);
+    ln_to_bop<D / 32>(xb, xr, P.eps);                     // LN2(x1)
+    WMZ_TS(4);
 #pragma unroll 1
     for (int c = 0; c < M / MC; ++c) {                                 // feed-forward, MC hidden units at a time
-      f32x4 z[MC / 16];
-      zero_acc(z);
-      gemm_stage<MC, D, D * 2>(z, actA, ring0, ws, li, g);             // W1[c] LN2(x1)
-      add_vec<MC / 16>(z, v_b1 + c * MC, g);
-      tile_to_lds<MC / 16, MC>(zc, z, 0, li, g, [](float v) { return gelu_erf(v); });
-      gemm_stage<D, MC, MC * 2>(xr, zc, ring0, ws, li, g);             // x1 += W2[:, c] GELU(.)
+      f32x16 z[1];
+      init_vec<1>(z, v_b1 + c * MC);                                   // b1[c]
+      gemm_stage<1, D / 16>(z, xb, ring0, ws, lane);                   // + W1[c] LN2(x1)
+      WMZ_TS(5 + 3 * c);
+      Frag8<bf16_t> gb[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = wmz_gelu_fast(z[0][8 * m + j]);
+        pack8(gb[m], y);
+      }
+      WMZ_TS(6 + 3 * c);
+      gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane);            // x1 += W2[:, c] GELU(.)
+      WMZ_TS(7 + 3 * c);
     }
-    add_vec<D / 16>(xr, v_b2, g);                                      //                 -> x2
-    tile_to_lds<D / 16, D>(actA, xr, 0, li, g, [](float v) { return v; });
-    lds_to_rows<D>(P.xo, actA, tok0, P.ntok, lane);
+    add_vec<D / 32>(xr, v_b2);                                         //                 -> x2
+    Frag8<bf16_t> x2b[D / 16];                                         // x2 as the stream carries it
+    if constexpr (TAIL) ln_and_pack<D / 32>(xb, x2b, xr, P.eps);   // + LN1'(x2), while x2 is still fp32
+    else bop_from_acc<D / 32>(x2b, xr);
+    WMZ_TS(30);
+    if (P.xflags & WMZ_FUSED_X_OUT_TILED) store_bop_tiled<D / 16>(P.xo + tok0 * D, x2b, lane);
+    else store_tile256(stg, P.xo, tok0, P.ntok, x2b, lane);
+    ws_stores(ws, 16);
+    WMZ_TS(31);
+    if constexpr (TAIL) {
+      f32x16 qa[I / 32];
+      zero_acc(qa);
+      gemm_stage<I / 32, D / 16>(qa, x2b, ring0, ws, lane);            // to_q on the raw stream
+      WMZ_TS(32);
+      Frag8<bf16_t> qb[I / 16];
+      bop_from_acc<I / 32>(qb, qa);
+      store_tile128(stg, P.q, I, tok0, P.ntok, 0, qb, lane);
+      ws_stores(ws, 8);
+    }
   } else {
-    if (P.z != nullptr) embed_rows<D>(actA, P, tok0, lane);          // first layer: x = embedding, also written to x_out
-    else {
-      i32x4 xpre[FT * (D * 2 / 16) / 64];
-      rows_fetch<D>(xpre, P.x, tok0, P.ntok, lane, P);
-      rows_put<D>(actA, xpre, lane);
+    if (P.z != nullptr) embed_bop<D>(xb, P, tokc, true, h);          // first layer: x = embedding, also written to x_out
+    else if (P.xflags & WMZ_FUSED_X_IN_TILED) load_bop_tiled<D / 16>(xb, P.x + src_row(P, tok0) * D, lane);
+    else load_bop<D / 16>(xb, P.x + src_row(P, tokc) * D + h * (D / 2));
+    const f32x4 vecv = *reinterpret_cast<const f32x4*>(P.vec + tid * 4);
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) ws_issue(ws);
+    *reinterpret_cast<f32x4*>(vecs + tid * 4) = vecv;
+    __syncthreads();
+    if (P.z != nullptr) {
+      if (P.xflags & WMZ_FUSED_X_OUT_TILED) store_bop_tiled<D / 16>(P.xo + tok0 * D, xb, lane);
+      else store_tile256(stg, P.xo, tok0, P.ntok, xb, lane);
+      ws_stores(ws, 16);
     }
-    lds_to_acc<D / 16, false>(xr, actA, li, g);
+    {
+      f32x16 qa[I / 32];
+      zero_acc(qa);
+      gemm_stage<I / 32, D / 16>(qa, xb, ring0, ws, lane);             // to_q on the raw stream
+      Frag8<bf16_t> qb[I / 16];
+      bop_from_acc<I / 32>(qb, qa);
+      store_tile128(stg, P.q, I, tok0, P.ntok, 0, qb, lane);
+      ws_stores(ws, 8);
+    }
+    acc_from_bop<D / 32>(xr, xb);
+    ln_to_bop<D / 32>(xb, xr, P.eps);                   // LN1'(x)
   }
   if constexpr (TAIL) {
-    {                                                                  // to_q on the raw stream (actA = x2, bf16)
-      f32x4 qa[I / 16];
-      zero_acc(qa);
-      gemm_stage<I, D, D * 2>(qa, actA, ring0, ws, li, g);
-      tile_to_lds<I / 16, I>(actA, qa, 0, li, g, [](float v) { return v; });
-      lds_to_rows<I>(P.q, actA, tok0, P.ntok, lane);
-    }
-    ln_to_lds<D / 16>(actA, xr, v_g1n, v_be1n, P.eps, li, g);          // LN1'(x2) -> actA
-    f32x4 ka[I / 16], va[I / 16];
-    zero_acc(ka);
-    zero_acc(va);
-    gemm_stage<I, D, D * 2>(ka, actA, ring0, ws, li, g);               // to_k
-    gemm_stage<I, D, D * 2>(va, actA, ring0, ws, li, g);               // to_v
-    add_vec<I / 16>(ka, v_bkv, g);
-    add_vec<I / 16>(va, v_bkv + I, g);
-    tile_to_lds<I / 16, 2 * I>(actA, ka, 0, li, g, [](float v) { return v; });
-    tile_to_lds<I / 16, 2 * I>(actA, va, I, li, g, [](float v) { return v; });
-    lds_to_rows<2 * I>(P.kv, actA, tok0, P.ntok, lane);
+    f32x16 ka[I / 32];
+    Frag8<bf16_t> kb[I / 16];
+    init_vec<I / 32>(ka, v_bk);
+    WMZ_TS(33);
+    gemm_stage<I / 32, D / 16>(ka, xb, ring0, ws, lane);               // to_k
+    WMZ_TS(34);
+    bop_from_acc<I / 32>(kb, ka);
+    store_tile128(stg, P.kv, I, tok0, P.ntok, 0, kb, lane);                       // k rows
+    ws_stores(ws, 8);
+    init_vec<I / 32>(ka, v_bv);
+    WMZ_TS(35);
+    gemm_stage<I / 32, D / 16>(ka, xb, ring0, ws, lane);               // to_v
+    WMZ_TS(36);
+    bop_from_acc<I / 32>(kb, ka);
+    store_tile128(stg, P.kv + (long)P.ntok * I, I, tok0, P.ntok, 0, kb, lane);    // v rows, behind the k rows
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the padding slabs still in flight target this workgroup's LDS
+  WMZ_TS(37);
 }
 
 }  // namespace
 
 static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_head, int has_tail, void* stream);
+static long long* g_fused_ts = nullptr;
+// Timing probe for kernel development (tools_time_fused.py): a device buffer of 8 * 64 int64; NULL switches it off.
+extern "C" int wmz_debug_fused_timestamps(void* buf) { g_fused_ts = (long long*)buf; return WMZ_OK; }
 
 extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
                                    const void* wpack, const float* vec, int ntok, int D, int I, int M, int has_head,
                                    int has_tail, float eps, void* stream) {
-  return wmz_layer_fused_fwd_planes(o, x, x_out, q_out, kv_out, wpack, vec, 1, 1, 1, ntok, D, I, M, has_head, has_tail, eps,
-                                    stream);
+  return wmz_layer_fused_fwd_planes(o, x, x_out, q_out, kv_out, wpack, vec, 1, 1, 1, ntok, D, I, M, has_head, has_tail, 0,
+                                    eps, stream);
 }
 
 extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
                                           const void* wpack, const float* vec, int B, int planes_out, int planes_in, int HW,
-                                          int D, int I, int M, int has_head, int has_tail, float eps, void* stream) {
+                                          int D, int I, int M, int has_head, int has_tail, int xflags, float eps,
+                                          void* stream) {
+  WMZ_REQUIRE((xflags & ~3) == 0, "wmz_layer_fused_fwd: bad layout flags");
+  WMZ_REQUIRE(xflags == 0 || ((long)planes_out * HW) % 32 == 0 && ((long)planes_in * HW) % 32 == 0,
+              "wmz_layer_fused_fwd: the tiled stream layout needs whole 32-token tiles per clip");
   WMZ_REQUIRE(B > 0 && HW > 0 && planes_out > 0 && planes_out <= planes_in, "wmz_layer_fused_fwd: bad plane counts");
   WMZ_REQUIRE((long)B * planes_in * HW < (1L << 31), "wmz_layer_fused_fwd: token count overflows int");
   const int ntok = B * planes_out * HW;
@@ -420,6 +597,7 @@ extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_
   P.z = nullptr; P.emb = P.pos_s = P.pos_h = P.pos_w = nullptr; P.S = P.H = P.W = P.num_classes = 0;
   P.rows_out = P.rows_in = P.row0 = 0;
   if (planes_out != planes_in) { P.rows_out = planes_out * HW; P.rows_in = planes_in * HW; P.row0 = (planes_in - planes_out) * HW; }
+  P.xflags = xflags;
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
@@ -428,13 +606,15 @@ extern "C" int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const
                                        const float* vec, int B, int S, int H, int W, int D, int I, int M, int num_classes,
                                        float eps, void* stream) {
   return wmz_embed_qkv_fused_fwd_planes(z, emb, pos_s, pos_h, pos_w, x_out, q_out, kv_out, wpack, vec, B, S, H, W, S, D, I, M,
-                                        num_classes, eps, stream);
+                                        num_classes, 0, eps, stream);
 }
 
 extern "C" int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                               const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                               const float* vec, int B, int S, int H, int W, int planes_out, int D, int I,
-                                              int M, int num_classes, float eps, void* stream) {
+                                              int M, int num_classes, int xflags, float eps, void* stream) {
+  WMZ_REQUIRE((xflags & ~WMZ_FUSED_X_OUT_TILED) == 0, "wmz_embed_qkv_fused_fwd: bad layout flags");
+  WMZ_REQUIRE(xflags == 0 || ((long)planes_out * H * W) % 32 == 0, "wmz_embed_qkv_fused_fwd: the tiled stream layout needs whole 32-token tiles per clip");
   WMZ_REQUIRE(planes_out > 0 && planes_out <= S, "wmz_embed_qkv_fused_fwd: bad plane count");
   WMZ_REQUIRE((long)B * S * H * W < (1L << 31), "wmz_embed_qkv_fused_fwd: token count overflows int");
   WMZ_REQUIRE(z && emb && pos_s && pos_h && pos_w && x_out && q_out && kv_out && wpack && vec, "wmz_embed_qkv_fused_fwd: null tensor");
@@ -445,6 +625,7 @@ extern "C" int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb
   P.rows_out = P.rows_in = P.row0 = 0;
   if (planes_out != S) { P.rows_out = planes_out * H * W; P.rows_in = S * H * W; P.row0 = (S - planes_out) * H * W; }
   P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
+  P.xflags = xflags;
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 
@@ -455,8 +636,9 @@ static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_h
   }
   static const int dbg_env = getenv("WMZ_FUSED_DBG") ? atoi(getenv("WMZ_FUSED_DBG")) : 0;
   P.dbg = dbg_env;
-  const size_t smem = FW * (ACTB + ZCB) + VECB + RING * SLAB;
-  dim3 grid((unsigned)wmz_cdiv(ntok, FT * FW)), block(NTHR);
+  P.ts = g_fused_ts;
+  const size_t smem = VECB + RING * SLAB + FW * 8192;
+  dim3 grid((unsigned)wmz_cdiv(ntok, TW * FW)), block(NTHR);
   hipStream_t st = (hipStream_t)stream;
 #define WMZ_FUSED(H, T)                                                                                            \
   do {                                                                                                             \

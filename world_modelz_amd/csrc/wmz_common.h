@@ -122,6 +122,18 @@ __device__ __forceinline__ float wmz_dgelu(float v) {
   return 0.5f * (1.f + wmz_erf(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
 }
 
+// GELU for kernels whose output is rounded to bf16 anyway: v * sigmoid(v * (c1 + c3 v^2 + c5 v^4)), coefficients fitted
+// (minimax over [-9, 9], tools in DESIGN.md) to the exact-erf GELU: max |error| 2.6e-5 absolute, two orders below the
+// bf16 resolution of the result, at 9 instructions (the erf form above costs ~20).  v^2 is clamped at 50: beyond |v| = 7
+// the sigmoid argument stays at 3.5 |v| (the polynomial would turn over at |v| = 11).
+__device__ __forceinline__ float wmz_gelu_fast(float v) {
+  const float w = fminf(v * v, 50.f);
+  float p = fmaf(-1.0148166e-3f, w, 0.10677913f);          // -(c5, c3, c1) * log2(e): exp2 of the negated argument
+  p = fmaf(p, w, 2.3011176f);
+  const float e = __builtin_amdgcn_exp2f(-p * v);
+  return v * __builtin_amdgcn_rcpf(1.f + e);
+}
+
 // wave64 butterfly helpers
 __device__ __forceinline__ float wave_xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask)); }
 __device__ __forceinline__ float wave_xor_add(float v, int mask) { return v + __shfl_xor(v, mask); }

@@ -7,19 +7,22 @@ from . import _lib as L
 
 D_, I_, M_ = 256, 128, 256
 _PAD = 4 * 16384        # >= RING-1 slabs the kernel's LDS-DMA prefetch runs past the last real slab
-MC_ = 64
+MC_ = 32
 
 
 def _pack_w(w):
-    """[N, K] -> [K/32][N][4 chunks][8]: the MFMA 16x16x32 A-operand rows of one 32-deep k-step, with the 16-byte chunk
-    index of row n XOR-ed by (-(n>>2)) & 3 (conflict-free ds_read_b128 in the kernel)."""
+    """[N, K] -> the kernel's stream of 1 KB MFMA 32x32x16 A operands, in (16-deep k-step, 32-feature block) order.
+    Piece (s, b), lane l = 32*h + r, 8 elements: W[f(b, r)][h*K/2 + 8*s + j] -- the k axis is walked so that lane half h
+    owns the contiguous features h*K/2.. of the activation, and output row r of block b is feature
+    f = ho*N/2 + 16*b + i with (ho, i) the lane half / accumulator register that MFMA row r lands in
+    (row = (i&3) + 8*(i>>2) + 4*ho), so every activation is a contiguous half row per lane."""
     N, K = w.shape
-    v = w.reshape(N, K // 32, 4, 8)
-    n = torch.arange(N, device=w.device)
-    f = (-(n >> 2)) & 3                                       # [N]
-    src = torch.arange(4, device=w.device)[None, :] ^ f[:, None]   # physical chunk c' holds logical chunk c'^f
-    v = torch.gather(v, 2, src[:, None, :, None].expand(N, K // 32, 4, 8))
-    return v.permute(1, 0, 2, 3).reshape(-1)
+    NB, KS = N // 32, K // 16
+    rho = torch.arange(32, device=w.device)
+    ho, i = (rho >> 2) & 1, (rho & 3) + 4 * (rho >> 3)
+    f = ho[None, :] * (16 * NB) + 16 * torch.arange(NB, device=w.device)[:, None] + i[None, :]      # [NB, 32]
+    v = w[f].reshape(NB, 32, 2, KS, 8)                      # [b, r, h, s, j]
+    return v.permute(3, 0, 2, 1, 4).reshape(-1)
 
 
 def supported(transformer, x_dtype):
@@ -35,25 +38,31 @@ def supported(transformer, x_dtype):
 
 
 def _layer_pack(head, tail):
-    """head / tail: (attn PreNorm, ff PreNorm) of the layer whose to_out+FF run, and of the layer whose q|k|v run."""
-    params, parts = [], []
+    """head / tail: (attn PreNorm, ff PreNorm) of the layer whose to_out+FF run, and of the layer whose q|k|v run.
+    The LayerNorm affines are folded into the GEMMs that consume them (W1' = W1 diag(g2), b1' = b1 + W1 be2; same for
+    to_k / to_v with the next layer's norm), so the kernel only normalises."""
+    params = []
     if head is not None:
         attn, ff = head
-        params += [attn.fn.to_out[0].weight, ff.fn.net[0].weight, ff.fn.net[3].weight]
+        params += [attn.fn.to_out[0].weight, ff.fn.net[0].weight, ff.fn.net[3].weight, ff.norm.weight]
     if tail is not None:
         attn_n = tail[0]
-        params += [attn_n.fn.to_q.weight, attn_n.fn.to_k.weight, attn_n.fn.to_v.weight]
+        params += [attn_n.fn.to_q.weight, attn_n.fn.to_k.weight, attn_n.fn.to_v.weight, attn_n.norm.weight]
 
     def build_w(*ws):
-        ws = [w.detach().to(torch.bfloat16) for w in ws]
+        ws = [w.detach().float() for w in ws]
+        bf = lambda w: w.to(torch.bfloat16)  # noqa: E731
         out, i = [], 0
         if head is not None:
-            out.append(_pack_w(ws[0]))
+            wout, w1, w2, g2 = ws[:4]
+            w1 = bf(w1 * g2[None, :])
+            out.append(_pack_w(bf(wout)))
             for c in range(M_ // MC_):          # feed-forward streamed MC hidden units at a time: W1 rows, then W2 columns
-                out += [_pack_w(ws[1][c * MC_:(c + 1) * MC_]), _pack_w(ws[2][:, c * MC_:(c + 1) * MC_])]
-            i = 3
+                out += [_pack_w(w1[c * MC_:(c + 1) * MC_]), _pack_w(bf(w2[:, c * MC_:(c + 1) * MC_]))]
+            i = 4
         if tail is not None:
-            out += [_pack_w(ws[i]), _pack_w(ws[i + 1]), _pack_w(ws[i + 2])]
+            wq, wk, wv, g1 = ws[i:i + 4]
+            out += [_pack_w(bf(wq)), _pack_w(bf(wk * g1[None, :])), _pack_w(bf(wv * g1[None, :]))]
         out.append(torch.zeros(_PAD // 2, dtype=torch.bfloat16, device=ws[0].device))
         return torch.cat(out)
     wpack = _cast.operand(tuple(params), torch.bfloat16, 'fusedw', build_w)
@@ -61,65 +70,45 @@ def _layer_pack(head, tail):
     vparams = []
     if head is not None:
         attn, ff = head
-        vparams += [attn.fn.to_out[0].bias, ff.norm.weight, ff.norm.bias, ff.fn.net[0].bias, ff.fn.net[3].bias]
+        vparams += [attn.fn.to_out[0].bias, ff.fn.net[0].bias, ff.fn.net[0].weight, ff.norm.bias, ff.fn.net[3].bias]
     if tail is not None:
         attn_n = tail[0]
-        vparams += [attn_n.norm.weight, attn_n.norm.bias, attn_n.fn.to_v.bias]
+        vparams += [attn_n.fn.to_k.weight, attn_n.fn.to_v.weight, attn_n.norm.bias, attn_n.fn.to_v.bias]
 
     def build_v(*vs):
         dev = vs[0].device
         z = lambda n: torch.zeros(n, device=dev)  # noqa: E731
         vs = [v.detach().float() for v in vs]
+        hv, tv = [z(D_), z(M_), z(D_)], [z(I_), z(I_)]
         if head is not None:
-            hv, rest = vs[:5], vs[5:]
-        else:
-            hv, rest = [z(D_), z(D_), z(D_), z(M_), z(D_)], vs
-        tv = [rest[0], rest[1], torch.cat([z(I_), rest[2]])] if tail is not None else [z(D_), z(D_), z(2 * I_)]
-        return torch.cat(hv + tv)
+            bout, b1, w1, be2, b2 = vs[:5]
+            hv = [bout, b1 + w1 @ be2, b2]
+            vs = vs[5:]
+        if tail is not None:
+            wk, wv, be1, bv = vs
+            tv = [wk @ be1, bv + wv @ be1]
+        v = torch.cat(hv + tv)                      # bout[D] b1'[M] b2[D] bk'[I] bv'[I]
+        return torch.cat([v, z(2048 - v.numel())])
     vec = _cast.operand(tuple(vparams), torch.float32, 'fusedv', build_v)
     return wpack, vec
 
 
-def layer_fused(o, x, head, tail, eps=1e-5):
-    """Returns (x_out | None, q | None, kv | None)."""
+X_IN_TILED, X_OUT_TILED = 1, 2      # include/wmz.h WMZ_FUSED_X_*_TILED
+
+
+def layer_fused(o, x, head, tail, eps=1e-5, xflags=0):
+    """One launch of the fused per-token kernel on row-major (or, with xflags, tiled-stream) x.
+    Returns (x_out | None, q | None, kv | None)."""
     ntok = x.numel() // D_
     wpack, vec = _layer_pack(head, tail)
     lead = x.shape[:-1]
     xo = torch.empty_like(x) if head is not None else None
     q = torch.empty(lead + (I_,), dtype=x.dtype, device=x.device) if tail is not None else None
-    kv = torch.empty(lead + (2 * I_,), dtype=x.dtype, device=x.device) if tail is not None else None
-    L.call('wmz_layer_fused_fwd', L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), ntok,
-           D_, I_, M_, 1 if head is not None else 0, 1 if tail is not None else 0, float(eps), L.stream())
+    kv = torch.empty((2,) + lead + (I_,), dtype=x.dtype, device=x.device) if tail is not None else None
+    L.call('wmz_layer_fused_fwd_planes', L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
+           1, 1, 1, ntok, D_, I_, M_, 1 if head is not None else 0, 1 if tail is not None else 0, int(xflags), float(eps),
+           L.stream())
     return xo, q, kv
-
-
-def embed_qkv_fused(tr, z, eps=1e-5):
-    """Embedding + layer 0's q | k|v in one launch.  Returns (x, q, kv)."""
-    B, S, H, W = z.shape
-    wpack, vec = _layer_pack(None, tr.layers[0])
-    dev = z.device
-    x = torch.empty((B, S, H, W, D_), dtype=torch.bfloat16, device=dev)
-    q = torch.empty((B, S, H, W, I_), dtype=torch.bfloat16, device=dev)
-    kv = torch.empty((B, S, H, W, 2 * I_), dtype=torch.bfloat16, device=dev)
-    L.call('wmz_embed_qkv_fused_fwd', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
-           L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
-           L.ptr(x), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), B, S, H, W, D_, I_, M_, tr.embedding.num_embeddings,
-           float(eps), L.stream())
-    return x, q, kv
-
-
-def transformer_forward(tr, x=None, z=None):
-    """depth x [attention, feed-forward] on the fused kernels: per layer ONE attention launch + ONE per-token launch;
-    with `z` (token grid) the embedding rides in the first per-token launch."""
-    layers = list(tr.layers)
-    if z is not None:
-        x, q, kv = embed_qkv_fused(tr, z)
-    else:
-        _, q, kv = layer_fused(None, x, None, layers[0])
-    for l, (attn, ff) in enumerate(layers):
-        o, _, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads)
-        x, q, kv = layer_fused(o, x, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None)
-    return x
 
 
 def cone_planes(S, eS, depth):
@@ -135,42 +124,64 @@ def cone_planes(S, eS, depth):
     return need, src
 
 
-def transformer_forward_last(tr, z):
-    """The last plane of transformer_forward(tr, z=z) ([B, H, W, D]) computing only its dependence cone: identical
-    arithmetic per token (bit-identical result), the planes that cannot reach the last frame are never launched."""
+def _run(tr, z, cone):
+    """embedding -> depth x [attention launch, per-token launch].  cone: only the planes the last frame depends on."""
     layers = list(tr.layers)
     depth = len(layers)
     B, S, H, W = z.shape
     HW = H * W
     eS = int(layers[0][0].fn.extents[0])
-    if any(int(a.fn.extents[0]) != eS for a, _ in layers):
-        return transformer_forward(tr, z=z)[:, -1]
-    need, src = cone_planes(S, eS, depth)
-    dev = z.device
-    bf = torch.bfloat16
+    if cone and any(int(a.fn.extents[0]) != eS for a, _ in layers):
+        cone = False
+    need, src = cone_planes(S, eS, depth) if cone else ([S] * depth, [S] * depth)
+    tiled = HW % 32 == 0                      # whole 32-token tiles per plane: the stream between layers stays tiled
+    dev, bf = z.device, torch.bfloat16
     n0 = src[0]
     wpack, vec = _layer_pack(None, layers[0])
     x = torch.empty((B, n0, H, W, D_), dtype=bf, device=dev)
     q = torch.empty((B, n0, H, W, I_), dtype=bf, device=dev)
-    kv = torch.empty((B, n0, H, W, 2 * I_), dtype=bf, device=dev)
+    kv = torch.empty((2, B, n0, H, W, I_), dtype=bf, device=dev)          # k planes, then v planes
     L.call('wmz_embed_qkv_fused_fwd_planes', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
            L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
            L.ptr(x), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), B, S, H, W, n0, D_, I_, M_,
-           tr.embedding.num_embeddings, 1e-5, L.stream())
+           tr.embedding.num_embeddings, X_OUT_TILED if tiled else 0, 1e-5, L.stream())
     for l, (attn, ff) in enumerate(layers):
         n_in, n_q = src[l], need[l]
-        heads = attn.fn.heads
-        ext = attn.fn.extents
+        heads, ext = attn.fn.heads, attn.fn.extents
         o = torch.empty((B, n_q, H, W, I_), dtype=bf, device=dev)
-        L.call('wmz_local3d_attn_fwd_planes', L.ptr(q), L.ptr(kv), L.ptr(kv[..., I_:]), L.ptr(o), None,
-               B, n_in, H, W, heads, I_ // heads, int(ext[0]), int(ext[1]), int(ext[2]), I_, 2 * I_, 2 * I_, I_,
+        if ops._profile_hook is not None:
+            ops._profile_hook('wmz_local3d_attn_fwd', True)
+        L.call('wmz_local3d_attn_fwd_planes', L.ptr(q), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(o), None,
+               B, n_in, H, W, heads, I_ // heads, int(ext[0]), int(ext[1]), int(ext[2]), I_, I_, I_, I_,
                n_in - n_q, n_q, L.dtype_code(bf), L.stream())
+        if ops._profile_hook is not None:
+            ops._profile_hook('wmz_local3d_attn_fwd', False)
         tail = layers[l + 1] if l + 1 < depth else None
         wpack, vec = _layer_pack((attn, ff), tail)
         xo = torch.empty((B, n_q, H, W, D_), dtype=bf, device=dev)
         q = torch.empty((B, n_q, H, W, I_), dtype=bf, device=dev) if tail is not None else None
-        kv = torch.empty((B, n_q, H, W, 2 * I_), dtype=bf, device=dev) if tail is not None else None
+        kv = torch.empty((2, B, n_q, H, W, I_), dtype=bf, device=dev) if tail is not None else None
+        xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if tiled and tail is not None else 0)
         L.call('wmz_layer_fused_fwd_planes', L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
-               B, n_q, n_in, HW, D_, I_, M_, 1, 1 if tail is not None else 0, 1e-5, L.stream())
+               B, n_q, n_in, HW, D_, I_, M_, 1, 1 if tail is not None else 0, xflags, 1e-5, L.stream())
         x = xo
-    return x[:, 0]
+    return x
+
+
+def transformer_forward(tr, x=None, z=None):
+    """depth x [attention, feed-forward] on the fused kernels: per layer ONE attention launch + ONE per-token launch, the
+    embedding riding in the first per-token launch.  Returns the stream [B, S, H, W, D] (row-major)."""
+    if z is not None:
+        return _run(tr, z, cone=False)
+    layers = list(tr.layers)
+    _, q, kv = layer_fused(None, x, None, layers[0])
+    for l, (attn, ff) in enumerate(layers):
+        o, _, _ = ops.local3d_attention_fwd(q, kv[0], kv[1], attn.fn.extents, attn.fn.heads)
+        x, q, kv = layer_fused(o, x, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None)
+    return x
+
+
+def transformer_forward_last(tr, z):
+    """The last plane of transformer_forward(tr, z=z) ([B, H, W, D]) computing only its dependence cone: identical
+    arithmetic per token (bit-identical result), the planes that cannot reach the last frame are never launched."""
+    return _run(tr, z, cone=True)[:, 0]
