@@ -19,8 +19,10 @@ with torch.no_grad():
     L.call('wmz_debug_fused_timestamps', None)
 t = ts.cpu().view(8, 64)
 names = {44: 'o+vec landed', 45: 'to_out gemm', 0: 'start', 1: 'all issued', 2: 'init bout', 3: '+x', 4: 'LN2', 30: 'b2+LN1+pack', 31: 'x stores', 32: 'q gemm', 33: 'q pack/store', 34: 'k gemm', 35: 'k pack/store', 36: 'v gemm', 37: 'end'}
-for c in range(8):
-    names[5 + 3 * c] = f'W1[{c}] gemm'; names[6 + 3 * c] = f'gelu[{c}]'; names[7 + 3 * c] = f'W2[{c}] gemm'
+names.update({48: ' W1[4] vmcnt done', 49: ' W1[4] barrier done', 50: ' W1[4] dma issued', 51: ' W1[4] group0 done', 52: ' W2[3] vmcnt done', 53: ' W2[3] barrier done', 54: ' W2[3] dma issued', 55: ' W2[3] group0 done'})
+names[5] = 'W1[0] gemm'; names[6] = 'gelu[0]'; names[29] = 'W2[7] gemm'
+for c in range(1, 8):
+    names[5 + 3 * c] = f'W1[{c}] gemm'; names[7 + 3 * c] = f'W2[{c-1}]+gelu[{c}]'
 for w in (0, 3, 7):
     base = int(t[w, 0]); prev = base
     print(f'--- wave {w} (100 MHz ticks? see total) total {int(t[w,37]) - base}')

@@ -84,10 +84,16 @@ struct WStream {
   char* ring;          // LDS ring base + this wave's 2 KB eighth
   int issue_slot;      // ring slot the next issued slab goes to
   int cur;             // ring slot of the slab being multiplied
-  int extra, extra_n;  // `extra` ordinary stores were issued behind the slabs in flight: the next extra_n waits allow for them
+  int wave;
+  int probe;           // timing probe slot base for the next slab (0 = off)
+  long long* ts;
+  // vmcnt bookkeeping: tot = every other VMEM op (row loads / stores) this wave has issued so far; t1..t3 = tot at the
+  // moment the three slabs in flight were issued, oldest first
+  int tot, t1, t2, t3;
 };
 
 __device__ __forceinline__ void ws_issue(WStream& ws) {
+  ws.t1 = ws.t2; ws.t2 = ws.t3; ws.t3 = ws.tot;
   if (ws.dbg & 2) return;
   char* dst = ws.ring + ws.issue_slot * SLAB;
 #pragma unroll
@@ -99,50 +105,62 @@ __device__ __forceinline__ void ws_issue(WStream& ws) {
 }
 
 // Before multiplying a slab: this wave's eighth of it has landed, then one barrier: every piece landed, and every wave is
-// done with the previous slab, whose slot is refilled right away.  vmcnt counts loads, stores and LDS-DMA together in issue
-// order: "landed" = all but the 2*(RING-2) pieces of the two younger slabs are done -- plus, for the three waits that
-// follow a burst of row stores, those stores (they sit between the slabs in flight and must not be waited for).
-__device__ __forceinline__ void ws_acquire(WStream& ws) {
+// done with the previous slab, whose slot the caller refills (ws_issue) once its first fragment reads are out (spreading
+// the sixteen requests over the stage instead measured slower).  vmcnt counts loads, stores
+// and LDS-DMA together in issue order: the oldest slab in flight has landed <=> at most [the 2*(RING-2) pieces of the
+// two younger slabs + every other op issued after its pieces (tot - t1)] is outstanding.
+__device__ __forceinline__ void ws_wait(WStream& ws) {
   static_assert(2 * (RING - 2) == 4, "vmcnt literals below follow RING (2 LDS-DMA pieces per wave per slab)");
+  const int e = ws.tot - ws.t1;
   if (!(ws.dbg & 2)) {
-    if (ws.extra_n > 0) {
-      if (ws.extra == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else if (ws.extra == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      --ws.extra_n;
-    } else {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#define WMZ_VMC(n) case n: asm volatile("s_waitcnt vmcnt(" #n " + 4)" ::: "memory"); break;
+    switch (e) {
+      WMZ_VMC(0) WMZ_VMC(1) WMZ_VMC(2) WMZ_VMC(3) WMZ_VMC(4) WMZ_VMC(5) WMZ_VMC(6) WMZ_VMC(7) WMZ_VMC(8) WMZ_VMC(9)
+      WMZ_VMC(10) WMZ_VMC(11) WMZ_VMC(12) WMZ_VMC(13) WMZ_VMC(14) WMZ_VMC(15) WMZ_VMC(16) WMZ_VMC(17) WMZ_VMC(18)
+      WMZ_VMC(19) WMZ_VMC(20) WMZ_VMC(21) WMZ_VMC(22) WMZ_VMC(23) WMZ_VMC(24) WMZ_VMC(25) WMZ_VMC(26) WMZ_VMC(27)
+      WMZ_VMC(28) WMZ_VMC(29) WMZ_VMC(30) WMZ_VMC(31) WMZ_VMC(32)
+      default: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;      // more than 32: waits for the surplus (safe)
     }
+#undef WMZ_VMC
   }
+  if (ws.probe && ws.ts) ws.ts[ws.probe] = __builtin_readcyclecounter();
   __builtin_amdgcn_s_barrier();
-  ws_issue(ws);
+  if (ws.probe && ws.ts) ws.ts[ws.probe + 1] = __builtin_readcyclecounter();
 }
 __device__ __forceinline__ void ws_release(WStream& ws) { ws.cur = ws.cur == RING - 1 ? 0 : ws.cur + 1; }
-__device__ __forceinline__ void ws_stores(WStream& ws, int n) { ws.extra = n; ws.extra_n = 3; }
+__device__ __forceinline__ void ws_extra(WStream& ws, int n) { ws.tot += n; }
+
+struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
 
 // acc[NB blocks of 32 features x 32 tokens] += W . act^T over KS 16-deep k-steps; the stream holds the pieces in
 // (k-step, block) order, so a k-step's operand is used by NB independent accumulators.  bget(s) yields the B operand
 // of k-step s (a register array, or an LDS read issued one k-step ahead).
-template <int NB, int KS, typename BGet>
-__device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const char* ring0, WStream& ws, int lane) {
+template <int NB, int KS, typename BGet, typename Side = NoSide>
+__device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const char* ring0, WStream& ws, int lane,
+                                             Side side = Side()) {
   constexpr int NP = NB * KS;
   static_assert(NP % PIECES == 0, "a stage is a whole number of slabs");
+  constexpr int AG = 4, GPS = PIECES / AG;                 // fragments per group, groups per slab
   Frag8<bf16_t> bcur, bnext = bget(0);
   bcur = bnext;
 #pragma unroll
   for (int sl = 0; sl < NP / PIECES; ++sl) {
-    ws_acquire(ws);
+    ws_wait(ws);
     const char* slab = ring0 + ws.cur * SLAB + lane * 16;
+    // A operands: groups of AG, the next group's ds_reads in flight under this group's MFMAs (8 fragments live, no more:
+    // the scheduler is fenced so that it cannot hoist the whole slab's reads into registers the chain needs)
+    Frag8<bf16_t> af[2][AG];
     if (!(ws.dbg & 1)) {
-      // A operands: groups of AG, the next group's ds_reads in flight under this group's MFMAs (8 fragments live, no more:
-      // the scheduler is fenced so that it cannot hoist the whole slab's reads into registers the chain needs)
-      constexpr int AG = 4;
-      Frag8<bf16_t> af[2][AG];
 #pragma unroll
       for (int j = 0; j < AG; ++j) af[0][j].v = *reinterpret_cast<const s16x8*>(slab + j * 1024);
+    }
+    ws_issue(ws);                                          // refill the retired slot while the first fragments arrive
+    if (ws.probe && ws.ts) ws.ts[ws.probe + 2] = __builtin_readcyclecounter();
+    if (!(ws.dbg & 1)) {
 #pragma unroll
-      for (int gq = 0; gq < PIECES / AG; ++gq) {
-        if (gq + 1 < PIECES / AG) {
+      for (int gq = 0; gq < GPS; ++gq) {
+        if (gq == 1 && ws.probe && ws.ts) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ws.ts[ws.probe + 3] = __builtin_readcyclecounter(); }
+        if (gq + 1 < GPS) {
 #pragma unroll
           for (int j = 0; j < AG; ++j)
             af[(gq + 1) & 1][j].v = *reinterpret_cast<const s16x8*>(slab + ((gq + 1) * AG + j) * 1024);
@@ -156,16 +174,17 @@ __device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const
           }
           mma32(acc[idx % NB], af[gq & 1][j], bcur);
         }
+        side(sl * GPS + gq);                               // VALU / store work that rides under this group's MFMAs
         WMZ_FENCE();
       }
     }
     ws_release(ws);
   }
 }
-template <int NB, int KS>
+template <int NB, int KS, typename Side = NoSide>
 __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[KS], const char* ring0, WStream& ws,
-                                           int lane) {
-  gemm_stage_b<NB, KS>(acc, [&](int s) { return bop[s]; }, ring0, ws, lane);
+                                           int lane, Side side = Side()) {
+  gemm_stage_b<NB, KS>(acc, [&](int s) { return bop[s]; }, ring0, ws, lane, side);
 }
 
 __device__ __forceinline__ f32x16 lds_vec16(const float* p) {
@@ -432,7 +451,10 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   ws.issue_slot = 0;
   ws.cur = 0;
   ws.dbg = P.dbg;
-  ws.extra = 0; ws.extra_n = 0;
+  ws.tot = ws.t1 = ws.t2 = ws.t3 = 0;
+  ws.wave = wave;
+  ws.probe = 0;
+  ws.ts = (P.ts != nullptr && blockIdx.x == 0 && lane == 0) ? P.ts + wave * 64 : nullptr;
   WMZ_TS(0);
   const long tok0 = (long)blockIdx.x * (TW * FW) + wave * TW;        // first token of this wave
   const long tok = tok0 + (lane & 31);
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
 #pragma unroll
       for (int s = 0; s < D / 16; ++s) xb[s].v = gload_untracked(xp + s * xs);
     }
-    ws_stores(ws, D / 16);                                             // 16 younger loads sit behind the primed slabs
+    ws_extra(ws, D / 16);                                             // 16 younger loads sit behind the primed slabs
     WMZ_TS(1);
     asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                  // o tile + vectors landed (6 slab pieces + 16 loads may fly)
     __builtin_amdgcn_s_barrier();                                      // everyone's share of the vectors did
@@ -479,13 +501,14 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     WMZ_TS(3);
     ln_to_bop<D / 32>(xb, xr, P.eps);                     // LN2(x1)
     WMZ_TS(4);
-#pragma unroll 1
-    for (int c = 0; c < M / MC; ++c) {                                 // feed-forward, MC hidden units at a time
+    // feed-forward, MC hidden units at a time: W1[c] -> GELU -> W2[c].  GELU(c) is VALU work that rides under the MFMAs of
+    // W2[c-1] (the stream is packed in that order: W1[0], W1[1], W2[0], W1[2], W2[1], .., W1[7], W2[6], W2[7]).
+    {
       f32x16 z[1];
-      init_vec<1>(z, v_b1 + c * MC);                                   // b1[c]
-      gemm_stage<1, D / 16>(z, xb, ring0, ws, lane);                   // + W1[c] LN2(x1)
-      WMZ_TS(5 + 3 * c);
-      Frag8<bf16_t> gb[2];
+      Frag8<bf16_t> gb[2], gn[2];
+      init_vec<1>(z, v_b1);
+      gemm_stage<1, D / 16>(z, xb, ring0, ws, lane);                   // b1[0] + W1[0] LN2(x1)
+      WMZ_TS(5);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         float y[8];
@@ -493,9 +516,28 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
         for (int j = 0; j < 8; ++j) y[j] = wmz_gelu_fast(z[0][8 * m + j]);
         pack8(gb[m], y);
       }
-      WMZ_TS(6 + 3 * c);
-      gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane);            // x1 += W2[:, c] GELU(.)
-      WMZ_TS(7 + 3 * c);
+      WMZ_TS(6);
+#pragma unroll 1
+      for (int c = 1; c < M / MC; ++c) {
+        init_vec<1>(z, v_b1 + c * MC);
+        if (c == 4) ws.probe = 48;
+        gemm_stage<1, D / 16>(z, xb, ring0, ws, lane);                 // b1[c] + W1[c] LN2(x1)
+        ws.probe = 0;
+        WMZ_TS(5 + 3 * c);
+        if (c == 4) ws.probe = 52;
+        float y[8];
+        gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane, [&](int g) {   // x1 += W2[:, c-1] GELU(c-1) | GELU(c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[(g & 1) * 4 + j] = wmz_gelu_fast(z[0][4 * g + j]);
+          if (g & 1) pack8(gn[g >> 1], y);
+        });
+        ws.probe = 0;
+        WMZ_TS(7 + 3 * c);
+        gb[0] = gn[0];
+        gb[1] = gn[1];
+      }
+      gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane);            // x1 += W2[:, 7] GELU(7)
+      WMZ_TS(29);
     }
     add_vec<D / 32>(xr, v_b2);                                         //                 -> x2
     Frag8<bf16_t> x2b[D / 16];                                         // x2 as the stream carries it
@@ -504,7 +546,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     WMZ_TS(30);
     if (P.xflags & WMZ_FUSED_X_OUT_TILED) store_bop_tiled<D / 16>(P.xo + tok0 * D, x2b, lane);
     else store_tile256(stg, P.xo, tok0, P.ntok, x2b, lane);
-    ws_stores(ws, 16);
+    ws_extra(ws, 16);
     WMZ_TS(31);
     if constexpr (TAIL) {
       f32x16 qa[I / 32];
@@ -514,7 +556,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
       Frag8<bf16_t> qb[I / 16];
       bop_from_acc<I / 32>(qb, qa);
       store_tile128(stg, P.q, I, tok0, P.ntok, 0, qb, lane);
-      ws_stores(ws, 8);
+      ws_extra(ws, 8);
     }
   } else {
     if (P.z != nullptr) embed_bop<D>(xb, P, tokc, true, h);          // first layer: x = embedding, also written to x_out
@@ -528,7 +570,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     if (P.z != nullptr) {
       if (P.xflags & WMZ_FUSED_X_OUT_TILED) store_bop_tiled<D / 16>(P.xo + tok0 * D, xb, lane);
       else store_tile256(stg, P.xo, tok0, P.ntok, xb, lane);
-      ws_stores(ws, 16);
+      ws_extra(ws, 16);
     }
     {
       f32x16 qa[I / 32];
@@ -537,7 +579,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
       Frag8<bf16_t> qb[I / 16];
       bop_from_acc<I / 32>(qb, qa);
       store_tile128(stg, P.q, I, tok0, P.ntok, 0, qb, lane);
-      ws_stores(ws, 8);
+      ws_extra(ws, 8);
     }
     acc_from_bop<D / 32>(xr, xb);
     ln_to_bop<D / 32>(xb, xr, P.eps);                   // LN1'(x)
@@ -551,7 +593,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     WMZ_TS(34);
     bop_from_acc<I / 32>(kb, ka);
     store_tile128(stg, P.kv, I, tok0, P.ntok, 0, kb, lane);                       // k rows
-    ws_stores(ws, 8);
+    ws_extra(ws, 8);
     init_vec<I / 32>(ka, v_bv);
     WMZ_TS(35);
     gemm_stage<I / 32, D / 16>(ka, xb, ring0, ws, lane);               // to_v

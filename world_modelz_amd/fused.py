@@ -57,8 +57,15 @@ def _layer_pack(head, tail):
             wout, w1, w2, g2 = ws[:4]
             w1 = bf(w1 * g2[None, :])
             out.append(_pack_w(bf(wout)))
-            for c in range(M_ // MC_):          # feed-forward streamed MC hidden units at a time: W1 rows, then W2 columns
-                out += [_pack_w(w1[c * MC_:(c + 1) * MC_]), _pack_w(bf(w2[:, c * MC_:(c + 1) * MC_]))]
+            # feed-forward streamed MC hidden units at a time, W1 rows one chunk ahead of the W2 columns (GELU of chunk c
+            # rides under the W2 GEMM of chunk c-1): W1[0], W1[1], W2[0], W1[2], W2[1], .., W1[7], W2[6], W2[7]
+            nch = M_ // MC_
+            p1 = [_pack_w(w1[c * MC_:(c + 1) * MC_]) for c in range(nch)]
+            p2 = [_pack_w(bf(w2[:, c * MC_:(c + 1) * MC_])) for c in range(nch)]
+            out.append(p1[0])
+            for c in range(1, nch):
+                out += [p1[c], p2[c - 1]]
+            out.append(p2[nch - 1])
             i = 4
         if tail is not None:
             wq, wk, wv, g1 = ws[i:i + 4]
