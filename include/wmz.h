@@ -170,6 +170,8 @@ int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const flo
 /* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
  * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */
 int wmz_debug_fused_timestamps(void* buf);
+/* Same for the 16-wide-plane attention forward kernel (16 waves x 64 int64). */
+int wmz_debug_attn_timestamps(void* buf);
 
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]

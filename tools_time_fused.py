@@ -32,4 +32,13 @@ for planes in (1, 4, 8, 16, 32, 64, 128, 256, 512):
         ht = timeit(lambda: fused.layer_fused(o, x, L[0], L[1], xflags=XF))
         h = timeit(lambda: fused.layer_fused(o, x, L[0], None, xflags=XF & 1))
         t = timeit(lambda: fused.layer_fused(None, x, None, L[1]))
+    if planes % 8 == 0:
+        tr = m.transformer
+        Bz = planes // 8
+        zz = torch.randint(0, 1025, (Bz, 8, 16, 16), device='cuda')
+        wp, vc = fused._layer_pack(None, L[0])
+        xe = torch.empty(Bz, 8, 16, 16, 256, device='cuda', dtype=torch.bfloat16); qe = torch.empty(Bz, 8, 16, 16, 128, device='cuda', dtype=torch.bfloat16); kve = torch.empty(2, Bz, 8, 16, 16, 128, device='cuda', dtype=torch.bfloat16)
+        from world_modelz_amd import _lib as LL
+        emb = timeit(lambda: LL.call('wmz_embed_qkv_fused_fwd_planes', zz.data_ptr(), tr.embedding.weight.data_ptr(), tr.pos_emb_s.weight.data_ptr(), tr.pos_emb_h.weight.data_ptr(), tr.pos_emb_w.weight.data_ptr(), xe.data_ptr(), qe.data_ptr(), kve.data_ptr(), wp.data_ptr(), vc.data_ptr(), Bz, 8, 16, 16, 8, 256, 128, 256, 1025, 2, 1e-5, LL.stream()))
+        print(f'   embed+tail {emb:7.1f} us')
     print(f'planes {planes:4d} tokens {planes*256:7d} wgs {planes*2:5d}: head+tail {ht:7.1f} us  head {h:7.1f}  tail {t:7.1f}', flush=True)

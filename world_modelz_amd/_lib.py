@@ -34,6 +34,7 @@ SIGNATURES = {
                        c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p],
     'wmz_embed_pos3d_fwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],
     'wmz_debug_fused_timestamps': [c_void_p],
+    'wmz_debug_attn_timestamps': [c_void_p],
     'wmz_layer_fused_fwd': [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p],
     'wmz_layer_fused_fwd_planes': [c_void_p] * 7 + [c_int] * 10 + [c_float, c_void_p],
     'wmz_embed_qkv_fused_fwd_planes': [c_void_p] * 10 + [c_int] * 10 + [c_float, c_void_p],

@@ -355,7 +355,7 @@ __device__ __forceinline__ void ln_stats(const f32x16 (&acc)[NB], float eps, flo
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) s += sv[i];
-  s += __shfl_xor(s, 32);
+  s = wave_halves_sum(s);
   const float mean = s / (float)NF;
   f32x16 qv = (f32x16)(0.f);
 #pragma unroll
@@ -363,7 +363,7 @@ __device__ __forceinline__ void ln_stats(const f32x16 (&acc)[NB], float eps, flo
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) q += qv[i];
-  q += __shfl_xor(q, 32);
+  q = wave_halves_sum(q);
   rstd = rsqrtf(q / (float)NF + eps);
   mr = -mean * rstd;
 }
@@ -433,6 +433,55 @@ __device__ __forceinline__ void embed_bop(Frag8<bf16_t> (&bop)[F / 16], const Fu
     }
     pack8(bop[c], y);
     if ((c & 1) == 1) WMZ_FENCE();     // 32 loads in flight, not 128
+  }
+}
+
+// The same for 16-wide planes cut into whole 32-token tiles (tile = two plane rows), cooperatively: the wave walks its 32
+// tokens one at a time, all 64 lanes fetching ONE 1 KB embedding row (4 features per lane, coalesced; the lane-per-token
+// form above gathers 64 different rows per instruction), adds the position rows (plane and the two plane-row terms
+// hoisted, the 16 column rows kept in registers), and drops the bf16 row into the wave's LDS image; the lanes then pick
+// up their own half rows.  Same fp32 sum order, e + ((s + h) + w): bit-identical to embed_bop.
+template <int F>
+__device__ __forceinline__ void embed_coop(Frag8<bf16_t> (&bop)[F / 16], char* stg, const FusedParams& P, long tok0, int lane) {
+  static_assert(F == 256, "one 1 KB fp32 row per wave instruction");
+  const long last = P.ntok - 1;
+  const long ts0 = src_row(P, tok0 < last ? tok0 : last);                 // first token of the tile in the full grid
+  const int h0 = (int)((ts0 / 16) % P.H), s = (int)((ts0 / (16L * P.H)) % P.S);
+  const int h1 = h0 + 1 < P.H ? h0 + 1 : h0;
+  const f32x4 ps = *reinterpret_cast<const f32x4*>(P.pos_s + (long)s * F + lane * 4);
+  const f32x4 a0 = ps + *reinterpret_cast<const f32x4*>(P.pos_h + (long)h0 * F + lane * 4);
+  const f32x4 a1 = ps + *reinterpret_cast<const f32x4*>(P.pos_h + (long)h1 * F + lane * 4);
+  f32x4 pw[16];
+#pragma unroll
+  for (int w = 0; w < 16; ++w) pw[w] = *reinterpret_cast<const f32x4*>(P.pos_w + (long)w * F + lane * 4);
+  const int t = lane & 31, hl = lane >> 5;
+  // the tile's 32 token ids: one coalesced load (lane t holds token t's id, clamped), handed out by v_readlane
+  int tkv;
+  {
+    const long tt = tok0 + t < last ? tok0 + t : last;
+    long tk = P.z[ts0 + (tt - (tok0 < last ? tok0 : last))];
+    tk = tk < 0 ? 0 : (tk >= P.num_classes ? P.num_classes - 1 : tk);
+    tkv = (int)tk;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {                                           // 16 tokens (one plane row) per pass
+    const f32x4 a = p ? a1 : a0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long tk = __builtin_amdgcn_readlane(tkv, 16 * p + i);
+      const f32x4 e = *reinterpret_cast<const f32x4*>(P.emb + tk * F + lane * 4);
+      const f32x4 y = e + (a + pw[i]);
+      s16x4 pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(y[r]);
+      *reinterpret_cast<s16x4*>(stg + i * 512 + ((((lane >> 1) ^ i) << 4) | ((lane & 1) << 3))) = pk;
+    }
+    if ((t >> 4) == p) {
+      const int tl = t & 15;
+#pragma unroll
+      for (int c = 0; c < F / 16; ++c)
+        bop[c].v = *reinterpret_cast<const s16x8*>(stg + tl * 512 + (((hl * 16 + c) ^ tl) << 4));
+    }
   }
 }
 
@@ -559,7 +608,11 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
       ws_extra(ws, 8);
     }
   } else {
-    if (P.z != nullptr) embed_bop<D>(xb, P, tokc, true, h);          // first layer: x = embedding, also written to x_out
+    if (P.z != nullptr) {                                            // first layer: x = embedding, also written to x_out
+      const bool coop = P.W == 16 && (P.H * 16) % 32 == 0 && (P.rows_out == 0 || (P.rows_out % 32 == 0 && P.rows_in % 32 == 0 && P.row0 % 32 == 0));
+      if (coop) embed_coop<D>(xb, stg, P, tok0, lane);
+      else embed_bop<D>(xb, P, tokc, true, h);
+    }
     else if (P.xflags & WMZ_FUSED_X_IN_TILED) load_bop_tiled<D / 16>(xb, P.x + src_row(P, tok0) * D, lane);
     else load_bop<D / 16>(xb, P.x + src_row(P, tokc) * D + h * (D / 2));
     const f32x4 vecv = *reinterpret_cast<const f32x4*>(P.vec + tid * 4);

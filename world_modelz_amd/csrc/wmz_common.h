@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <utility>
 
 #include "../../include/wmz.h"
 
@@ -132,6 +133,52 @@ __device__ __forceinline__ float wmz_gelu_fast(float v) {
   p = fmaf(p, w, 2.3011176f);
   const float e = __builtin_amdgcn_exp2f(-p * v);
   return v * __builtin_amdgcn_rcpf(1.f + e);
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>) -- for bodies that need the index as a constant
+// expression (instruction immediates in inline asm)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// LDS byte address of a pointer into __shared__ memory
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// ds_read_b64_tr_b16 as inline asm.  The builtin form is an "unknown memory access" to hipcc: with an LDS-DMA
+// (global_load_lds) in flight it puts s_waitcnt vmcnt(0) in front of every such read, i.e. it drains the slab being
+// prefetched before the current one may be used (measured: the prefetch then overlaps nothing).  The asm form is invisible
+// to that bookkeeping -- and to lgkmcnt tracking as well: the caller waits with ds_tr_wait() before using the results.
+template <int OFF>
+__device__ __forceinline__ s16x4 ds_read_tr16_asm(unsigned addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+__device__ __forceinline__ void ds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48 -> the same result in all four) with the
+// gfx950 row / half swaps: two VALU instructions per level, no LDS round trip (__shfl_xor is a ds_bpermute: ~100+ cycles
+// of latency each, and with an LDS-DMA in flight hipcc drains vmcnt in front of it).
+//   v_permlane16_swap d, s: rows 1, 3 of d <-> rows 0, 2 of s;   v_permlane32_swap d, s: upper half of d <-> lower half of s
+__device__ __forceinline__ float wave_groups_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned m = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float wave_groups_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned m = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float wave_halves_sum(float v) {          // lanes l, l^32
+  const unsigned u = __float_as_uint(v);
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // wave64 butterfly helpers
