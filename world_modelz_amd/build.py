@@ -48,7 +48,8 @@ def _compile(src, force, hdr_mtime):
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_mtime)):
         return obj, False
-    cmd = [_hipcc()] + COMMON + PER_FILE.get(src, []) + ['-c', path, '-o', obj]
+    extra = os.environ.get('WMZ_EXTRA_HIPCC_FLAGS', '').split()     # kernel-tuning experiments (-DWMZ_FUSED_HPS=1 ...)
+    cmd = [_hipcc()] + COMMON + PER_FILE.get(src, []) + extra + ['-c', path, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')

@@ -37,9 +37,15 @@ namespace {
 constexpr int TW = 32;          // tokens per wave
 constexpr int FW = 8;           // waves per workgroup (two per SIMD: one's epilogue overlaps the other's MFMAs)
 constexpr int NTHR = FW * 64;
-constexpr int SLAB = 16384;     // bytes per weight slab
-constexpr int PIECES = SLAB / 1024;   // MFMA A operands per slab
-constexpr int RING = 4;         // LDS ring slots: 3 slabs (48 KB) of the weight stream stay in flight
+constexpr int HALF = 16384;     // granule of the weight stream: every GEMM stage is a whole number of these
+constexpr int PIECES = HALF / 1024;   // MFMA A operands per granule
+#ifndef WMZ_FUSED_HPS
+#define WMZ_FUSED_HPS 2
+#endif
+constexpr int HPS = WMZ_FUSED_HPS;    // granules per slab = per workgroup barrier (1: 16 KB slabs, ring of 4; 2: 32 KB, ring of 2)
+constexpr int SLAB = HPS * HALF;      // bytes per weight slab (one LDS-DMA burst, one barrier)
+constexpr int RING = HPS == 1 ? 4 : 2;   // LDS ring slots; RING-1 slabs of the weight stream stay in flight
+constexpr int WPP = SLAB / 1024 / 8;  // LDS-DMA pieces per wave per slab
 constexpr int VECB = 8192;      // the layer's bias / LayerNorm vectors (2048 fp32), staged once per workgroup
 constexpr int MC = 32;          // feed-forward hidden chunk: W1 rows / W2 columns streamed MC at a time
 
@@ -81,14 +87,15 @@ __device__ __forceinline__ long src_row(const FusedParams& P, long t) {
 struct WStream {
   int dbg;
   const char* src;     // global address of the next slab to ISSUE (this lane's 16 bytes of piece 0 of its wave)
-  char* ring;          // LDS ring base + this wave's 2 KB eighth
+  char* ring;          // LDS ring base + this wave's eighth of a slab
   int issue_slot;      // ring slot the next issued slab goes to
   int cur;             // ring slot of the slab being multiplied
+  int half;            // granule of that slab the next stage starts at
   int wave;
   int probe;           // timing probe slot base for the next slab (0 = off)
   long long* ts;
   // vmcnt bookkeeping: tot = every other VMEM op (row loads / stores) this wave has issued so far; t1..t3 = tot at the
-  // moment the three slabs in flight were issued, oldest first
+  // moment the last three slabs were issued, oldest first
   int tot, t1, t2, t3;
 };
 
@@ -97,7 +104,7 @@ __device__ __forceinline__ void ws_issue(WStream& ws) {
   if (ws.dbg & 2) return;
   char* dst = ws.ring + ws.issue_slot * SLAB;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WPP; ++i)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws.src + i * 1024),
                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
   ws.src += SLAB;
@@ -106,20 +113,21 @@ __device__ __forceinline__ void ws_issue(WStream& ws) {
 
 // Before multiplying a slab: this wave's eighth of it has landed, then one barrier: every piece landed, and every wave is
 // done with the previous slab, whose slot the caller refills (ws_issue) once its first fragment reads are out (spreading
-// the sixteen requests over the stage instead measured slower).  vmcnt counts loads, stores
-// and LDS-DMA together in issue order: the oldest slab in flight has landed <=> at most [the 2*(RING-2) pieces of the
-// two younger slabs + every other op issued after its pieces (tot - t1)] is outstanding.
+// the requests over the stage instead measured slower).  vmcnt counts loads, stores and LDS-DMA together in issue
+// order: the oldest slab in flight has landed <=> at most [the WPP*(RING-2) pieces of the younger slabs + every other op
+// issued after its pieces (tot - its t)] is outstanding.
 __device__ __forceinline__ void ws_wait(WStream& ws) {
-  static_assert(2 * (RING - 2) == 4, "vmcnt literals below follow RING (2 LDS-DMA pieces per wave per slab)");
-  const int e = ws.tot - ws.t1;
+  constexpr int YB = WPP * (RING - 2);
+  static_assert(YB == 4 || YB == 0, "literals below");
+  const int e = ws.tot - (RING == 4 ? ws.t1 : (RING == 3 ? ws.t2 : ws.t3));
   if (!(ws.dbg & 2)) {
-#define WMZ_VMC(n) case n: asm volatile("s_waitcnt vmcnt(" #n " + 4)" ::: "memory"); break;
+#define WMZ_VMC(n) case n: if (YB == 4) asm volatile("s_waitcnt vmcnt(" #n " + 4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
     switch (e) {
       WMZ_VMC(0) WMZ_VMC(1) WMZ_VMC(2) WMZ_VMC(3) WMZ_VMC(4) WMZ_VMC(5) WMZ_VMC(6) WMZ_VMC(7) WMZ_VMC(8) WMZ_VMC(9)
       WMZ_VMC(10) WMZ_VMC(11) WMZ_VMC(12) WMZ_VMC(13) WMZ_VMC(14) WMZ_VMC(15) WMZ_VMC(16) WMZ_VMC(17) WMZ_VMC(18)
       WMZ_VMC(19) WMZ_VMC(20) WMZ_VMC(21) WMZ_VMC(22) WMZ_VMC(23) WMZ_VMC(24) WMZ_VMC(25) WMZ_VMC(26) WMZ_VMC(27)
       WMZ_VMC(28) WMZ_VMC(29) WMZ_VMC(30) WMZ_VMC(31) WMZ_VMC(32)
-      default: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;      // more than 32: waits for the surplus (safe)
+      default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;      // more than 32: waits for the surplus (safe)
     }
 #undef WMZ_VMC
   }
@@ -130,7 +138,16 @@ __device__ __forceinline__ void ws_wait(WStream& ws) {
 __device__ __forceinline__ void ws_release(WStream& ws) { ws.cur = ws.cur == RING - 1 ? 0 : ws.cur + 1; }
 __device__ __forceinline__ void ws_extra(WStream& ws, int n) { ws.tot += n; }
 
-struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
+// Side work of a GEMM stage: called once per group of AG MFMAs; kValuPerMfma tells the stage how many of its VALU
+// instructions the scheduler should place behind EACH MFMA (measured on MI355X at two waves per SIMD: up to ~2 VALU per
+// MFMA and wave hide completely, 4-8 cost about half their time, a block of VALU behind a block of MFMAs hides nothing).
+struct NoSide { static constexpr int kValuPerMfma = 0; __device__ __forceinline__ void operator()(int) const {} };
+template <int VPM, typename F> struct SideWork {
+  static constexpr int kValuPerMfma = VPM;
+  F f;
+  __device__ __forceinline__ void operator()(int g) const { f(g); }
+};
+template <int VPM, typename F> __device__ __forceinline__ SideWork<VPM, F> side_work(F f) { return SideWork<VPM, F>{f}; }
 
 // acc[NB blocks of 32 features x 32 tokens] += W . act^T over KS 16-deep k-steps; the stream holds the pieces in
 // (k-step, block) order, so a k-step's operand is used by NB independent accumulators.  bget(s) yields the B operand
@@ -145,8 +162,8 @@ __device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const
   bcur = bnext;
 #pragma unroll
   for (int sl = 0; sl < NP / PIECES; ++sl) {
-    ws_wait(ws);
-    const char* slab = ring0 + ws.cur * SLAB + lane * 16;
+    if (ws.half == 0) ws_wait(ws);
+    const char* slab = ring0 + ws.cur * SLAB + ws.half * HALF + lane * 16;
     // A operands: groups of AG, the next group's ds_reads in flight under this group's MFMAs (8 fragments live, no more:
     // the scheduler is fenced so that it cannot hoist the whole slab's reads into registers the chain needs)
     Frag8<bf16_t> af[2][AG];
@@ -154,7 +171,7 @@ __device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const
 #pragma unroll
       for (int j = 0; j < AG; ++j) af[0][j].v = *reinterpret_cast<const s16x8*>(slab + j * 1024);
     }
-    ws_issue(ws);                                          // refill the retired slot while the first fragments arrive
+    if (ws.half == 0) ws_issue(ws);                        // refill the retired slot while the first fragments arrive
     if (ws.probe && ws.ts) ws.ts[ws.probe + 2] = __builtin_readcyclecounter();
     if (!(ws.dbg & 1)) {
 #pragma unroll
@@ -174,11 +191,19 @@ __device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const
           }
           mma32(acc[idx % NB], af[gq & 1][j], bcur);
         }
-        side(sl * GPS + gq);                               // VALU / store work that rides under this group's MFMAs
+        side(sl * GPS + gq);                               // VALU work that rides under this group's MFMAs,
+        if constexpr (Side::kValuPerMfma > 0) {            // interleaved with them instruction by instruction
+#pragma unroll
+          for (int j = 0; j < AG; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, Side::kValuPerMfma, 0);
+          }
+        }
         WMZ_FENCE();
       }
     }
-    ws_release(ws);
+    if (ws.half == HPS - 1) { ws_release(ws); ws.half = 0; }
+    else ++ws.half;
   }
 }
 template <int NB, int KS, typename Side = NoSide>
@@ -233,11 +258,11 @@ __device__ __forceinline__ s16x8 gload_untracked(const bf16_t* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
-// vmcnt is in issue order: once at most the ring's 2*(RING-1) youngest pieces are outstanding, every older load is done.
+// vmcnt is in issue order: once at most the ring's WPP*(RING-1) youngest pieces are outstanding, every older load is done.
 template <int KS>
 __device__ __forceinline__ void wait_untracked(Frag8<bf16_t> (&b)[KS]) {
-  static_assert(2 * (RING - 1) == 6, "literal below");
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (WPP * (RING - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #pragma unroll
   for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(b[s].v));       // uses stay behind the wait
 }
@@ -302,6 +327,16 @@ __device__ __forceinline__ void stage_flush(const char* stg, bf16_t* dst, long t
     if (tok0 + r < ntok) *reinterpret_cast<s16x8*>(dst + (tok0 + r) * ROWF + col0 + c * 8) = v;
   }
 }
+// operand fragments parked in the wave's LDS image, lane-linear (each lane reads back what it wrote)
+__device__ __forceinline__ void frag_park(char* stg, int slot, const Frag8<bf16_t>& f, int lane) {
+  *reinterpret_cast<s16x8*>(stg + slot * 1024 + lane * 16) = f.v;
+}
+__device__ __forceinline__ Frag8<bf16_t> frag_unpark(const char* stg, int slot, int lane) {
+  Frag8<bf16_t> f;
+  f.v = *reinterpret_cast<const s16x8*>(stg + slot * 1024 + lane * 16);
+  return f;
+}
+
 // an I-feature tile (q, k, v: 128 features, every lane holds 8 chunks of its row): one pass
 __device__ __forceinline__ void store_tile128(char* stg, bf16_t* dst, int rowf, long tok0, int ntok, int col0,
                                               const Frag8<bf16_t> (&b)[8], int lane) {
@@ -495,8 +530,9 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   float* vecs = reinterpret_cast<float*>(smem);
   const char* ring0 = smem + VECB;
   WStream ws;
-  ws.ring = smem + VECB + wave * 2048;
-  ws.src = P.wpack + wave * 2048 + lane * 16;
+  ws.ring = smem + VECB + wave * (SLAB / 8);
+  ws.src = P.wpack + wave * (SLAB / 8) + lane * 16;
+  ws.half = 0;
   ws.issue_slot = 0;
   ws.cur = 0;
   ws.dbg = P.dbg;
@@ -516,6 +552,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   const float* v_bk = vecs + 2 * D + M + h * (I / 2);
   const float* v_bv = v_bk + I;
 
+  Frag8<bf16_t> qkvb[I / 16];                // q rows on their way out (TAIL)
   f32x16 xr[D / 32];                         // the residual stream of this lane's token (its half of the features), fp32
   Frag8<bf16_t> xb[D / 16];                  // a D-feature bf16 operand: LN output / the stream as stored
   if constexpr (HEAD) {
@@ -535,7 +572,9 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     }
     ws_extra(ws, D / 16);                                             // 16 younger loads sit behind the primed slabs
     WMZ_TS(1);
-    asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                  // o tile + vectors landed (6 slab pieces + 16 loads may fly)
+    if (WPP * (RING - 1) == 6) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");   // o tile + vectors landed (the primed slab
+    else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                          // pieces + 16 loads may fly)
+    static_assert(WPP * (RING - 1) == 6 || WPP * (RING - 1) == 4, "literals above");
     __builtin_amdgcn_s_barrier();                                      // everyone's share of the vectors did
     WMZ_TS(44);
     init_vec<D / 32>(xr, v_bout);
@@ -550,42 +589,57 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     WMZ_TS(3);
     ln_to_bop<D / 32>(xb, xr, P.eps);                     // LN2(x1)
     WMZ_TS(4);
-    // feed-forward, MC hidden units at a time: W1[c] -> GELU -> W2[c].  GELU(c) is VALU work that rides under the MFMAs of
-    // W2[c-1] (the stream is packed in that order: W1[0], W1[1], W2[0], W1[2], W2[1], .., W1[7], W2[6], W2[7]).
+    // feed-forward, MC hidden units at a time: W1[c] -> GELU -> W2[c], with the stream packed as W1[0], W1[1], W2[0], W1[2],
+    // W2[1], .., W1[7], W2[6], W2[7]: GELU(c) is VALU work that rides under the MFMAs of the two stages between W1[c] and
+    // W2[c] -- its first half under W2[c-1], its second half under W1[c+1] -- so no stage is VALU-bound.  The upper half
+    // of the LN2 operand is parked in the wave's LDS image for the duration (the registers carry two chunk accumulators).
+#pragma unroll
+    for (int sx = 8; sx < 16; ++sx) frag_park(stg, sx - 8, xb[sx], lane);
     {
-      f32x16 z[1];
+      auto lnb = [&](int sx) { return sx < 8 ? xb[sx] : frag_unpark(stg, sx - 8, lane); };
+      auto gelu_n = [&](float (&y)[8], const f32x16& zz, int first, int yo, int n) {   // n values zz[first..] -> y[yo..]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < n) y[yo + j] = wmz_gelu_fast(zz[first + j]);
+      };
+      f32x16 zc[1], zn[1];
       Frag8<bf16_t> gb[2], gn[2];
-      init_vec<1>(z, v_b1);
-      gemm_stage<1, D / 16>(z, xb, ring0, ws, lane);                   // b1[0] + W1[0] LN2(x1)
+      float y[8];
+      init_vec<1>(zc, v_b1);
+      gemm_stage_b<1, D / 16>(zc, lnb, ring0, ws, lane);                           // z0 = b1[0] + W1[0] LN2(x1)
       WMZ_TS(5);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = wmz_gelu_fast(z[0][8 * m + j]);
-        pack8(gb[m], y);
-      }
+      init_vec<1>(zn, v_b1 + MC);
+      gemm_stage_b<1, D / 16>(zn, lnb, ring0, ws, lane, side_work<9>([&](int g) {  // z1 | GELU(0), all of it
+        gelu_n(y, zc[0], 4 * g, (g & 1) * 4, 4);
+        if (g & 1) pack8(gb[g >> 1], y);
+      }));
+      zc[0] = zn[0];
       WMZ_TS(6);
 #pragma unroll 1
-      for (int c = 1; c < M / MC; ++c) {
-        init_vec<1>(z, v_b1 + c * MC);
+      for (int c = 1; c < M / MC - 1; ++c) {                                       // zc = z_c, gb = GELU(c-1)
         if (c == 4) ws.probe = 48;
-        gemm_stage<1, D / 16>(z, xb, ring0, ws, lane);                 // b1[c] + W1[c] LN2(x1)
+        gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane, side_work<5>([&](int g) {   // x1 += W2[:, c-1] GELU(c-1) | GELU(c) 0..7
+          gelu_n(y, zc[0], 2 * g, 2 * g, 2);
+          if (g == 3) pack8(gn[0], y);
+        }));
         ws.probe = 0;
         WMZ_TS(5 + 3 * c);
+        init_vec<1>(zn, v_b1 + (c + 1) * MC);
         if (c == 4) ws.probe = 52;
-        float y[8];
-        gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane, [&](int g) {   // x1 += W2[:, c-1] GELU(c-1) | GELU(c)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) y[(g & 1) * 4 + j] = wmz_gelu_fast(z[0][4 * g + j]);
-          if (g & 1) pack8(gn[g >> 1], y);
-        });
+        gemm_stage_b<1, D / 16>(zn, lnb, ring0, ws, lane, side_work<5>([&](int g) {      // z_{c+1} | GELU(c) 8..15
+          gelu_n(y, zc[0], 8 + 2 * g, 2 * g, 2);
+          if (g == 3) pack8(gn[1], y);
+        }));
         ws.probe = 0;
         WMZ_TS(7 + 3 * c);
+        zc[0] = zn[0];
         gb[0] = gn[0];
         gb[1] = gn[1];
       }
-      gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane);            // x1 += W2[:, 7] GELU(7)
+      gemm_stage<D / 32, MC / 16>(xr, gb, ring0, ws, lane, side_work<9>([&](int g) {     // x1 += W2[:, 6] GELU(6) | GELU(7), all of it
+        gelu_n(y, zc[0], 4 * g, (g & 1) * 4, 4);
+        if (g & 1) pack8(gn[g >> 1], y);
+      }));
+      gemm_stage<D / 32, MC / 16>(xr, gn, ring0, ws, lane);                        // x1 += W2[:, 7] GELU(7)
       WMZ_TS(29);
     }
     add_vec<D / 32>(xr, v_b2);                                         //                 -> x2
@@ -602,10 +656,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
       zero_acc(qa);
       gemm_stage<I / 32, D / 16>(qa, x2b, ring0, ws, lane);            // to_q on the raw stream
       WMZ_TS(32);
-      Frag8<bf16_t> qb[I / 16];
-      bop_from_acc<I / 32>(qb, qa);
-      store_tile128(stg, P.q, I, tok0, P.ntok, 0, qb, lane);
-      ws_extra(ws, 8);
+      bop_from_acc<I / 32>(qkvb, qa);                                  // stored under the to_k MFMAs below
     }
   } else {
     if (P.z != nullptr) {                                            // first layer: x = embedding, also written to x_out
@@ -629,10 +680,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
       f32x16 qa[I / 32];
       zero_acc(qa);
       gemm_stage<I / 32, D / 16>(qa, xb, ring0, ws, lane);             // to_q on the raw stream
-      Frag8<bf16_t> qb[I / 16];
-      bop_from_acc<I / 32>(qb, qa);
-      store_tile128(stg, P.q, I, tok0, P.ntok, 0, qb, lane);
-      ws_extra(ws, 8);
+      bop_from_acc<I / 32>(qkvb, qa);
     }
     acc_from_bop<D / 32>(xr, xb);
     ln_to_bop<D / 32>(xb, xr, P.eps);                   // LN1'(x)
@@ -641,11 +689,13 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     f32x16 ka[I / 32];
     Frag8<bf16_t> kb[I / 16];
     init_vec<I / 32>(ka, v_bk);
+    store_tile128(stg, P.q, I, tok0, P.ntok, 0, qkvb, lane);         // q rows (as side work under the to_k MFMAs: slower)
+    ws_extra(ws, 8);
     WMZ_TS(33);
     gemm_stage<I / 32, D / 16>(ka, xb, ring0, ws, lane);               // to_k
     WMZ_TS(34);
     bop_from_acc<I / 32>(kb, ka);
-    store_tile128(stg, P.kv, I, tok0, P.ntok, 0, kb, lane);                       // k rows
+    store_tile128(stg, P.kv, I, tok0, P.ntok, 0, kb, lane);            // k rows
     ws_extra(ws, 8);
     init_vec<I / 32>(ka, v_bv);
     WMZ_TS(35);
