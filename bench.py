@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cone', action='store_true', help='skip the secondary last-frame-cone figure (cleaner kernel traces)')
     ap.add_argument('--eager', action='store_true', help='replay the Python launch path instead of the hipGraph')
     ap.add_argument('--train-steps', type=int, default=8, help='timed full training steps reported as train_step (0 = skip)')
     a = ap.parse_args()
@@ -234,6 +235,19 @@ def main():
                       'launches_per_step': cfg['depth'] - 1, 'launches_timed': reps}
     else:
         fused_roof = None
+    # `traffic`: fabric-side bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
+    # gfx950 correction applied) -- they cannot be collected inside this process, so the committed measurement of the same
+    # kernels at the same shapes is reported (profiles/r01/v3_pmc_traffic.json says how it was taken); null if it is absent.
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'v3_pmc_traffic.json')) as f:
+            pmc = json.load(f)
+        attn_roof['traffic'] = pmc['attn_fwd_row16_kernel<128,1>']['traffic_bytes_per_launch']
+        attn_roof['traffic_source'] = 'profiles/r01/v3_pmc_traffic.json (rocprofv3 PMC pass, same kernel and shapes)'
+        if fused_roof is not None:
+            fused_roof['traffic'] = pmc['layer_fused_kernel<head,tail>']['traffic_bytes_per_launch']
+            fused_roof['traffic_source'] = attn_roof['traffic_source']
+    except (OSError, KeyError, ValueError):
+        pass
     # `roofline` = the kernel with the larger share of the step
     dominant_fused = fused_roof is not None and fused_ms * (cfg['depth'] - 1) > attn_ms * cfg['depth']
     out = {
@@ -255,7 +269,7 @@ def main():
     }
     # ---- secondary figure: the same forward with the dead planes elided (bit-identical logits; NOT the headline)
     cone = None
-    if use_fused and not a.eager:
+    if use_fused and not a.eager and not a.no_cone:
         wcfg.set_last_frame_cone(True)
         with torch.no_grad():
             crun = GraphedForward(model, z)
