@@ -175,22 +175,27 @@ def test_fused_layer_path_matches_unfused_and_oracle(wmz):
     assert e_f < 1.5 * e_u + 1e-3                        # keeping the residual stream in fp32 registers must not hurt
 
 
-@pytest.mark.parametrize('S,extents,depth,B', [(32, (3, 3, 3), 4, 2), (5, (3, 3, 3), 3, 3), (9, (1, 2, 3), 4, 1),
-                                                (12, (0, 3, 3), 2, 2), (7, (2, 1, 1), 1, 2)])
-def test_last_frame_cone_is_bit_identical(wmz, S, extents, depth, B):
+@pytest.mark.parametrize('S,extents,depth,B,HW', [(32, (3, 3, 3), 4, 2, (16, 16)), (5, (3, 3, 3), 3, 3, (16, 16)),
+                                                   (9, (1, 2, 3), 4, 1, (16, 16)), (12, (0, 3, 3), 2, 2, (16, 16)),
+                                                   (7, (2, 1, 1), 1, 2, (16, 16)),
+                                                   (6, (2, 2, 2), 3, 2, (8, 8)),      # W != 16: general attention kernel
+                                                   (5, (1, 1, 2), 2, 3, (5, 5)),      # ragged tiles: row-major stream,
+                                                   (4, (1, 3, 3), 2, 1, (40, 16))])   # per-lane embedding; H > 16
+def test_last_frame_cone_is_bit_identical(wmz, S, extents, depth, B, HW):
     """The denoiser returns the last frame's logits only (reference main.py:33-36).  With config.last_frame_cone the
     planes outside that frame's dependence cone are not launched: the logits must equal the full-grid ones BIT FOR BIT
     (same kernels, same per-token arithmetic), including when the cone is clipped by the clip length, eS = 0, depth 1."""
     from world_modelz_amd import fused
     torch.manual_seed(11)
-    m = wmz['main'].VqVideoDiffusionModel(data_shape=(S, 16, 16), dim=256, num_classes=257, extents=extents, depth=depth,
+    Hh, Ww = HW
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(S, Hh, Ww), dim=256, num_classes=257, extents=extents, depth=depth,
                                           dim_head=128, mlp_dim=256, heads=1)
     with torch.no_grad():
         for n, p in m.named_parameters():
             if 'norm' in n or n.endswith('bias'):
                 p.add_(0.2 * torch.randn_like(p))
     m = m.cuda().eval()
-    z = torch.randint(0, 258, (B, S, 16, 16)).cuda()
+    z = torch.randint(0, 258, (B, S, Hh, Ww)).cuda()
     need, src = fused.cone_planes(S, extents[0], depth)
     assert need[-1] == 1 and all(1 <= n <= S for n in need) and all(s >= n for s, n in zip(src, need))
     with wmz['config'].compute_dtype(torch.bfloat16), torch.no_grad():
@@ -198,7 +203,7 @@ def test_last_frame_cone_is_bit_identical(wmz, S, extents, depth, B):
             full = m(z)
         with wmz['config'].last_frame_cone(True):
             cone = m(z)
-    assert full.shape == cone.shape == (B, 16, 16, 257)
+    assert full.shape == cone.shape == (B, Hh, Ww, 257)
     assert torch.equal(full, cone)
     # and the full-grid result is the oracle's (bf16 operand tolerance)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
