@@ -239,8 +239,7 @@ __global__ __launch_bounds__(NT) void ln_stats_kernel(const T* __restrict__ X, l
       load4<T>(x + k, f);
       s += (f[0] + f[1]) + (f[2] + f[3]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum(s);
     const float mu = s / (float)K;
     float q = 0.f;
     for (int k = lane * 4; k < K; k += 256) {
@@ -249,20 +248,22 @@ __global__ __launch_bounds__(NT) void ln_stats_kernel(const T* __restrict__ X, l
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float d = f[e] - mu; q += d * d; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_sum(q);
     if (lane == 0) { mean[m] = mu; rstd[m] = rsqrtf(q / (float)K + eps); }
   }
 }
 
 // dx = rstd * (g*dy - mean_k(g*dy) - xhat * mean_k(g*dy*xhat)) + skip ;  dgamma += sum_m dy*xhat ; dbeta += sum_m dy
 // KMAX4 = K / 256 rounded up: per-lane column groups kept in registers.
+// 16 waves per workgroup: the dgamma / dbeta partials of 16 rows-in-flight meet in LDS, so each column receives a quarter of
+// the same-address float atomics a 4-wave workgroup would send (those serialise in L2 and all arrive at the end).
 template <typename T, int KG>
-__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY, long lddy,
+__global__ __launch_bounds__(1024 / KG) void ln_bwd_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY, long lddy,
                                                     const T* __restrict__ SKIP, long ldskip, const float* __restrict__ gamma,
                                                     T* __restrict__ DX, long lddx, float* __restrict__ dgamma,
                                                     float* __restrict__ dbeta, int M, int K, float eps) {
-  __shared__ float red[2][NT / 64][KG * 256];
+  constexpr int NTL = 1024 / KG;                        // 16 / 8 / 4 waves: the LDS partials stay at 32 KB
+  __shared__ float red[2][NTL / 64][KG * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float gsum[KG][4], bsum[KG][4], gam[KG][4];
 #pragma unroll
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, lon
       const int k = c * 256 + lane * 4 + e;
       gam[c][e] = k < K ? gamma[k] : 0.f;
     }
-  for (int m = blockIdx.x * (NT / 64) + wave; m < M; m += gridDim.x * (NT / 64)) {
+  for (int m = blockIdx.x * (NTL / 64) + wave; m < M; m += gridDim.x * (NTL / 64)) {
     float xv[KG][4], dy[KG][4];
     float s = 0.f;
 #pragma unroll
@@ -288,8 +289,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, lon
       }
       s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum(s);
     const float mu = s / (float)K;
     float q = 0.f;
 #pragma unroll
@@ -300,8 +300,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, lon
         const float d = k < K ? xv[c][e] - mu : 0.f;
         q += d * d;
       }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_sum(q);
     const float rs = rsqrtf(q / (float)K + eps);
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -317,8 +316,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, lon
         gsum[c][e] += dy[c][e] * xh;
         bsum[c][e] += dy[c][e];
       }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
     c1 /= (float)K;
     c2 /= (float)K;
 #pragma unroll
@@ -342,10 +341,10 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ X, lon
       red[1][wave][c * 256 + lane * 4 + e] = bsum[c][e];
     }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += NT) {
+  for (int k = threadIdx.x; k < K; k += NTL) {
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int w = 0; w < NT / 64; ++w) { a += red[0][w][k]; b += red[1][w][k]; }
+    for (int w = 0; w < NTL / 64; ++w) { a += red[0][w][k]; b += red[1][w][k]; }
     atomicAdd(dgamma + k, a);
     atomicAdd(dbeta + k, b);
   }
@@ -436,10 +435,11 @@ extern "C" int wmz_layernorm_bwd(const void* x, long ldx, const void* dyhat, lon
   WMZ_REQUIRE(M > 0 && K > 0 && K % 4 == 0, "wmz_layernorm_bwd: bad shape (K %% 4 == 0 required)");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_layernorm_bwd: bad dtype %d", dtype);
   if (K > 1024) { wmz_set_error("wmz_layernorm_bwd: K=%d > 1024 not built", K); return WMZ_ERR_UNSUPPORTED; }
-  const int grid = wmz_cdiv(M, 16) < 1024 ? wmz_cdiv(M, 16) : 1024;
   hipStream_t st = (hipStream_t)stream;
-  const int kg = wmz_cdiv(K, 256);
-#define WMZ_LNB(T, KG) hipLaunchKernelGGL((ln_bwd_kernel<T, KG>), dim3(grid), dim3(NT), 0, st, (const T*)x, ldx, (const T*)dyhat, lddy, \
+  const int kg = wmz_cdiv(K, 256) <= 1 ? 1 : (wmz_cdiv(K, 256) == 2 ? 2 : 4);
+  const int rows_per_wg = 16 / kg * 4;
+  const int grid = wmz_cdiv(M, rows_per_wg) < 256 * kg ? wmz_cdiv(M, rows_per_wg) : 256 * kg;
+#define WMZ_LNB(T, KG) hipLaunchKernelGGL((ln_bwd_kernel<T, KG>), dim3(grid), dim3(1024 / KG), 0, st, (const T*)x, ldx, (const T*)dyhat, lddy, \
                                           (const T*)skip, ldskip, gamma, (T*)dx, lddx, dgamma, dbeta, M, K, eps)
   if (dtype == WMZ_BF16) { if (kg == 1) WMZ_LNB(bf16_t, 1); else if (kg == 2) WMZ_LNB(bf16_t, 2); else WMZ_LNB(bf16_t, 4); }
   else { if (kg == 1) WMZ_LNB(float, 1); else if (kg == 2) WMZ_LNB(float, 2); else WMZ_LNB(float, 4); }

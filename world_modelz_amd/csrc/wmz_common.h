@@ -181,6 +181,19 @@ __device__ __forceinline__ float wave_halves_sum(float v) {          // lanes l,
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Sum over all 64 lanes, result in every lane: four DPP row rotations (within the 16-lane rows) and the two swaps above
+// (across the rows) -- VALU only.  The __shfl_xor butterfly is six ds_bpermute round trips per reduction.
+template <int N> __device__ __forceinline__ float dpp_row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 | N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_row_ror<8>(v);
+  v += dpp_row_ror<4>(v);
+  v += dpp_row_ror<2>(v);
+  v += dpp_row_ror<1>(v);
+  return wave_groups_sum(v);
+}
+
 // wave64 butterfly helpers
 __device__ __forceinline__ float wave_xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask)); }
 __device__ __forceinline__ float wave_xor_add(float v, int mask) { return v + __shfl_xor(v, mask); }
