@@ -67,6 +67,13 @@ int wmz_linear_fwd(const void* A, long lda, const void* Wt, const float* bias, c
                    void* C, long ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
                    float ln_eps, int flags, int out_f32, int dtype, void* stream);
 
+/* The same with the LayerNorm statistics supplied (mean / rstd [M] from wmz_layernorm_stats, or NULL): the training
+ * forward computes them once, the prologue skips its two passes over A, and the backward reuses them. */
+int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, const float* bias, const void* residual, long ldr,
+                         void* C, long ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
+                         const float* ln_mean, const float* ln_rstd, float ln_eps, int flags, int out_f32, int dtype,
+                         void* stream);
+
 /* Weight / bias gradient of the family above: dW[N,K] += dC[M,N]^T . A'[M,K], dbias[N] += colsum(dC), where
  * A' = A, LayerNorm(A) (ln_* non-NULL; mean/rstd from wmz_layernorm_stats) or GELU(A) (gelu_in).  dW / dbias are fp32
  * and ACCUMULATED with float atomics (split over M): zero them first, or pass .grad buffers to accumulate. */

@@ -85,7 +85,7 @@ def attention_block_backward(ctx, dy):
     g_ln_g = g_ln_b = None
     dk, dv = dkv[..., :I], dkv[..., I:]
     if ln_g is not None:
-        stats = ops.layernorm_stats(x_kv, LN_EPS)
+        stats = ctx.ln_stats if getattr(ctx, 'ln_stats', None) is not None else ops.layernorm_stats(x_kv, LN_EPS)
         lnp = (ln_g.detach(), ln_b.detach())
         g_wk = _emit(wk, lambda w: ops.linear_wgrad(dk, x_kv, w, None, ln=lnp, ln_stats=stats))
         g_wv, g_bv = _emit2(wv, bv, lambda w, b: ops.linear_wgrad(dv, x_kv, w, b, ln=lnp, ln_stats=stats))
@@ -117,7 +117,7 @@ def feed_forward_block_backward(ctx, dy):
     dxhat = ops.linear_dgrad(dz, _wt(w1, dt, 'w1T'))
     dg = db = None
     if ln_g is not None:
-        stats = ops.layernorm_stats(x, LN_EPS)
+        stats = ctx.ln_stats if getattr(ctx, 'ln_stats', None) is not None else ops.layernorm_stats(x, LN_EPS)
         lnp = (ln_g.detach(), ln_b.detach())
         dw1, db1 = _emit2(w1, b1, lambda w, b: ops.linear_wgrad(dz, x, w, b, ln=lnp, ln_stats=stats))
         # the transformer passes residual = x: fold the skip gradient into the LayerNorm backward

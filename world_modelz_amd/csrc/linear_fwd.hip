@@ -22,6 +22,7 @@ struct LinParams {
   void* C; long ldc;
   int M, N, K;
   const float* gamma; const float* beta; float eps;
+  const float* mean; const float* rstd;      // optional precomputed LayerNorm statistics (wmz_layernorm_stats)
   int flags, out_f32;
   int nbn;
 };
@@ -78,6 +79,14 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   const int K = P.K;
 
   if constexpr (LN) {
+   if (P.mean != nullptr) {
+    // statistics supplied by the caller (training: computed once, reused by the backward): no extra pass over A
+    for (int r = tid; r < BM; r += NT) {
+      const int gm = m0 + r < P.M ? m0 + r : P.M - 1;
+      mean_s[r] = P.mean[gm];
+      rstd_s[r] = P.rstd[gm];
+    }
+   } else {
     // 8 lanes per row, 32 rows per sweep; two passes (mean, then centred sum of squares)
     const int sub = tid & 7;
     for (int r = tid >> 3; r < BM; r += NT / 8) {
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
       sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
       if (sub == 0) { mean_s[r] = mean; rstd_s[r] = rsqrtf(sq / (float)K + P.eps); }
     }
+   }
   }
 
   // this thread's 4 chunks of each slab: rows r_i = (tid>>3) + 32 i, chunk column cc = tid & 7
@@ -302,7 +312,17 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 extern "C" int wmz_linear_fwd(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
                               long ldr, void* C, long ldc, int M, int N, int K, const float* ln_gamma,
                               const float* ln_beta, float ln_eps, int flags, int out_f32, int dtype, void* stream) {
+  return wmz_linear_fwd_stats(A, lda, Wt, bias, residual, ldr, C, ldc, M, N, K, ln_gamma, ln_beta, nullptr, nullptr, ln_eps,
+                              flags, out_f32, dtype, stream);
+}
+
+extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
+                                    long ldr, void* C, long ldc, int M, int N, int K, const float* ln_gamma,
+                                    const float* ln_beta, const float* ln_mean, const float* ln_rstd, float ln_eps,
+                                    int flags, int out_f32, int dtype, void* stream) {
   WMZ_REQUIRE(A && Wt && C, "wmz_linear_fwd: null tensor");
+  WMZ_REQUIRE((ln_mean == nullptr) == (ln_rstd == nullptr), "wmz_linear_fwd: ln_mean and ln_rstd go together");
+  WMZ_REQUIRE(ln_mean == nullptr || ln_gamma != nullptr, "wmz_linear_fwd: statistics without a LayerNorm prologue");
   WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
   WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0, "wmz_linear_fwd: K and lda must be multiples of 8 (K=%d lda=%ld)", K, lda);
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd: bad dtype %d", dtype);
@@ -310,6 +330,7 @@ extern "C" int wmz_linear_fwd(const void* A, long lda, const void* Wt, const flo
   LinParams P;
   P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = residual; P.ldr = ldr; P.C = C; P.ldc = ldc;
   P.M = M; P.N = N; P.K = K; P.gamma = ln_gamma; P.beta = ln_beta; P.eps = ln_eps; P.flags = flags;
+  P.mean = ln_mean; P.rstd = ln_rstd;
   P.out_f32 = out_f32;
   const int nbm = wmz_cdiv(M, BM);
   P.nbn = wmz_cdiv(N, BN);

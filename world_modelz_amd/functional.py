@@ -27,9 +27,11 @@ class _AttentionBlock(torch.autograd.Function):
         wkv_c = _cast.operand((wk, wv), dt, 'kv', lambda a, b: torch.cat([a, b], dim=0))
         bkv = _cast.operand((bv,), torch.float32, 'bkv', lambda b: torch.cat([torch.zeros_like(b), b]))
         lead = x_q.shape[:-1]
-        q = ops.linear_fwd(x_q, wq_c)                                           # to_q: no bias, raw input (Q1)
-        kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS)        # to_k | to_v on LN(x)
         need_bwd = grad_on and any(ctx.needs_input_grad)     # grad mode is always off inside forward()
+        # training: the LayerNorm statistics are computed once, handed to the GEMM prologue and kept for the backward
+        stats = ops.layernorm_stats(x_kv, LN_EPS) if (need_bwd and ln is not None) else None
+        q = ops.linear_fwd(x_q, wq_c)                                           # to_q: no bias, raw input (Q1)
+        kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS, ln_stats=stats)   # to_k | to_v on LN(x)
         o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], extents, heads, need_lse=need_bwd)
         if wout is not None:
             y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual)
@@ -38,6 +40,7 @@ class _AttentionBlock(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse)
             ctx.extents, ctx.heads, ctx.has_res = extents, heads, residual is not None
+            ctx.ln_stats = stats
             ctx.res_is_xkv = (residual is not None and residual.data_ptr() == x_kv.data_ptr()
                               and residual.shape == x_kv.shape)
         return y.reshape(*lead, y.shape[-1])
@@ -57,9 +60,11 @@ class _FeedForwardBlock(torch.autograd.Function):
         w1_c, w2_c = _cast.operand(w1, dt), _cast.operand(w2, dt)
         if need_bwd:
             # keep the pre-activation; GELU is applied while the second GEMM stages its A operand
-            z = ops.linear_fwd(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS)
+            stats = ops.layernorm_stats(x, LN_EPS) if ln is not None else None
+            z = ops.linear_fwd(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, ln_stats=stats)
             y = ops.linear_fwd(z, w2_c, bias=b2.detach(), residual=residual, gelu_in=True)
             ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z)
+            ctx.ln_stats = stats
             ctx.has_res = residual is not None
             ctx.res_is_x = residual is not None and residual.data_ptr() == x.data_ptr() and residual.shape == x.shape
         else:

@@ -53,8 +53,9 @@ def local3d_attention_fwd(q, k, v, extents, heads, need_lse=False, logits_dbg=Fa
 
 
 def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=False, gelu_in=False, out_f32=False,
-               out=None):
-    """act(LN?(a) @ weight^T + bias) + residual.   a: [..., K]; weight: [N, K] in a's dtype; bias / ln fp32."""
+               out=None, ln_stats=None):
+    """act(LN?(a) @ weight^T + bias) + residual.   a: [..., K]; weight: [N, K] in a's dtype; bias / ln fp32.
+    ln_stats = (mean, rstd) from layernorm_stats(a): the prologue then skips its own two passes over a."""
     K = a.shape[-1]
     N = weight.shape[0]
     dt = L.dtype_code(a.dtype)
@@ -75,8 +76,12 @@ def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=F
         assert g.dtype == torch.float32 and b.dtype == torch.float32
     if bias is not None:
         assert bias.dtype == torch.float32
-    L.call('wmz_linear_fwd', L.ptr(a), lda, L.ptr(weight), L.ptr(bias), L.ptr(residual), ldr, L.ptr(out), ldc,
-           M, N, K, L.ptr(g), L.ptr(b), float(ln_eps),
+    mean = rstd = None
+    if ln_stats is not None:
+        mean, rstd = ln_stats
+        assert ln is not None and mean.numel() == M and rstd.numel() == M
+    L.call('wmz_linear_fwd_stats', L.ptr(a), lda, L.ptr(weight), L.ptr(bias), L.ptr(residual), ldr, L.ptr(out), ldc,
+           M, N, K, L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(rstd), float(ln_eps),
            (L.WMZ_LIN_GELU if gelu else 0) | (L.WMZ_LIN_GELU_IN if gelu_in else 0), 1 if out_f32 else 0, dt,
            L.stream())
     return out
