@@ -174,6 +174,28 @@ int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const flo
                                    const float* vec, int B, int S, int H, int W, int planes_out, int D, int I, int M,
                                    int num_classes, int xflags, float eps, void* stream);
 
+/* Builds the packed weight stream and the vector block of wmz_layer_fused_fwd* from the layer's fp32 parameters in one
+ * launch (the LayerNorm affines g2/be2 -- the feed-forward's norm -- and g1/be1 -- the NEXT layer's attention norm -- are
+ * folded in).  Head parameters (wout .. b2) NULL: tail-only stream; tail parameters (g1 .. bv) NULL: head-only.
+ * wpack: (weights + 32 768) bf16, vec: 2048 fp32. */
+int wmz_layer_fused_pack(const float* wout, const float* bout, const float* g2, const float* be2, const float* w1,
+                         const float* b1, const float* w2, const float* b2, const float* g1, const float* be1,
+                         const float* wq, const float* wk, const float* wv, const float* bv, void* wpack, float* vec,
+                         int D, int I, int M, void* stream);
+
+/* Training forward on the same kernels (replaces the five per-op GEMM launches per layer of the training forward).
+ * Besides the inference outputs they write what the backward (wmz_linear_wgrad, wmz_layernorm_bwd, wmz_local3d_attn_bwd
+ * ..) reads, row-major: x1_out [ntok, D] = the feed-forward block's input (x + to_out(o)), x_out_rowmajor [ntok, D] = a
+ * row-major copy of x_out when x_out itself is tiled (NULL otherwise), and kv_out as ONE [ntok, 2I] buffer (k | v column
+ * halves).  The feed-forward pre-activation is not exported: the backward recomputes it with one LayerNorm-GEMM. */
+int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_out, void* x_out_rowmajor, void* x1_out, void* q_out,
+                              void* kv_out, const void* wpack, const float* vec, int ntok, int D, int I, int M,
+                              int has_head, int has_tail, int xflags, float eps, void* stream);
+int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+                                  const float* pos_w, void* x_out, void* x_out_rowmajor, void* q_out, void* kv_out,
+                                  const void* wpack, const float* vec, int B, int S, int H, int W, int D, int I, int M,
+                                  int num_classes, int xflags, float eps, void* stream);
+
 /* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
  * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */
 int wmz_debug_fused_timestamps(void* buf);

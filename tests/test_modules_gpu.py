@@ -209,3 +209,32 @@ def test_last_frame_cone_is_bit_identical(wmz, S, extents, depth, B, HW):
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     ref = oden.denoiser_forward(sd, z.cpu(), extents, 1)
     assert rel(cone, ref) < 3e-2
+
+
+def test_fused_kernel_stays_inside_its_buffers(wmz):
+    """384 tokens = 1.5 workgroups of the fused per-token kernel: the waves past the end must neither read nor write
+    (tiled stream layout: a whole 32-token tile per wave).  Every output is carved out of a larger canary-filled tensor."""
+    from world_modelz_amd import fused, _lib as L
+    torch.manual_seed(3)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(6, 8, 8), dim=256, num_classes=64, extents=(1, 1, 1), depth=2,
+                                          dim_head=128, mlp_dim=256, heads=1).cuda()
+    layers = list(m.transformer.layers)
+    ntok, D, I = 384, 256, 128
+    bf = torch.bfloat16
+    canary = 12345.0
+
+    def carve(n):
+        big = torch.full((n + 65536,), canary, dtype=bf, device='cuda')
+        return big, big[:n]
+    xbig, x = carve(ntok * D); x.copy_(torch.randn(ntok * D, device='cuda'))
+    obig, o = carve(ntok * I); o.copy_(torch.randn(ntok * I, device='cuda'))
+    outs = {k: carve(n) for k, n in (('xo', ntok * D), ('q', ntok * I), ('kv', 2 * ntok * I))}
+    wpack, vec = fused._layer_pack(layers[0], layers[1])
+    for xflags in (0, 3):
+        L.call('wmz_layer_fused_fwd_planes', L.ptr(o), L.ptr(x), L.ptr(outs['xo'][1]), L.ptr(outs['q'][1]), L.ptr(outs['kv'][1]),
+               L.ptr(wpack), L.ptr(vec), 1, 1, 1, ntok, D, I, 256, 1, 1, xflags, 1e-5, L.stream())
+        torch.cuda.synchronize()
+        for name, (big, view) in outs.items():
+            assert torch.isfinite(view.float()).all(), name
+            assert (big[view.numel():] == canary).all(), f'{name}: written past the end (xflags={xflags})'
+        assert (xbig[x.numel():] == canary).all() and (obig[o.numel():] == canary).all()

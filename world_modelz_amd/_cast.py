@@ -35,6 +35,20 @@ def operand(params, dtype, tag='w', build=None):
     return val
 
 
+def cached(params, tag, build):
+    """Like operand(), for values that are not a single cast tensor: `build(*params)` is kept until any parameter changes."""
+    params = tuple(params)
+    key = _key(params, None, tag)
+    ver = (_epoch,) + tuple((p._version, p.data_ptr()) for p in params)
+    hit = _cache.get(key)
+    if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
+        return hit[1]
+    with torch.no_grad():
+        val = build(*params)
+    _cache[key] = (ver, val, tuple(weakref.ref(p) for p in params))
+    return val
+
+
 def invalidate():
     """Parameters changed in place without torch noticing (wmz_adamw_step on the flat arena)."""
     global _epoch

@@ -70,6 +70,9 @@ struct FusedParams {
   // instruction of the kernel is then one contiguous KB.  Private to the fused path (layer -> layer); the last layer
   // writes row-major.
   int xflags;
+  // training forward (wmz_*_train): what the backward needs, row-major -- x1 (input of the feed-forward block), a row-major
+  // copy of x_out beside the tiled one, and k | v as the column halves of one [ntok, 2I] buffer
+  bf16_t* x1o; bf16_t* xo_rm; int kv_combined;
   long long* ts;        // timing probe (wmz_debug_fused_timestamps): workgroup 0 writes s_memtime at stage boundaries
 };
 // stage-boundary probe: wave w of workgroup 0 stores the shader clock into ts[w * 64 + slot]
@@ -544,6 +547,10 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   const long tok0 = (long)blockIdx.x * (TW * FW) + wave * TW;        // first token of this wave
   const long tok = tok0 + (lane & 31);
   const long tokc = tok < P.ntok ? tok : P.ntok - 1;                  // clamped: loads are unconditional
+  // tiled stream: ntok is a whole number of 32-token tiles, a wave's tile is all valid or all beyond the end -- a wave
+  // beyond the end re-reads the last tile and stores nothing
+  const bool tile_ok = tok0 < P.ntok;
+  const long tok0c = tile_ok ? tok0 : (P.ntok >= 32 ? P.ntok - 32 : 0);
   char* stg = smem + VECB + RING * SLAB + wave * 8192;                // this wave's store-staging image
   static_assert(NTHR * 4 == 2048 && FW * 1024 == VECB, "vector block is 2048 floats, one KB per wave");
   const float* v_bout = vecs + h * (D / 2);                            // bout[D] b1'[M] b2[D] bk'[I] bv'[I]
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     for (int i = 0; i < RING - 1; ++i) ws_issue(ws);                   // prime: RING-1 slabs in flight
     const bool xt = (P.xflags & WMZ_FUSED_X_IN_TILED) != 0;
     {
-      const bf16_t* xp = xt ? P.x + src_row(P, tok0) * D + lane * 8 : P.x + src_row(P, tokc) * D + h * (D / 2);
+      const bf16_t* xp = xt ? P.x + src_row(P, tok0c) * D + lane * 8 : P.x + src_row(P, tokc) * D + h * (D / 2);
       const int xs = xt ? 64 * 8 : 8;                                  // elements between consecutive k-steps
 #pragma unroll
       for (int s = 0; s < D / 16; ++s) xb[s].v = gload_untracked(xp + s * xs);
@@ -586,6 +593,11 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     wait_untracked<D / 16>(xb);                                        // the residual rows are older than the ring's 6 pieces
     WMZ_TS(45);
     add_bop<D / 32>(xr, xb);                                           // + x  -> x1
+    if (P.x1o != nullptr) {                                            // training: the backward's LayerNorm / wgrad input
+      bop_from_acc<D / 32>(xb, xr);
+      store_tile256(stg, P.x1o, tok0, P.ntok, xb, lane);
+      ws_extra(ws, 16);
+    }
     WMZ_TS(3);
     ln_to_bop<D / 32>(xb, xr, P.eps);                     // LN2(x1)
     WMZ_TS(4);
@@ -647,9 +659,10 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     if constexpr (TAIL) ln_and_pack<D / 32>(xb, x2b, xr, P.eps);   // + LN1'(x2), while x2 is still fp32
     else bop_from_acc<D / 32>(x2b, xr);
     WMZ_TS(30);
-    if (P.xflags & WMZ_FUSED_X_OUT_TILED) store_bop_tiled<D / 16>(P.xo + tok0 * D, x2b, lane);
+    if (P.xflags & WMZ_FUSED_X_OUT_TILED) { if (tile_ok) store_bop_tiled<D / 16>(P.xo + tok0 * D, x2b, lane); }
     else store_tile256(stg, P.xo, tok0, P.ntok, x2b, lane);
     ws_extra(ws, 16);
+    if (P.xo_rm != nullptr) { store_tile256(stg, P.xo_rm, tok0, P.ntok, x2b, lane); ws_extra(ws, 16); }
     WMZ_TS(31);
     if constexpr (TAIL) {
       f32x16 qa[I / 32];
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
       if (coop) embed_coop<D>(xb, stg, P, tok0, lane);
       else embed_bop<D>(xb, P, tokc, true, h);
     }
-    else if (P.xflags & WMZ_FUSED_X_IN_TILED) load_bop_tiled<D / 16>(xb, P.x + src_row(P, tok0) * D, lane);
+    else if (P.xflags & WMZ_FUSED_X_IN_TILED) load_bop_tiled<D / 16>(xb, P.x + src_row(P, tok0c) * D, lane);
     else load_bop<D / 16>(xb, P.x + src_row(P, tokc) * D + h * (D / 2));
     const f32x4 vecv = *reinterpret_cast<const f32x4*>(P.vec + tid * 4);
 #pragma unroll
@@ -672,9 +685,10 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     *reinterpret_cast<f32x4*>(vecs + tid * 4) = vecv;
     __syncthreads();
     if (P.z != nullptr) {
-      if (P.xflags & WMZ_FUSED_X_OUT_TILED) store_bop_tiled<D / 16>(P.xo + tok0 * D, xb, lane);
+      if (P.xflags & WMZ_FUSED_X_OUT_TILED) { if (tile_ok) store_bop_tiled<D / 16>(P.xo + tok0 * D, xb, lane); }
       else store_tile256(stg, P.xo, tok0, P.ntok, xb, lane);
       ws_extra(ws, 16);
+      if (P.xo_rm != nullptr) { store_tile256(stg, P.xo_rm, tok0, P.ntok, xb, lane); ws_extra(ws, 16); }
     }
     {
       f32x16 qa[I / 32];
@@ -695,14 +709,16 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     gemm_stage<I / 32, D / 16>(ka, xb, ring0, ws, lane);               // to_k
     WMZ_TS(34);
     bop_from_acc<I / 32>(kb, ka);
-    store_tile128(stg, P.kv, I, tok0, P.ntok, 0, kb, lane);            // k rows
+    if (P.kv_combined) store_tile128(stg, P.kv, 2 * I, tok0, P.ntok, 0, kb, lane);   // k | v column halves of [ntok, 2I]
+    else store_tile128(stg, P.kv, I, tok0, P.ntok, 0, kb, lane);       // k rows
     ws_extra(ws, 8);
     init_vec<I / 32>(ka, v_bv);
     WMZ_TS(35);
     gemm_stage<I / 32, D / 16>(ka, xb, ring0, ws, lane);               // to_v
     WMZ_TS(36);
     bop_from_acc<I / 32>(kb, ka);
-    store_tile128(stg, P.kv + (long)P.ntok * I, I, tok0, P.ntok, 0, kb, lane);    // v rows, behind the k rows
+    if (P.kv_combined) store_tile128(stg, P.kv, 2 * I, tok0, P.ntok, I, kb, lane);
+    else store_tile128(stg, P.kv + (long)P.ntok * I, I, tok0, P.ntok, 0, kb, lane);    // v rows, behind the k rows
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the padding slabs still in flight target this workgroup's LDS
   WMZ_TS(37);
@@ -720,6 +736,139 @@ extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, vo
                                    int has_tail, float eps, void* stream) {
   return wmz_layer_fused_fwd_planes(o, x, x_out, q_out, kv_out, wpack, vec, 1, 1, 1, ntok, D, I, M, has_head, has_tail, 0,
                                     eps, stream);
+}
+
+
+// ---- weight stream packer (host side of the kernel above used to be ~60 small torch launches per layer) ----------
+namespace {
+struct PackBlock { const float* w; long rs; int N, K; const float* gamma; long dst; };   // W[n*rs + k] (* gamma[k]) -> stream
+struct PackParams {
+  PackBlock blk[24]; int nblk; long total;          // total bf16 elements of the stream (without the padding)
+  bf16_t* wpack; long padded;
+  // vec: bout | b1 + W1 be2 | b2 | Wk be1 | bv + Wv be1   (2048 floats, zero padded)
+  const float *bout, *b1, *w1, *be2, *b2, *wk, *wv, *be1, *bv; float* vec; int D, I, M;
+};
+__global__ __launch_bounds__(256) void fused_pack_kernel(PackParams P) {
+  const long e8 = ((long)blockIdx.x * 256 + threadIdx.x) * 8;          // 8 consecutive stream elements = one lane's fragment
+  if (e8 < P.total) {
+    int bi = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.nblk; ++i) if (e8 >= P.blk[i].dst) bi = i;
+    const PackBlock B = P.blk[bi];
+    const long e = e8 - B.dst;
+    const int NB = B.N / 32;
+    const int piece = (int)(e / 512), lane = (int)((e % 512) / 8);
+    const int s = piece / NB, b = piece % NB;
+    const int r = lane & 31, h = lane >> 5;
+    const int f = ((r >> 2) & 1) * (16 * NB) + 16 * b + (r & 3) + 4 * (r >> 3);     // output feature of MFMA row r of block b
+    const int k0 = h * (B.K / 2) + 8 * s;
+    s16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = B.w[(long)f * B.rs + k0 + j];
+      if (B.gamma) x *= B.gamma[k0 + j];
+      v[j] = (short)f32_to_bf16_bits(x);
+    }
+    *reinterpret_cast<s16x8*>(P.wpack + e8) = v;
+  } else if (e8 < P.padded) {
+    *reinterpret_cast<s16x8*>(P.wpack + e8) = (s16x8)(0);
+  }
+  // the vector block: one thread per float (the three matrix-vector products are 256-long dots: tiny)
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < 2048) {
+    const int D = P.D, I = P.I, M = P.M;
+    float v = 0.f;
+    if (t < D) v = P.bout ? P.bout[t] : 0.f;
+    else if (t < D + M) {
+      const int n = t - D;
+      if (P.b1) { v = P.b1[n]; for (int k = 0; k < D; ++k) v = fmaf(P.w1[(long)n * D + k], P.be2[k], v); }
+    } else if (t < 2 * D + M) v = P.b2 ? P.b2[t - D - M] : 0.f;
+    else if (t < 2 * D + M + I) {
+      const int n = t - 2 * D - M;
+      if (P.wk) for (int k = 0; k < D; ++k) v = fmaf(P.wk[(long)n * D + k], P.be1[k], v);
+    } else if (t < 2 * D + M + 2 * I) {
+      const int n = t - 2 * D - M - I;
+      if (P.wv) { v = P.bv[n]; for (int k = 0; k < D; ++k) v = fmaf(P.wv[(long)n * D + k], P.be1[k], v); }
+    }
+    P.vec[t] = v;
+  }
+}
+}  // namespace
+
+extern "C" int wmz_layer_fused_pack(const float* wout, const float* bout, const float* g2, const float* be2, const float* w1,
+                                    const float* b1, const float* w2, const float* b2, const float* g1, const float* be1,
+                                    const float* wq, const float* wk, const float* wv, const float* bv, void* wpack,
+                                    float* vec, int D, int I, int M, void* stream) {
+  const bool head = wout != nullptr, tail = wq != nullptr;
+  WMZ_REQUIRE(wpack && vec && (head || tail), "wmz_layer_fused_pack: bad arguments");
+  WMZ_REQUIRE(D == 256 && I == 128 && M == 256, "wmz_layer_fused_pack: built for dim 256 / inner 128 / mlp 256");
+  WMZ_REQUIRE(!head || (bout && g2 && be2 && w1 && b1 && w2 && b2), "wmz_layer_fused_pack: head parameters missing");
+  WMZ_REQUIRE(!tail || (g1 && be1 && wk && wv && bv), "wmz_layer_fused_pack: tail parameters missing");
+  PackParams P;
+  int n = 0;
+  long off = 0;
+  auto add = [&](const float* w, long rs, int N, int K, const float* gamma) {
+    P.blk[n].w = w; P.blk[n].rs = rs; P.blk[n].N = N; P.blk[n].K = K; P.blk[n].gamma = gamma; P.blk[n].dst = off;
+    off += (long)N * K; ++n;
+  };
+  constexpr int MCH = 32;
+  if (head) {
+    add(wout, I, D, I, nullptr);
+    add(w1, D, MCH, D, g2);                                              // W1[0]
+    for (int c = 1; c < M / MCH; ++c) {
+      add(w1 + (long)c * MCH * D, D, MCH, D, g2);                        // W1[c]
+      add(w2 + (c - 1) * MCH, M, D, MCH, nullptr);                       // W2[:, c-1]
+    }
+    add(w2 + (M / MCH - 1) * MCH, M, D, MCH, nullptr);
+  }
+  if (tail) {
+    add(wq, D, I, D, nullptr);
+    add(wk, D, I, D, g1);
+    add(wv, D, I, D, g1);
+  }
+  P.nblk = n; P.total = off; P.padded = off + 65536 / 2;                 // + 64 KB of zeros behind the stream
+  P.wpack = (bf16_t*)wpack;
+  P.bout = head ? bout : nullptr; P.b1 = head ? b1 : nullptr; P.w1 = w1; P.be2 = be2; P.b2 = head ? b2 : nullptr;
+  P.wk = tail ? wk : nullptr; P.wv = tail ? wv : nullptr; P.be1 = be1; P.bv = bv; P.vec = vec; P.D = D; P.I = I; P.M = M;
+  const long threads = P.padded / 8 > 2048 ? P.padded / 8 : 2048;
+  hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)wmz_cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  WMZ_LAUNCH_CHECK("wmz_layer_fused_pack");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_out, void* x_out_rowmajor, void* x1_out,
+                                         void* q_out, void* kv_out, const void* wpack, const float* vec, int ntok, int D, int I,
+                                         int M, int has_head, int has_tail, int xflags, float eps, void* stream) {
+  WMZ_REQUIRE(x && wpack && vec && ntok > 0, "wmz_layer_fused_fwd_train: bad arguments");
+  WMZ_REQUIRE(has_head || has_tail, "wmz_layer_fused_fwd_train: nothing to do");
+  WMZ_REQUIRE(!has_head || (o && x_out), "wmz_layer_fused_fwd_train: head needs o and x_out");
+  WMZ_REQUIRE(!has_tail || (q_out && kv_out), "wmz_layer_fused_fwd_train: tail needs q_out and kv_out");
+  WMZ_REQUIRE((xflags & ~3) == 0 && (xflags == 0 || ntok % 32 == 0), "wmz_layer_fused_fwd_train: bad layout flags");
+  FusedParams P;
+  P.o = (const bf16_t*)o; P.x = (const bf16_t*)x; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
+  P.wpack = (const char*)wpack; P.vec = vec; P.ntok = ntok; P.eps = eps;
+  P.z = nullptr; P.emb = P.pos_s = P.pos_h = P.pos_w = nullptr; P.S = P.H = P.W = P.num_classes = 0;
+  P.rows_out = P.rows_in = P.row0 = 0;
+  P.xflags = xflags;
+  P.x1o = (bf16_t*)x1_out; P.xo_rm = (bf16_t*)x_out_rowmajor; P.kv_combined = 1;
+  return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
+}
+
+extern "C" int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+                                             const float* pos_w, void* x_out, void* x_out_rowmajor, void* q_out,
+                                             void* kv_out, const void* wpack, const float* vec, int B, int S, int H, int W,
+                                             int D, int I, int M, int num_classes, int xflags, float eps, void* stream) {
+  WMZ_REQUIRE(z && emb && pos_s && pos_h && pos_w && x_out && q_out && kv_out && wpack && vec, "wmz_embed_qkv_fused_fwd_train: null tensor");
+  WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && num_classes > 0 && (long)B * S * H * W < (1L << 31), "wmz_embed_qkv_fused_fwd_train: bad shape");
+  WMZ_REQUIRE((xflags & ~WMZ_FUSED_X_OUT_TILED) == 0 && (xflags == 0 || ((long)S * H * W) % 32 == 0), "wmz_embed_qkv_fused_fwd_train: bad layout flags");
+  FusedParams P;
+  P.o = nullptr; P.x = nullptr; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
+  P.wpack = (const char*)wpack; P.vec = vec; P.ntok = B * S * H * W; P.eps = eps;
+  P.rows_out = P.rows_in = P.row0 = 0;
+  P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
+  P.xflags = xflags;
+  P.x1o = nullptr; P.xo_rm = (bf16_t*)x_out_rowmajor; P.kv_combined = 1;
+  return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 
 extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
@@ -743,6 +892,7 @@ extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_
   P.rows_out = P.rows_in = P.row0 = 0;
   if (planes_out != planes_in) { P.rows_out = planes_out * HW; P.rows_in = planes_in * HW; P.row0 = (planes_in - planes_out) * HW; }
   P.xflags = xflags;
+  P.x1o = nullptr; P.xo_rm = nullptr; P.kv_combined = 0;
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
@@ -771,6 +921,7 @@ extern "C" int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb
   if (planes_out != S) { P.rows_out = planes_out * H * W; P.rows_in = S * H * W; P.row0 = (S - planes_out) * H * W; }
   P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
   P.xflags = xflags;
+  P.x1o = nullptr; P.xo_rm = nullptr; P.kv_combined = 0;
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 

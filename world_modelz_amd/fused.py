@@ -39,65 +39,32 @@ def supported(transformer, x_dtype):
 
 def _layer_pack(head, tail):
     """head / tail: (attn PreNorm, ff PreNorm) of the layer whose to_out+FF run, and of the layer whose q|k|v run.
-    The LayerNorm affines are folded into the GEMMs that consume them (W1' = W1 diag(g2), b1' = b1 + W1 be2; same for
-    to_k / to_v with the next layer's norm), so the kernel only normalises."""
+    Returns (wpack bf16, vec fp32) built by ONE launch of wmz_layer_fused_pack from the fp32 parameters: the weights in
+    the kernel's streaming order (see _pack_w for the element order; W1 rows one chunk ahead of the W2 columns:
+    W1[0], W1[1], W2[0], W1[2], W2[1], .., W1[7], W2[6], W2[7]) with the LayerNorm affines folded in (W1' = W1 diag(g2),
+    b1' = b1 + W1 be2; same for to_k / to_v with the next layer's norm), and bout | b1' | b2 | bk' | bv'."""
     params = []
     if head is not None:
         attn, ff = head
-        params += [attn.fn.to_out[0].weight, ff.fn.net[0].weight, ff.fn.net[3].weight, ff.norm.weight]
+        params += [attn.fn.to_out[0].weight, attn.fn.to_out[0].bias, ff.norm.weight, ff.norm.bias,
+                   ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias]
     if tail is not None:
-        attn_n = tail[0]
-        params += [attn_n.fn.to_q.weight, attn_n.fn.to_k.weight, attn_n.fn.to_v.weight, attn_n.norm.weight]
+        an = tail[0]
+        params += [an.norm.weight, an.norm.bias, an.fn.to_q.weight, an.fn.to_k.weight, an.fn.to_v.weight, an.fn.to_v.bias]
 
-    def build_w(*ws):
-        ws = [w.detach().float() for w in ws]
-        bf = lambda w: w.to(torch.bfloat16)  # noqa: E731
-        out, i = [], 0
-        if head is not None:
-            wout, w1, w2, g2 = ws[:4]
-            w1 = bf(w1 * g2[None, :])
-            out.append(_pack_w(bf(wout)))
-            # feed-forward streamed MC hidden units at a time, W1 rows one chunk ahead of the W2 columns (GELU of chunk c
-            # rides under the W2 GEMM of chunk c-1): W1[0], W1[1], W2[0], W1[2], W2[1], .., W1[7], W2[6], W2[7]
-            nch = M_ // MC_
-            p1 = [_pack_w(w1[c * MC_:(c + 1) * MC_]) for c in range(nch)]
-            p2 = [_pack_w(bf(w2[:, c * MC_:(c + 1) * MC_])) for c in range(nch)]
-            out.append(p1[0])
-            for c in range(1, nch):
-                out += [p1[c], p2[c - 1]]
-            out.append(p2[nch - 1])
-            i = 4
-        if tail is not None:
-            wq, wk, wv, g1 = ws[i:i + 4]
-            out += [_pack_w(bf(wq)), _pack_w(bf(wk * g1[None, :])), _pack_w(bf(wv * g1[None, :]))]
-        out.append(torch.zeros(_PAD // 2, dtype=torch.bfloat16, device=ws[0].device))
-        return torch.cat(out)
-    wpack = _cast.operand(tuple(params), torch.bfloat16, 'fusedw', build_w)
-
-    vparams = []
-    if head is not None:
-        attn, ff = head
-        vparams += [attn.fn.to_out[0].bias, ff.fn.net[0].bias, ff.fn.net[0].weight, ff.norm.bias, ff.fn.net[3].bias]
-    if tail is not None:
-        attn_n = tail[0]
-        vparams += [attn_n.fn.to_k.weight, attn_n.fn.to_v.weight, attn_n.norm.bias, attn_n.fn.to_v.bias]
-
-    def build_v(*vs):
-        dev = vs[0].device
-        z = lambda n: torch.zeros(n, device=dev)  # noqa: E731
-        vs = [v.detach().float() for v in vs]
-        hv, tv = [z(D_), z(M_), z(D_)], [z(I_), z(I_)]
-        if head is not None:
-            bout, b1, w1, be2, b2 = vs[:5]
-            hv = [bout, b1 + w1 @ be2, b2]
-            vs = vs[5:]
-        if tail is not None:
-            wk, wv, be1, bv = vs
-            tv = [wk @ be1, bv + wv @ be1]
-        v = torch.cat(hv + tv)                      # bout[D] b1'[M] b2[D] bk'[I] bv'[I]
-        return torch.cat([v, z(2048 - v.numel())])
-    vec = _cast.operand(tuple(vparams), torch.float32, 'fusedv', build_v)
-    return wpack, vec
+    def build(*ps):
+        ps = [p.detach() for p in ps]
+        assert all(p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+        hp = ps[:8] if head is not None else [None] * 8
+        tp = ps[-6:] if tail is not None else [None] * 6
+        nw = (D_ * I_ + 2 * M_ * D_ if head is not None else 0) + (3 * I_ * D_ if tail is not None else 0)
+        dev = ps[0].device
+        wpack = torch.empty(nw + _PAD // 2, dtype=torch.bfloat16, device=dev)
+        vec = torch.empty(2048, dtype=torch.float32, device=dev)
+        L.call('wmz_layer_fused_pack', *[L.ptr(t) for t in hp], *[L.ptr(t) for t in tp], L.ptr(wpack), L.ptr(vec),
+               D_, I_, M_, L.stream())
+        return wpack, vec
+    return _cast.cached(params, 'fusedpack', build)
 
 
 X_IN_TILED, X_OUT_TILED = 1, 2      # include/wmz.h WMZ_FUSED_X_*_TILED
