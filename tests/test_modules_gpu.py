@@ -167,7 +167,11 @@ def test_fused_layer_path_matches_unfused_and_oracle(wmz):
         assert fused.supported(m.transformer, torch.bfloat16)
         with torch.no_grad():
             x_fused = m.transformer(z.cuda())
-        x_unfused = m.transformer(z.cuda())              # grad mode on -> per-op path
+        wmz['config'].set_fused_training(False)
+        try:
+            x_unfused = m.transformer(z.cuda())          # grad mode on, fused training off -> per-op path
+        finally:
+            wmz['config'].set_fused_training(True)
     e_f, e_u = rel(x_fused, ref), rel(x_unfused, ref)
     print(f'fused vs oracle {e_f:.3e}, per-op vs oracle {e_u:.3e}, fused vs per-op {rel(x_fused, x_unfused):.3e}')
     assert e_f < 2e-2 and e_u < 2e-2

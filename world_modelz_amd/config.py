@@ -59,3 +59,17 @@ def last_frame_cone(on):
         yield
     finally:
         set_last_frame_cone(prev)
+
+
+# Training forward of the denoiser on the fused kernels (bf16, default widths): one attention launch + one per-token
+# launch per layer instead of six; the backward recomputes the feed-forward pre-activation.  Off: the op-by-op forward.
+_fused_training = os.environ.get('WMZ_FUSED_TRAINING', '1') != '0'
+
+
+def get_fused_training():
+    return _fused_training
+
+
+def set_fused_training(on):
+    global _fused_training
+    _fused_training = bool(on)

@@ -159,3 +159,115 @@ def transformer_forward_last(tr, z):
     """The last plane of transformer_forward(tr, z=z) ([B, H, W, D]) computing only its dependence cone: identical
     arithmetic per token (bit-identical result), the planes that cannot reach the last frame are never launched."""
     return _run(tr, z, cone=True)[:, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training forward on the fused kernels (wmz_*_train): one attention launch + one per-token launch per layer, and the
+# tensors the op-by-op backward (backward.py) reads are written row-major on the way
+
+def _embed_train(tr, z, tiled):
+    B, S, H, W = z.shape
+    dev, bf = z.device, torch.bfloat16
+    wpack, vec = _layer_pack(None, tr.layers[0])
+    x_rm = torch.empty((B, S, H, W, D_), dtype=bf, device=dev)
+    x_t = torch.empty((B, S, H, W, D_), dtype=bf, device=dev) if tiled else None
+    q = torch.empty((B, S, H, W, I_), dtype=bf, device=dev)
+    kv = torch.empty((B, S, H, W, 2 * I_), dtype=bf, device=dev)
+    L.call('wmz_embed_qkv_fused_fwd_train', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
+           L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
+           L.ptr(x_t if tiled else x_rm), L.ptr(x_rm if tiled else None), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
+           B, S, H, W, D_, I_, M_, tr.embedding.num_embeddings, X_OUT_TILED if tiled else 0, 1e-5, L.stream())
+    return (x_t if tiled else x_rm), x_rm, q, kv
+
+
+def _layer_train(o, x_in, head, tail, tiled):
+    """x_in: the stream in the layout the previous launch left it in (tiled if `tiled`).  Returns (x_next, x_rm, x1, q, kv):
+    x_next in that same layout for the next launch (None after the last layer), x_rm / x1 row-major for the backward."""
+    lead = o.shape[:-1]
+    dev, bf = o.device, torch.bfloat16
+    ntok = o.numel() // I_
+    wpack, vec = _layer_pack(head, tail)
+    x_rm = torch.empty(lead + (D_,), dtype=bf, device=dev)
+    x1 = torch.empty(lead + (D_,), dtype=bf, device=dev)
+    out_tiled = tiled and tail is not None
+    x_t = torch.empty(lead + (D_,), dtype=bf, device=dev) if out_tiled else None
+    q = torch.empty(lead + (I_,), dtype=bf, device=dev) if tail is not None else None
+    kv = torch.empty(lead + (2 * I_,), dtype=bf, device=dev) if tail is not None else None
+    xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if out_tiled else 0)
+    L.call('wmz_layer_fused_fwd_train', L.ptr(o), L.ptr(x_in), L.ptr(x_t if out_tiled else x_rm),
+           L.ptr(x_rm if out_tiled else None), L.ptr(x1), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), ntok, D_, I_, M_,
+           1, 1 if tail is not None else 0, xflags, 1e-5, L.stream())
+    return (x_t if out_tiled else (x_rm if tail is not None else None)), x_rm, x1, q, kv
+
+
+def _layer_params(attn, ff):
+    a, f = attn.fn, ff.fn
+    return [attn.norm.weight, attn.norm.bias, a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_v.bias,
+            a.to_out[0].weight, a.to_out[0].bias, ff.norm.weight, ff.norm.bias,
+            f.net[0].weight, f.net[0].bias, f.net[3].weight, f.net[3].bias]
+
+
+class _Ctx:                      # what backward.attention_block_backward / feed_forward_block_backward read off a ctx
+    def __init__(self, saved, **kw):
+        self.saved_tensors = saved
+        self.__dict__.update(kw)
+
+
+class _TrainForward(torch.autograd.Function):
+    """The whole transformer stack (embedding + depth x [attention, feed-forward]) as one autograd node: forward on the
+    fused kernels, backward layer by layer through the same block backward functions as the op-by-op path (the
+    feed-forward pre-activation is recomputed there by one LayerNorm-GEMM instead of being stored)."""
+
+    @staticmethod
+    def forward(ctx, tr, z, *params):
+        layers = list(tr.layers)
+        B, S, H, W = z.shape
+        tiled = (H * W) % 32 == 0
+        x_cur, x_rm, q, kv = _embed_train(tr, z, tiled)
+        saved = []
+        for l, (attn, ff) in enumerate(layers):
+            o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads, need_lse=True)
+            x_in_rm = x_rm
+            x_cur, x_rm, x1, q_n, kv_n = _layer_train(o, x_cur, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None, tiled)
+            saved += [x_in_rm, q, kv, o, lse, x1]
+            q, kv = q_n, kv_n
+        ctx.tr = tr
+        ctx.save_for_backward(z, *saved)
+        return x_rm
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import backward as Bk
+        from .functional import LN_EPS
+        tr = ctx.tr
+        layers = list(tr.layers)
+        z, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        grads = [None] * (14 * len(layers))
+        dy = dy.contiguous()
+        for l in range(len(layers) - 1, -1, -1):
+            attn, ff = layers[l]
+            x_in, q, kv, o, lse, x1 = saved[6 * l:6 * l + 6]
+            an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
+            dt = x1.dtype
+            # feed-forward block: y = W2 GELU(W1 LN(x1) + b1) + b2 + x1
+            stats = ops.layernorm_stats(x1, LN_EPS)
+            zpre = ops.linear_fwd(x1, _cast.operand(w1, dt), bias=b1.detach(), ln=(fn_g.detach(), fn_b.detach()), ln_eps=LN_EPS,
+                                  ln_stats=stats)
+            cf = _Ctx((x1, fn_g, fn_b, w1, b1, w2, b2, zpre), has_res=True, res_is_x=True, ln_stats=stats)
+            dx1, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2, _, _ = Bk.feed_forward_block_backward(cf, dy)
+            # attention block: x1 = to_out(attn(LN(x), q = x)) + x
+            ca = _Ctx((x_in, x_in, an_g, an_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse), extents=attn.fn.extents,
+                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, ln_stats=None)
+            r = Bk.attention_block_backward(ca, dx1)
+            dy = r[0]
+            grads[14 * l:14 * l + 14] = [r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]
+        ce = _Ctx((z,), params=(tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight))
+        ge = Bk.embed_backward(ce, dy)
+        return (None, None, ge[1], ge[2], ge[3], ge[4], *grads)
+
+
+def transformer_forward_train(tr, z):
+    params = [tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight]
+    for attn, ff in tr.layers:
+        params += _layer_params(attn, ff)
+    return _TrainForward.apply(tr, z, *params)

@@ -143,6 +143,10 @@ class Local3dAttentionTransformer(nn.Module):
                 # inference, bf16, default widths: one attention launch + one per-token launch per layer, the
                 # embedding fused into the first one
                 return fused.transformer_forward(self, z=img_z)
+        else:
+            from . import config, fused
+            if config.get_fused_training() and fused.supported(self, config.get_compute_dtype()):
+                return fused.transformer_forward_train(self, img_z)     # training forward on the fused kernels
         x = Fw.embed_tokens(img_z, self.embedding.weight, self.pos_emb_s.weight, self.pos_emb_h.weight,
                             self.pos_emb_w.weight)
         for attn, ff in self.layers:
