@@ -773,25 +773,26 @@ __global__ __launch_bounds__(256) void fused_pack_kernel(PackParams P) {
   } else if (e8 < P.padded) {
     *reinterpret_cast<s16x8*>(P.wpack + e8) = (s16x8)(0);
   }
-  // the vector block: one thread per float (the three matrix-vector products are 256-long dots: tiny)
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < 2048) {
-    const int D = P.D, I = P.I, M = P.M;
-    float v = 0.f;
-    if (t < D) v = P.bout ? P.bout[t] : 0.f;
-    else if (t < D + M) {
-      const int n = t - D;
-      if (P.b1) { v = P.b1[n]; for (int k = 0; k < D; ++k) v = fmaf(P.w1[(long)n * D + k], P.be2[k], v); }
-    } else if (t < 2 * D + M) v = P.b2 ? P.b2[t - D - M] : 0.f;
-    else if (t < 2 * D + M + I) {
-      const int n = t - 2 * D - M;
-      if (P.wk) for (int k = 0; k < D; ++k) v = fmaf(P.wk[(long)n * D + k], P.be1[k], v);
-    } else if (t < 2 * D + M + 2 * I) {
-      const int n = t - 2 * D - M - I;
-      if (P.wv) { v = P.bv[n]; for (int k = 0; k < D; ++k) v = fmaf(P.wv[(long)n * D + k], P.be1[k], v); }
-    }
-    P.vec[t] = v;
+}
+// the vector block: bout | b1 + W1 be2 | b2 | Wk be1 | bv + Wv be1.  One wave per entry: plain entries are a copy, the
+// matrix-vector entries a coalesced 256-long dot (4 floats per lane) + wave reduction.
+__global__ __launch_bounds__(256) void fused_pack_vec_kernel(PackParams P) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= 2048) return;
+  const int D = P.D, I = P.I, M = P.M;
+  const float* row = nullptr; const float* vecb = nullptr; float base = 0.f;
+  if (t < D) base = P.bout ? P.bout[t] : 0.f;
+  else if (t < D + M) { if (P.b1) { base = P.b1[t - D]; row = P.w1 + (long)(t - D) * D; vecb = P.be2; } }
+  else if (t < 2 * D + M) base = P.b2 ? P.b2[t - D - M] : 0.f;
+  else if (t < 2 * D + M + I) { if (P.wk) { row = P.wk + (long)(t - 2 * D - M) * D; vecb = P.be1; } }
+  else if (t < 2 * D + M + 2 * I) { if (P.wv) { base = P.bv[t - 2 * D - M - I]; row = P.wv + (long)(t - 2 * D - M - I) * D; vecb = P.be1; } }
+  float acc = 0.f;
+  if (row != nullptr) {                                   // wave-uniform
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + lane * 4), b = *reinterpret_cast<const f32x4*>(vecb + lane * 4);
+    acc = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    acc = wave_sum(acc);
   }
+  if (lane == 0) P.vec[t] = base + acc;
 }
 }  // namespace
 
@@ -830,8 +831,8 @@ extern "C" int wmz_layer_fused_pack(const float* wout, const float* bout, const 
   P.wpack = (bf16_t*)wpack;
   P.bout = head ? bout : nullptr; P.b1 = head ? b1 : nullptr; P.w1 = w1; P.be2 = be2; P.b2 = head ? b2 : nullptr;
   P.wk = tail ? wk : nullptr; P.wv = tail ? wv : nullptr; P.be1 = be1; P.bv = bv; P.vec = vec; P.D = D; P.I = I; P.M = M;
-  const long threads = P.padded / 8 > 2048 ? P.padded / 8 : 2048;
-  hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)wmz_cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)wmz_cdiv(P.padded / 8, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  hipLaunchKernelGGL(fused_pack_vec_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, P);
   WMZ_LAUNCH_CHECK("wmz_layer_fused_pack");
   return WMZ_OK;
 }
