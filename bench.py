@@ -93,7 +93,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cone', action='store_true', help='skip the secondary last-frame-cone figure (cleaner kernel traces)')
     ap.add_argument('--eager', action='store_true', help='replay the Python launch path instead of the hipGraph')
-    ap.add_argument('--train-steps', type=int, default=8, help='timed full training steps reported as train_step (0 = skip)')
+    ap.add_argument('--train-steps', type=int, default=30, help='timed full training steps reported as train_step (0 = skip)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -311,7 +311,7 @@ def main():
             zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
             tr.forward_backward(zc, tgt)
             tr.optimizer_step()
-        for _ in range(3):
+        for _ in range(5):
             tstep()
         barrier()
         tt0 = time.perf_counter()
