@@ -174,6 +174,15 @@ int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const flo
                                    const float* vec, int B, int S, int H, int W, int planes_out, int D, int I, int M,
                                    int num_classes, int xflags, float eps, void* stream);
 
+/* All MFMA-operand copies of the fp32 parameters in one launch (after wmz_adamw_step has rewritten the weights): entry i
+ * turns the logical matrix [rows0 + rows1, cols] = (src0 ; src1) -- src1 optional (row concatenation, e.g. to_k over
+ * to_v), src0 NULL = zero rows -- into dst[i], row-major or transposed (WMZ_OPERAND_TRANSPOSE: what the dgrad GEMMs
+ * read), bf16 or fp32 (WMZ_OPERAND_F32).  The tables are HOST arrays of n <= 64 entries. */
+#define WMZ_OPERAND_TRANSPOSE 1
+#define WMZ_OPERAND_F32 2
+int wmz_operands_refresh(const void* const* src0, const void* const* src1, const int* rows0, const int* rows1,
+                         const int* cols, void* const* dst, const int* flags, int n, void* stream);
+
 /* Builds the packed weight stream and the vector block of wmz_layer_fused_fwd* from the layer's fp32 parameters in one
  * launch (the LayerNorm affines g2/be2 -- the feed-forward's norm -- and g1/be1 -- the NEXT layer's attention norm -- are
  * folded in).  Head parameters (wout .. b2) NULL: tail-only stream; tail parameters (g1 .. bv) NULL: head-only.

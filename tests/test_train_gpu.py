@@ -180,3 +180,34 @@ def test_fused_training_forward_matches_op_by_op(shape, depth):
         assert e_f < 6e-2, (n, e_f, e_o)
         assert e_f < 2.5 * e_o + 2e-2, (n, e_f, e_o)       # no worse than the op-by-op bf16 path, up to noise
     print(f'fused-training gradients: worst relative error vs the fp32 oracle {worst:.3e}')
+
+
+def test_bulk_operand_refresh_is_exact():
+    """wmz_operands_refresh (one launch for every cast / transpose / concatenation the step needs) against the tensor-op
+    formulation it replaces: bit-exact, and the refreshed entries are what _cast.operand() then returns."""
+    import world_modelz_amd
+    from world_modelz_amd import _cast
+    torch.manual_seed(5)
+    bf = torch.bfloat16
+    wk = torch.nn.Parameter(torch.randn(128, 256, device='cuda'))
+    wv = torch.nn.Parameter(torch.randn(128, 256, device='cuda'))
+    bv = torch.nn.Parameter(torch.randn(128, device='cuda'))
+    w1 = torch.nn.Parameter(torch.randn(256, 72, device='cuda'))
+    bulk = _cast.BulkOperands()
+    d_w1 = bulk.add((w1,), bf, 'w')
+    d_w1t = bulk.add((w1,), bf, 'w1T', transpose=True)
+    d_kv = bulk.add((wk, wv), bf, 'kv')
+    d_kvt = bulk.add((wk, wv), bf, 'kvT', transpose=True)
+    d_bkv = bulk.add((bv,), torch.float32, 'bkv', zero_first=True)
+    bulk.refresh()
+    torch.cuda.synchronize()
+    assert torch.equal(d_w1, w1.detach().to(bf))
+    assert torch.equal(d_w1t, w1.detach().t().to(bf).contiguous())
+    assert torch.equal(d_kv, torch.cat([wk, wv]).detach().to(bf))
+    assert torch.equal(d_kvt, torch.cat([wk, wv]).detach().t().to(bf).contiguous())
+    assert torch.equal(d_bkv, torch.cat([torch.zeros_like(bv), bv]).detach())
+    assert _cast.operand(w1, bf).data_ptr() == d_w1.data_ptr()
+    assert _cast.operand((wk, wv), bf, 'kvT', lambda a, b: torch.cat([a, b], dim=0).t()).data_ptr() == d_kvt.data_ptr()
+    with torch.no_grad():
+        w1.mul_(2.0)                                     # an in-place change torch sees: the stale entry must not be served
+    assert torch.equal(_cast.operand(w1, bf), w1.detach().to(bf))

@@ -57,3 +57,48 @@ def invalidate():
 
 def clear():
     _cache.clear()
+
+
+class BulkOperands:
+    """Operand copies that are rebuilt together, by ONE launch of wmz_operands_refresh (training: after every optimizer
+    step).  Each entry is registered under the same (params, dtype, tag) key the forward / backward code asks operand()
+    for; refresh() fills the persistent destination tensors and stamps the cache entries valid for the current parameter
+    versions, so those operand() calls hit.  Anything not registered, or invalidated in another way, still takes the
+    ordinary per-operand path."""
+
+    def __init__(self):
+        self.entries = []          # (params, dtype, tag, transpose, zero_first, dst)
+
+    def add(self, params, dtype, tag='w', transpose=False, zero_first=False):
+        params = tuple(params)
+        rows = sum(p.shape[0] for p in params) + (params[0].shape[0] if zero_first else 0)
+        cols = params[0].numel() // params[0].shape[0]
+        assert len(params) <= 2 and not (zero_first and len(params) != 1)
+        shape = (cols, rows) if transpose else ((rows, cols) if params[0].dim() > 1 else (rows,))
+        dst = torch.empty(shape, dtype=dtype, device=params[0].device)
+        self.entries.append((params, dtype, tag, transpose, zero_first, dst))
+        return dst
+
+    def refresh(self):
+        import ctypes
+        from . import _lib as L
+        for i0 in range(0, len(self.entries), 64):
+            ent = self.entries[i0:i0 + 64]
+            n = len(ent)
+            vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+            s0, s1, r0, r1, cc, dd, ff = vp(), vp(), ci(), ci(), ci(), vp(), ci()
+            for i, (params, dtype, tag, tr, zf, dst) in enumerate(ent):
+                a = params[0].detach()
+                b = params[1].detach() if len(params) > 1 else None
+                assert a.dtype == torch.float32 and a.is_contiguous() and (b is None or b.is_contiguous())
+                if zf:
+                    s0[i], s1[i], r0[i], r1[i] = None, a.data_ptr(), a.shape[0], a.shape[0]
+                else:
+                    s0[i], s1[i], r0[i], r1[i] = a.data_ptr(), (b.data_ptr() if b is not None else None), a.shape[0], (b.shape[0] if b is not None else 0)
+                cc[i] = a.numel() // a.shape[0]
+                dd[i] = dst.data_ptr()
+                ff[i] = (1 if tr else 0) | (2 if dtype == torch.float32 else 0)
+            L.call('wmz_operands_refresh', s0, s1, r0, r1, cc, dd, ff, n, L.stream())
+        for params, dtype, tag, tr, zf, dst in self.entries:
+            ver = (_epoch,) + tuple((p._version, p.data_ptr()) for p in params)
+            _cache[_key(params, dtype, tag)] = (ver, dst, tuple(weakref.ref(p) for p in params))

@@ -38,6 +38,7 @@ SIGNATURES = {
     'wmz_debug_fused_timestamps': [c_void_p],
     'wmz_debug_attn_timestamps': [c_void_p],
     'wmz_layer_fused_fwd': [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p],
+    'wmz_operands_refresh': [c_void_p] * 7 + [c_int, c_void_p],
     'wmz_layer_fused_pack': [c_void_p] * 16 + [c_int] * 3 + [c_void_p],
     'wmz_layer_fused_fwd_train': [c_void_p] * 9 + [c_int] * 7 + [c_float, c_void_p],
     'wmz_embed_qkv_fused_fwd_train': [c_void_p] * 11 + [c_int] * 9 + [c_float, c_void_p],

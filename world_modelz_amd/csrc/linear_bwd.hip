@@ -4,6 +4,7 @@
 //   wmz_layernorm_bwd   dx = LN'(x)^T dyhat (+ skip gradient),  dgamma, dbeta
 // (the data gradient dA' = dC . W is wmz_linear_fwd on the transposed weight, optionally x gelu'(z).)
 #include "wmz_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -368,7 +369,8 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
   P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
   const int tiles = P.nbn * P.nbk;
-  int split = wmz_cdiv(256, tiles);          // ~one workgroup per CU: every extra split is another 64 KB of float atomics
+  static const int wg_target = getenv("WMZ_WGRAD_WGS") ? atoi(getenv("WMZ_WGRAD_WGS")) : 256;
+  int split = wmz_cdiv(wg_target, tiles);    // ~one workgroup per CU: every extra split is another 64 KB of float atomics
   const int max_split = wmz_cdiv(M, 4 * WG_MS);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;

@@ -136,6 +136,35 @@ class DenoiserTrainer:
         if distributed:
             broadcast_parameters(self.arena)
         self.sampler = LossAwareSamplerEma(num_histogram_buckets=100, uniform_p=0.01, alpha=0.9, warmup=10)
+        self.operands = self._register_operands()
+        self.operands.refresh()
+
+    def _register_operands(self):
+        """Every operand copy the step asks _cast.operand() for (bf16 casts, dgrad transposes, k|v concatenations), so
+        that ONE launch rebuilds them all after the optimizer step."""
+        from .config import get_compute_dtype
+        dt = get_compute_dtype()
+        bulk = _cast.BulkOperands()
+        if dt == torch.float32 or not self.arena.flat_param.is_cuda:
+            return bulk                                  # parity mode: weights are used as they are, transposes per use
+        tr = self.model.transformer
+        for attn, ff in tr.layers:
+            a, f = attn.fn, ff.fn
+            bulk.add((a.to_q.weight,), dt, 'w')
+            bulk.add((a.to_q.weight,), dt, 'wqT', transpose=True)
+            bulk.add((a.to_k.weight, a.to_v.weight), dt, 'kv')
+            bulk.add((a.to_k.weight, a.to_v.weight), dt, 'kvT', transpose=True)
+            bulk.add((a.to_v.bias,), torch.float32, 'bkv', zero_first=True)
+            if not isinstance(a.to_out, torch.nn.Identity):
+                bulk.add((a.to_out[0].weight,), dt, 'w')
+                bulk.add((a.to_out[0].weight,), dt, 'woutT', transpose=True)
+            bulk.add((f.net[0].weight,), dt, 'w')
+            bulk.add((f.net[0].weight,), dt, 'w1T', transpose=True)
+            bulk.add((f.net[3].weight,), dt, 'w')
+            bulk.add((f.net[3].weight,), dt, 'w2T', transpose=True)
+        bulk.add((self.model.logit_proj.weight,), dt, 'w')
+        bulk.add((self.model.logit_proj.weight,), dt, 'wT', transpose=True)
+        return bulk
 
     def forward_backward(self, batch_z, target):
         """Forward, per-sample CE over the last frame, backward.  Returns (per_sample_loss[B], mean loss) on device."""
@@ -159,6 +188,7 @@ class DenoiserTrainer:
         L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                float(lr), self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), st)
         _cast.invalidate()            # the kernel rewrote the arena behind torch's version counters
+        self.operands.refresh()       # ... and every operand copy of the weights is rebuilt by one launch
         return self.sq
 
     def train_step(self, batch_z, r=None, generator=None):
