@@ -97,8 +97,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtr
       }
     }
     if constexpr (MODE == 0) {
-      dsum = wave_xor_add(dsum, 16);
-      dsum = wave_xor_add(dsum, 32);
+      dsum = wave_groups_sum(dsum);
       own_del = dsum;
       own_lse = active ? P.lse[row * G.heads + head] * L2E : 0.f;
       if (active && g == 0) P.delta[row * G.heads + head] = dsum;
@@ -207,24 +206,39 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtr
       }
       Frag8<bf16_t> dsf;
       frag_from_f32<bf16_t>(dsf, dsv);
-      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      // transposed fragments by inline-asm reads: the builtin makes hipcc drain vmcnt (the next slab's LDS-DMA) in front
+      // of every one of them (wmz_common.h: ds_read_tr16_asm)
+      {
+        const unsigned ya0 = lds_addr(Y1s + to0), ya1 = lds_addr(Y1s + to1);
+        s16x4 x0[MT], x1[MT];
+        static_for<MT>([&](auto mt) {
+          x0[mt] = ds_read_tr16_asm<mt * 32>(ya0);
+          x1[mt] = ds_read_tr16_asm<mt * 32>(ya1);
+        });
+        ds_tr_wait();
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Y1s + to0 + mt * 32));
-        const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Y1s + to1 + mt * 32));
-        Frag8<bf16_t> yf;
-        yf.v = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-        mma16(acc1[mt], yf, dsf);
+        for (int mt = 0; mt < MT; ++mt) {
+          asm volatile("" : "+v"(x0[mt]), "+v"(x1[mt]));
+          Frag8<bf16_t> yf;
+          yf.v = __builtin_shufflevector(x0[mt], x1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
+          mma16(acc1[mt], yf, dsf);
+        }
       }
       if constexpr (MODE == 1) {
         Frag8<bf16_t> pf;
         frag_from_f32<bf16_t>(pf, pv);
+        const unsigned ya0 = lds_addr(Y2s + to0), ya1 = lds_addr(Y2s + to1);
+        s16x4 x0[MT], x1[MT];
+        static_for<MT>([&](auto mt) {
+          x0[mt] = ds_read_tr16_asm<mt * 32>(ya0);
+          x1[mt] = ds_read_tr16_asm<mt * 32>(ya1);
+        });
+        ds_tr_wait();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Y2s + to0 + mt * 32));
-          const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Y2s + to1 + mt * 32));
+          asm volatile("" : "+v"(x0[mt]), "+v"(x1[mt]));
           Frag8<bf16_t> yf;
-          yf.v = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+          yf.v = __builtin_shufflevector(x0[mt], x1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
           mma16(acc2[mt], yf, pf);
         }
       }
