@@ -286,3 +286,32 @@ def test_attention_row16_deferred_max_branch(ops):
     assert rel(out, ref) < 1e-2
     for pos in [(0, 4, 13, 13), (0, 3, 8, 8)]:
         assert rel(out[pos], ref[pos]) < 2e-2
+
+
+def test_attention_full_size_properties(ops):
+    """BASELINE configs[3] size (8 x 32 x 16 x 16 tokens, dim_head 128, window 7x7x7), where the CPU oracle takes too long
+    for a unit test: size-independent properties of softmax attention instead.
+      * V constant per feature  -> every output row equals that constant (the weights of a row sum to 1);
+      * linearity in V: attn(q, k, a*V1 + b*V2) = a*attn(q, k, V1) + b*attn(q, k, V2) (same weights);
+      * one clip of the batch equals the same clip run alone (clips are independent: the data-parallel sharding);
+      * translation along the time axis away from the clip ends: shifting q, k, v by one plane shifts the output."""
+    torch.manual_seed(31)
+    B, S, H, W, I = 8, 32, 16, 16, 128
+    ext = (3, 3, 3)
+    q, k = (torch.randn(B, S, H, W, I, device='cuda').bfloat16() for _ in range(2))
+    v1, v2 = (torch.randn(B, S, H, W, I, device='cuda').bfloat16() for _ in range(2))
+
+    def attn(qq, kk, vv):
+        return ops.local3d_attention_fwd(qq, kk, vv, ext, 1)[0].float()
+    const = torch.randn(I, device='cuda').bfloat16()
+    out_c = attn(q, k, const.expand(B, S, H, W, I).contiguous())
+    assert (out_c - const.float()).abs().max() < 2e-2 * const.float().abs().max()
+    o1, o2 = attn(q, k, v1), attn(q, k, v2)
+    o12 = attn(q, k, (0.5 * v1.float() - 0.25 * v2.float()).bfloat16())
+    lin = 0.5 * o1 - 0.25 * o2
+    assert float((o12 - lin).norm() / lin.norm()) < 1.5e-2            # bf16 rounding of the mixed V and of the outputs
+    alone = attn(q[3:4].contiguous(), k[3:4].contiguous(), v1[3:4].contiguous())
+    assert torch.equal(alone[0], o1[3])
+    shifted = attn(q[:, 1:].contiguous(), k[:, 1:].contiguous(), v1[:, 1:].contiguous())
+    # planes whose window does not touch either end of either clip see exactly the same keys
+    assert torch.equal(shifted[:, 3:S - 5], o1[:, 4:S - 4])

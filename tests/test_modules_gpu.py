@@ -242,3 +242,32 @@ def test_fused_kernel_stays_inside_its_buffers(wmz):
             assert torch.isfinite(view.float()).all(), name
             assert (big[view.numel():] == canary).all(), f'{name}: written past the end (xflags={xflags})'
         assert (xbig[x.numel():] == canary).all() and (obig[o.numel():] == canary).all()
+
+
+def test_denoiser_full_size_properties(wmz):
+    """BASELINE configs[3] (B = 8 clips of 32x16x16, codebook 1024, default denoiser) -- properties that hold at any size:
+      * a clip's logits do not depend on its batch neighbours (bit-exact: the data-parallel sharding is exact);
+      * the last frame's logits only depend on its dependence cone: tokens more than (depth-1)*eS + eS planes back can be
+        anything (checked with the FULL-grid forward, i.e. as a property of the model, and then cone == full);
+      * graph replay == eager."""
+    from world_modelz_amd.graph import GraphedForward
+    torch.manual_seed(41)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=256, num_classes=1024, extents=(3, 3, 3), depth=4,
+                                          dim_head=128, mlp_dim=256, heads=1).cuda().eval()
+    z = torch.randint(0, 1025, (8, 32, 16, 16), device='cuda')
+    cfg = wmz['config']
+    with cfg.compute_dtype(torch.bfloat16), torch.no_grad():
+        with cfg.last_frame_cone(False):
+            full = m(z)
+            assert torch.equal(m(z[5:6])[0], full[5])
+            z2 = z.clone()
+            z2[:, :32 - 13] = torch.randint(0, 1025, (8, 19, 16, 16), device='cuda')     # outside the 13-plane cone
+            assert torch.equal(m(z2), full)
+            z3 = z.clone()
+            z3[:, 32 - 13] = (z3[:, 32 - 13] + 1) % 1025                                  # the first plane inside it
+            assert not torch.equal(m(z3), full)
+            g = GraphedForward(m, z)
+            assert torch.equal(g(z), full)
+        with cfg.last_frame_cone(True):
+            assert torch.equal(m(z), full)
+    assert torch.isfinite(full).all() and full.shape == (8, 16, 16, 1024)
