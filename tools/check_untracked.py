@@ -1,8 +1,8 @@
 """Build-time check for csrc/layer_fused.hip: the residual rows are fetched by inline-asm loads hipcc does not track, so
 nothing may read or overwrite their destination registers between the load and the counted s_waitcnt that retires them.
-Compiles the kernel to ISA and scans the span.   python tools_check_untracked.py"""
+Compiles the kernel to ISA and scans the span.   python tools/check_untracked.py"""
 import re, subprocess, sys, os
-src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'world_modelz_amd', 'csrc', 'layer_fused.hip')
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'world_modelz_amd', 'csrc', 'layer_fused.hip')
 asm = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', src, '-o', '-'],
                      capture_output=True, text=True).stdout
 bad_total = 0

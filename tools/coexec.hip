@@ -1,5 +1,5 @@
 // Micro-benchmark: do VALU instructions of a wave overlap its own / its SIMD partner's MFMAs?  (kernel development aid)
-// build: hipcc --offload-arch=gfx950 -O3 tools_micro/coexec.hip -o tools_micro/coexec ; run on the GPU box: ./tools_micro/coexec
+// build: hipcc --offload-arch=gfx950 -O3 tools/coexec.hip -o tools/coexec ; run on the GPU box: ./tools/coexec
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(16))) float f32x16;

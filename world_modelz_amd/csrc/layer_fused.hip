@@ -728,7 +728,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
 
 static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_head, int has_tail, void* stream);
 static long long* g_fused_ts = nullptr;
-// Timing probe for kernel development (tools_time_fused.py): a device buffer of 8 * 64 int64; NULL switches it off.
+// Timing probe for kernel development (tools/ts_fused.py): a device buffer of 8 * 64 int64; NULL switches it off.
 extern "C" int wmz_debug_fused_timestamps(void* buf) { g_fused_ts = (long long*)buf; return WMZ_OK; }
 
 extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
