@@ -138,3 +138,18 @@ def test_cone_planes_schedule():
                     assert need[l] == S - min(live), (S, eS, depth, l)
                     live = {k for s in live for k in range(max(0, s - eS), min(S - 1, s + eS) + 1)}
                     assert src[l] == S - min(live)
+
+
+def test_untracked_loads_stay_untouched_until_their_wait():
+    """layer_fused.hip fetches the residual rows with inline-asm loads that hipcc does not track (so that it does not drain
+    the weight ring at their first use).  That is only safe if no instruction touches their destination registers before
+    the counted s_waitcnt: tools/check_untracked.py compiles the kernel to ISA and scans exactly that span."""
+    import os, shutil, subprocess, sys
+    if shutil.which('hipcc') is None:
+        import pytest
+        pytest.skip('hipcc not on PATH')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_untracked.py')], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('touches in between: 0') >= 2, r.stdout
