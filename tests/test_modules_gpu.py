@@ -271,3 +271,38 @@ def test_denoiser_full_size_properties(wmz):
         with cfg.last_frame_cone(True):
             assert torch.equal(m(z), full)
     assert torch.isfinite(full).all() and full.shape == (8, 16, 16, 1024)
+
+
+def test_weight_stream_packer_matches_the_documented_order(wmz):
+    """wmz_layer_fused_pack (one launch) against the tensor-op statement of the same layout (fused._pack_w + the folding
+    rules in fused._layer_pack's docstring): bit-exact stream, vector block to fp32 round-off."""
+    from world_modelz_amd import fused
+    torch.manual_seed(9)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(4, 16, 16), dim=256, num_classes=32, extents=(1, 1, 1), depth=2,
+                                          dim_head=128, mlp_dim=256, heads=1)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'norm' in n or n.endswith('bias'):
+                p.add_(0.3 * torch.randn_like(p))
+    m = m.cuda()
+    (attn, ff), (attn_n, _) = m.transformer.layers[0], m.transformer.layers[1]
+    wpack, vec = fused._layer_pack((attn, ff), (attn_n, None))
+    bf = lambda w: w.to(torch.bfloat16)  # noqa: E731
+    with torch.no_grad():
+        wout, bout = attn.fn.to_out[0].weight, attn.fn.to_out[0].bias
+        g2, be2 = ff.norm.weight, ff.norm.bias
+        w1, b1, w2, b2 = ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias
+        g1, be1 = attn_n.norm.weight, attn_n.norm.bias
+        wq, wk, wv, bv = attn_n.fn.to_q.weight, attn_n.fn.to_k.weight, attn_n.fn.to_v.weight, attn_n.fn.to_v.bias
+        w1f = bf(w1 * g2[None, :])
+        p1 = [fused._pack_w(w1f[c * 32:(c + 1) * 32]) for c in range(8)]
+        p2 = [fused._pack_w(bf(w2[:, c * 32:(c + 1) * 32])) for c in range(8)]
+        parts = [fused._pack_w(bf(wout)), p1[0]]
+        for c in range(1, 8):
+            parts += [p1[c], p2[c - 1]]
+        parts += [p2[7], fused._pack_w(bf(wq)), fused._pack_w(bf(wk * g1[None, :])), fused._pack_w(bf(wv * g1[None, :]))]
+        ref = torch.cat(parts)
+        vref = torch.cat([bout, b1 + w1 @ be2, b2, wk @ be1, bv + wv @ be1])
+    assert torch.equal(wpack[:ref.numel()], ref)
+    assert (wpack[ref.numel():] == 0).all() and wpack.numel() == ref.numel() + 32768
+    assert torch.allclose(vec[:vref.numel()], vref, rtol=1e-5, atol=1e-5) and (vec[vref.numel():] == 0).all()
