@@ -195,12 +195,18 @@ __device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const
           mma32(acc[idx % NB], af[gq & 1][j], bcur);
         }
         side(sl * GPS + gq);                               // VALU work that rides under this group's MFMAs,
-        if constexpr (Side::kValuPerMfma > 0) {            // interleaved with them instruction by instruction
+        // Order inside the group: the NEXT group's fragment reads go out first (left to itself the scheduler sinks them
+        // behind the MFMAs and the wave then waits a full LDS round trip per group), then the MFMAs, each followed by
+        // its share of the side work.
+        if (gq + 1 < GPS) __builtin_amdgcn_sched_group_barrier(0x100, AG, 0);
+        if constexpr (Side::kValuPerMfma > 0) {
 #pragma unroll
           for (int j = 0; j < AG; ++j) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, Side::kValuPerMfma, 0);
           }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, AG, 0);
         }
         WMZ_FENCE();
       }
@@ -322,12 +328,16 @@ template <int ROWF>
 __device__ __forceinline__ void stage_flush(const char* stg, bf16_t* dst, long tok0, int ntok, int col0, int lane) {
   asm volatile("" : "+s"(tok0), "+v"(lane));   // compute the store addresses HERE (hoisted / shared with the prologue's
                                                // index math they only get spilled)
+  // all eight LDS reads first, unconditionally, then the predicated stores: with the read inside the predicate hipcc
+  // emits branch / read / wait / store per KB, eight LDS round trips in a row
+  s16x8 v[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const s16x8*>(stg + p * 1024 + lane * 16);
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int r = p * 4 + (lane >> 4), pc = lane & 15;
-    const s16x8 v = *reinterpret_cast<const s16x8*>(stg + p * 1024 + lane * 16);
     const int c = pc ^ (r & 15);
-    if (tok0 + r < ntok) *reinterpret_cast<s16x8*>(dst + (tok0 + r) * ROWF + col0 + c * 8) = v;
+    if (tok0 + r < ntok) *reinterpret_cast<s16x8*>(dst + (tok0 + r) * ROWF + col0 + c * 8) = v[p];
   }
 }
 // operand fragments parked in the wave's LDS image, lane-linear (each lane reads back what it wrote)
