@@ -296,6 +296,29 @@ def main():
         wcfg.set_last_frame_cone(False)
         log(f'last-frame cone: {cone["ms_per_step"]:.3f} ms/step, identical={same}')
     out['last_frame_cone'] = cone
+    # ---- secondary figure: the stage in front of the denoiser: the frozen VQ auto-encoder turning frames into
+    # latent tokens -- conv encoder (NHWC implicit GEMM, BatchNorm in train mode: quirk Q3) + codebook argmin.  B*S frames
+    # of 64x64 RGB -> 16x16 tokens each (2 down-scale steps), codebook 1024 x 64.
+    frame_enc = None
+    if not a.no_cone:
+        from world_modelz_amd.train_vqae import VqAutoEncoder
+        torch.manual_seed(7)
+        ae = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
+        frames_in = torch.randn(cfg['B'] * cfg['S'], 3, 64, 64, device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                tok = ae.encode(frames_in)
+            barrier()
+            f0 = time.perf_counter()
+            for _ in range(5):
+                tok = ae.encode(frames_in)
+            torch.cuda.synchronize()
+            fel = (time.perf_counter() - f0) / 5
+        assert tok.shape == (cfg['B'] * cfg['S'], 16, 16)
+        frame_enc = {'value': cfg['B'] * cfg['S'] / fel, 'unit': 'frames/s', 'ms_per_batch': fel * 1e3,
+                     'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens (eager launches)"}
+        log(f'frame encoder: {fel * 1e3:.2f} ms per {cfg["B"] * cfg["S"]} frames')
+    out['frame_encoder'] = frame_enc
     # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> gradient all-reduce overlapped
     # on a side stream when n_gpus > 1 -> grad-norm -> AdamW), same shapes, same rules (barrier + sync both sides, max over
     # ranks).  Eager launches: the backward is not graph-captured yet.
