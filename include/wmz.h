@@ -220,6 +220,13 @@ int wmz_conv2d_nhwc_fwd(const void* x, const void* w, void* out, const float* bi
                         const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int Hi, int Wi,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, int dtype,
                         void* stream);
+/* The same with an INPUT prologue for 1x1 convolutions (KH = KW = 1, pad = 0): the A operand is LeakyReLU(x * in_scale[c]
+ * + in_shift[c]) (slope in_slope), applied while the slab is staged -- the training-mode BatchNorm + activation in front
+ * of the conv (autoencoder.py:21-25 Residual: conv3x3 -> BN -> LeakyReLU -> conv1x1) without a pass of its own. */
+int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, const float* bias, const float* scale,
+                            const float* shift, const void* residual, float* stat_sum, float* stat_sq,
+                            const float* in_scale, const float* in_shift, float in_slope, int B, int Hi, int Wi, int Cin,
+                            int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, int dtype, void* stream);
 /* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [C]). */
 int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream);
 /* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq, count), running stats updated with

@@ -47,6 +47,7 @@ SIGNATURES = {
     'wmz_local3d_attn_fwd_planes': [c_void_p] * 5 + [c_int] * 9 + [c_long] * 4 + [c_int, c_int, c_int, c_void_p],
     'wmz_embed_qkv_fused_fwd': [c_void_p] * 10 + [c_int] * 8 + [c_float, c_void_p],
     'wmz_conv2d_nhwc_fwd': [c_void_p] * 9 + [c_int] * 10 + [c_float, c_int, c_void_p],
+    'wmz_conv2d_nhwc_fwd_pre': [c_void_p] * 11 + [c_float] + [c_int] * 10 + [c_float, c_int, c_void_p],
     'wmz_channel_stats_nhwc': [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p],
     'wmz_bn_finalize': [c_void_p, c_void_p, c_double] + [c_void_p] * 4 + [c_double, c_double, c_int] + [c_void_p] * 4
                        + [c_int, c_void_p],

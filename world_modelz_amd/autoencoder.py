@@ -204,8 +204,8 @@ class Residual(nn.Module):
         if bn1.training:
             h, s, q = _conv(x, c1, dtype, stats=True)
             sc, sh = ops.bn_finalize(bn1, s, q, _count(h))
-            h = ops.affine_act_nhwc(h, sc, sh, leaky=True, slope=LEAKY)
-            h, s, q = _conv(h, c2, dtype, stats=True)
+            # BatchNorm apply + LeakyReLU ride in the 1x1 conv's operand staging (no pass over the hidden tensor)
+            h, s, q = _conv(h, c2, dtype, stats=True, pre=(sc, sh, LEAKY))
             sc2, sh2 = ops.bn_finalize(bn2, s, q, _count(h))
             if self.downsample is not None:
                 r, s, q = _conv(x, self.downsample[0], dtype, stats=True)

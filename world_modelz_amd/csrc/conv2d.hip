@@ -21,9 +21,38 @@ struct ConvParams {
   int B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int M, K, nbn;
   float slope; int leaky;
+  // input prologue (1x1 convs): a' = LeakyReLU(a * in_scale[c] + in_shift[c]) applied while the A slab is staged -- the
+  // training-mode BatchNorm + activation in FRONT of the conv, without a pass over the tensor of its own
+  const float* in_scale; const float* in_shift; float in_slope;
 };
 
 __device__ __forceinline__ int swz128(int r) { return ((r >> 1) << 4) & 112; }
+
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const i32x4& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const i32x4& c, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __int_as_float(c[i]);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const i32x4& c, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(((unsigned)c[i]) << 16);
+    f[2 * i + 1] = __uint_as_float(((unsigned)c[i]) & 0xFFFF0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ i32x4 f32_to_chunk(const float* f);
+template <> __device__ __forceinline__ i32x4 f32_to_chunk<float>(const float* f) {
+  i32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = __float_as_int(f[i]);
+  return c;
+}
+template <> __device__ __forceinline__ i32x4 f32_to_chunk<bf16_t>(const float* f) {
+  i32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = (int)((unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16));
+  return c;
+}
 
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
@@ -57,6 +86,16 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
   }
 
   i32x4 ra[4], rb[4];
+  auto pre = [&](i32x4 v, int k) {          // k = first input channel of the chunk (1x1 conv: k IS the channel)
+    float f[EPC];
+    chunk_to_f32<T>(v, f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float y = fmaf(f[e], P.in_scale[k + e], P.in_shift[k + e]);
+      f[e] = y > 0.f ? y : y * P.in_slope;
+    }
+    return f32_to_chunk<T>(f);
+  };
   auto fetch = [&](int k0) {
     const int k = k0 + cc * EPC;
     const int tap = k / P.Cin, ci = k - tap * P.Cin;
@@ -90,7 +129,9 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
     for (int i = 0; i < 4; ++i) {
       const int r = rr + 32 * i;
       const int off = r * ROWB + ((cc << 4) ^ swz128(r));
-      *reinterpret_cast<i32x4*>(As + off) = ra[i];
+      i32x4 av = ra[i];
+      if (P.in_scale != nullptr && k0 + cc * EPC < K && pok[i]) av = pre(av, k0 + cc * EPC);   // (rows past M stay zero)
+      *reinterpret_cast<i32x4*>(As + off) = av;
       *reinterpret_cast<i32x4*>(Bs + off) = rb[i];
     }
     __syncthreads();
@@ -348,7 +389,18 @@ extern "C" int wmz_conv2d_nhwc_fwd(const void* x, const void* w, void* out, cons
                                    const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B,
                                    int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky,
                                    float slope, int dtype, void* stream) {
+  return wmz_conv2d_nhwc_fwd_pre(x, w, out, bias, scale, shift, residual, stat_sum, stat_sq, nullptr, nullptr, 0.f, B, Hi, Wi,
+                                 Cin, Cout, KH, KW, stride, pad, leaky, slope, dtype, stream);
+}
+
+extern "C" int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, const float* bias, const float* scale,
+                                       const float* shift, const void* residual, float* stat_sum, float* stat_sq,
+                                       const float* in_scale, const float* in_shift, float in_slope, int B, int Hi, int Wi,
+                                       int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope,
+                                       int dtype, void* stream) {
   WMZ_REQUIRE(x && w && out, "wmz_conv2d_nhwc_fwd: null tensor");
+  WMZ_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wmz_conv2d_nhwc_fwd: in_scale and in_shift go together");
+  WMZ_REQUIRE(in_scale == nullptr || (KH == 1 && KW == 1 && pad == 0), "wmz_conv2d_nhwc_fwd: the input prologue is built for 1x1 convolutions without padding");
   WMZ_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
               "wmz_conv2d_nhwc_fwd: bad shape");
   WMZ_REQUIRE(Cin % 8 == 0, "wmz_conv2d_nhwc_fwd: Cin must be a multiple of 8 (zero-pad the input channels), got %d", Cin);
@@ -364,6 +416,7 @@ extern "C" int wmz_conv2d_nhwc_fwd(const void* x, const void* w, void* out, cons
   WMZ_REQUIRE(P.Ho > 0 && P.Wo > 0, "wmz_conv2d_nhwc_fwd: empty output");
   P.M = B * P.Ho * P.Wo; P.K = KH * KW * Cin; P.nbn = wmz_cdiv(Cout, BN);
   P.leaky = leaky; P.slope = slope;
+  P.in_scale = in_scale; P.in_shift = in_shift; P.in_slope = in_slope;
   dim3 grid((unsigned)(wmz_cdiv(P.M, BM) * P.nbn)), block(NT);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == WMZ_BF16) hipLaunchKernelGGL(conv2d_kernel<bf16_t>, grid, block, 0, st, P);

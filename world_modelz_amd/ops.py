@@ -228,7 +228,7 @@ def embed_pos3d_bwd(z, dx, tabs):
 # ------------------------------------------------------------------------------------------------ conv AE (NHWC)
 
 def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None, residual=None, leaky=False,
-                slope=0.01, stats=False):
+                slope=0.01, stats=False, pre=None):
     """x: [B,H,W,Cin] contiguous (Cin % 8 == 0), w_op: [Cout, KH*KW*Cin] in x's dtype -> [B,Ho,Wo,Cout] (+ sum, sq)."""
     B, Hi, Wi, Cin = x.shape
     Cout = w_op.shape[0]
@@ -242,9 +242,10 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
         q = torch.zeros(Cout, dtype=torch.float32, device=x.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
-    L.call('wmz_conv2d_nhwc_fwd', L.ptr(x), L.ptr(w_op), L.ptr(out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
-           L.ptr(residual), L.ptr(s), L.ptr(q), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 1 if leaky else 0,
-           float(slope), L.dtype_code(x.dtype), L.stream())
+    psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
+    L.call('wmz_conv2d_nhwc_fwd_pre', L.ptr(x), L.ptr(w_op), L.ptr(out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+           L.ptr(residual), L.ptr(s), L.ptr(q), L.ptr(psc), L.ptr(psh), float(psl), B, Hi, Wi, Cin, Cout, KH, KW, stride,
+           pad, 1 if leaky else 0, float(slope), L.dtype_code(x.dtype), L.stream())
     return (out, s, q) if stats else out
 
 
