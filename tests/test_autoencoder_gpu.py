@@ -224,3 +224,24 @@ def test_eval_mode_backward_is_refused(wmz):
     m.eval()
     with pytest.raises(NotImplementedError):
         m(g['x'].cuda())
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_conv1x1_input_prologue(dtype, tol):
+    """wmz_conv2d_nhwc_fwd_pre: LeakyReLU(x * scale[c] + shift[c]) applied while the 1x1 conv stages its operand, against
+    the two-pass formulation (affine_act then conv) and torch; ragged pixel count, channel counts off the tile sizes."""
+    from world_modelz_amd import ops
+    torch.manual_seed(23)
+    B, H, W, Cin, Cout = 3, 7, 5, 136, 72
+    x = torch.randn(B, H, W, Cin, device='cuda')
+    w = torch.randn(Cout, Cin, device='cuda') * 0.1
+    sc = torch.rand(Cin, device='cuda') + 0.5
+    sh = torch.randn(Cin, device='cuda') * 0.3
+    ref = torch.nn.functional.leaky_relu(x * sc + sh, 0.01) @ w.t()
+    xd, wd = x.to(dtype).contiguous(), w.to(dtype).contiguous()
+    fused, s1, q1 = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, stats=True, pre=(sc, sh, 0.01))
+    two = ops.conv2d_nhwc(ops.affine_act_nhwc(xd, sc, sh, leaky=True, slope=0.01), wd, 1, 1, 1, 0)
+    err = float((fused.float() - ref).norm() / ref.norm())
+    assert err < tol, err
+    assert float((fused.float() - two.float()).norm() / ref.norm()) < tol
+    assert torch.allclose(s1, fused.float().sum(dim=(0, 1, 2)), rtol=2e-3, atol=2e-2)
