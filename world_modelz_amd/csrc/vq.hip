@@ -104,8 +104,19 @@ __global__ __launch_bounds__(VQ_NT) void vq_argmin_kernel(const float* __restric
 
   float xr[E > 0 ? E : 1];
   if constexpr (E > 0) {
+    // unconditional, vectorised loads from a clamped row (a predicated load per element makes hipcc branch and wait per
+    // element: 64 L2 round trips in a row); rows past N are computed on the last row and never stored
+    const float* xrow = X + (rok ? row : (long)N - 1) * ldx;
+    if ((ldx & 3) == 0 && (reinterpret_cast<size_t>(X) & 15) == 0) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) xr[e] = rok ? X[row * ldx + e] : 0.f;
+      for (int e = 0; e < E; e += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + e);
+        xr[e] = v[0]; xr[e + 1] = v[1]; xr[e + 2] = v[2]; xr[e + 3] = v[3];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) xr[e] = xrow[e];
+    }
   } else {
     for (int i = tid; i < Ed * VQ_ROWS; i += VQ_NT) {
       const int r = i / Ed, e = i - r * Ed;
