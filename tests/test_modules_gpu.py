@@ -244,6 +244,27 @@ def test_fused_kernel_stays_inside_its_buffers(wmz):
         assert (xbig[x.numel():] == canary).all() and (obig[o.numel():] == canary).all()
 
 
+def test_fused_path_with_two_heads(wmz):
+    """inner dim 128 as 2 heads x 64: the fused inference path (full grid and cone) against the oracle and each other."""
+    torch.manual_seed(13)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(6, 16, 16), dim=256, num_classes=100, extents=(2, 2, 2), depth=3,
+                                          dim_head=64, mlp_dim=256, heads=2)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    z = torch.randint(0, 101, (2, 6, 16, 16))
+    ref = oden.denoiser_forward(sd, z, (2, 2, 2), 2)
+    cfg = wmz['config']
+    from world_modelz_amd import fused
+    with cfg.compute_dtype(torch.bfloat16), torch.no_grad():
+        assert fused.supported(m.transformer, torch.bfloat16)
+        with cfg.last_frame_cone(False):
+            full = m(z.cuda())
+        with cfg.last_frame_cone(True):
+            cone = m(z.cuda())
+    assert torch.equal(full, cone)
+    assert rel(full, ref) < 3e-2
+
+
 def test_denoiser_full_size_properties(wmz):
     """BASELINE configs[3] (B = 8 clips of 32x16x16, codebook 1024, default denoiser) -- properties that hold at any size:
       * a clip's logits do not depend on its batch neighbours (bit-exact: the data-parallel sharding is exact);
