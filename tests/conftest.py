@@ -35,3 +35,24 @@ def golden():
 
 def have_gpu():
     return torch.cuda.is_available()
+
+
+def near_tie_mismatches(idx, idx_ref, latents_ref, codebook, rel_gap=1e-5):
+    """VQ indices must be bit-identical to the reference's except at genuine near-ties.
+
+    idx, idx_ref: integer tensors of the same shape; latents_ref: the ORACLE's (or the golden) latents [.., E] for those
+    positions; codebook [C, E].  Every mismatching position must (i) have picked the oracle's second-best code and
+    (ii) sit where the oracle's top-2 distance gap (d2 - d1) / d1 is below rel_gap (fp64).  Returns the mismatch count."""
+    idx, idx_ref = idx.reshape(-1).cpu(), idx_ref.reshape(-1).cpu()
+    bad = (idx != idx_ref).nonzero().reshape(-1)
+    if bad.numel() == 0:
+        return 0
+    lat = latents_ref.reshape(-1, latents_ref.shape[-1]).double().cpu()[bad]
+    d = (lat[:, None, :] - codebook.double().cpu()[None]).pow(2).sum(-1)
+    top = d.topk(2, dim=-1, largest=False)
+    gap = (top.values[:, 1] - top.values[:, 0]) / top.values[:, 0]
+    print(f'[near-tie] {bad.numel()} of {idx.numel()} indices differ; oracle top-2 rel gaps: {gap.tolist()}')
+    assert torch.equal(top.indices[:, 0], idx_ref[bad]), 'reference index is not the oracle argmin'
+    assert torch.equal(top.indices[:, 1], idx[bad]), 'a differing index is not the runner-up code'
+    assert float(gap.max()) < rel_gap, f'index differs away from a near-tie (gap {float(gap.max()):.3e})'
+    return int(bad.numel())

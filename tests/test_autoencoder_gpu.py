@@ -3,7 +3,7 @@
 import pytest
 import torch
 
-from conftest import load_golden, sub
+from conftest import load_golden, near_tie_mismatches, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -75,7 +75,9 @@ def test_autoencoder_eval_vs_golden(wmz):
         out, ll, ppl = m(x)
     assert h.shape == g['eval/enc_out'].shape and rel(h, g['eval/enc_out']) < 1e-5
     assert idx.dtype == torch.int64 and idx.shape == g['eval/idx'].shape
-    assert (idx.cpu() == g['eval/idx']).float().mean() >= 0.98      # argmin on fp32 latents that differ in the last bits
+    # indices bit-identical to the reference except at genuine near-ties of the ORACLE's distances (the argmin kernel is
+    # bit-exact on equal inputs; the conv encoder in front of it differs from ATen's in the last bits)
+    near_tie_mismatches(idx, g['eval/idx'], g['eval/enc_out'].permute(0, 2, 3, 1), g['sd0/vq.embedding'][0])
     assert rel(rec, g['eval/decoded']) < 1e-5
     if torch.equal(idx.cpu(), g['eval/idx']):
         assert rel(out, g['eval/recon']) < 1e-5
@@ -91,7 +93,8 @@ def test_autoencoder_train_mode_bn_vs_golden(wmz):
     m.train()
     with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
         idx = m.encode(g['x'].cuda())
-    assert (idx.cpu() == g['train/idx']).float().mean() >= 0.98
+    lat_ref = oae.encoder_forward({k: v.clone() for k, v in sub(g, 'sd0/').items()}, g['x'], training=True)
+    near_tie_mismatches(idx, g['train/idx'], lat_ref.permute(0, 2, 3, 1), g['sd0/vq.embedding'][0])
     assert not torch.equal(idx.cpu(), g['eval/idx'])
     sd1 = sub(g, 'sd1/')
     for k, v in m.state_dict().items():
@@ -121,7 +124,9 @@ def test_config1_frame_roundtrip(wmz):
         idx = m.encode(g['x'].cuda())
         rec = m.decode(g['idx'].cuda())
     assert idx.shape == (1, 8, 8)
-    assert (idx.cpu() == g['idx']).float().mean() >= 0.95
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    lat_ref = oae.encoder_forward(sd_cpu, g['x'], training=False)
+    near_tie_mismatches(idx, g['idx'], lat_ref.permute(0, 2, 3, 1), sd_cpu['vq.embedding'][0])
     assert rec.shape == (1, 3, 64, 64)
     assert torch.allclose(rec[0, :, :4, :4].cpu(), g['recon_corner'], rtol=1e-4, atol=1e-5)
     assert abs(float(rec.mean()) - float(g['recon_mean'])) < 1e-5

@@ -6,7 +6,8 @@ ordinary nn.Conv2d / nn.BatchNorm2d, created in the reference's order so that se
 forward passes run NHWC implicit-GEMM convolutions on MFMA with BatchNorm / LeakyReLU / skip adds fused into the
 epilogues (eval mode) or applied by one elementwise kernel after the batch statistics are known (training mode,
 which is what the frozen AE runs in inside main.py -- quirk Q3: running statistics are updated even under no_grad).
-Tensors cross the module boundary as logical NCHW in channels_last memory format: no layout copies inside.
+Tensors cross the module boundary as logical NCHW in channels_last memory format: no layout copies inside; public
+`forward()`s return the caller's dtype (boundary dtype rule, see local_3d_attention.py), `forward_nhwc` the compute dtype.
 With gradients enabled (VQ-AE training, train_vqae.py:125-192) the blocks run op by op through autograd Functions over
 the HIP kernels: data gradient = the same implicit-GEMM conv on the (zero-dilated for stride 2) output gradient with
 flipped, transposed weights; weight gradient = split-M MFMA GEMM with an implicit-im2col operand; training-mode
@@ -65,9 +66,11 @@ def _to_nchw_view(y):
     return y.permute(0, 3, 1, 2)
 
 
-def _grad_path(*mods):
-    """True when this forward must be differentiable (training through the HIP autograd Functions)."""
-    if not torch.is_grad_enabled() or not any(p.requires_grad for m in mods for p in m.parameters()):
+def _grad_path(x, *mods):
+    """True when this forward must be differentiable (training through the HIP autograd Functions): some parameter of the
+    block is trainable, or the INPUT carries a gradient (a frozen block inside a trainable encoder must still pass the
+    gradient on to the layers in front of it)."""
+    if not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for m in mods for p in m.parameters())):
         return False
     for m in mods:
         for sub in m.modules():
@@ -193,7 +196,7 @@ class Residual(nn.Module):
 
     def forward_nhwc(self, x, dtype):
         c1, bn1, c2, bn2 = self._block[0], self._block[1], self._block[3], self._block[4]
-        if _grad_path(self):
+        if _grad_path(x, self):
             h = _bnact_g(_conv_g(x, c1), bn1)
             h = _conv_g(h, c2)
             if self.downsample is not None:
@@ -225,7 +228,7 @@ class Residual(nn.Module):
 
     def forward(self, x):
         dt = get_compute_dtype()
-        return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt))
+        return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt)).to(x.dtype)
 
 
 class ResidualStack(nn.Module):
@@ -245,7 +248,7 @@ class ResidualStack(nn.Module):
 
     def forward(self, x):
         dt = get_compute_dtype()
-        return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt))
+        return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt)).to(x.dtype)
 
 
 class SimpleResidualEncoder(nn.Module):
@@ -261,14 +264,14 @@ class SimpleResidualEncoder(nn.Module):
     def forward_nhwc(self, x):
         """NCHW frames -> [B,h,w,E] latents (what VectorQuantizerEMA wants: no NCHW<->NHWC flips)."""
         dt = get_compute_dtype()
-        if _grad_path(self):
+        if _grad_path(x, self):
             h = F.leaky_relu(_conv_g(_to_nhwc(x, dt), self._conv_1), LEAKY)
         else:
             h = _conv(_to_nhwc(x, dt), self._conv_1, dt, leaky=True, slope=LEAKY)
         return self._residual_stack.forward_nhwc(h, dt)
 
     def forward(self, x):
-        return _to_nchw_view(self.forward_nhwc(x))
+        return _to_nchw_view(self.forward_nhwc(x)).to(x.dtype)
 
 
 class UpscaleResidual(nn.Module):
@@ -290,7 +293,7 @@ class UpscaleResidual(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward_nhwc(self, x, dtype):
-        if _grad_path(self):
+        if _grad_path(x, self):
             h = _bnact_g(x, self.bn1)
             if self.upsample:
                 h = _Bilinear2xFn.apply(h)
@@ -322,7 +325,7 @@ class UpscaleResidual(nn.Module):
 
     def forward(self, x):
         dt = get_compute_dtype()
-        return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt))
+        return _to_nchw_view(self.forward_nhwc(_to_nhwc(x, dt), dt)).to(x.dtype)
 
 
 class SimpleResidualDecoder(nn.Module):
@@ -340,11 +343,11 @@ class SimpleResidualDecoder(nn.Module):
         """[B,h,w,E] latents (NHWC, C % 8 == 0) -> logical NCHW image."""
         dt = get_compute_dtype()
         mods = list(self.decoder_stack)
-        grad = _grad_path(self)
+        grad = _grad_path(h, self)
         h = _conv_g(h, mods[0]) if grad else _conv(h, mods[0], dt)
         for m in mods[1:-1]:
             h = m.forward_nhwc(h, dt)
         return _to_nchw_view(_conv_g(h, mods[-1]) if grad else _conv(h, mods[-1], dt))
 
     def forward(self, x):
-        return self.forward_nhwc(_to_nhwc(x, get_compute_dtype()))
+        return self.forward_nhwc(_to_nhwc(x, get_compute_dtype())).to(x.dtype)

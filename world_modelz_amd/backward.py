@@ -58,7 +58,7 @@ def attention_block_backward(ctx, dy):
     dt = x_kv.dtype
     I = wq.shape[0]
     dy = dy.contiguous()
-    same_src = x_kv.data_ptr() == x_q.data_ptr() and x_kv.shape == x_q.shape
+    same_src = ctx.same_src              # the caller passed ONE tensor as x and q (decided by identity in forward)
     # ---- to_out (+ residual): y = o Wout^T + bout + residual
     d_res = dy if ctx.has_res else None
     g_wout = g_bout = None
@@ -102,7 +102,7 @@ def attention_block_backward(ctx, dy):
     g_xkv = dx_kv.reshape(x_kv.shape)
     g_xq = None if fold_q else dxq.reshape(x_q.shape)
     g_res = None if (not ctx.has_res or fold_res) else d_res
-    return (g_xkv, g_xq, g_ln_g, g_ln_b, g_wq, g_wk, g_wv, g_bv, g_wout, g_bout, g_res, None, None, None)
+    return (g_xkv, g_xq, g_ln_g, g_ln_b, g_wq, g_wk, g_wv, g_bv, g_wout, g_bout, g_res, None, None, None, None, None)
 
 
 def feed_forward_block_backward(ctx, dy):
@@ -133,7 +133,7 @@ def feed_forward_block_backward(ctx, dy):
         dw1, db1 = _emit2(w1, b1, lambda w, b: ops.linear_wgrad(dz, x, w, b))
         dx = dxhat
         g_res = d_res
-    return dx.reshape(x.shape), dg, db, dw1, db1, dw2, db2, g_res, None
+    return dx.reshape(x.shape), dg, db, dw1, db1, dw2, db2, g_res, None, None
 
 
 def embed_backward(ctx, dx):
@@ -201,4 +201,4 @@ def dense_attention_block_backward(ctx, dy):
         ops.linear_wgrad(dqkv, x, dwqkv, None)
         dx = dxhat + d_res if fold else dxhat
     g_res = None if (not ctx.has_res or fold) else d_res
-    return dx.reshape(x.shape), dg, db, dwqkv, dwout, dbout, g_res, None, None
+    return dx.reshape(x.shape), dg, db, dwqkv, dwout, dbout, g_res, None, None, None

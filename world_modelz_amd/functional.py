@@ -19,7 +19,8 @@ LN_EPS = 1e-5
 
 class _AttentionBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, residual, extents, heads, grad_on):
+    def forward(ctx, x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, residual, extents, heads, grad_on, same_src,
+                res_is_xkv):
         dt = x_kv.dtype
         I = wq.shape[0]
         ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
@@ -41,8 +42,9 @@ class _AttentionBlock(torch.autograd.Function):
             ctx.save_for_backward(x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse)
             ctx.extents, ctx.heads, ctx.has_res = extents, heads, residual is not None
             ctx.ln_stats = stats
-            ctx.res_is_xkv = (residual is not None and residual.data_ptr() == x_kv.data_ptr()
-                              and residual.shape == x_kv.shape)
+            # gradient folding is decided by autograd identity of the caller's tensors (attention_block), never by
+            # storage: attn(x, q=x.detach()) or an aliased residual must get separate gradients
+            ctx.same_src, ctx.res_is_xkv = bool(same_src), bool(res_is_xkv)
         return y.reshape(*lead, y.shape[-1])
 
     @staticmethod
@@ -53,7 +55,7 @@ class _AttentionBlock(torch.autograd.Function):
 
 class _FeedForwardBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, residual, grad_on):
+    def forward(ctx, x, ln_g, ln_b, w1, b1, w2, b2, residual, grad_on, res_is_x):
         dt = x.dtype
         ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
         need_bwd = grad_on and any(ctx.needs_input_grad)
@@ -66,7 +68,7 @@ class _FeedForwardBlock(torch.autograd.Function):
             ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z)
             ctx.ln_stats = stats
             ctx.has_res = residual is not None
-            ctx.res_is_x = residual is not None and residual.data_ptr() == x.data_ptr() and residual.shape == x.shape
+            ctx.res_is_x = bool(res_is_x)
         else:
             h = ops.linear_fwd(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, gelu=True)
             y = ops.linear_fwd(h, w2_c, bias=b2.detach(), residual=residual)
@@ -117,12 +119,12 @@ def _as_compute(x):
 def attention_block(x_kv, x_q, ln, wq, wk, wv, bv, wout, bout, residual, extents, heads):
     g, b = (None, None) if ln is None else ln
     return _AttentionBlock.apply(x_kv, x_q, g, b, wq, wk, wv, bv, wout, bout, residual, tuple(int(e) for e in extents),
-                                 int(heads), torch.is_grad_enabled())
+                                 int(heads), torch.is_grad_enabled(), x_q is x_kv, residual is x_kv)
 
 
 def feed_forward_block(x, ln, w1, b1, w2, b2, residual):
     g, b = (None, None) if ln is None else ln
-    return _FeedForwardBlock.apply(x, g, b, w1, b1, w2, b2, residual, torch.is_grad_enabled())
+    return _FeedForwardBlock.apply(x, g, b, w1, b1, w2, b2, residual, torch.is_grad_enabled(), residual is x)
 
 
 def embed_tokens(z, emb, pos_s, pos_h, pos_w):
@@ -148,7 +150,7 @@ class _DenseAttentionBlock(torch.autograd.Function):
     minecraft/transformer.py:11-63 plus the `+ x` of :77."""
 
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, wqkv, wout, bout, residual, heads, grad_on):
+    def forward(ctx, x, ln_g, ln_b, wqkv, wout, bout, residual, heads, grad_on, res_is_x):
         dt = x.dtype
         B, n, _ = x.shape
         I = wqkv.shape[0] // 3
@@ -166,7 +168,7 @@ class _DenseAttentionBlock(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x, ln_g, ln_b, wqkv, wout, bout, qkv, o, lse)
             ctx.heads, ctx.has_res = heads, residual is not None
-            ctx.res_is_x = residual is not None and residual.data_ptr() == x.data_ptr() and residual.shape == x.shape
+            ctx.res_is_x = bool(res_is_x)
         return y
 
     @staticmethod
@@ -192,7 +194,8 @@ class _EmbedIndexed(torch.autograd.Function):
 
 def dense_attention_block(x, ln, wqkv, wout, bout, residual, heads):
     g, b = (None, None) if ln is None else ln
-    return _DenseAttentionBlock.apply(x, g, b, wqkv, wout, bout, residual, int(heads), torch.is_grad_enabled())
+    return _DenseAttentionBlock.apply(x, g, b, wqkv, wout, bout, residual, int(heads), torch.is_grad_enabled(),
+                                      residual is x)
 
 
 def embed_tokens_indexed(tok, pos, emb, pos_s, pos_h, pos_w, shape):

@@ -254,10 +254,10 @@ class _TrainForward(torch.autograd.Function):
             zpre = ops.linear_fwd(x1, _cast.operand(w1, dt), bias=b1.detach(), ln=(fn_g.detach(), fn_b.detach()), ln_eps=LN_EPS,
                                   ln_stats=stats)
             cf = _Ctx((x1, fn_g, fn_b, w1, b1, w2, b2, zpre), has_res=True, res_is_x=True, ln_stats=stats)
-            dx1, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2, _, _ = Bk.feed_forward_block_backward(cf, dy)
+            dx1, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2 = Bk.feed_forward_block_backward(cf, dy)[:7]
             # attention block: x1 = to_out(attn(LN(x), q = x)) + x
             ca = _Ctx((x_in, x_in, an_g, an_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse), extents=attn.fn.extents,
-                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, ln_stats=None)
+                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, same_src=True, ln_stats=None)
             r = Bk.attention_block_backward(ca, dx1)
             dy = r[0]
             grads[14 * l:14 * l + 14] = [r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]

@@ -8,23 +8,45 @@ capturable; torch's caching allocator provides the graph-private pool for interm
 """
 import torch
 
+from . import _cast, config
+
 
 class GraphedForward:
+    """The captured graph bakes in the device addresses of the operand copies of the weights (bf16 casts, packed weight
+    streams: _cast).  It therefore (i) holds strong references to every operand tensor that existed at capture time, so
+    none of them can be freed and recycled under a retained graph, and (ii) stamps the parameter versions / addresses,
+    the _cast epoch and the run-time configuration it was captured under, and re-captures when any of them changed
+    (optimizer step, load_state_dict, EMA copy, .to(), another compute dtype) instead of replaying stale weights."""
+
     def __init__(self, model, example, warmup=3):
         self.model = model
         self.static_in = example.clone()
+        self.warmup = warmup
+        self.recaptures = 0
+        self._capture()
+
+    def _stamp(self):
+        return (_cast._epoch, config.get_compute_dtype(), config.get_last_frame_cone(),
+                tuple((t._version, t.data_ptr()) for t in list(self.model.parameters()) + list(self.model.buffers())))
+
+    def _capture(self):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():
-            for _ in range(warmup):
-                model(self.static_in)
+            for _ in range(self.warmup):
+                self.model(self.static_in)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.static_out = model(self.static_in)
+            self.static_out = self.model(self.static_in)
+        self._operands = [h[1] for h in _cast._cache.values()]      # strong references (tensors or tuples of tensors)
+        self.stamp = self._stamp()
 
     def __call__(self, tokens):
+        if self._stamp() != self.stamp:
+            self.recaptures += 1
+            self._capture()
         if tokens is not self.static_in:
             self.static_in.copy_(tokens, non_blocking=True)
         self.graph.replay()

@@ -5,6 +5,13 @@ Same classes, constructor signatures, attribute names and state_dict keys as the
 reference checkpoints load and `from local_3d_attention import Local3dAttentionTransformer` keeps working
 (see world_modelz_amd/dropin/).  The bodies call the fused HIP blocks in functional.py; nothing here runs on
 the CPU and nothing materialises the unfolded key/value windows.
+
+Dtype rule at the module boundary: every public `forward()` returns its result in the dtype of its floating-point
+input (token-index inputs: the dtype of the module's parameters), whatever the compute dtype (config.py) is -- so
+reference code that composes these modules with plain torch layers (main.py:33-36 feeds the transformer's output to an
+fp32 nn.Linear) keeps working in the bf16 speed mode.  The stack's own layer loop and the drop-in
+VqVideoDiffusionModel use the internal entry points (`forward_prenorm`, `forward_compute`) and stay in the compute
+dtype end to end.
 """
 import torch
 from torch import nn
@@ -24,7 +31,7 @@ class PreNorm(nn.Module):
     def forward(self, x, **kwargs):
         fused = getattr(self.fn, 'forward_prenorm', None)
         if fused is not None:
-            return fused(x, self.norm, **kwargs)         # LayerNorm rides in the GEMM prologue
+            return fused(x, self.norm, **kwargs).to(x.dtype)         # LayerNorm rides in the GEMM prologue
         return self.fn(nn.functional.layer_norm(x, self.norm.normalized_shape, self.norm.weight, self.norm.bias,
                                                 self.norm.eps), **kwargs)
 
@@ -42,12 +49,15 @@ class FeedForward(nn.Module):
         if self.dropout > 0 and self.training:
             raise NotImplementedError('dropout > 0 in training is not built into the fused HIP feed-forward '
                                       '(reference default and every published run use dropout 0)')
+        res_same = residual is x
         x = Fw._as_compute(x)
+        if residual is not None:
+            residual = x if res_same else Fw._as_compute(residual)
         l1, l2 = self.net[0], self.net[3]
         return Fw.feed_forward_block(x, ln, l1.weight, l1.bias, l2.weight, l2.bias, residual)
 
     def forward(self, x):
-        return self._run(x, None, None)
+        return self._run(x, None, None).to(x.dtype)
 
     def forward_prenorm(self, x, norm, residual=None):
         return self._run(x, (norm.weight, norm.bias), residual)
@@ -80,7 +90,11 @@ class Local3dAttention(nn.Module):
     def _run(self, x, q, ln, residual):
         if self.dropout > 0 and self.training:
             raise NotImplementedError('dropout > 0 in training is not built into the fused HIP attention block')
-        x, q = Fw._as_compute(x), Fw._as_compute(q)
+        same, res_same = q is x, residual is x            # attn(x, q=x) + x: keep ONE tensor so the backward folds the paths
+        x = Fw._as_compute(x)
+        q = x if same else Fw._as_compute(q)
+        if residual is not None:
+            residual = x if res_same else Fw._as_compute(residual)
         if isinstance(self.to_out, nn.Identity):
             wo = bo = None
         else:
@@ -90,7 +104,7 @@ class Local3dAttention(nn.Module):
         return y.reshape(q.shape[:-1] + (y.shape[-1],))
 
     def forward(self, x, q):
-        return self._run(x, q, None, None)
+        return self._run(x, q, None, None).to(q.dtype)
 
     def forward_prenorm(self, x, norm, q, residual=None):
         return self._run(x, q, (norm.weight, norm.bias), residual)
@@ -99,9 +113,10 @@ class Local3dAttention(nn.Module):
         """Attention core on already-projected tensors (reference :78-99), returned like the reference as
         [(b s h w), heads, 1, dim_head]."""
         from . import ops
+        dt_in = q.dtype
         k, v, q = Fw._as_compute(k), Fw._as_compute(v), Fw._as_compute(q)
         out, _, _ = ops.local3d_attention_fwd(q, k, v, self.extents, self.heads)
-        return out.reshape(-1, self.heads, 1, out.shape[-1] // self.heads)
+        return out.reshape(-1, self.heads, 1, out.shape[-1] // self.heads).to(dt_in)
 
 
 class Local3dAttentionTransformer(nn.Module):
@@ -131,6 +146,11 @@ class Local3dAttentionTransformer(nn.Module):
         return ((ps + ph) + pw).expand(batch_shape[0], s, h, w, -1)
 
     def forward(self, img_z):
+        """[B,S,H,W] int64 tokens -> [B,S,H,W,dim] in the parameters' dtype (see the module docstring's dtype rule)."""
+        return self.forward_compute(img_z).to(self.embedding.weight.dtype)
+
+    def forward_compute(self, img_z):
+        """forward() without the boundary cast: the residual stream in the compute dtype (internal callers)."""
         if not img_z.is_cuda:
             raise Fw.ops.L.WmzError('Local3dAttentionTransformer runs on the GPU only (no CPU fallback)')
         _, S, H, W = img_z.shape

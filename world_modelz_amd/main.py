@@ -27,6 +27,6 @@ class VqVideoDiffusionModel(nn.Module):
                     raise IndexError('token grid larger than the position-embedding tables')
                 last = fused.transformer_forward_last(tr, x)      # only the planes the last frame depends on
                 return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)
-        h = self.transformer(x)
+        h = self.transformer.forward_compute(x)
         last = h[:, -1]                       # [B,H,W,D] view: uniform row stride, no copy
         return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)

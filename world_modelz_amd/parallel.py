@@ -45,25 +45,48 @@ class FlatArena:
                 p._wmz_grad = p.grad
 
 
+def layer_bucket_key(name):
+    """Bucket key of a denoiser parameter name: one bucket per transformer layer (`...layers.<l>.`), one for whatever
+    precedes the layers (embeddings) and one for what follows (the logit head) -- consecutive in arena order."""
+    parts = name.split('.')
+    if 'layers' in parts:
+        i = parts.index('layers')
+        if i + 1 < len(parts) and parts[i + 1].isdigit():
+            return 'layer' + parts[i + 1]
+    return 'pre' if ('emb' in name) else 'post'
+
+
 class BucketedAllReduce:
     """Overlapped gradient all-reduce over a FlatArena.
 
-    buckets: consecutive parameter ranges (in arena order) of at most `bucket_bytes`; parameters are registered in
-    module order, the backward produces them roughly in reverse, so buckets complete back to front."""
+    buckets: consecutive parameter ranges (in arena order), cut either where `group_of(parameter name)` changes (one
+    bucket per transformer layer: layer_bucket_key) or at `bucket_bytes`; parameters are registered in module order, the
+    backward produces them roughly in reverse, so buckets complete back to front and the collective of layer l runs on
+    the side stream under the backward of layer l-1.  rounds: backward passes per optimizer step (gradient
+    accumulation) -- a bucket is reduced when its last gradient of the LAST round has landed.
+    `always`: register the hooks and run the collectives even in a world of one (exercises the side-stream path on a
+    single GPU; RCCL's all-reduce over one rank is an in-place no-op copy)."""
 
-    def __init__(self, arena, process_group=None, bucket_bytes=4 << 20):
+    def __init__(self, arena, process_group=None, bucket_bytes=4 << 20, group_of=None, rounds=1, always=False):
         self.arena = arena
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (always and dist.is_initialized())
+        self.rounds = int(rounds)
         self.cuda = arena.flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.buckets = []                      # (start_elem, end_elem, [param indices])
-        cur, start = [], 0
+        self.order = []                        # bucket ids in the order their collectives are enqueued this step
+        self.last_order = []                   # ... and were in the step finish() closed last
+        cur, start, key = [], 0, None
         for i, (p, o) in enumerate(zip(arena.params, arena.offsets)):
-            if cur and (o + p.numel() - start) * 4 > bucket_bytes:
+            k = group_of(arena.names[id(p)]) if group_of is not None else None
+            cut = (k != key) if group_of is not None else ((o + p.numel() - start) * 4 > bucket_bytes)
+            if cur and cut:
                 self.buckets.append((start, o, cur))
                 cur, start = [], o
             cur.append(i)
+            key = k
         self.buckets.append((start, arena.numel, cur))
         self.bucket_of = {}
         for b, (_, _, idxs) in enumerate(self.buckets):
@@ -73,7 +96,7 @@ class BucketedAllReduce:
         self.handles = []
         self.launched = []
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(i)
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))     # gradients arriving through autograd
@@ -81,7 +104,7 @@ class BucketedAllReduce:
         self.reset()
 
     def reset(self):
-        self.pending = [len(idxs) for (_, _, idxs) in self.buckets]
+        self.pending = [len(idxs) * self.rounds for (_, _, idxs) in self.buckets]
         self.handles = []
         self.launched = [False] * len(self.buckets)
 
@@ -97,6 +120,7 @@ class BucketedAllReduce:
         s, e, _ = self.buckets[b]
         view = self.arena.flat_grad[s:e]
         self.launched[b] = True
+        self.order.append(b)
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())      # the bucket's gradients are complete
             with torch.cuda.stream(self.stream):
@@ -107,7 +131,7 @@ class BucketedAllReduce:
     def finish(self):
         """Call after backward(): reduces any bucket whose hooks did not all fire (unused parameters) and makes the
         compute stream wait for the side stream.  Returns the factor consumers must apply to the summed gradient."""
-        if self.world > 1:
+        if self.active:
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
                     self._launch(b)
@@ -116,6 +140,7 @@ class BucketedAllReduce:
             else:
                 for h in self.handles:
                     h.wait()
+        self.last_order, self.order = self.order, []
         self.reset()
         return 1.0 / self.world
 

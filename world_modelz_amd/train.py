@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import _cast
 from . import _lib as L
-from .parallel import BucketedAllReduce, FlatArena, broadcast_parameters
+from .parallel import BucketedAllReduce, FlatArena, broadcast_parameters, layer_bucket_key
 
 P_MAX_UNIFORM = 0.1     # main.py:208
 
@@ -21,26 +21,33 @@ P_MAX_UNIFORM = 0.1     # main.py:208
 _corrupt_calls = 0
 
 
-def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None):
+def _dp_rank():
+    d = torch.distributed
+    return d.get_rank() if d.is_available() and d.is_initialized() else 0
+
+
+def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None, rank=None):
     """main.py:240-259 on the GPU without the [B,HW,C] one-hot / lerp / multinomial temporaries: ONE kernel.
 
     multinomial(lerp(one_hot(z), 1/C, a)) with a = 0.1 r has the closed form "with probability a redraw uniformly
     over all C codes, else keep z" (checked against the reference's categorical law in tests); then positions with
     rand < r become the mask token C.  Same distribution as the reference, not the same RNG stream (in-kernel
-    Philox keyed by `seed` -- default torch's initial seed -- and a per-call stream id)."""
+    Philox keyed by `seed` -- default torch's initial seed -- and a stream id made of the data-parallel rank and a
+    per-process call counter, so that ranks seeded alike still draw different masks for their different clips)."""
     global _corrupt_calls
     assert batch_z.is_cuda and batch_z.dtype == torch.int64
     B, S = batch_z.shape[:2]
     HW = batch_z[0, 0].numel()
-    out = batch_z.clone()
-    target = torch.empty_like(batch_z[:, -1]).contiguous()
+    src = batch_z.contiguous()                         # the kernel indexes [B, S, HW] densely: never keep foreign strides
+    out = src.clone()
+    target = torch.empty((B,) + tuple(batch_z.shape[2:]), dtype=torch.int64, device=batch_z.device)
     r = r.to(batch_z.device, torch.float32).contiguous()
     if seed is None:
         seed = generator.initial_seed() if generator is not None else torch.initial_seed()
     _corrupt_calls += 1
-    src = batch_z.contiguous()
+    stream_id = ((_dp_rank() if rank is None else int(rank)) << 40) | (_corrupt_calls & ((1 << 40) - 1))
     L.call('wmz_corrupt_tokens', src.data_ptr() + (S - 1) * HW * 8, S * HW, L.ptr(r), out.data_ptr() + (S - 1) * HW * 8,
-           S * HW, L.ptr(target), B, HW, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, _corrupt_calls, L.stream())
+           S * HW, L.ptr(target), B, HW, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_id, L.stream())
     return out, target
 
 
@@ -120,7 +127,10 @@ class DenoiserTrainer:
     """One object = model + flat arenas + AdamW state + (optional) data-parallel reducer."""
 
     def __init__(self, model, num_embeddings, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, warmup=500,
-                 max_steps=200 * 1000, distributed=None, bucket_bytes=4 << 20):
+                 max_steps=200 * 1000, distributed=None, bucket_bytes=None, accumulation_steps=1):
+        """bucket_bytes None: one all-reduce bucket per transformer layer (plus the embeddings and the head), so the
+        collective of layer l overlaps the backward of layer l-1; a number: consecutive parameters up to that size.
+        accumulation_steps: micro-batches per optimizer step (main.py:221, :275-276: each micro-loss is divided by it)."""
         self.model = model
         self.C = num_embeddings
         self.arena = FlatArena(model)
@@ -132,9 +142,18 @@ class DenoiserTrainer:
         self.step_count = 0
         if distributed is None:
             distributed = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-        self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes) if distributed else None
+        self.acc_steps = int(accumulation_steps)
+        assert self.acc_steps >= 1
+        self.reducer = BucketedAllReduce(self.arena, bucket_bytes=bucket_bytes,
+                                         group_of=None if bucket_bytes is not None else layer_bucket_key,
+                                         rounds=self.acc_steps, always=True) if distributed else None
         if distributed:
             broadcast_parameters(self.arena)
+        self.rank = _dp_rank()
+        # every rank draws its own noise levels: a generator of its own, keyed by the rank, so that ranks
+        # started from the same torch seed do not all apply one r / one mask pattern to their different clips
+        self.sampler_gen = torch.Generator()
+        self.sampler_gen.manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0x7FFFFFFFFFFFFFFF)
         self.sampler = LossAwareSamplerEma(num_histogram_buckets=100, uniform_p=0.01, alpha=0.9, warmup=10)
         self.operands = self._register_operands()
         self.operands.refresh()
@@ -166,13 +185,14 @@ class DenoiserTrainer:
         bulk.add((self.model.logit_proj.weight,), dt, 'wT', transpose=True)
         return bulk
 
-    def forward_backward(self, batch_z, target):
-        """Forward, per-sample CE over the last frame, backward.  Returns (per_sample_loss[B], mean loss) on device."""
+    def forward_backward(self, batch_z, target, loss_scale=1.0):
+        """Forward, per-sample CE over the last frame, backward of loss.mean() * loss_scale (gradient accumulation:
+        main.py:274-278).  Returns (per_sample_loss[B], mean loss) on device."""
         y = self.model(batch_z)
         loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
         per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
         mean = loss.mean()
-        mean.backward()
+        (mean if loss_scale == 1.0 else mean * loss_scale).backward()
         return per_sample.detach(), mean.detach()
 
     def optimizer_step(self, lr=None):
@@ -192,13 +212,22 @@ class DenoiserTrainer:
         return self.sq
 
     def train_step(self, batch_z, r=None, generator=None):
-        """corrupt -> forward/backward (all-reduce overlapped) -> grad-norm -> AdamW; sampler update on the host."""
-        B = batch_z.shape[0]
-        if r is None:
-            r = self.sampler.sample(B)
+        """corrupt -> forward/backward (all-reduce overlapped) -> grad-norm -> AdamW; sampler update on the host.
+        batch_z: one micro-batch [B,S,H,W], or a list of `accumulation_steps` of them (main.py:221-280: gradients
+        accumulate over the micro-batches, each micro-loss scaled by 1/acc_steps, loss_sum is their sum)."""
+        micro = list(batch_z) if isinstance(batch_z, (list, tuple)) else [batch_z]
+        assert len(micro) == self.acc_steps, f'expected {self.acc_steps} micro-batches, got {len(micro)}'
+        rs = list(r) if isinstance(r, (list, tuple)) else [r] * len(micro)
         self.arena.zero_grad()
-        zc, target = corrupt_last_frame(batch_z, r, self.C, generator)
-        per_sample, mean = self.forward_backward(zc, target)
+        loss_sum, seen = 0.0, []
+        for z, rr in zip(micro, rs):
+            if rr is None:
+                rr = self.sampler.sample(z.shape[0], generator=self.sampler_gen)
+            zc, target = corrupt_last_frame(z, rr, self.C, generator, rank=self.rank)
+            per_sample, mean = self.forward_backward(zc, target, 1.0 / self.acc_steps)
+            loss_sum = loss_sum + mean / self.acc_steps
+            seen.append((rr, per_sample))
         sq = self.optimizer_step()
-        self.sampler.update_with_losses(r, per_sample)        # the step's one host sync (reference: ~50)
-        return float(mean), math.sqrt(float(sq))
+        for rr, per_sample in seen:
+            self.sampler.update_with_losses(rr, per_sample)   # the step's host sync (reference: ~50 per micro-batch)
+        return float(loss_sum), math.sqrt(float(sq))

@@ -30,12 +30,15 @@ class Attention(nn.Module):
     def _run(self, x, ln, residual):
         if self.p_drop > 0 and self.training:
             raise NotImplementedError('dropout > 0 in training is not built into the fused HIP attention block')
+        res_same = residual is x
         x = Fw._as_compute(x)
+        if residual is not None:
+            residual = x if res_same else Fw._as_compute(residual)
         wo, bo = (None, None) if isinstance(self.to_out, nn.Identity) else (self.to_out[0].weight, self.to_out[0].bias)
         return Fw.dense_attention_block(x, ln, self.to_qkv.weight, wo, bo, residual, self.heads)
 
     def forward(self, x):
-        return self._run(x, None, None)
+        return self._run(x, None, None).to(x.dtype)
 
     def forward_prenorm(self, x, norm, residual=None):
         return self._run(x, (norm.weight, norm.bias), residual)
@@ -52,6 +55,9 @@ class Transformer(nn.Module):
             ]))
 
     def forward(self, x):
+        return self.forward_compute(x).to(x.dtype)       # boundary dtype rule: see local_3d_attention.py
+
+    def forward_compute(self, x):
         x = Fw._as_compute(x)
         for attn, ff in self.layers:
             x = attn.fn.forward_prenorm(x, attn.norm, residual=x)     # attn(x) + x
