@@ -10,7 +10,9 @@
  *  - `dtype` selects the element type of activations: WMZ_F32 or WMZ_BF16 (accumulation is always fp32);
  *    parameters marked `float*` are always fp32, indices are int64 like the reference's LongTensors;
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued;
- *  - no allocation, no host sync, no global state: safe to capture in a hipGraph, re-entrant per stream;
+ *  - no allocation, no host sync, no global state (the wmz_debug_* development probes at the end of this file are the
+ *    one exception: process-wide switches that production callers never touch): safe to capture in a hipGraph,
+ *    re-entrant per stream;
  *  - return 0 on success, WMZ_ERR_* otherwise; wmz_last_error() gives the message (thread-local).
  */
 #ifndef WMZ_H_
@@ -46,6 +48,12 @@ const char* wmz_last_error(void);
 int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, float* logits_dbg,
                          int B, int S, int H, int W, int heads, int dh, int eS, int eH, int eW,
                          long ldq, long ldk, long ldv, long ldo, int dtype, void* stream);
+
+/* Same contract, always on the general kernel (any W, fp32 / bf16) even where wmz_local3d_attn_fwd would pick the
+ * 16-wide-plane fast path: the parity tests hold the two against each other. */
+int wmz_local3d_attn_fwd_general(const void* q, const void* k, const void* v, void* out, float* lse, float* logits_dbg,
+                                 int B, int S, int H, int W, int heads, int dh, int eS, int eH, int eW,
+                                 long ldq, long ldk, long ldv, long ldo, int dtype, void* stream);
 
 /* Backward of the above given the saved lse: dq, dk, dv.  Gather form, no atomics (the window relation is
  * symmetric): one query-owner pass (dq, and delta = rowsum(dout*out) into delta_ws, fp32 [N, heads]) and one
@@ -210,6 +218,10 @@ int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const floa
 int wmz_debug_fused_timestamps(void* buf);
 /* Same for the 16-wide-plane attention forward kernel (16 waves x 64 int64). */
 int wmz_debug_attn_timestamps(void* buf);
+/* development knobs of the attention forward: dbg = ablation switches (1 skip the per-tile compute, 2 skip the K/V
+ * staging: timing experiments only, results are garbage), variant = A/B selector between kernel instantiations;
+ * (0, 0) is the product behaviour. */
+int wmz_debug_attn_knobs(int dbg, int variant);
 
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]

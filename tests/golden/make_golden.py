@@ -357,6 +357,161 @@ def gen_step(R):
     npz('step_tiny', **arrs)
 
 
+def gen_sampler(R):
+    """main.py:evaluate_model (:50-117) run by the reference itself with its two random draws replaced by injected uniform
+    fields (oracle/sampler.py defines the inverse-CDF categorical draw both sides use).  Records the context tokens, every
+    last frame fed to the model, the generated token frames and the decoded images."""
+    import random
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import sampler as osamp
+    main, TV = R['main'], R['tv']
+    C, B, n_past, width, steps, iters = 16, 2, 2, 16, 2, 30
+    for tag, topk in (('', -1), ('_topk', 4)):
+        for seed in range(900, 960):
+            torch.manual_seed(seed)
+            random.seed(seed)
+            ae = TV.VqAutoEncoder(embedding_dim=8, num_embeddings=C, downscale_steps=2, hidden_planes=8, in_channels=1)
+            model = main.VqVideoDiffusionModel(data_shape=(n_past + 1, 4, 4), dim=16, num_classes=C, extents=(1, 1, 1),
+                                               depth=2, dim_head=8, mlp_dim=24, heads=2)
+            with torch.no_grad():                                   # make the logits peaked enough to matter
+                model.logit_proj.weight.mul_(6.0)
+            sd_model = {k: v.clone() for k, v in model.state_dict().items()}
+            sd_ae = {k: v.clone() for k, v in ae.state_dict().items()}
+            dataset = [np.random.RandomState(seed + j).rand(n_past + 1, width, width, 1).astype(np.float32) for j in range(5)]
+            u_multi = torch.rand(steps, iters, B * 16)
+            u_mask = torch.rand(steps, iters, B, 16)
+            it_multi, it_mask = iter(u_multi.reshape(-1, B * 16)), iter(u_mask.reshape(-1, B, 16))
+            cap = dict(z0=None, fed=[], tokens=[], margin=1.0)
+            real_encode, real_decode, real_forward = ae.encode, ae.decode, model.forward
+
+            def encode(x):
+                z = real_encode(x)
+                cap['z0'] = z.clone()
+                return z
+
+            def decode(z):
+                cap['tokens'].append(z.clone())
+                return real_decode(z)
+
+            def forward(z):
+                cap['fed'].append(z[:, -1].clone())
+                return real_forward(z)
+
+            def fake_multinomial(p, num_samples, replacement=False, **kw):
+                u = next(it_multi)
+                cap['margin'] = min(cap['margin'], osamp.icdf_margin(p, u))
+                return osamp.multinomial_icdf(p, u).view(-1, 1)
+
+            def fake_rand(*size, **kw):
+                u = next(it_mask)
+                assert tuple(u.shape) == tuple(size), (u.shape, size)
+                return u
+
+            ae.encode, ae.decode, model.forward = encode, decode, forward
+            keep = torch.multinomial, torch.rand
+            torch.multinomial, torch.rand = fake_multinomial, fake_rand
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    images, _ = main.evaluate_model(device=torch.device('cpu'), model=model, decoder_model=ae,
+                                                    num_embeddings=C, mask_token_index=C, batch_size=B, num_steps=steps,
+                                                    n_past=n_past, image_width=width, dataset=dataset, sample_topk=topk)
+            finally:
+                torch.multinomial, torch.rand = keep
+            if cap['margin'] > 2e-5:
+                break
+        else:
+            raise RuntimeError('no seed with a safe inverse-CDF margin')
+        z0 = cap['z0'].view(B, n_past + 1, 4, 4)
+        arrs = dict(z0=z0, u_multi=u_multi, u_mask=u_mask, fed=torch.stack(cap['fed']), tokens=torch.stack(cap['tokens']),
+                    images=images, margin=np.array(cap['margin']), seed=np.array(seed), topk=np.array(topk),
+                    num_embeddings=np.array(C), extents=np.array((1, 1, 1)), heads=np.array(2))
+        arrs.update(sd_arrays(sd_model, 'model/'))
+        arrs.update(sd_arrays(sd_ae, 'ae0/'))                      # AE state BEFORE the run (train-mode BN mutates it, Q3)
+        arrs.update(sd_arrays(ae.state_dict(), 'ae1/'))            # ... and after
+        npz('sampler_tiny' + tag, **arrs)
+
+
+def gen_checkpoint(R):
+    """Reference-format checkpoints: the dicts train_vqae.py:168-179 and main.py:297-309 torch.save, holding
+    the pickled argparse Namespace of the reference's own parsers, written after one real optimizer step each; plus what
+    main.py:376-402 rebuilds from them (frozen AE in train mode -> tokens -> denoiser / EMA-denoiser logits)."""
+    import copy
+    main, TV = R['main'], R['tv']
+    sys.modules.pop('model_ema_v2', None)
+    from model_ema_v2 import ModelEmaV2
+    argv = sys.argv
+    try:
+        sys.argv = ['train_vqae.py', '--embedding_dim', '8', '--num_embeddings', '16', '--downscale_steps', '2',
+                    '--hidden_planes', '8', '--image_width', '16', '--name', 'vqvdvq_tiny', '--device', 'cpu']
+        opt_ae = TV.parse_args()
+        sys.argv = ['main.py', '--dim', '16', '--extents', '1,1,1', '--depth', '2', '--mlp_dim', '24', '--dim_head', '8',
+                    '--heads', '2', '--n_past', '2', '--image_width', '16', '--decoder_model', 'ckpt_vqae_tiny.pth',
+                    '--ema_decay', '0.9', '--name', 'vq_diffusion_tiny', '--device', 'cpu', '--batch_size', '2']
+        opt = main.parse_args()
+    finally:
+        sys.argv = argv
+    # ---- VQ-AE: train_vqae.main (:241) + one step of train (:139-150) + the save of :172-179
+    torch.manual_seed(opt_ae.manual_seed)
+    ae = TV.VqAutoEncoder(opt_ae.embedding_dim, opt_ae.num_embeddings, opt_ae.downscale_steps,
+                          hidden_planes=opt_ae.hidden_planes, in_channels=1)
+    optim_ae = torch.optim.AdamW(ae.parameters(), lr=opt_ae.lr, betas=(0.9, 0.999), weight_decay=opt_ae.weight_decay)
+    sched_ae = torch.optim.lr_scheduler.StepLR(optim_ae, step_size=3, gamma=0.5)
+    batch = torch.rand(8, 1, 16, 16)
+    ae.train()
+    rec, latent_loss, _ = ae(batch)
+    loss = torch.nn.SmoothL1Loss(reduction='mean')(rec, batch) + opt_ae.latent_loss_weight * latent_loss
+    optim_ae.zero_grad()
+    loss.backward()
+    optim_ae.step()
+    torch.save({'step': 1, 'lr': sched_ae.get_last_lr(), 'model_state_dict': ae.state_dict(),
+                'optimizer_state_dict': optim_ae.state_dict(), 'loss': {'train_recon_error': [loss.item()]}, 'opt': opt_ae},
+               os.path.join(HERE, 'ckpt_vqae_tiny.pth'))
+    # ---- denoiser: main.main (:376-402, :432-442) + one optimizer step + the save of :302-309
+    torch.manual_seed(opt.manual_seed)
+    decoder_data = torch.load(os.path.join(HERE, opt.decoder_model), map_location='cpu', weights_only=False)
+    chk = decoder_data['opt']
+    dec = TV.VqAutoEncoder(chk.embedding_dim, chk.num_embeddings, chk.downscale_steps, hidden_planes=chk.hidden_planes, in_channels=1)
+    dec.load_state_dict(decoder_data['model_state_dict'])
+    x = torch.rand(opt.n_past + 1, 1, 16, 16)
+    z = dec.encode(x)                                                # (3, 4, 4) -> data_shape (:388-394)
+    extents = [int(e) for e in opt.extents.split(',')]
+    model = main.VqVideoDiffusionModel(data_shape=z.shape, dim=opt.dim, num_classes=chk.num_embeddings, extents=extents,
+                                       depth=opt.depth, mlp_dim=opt.mlp_dim, dim_head=opt.dim_head, heads=opt.heads,
+                                       dropout=opt.dropout)
+    optim = torch.optim.AdamW(model.parameters(), lr=opt.lr, betas=(0.9, 0.999), weight_decay=opt.weight_decay, amsgrad=False)
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(optim, opt.max_steps)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sched = R['warm'].GradualWarmupScheduler(optim, multiplier=1.0, total_epoch=opt.warmup, after_scheduler=cos)
+        ema = ModelEmaV2(model, decay=opt.ema_decay)
+        zb = torch.randint(0, chk.num_embeddings + 1, (2, 3, 4, 4))
+        for g_ in optim.param_groups:
+            g_['lr'] = 1e-2                                        # warm-up starts at lr 0: force a visible step
+        y = model(zb)
+        torch.nn.functional.cross_entropy(y.reshape(-1, chk.num_embeddings), torch.randint(0, chk.num_embeddings, (32,))).backward()
+        optim.step()
+        sched.step()
+        ema.update(model)
+    torch.save({'step': 1, 'lr': sched.get_last_lr(), 'model_state_dict': model.state_dict(),
+                'ema_model_state_dict': ema.module.state_dict(), 'optimizer_state_dict': optim.state_dict(), 'opt': opt},
+               os.path.join(HERE, 'ckpt_denoiser_tiny.pth'))
+    for f in ('ckpt_vqae_tiny.pth', 'ckpt_denoiser_tiny.pth'):
+        print(f'{f}: {os.path.getsize(os.path.join(HERE, f)) / 1024:.1f} KB')
+    # ---- what a user of main.py gets back from the two files (fresh objects, like a new process)
+    dec2 = TV.VqAutoEncoder(chk.embedding_dim, chk.num_embeddings, chk.downscale_steps, hidden_planes=chk.hidden_planes, in_channels=1)
+    dec2.load_state_dict(torch.load(os.path.join(HERE, 'ckpt_vqae_tiny.pth'), map_location='cpu', weights_only=False)['model_state_dict'])
+    frames = torch.rand(2 * 3, 1, 16, 16)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        tokens = dec2.encode(frames).view(2, 3, 4, 4)              # train-mode BatchNorm, as main.py runs it (Q3)
+        recon = dec2.decode(tokens.view(-1, 4, 4))
+        logits = model(tokens)
+        logits_ema = ema.module(tokens)
+    npz('ckpt_tiny_expect', frames=frames, tokens=tokens, recon=recon, logits=logits, logits_ema=logits_ema,
+        data_shape=np.array(tuple(z.shape)))
+
+
 def gen_sparse(ref_root):
     SD = import_sparse(ref_root)
     torch.manual_seed(800)
@@ -378,7 +533,7 @@ def main():
     torch.set_num_threads(1)          # fixed reduction partitioning for reproducible fixtures
     R = import_reference(a.ref)
     gens = dict(attn_core=gen_attn_core, attn_module=gen_attn_module, transformer=gen_transformer, vq=gen_vq,
-                vq_forward=gen_vq_forward, ae=gen_ae, step=gen_step)
+                vq_forward=gen_vq_forward, ae=gen_ae, step=gen_step, sampler=gen_sampler, checkpoint=gen_checkpoint)
     for name, fn in gens.items():
         if a.only and a.only != name:
             continue

@@ -253,21 +253,31 @@ def test_library_refuses_cpu_tensors(ops):
     ((1, 6, 16, 16), 1, 128, (5, 0, 7)),       # wide column window, single row
 ])
 def test_attention_row16_fast_path(ops, shape, heads, dh, ext):
-    """bf16, W == 16 takes attn_fwd_row16.hip (padded LDS rows, bias masks, deferred max): against the oracle and
-    against the general kernel (forced by asking for the logits probe).  out within 1e-2 rel of the fp32 oracle
-    (P is bf16 for the PV MFMA), the two kernels within 4e-3 of each other, lse within 1e-4."""
+    """bf16, W == 16 takes attn_fwd_row16.hip -- the kernel bench.py times.  Probed directly (its own logits dump, not the
+    general kernel's): scaled logits <= 1e-3 rel against the fp32 oracle on the same bf16 inputs (north_star bar; measured
+    ~1e-6, bf16 products are exact in the fp32 accumulator), masked slots the literal -1e9, lse <= 1e-4, out <= 3e-3 rel
+    (P and the output are rounded to bf16: 2^-9 per element), and against the general kernel."""
     torch.manual_seed(21)
     B, S, H, W = shape
     I = heads * dh
     q, k, v = (torch.randn(B, S, H, W, I).bfloat16() for _ in range(3))
     ref, ref_logits = oat.local_attention(k.float(), v.float(), q.float(), ext, heads, return_logits=True)
-    fast, lse_f, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True)
-    gen, lse_g, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True, logits_dbg=True)
-    assert rel(fast, ref) < 1e-2
-    assert rel(fast, gen) < 4e-3
+    fast, lse_f, dbg = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True, logits_dbg=True)
+    plain, _, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads)        # the un-probed instantiation
+    gen, lse_g, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True, general=True)
+    assert torch.equal(fast, plain)
+    logits = dbg.cpu().reshape(ref_logits.shape)
+    live = ref_logits != -1e9
+    assert torch.equal(logits == -1e9, ~live)
+    err = float((logits[live] - ref_logits[live]).abs().max() / ref_logits[live].abs().max())
+    assert err < 1e-3 and rel(logits[live], ref_logits[live]) < 1e-3, err
+    e_out, e_gen = rel(fast, ref), rel(fast, gen)
+    print(f'[row16 {shape} {ext}] logits max err {err:.1e}, out vs oracle {e_out:.2e}, vs general kernel {e_gen:.2e}')
+    assert e_out < 3e-3
+    assert e_gen < 3e-3
     lse_ref = torch.logsumexp(ref_logits, -1).reshape(-1, heads)
     assert torch.allclose(lse_f.cpu(), lse_ref, rtol=1e-4, atol=1e-4)
-    assert torch.allclose(lse_f.cpu(), lse_g.cpu(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(lse_f.cpu(), lse_g.cpu(), rtol=1e-5, atol=2e-5)
 
 
 def test_attention_row16_deferred_max_branch(ops):
@@ -283,9 +293,16 @@ def test_attention_row16_deferred_max_branch(ops):
     ref = oat.local_attention(k.float(), v.float(), q.float(), (3, 3, 3), 1)
     out, _, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), (3, 3, 3), 1)
     assert torch.isfinite(out).all()
-    assert rel(out, ref) < 1e-2
+    assert rel(out, ref) < 3e-3
     for pos in [(0, 4, 13, 13), (0, 3, 8, 8)]:
-        assert rel(out[pos], ref[pos]) < 2e-2
+        assert rel(out[pos], ref[pos]) < 1e-2
+    # very negative logits everywhere (the first step must SET the running max, not assume 0): q . k ~ -3000 / sqrt(128)
+    qn = torch.full((1, 3, 16, 16, 128), 5.0).bfloat16()
+    kn = (-torch.full((1, 3, 16, 16, 128), 5.0) + 0.05 * torch.randn(1, 3, 16, 16, 128)).bfloat16()
+    vn = torch.randn(1, 3, 16, 16, 128).bfloat16()
+    refn = oat.local_attention(kn.float(), vn.float(), qn.float(), (1, 1, 1), 1)
+    outn, lsen, _ = ops.local3d_attention_fwd(dev(qn), dev(kn), dev(vn), (1, 1, 1), 1, need_lse=True)
+    assert torch.isfinite(outn).all() and torch.isfinite(lsen).all() and rel(outn, refn) < 5e-3
 
 
 def test_attention_full_size_properties(ops):

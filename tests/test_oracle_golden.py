@@ -214,3 +214,21 @@ def test_vq_distance_summation_order(E):
     torch.manual_seed(E)
     x, emb = torch.randn(37, E), torch.randn(1, 29, E)
     assert torch.equal(ovq.distances_avx_order(x, emb), ovq.distances(x, emb))
+
+
+@pytest.mark.parametrize('name', ['sampler_tiny', 'sampler_tiny_topk'])
+def test_sampler_loop_vs_reference_capture(name):
+    """oracle.sampler.evaluate_tokens == the reference's evaluate_model (main.py:50-117) run with the same injected
+    uniform fields: every last frame fed to the model and every generated frame, token for token."""
+    from oracle import sampler as osamp
+    g = load_golden(name)
+    sd = sub(g, 'model/')
+    ext, heads, C = tuple(int(e) for e in g['extents']), int(g['heads']), int(g['num_embeddings'])
+    frames, z_final, fed = osamp.evaluate_tokens(lambda z: oden.denoiser_forward(sd, z, ext, heads), g['z0'], C,
+                                                 g['tokens'].shape[0], g['u_multi'], g['u_mask'], sample_topk=int(g['topk']))
+    assert torch.equal(torch.stack(fed), g['fed'])
+    assert torch.equal(torch.stack(frames), g['tokens'])
+    assert float(g['margin']) > 2e-5                       # every categorical draw sits clear of a CDF step
+    # the frames shift by one per generated frame (:115): [c0, c1, *] -> [c1, f1, f1] -> [f1, f2, f2]
+    assert torch.equal(z_final[:, 0], frames[0]) and torch.equal(z_final[:, 1], frames[1])
+    assert torch.equal(z_final[:, 2], frames[1])

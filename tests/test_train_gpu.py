@@ -106,6 +106,40 @@ def test_sampler_loop_runs_and_unmasks(wmz):
     assert int(torch.isfinite(tk).sum()) == 18
 
 
+@pytest.mark.parametrize('name', ['sampler_tiny', 'sampler_tiny_topk'])
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_sampler_loop_token_for_token_vs_reference(wmz, name, use_graph):
+    """evaluate_model (main.py:50-117) captured from the reference with injected uniforms: the GPU sampler must feed the
+    model the same last frame in each of the 2 x 30 iterations and generate the same frames, token for token; the decoded
+    images follow through the (train-mode BatchNorm, quirk Q3) VQ-AE decoder."""
+    from world_modelz_amd import sample
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    g = load_golden(name)
+    C = int(g['num_embeddings'])
+    sd = sub(g, 'model/')
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 4, 4), dim=16, num_classes=C, extents=tuple(int(e) for e in g['extents']),
+                                          depth=2, dim_head=8, mlp_dim=24, heads=int(g['heads']))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    trace = []
+    with wmz['config'].compute_dtype(torch.float32):
+        frames, zf = sample.sample_frames(m, g['z0'].cuda(), C, num_frames=g['tokens'].shape[0], sample_topk=int(g['topk']),
+                                          uniforms=(g['u_multi'], g['u_mask']), use_graph=use_graph, trace=trace)
+    fed = torch.stack(trace).cpu()
+    first_bad = (fed != g['fed']).flatten(1).any(1).nonzero()
+    assert torch.equal(fed, g['fed']), f'first differing iteration: {int(first_bad[0]) if len(first_bad) else None}'
+    assert torch.equal(torch.stack(frames).cpu(), g['tokens'])
+    assert torch.equal(zf[:, 0].cpu(), g['tokens'][0]) and torch.equal(zf[:, 1].cpu(), g['tokens'][1])
+    # decode like evaluate_model does (:113): the reference's decoder ran in train mode on ae state 'ae0' -> encode of the
+    # context mutated the encoder's BN statistics only; the decoder's BN statistics are batch statistics either way
+    ae = VqAutoEncoder(embedding_dim=8, num_embeddings=C, downscale_steps=2, hidden_planes=8, in_channels=1)
+    ae.load_state_dict(sub(g, 'ae0/'), strict=True)
+    ae = ae.cuda().train()
+    with wmz['config'].compute_dtype(torch.float32), torch.no_grad():
+        img = torch.cat([ae.decode(f) for f in frames], 0)
+    assert rel(img, g['images'][2:]) < 1e-5
+
+
 def test_fused_cross_entropy_vs_torch(wmz):
     tr = wmz['train']
     torch.manual_seed(5)

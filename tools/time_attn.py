@@ -1,12 +1,24 @@
-import sys, torch
+"""Per-launch time of the 16-wide-plane attention forward at config-4 shapes (graph of 50 launches).
+WMZ_ATTN_VARIANTS="0,10,11": development A/B between kernel instantiations (wmz_debug_attn_knobs)."""
+import os, sys, torch
 sys.path.insert(0, '.')
-from world_modelz_amd import ops
+from world_modelz_amd import ops, _lib as L
+torch.manual_seed(0)
 qkv = torch.randn(8, 32, 16, 16, 384, device='cuda').bfloat16()
 q, k, v = qkv[..., :128], qkv[..., 128:256], qkv[..., 256:]
-for _ in range(5): ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(50): ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1)
-e1.record(); torch.cuda.synchronize()
-print('attn fwd us:', e0.elapsed_time(e1) * 1000 / 50)
+ext = tuple(int(e) for e in os.environ.get('WMZ_EXT', '3,3,3').split(','))
+for var in [int(x) for x in os.environ.get('WMZ_ATTN_VARIANTS', '0').split(',')]:
+    L.call('wmz_debug_attn_knobs', 0, var)
+    for _ in range(5): ops.local3d_attention_fwd(q, k, v, ext, 1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(50): ops.local3d_attention_fwd(q, k, v, ext, 1)
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1000 / 50)
+    print(f'attn fwd variant {var} ext {ext}: {best:.2f} us per launch', flush=True)
+L.call('wmz_debug_attn_knobs', 0, 0)

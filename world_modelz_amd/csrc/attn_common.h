@@ -19,6 +19,7 @@ struct AttnGeom {
   float scale;   // dh^-0.5
   int qs0, Sq;   // query planes [qs0, qs0+Sq) only; out / lse are compact [B, Sq, H, W, ..] (forward; full grid: 0, S)
   int dbg;       // ablation switches for timing experiments: 1 = skip the per-tile compute, 2 = skip the K/V staging
+  int variant;   // development A/B switch between kernel instantiations (wmz_debug_attn_knobs); 0 = product default
 };
 
 struct TileInfo { int hlo, hhi, wlo, whi; };

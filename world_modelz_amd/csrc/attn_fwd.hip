@@ -252,29 +252,40 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
 }  // namespace
 
 // fast path for 16-wide planes (attn_fwd_row16.hip)
-int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, const AttnGeom& G,
-                                hipStream_t st);
+int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
+                                const AttnGeom& G, hipStream_t st);
+
+// development knobs (wmz_debug_attn_knobs): ablation switches and kernel-variant selector, 0 / 0 in production
+static int g_attn_dbg = 0, g_attn_variant = 0;
+extern "C" int wmz_debug_attn_knobs(int dbg, int variant) { g_attn_dbg = dbg; g_attn_variant = variant; return WMZ_OK; }
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse, float* logits_dbg, int B, int S,
                          int H, int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
-                         int q_plane0, int q_planes, int dtype, void* stream);
+                         int q_plane0, int q_planes, int dtype, void* stream, bool general);
 
 extern "C" int wmz_local3d_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                                     float* logits_dbg, int B, int S, int H, int W, int heads, int dh, int eS, int eH,
                                     int eW, long ldq, long ldk, long ldv, long ldo, int dtype, void* stream) {
-  return attn_fwd_impl(q, k, v, out, lse, logits_dbg, B, S, H, W, heads, dh, eS, eH, eW, ldq, ldk, ldv, ldo, 0, S, dtype, stream);
+  return attn_fwd_impl(q, k, v, out, lse, logits_dbg, B, S, H, W, heads, dh, eS, eH, eW, ldq, ldk, ldv, ldo, 0, S, dtype, stream, false);
+}
+
+// Same contract, always on the general kernel (any W, fp32 or bf16): the parity tests compare the fast path with it.
+extern "C" int wmz_local3d_attn_fwd_general(const void* q, const void* k, const void* v, void* out, float* lse,
+                                            float* logits_dbg, int B, int S, int H, int W, int heads, int dh, int eS, int eH,
+                                            int eW, long ldq, long ldk, long ldv, long ldo, int dtype, void* stream) {
+  return attn_fwd_impl(q, k, v, out, lse, logits_dbg, B, S, H, W, heads, dh, eS, eH, eW, ldq, ldk, ldv, ldo, 0, S, dtype, stream, true);
 }
 
 extern "C" int wmz_local3d_attn_fwd_planes(const void* q, const void* k, const void* v, void* out, float* lse, int B, int S,
                                            int H, int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk,
                                            long ldv, long ldo, int q_plane0, int q_planes, int dtype, void* stream) {
   return attn_fwd_impl(q, k, v, out, lse, nullptr, B, S, H, W, heads, dh, eS, eH, eW, ldq, ldk, ldv, ldo, q_plane0, q_planes,
-                       dtype, stream);
+                       dtype, stream, false);
 }
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse, float* logits_dbg, int B, int S,
                          int H, int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
-                         int q_plane0, int q_planes, int dtype, void* stream) {
+                         int q_plane0, int q_planes, int dtype, void* stream, bool general) {
   WMZ_REQUIRE(q && k && v && out, "wmz_local3d_attn_fwd: null tensor");
   WMZ_REQUIRE(q_plane0 >= 0 && q_planes > 0 && q_plane0 + q_planes <= S, "wmz_local3d_attn_fwd: query planes [%d, %d) outside [0, %d)", q_plane0, q_plane0 + q_planes, S);
   WMZ_REQUIRE(logits_dbg == nullptr || q_planes == S, "wmz_local3d_attn_fwd: the logits probe needs the full grid");
@@ -291,12 +302,11 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
   G.HW = H * W; G.tiles = (G.HW + 15) / 16; G.qgroups = 0;
   G.qs0 = q_plane0; G.Sq = q_planes;
   G.scale = 1.0f / sqrtf((float)dh);
-  static const int dbg_env = getenv("WMZ_ATTN_DBG") ? atoi(getenv("WMZ_ATTN_DBG")) : 0;
-  G.dbg = dbg_env;
+  G.dbg = g_attn_dbg;
+  G.variant = g_attn_variant;
   hipStream_t st = (hipStream_t)stream;
-  static const bool no_fast = getenv("WMZ_ATTN_GENERAL") != nullptr;   // force the general kernel (A/B timing, tests)
-  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && logits_dbg == nullptr && !no_fast)
-    return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, G, st);
+  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !general)
+    return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G, st);
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {
     if (DHp == 32) return launch<bf16_t, 32, 1, 8, 16>(q, k, v, out, lse, logits_dbg, G, st);

@@ -28,8 +28,9 @@ def _rows(t):
     return t, flat.shape[0], C
 
 
-def local3d_attention_fwd(q, k, v, extents, heads, need_lse=False, logits_dbg=False):
-    """q, k, v: [B,S,H,W,heads*dh] (last dim contiguous, uniform row stride).  Returns (out, lse, logits)."""
+def local3d_attention_fwd(q, k, v, extents, heads, need_lse=False, logits_dbg=False, general=False):
+    """q, k, v: [B,S,H,W,heads*dh] (last dim contiguous, uniform row stride).  Returns (out, lse, logits).
+    general: take the general kernel even where the 16-wide-plane fast path applies (parity tests)."""
     B, S, H, W, I = q.shape
     dh = I // heads
     dt = L.dtype_code(q.dtype)
@@ -45,7 +46,8 @@ def local3d_attention_fwd(q, k, v, extents, heads, need_lse=False, logits_dbg=Fa
         dbg = torch.full((N, heads, K), -1e9, dtype=torch.float32, device=q.device)
     if _profile_hook is not None:
         _profile_hook('wmz_local3d_attn_fwd', True)
-    L.call('wmz_local3d_attn_fwd', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dbg),
+    L.call('wmz_local3d_attn_fwd_general' if general else 'wmz_local3d_attn_fwd', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out),
+           L.ptr(lse), L.ptr(dbg),
            B, S, H, W, heads, dh, int(extents[0]), int(extents[1]), int(extents[2]), ldq, ldk, ldv, I, dt, L.stream())
     if _profile_hook is not None:
         _profile_hook('wmz_local3d_attn_fwd', False)

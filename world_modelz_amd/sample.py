@@ -18,11 +18,25 @@ def top_k_logits(logits, k):
     return logits.masked_fill(logits < v[:, [-1]], -float('inf'))
 
 
+def categorical_from_uniform(p, u):
+    """Inverse-CDF categorical draw: the first class whose cumulative weight exceeds u * total (u in [0, 1), one per row).
+    This is the definition the sampler-parity fixtures are captured with (torch.multinomial replaced by it inside the
+    reference's evaluate_model, tests/golden/make_golden.py), so with the same uniforms the draws are the reference's."""
+    cdf = p.cumsum(dim=-1)
+    x = (u.to(cdf.dtype) * cdf[:, -1]).unsqueeze(-1)
+    return (cdf <= x).sum(dim=-1).clamp(max=p.shape[-1] - 1)
+
+
 @torch.no_grad()
 def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iterations=30, sample_topk=-1, noise_schedule=None,
-                  consistent_masking=False, generator=None, use_graph=True):
+                  consistent_masking=False, generator=None, use_graph=True, uniforms=None, trace=None):
     """batch_z: int64 [B,S,H,W] context tokens on the GPU (the last frame is overwritten).  Returns the list of generated
-    latent frames [B,H,W] (decode them with VqAutoEncoder.decode) and the final batch_z."""
+    latent frames [B,H,W] (decode them with VqAutoEncoder.decode) and the final batch_z.
+
+    uniforms = (u_multi [num_frames, num_eval_iterations, B*H*W], u_mask [num_frames, num_eval_iterations, B, H*W]):
+    injected randomness -- the categorical draw becomes categorical_from_uniform and the re-mask field u_mask > alpha
+    (main.py:85, :97-100), which makes the loop a deterministic function of its inputs (parity tests); default: device RNG.
+    trace: optional list that receives every last frame fed to the model."""
     assert batch_z.is_cuda
     B, S, H, W = batch_z.shape
     mask_token = num_embeddings
@@ -30,23 +44,32 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
     batch_z[:, -1] = mask_token                                   # destroy all information in the last frame (:62)
     fwd = GraphedForward(model, batch_z) if use_graph else None
     dev = batch_z.device
+    if uniforms is not None:
+        u_multi, u_mask = (t.to(dev) for t in uniforms)
+        assert u_multi.shape[:2] == (num_frames, num_eval_iterations) and u_mask.shape[:2] == (num_frames, num_eval_iterations)
     out = []
-    for _ in range(num_frames):
+    for f in range(num_frames):
         logits = torch.zeros(B * H * W, num_embeddings, device=dev)      # flat start (:71)
         last_mask = torch.ones(B, H * W, dtype=torch.bool, device=dev)
         for i in range(num_eval_iterations):
             if sample_topk > 0:
                 logits = top_k_logits(logits, sample_topk)
             p = F.softmax(logits, dim=-1)
-            denoised = torch.multinomial(p, 1, True, generator=generator).view(B, H * W)
+            if uniforms is not None:
+                denoised = categorical_from_uniform(p, u_multi[f, i].reshape(-1)).view(B, H * W)
+            else:
+                denoised = torch.multinomial(p, 1, True, generator=generator).view(B, H * W)
             frac = (i + 1) / num_eval_iterations
             alpha = min(max(noise_schedule(frac) if noise_schedule is not None else frac, 0.0), 1.0)
-            mask = torch.rand(B, H * W, device=dev, generator=generator) > alpha
+            u = u_mask[f, i].view(B, H * W) if uniforms is not None else torch.rand(B, H * W, device=dev, generator=generator)
+            mask = u > alpha
             if consistent_masking:
                 mask = last_mask & mask
                 last_mask = mask
             frame = torch.where(mask, torch.full_like(denoised, mask_token), denoised)
             batch_z[:, -1] = frame.view(B, H, W)
+            if trace is not None:
+                trace.append(frame.view(B, H, W).clone())
             logits = (fwd(batch_z) if fwd is not None else model(batch_z)).reshape(B * H * W, num_embeddings).float()
         out.append(denoised.view(B, H, W).clone())
         batch_z[:, :-1] = batch_z[:, 1:].clone()                  # shift frames (:115)
