@@ -63,13 +63,15 @@ __device__ __forceinline__ unsigned piece_voff(int piece, int lane, unsigned ld_
   return (unsigned)((prow << 4) + (r & 15)) * ld_bytes + (unsigned)c * 16u;
 }
 
-template <int DH, int SPLIT, bool ALIGNED, bool PROBE, bool TS>
+template <int DH, int MODE, bool ALIGNED, bool PROBE, bool TS>
 __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                   const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                   float* __restrict__ LSE, float* __restrict__ DBG,
                                                                   AttnGeom G, long long* ts) {
   using I = Img<DH>;
   constexpr int KS = DH / 32, MT = DH / 16;
+  constexpr int SPLIT = MODE & 3;                        // where the LDS-DMA pieces of the next slab are issued
+  constexpr bool EPI16 = (MODE & 4) != 0;                // 16-byte output stores (lane pairs swap halves)
   __shared__ __attribute__((aligned(1024))) char smem[NBUF * I::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,16 +101,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
 
   Frag8<bf16_t> qf[KS];
   f32x4 o[MT];
-  {
-    const bf16_t* qrow = Q + (plane_q + (act ? hq : 0) * 16 + li) * G.ldq + (long)head * DH;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      frag_zero(qf[ks]);
-      if (act) frag_load(qf[ks], qrow + ks * 32 + g * 8);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) o[mt] = (f32x4)(0.f);
-  }
+  for (int mt = 0; mt < MT; ++mt) o[mt] = (f32x4)(0.f);
   float m_run = 0.f, l_run = 0.f;                        // m_run: log2 units of the scaled logits; set by the first step
   bool first = true;
 
@@ -201,6 +195,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
     issue_k(C0{}); issue_k(C1{}); issue_k(C2{});
     issue_v(C0{}); issue_v(C1{}); issue_v(C2{});
   }
+  {
+    // Q after the first slab's requests: both are in flight together (rows past the plane load a valid row, never stored)
+    const bf16_t* qrow = Q + (plane_q + (act ? hq : 0) * 16 + li) * G.ldq + (long)head * DH;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) frag_load(qf[ks], qrow + ks * 32 + g * 8);
+  }
   WMZ_ATS(2);
   for (int j = 0; j < nslab; ++j) {
     const int pl = j / nch, rem = j - pl * nch;
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
       if constexpr (SPLIT == 0) { issue_k(C1{}); issue_k(C2{}); issue_v(C0{}); issue_v(C1{}); issue_v(C2{}); k1 = v1 = k2 = v2 = v0 = false; }
       if constexpr (SPLIT == 1) { issue_k(C1{}); issue_k(C2{}); k1 = k2 = false; }
       if constexpr (SPLIT == 2) { issue_v(C0{}); v0 = false; }
+      if constexpr (SPLIT == 3) { issue_k(C1{}); issue_k(C2{}); issue_v(C0{}); k1 = k2 = v0 = false; }
     }
     if (j < 15) WMZ_ATS(5 + 4 * j);
     const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
           x0[mt] = ds_read_tr16_asm<mt * 32>(va0);
           x1[mt] = ds_read_tr16_asm<mt * 32>(va1);
         });
-        if constexpr (SPLIT >= 1) { if (v0) { issue_v(C0{}); v0 = false; } }
+        if constexpr (SPLIT == 1 || SPLIT == 2) { if (v0) { issue_v(C0{}); v0 = false; } }
         if constexpr (SPLIT == 2) { if (k1) { issue_k(C1{}); k1 = false; } }
+        if constexpr (SPLIT == 3) { if (v1) { issue_v(C1{}); v1 = false; } }
         if constexpr (PROBE) {
           const int kw = (2 * G.eW + 1), kh = (2 * G.eH + 1);
           const long qn = plane_o + hq * 16 + li;
@@ -277,7 +279,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
         l_run += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         Frag8<bf16_t> pf;
         frag_from_f32<bf16_t>(pf, p);
-        if constexpr (SPLIT >= 1) { if (v1) { issue_v(C1{}); v1 = false; } }
+        if constexpr (SPLIT == 1 || SPLIT == 2) { if (v1) { issue_v(C1{}); v1 = false; } }
+        if constexpr (SPLIT == 3) { if (v2) { issue_v(C2{}); v2 = false; } }
         // ---- O^T += V^T P^T
         ds_tr_wait();
 #pragma unroll
@@ -351,12 +354,30 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
     float l = wave_groups_sum(l_run);
     const float inv = 1.f / l;
     bf16_t* orow = O + (plane_o + hq * 16 + li) * G.ldo + (long)head * DH;
+    if constexpr (EPI16) {
+      // lane (g, li) holds dh 16 mt + 4g .. +3 of query li; lanes g and g ^ 1 swap halves of an (mt, mt + 1) pair, so that the
+      // even lane owns dh 16 mt + 4g .. +7 and the odd lane dh 16 (mt + 1) + 4 (g - 1) .. +7: one 16-byte store each
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      s16x4 pk;
+      for (int mt = 0; mt < MT; mt += 2) {
+        unsigned a0 = (unsigned)f32_to_bf16_bits(o[mt][0] * inv) | ((unsigned)f32_to_bf16_bits(o[mt][1] * inv) << 16);
+        unsigned a1 = (unsigned)f32_to_bf16_bits(o[mt][2] * inv) | ((unsigned)f32_to_bf16_bits(o[mt][3] * inv) << 16);
+        unsigned b0 = (unsigned)f32_to_bf16_bits(o[mt + 1][0] * inv) | ((unsigned)f32_to_bf16_bits(o[mt + 1][1] * inv) << 16);
+        unsigned b1 = (unsigned)f32_to_bf16_bits(o[mt + 1][2] * inv) | ((unsigned)f32_to_bf16_bits(o[mt + 1][3] * inv) << 16);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);     // odd rows of a <-> even rows of b
+        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+        i32x4 pk;
+        pk[0] = (int)s0[0]; pk[1] = (int)s1[0]; pk[2] = (int)s0[1]; pk[3] = (int)s1[1];
+        const int col = (g & 1) ? (mt + 1) * 16 + 4 * (g - 1) : mt * 16 + 4 * g;
+        *reinterpret_cast<i32x4*>(orow + col) = pk;
+      }
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(o[mt][r] * inv);
-      *reinterpret_cast<s16x4*>(orow + mt * 16 + 4 * g) = pk;
+      for (int mt = 0; mt < MT; ++mt) {
+        s16x4 pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(o[mt][r] * inv);
+        *reinterpret_cast<s16x4*>(orow + mt * 16 + 4 * g) = pk;
+      }
     }
     if (LSE != nullptr && g == 0) LSE[(plane_o + hq * 16 + li) * G.heads + head] = m_run * 0.6931471805599453f + logf(l);
   }
@@ -364,11 +385,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
 #undef WMZ_ATS
 }
 
-template <int DH, int SPLIT, bool ALIGNED, bool PROBE, bool TS>
+template <int DH, int MODE, bool ALIGNED, bool PROBE, bool TS>
 int launch_row16(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg, AttnGeom G, hipStream_t st) {
   G.qgroups = wmz_cdiv(G.H, NW);
   const long nwg = (long)G.B * G.heads * G.Sq * G.qgroups;
-  hipLaunchKernelGGL((attn_fwd_row16_kernel<DH, SPLIT, ALIGNED, PROBE, TS>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, (const bf16_t*)q,
+  hipLaunchKernelGGL((attn_fwd_row16_kernel<DH, MODE, ALIGNED, PROBE, TS>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, (const bf16_t*)q,
                      (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, dbg, G, g_attn_ts);
   WMZ_LAUNCH_CHECK("wmz_local3d_attn_fwd(row16)");
   return WMZ_OK;
@@ -392,17 +413,19 @@ int by_dh(const void* q, const void* k, const void* v, void* out, float* lse, fl
 // instantiation, which carries no stamp code at all.
 extern "C" int wmz_debug_attn_timestamps(void* buf) { g_attn_ts = (long long*)buf; return WMZ_OK; }
 
-#ifndef WMZ_ATTN_SPLIT
-#define WMZ_ATTN_SPLIT 2
+#ifndef WMZ_ATTN_MODE
+#define WMZ_ATTN_MODE 5          // K pieces right behind the barrier, V pieces inside the first step; 16-byte output stores
 #endif
 
 // Called by wmz_local3d_attn_fwd when the shape qualifies (bf16, W == 16, dim_head in {32,64,128}).  dbg: optional logits
 // probe [N, heads, window] (natural-log-domain scaled logits of the in-window slots, pre-filled with -1e9 by the caller).
 int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
                                 const AttnGeom& G, hipStream_t st) {
-  if (dbg != nullptr) return by_dh<WMZ_ATTN_SPLIT, true, false>(q, k, v, out, lse, dbg, G, st);
-  if (g_attn_ts != nullptr) return by_dh<WMZ_ATTN_SPLIT, false, true>(q, k, v, out, lse, nullptr, G, st);
+  if (dbg != nullptr) return by_dh<WMZ_ATTN_MODE, true, false>(q, k, v, out, lse, dbg, G, st);
+  if (g_attn_ts != nullptr) return by_dh<WMZ_ATTN_MODE, false, true>(q, k, v, out, lse, nullptr, G, st);
   if (G.variant == 10) return by_dh<0, false, false>(q, k, v, out, lse, nullptr, G, st);
-  if (G.variant == 11) return by_dh<1, false, false>(q, k, v, out, lse, nullptr, G, st);
-  return by_dh<WMZ_ATTN_SPLIT, false, false>(q, k, v, out, lse, nullptr, G, st);
+  if (G.variant == 12) return by_dh<2, false, false>(q, k, v, out, lse, nullptr, G, st);
+  if (G.variant == 13) return by_dh<3, false, false>(q, k, v, out, lse, nullptr, G, st);
+  if (G.variant == 15) return by_dh<5, false, false>(q, k, v, out, lse, nullptr, G, st);
+  return by_dh<WMZ_ATTN_MODE, false, false>(q, k, v, out, lse, nullptr, G, st);
 }
