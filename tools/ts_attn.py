@@ -3,16 +3,24 @@ import sys, torch
 sys.path.insert(0, '.')
 from world_modelz_amd import ops, _lib as L
 torch.manual_seed(0)
+import os
 B, S = 8, 32
+DBG = int(os.environ.get('WMZ_DBG', '0'))
 qkv = torch.randn(B, S, 16, 16, 384, device='cuda').bfloat16()
 q, k, v = qkv[..., :128], qkv[..., 128:256], qkv[..., 256:]
 ts = torch.zeros(16 * 64, dtype=torch.int64, device='cuda')
 for _ in range(3): ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1)
+L.call('wmz_debug_attn_knobs', DBG, 0)
+for _ in range(300): ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1)
 L.call('wmz_debug_attn_timestamps', ts.data_ptr())
 ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1)
 torch.cuda.synchronize()
 L.call('wmz_debug_attn_timestamps', None)
 t = ts.cpu().view(16, 64)
+for w in (0, 8):
+    dc, dr = int(t[w, 62] - t[w, 0]), int(t[w, 61] - t[w, 60])
+    print(f'wave {w}: {dc} shader cycles in {dr} ticks of 100 MHz -> in-kernel clock {dc / max(dr, 1) * 0.1:.2f} GHz')
+t[:, 60:62] = 0
 names = {0: 'start', 1: 'q loaded/setup', 2: 'prime issued', 63: 'loop end', 62: 'stored'}
 for j in range(15):
     names[3 + 4 * j] = f'slab {j} vmcnt'; names[4 + 4 * j] = f'slab {j} barrier'; names[5 + 4 * j] = f'slab {j} issue'; names[6 + 4 * j] = f'slab {j} compute'

@@ -38,12 +38,29 @@ constexpr int NBUF = 2;               // LDS slab ring: one slab in flight
 constexpr float DEFER = 8.f;          // log2 units
 
 template <int DH> struct Img {
-  static constexpr int KROW = DH * 2 + 16, VROW = DH * 2 + 32;
+#ifndef WMZ_ATTN_KPAD
+#define WMZ_ATTN_KPAD 32
+#endif
+  static constexpr int KROW = DH * 2 + WMZ_ATTN_KPAD, VROW = DH * 2 + 32;
   static constexpr int KIMG = KC * 16 * KROW, VIMG = KC * 16 * VROW;
   static constexpr int BUF = KIMG + VIMG;
   static constexpr int PK = KIMG / 1024, PV = VIMG / 1024;            // 1 KB DMA pieces per image
   static constexpr int NPK = (PK + NW - 1) / NW, NPV = (PV + NW - 1) / NW;   // ... per wave
   static_assert(KIMG % 1024 == 0 && VIMG % 1024 == 0, "images must be whole 1 KB DMA pieces");
+};
+
+// Issue points of the next slab's LDS-DMA pieces inside a slab iteration: 0 = right behind the barrier, 1 = behind the
+// first step's QK^T MFMAs, 2 = behind its softmax, 3 = behind its PV MFMAs, 4 = after the wave's last step.  A wave has up
+// to three K pieces and three V pieces; whatever a wave without a (first) step has left goes out at point 4.
+constexpr int kSched[8][6] = {
+    {0, 0, 0, 0, 0, 0},   // 0: everything behind the barrier
+    {0, 0, 0, 1, 2, 4},   // 1: K behind the barrier, V spread over the first step
+    {0, 1, 3, 0, 2, 4},   // 2: one piece per point
+    {0, 0, 0, 0, 1, 2},   // 3
+    {1, 1, 1, 3, 3, 3},   // 4: K under the QK^T MFMAs, V under the PV MFMAs
+    {0, 1, 1, 1, 3, 3},   // 5
+    {0, 0, 0, 1, 1, 1},   // 6: K behind the barrier, V under the QK^T MFMAs
+    {0, 0, 1, 1, 3, 3},   // 7
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -70,14 +87,15 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
                                                                   AttnGeom G, long long* ts) {
   using I = Img<DH>;
   constexpr int KS = DH / 32, MT = DH / 16;
-  constexpr int SPLIT = MODE & 3;                        // where the LDS-DMA pieces of the next slab are issued
-  constexpr bool EPI16 = (MODE & 4) != 0;                // 16-byte output stores (lane pairs swap halves)
+  constexpr int SPLIT = MODE & 7;                        // where the LDS-DMA pieces of the next slab are issued (kSched)
+  constexpr bool EPI16 = (MODE & 8) != 0;                // 16-byte output stores (lane pairs swap halves)
   __shared__ __attribute__((aligned(1024))) char smem[NBUF * I::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
 #define WMZ_ATS(slot) do { if constexpr (TS) { if (blockIdx.x == 0 && lane == 0) ts[wave * 64 + (slot)] = __builtin_readcyclecounter(); } } while (0)
   WMZ_ATS(0);
+  if constexpr (TS) { if (blockIdx.x == 0 && lane == 0) ts[wave * 64 + 60] = __builtin_amdgcn_s_memrealtime(); }   // 100 MHz
 
   int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int og = lid % G.qgroups; lid /= G.qgroups;
@@ -128,19 +146,28 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
     for (int i = 0; i < I::NPV; ++i) vvo[i] = piece_voff<DH, I::VROW>(wave + NW * i, lane, ldv_b, 14);
   }
 
-  // scalar state of the slab being prefetched (set by slab_bases)
+  // Scalar state of the slab being prefetched.  It is advanced INCREMENTALLY (adds, one 32-bit multiply) and at the END of
+  // a slab iteration, in front of the barrier: right behind a barrier the scalar unit of the CU is shared by 16 waves, and
+  // ~55 scalar instructions of index arithmetic per wave there cost every wave ~1k cycles per slab.
+  const unsigned rsk = 16u * ldk_b, rsv = 16u * ldv_b;                   // bytes per plane row of 16 keys
+  const long psk = (long)HW * (long)ldk_b, psv = (long)HW * (long)ldv_b; // bytes per key plane
+  const char* kpl = (const char*)(K + ((long)b * G.S + sk_lo) * HW * G.ldk + (long)head * DH);   // next slab's key plane
+  const char* vpl = (const char*)(V + ((long)b * G.S + sk_lo) * HW * G.ldv + (long)head * DH);
+  int pl_n = 0, rem_n = 0, base_n = 0, jn = 0;                           // next slab: plane, slab in plane, first row, index
   const char* kp = nullptr;
   const char* vp = nullptr;
   char* dbuf = nullptr;
   int dlim = 14;
-  auto slab_bases = [&](int j) {
-    const int pl = j / nch, rem = j - pl * nch;
-    const int base = ((c_first + (rem >> 1)) << 4) + (rem & 1);
-    const long plane_k = ((long)b * G.S + (sk_lo + pl)) * HW;
-    kp = (const char*)(K + (plane_k + (long)base * 16) * G.ldk + (long)head * DH);
-    vp = (const char*)(V + (plane_k + (long)base * 16) * G.ldv + (long)head * DH);
-    dbuf = smem + (j % NBUF) * I::BUF;
-    dlim = max(H - 1 - base, 0);
+  auto next_state = [&]() {                                              // descriptors of slab (pl_n, rem_n)
+    base_n = ((c_first + (rem_n >> 1)) << 4) + (rem_n & 1);
+    kp = kpl + (unsigned)base_n * rsk;
+    vp = vpl + (unsigned)base_n * rsv;
+    dbuf = smem + (jn & 1) * I::BUF;
+    dlim = max(H - 1 - base_n, 0);
+  };
+  auto advance = [&]() {                                                 // step (pl_n, rem_n) to the following slab
+    ++jn;
+    if (++rem_n == nch) { rem_n = 0; ++pl_n; kpl += psk; vpl += psv; }
   };
   auto issue_k = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -167,6 +194,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
   using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
   static_assert(I::NPK <= 3 && I::NPV <= 3, "at most three pieces of each image per wave");
   const bool staging = !(G.dbg & 2);
 
@@ -190,8 +218,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   };
 
   WMZ_ATS(1);
+  next_state();
   if (nslab > 0 && staging) {
-    slab_bases(0);
     issue_k(C0{}); issue_k(C1{}); issue_k(C2{});
     issue_v(C0{}); issue_v(C1{}); issue_v(C2{});
   }
@@ -202,24 +230,28 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
     for (int ks = 0; ks < KS; ++ks) frag_load(qf[ks], qrow + ks * 32 + g * 8);
   }
   WMZ_ATS(2);
+  int pl = 0, base = base_n;                              // current slab: key plane, plane row of slab row 0 (slab row r <-> base + 2r)
+  advance();
+  next_state();                                          // slab 1's descriptors
   for (int j = 0; j < nslab; ++j) {
-    const int pl = j / nch, rem = j - pl * nch;
-    const int base = ((c_first + (rem >> 1)) << 4) + (rem & 1);   // plane row of slab row 0; slab row r <-> base + 2r
-    const char* Sb = smem + (j % NBUF) * I::BUF;           // this slab's K image, V image behind it
+    const char* Sb = smem + (j & 1) * I::BUF;              // this slab's K image, V image behind it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of slab j landed ...
     if (j < 15) WMZ_ATS(3 + 4 * j);
     __builtin_amdgcn_s_barrier();                        // ... everyone's did, and slab j-1 is retired: refill its slot
     if (j < 15) WMZ_ATS(4 + 4 * j);
     const bool more = j + 1 < nslab && staging;
-    bool k1 = more, v1 = more, k2 = more, v2 = more, v0 = more;          // pieces still to issue for slab j + 1
-    if (more) {
-      slab_bases(j + 1);
-      issue_k(C0{});
-      if constexpr (SPLIT == 0) { issue_k(C1{}); issue_k(C2{}); issue_v(C0{}); issue_v(C1{}); issue_v(C2{}); k1 = v1 = k2 = v2 = v0 = false; }
-      if constexpr (SPLIT == 1) { issue_k(C1{}); issue_k(C2{}); k1 = k2 = false; }
-      if constexpr (SPLIT == 2) { issue_v(C0{}); v0 = false; }
-      if constexpr (SPLIT == 3) { issue_k(C1{}); issue_k(C2{}); issue_v(C0{}); k1 = k2 = v0 = false; }
-    }
+    bool pend[6] = {more, more, more, more, more, more};                 // K0 K1 K2 V0 V1 V2 of slab j + 1 not requested yet
+    auto issue_at = [&](auto pc, bool flush) {
+      constexpr int pt = decltype(pc)::value;
+      static_for<6>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if ((flush || kSched[SPLIT][i] == pt) && pend[i]) {
+          if constexpr (i < 3) issue_k(std::integral_constant<int, i>{}); else issue_v(std::integral_constant<int, i - 3>{});
+          pend[i] = false;
+        }
+      });
+    };
+    issue_at(C0{}, false);
     if (j < 15) WMZ_ATS(5 + 4 * j);
     const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
     if (act && !(G.dbg & 1)) {
@@ -244,9 +276,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
           x0[mt] = ds_read_tr16_asm<mt * 32>(va0);
           x1[mt] = ds_read_tr16_asm<mt * 32>(va1);
         });
-        if constexpr (SPLIT == 1 || SPLIT == 2) { if (v0) { issue_v(C0{}); v0 = false; } }
-        if constexpr (SPLIT == 2) { if (k1) { issue_k(C1{}); k1 = false; } }
-        if constexpr (SPLIT == 3) { if (v1) { issue_v(C1{}); v1 = false; } }
+        issue_at(C1{}, false);
         if constexpr (PROBE) {
           const int kw = (2 * G.eW + 1), kh = (2 * G.eH + 1);
           const long qn = plane_o + hq * 16 + li;
@@ -279,8 +309,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
         l_run += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         Frag8<bf16_t> pf;
         frag_from_f32<bf16_t>(pf, p);
-        if constexpr (SPLIT == 1 || SPLIT == 2) { if (v1) { issue_v(C1{}); v1 = false; } }
-        if constexpr (SPLIT == 3) { if (v2) { issue_v(C2{}); v2 = false; } }
+        issue_at(C2{}, false);
         // ---- O^T += V^T P^T
         ds_tr_wait();
 #pragma unroll
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
           vf.v = __builtin_shufflevector(x0[mt], x1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
           mma16(o[mt], vf, pf);
         }
-        if constexpr (SPLIT == 2) { if (k2) { issue_k(C2{}); k2 = false; } }
+        issue_at(C3{}, false);
       }
       if (t0 <= hi) {
         // ---- odd last key row of the slab: a 16-key step
@@ -341,11 +370,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
       }
     }
     // whatever of slab j + 1 has not been requested yet
-    if (k1) issue_k(C1{});
-    if (k2) issue_k(C2{});
-    if (v0) issue_v(C0{});
-    if (v1) issue_v(C1{});
-    if (v2) issue_v(C2{});
+    issue_at(C3{}, true);
+    // the slab just requested becomes the current one; its successor's descriptors are worked out here, ahead of the barrier
+    pl = pl_n;
+    base = base_n;
+    advance();
+    next_state();
     if (j < 15) WMZ_ATS(6 + 4 * j);
   }
   WMZ_ATS(63);
@@ -382,6 +412,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
     if (LSE != nullptr && g == 0) LSE[(plane_o + hq * 16 + li) * G.heads + head] = m_run * 0.6931471805599453f + logf(l);
   }
   WMZ_ATS(62);
+  if constexpr (TS) { if (blockIdx.x == 0 && lane == 0) ts[wave * 64 + 61] = __builtin_amdgcn_s_memrealtime(); }
 #undef WMZ_ATS
 }
 
@@ -414,7 +445,7 @@ int by_dh(const void* q, const void* k, const void* v, void* out, float* lse, fl
 extern "C" int wmz_debug_attn_timestamps(void* buf) { g_attn_ts = (long long*)buf; return WMZ_OK; }
 
 #ifndef WMZ_ATTN_MODE
-#define WMZ_ATTN_MODE 5          // K pieces right behind the barrier, V pieces inside the first step; 16-byte output stores
+#define WMZ_ATTN_MODE 9          // kSched[1]: K pieces behind the barrier, V pieces inside the first step; 16-byte output stores
 #endif
 
 // Called by wmz_local3d_attn_fwd when the shape qualifies (bf16, W == 16, dim_head in {32,64,128}).  dbg: optional logits
@@ -423,9 +454,16 @@ int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, voi
                                 const AttnGeom& G, hipStream_t st) {
   if (dbg != nullptr) return by_dh<WMZ_ATTN_MODE, true, false>(q, k, v, out, lse, dbg, G, st);
   if (g_attn_ts != nullptr) return by_dh<WMZ_ATTN_MODE, false, true>(q, k, v, out, lse, nullptr, G, st);
-  if (G.variant == 10) return by_dh<0, false, false>(q, k, v, out, lse, nullptr, G, st);
-  if (G.variant == 12) return by_dh<2, false, false>(q, k, v, out, lse, nullptr, G, st);
-  if (G.variant == 13) return by_dh<3, false, false>(q, k, v, out, lse, nullptr, G, st);
-  if (G.variant == 15) return by_dh<5, false, false>(q, k, v, out, lse, nullptr, G, st);
+  switch (G.variant) {                                   // development A/B (wmz_debug_attn_knobs)
+    case 10: return by_dh<8 + 0, false, false>(q, k, v, out, lse, nullptr, G, st);
+    case 11: return by_dh<8 + 1, false, false>(q, k, v, out, lse, nullptr, G, st);
+    case 12: return by_dh<8 + 2, false, false>(q, k, v, out, lse, nullptr, G, st);
+    case 13: return by_dh<8 + 3, false, false>(q, k, v, out, lse, nullptr, G, st);
+    case 14: return by_dh<8 + 4, false, false>(q, k, v, out, lse, nullptr, G, st);
+    case 15: return by_dh<8 + 5, false, false>(q, k, v, out, lse, nullptr, G, st);
+    case 16: return by_dh<8 + 6, false, false>(q, k, v, out, lse, nullptr, G, st);
+    case 17: return by_dh<8 + 7, false, false>(q, k, v, out, lse, nullptr, G, st);
+    default: break;
+  }
   return by_dh<WMZ_ATTN_MODE, false, false>(q, k, v, out, lse, nullptr, G, st);
 }
