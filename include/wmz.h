@@ -82,6 +82,12 @@ int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, const float* b
                          const float* ln_mean, const float* ln_rstd, float ln_eps, int flags, int out_f32, int dtype,
                          void* stream);
 
+/* logit_proj on the LAST FRAME of every clip, read in place (main.py:35-36: x[:, -1] -> nn.Linear): C[M,N] = A' Wt^T + bias
+ * where row m of A' is A + (m / rows_per_block) * block_stride + (m % rows_per_block) * lda (elements); rows_per_block =
+ * H*W, block_stride = S*H*W*D selects the last plane of each clip of a [B,S,H,W,D] stream without a gather copy. */
+int wmz_linear_fwd_blocked(const void* A, long lda, int rows_per_block, long block_stride, const void* Wt,
+                           const float* bias, void* C, long ldc, int M, int N, int K, int out_f32, int dtype, void* stream);
+
 /* Weight / bias gradient of the family above: dW[N,K] += dC[M,N]^T . A'[M,K], dbias[N] += colsum(dC), where
  * A' = A, LayerNorm(A) (ln_* non-NULL; mean/rstd from wmz_layernorm_stats) or GELU(A) (gelu_in).  dW / dbias are fp32
  * and ACCUMULATED with float atomics (split over M): zero them first, or pass .grad buffers to accumulate. */

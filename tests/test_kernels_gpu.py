@@ -146,6 +146,28 @@ def test_linear_plain_bias_gelu_residual(ops, M, N, K, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,S,HW,D,N', [(8, 5, 256, 256, 1024), (3, 4, 20, 32, 50), (2, 1, 77, 64, 130)])
+def test_linear_on_last_frame_blocks(ops, dtype, B, S, HW, D, N):
+    """logit_proj on x[:, -1] read in place (wmz_linear_fwd_blocked, 64-row tiles for small M): equals the GEMM on a
+    gathered copy, and the reference expression on the strided view."""
+    torch.manual_seed(6)
+    x = torch.randn(B, S, HW, D).to(dtype)
+    w = (torch.randn(N, D) / D ** 0.5).to(dtype)
+    b = torch.randn(N)
+    xd = dev(x)
+    last = xd[:, -1]
+    assert S == 1 or not last.is_contiguous()
+    y = ops.linear_fwd_blocks(last, dev(w), dev(b), out_f32=True)
+    ref = x[:, -1].float() @ w.float().t() + b
+    assert y.dtype == torch.float32 and y.shape == (B, HW, N)
+    assert rel(y, ref) < (2e-6 if dtype == torch.float32 else 1e-5)
+    y2 = ops.linear_fwd(last.contiguous(), dev(w), bias=dev(b), out_f32=True)
+    assert torch.equal(y, y2)
+    yb = ops.linear_fwd_blocks(last, dev(w), dev(b))
+    assert yb.dtype == dtype and rel(yb, ref) < (2e-6 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_linear_layernorm_prologue(ops, dtype):
     torch.manual_seed(5)
     M, N, K = 333, 256, 256

@@ -9,6 +9,11 @@ from conftest import load_golden, sub
 pytestmark = pytest.mark.gpu
 
 
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
 @pytest.fixture(scope='module')
 def wmz():
     assert torch.cuda.is_available()

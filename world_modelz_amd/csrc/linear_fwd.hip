@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128, CPR = 8, NT = 256;
+constexpr int BN = 128, ROWB = 128, CPR = 8, NT = 256;
 
 struct LinParams {
   const void* A; long lda;
@@ -25,7 +25,16 @@ struct LinParams {
   const float* mean; const float* rstd;      // optional precomputed LayerNorm statistics (wmz_layernorm_stats)
   int flags, out_f32;
   int nbn;
+  int rpb; long bstride;                     // A rows in blocks: row m lives at A + (m / rpb) * bstride + (m % rpb) * lda (rpb 0: plain)
 };
+
+// address of A row m (blocked rows: the last frame of every clip, x[:, -1], read in place)
+template <typename T> __device__ __forceinline__ const T* a_row(const LinParams& P, int m) {
+  const T* A = reinterpret_cast<const T*>(P.A);
+  if (P.rpb == 0) return A + (long)m * P.lda;
+  const int blk = m / P.rpb;
+  return A + (long)blk * P.bstride + (long)(m - blk * P.rpb) * P.lda;
+}
 
 __device__ __forceinline__ int swz128(int r) { return ((r >> 1) << 4) & 112; }
 
@@ -59,9 +68,13 @@ template <> __device__ __forceinline__ i32x4 f32_to_chunk<bf16_t>(const float* f
 }
 
 // PRO: 0 = A as is, 1 = LayerNorm(A) over K, 2 = GELU(A) (FeedForward second GEMM reading the saved pre-activation)
-template <typename T, int PRO>
+// BM = 128: 4 waves as 2 x 2, each 64 x 64.  BM = 64 (small-M GEMMs that would otherwise leave CUs idle: the last-frame logits,
+// M = B*H*W): 4 waves side by side, each 64 rows x 32 columns; generic (per-lane) epilogue only.
+template <typename T, int PRO, int BM>
 __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   constexpr bool LN = PRO == 1;
+  constexpr int NJ = BM == 128 ? 2 : 1;      // 32-column MFMA blocks per wave
+  constexpr int AI = BM / 32;                // A rows per thread per slab
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = CPR * EPC;              // 64 (bf16) / 32 (f32)
   constexpr int KSTEPS = BK / 16;
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
       const int gm = m0 + r;
       float sum = 0.f;
       if (gm < P.M) {
-        const T* row = A + (long)gm * P.lda;
+        const T* row = a_row<T>(P, gm);
         for (int c = sub; c * EPC < K; c += 8) {
           float f[EPC];
           chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(row + c * EPC), f);
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
       const float mean = sum / (float)K;
       float sq = 0.f;
       if (gm < P.M) {
-        const T* row = A + (long)gm * P.lda;
+        const T* row = a_row<T>(P, gm);
         for (int c = sub; c * EPC < K; c += 8) {
           float f[EPC];
           chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(row + c * EPC), f);
@@ -121,28 +134,31 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 
   // this thread's 4 chunks of each slab: rows r_i = (tid>>3) + 32 i, chunk column cc = tid & 7
   const int cc = tid & 7, rr = tid >> 3;
-  i32x4 ra[4], rb[4];
+  i32x4 ra[AI], rb[4];
+  const T* arow[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) arow[i] = a_row<T>(P, min(m0 + rr + 32 * i, P.M - 1));
   auto fetch = [&](int k0) {
     const int k = k0 + cc * EPC;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rr + 32 * i;
-      ra[i] = (i32x4)(0);
+      if (i < AI) ra[i < AI ? i : 0] = (i32x4)(0);
       rb[i] = (i32x4)(0);
       if (k < K) {
-        if (m0 + r < P.M) ra[i] = *reinterpret_cast<const i32x4*>(A + (long)(m0 + r) * P.lda + k);
+        if (i < AI && m0 + r < P.M) ra[i < AI ? i : 0] = *reinterpret_cast<const i32x4*>(arow[i < AI ? i : 0] + k);
         if (n0 + r < P.N) rb[i] = *reinterpret_cast<const i32x4*>(Wt + (long)(n0 + r) * K + k);
       }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16)(0.f);
 
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int wr = BM == 128 ? (wave >> 1) * 64 : 0, wc = BM == 128 ? (wave & 1) * 64 : wave * 32;
   const int l31 = lane & 31, hh = lane >> 5;
 
   fetch(0);
@@ -152,7 +168,10 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rr + 32 * i;
-      i32x4 va = ra[i];
+      const int off = r * ROWB + ((cc << 4) ^ swz128(r));
+      *reinterpret_cast<i32x4*>(Bs + off) = rb[i];
+      if (i >= AI) continue;
+      i32x4 va = ra[i < AI ? i : 0];
       if constexpr (LN) {
         if (k < K) {
           float f[EPC];
@@ -169,15 +188,13 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
         for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
         va = f32_to_chunk<T>(f);
       }
-      const int off = r * ROWB + ((cc << 4) ^ swz128(r));
       *reinterpret_cast<i32x4*>(As + off) = va;
-      *reinterpret_cast<i32x4*>(Bs + off) = rb[i];
     }
     __syncthreads();
     if (k0 + BK < K) fetch(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
-      Frag8<T> af[2], bf[2];
+      Frag8<T> af[2], bf[NJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = wr + 32 * i + l31;
@@ -192,22 +209,24 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { af[i].v[e] = x[e]; af[i].v[4 + e] = y[e]; }
         }
-        const int rn = wc + 32 * i + l31;
-        const char* rowb = Bs + rn * ROWB;
-        const int swb = swz128(rn);
-        if constexpr (sizeof(T) == 2) {
-          bf[i].v = *reinterpret_cast<const s16x8*>(rowb + (b0 ^ swb));
-        } else {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(rowb + (b0 ^ swb));
-          const f32x4 y = *reinterpret_cast<const f32x4*>(rowb + ((b0 + 16) ^ swb));
+        if (i < NJ) {
+          const int rn = wc + 32 * i + l31;
+          const char* rowb = Bs + rn * ROWB;
+          const int swb = swz128(rn);
+          if constexpr (sizeof(T) == 2) {
+            bf[i < NJ ? i : 0].v = *reinterpret_cast<const s16x8*>(rowb + (b0 ^ swb));
+          } else {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(rowb + (b0 ^ swb));
+            const f32x4 y = *reinterpret_cast<const f32x4*>(rowb + ((b0 + 16) ^ swb));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bf[i].v[e] = x[e]; bf[i].v[4 + e] = y[e]; }
+            for (int e = 0; e < 4; ++e) { bf[i < NJ ? i : 0].v[e] = x[e]; bf[i < NJ ? i : 0].v[4 + e] = y[e]; }
+          }
         }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma32(acc[i][j], af[i], bf[j]);
+        for (int j = 0; j < NJ; ++j) mma32(acc[i][j], af[i], bf[j]);
     }
   }
 
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   const bool gelu = (P.flags & WMZ_LIN_GELU) != 0;
   const bool dgelu = (P.flags & WMZ_LIN_DGELU) != 0;
   const T* R = reinterpret_cast<const T*>(P.res);
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2 && BM == 128) {
     if (!P.out_f32 && (P.ldc % 8) == 0 && (R == nullptr || (P.ldr % 8) == 0)) {
       // 16-bit outputs: a lane owns ONE column, so direct stores would be 2 bytes each.  Stage the fp32 tile through LDS
       // (64 rows per round = the 32 KB the slabs occupied) and leave as whole 16-byte row chunks; the residual / gelu'
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int col = n0 + wc + 32 * j + l31;
       if (col >= P.N) continue;
       const float bv = P.bias ? P.bias[col] : 0.f;
@@ -316,6 +335,30 @@ extern "C" int wmz_linear_fwd(const void* A, long lda, const void* Wt, const flo
                               flags, out_f32, dtype, stream);
 }
 
+static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtype, hipStream_t st) {
+  const bool ln = ln_gamma != nullptr;
+  const bool gin = (flags & WMZ_LIN_GELU_IN) != 0;
+  WMZ_REQUIRE(!(ln && gin), "wmz_linear_fwd: LayerNorm and GELU prologues are exclusive");
+  P.nbn = wmz_cdiv(P.N, BN);
+  // small-M GEMMs with fp32 output (the last-frame logits: M = B*H*W): 64-row tiles, so that the grid covers the chip
+  const bool small = P.out_f32 && !ln && !gin && (long)wmz_cdiv(P.M, 128) * P.nbn < 192;
+  const int bm = small ? 64 : 128;
+  dim3 grid((unsigned)(wmz_cdiv(P.M, bm) * P.nbn)), block(NT);
+  if (dtype == WMZ_BF16) {
+    if (small) hipLaunchKernelGGL((linear_kernel<bf16_t, 0, 64>), grid, block, 0, st, P);
+    else if (ln) hipLaunchKernelGGL((linear_kernel<bf16_t, 1, 128>), grid, block, 0, st, P);
+    else if (gin) hipLaunchKernelGGL((linear_kernel<bf16_t, 2, 128>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((linear_kernel<bf16_t, 0, 128>), grid, block, 0, st, P);
+  } else {
+    if (small) hipLaunchKernelGGL((linear_kernel<float, 0, 64>), grid, block, 0, st, P);
+    else if (ln) hipLaunchKernelGGL((linear_kernel<float, 1, 128>), grid, block, 0, st, P);
+    else if (gin) hipLaunchKernelGGL((linear_kernel<float, 2, 128>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((linear_kernel<float, 0, 128>), grid, block, 0, st, P);
+  }
+  WMZ_LAUNCH_CHECK("wmz_linear_fwd");
+  return WMZ_OK;
+}
+
 extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
                                     long ldr, void* C, long ldc, int M, int N, int K, const float* ln_gamma,
                                     const float* ln_beta, const float* ln_mean, const float* ln_rstd, float ln_eps,
@@ -332,22 +375,24 @@ extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, con
   P.M = M; P.N = N; P.K = K; P.gamma = ln_gamma; P.beta = ln_beta; P.eps = ln_eps; P.flags = flags;
   P.mean = ln_mean; P.rstd = ln_rstd;
   P.out_f32 = out_f32;
-  const int nbm = wmz_cdiv(M, BM);
-  P.nbn = wmz_cdiv(N, BN);
-  dim3 grid((unsigned)(nbm * P.nbn)), block(NT);
-  hipStream_t st = (hipStream_t)stream;
-  const bool ln = ln_gamma != nullptr;
-  const bool gin = (flags & WMZ_LIN_GELU_IN) != 0;
-  WMZ_REQUIRE(!(ln && gin), "wmz_linear_fwd: LayerNorm and GELU prologues are exclusive");
-  if (dtype == WMZ_BF16) {
-    if (ln) hipLaunchKernelGGL((linear_kernel<bf16_t, 1>), grid, block, 0, st, P);
-    else if (gin) hipLaunchKernelGGL((linear_kernel<bf16_t, 2>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((linear_kernel<bf16_t, 0>), grid, block, 0, st, P);
-  } else {
-    if (ln) hipLaunchKernelGGL((linear_kernel<float, 1>), grid, block, 0, st, P);
-    else if (gin) hipLaunchKernelGGL((linear_kernel<float, 2>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((linear_kernel<float, 0>), grid, block, 0, st, P);
-  }
-  WMZ_LAUNCH_CHECK("wmz_linear_fwd");
-  return WMZ_OK;
+  P.rpb = 0; P.bstride = 0;
+  return linear_launch(P, ln_gamma, flags, dtype, (hipStream_t)stream);
+}
+
+// logit_proj on the LAST FRAME of every clip (main.py:35-36: x[:, -1] -> nn.Linear), read in place: A's rows come in blocks of
+// rows_per_block (= H*W) rows lda apart, the blocks block_stride apart (= S*H*W*D for the last plane of each clip).
+extern "C" int wmz_linear_fwd_blocked(const void* A, long lda, int rows_per_block, long block_stride, const void* Wt,
+                                      const float* bias, void* C, long ldc, int M, int N, int K, int out_f32, int dtype,
+                                      void* stream) {
+  WMZ_REQUIRE(A && Wt && C, "wmz_linear_fwd_blocked: null tensor");
+  WMZ_REQUIRE(M > 0 && N > 0 && K > 0 && rows_per_block > 0, "wmz_linear_fwd_blocked: bad shape M=%d N=%d K=%d rows_per_block=%d", M, N, K, rows_per_block);
+  WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0 && block_stride % 8 == 0, "wmz_linear_fwd_blocked: K, lda, block_stride must be multiples of 8");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd_blocked: bad dtype %d", dtype);
+  LinParams P;
+  P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = nullptr; P.ldr = 0; P.C = C; P.ldc = ldc;
+  P.M = M; P.N = N; P.K = K; P.gamma = nullptr; P.beta = nullptr; P.eps = 0.f; P.flags = 0;
+  P.mean = nullptr; P.rstd = nullptr;
+  P.out_f32 = out_f32;
+  P.rpb = rows_per_block; P.bstride = block_stride;
+  return linear_launch(P, nullptr, 0, dtype, (hipStream_t)stream);
 }

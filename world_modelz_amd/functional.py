@@ -99,7 +99,13 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, out_f32):
-        y = ops.linear_fwd(x, _cast.operand(w, x.dtype), bias=None if b is None else b.detach(), out_f32=out_f32)
+        bias = None if b is None else b.detach()
+        if x.dim() >= 3 and not x.is_contiguous() and x[0].is_contiguous() and x.stride(0) % 8 == 0:
+            # a batch of contiguous row blocks a fixed stride apart -- the last frame x[:, -1] of the stream: read in place
+            xb = x.view(x.shape[0], -1, x.shape[-1])
+            y = ops.linear_fwd_blocks(xb, _cast.operand(w, x.dtype), bias, out_f32).view(*x.shape[:-1], w.shape[0])
+        else:
+            y = ops.linear_fwd(x, _cast.operand(w, x.dtype), bias=bias, out_f32=out_f32)
         ctx.save_for_backward(x, w, b)
         return y
 

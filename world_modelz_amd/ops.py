@@ -89,6 +89,18 @@ def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=F
     return out
 
 
+def linear_fwd_blocks(a, weight, bias=None, out_f32=False):
+    """a: [Bk, R, K] with contiguous rows inside each block and an arbitrary block stride (x[:, -1] of a [B,S,H,W,D]
+    stream, flattened to [B, H*W, D]) -> [Bk, R, N] = a @ weight^T + bias, the blocks read in place."""
+    Bk, R, K = a.shape
+    N = weight.shape[0]
+    assert a.stride(2) == 1 and weight.dtype == a.dtype and weight.is_contiguous() and weight.shape[1] == K
+    out = torch.empty((Bk, R, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
+    L.call('wmz_linear_fwd_blocked', L.ptr(a), a.stride(1), R, a.stride(0), L.ptr(weight), L.ptr(bias), L.ptr(out), N,
+           Bk * R, N, K, 1 if out_f32 else 0, L.dtype_code(a.dtype), L.stream())
+    return out
+
+
 def embed_pos3d_fwd(z, emb, pos_s, pos_h, pos_w, dtype):
     B, S, H, W = z.shape
     D = emb.shape[1]
