@@ -94,6 +94,15 @@ int wmz_linear_fwd_blocked(const void* A, long lda, int rows_per_block, long blo
 int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N, int K,
                      const float* ln_gamma, const float* ln_beta, const float* ln_mean, const float* ln_rstd,
                      int gelu_in, int dtype, void* stream);
+
+/* The same with a two-stage reduction instead of float atomics: the slices of M leave their 128 x 128 partial tiles in
+ * `workspace` (fp32, at least wmz_linear_wgrad_workspace_floats(M, N, K, dtype) floats, contents undefined afterwards) and
+ * a second launch adds their sum to dW / dbias -- deterministic summation order, no same-address atomics.  The caller
+ * owns the workspace (the library never allocates); one workspace can serve every wgrad on a stream. */
+long wmz_linear_wgrad_workspace_floats(int M, int N, int K, int dtype);
+int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N, int K,
+                        const float* ln_gamma, const float* ln_beta, const float* ln_mean, const float* ln_rstd,
+                        int gelu_in, float* workspace, long workspace_floats, int dtype, void* stream);
 /* nn.LayerNorm statistics (PreNorm, local_3d_attention.py:14): mean[M], rstd[M] over the K axis. */
 int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
                         void* stream);
@@ -279,6 +288,12 @@ int wmz_bilinear2x_nhwc_bwd(const void* dy, void* dx, int B, int H, int W, int C
 int wmz_corrupt_tokens(const int64_t* z_last, long clip_stride, const float* r, int64_t* out, long out_stride,
                        int64_t* target, int B, int HW, int C, unsigned long long seed, unsigned long long stream_id,
                        void* stream);
+/* The same with the low 40 bits of the stream id read from device memory when the kernel runs (`counter`, one uint64 the
+ * caller advances between launches; stream_hi supplies the bits above, e.g. the data-parallel rank << 40): the launch
+ * can be captured in a hipGraph and still draw a fresh corruption on every replay. */
+int wmz_corrupt_tokens_dev(const int64_t* z_last, long clip_stride, const float* r, int64_t* out, long out_stride,
+                           int64_t* target, int B, int HW, int C, unsigned long long seed, unsigned long long stream_hi,
+                           const unsigned long long* counter, void* stream);
 /* CrossEntropyLoss(reduction='none') over fp32 logits [R, C] (row stride ld): loss[R], lse[R]; and its gradient
  * dlogits[r,c] = (softmax - one_hot) * grad_rows[r], written in `dtype` (the GEMM operand type of the backward). */
 int wmz_ce_fwd(const float* logits, long ld, const int64_t* target, float* loss, float* lse, long R, int C, void* stream);
@@ -292,6 +307,10 @@ int wmz_grad_sqnorm(const float* g, long n, float scale, float* out, void* strea
  * grad_scale * g (1/world after a SUM all-reduce); `step` is the 1-based step count for the bias corrections. */
 int wmz_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, long step, double grad_scale, void* stream);
+/* The same with the per-step scalars in device memory, hyper = [lr, 1 - beta1^t, sqrt(1 - beta2^t)] (fp32): a captured
+ * training step is replayed with a new learning rate / bias correction each time. */
+int wmz_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, double beta1, double beta2,
+                       double eps, double weight_decay, double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

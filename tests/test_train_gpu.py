@@ -145,6 +145,53 @@ def test_sampler_loop_token_for_token_vs_reference(wmz, name, use_graph):
     assert rel(img, g['images'][2:]) < 1e-5
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_graphed_training_step_matches_eager(wmz, dtype):
+    """DenoiserTrainer.enable_graph: the whole step as one hipGraph.  With r = 0 the corruption is the identity (no mask,
+    no redraw), so graphed and eager trainers started from the same weights must walk the same trajectory (lr schedule and
+    AdamW bias corrections come from device memory in the graph); then with random r the graph must draw a fresh
+    corruption on every replay."""
+    torch.manual_seed(8)
+    C = 64
+    def make():
+        torch.manual_seed(9)
+        m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=C, extents=(1, 1, 1), depth=2,
+                                              dim_head=128, mlp_dim=256, heads=1).cuda()
+        return m
+    z = torch.randint(0, C, (2, 3, 16, 16), device='cuda')
+    r0 = torch.zeros(2)
+    with wmz['config'].compute_dtype(dtype):
+        me, mg = make(), make()
+        te = wmz['train'].DenoiserTrainer(me, C, lr=1e-3, warmup=2, max_steps=100, distributed=False)
+        tg = wmz['train'].DenoiserTrainer(mg, C, lr=1e-3, warmup=2, max_steps=100, distributed=False)
+        # enable_graph's warm-up steps are real steps: give the eager trainer the same ones (r = 0 via a stub sampler)
+        class Zero:
+            def sample(self, n, generator=None): return torch.zeros(n)
+            def update_with_losses(self, *a): pass
+        te.sampler, tg.sampler = Zero(), Zero()
+        tg.enable_graph(z, warmup=2)
+        for _ in range(2):
+            te.train_step(z, r=r0)
+        for it in range(3):
+            le, ge = te.train_step(z, r=r0)
+            lg, gg = tg.train_step(z, r=r0)
+            assert abs(le - lg) < (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, abs(le)), (it, le, lg)
+            assert abs(ge - gg) < (1e-3 if dtype == torch.float32 else 5e-2) * max(1.0, abs(ge)), (it, ge, gg)
+        assert te.step_count == tg.step_count == 5
+        tol = dict(rtol=1e-4, atol=1e-6) if dtype == torch.float32 else dict(rtol=0, atol=3e-3)
+        for (n, a), b in zip(me.named_parameters(), mg.parameters()):
+            assert torch.allclose(a, b, **tol), n
+        # eager inference after graphed steps sees the updated weights (operand caches invalidated)
+        with torch.no_grad():
+            assert torch.allclose(me(z), mg(z), rtol=1e-3, atol=(1e-4 if dtype == torch.float32 else 5e-2))
+        # fresh corruption per replay: the device counter advances, so two replays with the same r differ in loss
+        r1 = torch.full((2,), 0.7)
+        l1, _ = tg.train_step(z, r=r1)
+        c1 = int(tg._g_ctr)
+        l2, _ = tg.train_step(z, r=r1)
+        assert int(tg._g_ctr) == c1 + 1 and l1 != l2
+
+
 def test_fused_cross_entropy_vs_torch(wmz):
     tr = wmz['train']
     torch.manual_seed(5)

@@ -28,6 +28,8 @@ SIGNATURES = {
     'wmz_local3d_attn_bwd': [c_void_p] * 10 + [c_int] * 9 + [c_long] * 8 + [c_int, c_void_p],
     'wmz_linear_wgrad': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                         + [c_int, c_int, c_void_p],
+    'wmz_linear_wgrad_ws': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
+                           + [c_int, c_void_p, c_long, c_int, c_void_p],
     'wmz_layernorm_stats': [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_layernorm_bwd': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                           c_void_p, c_int, c_int, c_float, c_int, c_void_p],
@@ -65,6 +67,9 @@ SIGNATURES = {
     'wmz_embed_indexed_bwd': [c_void_p] * 7 + [c_long] + [c_int] * 6 + [c_void_p],
     'wmz_corrupt_tokens': [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
                            ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p],
+    'wmz_corrupt_tokens_dev': [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
+                               ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p],
+    'wmz_adamw_step_dev': [c_void_p] * 4 + [c_long, c_void_p] + [c_double] * 5 + [c_void_p],
     'wmz_ce_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     'wmz_ce_bwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     'wmz_grad_sqnorm': [c_void_p, c_long, c_float, c_void_p, c_void_p],
@@ -91,6 +96,9 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.wmz_version.restype = c_int
         L.wmz_last_error.restype = ctypes.c_char_p
+        if hasattr(L, 'wmz_linear_wgrad_workspace_floats'):
+            L.wmz_linear_wgrad_workspace_floats.restype = c_long
+            L.wmz_linear_wgrad_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name, None)
             if fn is None:

@@ -53,6 +53,41 @@ def _emit2(p1, p2, fill):
     return b1, b2
 
 
+def _wgrad_kv(wk, wv, bv, dkv, x_kv, lnp, stats):
+    """to_k and to_v weight gradients by ONE GEMM on dk | dv (they share the operand LN(x) and its prologue):
+    dW[2I, D] = [dk | dv]^T LN(x).  Under a FlatArena the two gradient slices are adjacent (to_k.weight, to_v.weight are
+    registered back to back), so the kernel accumulates straight into them.  Returns (g_wk, g_wv, g_bv) for autograd."""
+    I = wk.shape[0]
+    bk_, bw_, bb_ = (getattr(p, '_wmz_grad', None) for p in (wk, wv, bv))
+    direct = (bk_ is not None and bw_ is not None and bb_ is not None and bk_.is_contiguous() and bw_.is_contiguous()
+              and bw_.data_ptr() == bk_.data_ptr() + 4 * bk_.numel())
+    db = torch.zeros(2 * I, dtype=torch.float32, device=dkv.device)
+    if direct:
+        dw = torch.as_strided(bk_, (2 * I, wk.shape[1]), (wk.shape[1], 1))
+    else:
+        dw = torch.zeros((2 * I, wk.shape[1]), dtype=torch.float32, device=dkv.device)
+    ops.linear_wgrad(dkv, x_kv, dw, db, ln=lnp, ln_stats=stats)
+    if direct:
+        bb_ += db[I:]
+        for p in (wk, wv, bv):
+            ready = getattr(p, '_wmz_ready', None)
+            if ready is not None:
+                ready()
+        return None, None, None
+    outs = []
+    for p, g in ((wk, dw[:I]), (wv, dw[I:]), (bv, db[I:])):
+        buf = getattr(p, '_wmz_grad', None)
+        if buf is not None:
+            buf += g
+            ready = getattr(p, '_wmz_ready', None)
+            if ready is not None:
+                ready()
+            outs.append(None)
+        else:
+            outs.append(g)
+    return tuple(outs)
+
+
 def attention_block_backward(ctx, dy):
     x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse = ctx.saved_tensors
     dt = x_kv.dtype
@@ -87,8 +122,7 @@ def attention_block_backward(ctx, dy):
     if ln_g is not None:
         stats = ctx.ln_stats if getattr(ctx, 'ln_stats', None) is not None else ops.layernorm_stats(x_kv, LN_EPS)
         lnp = (ln_g.detach(), ln_b.detach())
-        g_wk = _emit(wk, lambda w: ops.linear_wgrad(dk, x_kv, w, None, ln=lnp, ln_stats=stats))
-        g_wv, g_bv = _emit2(wv, bv, lambda w, b: ops.linear_wgrad(dv, x_kv, w, b, ln=lnp, ln_stats=stats))
+        g_wk, g_wv, g_bv = _wgrad_kv(wk, wv, bv, dkv, x_kv, lnp, stats)
         holder = {}
 
         def fill_ln(gg, gb):
@@ -96,8 +130,7 @@ def attention_block_backward(ctx, dy):
         g_ln_g, g_ln_b = _emit2(ln_g, ln_b, fill_ln)
         dx_kv = holder['dx']
     else:
-        g_wk = _emit(wk, lambda w: ops.linear_wgrad(dk, x_kv, w))
-        g_wv, g_bv = _emit2(wv, bv, lambda w, b: ops.linear_wgrad(dv, x_kv, w, b))
+        g_wk, g_wv, g_bv = _wgrad_kv(wk, wv, bv, dkv, x_kv, None, None)
         dx_kv = dxhat if skip is None else dxhat + skip.reshape(dxhat.shape)
     g_xkv = dx_kv.reshape(x_kv.shape)
     g_xq = None if fold_q else dxq.reshape(x_q.shape)

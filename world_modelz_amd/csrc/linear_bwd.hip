@@ -50,7 +50,7 @@ struct WgParams {
   int M, N, K;
   const float* gamma; const float* beta; const float* mean; const float* rstd;
   int gelu_in;
-  int nbn, nbk, rows_per_wg;
+  int nbn, nbk, rows_per_wg, nsplit;
   // PRO == 3: A is the implicit im2col of an NHWC tensor x[B,Hi,Wi,Cin] (row m = output pixel, k = (kh, kw, ci))
   int Hi, Wi, Cin, Ho, Wo, KW, cstride, cpad;
 };
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(WgParams P) {
   __shared__ __attribute__((aligned(16))) char As[WG_MS * ROWB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);          // the tiles of one slice of M share an XCD: its L2 serves the operands' re-reads
   const int bk = bid % P.nbk; bid /= P.nbk;
   const int bn = bid % P.nbn; bid /= P.nbn;
   const int split = bid;
@@ -198,6 +198,245 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(WgParams P) {
       }
     }
   if (P.dbias != nullptr && bk == 0 && tid < WG_BN && n0 + tid < P.N) atomicAdd(P.dbias + n0 + tid, bsum);
+}
+
+
+// ---- wgrad, version 2: the same 128 x 128 output tile and operand handling, but
+//   * slabs of 64 rows (bf16; 32 for fp32) in a DOUBLE-buffered LDS image: one barrier per slab and 16 MFMAs per wave
+//     between two barriers (version 1: two barriers around 8 MFMAs);
+//   * the slices of M do not meet in float atomics (version 1: 64 KB of same-address atomics per workgroup, all at the end,
+//     serialised memory-side) but in a workspace [split][N][K] (+ [split][N] for the bias) that wgrad_reduce_kernel sums
+//     into dW / dbias: two-stage reduction, deterministic summation order.
+template <typename T> struct W2 { static constexpr int MS = sizeof(T) == 2 ? 64 : 32; };
+
+template <typename T, int PRO>
+__global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __restrict__ ws) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int ROWB = WG_BN * (int)sizeof(T);
+  constexpr int CPR = ROWB / 16;
+  constexpr int MS = W2<T>::MS;
+  constexpr int PER_T = MS * CPR / NT;                 // 4
+  constexpr int IMG = MS * ROWB;                       // 16 KB
+  __shared__ __attribute__((aligned(16))) char smem[4 * IMG];   // [buffer][dC image | A image]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);          // the tiles of one slice of M share an XCD: its L2 serves the operands' re-reads
+  const int bk = bid % P.nbk; bid /= P.nbk;
+  const int bn = bid % P.nbn; bid /= P.nbn;
+  const int split = bid;
+  const int n0 = bn * WG_BN, k0 = bk * WG_BK;
+  const int m_begin = split * P.rows_per_wg, m_end = min(P.M, m_begin + P.rows_per_wg);
+  const T* dC = reinterpret_cast<const T*>(P.dC);
+  const T* A = reinterpret_cast<const T*>(P.A);
+
+  // two register sets: the loads of slabs s + 1 and s + 2 are in flight while slab s is multiplied (one slab ahead the
+  // loop runs at one memory round trip per slab: ~3k cycles for 16 MFMAs)
+  i32x4 rcs[2][PER_T], ras[2][PER_T];
+  float lmu[2][PER_T], lrs[2][PER_T];                  // LayerNorm statistics of the rows in flight (PRO 1)
+  auto fetch = [&](auto setc, int m0) {
+    constexpr int S = decltype(setc)::value;
+    i32x4 (&rc)[PER_T] = rcs[S];
+    i32x4 (&ra)[PER_T] = ras[S];
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int m = m0 + r;
+      rc[it] = (i32x4)(0);
+      ra[it] = (i32x4)(0);
+      if constexpr (PRO == 1) { lmu[S][it] = 0.f; lrs[S][it] = 0.f; }
+      if (m < m_end) {
+        if (n0 + c * EPC < P.N) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * EPC);
+        if (k0 + c * EPC < P.K) {
+          ra[it] = *reinterpret_cast<const i32x4*>(A + (long)m * P.lda + k0 + c * EPC);
+          if constexpr (PRO == 1) { lmu[S][it] = P.mean[m]; lrs[S][it] = P.rstd[m]; }
+        }
+      }
+    }
+  };
+  // the prologue arithmetic runs when the slab goes to LDS, not when it is requested: the loads stay in flight
+  auto stash = [&](auto setc, int buf) {
+    constexpr int S = decltype(setc)::value;
+    char* Cs = smem + buf * 2 * IMG;
+    char* As = Cs + IMG;
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int off = r * ROWB + ((c << 4) ^ wswz<T>(r));
+      i32x4 v = ras[S][it];
+      if constexpr (PRO == 1 || PRO == 2) {
+        if (k0 + c * EPC < P.K) {
+          float f[EPC];
+          unpack_chunk<T>(v, f);
+          if constexpr (PRO == 1) {
+            const float mu = lmu[S][it], rs = lrs[S][it];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k0 + c * EPC + e] + P.beta[k0 + c * EPC + e];
+            if (rs == 0.f) {
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) f[e] = 0.f;          // rows past the slice
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
+          }
+          v = pack_chunk<T>(f);
+        }
+      }
+      *reinterpret_cast<i32x4*>(Cs + off) = rcs[S][it];
+      *reinterpret_cast<i32x4*>(As + off) = v;
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+#if 0
+          if constexpr (PRO == 1 || PRO == 2) {
+            float f[EPC];
+            unpack_chunk<T>(v, f);
+            if constexpr (PRO == 1) {
+              const float mu = P.mean[m], rs = P.rstd[m];
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k0 + c * EPC + e] + P.beta[k0 + c * EPC + e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
+            }
+            v = pack_chunk<T>(f);
+          }
+          ra[it] = v;
+        }
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    char* Cs = smem + buf * 2 * IMG;
+    char* As = Cs + IMG;
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int off = r * ROWB + ((c << 4) ^ wswz<T>(r));
+      *reinterpret_cast<i32x4*>(Cs + off) = rc[it];
+      *reinterpret_cast<i32x4*>(As + off) = ra[it];
+    }
+  };
+
+#endif
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+  float bsum = 0.f;                                    // threads 0..127 of the bk == 0 workgroups: column sums of dC
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+
+  auto compute = [&](int cur) {
+    const char* Cs = smem + cur * 2 * IMG;
+    const char* As = Cs + IMG;
+    if (P.dbias != nullptr && bk == 0 && tid < WG_BN) {
+#pragma unroll 8
+      for (int r = 0; r < MS; ++r) {
+        const char* p = Cs + r * ROWB + ((tid * (int)sizeof(T)) ^ wswz<T>(r));
+        bsum += Elem<T>::to_f32(*reinterpret_cast<const T*>(p));
+      }
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ms += 16) {
+      Frag8<T> cf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wg_col_frag<T>(cf[i], Cs, ms, wn + 32 * i, lane);
+        wg_col_frag<T>(af[i], As, ms, wk + 32 * i, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32(acc[i][j], cf[i], af[j]);
+    }
+  };
+  // slab s lives in LDS buffer s & 1; register set 0 carries the odd slabs on their way in, set 1 the even ones
+  if (m_begin < m_end) {
+    fetch(S1{}, m_begin);
+    fetch(S0{}, m_begin + MS);                         // (rows past m_end come back as zeros)
+    stash(S1{}, 0);
+    fetch(S1{}, m_begin + 2 * MS);
+  }
+  __syncthreads();
+  for (int m0 = m_begin; m0 < m_end; m0 += 2 * MS) {
+    compute(0);                                        // slab s (even)
+    stash(S0{}, 1);                                    // slab s + 1 -> buffer 1 (last read before the previous barrier)
+    fetch(S0{}, m0 + 3 * MS);
+    __syncthreads();
+    if (m0 + MS < m_end) compute(1);                   // slab s + 1
+    stash(S1{}, 0);                                    // slab s + 2
+    fetch(S1{}, m0 + 4 * MS);
+    __syncthreads();
+  }
+
+  // D: row (n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (k') = lane&31
+  const int l31 = lane & 31, hh = lane >> 5;
+  float* part = ws != nullptr ? ws + (long)split * P.N * P.K : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = k0 + wk + 32 * j + l31;
+      if (kc >= P.K) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = n0 + wn + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (n < P.N) {
+          if (part != nullptr) part[(long)n * P.K + kc] = acc[i][j][reg];
+          else atomicAdd(P.dW + (long)n * P.K + kc, acc[i][j][reg]);
+        }
+      }
+    }
+  if (P.dbias != nullptr && bk == 0 && tid < WG_BN && n0 + tid < P.N) {
+    if (ws != nullptr) ws[(long)P.nsplit * P.N * P.K + (long)split * P.N + n0 + tid] = bsum;
+    else atomicAdd(P.dbias + n0 + tid, bsum);
+  }
+}
+
+// dW[n, k] += sum over the slices; dbias[n] += sum over the slices (fixed order: deterministic).  A workgroup owns 256
+// consecutive floats of dW (64 lanes x float4 = one KB per wave instruction); its sixteen waves take the slices s = w,
+// w + 16, ..: every load is a full coalesced KB and all of a wave's loads are in flight together; the partial sums meet
+// in LDS.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
+                                                            float* __restrict__ dbias, int nsplit, long NK, int N, int nblk_w) {
+  __shared__ f32x4 red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < nblk_w) {
+    const long q = ((long)blockIdx.x * 64 + lane) * 4;
+    f32x4 a = (f32x4)(0.f);
+    if (q < NK) {
+      int s = wave;
+      for (; s + 48 < nsplit; s += 64) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(ws + (long)(s + 16 * u) * NK + q);
+        a += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      for (; s < nsplit; s += 16) a += *reinterpret_cast<const f32x4*>(ws + (long)s * NK + q);
+    }
+    red[wave][lane] = a;
+    __syncthreads();
+    if (wave == 0 && q < NK) {
+      f32x4 t = red[0][lane];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) t += red[w][lane];
+      f32x4* d = reinterpret_cast<f32x4*>(dW + q);
+      *d = *d + t;
+    }
+  } else if (dbias != nullptr) {
+    const long n = ((long)blockIdx.x - nblk_w) * 1024 + threadIdx.x;
+    if (n < N) {
+      float a = 0.f;
+      const float* wb = ws + (long)nsplit * NK;
+      for (int s = 0; s < nsplit; ++s) a += wb[(long)s * N + n];
+      dbias[n] += a;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -367,7 +606,7 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
   P.gamma = ln_gamma; P.beta = ln_beta; P.mean = ln_mean; P.rstd = ln_rstd; P.gelu_in = gelu_in;
   P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
-  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
+  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK); P.nsplit = 0;
   const int tiles = P.nbn * P.nbk;
   static const int wg_target = getenv("WMZ_WGRAD_WGS") ? atoi(getenv("WMZ_WGRAD_WGS")) : 256;
   int split = wmz_cdiv(wg_target, tiles);    // ~one workgroup per CU: every extra split is another 64 KB of float atomics
@@ -387,6 +626,56 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   return WMZ_OK;
 }
 
+// slices of M for a wgrad of these sizes (shared by the launch and by the workspace query)
+static int wgrad_split(int M, int N, int K, int ms, int* rows_per_wg) {
+  const int tiles = wmz_cdiv(N, WG_BN) * wmz_cdiv(K, WG_BK);
+  static const int target = getenv("WMZ_WGRAD2_WGS") ? atoi(getenv("WMZ_WGRAD2_WGS")) : 256;
+  int split = wmz_cdiv(target, tiles);         // two resident workgroups per CU
+  const int max_split = wmz_cdiv(M, 4 * ms);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  *rows_per_wg = wmz_cdiv(wmz_cdiv(M, split), ms) * ms;
+  return wmz_cdiv(M, *rows_per_wg);
+}
+
+extern "C" long wmz_linear_wgrad_workspace_floats(int M, int N, int K, int dtype) {
+  int rows;
+  const int split = wgrad_split(M, N, K, dtype == WMZ_BF16 ? 64 : 32, &rows);
+  return (long)split * ((long)N * K + N);
+}
+
+extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N,
+                                   int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
+                                   const float* ln_rstd, int gelu_in, float* workspace, long workspace_floats, int dtype,
+                                   void* stream) {
+  WMZ_REQUIRE(dC && A && dW && workspace, "wmz_linear_wgrad_ws: null tensor");
+  WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_wgrad_ws: bad shape");
+  WMZ_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0, "wmz_linear_wgrad_ws: N, K and row strides must be multiples of 8");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_wgrad_ws: bad dtype %d", dtype);
+  const bool ln = ln_gamma != nullptr;
+  WMZ_REQUIRE(!ln || (ln_beta && ln_mean && ln_rstd), "wmz_linear_wgrad_ws: LayerNorm prologue needs gamma, beta, mean, rstd");
+  WMZ_REQUIRE(!(ln && gelu_in), "wmz_linear_wgrad_ws: LayerNorm and GELU prologues are exclusive");
+  WMZ_REQUIRE(workspace_floats >= wmz_linear_wgrad_workspace_floats(M, N, K, dtype), "wmz_linear_wgrad_ws: workspace too small (%ld floats)", workspace_floats);
+  WgParams P;
+  P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
+  P.gamma = ln_gamma; P.beta = ln_beta; P.mean = ln_mean; P.rstd = ln_rstd; P.gelu_in = gelu_in;
+  P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
+  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
+  P.nsplit = wgrad_split(M, N, K, dtype == WMZ_BF16 ? 64 : 32, &P.rows_per_wg);
+  dim3 grid((unsigned)(P.nbn * P.nbk * P.nsplit)), block(NT);
+  hipStream_t st = (hipStream_t)stream;
+  const int pro = ln ? 1 : (gelu_in ? 2 : 0);
+#define WMZ_WG2(T, PRO) hipLaunchKernelGGL((wgrad2_kernel<T, PRO>), grid, block, 0, st, P, workspace)
+  if (dtype == WMZ_BF16) { if (pro == 1) WMZ_WG2(bf16_t, 1); else if (pro == 2) WMZ_WG2(bf16_t, 2); else WMZ_WG2(bf16_t, 0); }
+  else { if (pro == 1) WMZ_WG2(float, 1); else if (pro == 2) WMZ_WG2(float, 2); else WMZ_WG2(float, 0); }
+#undef WMZ_WG2
+  const long NK = (long)N * K;
+  const int nblk_w = wmz_cdiv(NK, 256), nblk_b = dbias != nullptr ? wmz_cdiv(N, 1024) : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblk_w + nblk_b)), dim3(1024), 0, st, workspace, dW, dbias, P.nsplit, NK, N, nblk_w);
+  WMZ_LAUNCH_CHECK("wmz_linear_wgrad_ws");
+  return WMZ_OK;
+}
+
 extern "C" int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin,
                                      int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream) {
   WMZ_REQUIRE(x && dy && dW, "wmz_conv2d_nhwc_wgrad: null tensor");
@@ -401,7 +690,7 @@ extern "C" int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, f
   P.dC = dy; P.ldc = Cout; P.A = x; P.lda = 0; P.dW = dW; P.dbias = dbias;
   P.M = B * P.Ho * P.Wo; P.N = Cout; P.K = KH * KW * Cin;
   P.gamma = P.beta = P.mean = P.rstd = nullptr; P.gelu_in = 0;
-  P.nbn = wmz_cdiv(P.N, WG_BN); P.nbk = wmz_cdiv(P.K, WG_BK);
+  P.nbn = wmz_cdiv(P.N, WG_BN); P.nbk = wmz_cdiv(P.K, WG_BK); P.nsplit = 0;
   const int tiles = P.nbn * P.nbk;
   int split = wmz_cdiv(256, tiles);
   const int max_split = wmz_cdiv(P.M, 4 * WG_MS);

@@ -33,7 +33,9 @@ __device__ __forceinline__ void philox4(unsigned long long idx, unsigned long lo
 __global__ __launch_bounds__(256) void corrupt_kernel(const int64_t* __restrict__ z_last, long clip_stride,
                                                       const float* __restrict__ r, int64_t* __restrict__ out,
                                                       long out_stride, int64_t* __restrict__ target, int B, int HW, int C,
-                                                      unsigned long long seed, unsigned long long stream) {
+                                                      unsigned long long seed, unsigned long long stream,
+                                                      const unsigned long long* __restrict__ counter) {
+  if (counter != nullptr) stream |= *counter & ((1ull << 40) - 1);      // per-call stream id kept in device memory (hipGraph replay)
   const long total = (long)B * HW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int b = (int)(i / HW);
@@ -97,8 +99,22 @@ extern "C" int wmz_corrupt_tokens(const int64_t* z_last, long clip_stride, const
   const long total = (long)B * HW;
   const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   hipLaunchKernelGGL(corrupt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_last, clip_stride, r, out, out_stride,
-                     target, B, HW, C, seed, stream_id);
+                     target, B, HW, C, seed, stream_id, (const unsigned long long*)nullptr);
   WMZ_LAUNCH_CHECK("wmz_corrupt_tokens");
+  return WMZ_OK;
+}
+
+// The same with the low 40 bits of the Philox stream id read from device memory at run time (`counter`, which the caller
+// advances between launches): the launch can sit in a hipGraph and still draw a fresh mask on every replay.
+extern "C" int wmz_corrupt_tokens_dev(const int64_t* z_last, long clip_stride, const float* r, int64_t* out, long out_stride,
+                                      int64_t* target, int B, int HW, int C, unsigned long long seed,
+                                      unsigned long long stream_hi, const unsigned long long* counter, void* stream) {
+  WMZ_REQUIRE(z_last && r && out && counter && B > 0 && HW > 0 && C > 0, "wmz_corrupt_tokens_dev: bad arguments");
+  const long total = (long)B * HW;
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(corrupt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_last, clip_stride, r, out, out_stride,
+                     target, B, HW, C, seed, stream_hi & ~((1ull << 40) - 1), counter);
+  WMZ_LAUNCH_CHECK("wmz_corrupt_tokens_dev");
   return WMZ_OK;
 }
 

@@ -192,8 +192,20 @@ def linear_dgrad(dc, weight_t, dgelu_z=None):
     return out
 
 
+_wgrad_ws = {}          # device -> fp32 scratch for the two-stage weight-gradient reduction (grown on demand, never shrunk)
+
+
+def _workspace(device, floats):
+    w = _wgrad_ws.get(device)
+    if w is None or w.numel() < floats:
+        w = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+        _wgrad_ws[device] = w
+    return w
+
+
 def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False):
-    """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc).  dw / dbias fp32, accumulated."""
+    """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc).  dw / dbias fp32, accumulated (two-stage reduction through a
+    per-device workspace: deterministic, no float atomics)."""
     dt = L.dtype_code(dc.dtype)
     dc, M, ldc = _rows(dc)
     a, Ma, lda = _rows(a)
@@ -203,8 +215,10 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False):
     if ln is not None:
         g, b = ln
         mean, rstd = ln_stats
-    L.call('wmz_linear_wgrad', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
-           L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, dt, L.stream())
+    need = L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
+    ws = _workspace(dc.device, need)
+    L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
+           L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, L.ptr(ws), ws.numel(), dt, L.stream())
 
 
 def layernorm_stats(x, eps=1e-5):

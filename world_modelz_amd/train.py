@@ -26,7 +26,7 @@ def _dp_rank():
     return d.get_rank() if d.is_available() and d.is_initialized() else 0
 
 
-def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None, rank=None):
+def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None, rank=None, counter=None):
     """main.py:240-259 on the GPU without the [B,HW,C] one-hot / lerp / multinomial temporaries: ONE kernel.
 
     multinomial(lerp(one_hot(z), 1/C, a)) with a = 0.1 r has the closed form "with probability a redraw uniformly
@@ -44,8 +44,16 @@ def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None, ra
     r = r.to(batch_z.device, torch.float32).contiguous()
     if seed is None:
         seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+    rank = _dp_rank() if rank is None else int(rank)
+    if counter is not None:
+        # hipGraph replay: the per-call part of the stream id is a device counter (uint64 in an int64 tensor) that the
+        # caller advances inside the graph
+        L.call('wmz_corrupt_tokens_dev', src.data_ptr() + (S - 1) * HW * 8, S * HW, L.ptr(r), out.data_ptr() + (S - 1) * HW * 8,
+               S * HW, L.ptr(target), B, HW, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, rank << 40, L.ptr(counter),
+               L.stream())
+        return out, target
     _corrupt_calls += 1
-    stream_id = ((_dp_rank() if rank is None else int(rank)) << 40) | (_corrupt_calls & ((1 << 40) - 1))
+    stream_id = (rank << 40) | (_corrupt_calls & ((1 << 40) - 1))
     L.call('wmz_corrupt_tokens', src.data_ptr() + (S - 1) * HW * 8, S * HW, L.ptr(r), out.data_ptr() + (S - 1) * HW * 8,
            S * HW, L.ptr(target), B, HW, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_id, L.stream())
     return out, target
@@ -157,6 +165,7 @@ class DenoiserTrainer:
         self.sampler = LossAwareSamplerEma(num_histogram_buckets=100, uniform_p=0.01, alpha=0.9, warmup=10)
         self.operands = self._register_operands()
         self.operands.refresh()
+        self._graph = None                 # captured training step (enable_graph)
 
     def _register_operands(self):
         """Every operand copy the step asks _cast.operand() for (bf16 casts, dgrad transposes, k|v concatenations), so
@@ -211,10 +220,79 @@ class DenoiserTrainer:
         self.operands.refresh()       # ... and every operand copy of the weights is rebuilt by one launch
         return self.sq
 
+    # ------------------------------------------------------------------------------------------------ hipGraph
+    def enable_graph(self, example_batch, warmup=3):
+        """Capture corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand re-pack as ONE hipGraph and replay
+        it from train_step() (single micro-batch, no data parallelism: the overlapped all-reduce path stays eager).
+        What changes per step lives in device memory: the clips and their noise levels (static input tensors), the
+        corruption's stream counter (advanced inside the graph), the learning rate and AdamW bias corrections (`hyper`).
+        The warm-up steps are REAL optimizer steps on `example_batch`."""
+        assert self.reducer is None and self.acc_steps == 1, 'the graphed step is single-process, one micro-batch'
+        dev = self.arena.flat_param.device
+        self._g_z = example_batch.contiguous().clone()
+        self._g_r = torch.zeros(example_batch.shape[0], dtype=torch.float32, device=dev)
+        self._g_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._g_hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._g_seed = torch.initial_seed()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._set_step_inputs(None)
+                self._graph_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._set_step_inputs(None)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._g_out = self._graph_body()
+        self.step_count -= 1               # capturing records the launches, it does not run a step
+        self._graph = g
+        return self
+
+    def _set_step_inputs(self, r):
+        """Host side of one graphed step: next noise levels and the optimizer scalars of step t into device memory."""
+        B = self._g_z.shape[0]
+        if r is None:
+            r = self.sampler.sample(B, generator=self.sampler_gen)
+        self._g_r_host = r
+        self._g_r.copy_(r.to(torch.float32), non_blocking=True)
+        self.step_count += 1
+        lr = lr_at(self.step_count, self.lr, self.warmup, self.max_steps)
+        bc1 = 1.0 - self.betas[0] ** self.step_count
+        bc2 = 1.0 - self.betas[1] ** self.step_count
+        self._g_hyper.copy_(torch.tensor([lr, bc1, math.sqrt(bc2)], dtype=torch.float32), non_blocking=True)
+
+    def _graph_body(self):
+        a = self.arena
+        a.flat_grad.zero_()
+        zc, target = corrupt_last_frame(self._g_z, self._g_r, self.C, seed=self._g_seed, rank=self.rank, counter=self._g_ctr)
+        self._g_ctr += 1
+        # whatever is derived from the weights is rebuilt INSIDE the graph, every replay: the bulk operand copies by one
+        # launch here, the fused kernels' weight streams by the forward (their cache entries are stale by construction)
+        _cast.invalidate()
+        self.operands.refresh()
+        per_sample, mean = self.forward_backward(zc, target)
+        st = L.stream()
+        self.sq.zero_()
+        L.call('wmz_grad_sqnorm', L.ptr(a.flat_grad), a.numel, 1.0, L.ptr(self.sq), st)
+        L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
+               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, st)
+        return per_sample, mean, self.sq
+
     def train_step(self, batch_z, r=None, generator=None):
         """corrupt -> forward/backward (all-reduce overlapped) -> grad-norm -> AdamW; sampler update on the host.
         batch_z: one micro-batch [B,S,H,W], or a list of `accumulation_steps` of them (main.py:221-280: gradients
         accumulate over the micro-batches, each micro-loss scaled by 1/acc_steps, loss_sum is their sum)."""
+        if self._graph is not None and not isinstance(batch_z, (list, tuple)) and batch_z.shape == self._g_z.shape:
+            self._g_z.copy_(batch_z, non_blocking=True)
+            self._set_step_inputs(r)
+            self._graph.replay()
+            _cast.invalidate()             # the replay rewrote the weights: eager consumers rebuild their operand copies
+            per_sample, mean, sq = self._g_out
+            out = torch.cat([mean.reshape(1), sq.reshape(1), per_sample]).cpu()     # the step's one host sync
+            self.sampler.update_with_losses(self._g_r_host, out[2:])
+            return float(out[0]), math.sqrt(float(out[1]))
         micro = list(batch_z) if isinstance(batch_z, (list, tuple)) else [batch_z]
         assert len(micro) == self.acc_steps, f'expected {self.acc_steps} micro-batches, got {len(micro)}'
         rs = list(r) if isinstance(r, (list, tuple)) else [r] * len(micro)
