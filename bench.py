@@ -81,7 +81,12 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
     med = times[len(times) // 2]
     return {'value': cfg['S'] / med, 'unit': 'latent-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'{len(times)} x one 1x{cfg["S"]}x{cfg["H"]}x{cfg["W"]} clip forward (fp32 torch CPU oracle), '
-                      f'median {med * 1e3:.0f} ms'}
+                      f'median {med * 1e3:.0f} ms',
+            # the oracle walks the window offsets instead of materialising the unfold, so it is ~9x FASTER than the reference's
+            # own CPU path; the reference cannot travel to this box, its number from the build container is quoted beside it
+            'reference_elsewhere': {'value': 18.3, 'unit': 'latent-frames/s', 'cores': 8, 'kind': 'reference',
+                                    'sample': 'BASELINE.md section 2: the reference\'s own VqVideoDiffusionModel.forward on one '
+                                              '1x32x16x16 clip, 1.75 s, torch 2.10 fp32, survey container (8 cores) -- not this host'}}
 
 
 def main():
@@ -198,17 +203,18 @@ def main():
         with torch.cuda.graph(g):
             for _ in range(reps):
                 fn()
-        g.replay()
+        for _ in range(3):                 # clocks / caches settled before the timed replays
+            g.replay()
         torch.cuda.synchronize()
         times = []
-        for _ in range(3):
+        for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             g.replay()
             e1.record()
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) / reps)
-        return sorted(times)[1]
+        return sorted(times)[2]
 
     reps = 50
     with torch.no_grad():
@@ -236,16 +242,29 @@ def main():
     else:
         fused_roof = None
     # `traffic`: fabric-side bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
-    # gfx950 correction applied) -- they cannot be collected inside this process, so the committed measurement of the same
-    # kernels at the same shapes is reported (profiles/r01/v3_pmc_traffic.json says how it was taken); null if it is absent.
+    # gfx950 correction applied: tools/pmc_traffic.py) -- they cannot be collected inside this process, so the committed
+    # measurement of the same kernels at the same shapes is reported, but ONLY while the kernel sources still hash to what was
+    # measured; otherwise traffic stays null (and `traffic_stale` says why) instead of going stale silently.
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'v3_pmc_traffic.json')) as f:
+        import hashlib
+        with open(os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')) as f:
             pmc = json.load(f)
-        attn_roof['traffic'] = pmc['attn_fwd_row16_kernel<128,1>']['traffic_bytes_per_launch']
-        attn_roof['traffic_source'] = 'profiles/r01/v3_pmc_traffic.json (rocprofv3 PMC pass, same kernel and shapes)'
-        if fused_roof is not None:
-            fused_roof['traffic'] = pmc['layer_fused_kernel<head,tail>']['traffic_bytes_per_launch']
-            fused_roof['traffic_source'] = attn_roof['traffic_source']
+
+        def src_hash(names):
+            h = hashlib.sha256()
+            for n in names:
+                with open(os.path.join(ROOT, 'world_modelz_amd', 'csrc', n), 'rb') as fh:
+                    h.update(fh.read())
+            return h.hexdigest()[:16]
+        for roof, key in ((attn_roof, 'attn_fwd_row16_kernel'), (fused_roof, 'layer_fused_kernel<head,tail>')):
+            if roof is None or key not in pmc:
+                continue
+            ent = pmc[key]
+            if src_hash(ent['sources']) == ent['source_sha16']:
+                roof['traffic'] = ent['traffic_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/r02/pmc_traffic.json (rocprofv3 PMC passes, same kernel source and shapes)'
+            else:
+                roof['traffic_stale'] = 'kernel source changed since profiles/r02/pmc_traffic.json was measured'
     except (OSError, KeyError, ValueError):
         pass
     # `roofline` = the kernel with the larger share of the step
@@ -319,21 +338,46 @@ def main():
                      'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens (eager launches)"}
         log(f'frame encoder: {fel * 1e3:.2f} ms per {cfg["B"] * cfg["S"]} frames')
     out['frame_encoder'] = frame_enc
-    # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> gradient all-reduce overlapped
-    # on a side stream when n_gpus > 1 -> grad-norm -> AdamW), same shapes, same rules (barrier + sync both sides, max over
-    # ranks).  Eager launches: the backward is not graph-captured yet.
+    # ---- secondary figure: the VQ codebook nearest-neighbour micro-bench of SURVEY 8(d): x = randn(N, 64), codebook =
+    # randn(C, 64), N = 65 536, C in {512, 1024, 8192}, seed 0.  Bound: the fp32 vector ALU -- the bit-exact distance is three
+    # UN-fused lane operations per (n, c, e) (sub, mul, add in ATen's order), so the ceiling is the VALU's lane-op rate
+    # (half the 157.3 TFLOP/s FMA peak); HBM traffic (N*E*4 in, N*8 out, codebook resident) is two orders below its roof.
+    vq = None
+    if not a.no_cone:
+        vq = []
+        gvq = torch.Generator(device='cpu').manual_seed(0)
+        Nq, Eq = 65536, 64
+        xq = torch.randn(Nq, Eq, generator=gvq).to(dev)
+        for Cq in (512, 1024, 8192):
+            cbq = torch.randn(Cq, Eq, generator=gvq).to(dev)
+            vq_ms = time_kernel(lambda: ops.vq_argmin(xq, cbq), 10)
+            lane_ops = 3.0 * Nq * Cq * Eq
+            vq.append({'N': Nq, 'C': Cq, 'E': Eq, 'ms': vq_ms, 'rows_per_s': Nq / (vq_ms * 1e-3),
+                       'roofline': {'bound': 'valu-f32', 'achieved': lane_ops / (vq_ms * 1e-3) / 1e12, 'peak': 78.65,
+                                    'unit': 'T lane-op/s', 'frac': lane_ops / (vq_ms * 1e-3) / 1e12 / 78.65},
+                       'hbm_GBs': (Nq * Eq * 4 + Nq * 8) / (vq_ms * 1e-3) / 1e9})
+        log('vq argmin: ' + ', '.join(f"C={v['C']} {v['ms'] * 1e3:.0f} us ({v['roofline']['frac']:.2f} of the f32 VALU)" for v in vq))
+    out['vq_argmin'] = vq
+    # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand
+    # re-pack), same shapes, same rules (barrier + sync both sides, max over ranks).  One GPU: the whole step is ONE hipGraph
+    # replay (DenoiserTrainer.enable_graph) plus the loss-aware sampler's one host read-back per step.  n_gpus > 1: eager
+    # launches with the per-layer gradient all-reduce buckets overlapped on a side stream.
     train = None
     if a.train_steps > 0:
         from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame
         model.train()
         tr = DenoiserTrainer(model, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=world > 1)
         rfix = torch.full((cfg['B'],), 0.5)
-
-        def tstep():
-            tr.arena.zero_grad()
-            zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
-            tr.forward_backward(zc, tgt)
-            tr.optimizer_step()
+        graphed = world == 1 and not a.eager
+        if graphed:
+            tr.enable_graph(z)
+            tstep = lambda: tr.train_step(z, r=rfix)  # noqa: E731
+        else:
+            def tstep():
+                tr.arena.zero_grad()
+                zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
+                tr.forward_backward(zc, tgt)
+                tr.optimizer_step()
         for _ in range(5):
             tstep()
         barrier()
@@ -347,11 +391,28 @@ def main():
             t = torch.tensor([tel], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             tel = float(t.item())
+        tms = tel / a.train_steps * 1e3
+        # a training step is ~3x the forward's flops (no recompute of the attention core: the backward works
+        # from the saved log-sum-exp); bytes likewise ~3x the forward's algorithmic bytes (activations written once, read by
+        # the backward, gradients written once)
+        D_, I_, M_, L_ = cfg['dim'], cfg['dim_head'] * cfg['heads'], cfg['mlp_dim'], cfg['depth']
+        Kw = (2 * cfg['extents'][0] + 1) * (2 * cfg['extents'][1] + 1) * (2 * cfg['extents'][2] + 1)
+        fwd_flops = L_ * (6.0 * N * D_ * I_ + 4.0 * N * Kw * I_ + 2.0 * N * I_ * D_ + 4.0 * N * D_ * M_) \
+            + 2.0 * cfg['B'] * cfg['H'] * cfg['W'] * D_ * cfg['C']
         train = {'value': cfg['B'] * cfg['S'] * world * a.train_steps / tel, 'unit': 'latent-frames/s',
-                 'ms_per_step': tel / a.train_steps * 1e3, 'steps': a.train_steps,
-                 'what': 'corrupt + forward + CE + backward + (overlapped RCCL gradient all-reduce) + grad-norm + AdamW, '
-                         'eager launches', 'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0}
-        log(f'train step {train["ms_per_step"]:.2f} ms')
+                 'ms_per_step': tms, 'steps': a.train_steps,
+                 'what': 'corrupt + forward + CE + backward + grad-norm + AdamW + operand re-pack: '
+                         + ('ONE hipGraph replay per step + the sampler\'s host read-back' if graphed else
+                            'eager launches, per-layer RCCL gradient all-reduce overlapped on a side stream'),
+                 'launch_mode': 'hipGraph' if graphed else 'eager',
+                 'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0,
+                 'train_roofline': {'algorithmic_flops_per_step': 3.0 * fwd_flops,
+                                    'achieved_TFLOPs': 3.0 * fwd_flops / (tms * 1e-3) / 1e12, 'mfma_peak_TFLOPs': 2500.0,
+                                    'frac_of_mfma_peak': 3.0 * fwd_flops / (tms * 1e-3) / 1e12 / 2500.0,
+                                    'algorithmic_bytes_per_step': 3 * step_bytes,
+                                    'achieved_GBs': 3 * step_bytes / (tms * 1e-3) / 1e9,
+                                    'frac_of_8TBs': 3 * step_bytes / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        log(f'train step {train["ms_per_step"]:.2f} ms ({train["launch_mode"]})')
     out['train_step'] = train
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
