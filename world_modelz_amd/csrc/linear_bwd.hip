@@ -254,6 +254,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
       }
     }
   };
+  // a thread always lands on the same chunk column (NT is a multiple of CPR): its LayerNorm affine lives in registers
+  float gam[EPC], bet[EPC];
+  if constexpr (PRO == 1) {
+    const int kc0 = k0 + (tid % CPR) * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { gam[e] = kc0 + e < P.K ? P.gamma[kc0 + e] : 0.f; bet[e] = kc0 + e < P.K ? P.beta[kc0 + e] : 0.f; }
+  }
   // the prologue arithmetic runs when the slab goes to LDS, not when it is requested: the loads stay in flight
   auto stash = [&](auto setc, int buf) {
     constexpr int S = decltype(setc)::value;
@@ -270,16 +277,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
           float f[EPC];
           unpack_chunk<T>(v, f);
           if constexpr (PRO == 1) {
-            const float mu = lmu[S][it], rs = lrs[S][it];
+            const float rs = lrs[S][it], mr = -lmu[S][it] * rs;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k0 + c * EPC + e] + P.beta[k0 + c * EPC + e];
-            if (rs == 0.f) {
-#pragma unroll
-              for (int e = 0; e < EPC; ++e) f[e] = 0.f;          // rows past the slice
-            }
+            for (int e = 0; e < EPC; ++e) f[e] = fmaf(fmaf(f[e], rs, mr), gam[e], bet[e]);
           } else {
+            // bf16: the fitted GELU of the fused forward (2.6e-5 abs from the erf form, two orders below bf16 resolution)
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
+            for (int e = 0; e < EPC; ++e) f[e] = sizeof(T) == 2 ? wmz_gelu_fast(f[e]) : gelu_erf(f[e]);
           }
           v = pack_chunk<T>(f);
         }
@@ -376,7 +380,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
 
   // D: row (n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (k') = lane&31
   const int l31 = lane & 31, hh = lane >> 5;
-  float* part = ws != nullptr ? ws + (long)split * P.N * P.K : nullptr;
+  // workspace layout [256-float block of dW][slice][256]: the reduction then streams 64 KB runs instead of gathering one KB
+  // from each of the slices 256 KB apart (same HBM channel, a new DRAM row every time)
+  const long nblk256 = ((long)P.N * P.K + 255) >> 8;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -387,13 +393,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
       for (int reg = 0; reg < 16; ++reg) {
         const int n = n0 + wn + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
         if (n < P.N) {
-          if (part != nullptr) part[(long)n * P.K + kc] = acc[i][j][reg];
-          else atomicAdd(P.dW + (long)n * P.K + kc, acc[i][j][reg]);
+          const long q = (long)n * P.K + kc;
+          if (ws != nullptr) ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[i][j][reg];
+          else atomicAdd(P.dW + q, acc[i][j][reg]);
         }
       }
     }
   if (P.dbias != nullptr && bk == 0 && tid < WG_BN && n0 + tid < P.N) {
-    if (ws != nullptr) ws[(long)P.nsplit * P.N * P.K + (long)split * P.N + n0 + tid] = bsum;
+    if (ws != nullptr) ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = bsum;
     else atomicAdd(P.dbias + n0 + tid, bsum);
   }
 }
@@ -410,14 +417,15 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     const long q = ((long)blockIdx.x * 64 + lane) * 4;
     f32x4 a = (f32x4)(0.f);
     if (q < NK) {
+      const float* base = ws + ((long)blockIdx.x * nsplit << 8) + lane * 4;       // this block's [slice][256] run
       int s = wave;
       for (; s + 48 < nsplit; s += 64) {
         f32x4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(ws + (long)(s + 16 * u) * NK + q);
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + ((long)(s + 16 * u) << 8));
         a += (v[0] + v[1]) + (v[2] + v[3]);
       }
-      for (; s < nsplit; s += 16) a += *reinterpret_cast<const f32x4*>(ws + (long)s * NK + q);
+      for (; s < nsplit; s += 16) a += *reinterpret_cast<const f32x4*>(base + ((long)s << 8));
     }
     red[wave][lane] = a;
     __syncthreads();
@@ -429,12 +437,28 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
       *d = *d + t;
     }
   } else if (dbias != nullptr) {
-    const long n = ((long)blockIdx.x - nblk_w) * 1024 + threadIdx.x;
+    // bias: 64 entries per workgroup, the slices spread over the 16 waves like above (a thread per entry walking all the
+    // slices serially costs one memory round trip per few slices: 20+ us for 128 slices)
+    const long n = ((long)blockIdx.x - nblk_w) * 64 + lane;
+    const float* wb = ws + ((long)nblk_w * nsplit << 8);
+    float a = 0.f;
     if (n < N) {
-      float a = 0.f;
-      const float* wb = ws + (long)nsplit * NK;
-      for (int s = 0; s < nsplit; ++s) a += wb[(long)s * N + n];
-      dbias[n] += a;
+      int s = wave;
+      for (; s + 48 < nsplit; s += 64) {
+        const float v0 = wb[(long)s * N + n], v1 = wb[(long)(s + 16) * N + n];
+        const float v2 = wb[(long)(s + 32) * N + n], v3 = wb[(long)(s + 48) * N + n];
+        a += (v0 + v1) + (v2 + v3);
+      }
+      for (; s < nsplit; s += 16) a += wb[(long)s * N + n];
+    }
+    float* redf = reinterpret_cast<float*>(red);
+    redf[wave * 64 + lane] = a;
+    __syncthreads();
+    if (wave == 0 && n < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += redf[w * 64 + lane];
+      dbias[n] += t;
     }
   }
 }
@@ -641,7 +665,7 @@ static int wgrad_split(int M, int N, int K, int ms, int* rows_per_wg) {
 extern "C" long wmz_linear_wgrad_workspace_floats(int M, int N, int K, int dtype) {
   int rows;
   const int split = wgrad_split(M, N, K, dtype == WMZ_BF16 ? 64 : 32, &rows);
-  return (long)split * ((long)N * K + N);
+  return (long)split * ((((long)N * K + 255) >> 8) * 256 + N);
 }
 
 extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N,
@@ -670,7 +694,7 @@ extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long
   else { if (pro == 1) WMZ_WG2(float, 1); else if (pro == 2) WMZ_WG2(float, 2); else WMZ_WG2(float, 0); }
 #undef WMZ_WG2
   const long NK = (long)N * K;
-  const int nblk_w = wmz_cdiv(NK, 256), nblk_b = dbias != nullptr ? wmz_cdiv(N, 1024) : 0;
+  const int nblk_w = wmz_cdiv(NK, 256), nblk_b = dbias != nullptr ? wmz_cdiv(N, 64) : 0;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblk_w + nblk_b)), dim3(1024), 0, st, workspace, dW, dbias, P.nsplit, NK, N, nblk_w);
   WMZ_LAUNCH_CHECK("wmz_linear_wgrad_ws");
   return WMZ_OK;
