@@ -25,7 +25,7 @@ def timeit(fn, reps=50):
     return sorted(ts)[1]
 import os
 XF = int(os.environ.get('XF', '3'))
-for planes in (1, 4, 8, 16, 32, 64, 128, 256, 512):
+for planes in [int(p) for p in os.environ.get('PLANES', '1,4,8,16,32,64,128,256,512').split(',')]:
     x = torch.randn(planes, 16, 16, 256, device='cuda').bfloat16()
     o = torch.randn(planes, 16, 16, 128, device='cuda').bfloat16()
     with torch.no_grad():

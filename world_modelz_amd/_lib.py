@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libwmz_hip.so')
+LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16 = 0, 1
 WMZ_LIN_GELU = 1

@@ -27,7 +27,18 @@
 //     addresser right behind the barrier (SPLIT).
 #include "attn_common.h"
 
+// Compile-time ablations for timing experiments (tools/variants builds; results are garbage): bit 0 no LDS fragment reads,
+// bit 1 no softmax arithmetic, bit 2 no MFMAs.  0 in the product.
+#ifndef WMZ_ATTN_ABL
+#define WMZ_ATTN_ABL 0
+#endif
+
 namespace {
+
+template <typename A, typename B>
+__device__ __forceinline__ void mma16_abl(f32x4& acc, const A& a, const B& b) {
+  if constexpr (WMZ_ATTN_ABL & 4) { asm volatile("" :: "v"(a.v), "v"(b.v)); } else { mma16(acc, a, b); }
+}
 
 // development probes (the only process-wide state of the library, see include/wmz.h): stamp buffer and A/B knobs
 long long* g_attn_ts = nullptr;     // 16 waves x 64 int64, wmz_debug_attn_timestamps
@@ -264,18 +275,26 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           Frag8<bf16_t> ka, kb;
-          ka.v = *reinterpret_cast<const s16x8*>(Sb + ko + ks * 64);
-          kb.v = *reinterpret_cast<const s16x8*>(Sb + ko + 16 * I::KROW + ks * 64);
-          mma16(sc0, ka, qf[ks]);
-          mma16(sc1, kb, qf[ks]);
+          if constexpr (WMZ_ATTN_ABL & 1) { ka.v = qf[ks].v; kb.v = qf[ks].v; }
+          else {
+            ka.v = *reinterpret_cast<const s16x8*>(Sb + ko + ks * 64);
+            kb.v = *reinterpret_cast<const s16x8*>(Sb + ko + 16 * I::KROW + ks * 64);
+          }
+          mma16_abl(sc0, ka, qf[ks]);
+          mma16_abl(sc1, kb, qf[ks]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- V^T fragments requested now: their LDS latency runs under the softmax
         s16x4 x0[MT], x1[MT];
-        static_for<MT>([&](auto mt) {
-          x0[mt] = ds_read_tr16_asm<mt * 32>(va0);
-          x1[mt] = ds_read_tr16_asm<mt * 32>(va1);
-        });
+        if constexpr (WMZ_ATTN_ABL & 1) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) { x0[mt] = (s16x4)((short)va0); x1[mt] = (s16x4)((short)va1); }
+        } else {
+          static_for<MT>([&](auto mt) {
+            x0[mt] = ds_read_tr16_asm<mt * 32>(va0);
+            x1[mt] = ds_read_tr16_asm<mt * 32>(va1);
+          });
+        }
         issue_at(C1{}, false);
         if constexpr (PROBE) {
           const int kw = (2 * G.eW + 1), kh = (2 * G.eH + 1);
@@ -304,11 +323,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
                                __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
         if (first || __any(mx > DEFER)) rescale(mx, t);
         float p[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) p[r] = __builtin_amdgcn_exp2f(t[r]);
-        l_run += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         Frag8<bf16_t> pf;
-        frag_from_f32<bf16_t>(pf, p);
+        if constexpr (WMZ_ATTN_ABL & 2) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) pf.v[r] = (short)__builtin_bit_cast(int, sc0[r & 3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) p[r] = __builtin_amdgcn_exp2f(t[r]);
+          l_run += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+          frag_from_f32<bf16_t>(pf, p);
+        }
         issue_at(C2{}, false);
         // ---- O^T += V^T P^T
         ds_tr_wait();
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
           asm volatile("" : "+v"(x0[mt]), "+v"(x1[mt]));       // uses stay behind the wait
           Frag8<bf16_t> vf;
           vf.v = __builtin_shufflevector(x0[mt], x1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
-          mma16(o[mt], vf, pf);
+          mma16_abl(o[mt], vf, pf);
         }
         issue_at(C3{}, false);
       }

@@ -35,7 +35,11 @@
 namespace {
 
 constexpr int TW = 32;          // tokens per wave
-constexpr int FW = 8;           // waves per workgroup (two per SIMD: one's epilogue overlaps the other's MFMAs)
+#ifndef WMZ_FUSED_FW
+#define WMZ_FUSED_FW 8
+#endif
+constexpr int FW = WMZ_FUSED_FW; // waves per workgroup.  8: one workgroup of 256 tokens per CU (two waves per SIMD, one's epilogue
+                                // overlaps the other's MFMAs).  4: two independent workgroups of 128 tokens per CU, out of phase
 constexpr int NTHR = FW * 64;
 constexpr int HALF = 16384;     // granule of the weight stream: every GEMM stage is a whole number of these
 constexpr int PIECES = HALF / 1024;   // MFMA A operands per granule
@@ -44,8 +48,11 @@ constexpr int PIECES = HALF / 1024;   // MFMA A operands per granule
 #endif
 constexpr int HPS = WMZ_FUSED_HPS;    // granules per slab = per workgroup barrier (1: 16 KB slabs, ring of 4; 2: 32 KB, ring of 2)
 constexpr int SLAB = HPS * HALF;      // bytes per weight slab (one LDS-DMA burst, one barrier)
-constexpr int RING = HPS == 1 ? 4 : 2;   // LDS ring slots; RING-1 slabs of the weight stream stay in flight
-constexpr int WPP = SLAB / 1024 / 8;  // LDS-DMA pieces per wave per slab
+#ifndef WMZ_FUSED_RING
+#define WMZ_FUSED_RING (WMZ_FUSED_HPS == 1 ? 4 : 2)
+#endif
+constexpr int RING = WMZ_FUSED_RING;  // LDS ring slots; RING-1 slabs of the weight stream stay in flight
+constexpr int WPP = SLAB / 1024 / FW; // LDS-DMA pieces per wave per slab
 constexpr int VECB = 8192;      // the layer's bias / LayerNorm vectors (2048 fp32), staged once per workgroup
 constexpr int MC = 32;          // feed-forward hidden chunk: W1 rows / W2 columns streamed MC at a time
 
@@ -277,8 +284,12 @@ __device__ __forceinline__ void wait_untracked(Frag8<bf16_t> (&b)[KS]) {
 }
 // the 8 KB vector block by LDS-DMA: wave w moves KB w
 __device__ __forceinline__ void vec_dma(float* vecs, const float* src, int wave, int lane) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wave * 256 + lane * 4),
-                                   (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(vecs) + wave * 1024), 16, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 8 / FW; ++i) {
+    const int kb = wave * (8 / FW) + i;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kb * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(vecs) + kb * 1024), 16, 0, 0);
+  }
 }
 template <int NB>
 __device__ __forceinline__ void add_bop(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[2 * NB]) {
@@ -534,7 +545,7 @@ __device__ __forceinline__ void embed_coop(Frag8<bf16_t> (&bop)[F / 16], char* s
 }
 
 template <int D, int I, int M, bool HEAD, bool TAIL>
-__global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
+__global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P) {
   static_assert(D == 256 && M == 256 && I == 128, "built for the default denoiser widths");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -543,8 +554,8 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   float* vecs = reinterpret_cast<float*>(smem);
   const char* ring0 = smem + VECB;
   WStream ws;
-  ws.ring = smem + VECB + wave * (SLAB / 8);
-  ws.src = P.wpack + wave * (SLAB / 8) + lane * 16;
+  ws.ring = smem + VECB + wave * (SLAB / FW);
+  ws.src = P.wpack + wave * (SLAB / FW) + lane * 16;
   ws.half = 0;
   ws.issue_slot = 0;
   ws.cur = 0;
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
   const bool tile_ok = tok0 < P.ntok;
   const long tok0c = tile_ok ? tok0 : (P.ntok >= 32 ? P.ntok - 32 : 0);
   char* stg = smem + VECB + RING * SLAB + wave * 8192;                // this wave's store-staging image
-  static_assert(NTHR * 4 == 2048 && FW * 1024 == VECB, "vector block is 2048 floats, one KB per wave");
+  static_assert(VECB == 8192 && 8 % FW == 0, "vector block is 2048 floats, 8 / FW KB per wave");
   const float* v_bout = vecs + h * (D / 2);                            // bout[D] b1'[M] b2[D] bk'[I] bv'[I]
   const float* v_b1 = vecs + D + h * (MC / 2);
   const float* v_b2 = vecs + D + M + h * (D / 2);
@@ -689,10 +700,13 @@ __global__ __launch_bounds__(NTHR, 1) void layer_fused_kernel(FusedParams P) {
     }
     else if (P.xflags & WMZ_FUSED_X_IN_TILED) load_bop_tiled<D / 16>(xb, P.x + src_row(P, tok0c) * D, lane);
     else load_bop<D / 16>(xb, P.x + src_row(P, tokc) * D + h * (D / 2));
-    const f32x4 vecv = *reinterpret_cast<const f32x4*>(P.vec + tid * 4);
+    f32x4 vecv[8 / FW];
+#pragma unroll
+    for (int i = 0; i < 8 / FW; ++i) vecv[i] = *reinterpret_cast<const f32x4*>(P.vec + (tid + i * NTHR) * 4);
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) ws_issue(ws);
-    *reinterpret_cast<f32x4*>(vecs + tid * 4) = vecv;
+#pragma unroll
+    for (int i = 0; i < 8 / FW; ++i) *reinterpret_cast<f32x4*>(vecs + (tid + i * NTHR) * 4) = vecv[i];
     __syncthreads();
     if (P.z != nullptr) {
       if (P.xflags & WMZ_FUSED_X_OUT_TILED) { if (tile_ok) store_bop_tiled<D / 16>(P.xo + tok0 * D, xb, lane); }
