@@ -153,3 +153,19 @@ def test_untracked_loads_stay_untouched_until_their_wait():
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count('touches in between: 0') >= 2, r.stdout
+
+
+def test_lazy_one_hot_behaves_like_the_dense_encodings():
+    """VectorQuantizerEMA.forward returns `encodings` (reference vq.py:39) as a stand-in that materialises the dense one-hot
+    only when it is read: torch functions, tensor methods, indexing."""
+    from world_modelz_amd.vq import LazyOneHot
+    idx = torch.tensor([2, 0, 3, 3, 1])
+    e = LazyOneHot(idx, 4)
+    assert e.shape == (5, 1, 4) and e.dtype == torch.float32 and e._dense is None     # nothing built yet
+    dense = torch.nn.functional.one_hot(idx, 4).float().unsqueeze(1)
+    assert torch.equal(e.argmax(-1), idx.unsqueeze(1))
+    assert torch.equal(torch.sum(e, dim=0), dense.sum(0))
+    assert torch.equal(e.mean(dim=0), dense.mean(0)) and torch.equal(e[1], dense[1])
+    x = torch.randn(5, 8)
+    assert torch.allclose(torch.matmul(e.squeeze(1).t(), x), dense.squeeze(1).t() @ x)
+    assert torch.equal(e * 2.0, dense * 2.0) and float(e.sum()) == 5.0

@@ -192,6 +192,50 @@ def test_graphed_training_step_matches_eager(wmz, dtype):
         assert int(tg._g_ctr) == c1 + 1 and l1 != l2
 
 
+def test_training_step_full_size_properties(wmz):
+    """BASELINE configs[2] / [3] sizes (cfg-3: B = 16 clips of 16x16x16; cfg-4 per GPU: B = 8 of 32x16x16; codebook 1024,
+    default denoiser), where the CPU oracle takes minutes per clip: size-independent properties of one bf16 training step.
+      * fused training forward == op-by-op forward (loss and every gradient, bf16 tolerance) at full size;
+      * gradients are additive over clips: grad(mean loss over B clips) == mean over halves of grad(mean loss over each
+        half) -- the exactness of the data-parallel sharding, checked on the real kernels;
+      * a clip's per-sample loss does not depend on its batch neighbours (bit-exact)."""
+    from world_modelz_amd.train import cross_entropy_rows
+    cfg = wmz['config']
+    for (B, S) in ((16, 16), (8, 32)):
+        torch.manual_seed(77)
+        m = wmz['main'].VqVideoDiffusionModel(data_shape=(S, 16, 16), dim=256, num_classes=1024, extents=(3, 3, 3), depth=4,
+                                              dim_head=128, mlp_dim=256, heads=1).cuda().train()
+        z = torch.randint(0, 1025, (B, S, 16, 16), device='cuda')
+        tgt = torch.randint(0, 1024, (B, 16, 16), device='cuda')
+
+        def grads(zz, tt, fused_on):
+            cfg.set_fused_training(fused_on)
+            m.zero_grad(set_to_none=True)
+            with cfg.compute_dtype(torch.bfloat16):
+                y = m(zz)
+                loss = cross_entropy_rows(y.reshape(-1, 1024), tt.reshape(-1))
+                per = loss.view(zz.shape[0], -1).mean(1)
+                loss.mean().backward()
+            return per.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        try:
+            per_f, g_f = grads(z, tgt, True)
+            per_u, g_u = grads(z, tgt, False)
+            h = B // 2
+            per_a, g_a = grads(z[:h], tgt[:h], True)
+            per_b, g_b = grads(z[h:], tgt[h:], True)
+        finally:
+            cfg.set_fused_training(True)
+        assert torch.isfinite(per_f).all()
+        assert rel(per_f, per_u) < 5e-3
+        worst_fu = max(rel(g_f[n], g_u[n]) for n in g_f)
+        worst_add = max(rel(0.5 * (g_a[n] + g_b[n]), g_f[n]) for n in g_f)
+        print(f'[full-size step B={B} S={S}] fused vs op-by-op worst grad rel {worst_fu:.2e}; clip additivity {worst_add:.2e}')
+        assert worst_fu < 1.5e-2                     # measured 5-6e-3
+        assert worst_add < 2e-3                      # fp32 accumulation order only (the activations are identical)
+        assert torch.equal(per_a, per_f[:h]) and torch.equal(per_b, per_f[h:])
+        del m
+
+
 def test_fused_cross_entropy_vs_torch(wmz):
     tr = wmz['train']
     torch.manual_seed(5)
@@ -297,3 +341,100 @@ def test_bulk_operand_refresh_is_exact():
     with torch.no_grad():
         w1.mul_(2.0)                                     # an in-place change torch sees: the stale entry must not be served
     assert torch.equal(_cast.operand(w1, bf), w1.detach().to(bf))
+
+
+def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
+    """SURVEY 8(e) on ONE GPU: a world-1 `nccl` (= RCCL) process group, DenoiserTrainer(distributed=True).  The HIP backward
+    accumulates straight into the flat gradient arena and tells the reducer (`_wmz_ready`), which all-reduces each per-layer
+    bucket on a SIDE stream as soon as its last gradient has landed.  Checked: every bucket's collective is enqueued by the
+    backward itself (not by finish()), deepest layer first, the head's bucket before the layers', the embeddings' last; and
+    the step equals the non-distributed trainer's step."""
+    import os
+    import torch.distributed as dist
+    from world_modelz_amd import config, main, train
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        def make():
+            torch.manual_seed(21)
+            return main.VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=64, extents=(1, 1, 1), depth=3,
+                                              dim_head=128, mlp_dim=256, heads=1).cuda()
+        z = torch.randint(0, 64, (2, 3, 16, 16), device='cuda')
+        r = torch.zeros(2)
+        with config.compute_dtype(torch.bfloat16):
+            md, ms = make(), make()
+            td = train.DenoiserTrainer(md, 64, lr=1e-3, warmup=0, distributed=True)
+            ts = train.DenoiserTrainer(ms, 64, lr=1e-3, warmup=0, distributed=False)
+            red = td.reducer
+            assert red is not None and red.active and red.world == 1
+            assert len(red.buckets) == 3 + 2                      # one per layer + embeddings + head
+            launched_by_backward = []
+            orig_finish = red.finish
+
+            def finish():
+                launched_by_backward.append(list(red.order))      # what the hooks enqueued before finish() ran
+                return orig_finish()
+            red.finish = finish
+            for _ in range(2):
+                ld, gd = td.train_step(z, r=r)
+                ls, gs = ts.train_step(z, r=r)
+                assert abs(ld - ls) < 1e-3 * max(1.0, abs(ls)) and abs(gd - gs) < 2e-2 * max(1.0, gs)
+        for order in launched_by_backward:
+            assert sorted(order) == list(range(5)), f'buckets left for finish(): {order}'
+            assert order[0] == 4 and order[-1] == 0               # head first, embeddings last
+            assert order[1:4] == [3, 2, 1]                        # layers back to front
+        for (n, a), b in zip(md.named_parameters(), ms.parameters()):
+            assert torch.allclose(a, b, rtol=0, atol=3e-3), n
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver\'s multi-GPU tier)')
+def test_two_rank_rccl_training_matches_single_process(tmp_path):
+    """Two ranks over RCCL: replicas stay bit-identical and the reduced gradient equals the single-process mean-loss
+    gradient (ranks are started as fresh child processes: nothing here has touched the GPU in them before)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'rank.py'
+    script.write_text(f'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+rank = int(os.environ['RANK']); torch.cuda.set_device(rank)
+dist.init_process_group('nccl', device_id=torch.device('cuda', rank))
+from world_modelz_amd import config, main, train
+torch.manual_seed(5)
+m = main.VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=64, extents=(1, 1, 1), depth=2, dim_head=128, mlp_dim=256, heads=1).cuda()
+torch.manual_seed(6)
+z = torch.randint(0, 64, (4, 3, 16, 16), device='cuda')
+with config.compute_dtype(torch.bfloat16):
+    tr = train.DenoiserTrainer(m, 64, lr=1e-3, warmup=0, distributed=True)
+    for _ in range(3):
+        tr.train_step(z[2 * rank:2 * rank + 2], r=torch.zeros(2))
+flat = tr.arena.flat_param.clone()
+other = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(other, flat)
+assert torch.equal(other[0], other[1]), 'replicas diverged'
+if rank == 0:
+    torch.save(flat.cpu(), {str(tmp_path / "dp.pt")!r})
+dist.destroy_process_group()
+''')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29541', str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    from world_modelz_amd import config, main, train
+    torch.manual_seed(5)
+    m = main.VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=64, extents=(1, 1, 1), depth=2, dim_head=128,
+                                   mlp_dim=256, heads=1).cuda()
+    torch.manual_seed(6)
+    z = torch.randint(0, 64, (4, 3, 16, 16), device='cuda')
+    with config.compute_dtype(torch.bfloat16):
+        tr = train.DenoiserTrainer(m, 64, lr=1e-3, warmup=0, distributed=False)
+        for _ in range(3):
+            tr.train_step(z, r=torch.zeros(4))
+    dp = torch.load(str(tmp_path / 'dp.pt'))
+    assert torch.allclose(tr.arena.flat_param.cpu(), dp, rtol=0, atol=3e-3)

@@ -13,6 +13,64 @@ from . import ops
 from ._lib import WmzError
 
 
+class LazyOneHot:
+    """The `encodings` return value of VectorQuantizerEMA.forward (reference vq.py:39: a dense fp32 one-hot [N, 1, C]):
+    268 MB at N = 65 536, C = 1024, and no caller in scope reads it (train_vqae.py:38 drops it).  This stands in for the
+    tensor and builds it only when something actually looks at it: any torch function or tensor method applied to it
+    materialises the dense one-hot first (`.indices` gives the int64 codes without materialising anything)."""
+
+    def __init__(self, indices, num_embeddings):
+        self.indices = indices                      # int64 [N]
+        self._C = num_embeddings
+        self._dense = None
+
+    @property
+    def shape(self):
+        return torch.Size((self.indices.shape[0], 1, self._C))
+
+    dtype = torch.float32
+
+    @property
+    def device(self):
+        return self.indices.device
+
+    def materialize(self):
+        if self._dense is None:
+            N = self.indices.shape[0]
+            self._dense = torch.zeros(N, 1, self._C, device=self.indices.device).scatter_(-1, self.indices.view(N, 1, 1), 1.0)
+        return self._dense
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def dense(a):
+            if isinstance(a, cls):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(dense(b) for b in a)
+            return a
+        return func(*dense(args), **{k: dense(v) for k, v in (kwargs or {}).items()})
+
+    def __getattr__(self, name):                    # tensor methods / attributes: .argmax(-1), .sum(0), .size() ...
+        if name.startswith('__') and name.endswith('__'):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+
+def _binary(name):
+    def op(self, *args):
+        return getattr(self.materialize(), name)(*args)
+    return op
+
+
+for _n in ('add', 'radd', 'sub', 'rsub', 'mul', 'rmul', 'truediv', 'rtruediv', 'matmul', 'rmatmul', 'neg', 'eq', 'ne', 'lt',
+           'le', 'gt', 'ge', 'len', 'float', 'bool'):
+    setattr(LazyOneHot, f'__{_n}__', _binary(f'__{_n}__'))
+LazyOneHot.__hash__ = object.__hash__
+
+
 class VectorQuantizerEMA(nn.Module):
     def __init__(self, embedding_dim, num_embeddings, num_latents=1, decay=0.99, eps=1e-5):
         super().__init__()
@@ -67,17 +125,19 @@ class VectorQuantizerEMA(nn.Module):
         counts = torch.zeros(C, device=flat.device)
         dw = torch.zeros(C, self.embedding_dim, device=flat.device) if self.training else None
         ops.vq_ema_stats(flat.detach(), idx, cb, counts, dw, self.accumulated_error[0])   # :35-36 always, :43-46
-        encodings = torch.zeros(N, 1, C, device=flat.device).scatter_(-1, idx.view(N, 1, 1), 1.0)   # returned (:39)
+        encodings = LazyOneHot(idx, C)                                        # returned (:39), dense only if it is read
+        local_counts = counts
         if self.training:
             if self.sync_stats is not None and torch.distributed.is_initialized():
                 group = None if self.sync_stats is True else self.sync_stats
+                local_counts = counts.clone()
                 torch.distributed.all_reduce(counts, group=group)
                 torch.distributed.all_reduce(dw, group=group)
             ops.vq_ema_update(self.embedding, self.cluster_size, self.activation_count, counts, dw, self.decay, self.eps)
         quantized = quantized.view_as(input).to(input.dtype)
         commitment_loss = F.mse_loss(quantized.detach(), input)               # :67
         quantized = input + (quantized - input).detach()                      # straight-through (:70)
-        avg_probs = counts / N if self.sync_stats is None else encodings.mean(dim=0)[0]
+        avg_probs = local_counts / N                                          # == encodings.mean(0) (:72), this rank's batch
         perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10) / self.num_latents))
         return quantized, encodings, commitment_loss, perplexity
 
