@@ -28,6 +28,7 @@ SIGNATURES = {
     'wmz_local3d_attn_bwd': [c_void_p] * 10 + [c_int] * 9 + [c_long] * 8 + [c_int, c_void_p],
     'wmz_linear_wgrad': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                         + [c_int, c_int, c_void_p],
+    'wmz_linear_wgrad_workspace_floats': [c_int, c_int, c_int, c_int],      # returns long (restype set in lib())
     'wmz_linear_wgrad_ws': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                            + [c_int, c_void_p, c_long, c_int, c_void_p],
     'wmz_layernorm_stats': [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
@@ -96,15 +97,12 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.wmz_version.restype = c_int
         L.wmz_last_error.restype = ctypes.c_char_p
-        if hasattr(L, 'wmz_linear_wgrad_workspace_floats'):
-            L.wmz_linear_wgrad_workspace_floats.restype = c_long
-            L.wmz_linear_wgrad_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name, None)
             if fn is None:
                 continue  # declared but not built yet: calling it raises below
             fn.argtypes = argtypes
-            fn.restype = c_int
+            fn.restype = c_long if name.endswith('_workspace_floats') else c_int
         _lib = L
     return _lib
 
