@@ -250,3 +250,32 @@ def test_conv1x1_input_prologue(dtype, tol):
     assert err < tol, err
     assert float((fused.float() - two.float()).norm() / ref.norm()) < tol
     assert torch.allclose(s1, fused.float().sum(dim=(0, 1, 2)), rtol=2e-3, atol=2e-2)
+
+
+def test_vqae_trainer_step_matches_torch_adamw_and_revives_dead_codes(wmz):
+    """VqaeTrainer (train_vqae.py:125-164): one fp32 step from the reference capture's state == the captured gradients fed to
+    torch.optim.AdamW (lr 2e-4, weight decay 0); the StepLR epoch schedule; reuse_inactive + reset_stats on the interval."""
+    from world_modelz_amd import train
+    g = load_golden('ae_roundtrip')
+    m = _model(wmz, sub(g, 'sd1/'))
+    with wmz['config'].compute_dtype(torch.float32):
+        tr = train.VqaeTrainer(m, lr=2e-4, loss_fn='SmoothL1', latent_loss_weight=0.25, vq_reuse_interval=2, steps_per_epoch=1,
+                               distributed=False)
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        loss, r_loss, l_loss, ppl = tr.train_step(g['x'].cuda())
+    if abs(loss - float(g['train/loss'])) < 1e-5:              # no VQ index flipped at a near-tie
+        ref = {n: before[n].cpu().clone().requires_grad_(True) for n in before}
+        for n in ref:
+            ref[n].grad = g['train/grad/' + n].clone()
+        torch.optim.AdamW(list(ref.values()), lr=2e-4, betas=(0.9, 0.999), weight_decay=0.0).step()
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.detach().cpu(), ref[n].detach(), rtol=1e-4, atol=3e-6), n
+    assert tr.lr_now() == 2e-4
+    with wmz['config'].compute_dtype(torch.float32):
+        m.vq.activation_count[0, :5] = 0                         # pretend five codes were never used since the last reset
+        tr.train_step(g['x'].cuda())                              # step 2: interval hit
+    assert tr.step_count == 2 and float(m.vq.activation_count.sum()) == 0 and float(m.vq.accumulated_error.sum()) == 0
+    tr.step_count = 7
+    assert abs(tr.lr_now() - 2e-4 * 0.25) < 1e-12               # epoch 7 // 3 = 2 halvings
+    with pytest.raises(RuntimeError):
+        train.VqaeTrainer(m, loss_fn='Huber')

@@ -11,7 +11,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from . import _cast
+from . import _cast, ops
 from . import _lib as L
 from .parallel import BucketedAllReduce, FlatArena, broadcast_parameters, layer_bucket_key
 
@@ -57,6 +57,82 @@ def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None, ra
     L.call('wmz_corrupt_tokens', src.data_ptr() + (S - 1) * HW * 8, S * HW, L.ptr(r), out.data_ptr() + (S - 1) * HW * 8,
            S * HW, L.ptr(target), B, HW, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_id, L.stream())
     return out, target
+
+
+def corrupt_tokens(tokens, r, num_embeddings, generator=None, seed=None, rank=None):
+    """The same corruption law on a [B, n] token matrix (minecraft/sparse_diffusion.py:440-449: every gathered context token
+    is perturbed).  Returns (corrupted [B, n], target [B, n])."""
+    global _corrupt_calls
+    assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.dim() == 2
+    B, n = tokens.shape
+    src = tokens.contiguous()
+    out = torch.empty_like(src)
+    target = torch.empty_like(src)
+    r = r.reshape(-1).to(tokens.device, torch.float32).contiguous()
+    if seed is None:
+        seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+    rank = _dp_rank() if rank is None else int(rank)
+    _corrupt_calls += 1
+    L.call('wmz_corrupt_tokens', L.ptr(src), n, L.ptr(r), L.ptr(out), n, L.ptr(target), B, n, int(num_embeddings),
+           int(seed) & 0xFFFFFFFFFFFFFFFF, (rank << 40) | (_corrupt_calls & ((1 << 40) - 1)), L.stream())
+    return out, target
+
+
+class _LinearCrossEntropy(torch.autograd.Function):
+    """mean CrossEntropy(x W^T + b, target) WITHOUT the [R, C] logits in memory (config 5: R = 3072 rows per GPU x C = 8192
+    classes x fp32 = 100 MB, 800 MB for the global batch on one device): the rows are walked in chunks whose logits stay
+    cache-resident -- GEMM (fp32 out) -> row log-sum-exp and loss -> softmax - one_hot (already scaled by 1/R, bf16) -> its
+    dgrad and wgrad -- so the gradient w.r.t. x, W and b is complete when the forward returns; backward() only scales it."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, target, chunk):
+        from . import backward as Bk
+        R, K = x.shape
+        C = w.shape[0]
+        dt = x.dtype
+        w_c, wT = _cast.operand(w, dt), Bk._wt(w, dt, 'wT')
+        loss = torch.empty(R, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        wbuf, bbuf = getattr(w, '_wmz_grad', None), getattr(b, '_wmz_grad', None) if b is not None else None
+        direct = wbuf is not None and (b is None or bbuf is not None)
+        dw = wbuf if direct else torch.zeros(w.shape, dtype=torch.float32, device=x.device)
+        db = (bbuf if direct else torch.zeros(C, dtype=torch.float32, device=x.device)) if b is not None else None
+        ones = torch.full((min(chunk, R),), 1.0 / R, dtype=torch.float32, device=x.device)
+        target = target.contiguous()
+        for r0 in range(0, R, chunk):
+            r1 = min(R, r0 + chunk)
+            xs = x[r0:r1]
+            lg = ops.linear_fwd(xs, w_c, bias=None if b is None else b.detach(), out_f32=True)
+            lse = torch.empty(r1 - r0, dtype=torch.float32, device=x.device)
+            L.call('wmz_ce_fwd', L.ptr(lg), lg.stride(0), L.ptr(target[r0:r1]), L.ptr(loss[r0:r1]), L.ptr(lse), r1 - r0, C, L.stream())
+            d = torch.empty((r1 - r0, C), dtype=dt, device=x.device)
+            L.call('wmz_ce_bwd', L.ptr(lg), lg.stride(0), L.ptr(target[r0:r1]), L.ptr(lse), L.ptr(ones), L.ptr(d), r1 - r0, C,
+                   L.dtype_code(dt), L.stream())
+            dx[r0:r1] = ops.linear_dgrad(d, wT)
+            ops.linear_wgrad(d, xs, dw, db)
+        ctx.direct = direct
+        ctx.params = (w, b)
+        ctx.save_for_backward(dx, None if direct else dw, None if (direct or db is None) else db)
+        ctx.mark_non_differentiable(loss)
+        return loss.mean(), loss
+
+    @staticmethod
+    def backward(ctx, g, _g_rows):
+        dx, dw, db = ctx.saved_tensors
+        w, b = ctx.params
+        if ctx.direct:
+            # the arena already holds d(mean loss)/dW: only a plain `mean.backward()` (g == 1) is meaningful on this path
+            for p in (w, b):
+                ready = getattr(p, '_wmz_ready', None) if p is not None else None
+                if ready is not None:
+                    ready()
+            return dx * g.to(dx.dtype), None, None, None, None
+        return dx * g.to(dx.dtype), dw * g, (db * g if db is not None else None), None, None
+
+
+def linear_cross_entropy(x, w, b, target, chunk=1024):
+    """(mean loss, per-row loss [R], detached) of CrossEntropy(x W^T + b, target) over rows x: [R, K]."""
+    return _LinearCrossEntropy.apply(x, w, b, target, chunk)
 
 
 class _CrossEntropyRows(torch.autograd.Function):
@@ -131,8 +207,9 @@ def lr_at(step, base_lr, warmup, max_steps):
     return 0.5 * base_lr * (1 + math.cos(math.pi * max(e - warmup - 1, 0) / max_steps))
 
 
-class DenoiserTrainer:
-    """One object = model + flat arenas + AdamW state + (optional) data-parallel reducer."""
+class _TrainerBase:
+    """One object = model + flat arenas + AdamW state + (optional) data-parallel reducer; subclasses supply the step body
+    (DenoiserTrainer: main.py:216-287 on token grids; SparseDenoiserTrainer: minecraft/sparse_diffusion.py:398-467)."""
 
     def __init__(self, model, num_embeddings, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, warmup=500,
                  max_steps=200 * 1000, distributed=None, bucket_bytes=None, accumulation_steps=1):
@@ -178,11 +255,15 @@ class DenoiserTrainer:
         tr = self.model.transformer
         for attn, ff in tr.layers:
             a, f = attn.fn, ff.fn
-            bulk.add((a.to_q.weight,), dt, 'w')
-            bulk.add((a.to_q.weight,), dt, 'wqT', transpose=True)
-            bulk.add((a.to_k.weight, a.to_v.weight), dt, 'kv')
-            bulk.add((a.to_k.weight, a.to_v.weight), dt, 'kvT', transpose=True)
-            bulk.add((a.to_v.bias,), torch.float32, 'bkv', zero_first=True)
+            if hasattr(a, 'to_qkv'):                     # config 5: lucidrains ViT block with one fused projection
+                bulk.add((a.to_qkv.weight,), dt, 'w')
+                bulk.add((a.to_qkv.weight,), dt, 'wqkvT', transpose=True)
+            else:
+                bulk.add((a.to_q.weight,), dt, 'w')
+                bulk.add((a.to_q.weight,), dt, 'wqT', transpose=True)
+                bulk.add((a.to_k.weight, a.to_v.weight), dt, 'kv')
+                bulk.add((a.to_k.weight, a.to_v.weight), dt, 'kvT', transpose=True)
+                bulk.add((a.to_v.bias,), torch.float32, 'bkv', zero_first=True)
             if not isinstance(a.to_out, torch.nn.Identity):
                 bulk.add((a.to_out[0].weight,), dt, 'w')
                 bulk.add((a.to_out[0].weight,), dt, 'woutT', transpose=True)
@@ -193,16 +274,6 @@ class DenoiserTrainer:
         bulk.add((self.model.logit_proj.weight,), dt, 'w')
         bulk.add((self.model.logit_proj.weight,), dt, 'wT', transpose=True)
         return bulk
-
-    def forward_backward(self, batch_z, target, loss_scale=1.0):
-        """Forward, per-sample CE over the last frame, backward of loss.mean() * loss_scale (gradient accumulation:
-        main.py:274-278).  Returns (per_sample_loss[B], mean loss) on device."""
-        y = self.model(batch_z)
-        loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
-        per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
-        mean = loss.mean()
-        (mean if loss_scale == 1.0 else mean * loss_scale).backward()
-        return per_sample.detach(), mean.detach()
 
     def optimizer_step(self, lr=None):
         """Finish the all-reduce, grad-norm (device scalar, no sync), AdamW.  Returns the squared grad-norm tensor."""
@@ -219,6 +290,20 @@ class DenoiserTrainer:
         _cast.invalidate()            # the kernel rewrote the arena behind torch's version counters
         self.operands.refresh()       # ... and every operand copy of the weights is rebuilt by one launch
         return self.sq
+
+
+class DenoiserTrainer(_TrainerBase):
+    """The step body of vq-video-diffusion/main.py:train on [B,S,H,W] token clips (last frame corrupted and predicted)."""
+
+    def forward_backward(self, batch_z, target, loss_scale=1.0):
+        """Forward, per-sample CE over the last frame, backward of loss.mean() * loss_scale (gradient accumulation:
+        main.py:274-278).  Returns (per_sample_loss[B], mean loss) on device."""
+        y = self.model(batch_z)
+        loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
+        per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
+        mean = loss.mean()
+        (mean if loss_scale == 1.0 else mean * loss_scale).backward()
+        return per_sample.detach(), mean.detach()
 
     # ------------------------------------------------------------------------------------------------ hipGraph
     def enable_graph(self, example_batch, warmup=3):
@@ -309,3 +394,107 @@ class DenoiserTrainer:
         for rr, per_sample in seen:
             self.sampler.update_with_losses(rr, per_sample)   # the step's host sync (reference: ~50 per micro-batch)
         return float(loss_sum), math.sqrt(float(sq))
+
+
+class SparseDenoiserTrainer(_TrainerBase):
+    """The step body of minecraft/sparse_diffusion.py:train (:398-467) for VqSparseDiffusionModel (config 5): per clip,
+    `num_context` grid positions are drawn (uniformly, or from a frame window that widens with the noise level: :403-408),
+    their tokens gathered and corrupted with the same mask + uniform-redraw law (:440-449), the model predicts every
+    gathered token, CE over all of them (:455-462).  The 8192-way logits never exist in memory (linear_cross_entropy)."""
+
+    def __init__(self, model, num_embeddings, num_context=512, sampling_type='neighbors', **kw):
+        super().__init__(model, num_embeddings, **kw)
+        self.num_context = int(num_context)
+        if sampling_type not in ('uniform', 'neighbors'):
+            raise ValueError('Specified sampling_type not supported')          # sparse_diffusion.py:408
+        self.sampling_type = sampling_type
+
+    def sample_positions(self, B, r, device):
+        from .sparse_diffusion import sample_flat_positions, sample_time_dependent
+        S, H, W = self.model.shape
+        if self.sampling_type == 'uniform':
+            return sample_flat_positions(B, self.num_context, S, H, W, device)
+        return sample_time_dependent(B, self.num_context, S, H, W, r, device)
+
+    def forward_backward(self, tokens, indices, target, loss_scale=1.0):
+        """tokens / indices / target: [B, n].  Returns (per-sample loss [B], mean loss) on device."""
+        from . import functional as Fw
+        m = self.model
+        h = Fw.embed_tokens_indexed(tokens, indices, m.embedding.weight, m.pos_emb_s.weight, m.pos_emb_h.weight,
+                                    m.pos_emb_w.weight, m.shape)
+        h = m.transformer.forward_compute(h)
+        mean, rows = linear_cross_entropy(h.reshape(-1, h.shape[-1]), m.logit_proj.weight, m.logit_proj.bias, target.reshape(-1))
+        (mean if loss_scale == 1.0 else mean * loss_scale).backward()
+        return rows.view(tokens.shape[0], -1).mean(dim=1), mean.detach()
+
+    def train_step(self, batch_z, r=None, indices=None, generator=None):
+        """batch_z: [B,S,H,W] token clips (the frozen VQ-AE's output).  Returns (mean loss, grad norm)."""
+        B = batch_z.shape[0]
+        if r is None:
+            r = self.sampler.sample(B, generator=self.sampler_gen)
+        if indices is None:
+            indices = self.sample_positions(B, r, batch_z.device)
+        self.arena.zero_grad()
+        gathered = torch.gather(batch_z.reshape(B, -1), 1, indices)                  # :437
+        tokens, target = corrupt_tokens(gathered, r, self.C, generator, rank=self.rank)
+        per_sample, mean = self.forward_backward(tokens, indices, target)
+        sq = self.optimizer_step()
+        self.sampler.update_with_losses(r, per_sample)
+        return float(mean), math.sqrt(float(sq))
+
+
+class VqaeTrainer:
+    """The step body of vq-video-diffusion/train_vqae.py:train (:125-164) for the drop-in VqAutoEncoder: reconstruction loss
+    (SmoothL1 / MSE / L1, :264-271) + latent_loss_weight x commitment loss (:148), AdamW (lr 2e-4, weight decay 0: :254-256)
+    with the per-epoch StepLR(step_size 3, gamma 0.5) schedule (:262), and every `vq_reuse_interval` steps the dead-code
+    revival `vq.reuse_inactive()` + `vq.reset_stats()` (:160-164).  Parameters / gradients / moments live in one flat arena
+    (one grad-norm-free AdamW launch per step); under data parallelism the gradient buckets are all-reduced as for the
+    denoiser and the VQ EMA statistics are all-reduced inside VectorQuantizerEMA.forward (vq.sync_stats)."""
+
+    LOSSES = {'SmoothL1': F.smooth_l1_loss, 'MSE': F.mse_loss, 'MAE': F.l1_loss, 'L1': F.l1_loss}
+
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, loss_fn='SmoothL1',
+                 latent_loss_weight=0.01, vq_reuse_interval=500, steps_per_epoch=None, distributed=None):
+        if loss_fn not in self.LOSSES:
+            raise RuntimeError('Unsupported loss function type specified.')     # train_vqae.py:271
+        self.model, self.loss_fn = model, self.LOSSES[loss_fn]
+        self.latent_loss_weight, self.vq_reuse_interval = latent_loss_weight, vq_reuse_interval
+        self.arena = FlatArena(model)
+        self.m = torch.zeros_like(self.arena.flat_param)
+        self.v = torch.zeros_like(self.arena.flat_param)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.steps_per_epoch = steps_per_epoch
+        self.step_count = 0
+        if distributed is None:
+            distributed = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        self.reducer = BucketedAllReduce(self.arena, bucket_bytes=1 << 20, always=True) if distributed else None
+        if distributed:
+            broadcast_parameters(self.arena)
+            model.vq.sync_stats = True
+        self.reused = 0
+
+    def lr_now(self):
+        """StepLR(step_size=3, gamma=0.5) stepped once per epoch (train_vqae.py:192, :262)."""
+        if not self.steps_per_epoch:
+            return self.lr
+        return self.lr * 0.5 ** ((self.step_count // self.steps_per_epoch) // 3)
+
+    def train_step(self, batch):
+        """batch: [B, C, H, W] frames on the GPU.  Returns (loss, reconstruction loss, latent loss, perplexity) as floats."""
+        self.model.train()
+        self.arena.zero_grad()
+        recon, latent_loss, perplexity = self.model(batch)
+        r_loss = self.loss_fn(recon, batch)
+        loss = r_loss + self.latent_loss_weight * latent_loss
+        loss.backward()
+        scale = self.reducer.finish() if self.reducer is not None else 1.0
+        lr = self.lr_now()
+        self.step_count += 1
+        a = self.arena
+        L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel, float(lr),
+               self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), L.stream())
+        _cast.invalidate()
+        if self.vq_reuse_interval and self.step_count % self.vq_reuse_interval == 0:
+            self.reused = self.model.vq.reuse_inactive()
+            self.model.vq.reset_stats()
+        return float(loss), float(r_loss), float(latent_loss), float(perplexity)
