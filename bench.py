@@ -414,6 +414,40 @@ def main():
                                     'frac_of_8TBs': 3 * step_bytes / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         log(f'train step {train["ms_per_step"]:.2f} ms ({train["launch_mode"]})')
     out['train_step'] = train
+    # ---- secondary figure: BASELINE configs[4], the sparse masked-denoise path (minecraft/sparse_diffusion.py): 64-frame clips of
+    # 16x16 latents, codebook 8192, 512 context tokens per clip, dim 512 / 4 heads x 128 / depth 8 / mlp 1024, global batch 48 on
+    # 8 GPUs = 6 clips per GPU; one full training step (position sampling, gather, corruption, forward, chunked 8192-way
+    # linear + cross-entropy, backward, AdamW), eager launches.
+    sparse = None
+    if a.train_steps > 0 and not a.no_cone:
+        from world_modelz_amd.sparse_diffusion import VqSparseDiffusionModel
+        from world_modelz_amd.train import SparseDenoiserTrainer
+        del tr
+        torch.manual_seed(43)
+        sm = VqSparseDiffusionModel(shape=(64, 16, 16), dim=512, num_classes=8192, depth=8, dim_head=128, mlp_dim=1024, heads=4).to(dev)
+        st = SparseDenoiserTrainer(sm, 8192, num_context=512, lr=1e-4, warmup=500, distributed=world > 1)
+        zs = torch.randint(0, 8192, (6, 64, 16, 16), generator=gen).to(dev)
+        rs = torch.full((6,), 0.5)
+        for _ in range(3):
+            st.train_step(zs, r=rs)
+        barrier()
+        s0 = time.perf_counter()
+        nst = max(1, a.train_steps // 3)
+        for _ in range(nst):
+            st.train_step(zs, r=rs)
+        torch.cuda.synchronize()
+        barrier()
+        sel = time.perf_counter() - s0
+        if world > 1:
+            t = torch.tensor([sel], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            sel = float(t.item())
+        sparse = {'value': 6 * world * nst / sel, 'unit': 'clips/s', 'ms_per_step': sel / nst * 1e3, 'steps': nst,
+                  'tokens_per_s': 6 * 512 * world * nst / sel,
+                  'what': 'config 5 per GPU: 6 clips x 512 context tokens of 64x16x16 latents, codebook 8192, '
+                          'VqSparseDiffusionModel dim 512 / 4x128 / depth 8 / mlp 1024, full training step (eager launches)'}
+        log(f'sparse (config 5) train step {sparse["ms_per_step"]:.2f} ms')
+    out['sparse_step'] = sparse
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             log(f'cpu baseline on {usable_cores()} threads')

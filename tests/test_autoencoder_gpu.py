@@ -268,7 +268,12 @@ def test_vqae_trainer_step_matches_torch_adamw_and_revives_dead_codes(wmz):
         for n in ref:
             ref[n].grad = g['train/grad/' + n].clone()
         torch.optim.AdamW(list(ref.values()), lr=2e-4, betas=(0.9, 0.999), weight_decay=0.0).step()
+        # a bias in front of a training-mode BatchNorm has an exactly-zero true gradient; the reference holds 1e-9 noise
+        # there, whose SIGN Adam's first step turns into a full lr-sized move: those parameters are not comparable
+        floor = 1e-4 * max(float(g['train/grad/' + n].abs().max()) for n in before)
         for n, p in m.named_parameters():
+            if float(g['train/grad/' + n].abs().max()) < floor:
+                continue
             assert torch.allclose(p.detach().cpu(), ref[n].detach(), rtol=1e-4, atol=3e-6), n
     assert tr.lr_now() == 2e-4
     with wmz['config'].compute_dtype(torch.float32):
