@@ -162,9 +162,20 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   // ~55 scalar instructions of index arithmetic per wave there cost every wave ~1k cycles per slab.
   const unsigned rsk = 16u * ldk_b, rsv = 16u * ldv_b;                   // bytes per plane row of 16 keys
   const long psk = (long)HW * (long)ldk_b, psv = (long)HW * (long)ldv_b; // bytes per key plane
-  const char* kpl = (const char*)(K + ((long)b * G.S + sk_lo) * HW * G.ldk + (long)head * DH);   // next slab's key plane
-  const char* vpl = (const char*)(V + ((long)b * G.S + sk_lo) * HW * G.ldv + (long)head * DH);
-  int pl_n = 0, rem_n = 0, base_n = 0, jn = 0;                           // next slab: plane, slab in plane, first row, index
+  // Key planes are walked in a ROTATED order: at its t-th plane every workgroup reads the plane p = t (mod 2 eS + 1) of its
+  // window, so the 2 eS + 1 workgroups that need plane p (query planes p - eS .. p + eS, one per CU of the same XCD, started
+  // together and in step) stage it at the same time: one of them misses in L2, the others hit.  Walking s - eS .. s + eS in
+  // order instead, a plane is read at 2 eS + 1 different times and has left the 4 MiB L2 (the clip's K / V alone fill it) in
+  // between.  The softmax is order-independent (online), the logits probe records the plane it actually visits.
+  // (The phase counts planes from the END of the clip: the trailing-planes entry point hands over only the last planes of a
+  // clip, and its visiting order -- hence every rounding -- must be the full grid's.)
+  const int nwin = 2 * G.eS + 1;
+  int p_first = s - G.eS;
+  { const int a = (((G.S - 1 - p_first) % nwin) + nwin) % nwin; p_first += a; }          // first plane of the window with S-1-p = 0 (mod nwin)
+  if (p_first > sk_hi || p_first < sk_lo) p_first = sk_lo;
+  const char* kpl = (const char*)(K + ((long)b * G.S + p_first) * HW * G.ldk + (long)head * DH);   // next slab's key plane
+  const char* vpl = (const char*)(V + ((long)b * G.S + p_first) * HW * G.ldv + (long)head * DH);
+  int pl_n = p_first - sk_lo, rem_n = 0, base_n = 0, jn = 0;             // next slab: plane (from sk_lo), slab in plane, first row, index
   const char* kp = nullptr;
   const char* vp = nullptr;
   char* dbuf = nullptr;
@@ -178,7 +189,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   };
   auto advance = [&]() {                                                 // step (pl_n, rem_n) to the following slab
     ++jn;
-    if (++rem_n == nch) { rem_n = 0; ++pl_n; kpl += psk; vpl += psv; }
+    if (++rem_n == nch) {
+      rem_n = 0;
+      if (sk_lo + pl_n == sk_hi) { kpl -= (long)pl_n * psk; vpl -= (long)pl_n * psv; pl_n = 0; }     // wrap to the window's first plane
+      else { ++pl_n; kpl += psk; vpl += psv; }
+    }
   };
   auto issue_k = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
     for (int ks = 0; ks < KS; ++ks) frag_load(qf[ks], qrow + ks * 32 + g * 8);
   }
   WMZ_ATS(2);
-  int pl = 0, base = base_n;                              // current slab: key plane, plane row of slab row 0 (slab row r <-> base + 2r)
+  int pl = pl_n, base = base_n;                            // current slab: key plane, plane row of slab row 0 (slab row r <-> base + 2r)
   advance();
   next_state();                                          // slab 1's descriptors
   for (int j = 0; j < nslab; ++j) {
