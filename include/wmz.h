@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 100
+#define WMZ_VERSION 101
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
@@ -106,11 +106,12 @@ int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float
 /* nn.LayerNorm statistics (PreNorm, local_3d_attention.py:14): mean[M], rstd[M] over the K axis. */
 int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
                         void* stream);
-/* nn.LayerNorm backward: dx = dLN(x)^T dyhat + skip (skip optional: the residual / un-normalised-q gradient),
+/* nn.LayerNorm backward: dx = dLN(x)^T dyhat + skip + skip2 (both optional: the residual gradient and the gradient of the
+ * un-normalised q path, which land on the same tensor in x = attn(LN(x), q = x) + x),
  * dgamma[K] += sum_m dyhat*xhat, dbeta[K] += sum_m dyhat (fp32, atomics). */
 int wmz_layernorm_bwd(const void* x, long ldx, const void* dyhat, long lddy, const void* skip, long ldskip,
-                      const float* gamma, void* dx, long lddx, float* dgamma, float* dbeta, int M, int K, float eps,
-                      int dtype, void* stream);
+                      const void* skip2, long ldskip2, const float* gamma, void* dx, long lddx, float* dgamma,
+                      float* dbeta, int M, int K, float eps, int dtype, void* stream);
 
 /* ---- Local3dAttentionTransformer embedding (local_3d_attention.py:140-157):
  * x[b,s,h,w,:] = emb[z[b,s,h,w]] + ((pos_s[s] + pos_h[h]) + pos_w[w]); tables fp32, x in `dtype`. */
@@ -219,14 +220,17 @@ int wmz_layer_fused_pack(const float* wout, const float* bout, const float* g2, 
  * Besides the inference outputs they write what the backward (wmz_linear_wgrad, wmz_layernorm_bwd, wmz_local3d_attn_bwd
  * ..) reads, row-major: x1_out [ntok, D] = the feed-forward block's input (x + to_out(o)), x_out_rowmajor [ntok, D] = a
  * row-major copy of x_out when x_out itself is tiled (NULL otherwise), and kv_out as ONE [ntok, 2I] buffer (k | v column
- * halves).  The feed-forward pre-activation is not exported: the backward recomputes it with one LayerNorm-GEMM. */
+ * halves).  The feed-forward pre-activation is not exported: the backward recomputes it with one LayerNorm-GEMM.
+ * ln_ff_stats / ln_attn_stats (optional, fp32 [2, ntok]: means then reciprocal standard deviations): the statistics of the
+ * two LayerNorms the kernel applies -- in front of the feed-forward, and in front of the next layer's k | v -- for the
+ * backward (wmz_linear_wgrad's LayerNorm prologue, wmz_linear_fwd_stats), which otherwise spends a pass per LayerNorm. */
 int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_out, void* x_out_rowmajor, void* x1_out, void* q_out,
-                              void* kv_out, const void* wpack, const float* vec, int ntok, int D, int I, int M,
-                              int has_head, int has_tail, int xflags, float eps, void* stream);
+                              void* kv_out, float* ln_ff_stats, float* ln_attn_stats, const void* wpack, const float* vec,
+                              int ntok, int D, int I, int M, int has_head, int has_tail, int xflags, float eps, void* stream);
 int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                   const float* pos_w, void* x_out, void* x_out_rowmajor, void* q_out, void* kv_out,
-                                  const void* wpack, const float* vec, int B, int S, int H, int W, int D, int I, int M,
-                                  int num_classes, int xflags, float eps, void* stream);
+                                  float* ln_attn_stats, const void* wpack, const float* vec, int B, int S, int H, int W,
+                                  int D, int I, int M, int num_classes, int xflags, float eps, void* stream);
 
 /* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
  * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */

@@ -32,7 +32,7 @@ SIGNATURES = {
     'wmz_linear_wgrad_ws': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                            + [c_int, c_void_p, c_long, c_int, c_void_p],
     'wmz_layernorm_stats': [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
-    'wmz_layernorm_bwd': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
+    'wmz_layernorm_bwd': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                           c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_embed_pos3d_bwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],
     'wmz_linear_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
@@ -47,8 +47,8 @@ SIGNATURES = {
     'wmz_layer_fused_fwd': [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p],
     'wmz_operands_refresh': [c_void_p] * 7 + [c_int, c_void_p],
     'wmz_layer_fused_pack': [c_void_p] * 16 + [c_int] * 3 + [c_void_p],
-    'wmz_layer_fused_fwd_train': [c_void_p] * 9 + [c_int] * 7 + [c_float, c_void_p],
-    'wmz_embed_qkv_fused_fwd_train': [c_void_p] * 11 + [c_int] * 9 + [c_float, c_void_p],
+    'wmz_layer_fused_fwd_train': [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p],
+    'wmz_embed_qkv_fused_fwd_train': [c_void_p] * 12 + [c_int] * 9 + [c_float, c_void_p],
     'wmz_layer_fused_fwd_planes': [c_void_p] * 7 + [c_int] * 10 + [c_float, c_void_p],
     'wmz_embed_qkv_fused_fwd_planes': [c_void_p] * 10 + [c_int] * 10 + [c_float, c_void_p],
     'wmz_local3d_attn_fwd_planes': [c_void_p] * 5 + [c_int] * 9 + [c_long] * 4 + [c_int, c_int, c_int, c_void_p],

@@ -112,11 +112,8 @@ def attention_block_backward(ctx, dy):
     dxhat = ops.linear_dgrad(dkv, wkvT)                      # gradient w.r.t. LN(x_kv) (or x_kv without a norm)
     fold_q = same_src                                        # attn(x, q=x): the q path lands on the same tensor
     fold_res = ctx.has_res and ctx.res_is_xkv                # ... + x: so does the residual path
-    skip = None
-    if fold_q:
-        skip = dxq
-    if fold_res:
-        skip = d_res if skip is None else skip + d_res
+    skip = dxq if fold_q else None
+    skip2 = d_res if fold_res else None                      # both skips go into the LayerNorm backward: no separate add
     g_ln_g = g_ln_b = None
     dk, dv = dkv[..., :I], dkv[..., I:]
     if ln_g is not None:
@@ -126,12 +123,15 @@ def attention_block_backward(ctx, dy):
         holder = {}
 
         def fill_ln(gg, gb):
-            holder['dx'] = ops.layernorm_bwd(x_kv, dxhat, ln_g.detach(), gg, gb, skip=skip, eps=LN_EPS)
+            holder['dx'] = ops.layernorm_bwd(x_kv, dxhat, ln_g.detach(), gg, gb, skip=skip, eps=LN_EPS, skip2=skip2)
         g_ln_g, g_ln_b = _emit2(ln_g, ln_b, fill_ln)
         dx_kv = holder['dx']
     else:
         g_wk, g_wv, g_bv = _wgrad_kv(wk, wv, bv, dkv, x_kv, None, None)
-        dx_kv = dxhat if skip is None else dxhat + skip.reshape(dxhat.shape)
+        dx_kv = dxhat
+        for sk in (skip, skip2):
+            if sk is not None:
+                dx_kv = dx_kv + sk.reshape(dxhat.shape)
     g_xkv = dx_kv.reshape(x_kv.shape)
     g_xq = None if fold_q else dxq.reshape(x_q.shape)
     g_res = None if (not ctx.has_res or fold_res) else d_res

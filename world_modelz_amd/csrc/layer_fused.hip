@@ -80,6 +80,9 @@ struct FusedParams {
   // training forward (wmz_*_train): what the backward needs, row-major -- x1 (input of the feed-forward block), a row-major
   // copy of x_out beside the tiled one, and k | v as the column halves of one [ntok, 2I] buffer
   bf16_t* x1o; bf16_t* xo_rm; int kv_combined;
+  // ... and the LayerNorm statistics the kernel computes anyway (fp32 [2, ntok]: the means, then the reciprocal standard
+  // deviations): st_ff of LN2(x1) in front of the feed-forward, st_attn of LN1'(x2) in front of the next layer's k | v
+  float* st_ff; float* st_attn;
   long long* ts;        // timing probe (wmz_debug_fused_timestamps): workgroup 0 writes s_memtime at stage boundaries
 };
 // stage-boundary probe: wave w of workgroup 0 stores the shader clock into ts[w * 64 + slot]
@@ -436,19 +439,29 @@ __device__ __forceinline__ void ln_block(Frag8<bf16_t>& lo, Frag8<bf16_t>& hi, c
   pack8(lo, a);
   pack8(hi, b);
 }
+// training: mean / rstd of the lane pair's token leave through the lower lane half (two wave-level stores)
+__device__ __forceinline__ void put_stats(float* st, long tok, int ntok, float rstd, float mr, int lane) {
+  if (lane < 32 && tok < ntok) {
+    st[tok] = -mr / rstd;
+    st[(long)ntok + tok] = rstd;
+  }
+}
 template <int NB>
-__device__ __forceinline__ void ln_to_bop(Frag8<bf16_t> (&bop)[2 * NB], const f32x16 (&acc)[NB], float eps) {
+__device__ __forceinline__ void ln_to_bop(Frag8<bf16_t> (&bop)[2 * NB], const f32x16 (&acc)[NB], float eps, float* st = nullptr,
+                                          long tok = 0, int ntok = 0, int lane = 0) {
   float rstd, mr;
   ln_stats<NB>(acc, eps, rstd, mr);
+  if (st != nullptr) put_stats(st, tok, ntok, rstd, mr, lane);
 #pragma unroll
   for (int b = 0; b < NB; ++b) ln_block(bop[2 * b], bop[2 * b + 1], acc[b], rstd, mr);
 }
 // x2 (fp32) -> normalised operand and x2 itself as bf16, block by block (each block of xr dies as its operands appear)
 template <int NB>
 __device__ __forceinline__ void ln_and_pack(Frag8<bf16_t> (&lnb)[2 * NB], Frag8<bf16_t> (&xb)[2 * NB], const f32x16 (&acc)[NB],
-                                            float eps) {
+                                            float eps, float* st = nullptr, long tok = 0, int ntok = 0, int lane = 0) {
   float rstd, mr;
   ln_stats<NB>(acc, eps, rstd, mr);
+  if (st != nullptr) put_stats(st, tok, ntok, rstd, mr, lane);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     ln_block(lnb[2 * b], lnb[2 * b + 1], acc[b], rstd, mr);
@@ -620,7 +633,8 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
       ws_extra(ws, 16);
     }
     WMZ_TS(3);
-    ln_to_bop<D / 32>(xb, xr, P.eps);                     // LN2(x1)
+    ln_to_bop<D / 32>(xb, xr, P.eps, P.st_ff, tok, P.ntok, lane);   // LN2(x1)
+    if (P.st_ff != nullptr) ws_extra(ws, 2);
     WMZ_TS(4);
     // feed-forward, MC hidden units at a time: W1[c] -> GELU -> W2[c], with the stream packed as W1[0], W1[1], W2[0], W1[2],
     // W2[1], .., W1[7], W2[6], W2[7]: GELU(c) is VALU work that rides under the MFMAs of the two stages between W1[c] and
@@ -677,7 +691,10 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
     }
     add_vec<D / 32>(xr, v_b2);                                         //                 -> x2
     Frag8<bf16_t> x2b[D / 16];                                         // x2 as the stream carries it
-    if constexpr (TAIL) ln_and_pack<D / 32>(xb, x2b, xr, P.eps);   // + LN1'(x2), while x2 is still fp32
+    if constexpr (TAIL) {                                              // + LN1'(x2), while x2 is still fp32
+      ln_and_pack<D / 32>(xb, x2b, xr, P.eps, P.st_attn, tok, P.ntok, lane);
+      if (P.st_attn != nullptr) ws_extra(ws, 2);
+    }
     else bop_from_acc<D / 32>(x2b, xr);
     WMZ_TS(30);
     if (P.xflags & WMZ_FUSED_X_OUT_TILED) { if (tile_ok) store_bop_tiled<D / 16>(P.xo + tok0 * D, x2b, lane); }
@@ -721,7 +738,8 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
       bop_from_acc<I / 32>(qkvb, qa);
     }
     acc_from_bop<D / 32>(xr, xb);
-    ln_to_bop<D / 32>(xb, xr, P.eps);                   // LN1'(x)
+    ln_to_bop<D / 32>(xb, xr, P.eps, P.st_attn, tok, P.ntok, lane);   // LN1'(x)
+    if (P.st_attn != nullptr) ws_extra(ws, 2);
   }
   if constexpr (TAIL) {
     f32x16 ka[I / 32];
@@ -862,7 +880,8 @@ extern "C" int wmz_layer_fused_pack(const float* wout, const float* bout, const 
 }
 
 extern "C" int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_out, void* x_out_rowmajor, void* x1_out,
-                                         void* q_out, void* kv_out, const void* wpack, const float* vec, int ntok, int D, int I,
+                                         void* q_out, void* kv_out, float* ln_ff_stats, float* ln_attn_stats,
+                                         const void* wpack, const float* vec, int ntok, int D, int I,
                                          int M, int has_head, int has_tail, int xflags, float eps, void* stream) {
   WMZ_REQUIRE(x && wpack && vec && ntok > 0, "wmz_layer_fused_fwd_train: bad arguments");
   WMZ_REQUIRE(has_head || has_tail, "wmz_layer_fused_fwd_train: nothing to do");
@@ -876,13 +895,15 @@ extern "C" int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_o
   P.rows_out = P.rows_in = P.row0 = 0;
   P.xflags = xflags;
   P.x1o = (bf16_t*)x1_out; P.xo_rm = (bf16_t*)x_out_rowmajor; P.kv_combined = 1;
+  P.st_ff = ln_ff_stats; P.st_attn = has_tail ? ln_attn_stats : nullptr;
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
 extern "C" int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                              const float* pos_w, void* x_out, void* x_out_rowmajor, void* q_out,
-                                             void* kv_out, const void* wpack, const float* vec, int B, int S, int H, int W,
-                                             int D, int I, int M, int num_classes, int xflags, float eps, void* stream) {
+                                             void* kv_out, float* ln_attn_stats, const void* wpack, const float* vec, int B,
+                                             int S, int H, int W, int D, int I, int M, int num_classes, int xflags, float eps,
+                                             void* stream) {
   WMZ_REQUIRE(z && emb && pos_s && pos_h && pos_w && x_out && q_out && kv_out && wpack && vec, "wmz_embed_qkv_fused_fwd_train: null tensor");
   WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && num_classes > 0 && (long)B * S * H * W < (1L << 31), "wmz_embed_qkv_fused_fwd_train: bad shape");
   WMZ_REQUIRE((xflags & ~WMZ_FUSED_X_OUT_TILED) == 0 && (xflags == 0 || ((long)S * H * W) % 32 == 0), "wmz_embed_qkv_fused_fwd_train: bad layout flags");
@@ -893,6 +914,7 @@ extern "C" int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb,
   P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
   P.xflags = xflags;
   P.x1o = nullptr; P.xo_rm = (bf16_t*)x_out_rowmajor; P.kv_combined = 1;
+  P.st_ff = nullptr; P.st_attn = ln_attn_stats;
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 
@@ -918,6 +940,7 @@ extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_
   if (planes_out != planes_in) { P.rows_out = planes_out * HW; P.rows_in = planes_in * HW; P.row0 = (planes_in - planes_out) * HW; }
   P.xflags = xflags;
   P.x1o = nullptr; P.xo_rm = nullptr; P.kv_combined = 0;
+  P.st_ff = P.st_attn = nullptr;
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
@@ -947,6 +970,7 @@ extern "C" int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb
   P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
   P.xflags = xflags;
   P.x1o = nullptr; P.xo_rm = nullptr; P.kv_combined = 0;
+  P.st_ff = P.st_attn = nullptr;
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 

@@ -523,7 +523,8 @@ __global__ __launch_bounds__(NT) void ln_stats_kernel(const T* __restrict__ X, l
 // the same-address float atomics a 4-wave workgroup would send (those serialise in L2 and all arrive at the end).
 template <typename T, int KG>
 __global__ __launch_bounds__(1024 / KG) void ln_bwd_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY, long lddy,
-                                                    const T* __restrict__ SKIP, long ldskip, const float* __restrict__ gamma,
+                                                    const T* __restrict__ SKIP, long ldskip, const T* __restrict__ SKIP2,
+                                                    long ldskip2, const float* __restrict__ gamma,
                                                     T* __restrict__ DX, long lddx, float* __restrict__ dgamma,
                                                     float* __restrict__ dbeta, int M, int K, float eps) {
   constexpr int NTL = 1024 / KG;                        // 16 / 8 / 4 waves: the LDS partials stay at 32 KB
@@ -590,6 +591,12 @@ __global__ __launch_bounds__(1024 / KG) void ln_bwd_kernel(const T* __restrict__
       if (k0 < K) {
         float sk[4] = {0.f, 0.f, 0.f, 0.f}, out[4];
         if (SKIP) load4<T>(SKIP + (long)m * ldskip + k0, sk);
+        if (SKIP2) {
+          float s2[4];
+          load4<T>(SKIP2 + (long)m * ldskip2 + k0, s2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sk[e] += s2[e];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = rs * (gam[c][e] * dy[c][e] - c1 - xv[c][e] * c2) + sk[e];
         store4<T>(DX + (long)m * lddx + k0, out);
@@ -744,8 +751,8 @@ extern "C" int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* 
 }
 
 extern "C" int wmz_layernorm_bwd(const void* x, long ldx, const void* dyhat, long lddy, const void* skip, long ldskip,
-                                 const float* gamma, void* dx, long lddx, float* dgamma, float* dbeta, int M, int K,
-                                 float eps, int dtype, void* stream) {
+                                 const void* skip2, long ldskip2, const float* gamma, void* dx, long lddx, float* dgamma,
+                                 float* dbeta, int M, int K, float eps, int dtype, void* stream) {
   WMZ_REQUIRE(x && dyhat && gamma && dx && dgamma && dbeta, "wmz_layernorm_bwd: null tensor");
   WMZ_REQUIRE(M > 0 && K > 0 && K % 4 == 0, "wmz_layernorm_bwd: bad shape (K %% 4 == 0 required)");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_layernorm_bwd: bad dtype %d", dtype);
@@ -755,7 +762,7 @@ extern "C" int wmz_layernorm_bwd(const void* x, long ldx, const void* dyhat, lon
   const int rows_per_wg = 16 / kg * 4;
   const int grid = wmz_cdiv(M, rows_per_wg) < 256 * kg ? wmz_cdiv(M, rows_per_wg) : 256 * kg;
 #define WMZ_LNB(T, KG) hipLaunchKernelGGL((ln_bwd_kernel<T, KG>), dim3(grid), dim3(1024 / KG), 0, st, (const T*)x, ldx, (const T*)dyhat, lddy, \
-                                          (const T*)skip, ldskip, gamma, (T*)dx, lddx, dgamma, dbeta, M, K, eps)
+                                          (const T*)skip, ldskip, (const T*)skip2, ldskip2, gamma, (T*)dx, lddx, dgamma, dbeta, M, K, eps)
   if (dtype == WMZ_BF16) { if (kg == 1) WMZ_LNB(bf16_t, 1); else if (kg == 2) WMZ_LNB(bf16_t, 2); else WMZ_LNB(bf16_t, 4); }
   else { if (kg == 1) WMZ_LNB(float, 1); else if (kg == 2) WMZ_LNB(float, 2); else WMZ_LNB(float, 4); }
 #undef WMZ_LNB

@@ -173,16 +173,18 @@ def _embed_train(tr, z, tiled):
     x_t = torch.empty((B, S, H, W, D_), dtype=bf, device=dev) if tiled else None
     q = torch.empty((B, S, H, W, I_), dtype=bf, device=dev)
     kv = torch.empty((B, S, H, W, 2 * I_), dtype=bf, device=dev)
+    st_attn = torch.empty((2, B * S * H * W), dtype=torch.float32, device=dev)       # LayerNorm statistics for the backward
     L.call('wmz_embed_qkv_fused_fwd_train', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
            L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
-           L.ptr(x_t if tiled else x_rm), L.ptr(x_rm if tiled else None), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
-           B, S, H, W, D_, I_, M_, tr.embedding.num_embeddings, X_OUT_TILED if tiled else 0, 1e-5, L.stream())
-    return (x_t if tiled else x_rm), x_rm, q, kv
+           L.ptr(x_t if tiled else x_rm), L.ptr(x_rm if tiled else None), L.ptr(q), L.ptr(kv), L.ptr(st_attn), L.ptr(wpack),
+           L.ptr(vec), B, S, H, W, D_, I_, M_, tr.embedding.num_embeddings, X_OUT_TILED if tiled else 0, 1e-5, L.stream())
+    return (x_t if tiled else x_rm), x_rm, q, kv, st_attn
 
 
 def _layer_train(o, x_in, head, tail, tiled):
-    """x_in: the stream in the layout the previous launch left it in (tiled if `tiled`).  Returns (x_next, x_rm, x1, q, kv):
-    x_next in that same layout for the next launch (None after the last layer), x_rm / x1 row-major for the backward."""
+    """x_in: the stream in the layout the previous launch left it in (tiled if `tiled`).  Returns (x_next, x_rm, x1, q, kv,
+    st_ff, st_attn): x_next in that same layout for the next launch (None after the last layer), x_rm / x1 row-major for the
+    backward, st_* the [2, ntok] LayerNorm statistics (feed-forward's norm; the next layer's attention norm or None)."""
     lead = o.shape[:-1]
     dev, bf = o.device, torch.bfloat16
     ntok = o.numel() // I_
@@ -194,10 +196,12 @@ def _layer_train(o, x_in, head, tail, tiled):
     q = torch.empty(lead + (I_,), dtype=bf, device=dev) if tail is not None else None
     kv = torch.empty(lead + (2 * I_,), dtype=bf, device=dev) if tail is not None else None
     xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if out_tiled else 0)
+    st_ff = torch.empty((2, ntok), dtype=torch.float32, device=dev)
+    st_attn = torch.empty((2, ntok), dtype=torch.float32, device=dev) if tail is not None else None
     L.call('wmz_layer_fused_fwd_train', L.ptr(o), L.ptr(x_in), L.ptr(x_t if out_tiled else x_rm),
-           L.ptr(x_rm if out_tiled else None), L.ptr(x1), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), ntok, D_, I_, M_,
-           1, 1 if tail is not None else 0, xflags, 1e-5, L.stream())
-    return (x_t if out_tiled else (x_rm if tail is not None else None)), x_rm, x1, q, kv
+           L.ptr(x_rm if out_tiled else None), L.ptr(x1), L.ptr(q), L.ptr(kv), L.ptr(st_ff), L.ptr(st_attn), L.ptr(wpack),
+           L.ptr(vec), ntok, D_, I_, M_, 1, 1 if tail is not None else 0, xflags, 1e-5, L.stream())
+    return (x_t if out_tiled else (x_rm if tail is not None else None)), x_rm, x1, q, kv, st_ff, st_attn
 
 
 def _layer_params(attn, ff):
@@ -223,14 +227,15 @@ class _TrainForward(torch.autograd.Function):
         layers = list(tr.layers)
         B, S, H, W = z.shape
         tiled = (H * W) % 32 == 0
-        x_cur, x_rm, q, kv = _embed_train(tr, z, tiled)
+        x_cur, x_rm, q, kv, st_attn = _embed_train(tr, z, tiled)
         saved = []
         for l, (attn, ff) in enumerate(layers):
             o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads, need_lse=True)
             x_in_rm = x_rm
-            x_cur, x_rm, x1, q_n, kv_n = _layer_train(o, x_cur, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None, tiled)
-            saved += [x_in_rm, q, kv, o, lse, x1]
-            q, kv = q_n, kv_n
+            x_cur, x_rm, x1, q_n, kv_n, st_ff, st_attn_n = _layer_train(o, x_cur, (attn, ff),
+                                                                       layers[l + 1] if l + 1 < len(layers) else None, tiled)
+            saved += [x_in_rm, q, kv, o, lse, x1, st_attn, st_ff]
+            q, kv, st_attn = q_n, kv_n, st_attn_n
         ctx.tr = tr
         ctx.save_for_backward(z, *saved)
         return x_rm
@@ -246,18 +251,18 @@ class _TrainForward(torch.autograd.Function):
         dy = dy.contiguous()
         for l in range(len(layers) - 1, -1, -1):
             attn, ff = layers[l]
-            x_in, q, kv, o, lse, x1 = saved[6 * l:6 * l + 6]
+            x_in, q, kv, o, lse, x1, st_attn, st_ff = saved[8 * l:8 * l + 8]
             an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
             dt = x1.dtype
             # feed-forward block: y = W2 GELU(W1 LN(x1) + b1) + b2 + x1
-            stats = ops.layernorm_stats(x1, LN_EPS)
+            stats = (st_ff[0], st_ff[1])                   # computed by the fused forward: no extra pass over x1
             zpre = ops.linear_fwd(x1, _cast.operand(w1, dt), bias=b1.detach(), ln=(fn_g.detach(), fn_b.detach()), ln_eps=LN_EPS,
                                   ln_stats=stats)
             cf = _Ctx((x1, fn_g, fn_b, w1, b1, w2, b2, zpre), has_res=True, res_is_x=True, ln_stats=stats)
             dx1, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2 = Bk.feed_forward_block_backward(cf, dy)[:7]
             # attention block: x1 = to_out(attn(LN(x), q = x)) + x
             ca = _Ctx((x_in, x_in, an_g, an_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse), extents=attn.fn.extents,
-                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, same_src=True, ln_stats=None)
+                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, same_src=True, ln_stats=(st_attn[0], st_attn[1]))
             r = Bk.attention_block_backward(ca, dx1)
             dy = r[0]
             grads[14 * l:14 * l + 14] = [r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]

@@ -230,15 +230,19 @@ def layernorm_stats(x, eps=1e-5):
     return mean, rstd
 
 
-def layernorm_bwd(x, dyhat, gamma, dgamma, dbeta, skip=None, eps=1e-5):
+def layernorm_bwd(x, dyhat, gamma, dgamma, dbeta, skip=None, eps=1e-5, skip2=None):
     x, M, ldx = _rows(x)
     dyhat, _, lddy = _rows(dyhat)
-    lds = 0
+    lds = lds2 = 0
+    if skip is None and skip2 is not None:
+        skip, skip2 = skip2, None
     if skip is not None:
         skip, _, lds = _rows(skip)
+    if skip2 is not None:
+        skip2, _, lds2 = _rows(skip2)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     K = x.shape[-1]
-    L.call('wmz_layernorm_bwd', L.ptr(x), ldx, L.ptr(dyhat), lddy, L.ptr(skip), lds, L.ptr(gamma), L.ptr(dx), K,
+    L.call('wmz_layernorm_bwd', L.ptr(x), ldx, L.ptr(dyhat), lddy, L.ptr(skip), lds, L.ptr(skip2), lds2, L.ptr(gamma), L.ptr(dx), K,
            L.ptr(dgamma), L.ptr(dbeta), M, K, float(eps), L.dtype_code(x.dtype), L.stream())
     return dx
 
