@@ -1,12 +1,24 @@
 // Local windowed 3D attention backward, fast path for 16-wide planes (bf16, dim_head in {32,64,128}).  Same math and the
-// same gather-form / two-role structure as attn_bwd.hip (which stays the general / fp32 path), with the forward fast
-// path's machinery (attn_fwd_row16.hip): key-row loop bounds + four column-window biases instead of per-element tests,
-// padded LDS rows (address = lane base + row offset + immediate), LDS-DMA double-buffered slabs of 8 plane rows.
+// same gather-form / two-role structure as attn_bwd.hip (which stays the general / fp32 path), on the forward fast path's
+// slab machinery (attn_fwd_row16.hip):
 //   MODE 0 (owner = one query row per wave, 16 waves):  dQ = scale * sum_j dS_ij K_j ;  delta_i = rowsum(dO_i * O_i)
 //   MODE 1 (owner = one key row per wave,    8 waves):  dK = scale * sum_i dS_ij Q_i ;  dV = sum_i P_ij dO_i
 // P_ij = exp2(c2 * s_ij + bias - lse2_i), dS_ij = P_ij (dO_i . V_j - delta_i).  Owner rows are MFMA B operands in registers,
 // the visiting rows' two tensors (K,V | Q,dO) are the slab images: row fragments for S^T and dP^T, transposed reads
 // (ds_read_b64_tr_b16) for acc^T += Y^T . dS^T.
+//
+// What the second version took over from the forward kernel:
+//   * a slab holds every OTHER row of a 16-row chunk (plane row = base + 2 * slab row): whatever its own row, a wave finds
+//     about half of its +-eH visiting rows in each slab.  With slabs of 8 CONSECUTIVE rows a wave did all of a plane's
+//     work in one slab and idled at the other's barrier -- up to twice the step-times per plane;
+//   * an odd last row of a slab is a 16-row step (4 + 4 MFMAs and MFMA 16x16x16 for the accumulation), not a half-empty
+//     32-row one;
+//   * the slab descriptors (64-bit bases, row limits) advance incrementally and AHEAD of the barrier, the per-lane LDS-DMA
+//     source offsets are computed once: right behind a barrier the CU's scalar unit is shared by all of its waves;
+//   * the visiting planes are walked in the order rotated by the plane index, so that the workgroups sharing a plane
+//     stage it at the same time (one L2 miss, the others hit);
+//   * the per-element arithmetic folds the constants: exponent = fma(s, c2, bias - lse2), dS = P * fma(dP, scale, -delta *
+//     scale) (MODE 0: both addends live in registers for the whole kernel).
 #include "attn_common.h"
 
 namespace {
@@ -17,25 +29,24 @@ template <int DH> struct BImg {
   static constexpr int ROWP = DH * 2 + 32;             // both read kinds hit this image: +32 B keeps tr reads conflict-free
   static constexpr int IMG = KC * 16 * ROWP;
   static constexpr int BUF = 2 * IMG + 2 * KC * 16 * 4; // Y1 | Y2 | visitor lse2 | visitor delta
+  static constexpr int PIECES = IMG / 1024;
   static_assert(IMG % 1024 == 0, "image must be whole 1 KB DMA pieces");
 };
 
-template <int DH, int NW>
-__device__ __forceinline__ void stage_img(char* dst, const bf16_t* plane, long ld, int row0, int last_row, int wave, int lane) {
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// byte offset (relative to plane row `base`) of the 16 bytes this lane fetches for DMA piece `piece`: slab row r = 16 t + w
+// is plane row base + 2 t, column w; pad chunks fetch chunk 0; rows past the plane are redirected to row_lim (never read)
+template <int DH>
+__device__ __forceinline__ unsigned bpiece_voff(int piece, int lane, unsigned ld_bytes, int row_lim) {
   constexpr int ROWP = BImg<DH>::ROWP;
-  constexpr int PIECES = BImg<DH>::IMG / 1024;
-#pragma unroll
-  for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
-    const int piece = wave + NW * i;
-    if (piece >= PIECES) break;
-    const int off = piece * 1024 + lane * 16;
-    const int r = off / ROWP;
-    int c = (off - r * ROWP) >> 4;
-    c = c < DH / 8 ? c : 0;
-    const int rr = min(r, last_row);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(plane + (long)(row0 + rr) * ld + c * 8),
-                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
-  }
+  const int off = piece * 1024 + lane * 16;
+  const int r = off / ROWP;
+  int c = (off - r * ROWP) >> 4;
+  c = c < DH / 8 ? c : 0;
+  const int prow = min(2 * (r >> 4), row_lim);
+  return (unsigned)((prow << 4) + (r & 15)) * ld_bytes + (unsigned)c * 16u;
 }
 
 struct RBwdPtrs {
@@ -46,11 +57,12 @@ struct RBwdPtrs {
   long ldx1, ldx2, ldy1, ldy2, ldo, ldg1, ldg2;
 };
 
-template <int DH, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtrs P, AttnGeom G) {
+template <int DH, int MODE, int NW, bool ALIGNED>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, AttnGeom G) {
   using I = BImg<DH>;
   constexpr int KS = DH / 32, MT = DH / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = (I::PIECES + NW - 1) / NW;          // DMA pieces per wave and image
+  __shared__ __attribute__((aligned(1024))) char smem[2 * I::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
@@ -62,7 +74,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtr
   const int b = lid / G.heads;
 
   const int HW = G.HW, H = G.H;
-  const int h = og * NW + wave;
+  const int h0 = og * NW;
+  const int h = h0 + wave;
   const bool active = h < H;
   const long plane_o = ((long)b * G.S + s) * HW;
   const float L2E = 1.4426950408889634f;
@@ -73,8 +86,96 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtr
 #pragma unroll
   for (int r = 0; r < 4; ++r) { const int d = 4 * g + r - li; bias[r] = (d <= G.eW && -d <= G.eW) ? 0.f : -INFINITY; }
 
+  // ---- slab geometry (as in attn_fwd_row16.hip)
+  const int my_lo = max(h - G.eH, 0), my_hi = min(h + G.eH, H - 1);
+  const int t_lo = max(h0 - G.eH, 0), t_hi = min(min(h0 + NW - 1, H - 1) + G.eH, H - 1);
+  const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
+  const int c_first = t_lo >> 4, c_last = t_hi >> 4;
+  const int nch = (c_last - c_first + 1) * 2;               // slabs per visiting plane: (16-row chunk) x (row parity)
+  const int nslab = (sk_hi - sk_lo + 1) * nch;
+  const unsigned ld1_b = (unsigned)P.ldy1 * 2u, ld2_b = (unsigned)P.ldy2 * 2u;
+  unsigned vo1[NP], vo2[NP];
+  if constexpr (ALIGNED) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      vo1[i] = bpiece_voff<DH>(wave + NW * i, lane, ld1_b, 14);
+      vo2[i] = bpiece_voff<DH>(wave + NW * i, lane, ld2_b, 14);
+    }
+  }
+  const unsigned rs1 = 16u * ld1_b, rs2 = 16u * ld2_b;
+  const long ps1 = (long)HW * (long)ld1_b, ps2 = (long)HW * (long)ld2_b;
+  const int nwin = 2 * G.eS + 1;
+  int p_first = s - G.eS;
+  { const int a = (((G.S - 1 - p_first) % nwin) + nwin) % nwin; p_first += a; }
+  if (p_first > sk_hi || p_first < sk_lo) p_first = sk_lo;
+  const char* y1pl = (const char*)(P.y1 + ((long)b * G.S + p_first) * HW * P.ldy1 + (long)head * DH);
+  const char* y2pl = (const char*)(P.y2 + ((long)b * G.S + p_first) * HW * P.ldy2 + (long)head * DH);
+  long vrow_pl = ((long)b * G.S + p_first) * HW;         // first (b, s, h, w) row index of the next slab's visiting plane
+  int pl_n = p_first - sk_lo, rem_n = 0, base_n = 0, jn = 0;
+  const char* y1p = nullptr;
+  const char* y2p = nullptr;
+  char* dbuf = nullptr;
+  int dlim = 14;
+  long vrow_n = 0;
+  auto next_state = [&]() {
+    base_n = ((c_first + (rem_n >> 1)) << 4) + (rem_n & 1);
+    y1p = y1pl + (unsigned)base_n * rs1;
+    y2p = y2pl + (unsigned)base_n * rs2;
+    dbuf = smem + (jn & 1) * I::BUF;
+    dlim = max(H - 1 - base_n, 0);
+    vrow_n = vrow_pl + (long)base_n * 16;
+  };
+  auto advance = [&]() {
+    ++jn;
+    if (++rem_n == nch) {
+      rem_n = 0;
+      if (sk_lo + pl_n == sk_hi) { y1pl -= (long)pl_n * ps1; y2pl -= (long)pl_n * ps2; vrow_pl -= (long)pl_n * HW; pl_n = 0; }
+      else { ++pl_n; y1pl += ps1; y2pl += ps2; vrow_pl += HW; }
+    }
+  };
+  auto issue = [&]() {                                   // all pieces of the slab described by the current state
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = wave + NW * i;
+      if (i * NW + NW <= I::PIECES || piece < I::PIECES) {
+        unsigned a, c;
+        if constexpr (ALIGNED) { a = vo1[i]; c = vo2[i]; }
+        else { a = bpiece_voff<DH>(piece, lane, ld1_b, dlim); c = bpiece_voff<DH>(piece, lane, ld2_b, dlim); }
+        __builtin_amdgcn_global_load_lds((gptr_t)(y1p + a), (lptr_t)(dbuf + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(y2p + c), (lptr_t)(dbuf + I::IMG + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // MODE 1: per-visitor (query) lse2 / delta of a slab (slab row r = 16 t + w <-> plane row base + 2 t, column w): plain
+  // loads issued BEFORE that slab's DMA (waiting for them never waits for the DMA), parked in registers during the previous
+  // slab's compute, written to LDS at its end
+  float vl = 0.f, vd = 0.f;
+  auto fetch_rows = [&]() {
+    vl = 0.f; vd = 0.f;
+    if (tid < KC * 16) {
+      const int prow = 2 * (tid >> 4);
+      if (prow <= dlim) {
+        const long row = vrow_n + (long)prow * 16 + (tid & 15);
+        vl = P.lse[row * G.heads + head] * L2E;
+        vd = P.delta[row * G.heads + head];
+      }
+    }
+  };
+  auto put_rows = [&](int slot) {
+    if (tid < KC * 16) {
+      float* vt = reinterpret_cast<float*>(smem + slot * I::BUF + 2 * I::IMG);
+      vt[tid] = vl;
+      vt[KC * 16 + tid] = vd;
+    }
+  };
+
+  next_state();
+  if constexpr (MODE == 1) { if (nslab > 0) { fetch_rows(); put_rows(0); } }
+  if (nslab > 0) issue();
+
+  // ---- owner rows (after the first slab's requests: both are in flight together)
   Frag8<bf16_t> x1f[KS], x2f[KS];
-  float own_lse = 0.f, own_del = 0.f;
+  float bl[4], nde = 0.f;                                // MODE 0: bias - own lse2 per column; -own delta * scale
   {
     const long row = plane_o + (active ? h : 0) * 16 + li;
     const bf16_t* r1 = P.x1 + row * P.ldx1 + (long)head * DH;
@@ -82,24 +183,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtr
     float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      frag_zero(x1f[ks]);
-      frag_zero(x2f[ks]);
-      if (active) {
-        frag_load(x1f[ks], r1 + ks * 32 + g * 8);
-        frag_load(x2f[ks], r2 + ks * 32 + g * 8);
-        if constexpr (MODE == 0) {
-          Frag8<bf16_t> of;
-          frag_load(of, P.o + row * P.ldo + (long)head * DH + ks * 32 + g * 8);
+      frag_load(x1f[ks], r1 + ks * 32 + g * 8);
+      frag_load(x2f[ks], r2 + ks * 32 + g * 8);
+      if constexpr (MODE == 0) {
+        Frag8<bf16_t> of;
+        frag_load(of, P.o + row * P.ldo + (long)head * DH + ks * 32 + g * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            dsum = fmaf(bf16_bits_to_f32((unsigned short)x2f[ks].v[j]), bf16_bits_to_f32((unsigned short)of.v[j]), dsum);
-        }
+        for (int j = 0; j < 8; ++j)
+          dsum = fmaf(bf16_bits_to_f32((unsigned short)x2f[ks].v[j]), bf16_bits_to_f32((unsigned short)of.v[j]), dsum);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bl[r] = bias[r];
     if constexpr (MODE == 0) {
       dsum = wave_groups_sum(dsum);
-      own_del = dsum;
-      own_lse = active ? P.lse[row * G.heads + head] * L2E : 0.f;
+      const float own_lse = P.lse[row * G.heads + head] * L2E;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bl[r] = bias[r] - own_lse;
+      nde = -dsum * G.scale;
       if (active && g == 0) P.delta[row * G.heads + head] = dsum;
     }
   }
@@ -114,107 +215,75 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtr
 
   const int rbase = li * I::ROWP + g * 16;                                  // row fragment: visitor row li, chunk g
   const int tbase = (4 * g + (li >> 2)) * I::ROWP + (li & 3) * 8;           // transposed read: rows 4g..4g+3, 4 columns
-  const int my_lo = max(h - G.eH, 0), my_hi = min(h + G.eH, H - 1);
-  const int h0 = og * NW;
-  const int t_lo = max(h0 - G.eH, 0), t_hi = min(min(h0 + NW - 1, H - 1) + G.eH, H - 1);
-  const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
-  const int nch = (t_hi - t_lo + KC) / KC;
-  const int nslab = (sk_hi - sk_lo + 1) * nch;
 
-  auto issue = [&](int j) {
-    const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
-    const long plane_v = ((long)b * G.S + (sk_lo + pl)) * HW;
-    const int nrow = min(KC, t_hi - c0 + 1) * 16;
-    char* buf = smem + (j & 1) * I::BUF;
-    stage_img<DH, NW>(buf, P.y1 + plane_v * P.ldy1 + (long)head * DH, P.ldy1, c0 * 16, nrow - 1, wave, lane);
-    stage_img<DH, NW>(buf + I::IMG, P.y2 + plane_v * P.ldy2 + (long)head * DH, P.ldy2, c0 * 16, nrow - 1, wave, lane);
-  };
-  // MODE 1: per-visitor (query) lse2 / delta of a slab: plain loads issued BEFORE that slab's DMA (so waiting for them
-  // never waits for the DMA), parked in registers during the previous slab's compute, written to LDS at its end
-  float vl = 0.f, vd = 0.f;
-  auto fetch_rows = [&](int j) {
-    vl = 0.f; vd = 0.f;
-    if (tid < KC * 16) {
-      const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
-      const long plane_v = ((long)b * G.S + (sk_lo + pl)) * HW;
-      if (tid < min(KC, t_hi - c0 + 1) * 16) {
-        vl = P.lse[(plane_v + c0 * 16 + tid) * G.heads + head] * L2E;
-        vd = P.delta[(plane_v + c0 * 16 + tid) * G.heads + head];
-      }
-    }
-  };
-  auto put_rows = [&](int j) {
-    if (tid < KC * 16) {
-      float* vt = reinterpret_cast<float*>(smem + (j & 1) * I::BUF + 2 * I::IMG);
-      vt[tid] = vl;
-      vt[KC * 16 + tid] = vd;
-    }
-  };
-  if constexpr (MODE == 1) { fetch_rows(0); put_rows(0); }
-  issue(0);
+  int base = base_n;
+  advance();
+  next_state();
   for (int j = 0; j < nslab; ++j) {
-    const int pl = j / nch, c0 = t_lo + (j - pl * nch) * KC;
-    const int c_hi = min(c0 + KC - 1, t_hi);
     const char* Y1s = smem + (j & 1) * I::BUF;
     const char* Y2s = Y1s + I::IMG;
     const float* vlse = reinterpret_cast<const float*>(Y1s + 2 * I::IMG);
     const float* vdel = vlse + KC * 16;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (j + 1 < nslab) {
-      if constexpr (MODE == 1) fetch_rows(j + 1);
-      issue(j + 1);
+    const bool more = j + 1 < nslab;
+    if (more) {
+      if constexpr (MODE == 1) fetch_rows();
+      issue();
     }
-    const int lo = active ? max(c0, my_lo) : 1, hi = active ? min(c_hi, my_hi) : 0;
-    for (int t0 = lo; t0 <= hi; t0 += 2) {
-      const bool has1 = t0 + 1 <= hi;
-      const int r0 = (t0 - c0) * 16, r1 = has1 ? r0 + 16 : r0;
-      const int ro0 = rbase + r0 * I::ROWP, ro1 = rbase + r1 * I::ROWP;
-      const int to0 = tbase + r0 * I::ROWP, to1 = tbase + r1 * I::ROWP;
-      f32x4 s0 = (f32x4)(0.f), s1 = (f32x4)(0.f), d0 = (f32x4)(0.f), d1 = (f32x4)(0.f);
+    const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
+    if (active) {
+      int t0 = lo;
+      for (; t0 + 1 <= hi; t0 += 2) {
+        // ---- two visiting rows: S^T and dP^T, then P, dS, then the accumulations
+        const int ro0 = rbase + t0 * 16 * I::ROWP, ro1 = ro0 + 16 * I::ROWP;
+        const int to0 = tbase + t0 * 16 * I::ROWP;
+        f32x4 s0 = (f32x4)(0.f), s1 = (f32x4)(0.f), d0 = (f32x4)(0.f), d1 = (f32x4)(0.f);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        Frag8<bf16_t> a0, a1, b0, b1;
-        a0.v = *reinterpret_cast<const s16x8*>(Y1s + ro0 + ks * 64);
-        a1.v = *reinterpret_cast<const s16x8*>(Y1s + ro1 + ks * 64);
-        b0.v = *reinterpret_cast<const s16x8*>(Y2s + ro0 + ks * 64);
-        b1.v = *reinterpret_cast<const s16x8*>(Y2s + ro1 + ks * 64);
-        mma16(s0, a0, x1f[ks]);
-        mma16(s1, a1, x1f[ks]);
-        mma16(d0, b0, x2f[ks]);
-        mma16(d1, b1, x2f[ks]);
-      }
-      f32x4 l0, l1, e0, e1;
-      if constexpr (MODE == 1) {
-        l0 = *reinterpret_cast<const f32x4*>(vlse + r0 + 4 * g);
-        l1 = *reinterpret_cast<const f32x4*>(vlse + r1 + 4 * g);
-        e0 = *reinterpret_cast<const f32x4*>(vdel + r0 + 4 * g);
-        e1 = *reinterpret_cast<const f32x4*>(vdel + r1 + 4 * g);
-      }
-      const float b1m = has1 ? 0.f : -INFINITY;
-      float pv[8], dsv[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ls0 = MODE == 1 ? l0[r] : own_lse, ls1 = MODE == 1 ? l1[r] : own_lse;
-        const float de0 = MODE == 1 ? e0[r] : own_del, de1 = MODE == 1 ? e1[r] : own_del;
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bias[r]) - ls0);
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, bias[r] + b1m) - ls1);
-        pv[r] = p0;
-        pv[4 + r] = p1;
-        dsv[r] = p0 * (d0[r] - de0) * G.scale;
-        dsv[4 + r] = p1 * (d1[r] - de1) * G.scale;
-      }
-      Frag8<bf16_t> dsf;
-      frag_from_f32<bf16_t>(dsf, dsv);
-      // transposed fragments by inline-asm reads: the builtin makes hipcc drain vmcnt (the next slab's LDS-DMA) in front
-      // of every one of them (wmz_common.h: ds_read_tr16_asm)
-      {
-        const unsigned ya0 = lds_addr(Y1s + to0), ya1 = lds_addr(Y1s + to1);
+        for (int ks = 0; ks < KS; ++ks) {
+          Frag8<bf16_t> a0, a1, b0, b1;
+          a0.v = *reinterpret_cast<const s16x8*>(Y1s + ro0 + ks * 64);
+          a1.v = *reinterpret_cast<const s16x8*>(Y1s + ro1 + ks * 64);
+          b0.v = *reinterpret_cast<const s16x8*>(Y2s + ro0 + ks * 64);
+          b1.v = *reinterpret_cast<const s16x8*>(Y2s + ro1 + ks * 64);
+          mma16(s0, a0, x1f[ks]);
+          mma16(s1, a1, x1f[ks]);
+          mma16(d0, b0, x2f[ks]);
+          mma16(d1, b1, x2f[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // transposed fragments of Y1 requested now (inline asm: the builtin makes hipcc drain the LDS-DMA in front of each)
+        const unsigned ya0 = lds_addr(Y1s + to0), ya1 = ya0 + 16 * I::ROWP;
         s16x4 x0[MT], x1[MT];
         static_for<MT>([&](auto mt) {
           x0[mt] = ds_read_tr16_asm<mt * 32>(ya0);
           x1[mt] = ds_read_tr16_asm<mt * 32>(ya1);
         });
+        float pv[8], dsv[8];
+        if constexpr (MODE == 1) {
+          const int r0 = t0 * 16 + 4 * g, r1 = r0 + 16;
+          const f32x4 l0 = *reinterpret_cast<const f32x4*>(vlse + r0), l1 = *reinterpret_cast<const f32x4*>(vlse + r1);
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(vdel + r0), e1 = *reinterpret_cast<const f32x4*>(vdel + r1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bias[r] - l0[r]));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, bias[r] - l1[r]));
+            pv[r] = p0;
+            pv[4 + r] = p1;
+            dsv[r] = p0 * ((d0[r] - e0[r]) * G.scale);
+            dsv[4 + r] = p1 * ((d1[r] - e1[r]) * G.scale);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bl[r]));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, bl[r]));
+            dsv[r] = p0 * fmaf(d0[r], G.scale, nde);
+            dsv[4 + r] = p1 * fmaf(d1[r], G.scale, nde);
+          }
+        }
+        Frag8<bf16_t> dsf;
+        frag_from_f32<bf16_t>(dsf, dsv);
         ds_tr_wait();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -223,29 +292,85 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_row16_kernel(RBwdPtr
           yf.v = __builtin_shufflevector(x0[mt], x1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
           mma16(acc1[mt], yf, dsf);
         }
+        if constexpr (MODE == 1) {
+          Frag8<bf16_t> pf;
+          frag_from_f32<bf16_t>(pf, pv);
+          const unsigned yb0 = lds_addr(Y2s + to0), yb1 = yb0 + 16 * I::ROWP;
+          s16x4 z0[MT], z1[MT];
+          static_for<MT>([&](auto mt) {
+            z0[mt] = ds_read_tr16_asm<mt * 32>(yb0);
+            z1[mt] = ds_read_tr16_asm<mt * 32>(yb1);
+          });
+          ds_tr_wait();
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            asm volatile("" : "+v"(z0[mt]), "+v"(z1[mt]));
+            Frag8<bf16_t> yf;
+            yf.v = __builtin_shufflevector(z0[mt], z1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
+            mma16(acc2[mt], yf, pf);
+          }
+        }
       }
-      if constexpr (MODE == 1) {
-        Frag8<bf16_t> pf;
-        frag_from_f32<bf16_t>(pf, pv);
-        const unsigned ya0 = lds_addr(Y2s + to0), ya1 = lds_addr(Y2s + to1);
-        s16x4 x0[MT], x1[MT];
-        static_for<MT>([&](auto mt) {
-          x0[mt] = ds_read_tr16_asm<mt * 32>(ya0);
-          x1[mt] = ds_read_tr16_asm<mt * 32>(ya1);
-        });
+      if (t0 <= hi) {
+        // ---- odd last visiting row of the slab: a 16-row step
+        const int ro0 = rbase + t0 * 16 * I::ROWP;
+        const int to0 = tbase + t0 * 16 * I::ROWP;
+        f32x4 s0 = (f32x4)(0.f), d0 = (f32x4)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          Frag8<bf16_t> a0, b0;
+          a0.v = *reinterpret_cast<const s16x8*>(Y1s + ro0 + ks * 64);
+          b0.v = *reinterpret_cast<const s16x8*>(Y2s + ro0 + ks * 64);
+          mma16(s0, a0, x1f[ks]);
+          mma16(d0, b0, x2f[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned ya0 = lds_addr(Y1s + to0);
+        s16x4 x0[MT];
+        static_for<MT>([&](auto mt) { x0[mt] = ds_read_tr16_asm<mt * 32>(ya0); });
+        float pv[4], dsv[4];
+        if constexpr (MODE == 1) {
+          const int r0 = t0 * 16 + 4 * g;
+          const f32x4 l0 = *reinterpret_cast<const f32x4*>(vlse + r0), e0 = *reinterpret_cast<const f32x4*>(vdel + r0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pv[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bias[r] - l0[r]));
+            dsv[r] = pv[r] * ((d0[r] - e0[r]) * G.scale);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dsv[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bl[r])) * fmaf(d0[r], G.scale, nde);
+        }
+        s16x4 dsf, pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsf[r] = (short)f32_to_bf16_bits(dsv[r]);
         ds_tr_wait();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          asm volatile("" : "+v"(x0[mt]), "+v"(x1[mt]));
-          Frag8<bf16_t> yf;
-          yf.v = __builtin_shufflevector(x0[mt], x1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
-          mma16(acc2[mt], yf, pf);
+          asm volatile("" : "+v"(x0[mt]));
+          acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x0[mt], dsf, acc1[mt], 0, 0, 0);
+        }
+        if constexpr (MODE == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pf[r] = (short)f32_to_bf16_bits(pv[r]);
+          const unsigned yb0 = lds_addr(Y2s + to0);
+          s16x4 z0[MT];
+          static_for<MT>([&](auto mt) { z0[mt] = ds_read_tr16_asm<mt * 32>(yb0); });
+          ds_tr_wait();
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            asm volatile("" : "+v"(z0[mt]));
+            acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(z0[mt], pf, acc2[mt], 0, 0, 0);
+          }
         }
       }
     }
     if constexpr (MODE == 1) {
-      if (j + 1 < nslab) put_rows(j + 1);
+      if (more) put_rows((j + 1) & 1);
     }
+    base = base_n;
+    advance();
+    next_state();
   }
   if (!active) return;
   const long orow = plane_o + h * 16 + li;
@@ -273,14 +398,8 @@ template <int DH, int MODE, int NW>
 int launch_one(const RBwdPtrs& P, AttnGeom G, hipStream_t st) {
   G.qgroups = wmz_cdiv(G.H, NW);
   const long nwg = (long)G.B * G.heads * G.S * G.qgroups;
-  const size_t smem = 2 * (size_t)BImg<DH>::BUF;
-  auto kern = attn_bwd_row16_kernel<DH, MODE, NW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), smem, st, P, G);
+  if ((G.H & 15) == 0) hipLaunchKernelGGL((attn_bwd_row16_kernel<DH, MODE, NW, true>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, P, G);
+  else hipLaunchKernelGGL((attn_bwd_row16_kernel<DH, MODE, NW, false>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, P, G);
   WMZ_LAUNCH_CHECK("wmz_local3d_attn_bwd(row16)");
   return WMZ_OK;
 }
