@@ -259,6 +259,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           x0[mt] = ds_read_tr16_asm<mt * 32>(ya0);
           x1[mt] = ds_read_tr16_asm<mt * 32>(ya1);
         });
+        // MODE 1 (two waves per SIMD, 256 registers): Y2's transposed fragments are requested here as well, so that BOTH
+        // accumulations run back to back behind one wait instead of read -> wait -> MFMA twice
+        s16x4 z0[MODE == 1 ? MT : 1], z1[MODE == 1 ? MT : 1];
+        if constexpr (MODE == 1) {
+          const unsigned yb0 = lds_addr(Y2s + to0), yb1 = yb0 + 16 * I::ROWP;
+          static_for<MT>([&](auto mt) {
+            z0[mt] = ds_read_tr16_asm<mt * 32>(yb0);
+            z1[mt] = ds_read_tr16_asm<mt * 32>(yb1);
+          });
+        }
         float pv[8], dsv[8];
         if constexpr (MODE == 1) {
           const int r0 = t0 * 16 + 4 * g, r1 = r0 + 16;
@@ -282,8 +292,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
             dsv[4 + r] = p1 * fmaf(d1[r], G.scale, nde);
           }
         }
-        Frag8<bf16_t> dsf;
+        Frag8<bf16_t> dsf, pf;
         frag_from_f32<bf16_t>(dsf, dsv);
+        if constexpr (MODE == 1) frag_from_f32<bf16_t>(pf, pv);
         ds_tr_wait();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -293,15 +304,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           mma16(acc1[mt], yf, dsf);
         }
         if constexpr (MODE == 1) {
-          Frag8<bf16_t> pf;
-          frag_from_f32<bf16_t>(pf, pv);
-          const unsigned yb0 = lds_addr(Y2s + to0), yb1 = yb0 + 16 * I::ROWP;
-          s16x4 z0[MT], z1[MT];
-          static_for<MT>([&](auto mt) {
-            z0[mt] = ds_read_tr16_asm<mt * 32>(yb0);
-            z1[mt] = ds_read_tr16_asm<mt * 32>(yb1);
-          });
-          ds_tr_wait();
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             asm volatile("" : "+v"(z0[mt]), "+v"(z1[mt]));
