@@ -235,6 +235,9 @@ int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const floa
 /* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
  * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */
 int wmz_debug_fused_timestamps(void* buf);
+/* Ablation switches of the fused per-token kernel (timing experiments only, results are garbage): 1 = skip the MFMA loops,
+ * 2 = skip the weight DMA and its waits; 0 = product behaviour. */
+int wmz_debug_fused_knobs(int dbg);
 /* Same for the 16-wide-plane attention forward kernel (16 waves x 64 int64). */
 int wmz_debug_attn_timestamps(void* buf);
 /* development knobs of the attention forward: dbg = ablation switches (1 skip the per-tile compute, 2 skip the K/V

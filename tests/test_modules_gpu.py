@@ -327,3 +327,23 @@ def test_weight_stream_packer_matches_the_documented_order(wmz):
     assert torch.equal(wpack[:ref.numel()], ref)
     assert (wpack[ref.numel():] == 0).all() and wpack.numel() == ref.numel() + 32768
     assert torch.allclose(vec[:vref.numel()], vref, rtol=1e-5, atol=1e-5) and (vec[vref.numel():] == 0).all()
+
+
+def test_out_of_vocabulary_tokens(wmz):
+    """Reference: nn.Embedding raises IndexError on an id >= vocabulary.  Default here: clamped in-kernel (no host sync in
+    the step); with config.set_check_tokens(True) the drop-in raises like the reference."""
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(2, 4, 4), dim=32, num_classes=10, extents=(1, 1, 1), depth=1, dim_head=16,
+                                          mlp_dim=32, heads=2).cuda()
+    z = torch.randint(0, 11, (1, 2, 4, 4), device='cuda')
+    z[0, 0, 0, 0] = 11                                  # one past the mask token
+    cfg = wmz['config']
+    with cfg.compute_dtype(torch.float32), torch.no_grad():
+        zc = z.clone(); zc[0, 0, 0, 0] = 10
+        assert torch.equal(m(z), m(zc))                 # clamped to the last row of the table
+        cfg.set_check_tokens(True)
+        try:
+            with pytest.raises(IndexError):
+                m(z)
+            m(zc)
+        finally:
+            cfg.set_check_tokens(False)

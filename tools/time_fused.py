@@ -1,5 +1,5 @@
 """Per-launch time of the fused per-token kernel at several token counts (graph of 50 launches, one event pair).
-WMZ_FUSED_DBG=1 skips the MFMA loops, =2 the weight DMA + waits (timing ablations only)."""
+FUSED_DBG=1 skips the MFMA loops, =2 the weight DMA + waits (timing ablations only, wmz_debug_fused_knobs)."""
 import sys, torch
 sys.path.insert(0, '.')
 from world_modelz_amd import config, fused
@@ -7,6 +7,9 @@ from world_modelz_amd.main import VqVideoDiffusionModel
 torch.manual_seed(0)
 m = VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=256, num_classes=1024, extents=(3, 3, 3), depth=4, dim_head=128, mlp_dim=256, heads=1).cuda()
 config.set_compute_dtype(torch.bfloat16)
+import os as _os
+from world_modelz_amd import _lib as _L
+_L.call('wmz_debug_fused_knobs', int(_os.environ.get('FUSED_DBG', '0')))
 L = list(m.transformer.layers)
 def timeit(fn, reps=50):
     side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())

@@ -73,3 +73,19 @@ def get_fused_training():
 def set_fused_training(on):
     global _fused_training
     _fused_training = bool(on)
+
+
+# The reference's nn.Embedding raises IndexError on a token id outside the vocabulary; the HIP embedding clamps instead (a
+# device-side check cannot raise without a host sync in the middle of the step).  With this switch on, the drop-in modules
+# validate their token inputs on the host before launching (one device->host sync per call): the reference's error behaviour
+# for debugging, off by default for throughput.
+_check_tokens = os.environ.get('WMZ_CHECK_TOKENS', '0') != '0'
+
+
+def get_check_tokens():
+    return _check_tokens
+
+
+def set_check_tokens(on):
+    global _check_tokens
+    _check_tokens = bool(on)

@@ -283,11 +283,7 @@ int launch(const BwdPtrs& P, AttnGeom G, hipStream_t st) {
                       2 * KC * 16 * sizeof(float);
   if (smem > 160 * 1024) { wmz_set_error("wmz_local3d_attn_bwd: plane too large for the LDS tables (H*W=%d)", G.HW); return WMZ_ERR_UNSUPPORTED; }
   auto kern = attn_bwd_kernel<T, DH, OPW, KC, MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, st, P, G);
   WMZ_LAUNCH_CHECK("wmz_local3d_attn_bwd");
   return WMZ_OK;
@@ -332,8 +328,7 @@ extern "C" int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v,
   PK.x1 = k; PK.x2 = v; PK.y1 = q; PK.y2 = dout; PK.o = nullptr; PK.lse = lse; PK.delta = delta_ws; PK.g1 = dk; PK.g2 = dv;
   PK.ldx1 = ldk; PK.ldx2 = ldv; PK.ldy1 = ldq; PK.ldy2 = lddo; PK.ldo = 0; PK.ldg1 = lddk; PK.ldg2 = lddv;
   hipStream_t st = (hipStream_t)stream;
-  static const bool no_fast = getenv("WMZ_ATTN_GENERAL") != nullptr;
-  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !no_fast)
+  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) )
     return wmz_attn_bwd_row16_dispatch(q, k, v, out, lse, dout, dq, dk, dv, delta_ws, G, lddo, lddq, lddk, lddv, st);
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {

@@ -238,11 +238,7 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
   if (smem > 160 * 1024) { wmz_set_error("wmz_local3d_attn_fwd: plane too large for the LDS tables (H*W=%d)", G.HW); return WMZ_ERR_UNSUPPORTED; }
   constexpr int NTHREADS = NWAVES * 64;
   auto kern = attn_fwd_kernel<T, DH, QPW, KC, NWAVES>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, st, (const T*)q, (const T*)k, (const T*)v,
                      (T*)out, lse, dbg, G);
   WMZ_LAUNCH_CHECK("wmz_local3d_attn_fwd");

@@ -770,6 +770,8 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
 
 static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_head, int has_tail, void* stream);
 static long long* g_fused_ts = nullptr;
+static int g_fused_dbg = 0;       // ablation switches (wmz_debug_fused_knobs): 1 = skip the MFMA loops, 2 = skip the weight DMA + waits
+extern "C" int wmz_debug_fused_knobs(int dbg) { g_fused_dbg = dbg; return WMZ_OK; }
 // Timing probe for kernel development (tools/ts_fused.py): a device buffer of 8 * 64 int64; NULL switches it off.
 extern "C" int wmz_debug_fused_timestamps(void* buf) { g_fused_ts = (long long*)buf; return WMZ_OK; }
 
@@ -979,8 +981,7 @@ static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_h
     wmz_set_error("wmz_layer_fused_fwd: built for dim 256 / inner 128 / mlp 256 (got %d/%d/%d); use the unfused path", D, I, M);
     return WMZ_ERR_UNSUPPORTED;
   }
-  static const int dbg_env = getenv("WMZ_FUSED_DBG") ? atoi(getenv("WMZ_FUSED_DBG")) : 0;
-  P.dbg = dbg_env;
+  P.dbg = g_fused_dbg;
   P.ts = g_fused_ts;
   const size_t smem = VECB + RING * SLAB + FW * 8192;
   dim3 grid((unsigned)wmz_cdiv(ntok, TW * FW)), block(NTHR);
@@ -988,8 +989,7 @@ static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_h
 #define WMZ_FUSED(H, T)                                                                                            \
   do {                                                                                                             \
     auto kern = layer_fused_kernel<256, 128, 256, H, T>;                                                           \
-    static bool attr = false;                                                                                      \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL(kern, grid, block, smem, st, P);                                                            \
   } while (0)
   if (has_head && has_tail) WMZ_FUSED(true, true);

@@ -639,7 +639,7 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
   P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK); P.nsplit = 0;
   const int tiles = P.nbn * P.nbk;
-  static const int wg_target = getenv("WMZ_WGRAD_WGS") ? atoi(getenv("WMZ_WGRAD_WGS")) : 256;
+  constexpr int wg_target = 256;             // ~one workgroup per CU (measured optimum)
   int split = wmz_cdiv(wg_target, tiles);    // ~one workgroup per CU: every extra split is another 64 KB of float atomics
   const int max_split = wmz_cdiv(M, 4 * WG_MS);
   if (split > max_split) split = max_split;
@@ -660,7 +660,7 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
 // slices of M for a wgrad of these sizes (shared by the launch and by the workspace query)
 static int wgrad_split(int M, int N, int K, int ms, int* rows_per_wg) {
   const int tiles = wmz_cdiv(N, WG_BN) * wmz_cdiv(K, WG_BK);
-  static const int target = getenv("WMZ_WGRAD2_WGS") ? atoi(getenv("WMZ_WGRAD2_WGS")) : 256;
+  constexpr int target = 256;                // measured: 512 slices double the partial-tile traffic and lose
   int split = wmz_cdiv(target, tiles);         // two resident workgroups per CU
   const int max_split = wmz_cdiv(M, 4 * ms);
   if (split > max_split) split = max_split;

@@ -156,6 +156,9 @@ class Local3dAttentionTransformer(nn.Module):
         _, S, H, W = img_z.shape
         if S > self.pos_emb_s.num_embeddings or H > self.pos_emb_h.num_embeddings or W > self.pos_emb_w.num_embeddings:
             raise IndexError('token grid larger than the position-embedding tables')
+        from .config import get_check_tokens
+        if get_check_tokens() and (int(img_z.min()) < 0 or int(img_z.max()) >= self.embedding.num_embeddings):
+            raise IndexError('index out of range in self')            # what nn.Embedding raises in the reference
         if not torch.is_grad_enabled():
             from . import fused
             from .config import get_compute_dtype
