@@ -152,16 +152,29 @@ def main():
 
     log(f'model built ({"eager" if a.eager else "hipGraph"}), starting {a.warmup} warm-up steps')
     with torch.no_grad():
+        # untimed pre-warm: the first ~50 replays after an idle period run 5-10 % slow (clock / power ramp), whatever W is
+        for _ in range(100):
+            step()
         for _ in range(a.warmup):
             step()
         barrier()
         log('warm-up done')
+        # a generational collection of the interpreter (tens of ms once the model, its state_dict copy and the graph
+        # runner are alive) must not land between two enqueues of the timed region: collect now, hold the collector off
+        import gc
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(a.steps):
             y = step()
+            marks.append(time.perf_counter())
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+        gc.enable()
+        if os.environ.get('WMZ_BENCH_MARKS'):
+            log('enqueue times per step (ms): ' + ' '.join(f'{(m - t0) * 1e3:.2f}' for m in marks) + f' | synced {(t1 - t0) * 1e3:.2f}')
     elapsed = t1 - t0
     log(f'{a.steps} timed steps in {elapsed:.3f} s')
     if world > 1:

@@ -220,17 +220,50 @@ int wmz_layer_fused_pack(const float* wout, const float* bout, const float* g2, 
  * Besides the inference outputs they write what the backward (wmz_linear_wgrad, wmz_layernorm_bwd, wmz_local3d_attn_bwd
  * ..) reads, row-major: x1_out [ntok, D] = the feed-forward block's input (x + to_out(o)), x_out_rowmajor [ntok, D] = a
  * row-major copy of x_out when x_out itself is tiled (NULL otherwise), and kv_out as ONE [ntok, 2I] buffer (k | v column
- * halves).  The feed-forward pre-activation is not exported: the backward recomputes it with one LayerNorm-GEMM.
+ * halves).  z_tiled_out (optional, needs the head and ntok % 32 == 0): the feed-forward pre-activation W1 LN(x1) + b1 as
+ * bf16 in the private tiled layout wmz_ff_fused_bwd reads (per 32-token tile [M/32 chunks][2][64 lanes][8]); NULL: not
+ * exported, the per-op backward recomputes it with one LayerNorm-GEMM.
  * ln_ff_stats / ln_attn_stats (optional, fp32 [2, ntok]: means then reciprocal standard deviations): the statistics of the
  * two LayerNorms the kernel applies -- in front of the feed-forward, and in front of the next layer's k | v -- for the
  * backward (wmz_linear_wgrad's LayerNorm prologue, wmz_linear_fwd_stats), which otherwise spends a pass per LayerNorm. */
 int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_out, void* x_out_rowmajor, void* x1_out, void* q_out,
-                              void* kv_out, float* ln_ff_stats, float* ln_attn_stats, const void* wpack, const float* vec,
-                              int ntok, int D, int I, int M, int has_head, int has_tail, int xflags, float eps, void* stream);
+                              void* kv_out, float* ln_ff_stats, float* ln_attn_stats, void* z_tiled_out, const void* wpack,
+                              const float* vec, int ntok, int D, int I, int M, int has_head, int has_tail, int xflags,
+                              float eps, void* stream);
 int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                   const float* pos_w, void* x_out, void* x_out_rowmajor, void* q_out, void* kv_out,
                                   float* ln_attn_stats, const void* wpack, const float* vec, int B, int S, int H, int W,
                                   int D, int I, int M, int num_classes, int xflags, float eps, void* stream);
+
+/* Fused per-token BACKWARD (bf16, dim 256 / inner 128 / mlp 256; csrc/layer_fused_bwd.hip): the counterpart of
+ * wmz_layer_fused_fwd_train.  Per layer, in backward order:
+ *   wmz_ff_fused_bwd    dy [ntok, D] (gradient w.r.t. the feed-forward block's output), the tiled pre-activation, the
+ *                       block's input x1 and its LayerNorm statistics ->
+ *                         g_out  = GELU(z)                 [ntok, M]   operand of dW2 = dy^T g
+ *                         dz_out = (dy W2) GELU'(z)        [ntok, M]   operand of dW1
+ *                         xhat_out = (x1 - mean) rstd      [ntok, D]   operand of dW1
+ *                         dx1_out = dy + LNbwd(dz W1')     [ntok, D]   gradient w.r.t. x1 (= to_out's output + residual)
+ *                         do_out  = dx1 Wout               [ntok, I]   gradient w.r.t. the attention output
+ *   wmz_local3d_attn_bwd  (do -> dq, dk | dv)
+ *   wmz_qkv_fused_bwd   dq [ntok, I], dk | dv [ntok, 2I], the layer's input x + statistics, res = dx1 ->
+ *                         dx = res + dq Wq + LNbwd(dk Wk' + dv Wv')      gradient w.r.t. the layer's input
+ *                         xhat_out = (x - mean) rstd                      operand of the to_k | to_v weight gradient
+ * wpack: the TRANSPOSED weight streams of wmz_layer_fused_bwd_pack (wpack_ff: 163 840 + 32 768 bf16, wpack_qkv: 98 304 +
+ * 32 768 bf16; the LayerNorm gammas are folded in).  Replaces wmz_linear_fwd x5 (dgrad / recompute) and wmz_layernorm_bwd
+ * x2 per layer; the weight gradients stay wmz_linear_wgrad calls on the operands written here, computed against the
+ * NORMALISED inputs, and wmz_ln_affine_grads turns such a raw gradient G[N, K] = dC^T xhat and s[N] = column sums of dC
+ * (ntok must be a multiple of 32 for both kernels) into the parameter gradients: dW += G diag(gamma) + s beta^T, dbias[n - bias_from] += s[n] (n >= bias_from; NULL: no
+ * bias), dgamma[k] += sum_n W[n,k] G[n,k], dbeta[k] += sum_n W[n,k] s[n]  (all fp32, accumulating). */
+int wmz_layer_fused_bwd_pack(const float* wq, const float* wk, const float* wv, const float* g1, const float* wout,
+                             const float* w1, const float* g2, const float* w2, void* wpack_qkv, void* wpack_ff, int D, int I,
+                             int M, void* stream);
+int wmz_ff_fused_bwd(const void* dy, const void* z_tiled, const void* x1, const float* ln_stats, void* g_out, void* dz_out,
+                     void* xhat_out, void* dx1_out, void* do_out, const void* wpack, int ntok, int D, int I, int M,
+                     void* stream);
+int wmz_qkv_fused_bwd(const void* dq, long lddq, const void* dkv, long lddkv, const void* x, const float* ln_stats,
+                      const void* res, void* dx, void* xhat_out, const void* wpack, int ntok, int D, int I, void* stream);
+int wmz_ln_affine_grads(const float* G, const float* s, const float* W, const float* gamma, const float* beta, float* dW,
+                        float* dbias, float* dgamma, float* dbeta, int N, int K, int bias_from, void* stream);
 
 /* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
  * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */

@@ -1,0 +1,122 @@
+"""GPU: the fused per-token backward kernels (csrc/layer_fused_bwd.hip) against a plain fp32 torch restatement of the same
+math (reference local_3d_attention.py:11-31 PreNorm / FeedForward, :46-53 to_q / to_k / to_v / to_out), through the C ABI."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+D, I, M = 256, 128, 256
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def layer():
+    from world_modelz_amd import config
+    from world_modelz_amd.local_3d_attention import Local3dAttentionTransformer
+    torch.manual_seed(5)
+    tr = Local3dAttentionTransformer(data_shape=(3, 16, 16), dim=D, num_classes=64, extents=(1, 1, 1), depth=1, mlp_dim=M,
+                                     dim_head=I, heads=1).cuda()
+    with torch.no_grad():                                  # non-trivial LayerNorm affines and biases
+        for p in tr.parameters():
+            if p.dim() == 1:
+                p.add_(0.3 * torch.randn_like(p))
+    return tr.layers[0]
+
+
+def _tile_z(z):
+    """[ntok, M] -> the tiled layout of layer_fused.hip (per 32-token tile [M/32 chunks][2][64 lanes = (h, t)][8])."""
+    n = z.shape[0]
+    v = z.reshape(n // 32, 32, M // 32, 2, 2, 8)           # tile, t, c, h, j, e
+    return v.permute(0, 2, 4, 3, 1, 5).contiguous().reshape(n, M)
+
+
+def _ln_bwd(dxhat, x, mean, rstd):
+    xh = (x - mean[:, None]) * rstd[:, None]
+    return rstd[:, None] * (dxhat - dxhat.mean(1, keepdim=True) - xh * (dxhat * xh).mean(1, keepdim=True)), xh
+
+
+def test_ff_fused_bwd_vs_torch(layer):
+    from world_modelz_amd import _lib as L, fused
+    attn, ff = layer
+    torch.manual_seed(1)
+    n = 2 * 16 * 16 * 3                                    # 1536 tokens: 6 workgroups, the last one ragged (8 waves x 32)
+    dy = torch.randn(n, D, device='cuda').bfloat16()
+    x1 = (torch.randn(n, D, device='cuda') * 1.5 + 0.2).bfloat16()
+    xf = x1.float()
+    mean, var = xf.mean(1), xf.var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    st = torch.stack([mean, rstd]).contiguous()
+    g2, be2 = ff.norm.weight.detach(), ff.norm.bias.detach()
+    w1, b1, w2 = ff.fn.net[0].weight.detach(), ff.fn.net[0].bias.detach(), ff.fn.net[3].weight.detach()
+    wout = attn.fn.to_out[0].weight.detach()
+    xh = (xf - mean[:, None]) * rstd[:, None]
+    z = ((xh * g2 + be2) @ w1.t() + b1).bfloat16()
+    zt = _tile_z(z)
+    _, wpack_ff = fused._layer_pack_bwd(attn, ff)
+    outs = [torch.empty(n, w, dtype=torch.bfloat16, device='cuda') for w in (M, M, D, D, I)]
+    g, dz, xhat1, dx1, do = outs
+    L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
+           L.ptr(do), L.ptr(wpack_ff), n, D, I, M, L.stream())
+    torch.cuda.synchronize()
+    zf = z.float().requires_grad_(True)
+    gr = torch.nn.functional.gelu(zf)
+    (dgelu,) = torch.autograd.grad(gr.sum(), zf)
+    w2b, w1b, woutb = w2.bfloat16().float(), (w1 * g2).bfloat16().float(), wout.bfloat16().float()
+    dz_r = (dy.float() @ w2b) * dgelu
+    dxhat = dz_r.bfloat16().float() @ w1b
+    lnb, xh_r = _ln_bwd(dxhat, xf, mean, rstd)
+    dx1_r = dy.float() + lnb
+    do_r = dx1_r.bfloat16().float() @ woutb
+    errs = dict(g=rel(g, gr), dz=rel(dz, dz_r), xhat=rel(xhat1, xh_r), dx1=rel(dx1, dx1_r), do=rel(do, do_r))
+    print('[ff_fused_bwd]', {k: f'{v:.2e}' for k, v in errs.items()})
+    assert all(v < 6e-3 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize('with_res', [True, False])
+def test_qkv_fused_bwd_vs_torch(layer, with_res):
+    from world_modelz_amd import _lib as L, fused
+    attn, ff = layer
+    torch.manual_seed(2)
+    n = 2 * 16 * 16 * 3
+    dq = torch.randn(n, I, device='cuda').bfloat16()
+    dkv = torch.randn(n, 2 * I, device='cuda').bfloat16()
+    x = (torch.randn(n, D, device='cuda') * 0.7 - 0.1).bfloat16()
+    res = torch.randn(n, D, device='cuda').bfloat16() if with_res else None
+    xf = x.float()
+    mean, var = xf.mean(1), xf.var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    st = torch.stack([mean, rstd]).contiguous()
+    g1 = attn.norm.weight.detach()
+    wq, wk, wv = (attn.fn.to_q.weight.detach(), attn.fn.to_k.weight.detach(), attn.fn.to_v.weight.detach())
+    wpack_qkv, _ = fused._layer_pack_bwd(attn, ff)
+    dx = torch.empty(n, D, dtype=torch.bfloat16, device='cuda')
+    xhat = torch.empty(n, D, dtype=torch.bfloat16, device='cuda')
+    L.call('wmz_qkv_fused_bwd', L.ptr(dq), I, L.ptr(dkv), 2 * I, L.ptr(x), L.ptr(st), L.ptr(res), L.ptr(dx), L.ptr(xhat),
+           L.ptr(wpack_qkv), n, D, I, L.stream())
+    torch.cuda.synchronize()
+    dxhat = dkv[:, :I].float() @ (wk * g1).bfloat16().float() + dkv[:, I:].float() @ (wv * g1).bfloat16().float()
+    lnb, xh_r = _ln_bwd(dxhat, xf, mean, rstd)
+    dx_r = lnb + dq.float() @ wq.bfloat16().float()
+    if with_res:
+        dx_r = dx_r + res.float()
+    e1, e2 = rel(dx, dx_r), rel(xhat, xh_r)
+    print(f'[qkv_fused_bwd res={with_res}] dx {e1:.2e} xhat {e2:.2e}')
+    assert e1 < 6e-3 and e2 < 6e-3
+
+
+def test_ln_affine_grads_vs_torch():
+    from world_modelz_amd import _lib as L
+    torch.manual_seed(3)
+    N, K = 256, 256
+    G, W = torch.randn(N, K, device='cuda'), torch.randn(N, K, device='cuda')
+    s, gamma, beta = torch.randn(N, device='cuda'), torch.randn(K, device='cuda'), torch.randn(K, device='cuda')
+    dW, dbias = torch.randn(N, K, device='cuda'), torch.randn(N - 128, device='cuda')
+    dg, db = torch.randn(K, device='cuda'), torch.randn(K, device='cuda')
+    ref = (dW + G * gamma + s[:, None] * beta, dbias + s[128:], dg + (W * G).sum(0), db + W.t() @ s)
+    L.call('wmz_ln_affine_grads', L.ptr(G), L.ptr(s), L.ptr(W), L.ptr(gamma), L.ptr(beta), L.ptr(dW), L.ptr(dbias), L.ptr(dg),
+           L.ptr(db), N, K, 128, L.stream())
+    for a, b in zip((dW, dbias, dg, db), ref):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)

@@ -14,7 +14,7 @@ import collections, csv, glob, hashlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {
     'attn_fwd_row16_kernel': ('attn', 'attn_fwd_row16_kernel', ['attn_fwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
-    'layer_fused_kernel<head,tail>': ('fused', 'layer_fused_kernel<256, 128, 256, true, true>', ['layer_fused.hip', 'wmz_common.h']),
+    'layer_fused_kernel<head,tail>': ('fused', 'layer_fused_kernel<256, 128, 256, true, true>', ['layer_fused.hip', 'fused_common.h', 'wmz_common.h']),
 }
 
 

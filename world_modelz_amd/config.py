@@ -75,6 +75,21 @@ def set_fused_training(on):
     _fused_training = bool(on)
 
 
+# ... and its backward on the fused per-token backward kernels (csrc/layer_fused_bwd.hip: wmz_ff_fused_bwd /
+# wmz_qkv_fused_bwd; the forward then also saves the feed-forward pre-activation).  Off: the op-by-op backward
+# (backward.py) behind the fused forward.
+_fused_backward = True
+
+
+def fused_backward():
+    return _fused_backward
+
+
+def set_fused_backward(on):
+    global _fused_backward
+    _fused_backward = bool(on)
+
+
 # The reference's nn.Embedding raises IndexError on a token id outside the vocabulary; the HIP embedding clamps instead (a
 # device-side check cannot raise without a host sync in the middle of the step).  With this switch on, the drop-in modules
 # validate their token inputs on the host before launching (one device->host sync per call): the reference's error behaviour

@@ -28,7 +28,7 @@
 #include "attn_common.h"
 
 // Compile-time ablations for timing experiments (tools/variants builds; results are garbage): bit 0 no LDS fragment reads,
-// bit 1 no softmax arithmetic, bit 2 no MFMAs.  0 in the product.
+// bit 1 no softmax arithmetic, bit 2 no MFMAs, bit 3 no V staging, bit 4 no K staging, bit 5 no slab loop at all, bit 6 one key plane only.  0 in the product.
 #ifndef WMZ_ATTN_ABL
 #define WMZ_ATTN_ABL 0
 #endif
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
   const int c_first = t_lo >> 4, c_last = t_hi >> 4;
   const int nch = (c_last - c_first + 1) * 2;               // slabs per key plane: (16-row chunk) x (row parity)
-  const int nslab = (sk_hi - sk_lo + 1) * nch;
+  const int nslab = (WMZ_ATTN_ABL & 32) ? 0 : (WMZ_ATTN_ABL & 64) ? nch : (sk_hi - sk_lo + 1) * nch;   // ablations: no slab loop / one key plane
 
   // ---- LDS-DMA descriptors: this wave's pieces are wave + 16 i; per-lane source offsets for planes of whole 16-row chunks
   const unsigned ldk_b = (unsigned)G.ldk * 2u, ldv_b = (unsigned)G.ldv * 2u;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   };
   auto issue_k = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    if constexpr (i < I::NPK) {
+    if constexpr (i < I::NPK && !(WMZ_ATTN_ABL & 16)) {
       const int piece = wave + NW * i;
       if (i * NW + NW <= I::PK || piece < I::PK) {       // wave-uniform
         unsigned vo;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   };
   auto issue_v = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    if constexpr (i < I::NPV) {
+    if constexpr (i < I::NPV && !(WMZ_ATTN_ABL & 8)) {
       const int piece = wave + NW * i;
       if (i * NW + NW <= I::PV || piece < I::PV) {
         unsigned vo;

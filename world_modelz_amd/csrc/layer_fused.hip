@@ -21,40 +21,9 @@
 //     rate that would bound the MFMAs (16-token waves with 16x16x32 sit exactly on that bound).
 //   * the feed-forward is walked 32 hidden units at a time (W1 rows -> GELU -> W2 columns), so its activation never
 //     exists in full and the chunk's accumulator (16 registers) is converted in place to the next operand.
-#include "wmz_common.h"
-#include <stdlib.h>
-
-// Compiler + scheduler fence: neither IR passes (memory clobber) nor the machine scheduler (sched_barrier) may move
-// loads across it.  Used to cap how many operand loads are in flight: the register file is the scarce resource here.
-#define WMZ_FENCE()                        \
-  do {                                     \
-    asm volatile("" ::: "memory");         \
-    __builtin_amdgcn_sched_barrier(0);     \
-  } while (0)
+#include "fused_common.h"
 
 namespace {
-
-constexpr int TW = 32;          // tokens per wave
-#ifndef WMZ_FUSED_FW
-#define WMZ_FUSED_FW 8
-#endif
-constexpr int FW = WMZ_FUSED_FW; // waves per workgroup.  8: one workgroup of 256 tokens per CU (two waves per SIMD, one's epilogue
-                                // overlaps the other's MFMAs).  4: two independent workgroups of 128 tokens per CU, out of phase
-constexpr int NTHR = FW * 64;
-constexpr int HALF = 16384;     // granule of the weight stream: every GEMM stage is a whole number of these
-constexpr int PIECES = HALF / 1024;   // MFMA A operands per granule
-#ifndef WMZ_FUSED_HPS
-#define WMZ_FUSED_HPS 2
-#endif
-constexpr int HPS = WMZ_FUSED_HPS;    // granules per slab = per workgroup barrier (1: 16 KB slabs, ring of 4; 2: 32 KB, ring of 2)
-constexpr int SLAB = HPS * HALF;      // bytes per weight slab (one LDS-DMA burst, one barrier)
-#ifndef WMZ_FUSED_RING
-#define WMZ_FUSED_RING (WMZ_FUSED_HPS == 1 ? 4 : 2)
-#endif
-constexpr int RING = WMZ_FUSED_RING;  // LDS ring slots; RING-1 slabs of the weight stream stay in flight
-constexpr int WPP = SLAB / 1024 / FW; // LDS-DMA pieces per wave per slab
-constexpr int VECB = 8192;      // the layer's bias / LayerNorm vectors (2048 fp32), staged once per workgroup
-constexpr int MC = 32;          // feed-forward hidden chunk: W1 rows / W2 columns streamed MC at a time
 
 struct FusedParams {
   const bf16_t* o;      // [ntok, I]   attention output               (HEAD)
@@ -83,6 +52,10 @@ struct FusedParams {
   // ... and the LayerNorm statistics the kernel computes anyway (fp32 [2, ntok]: the means, then the reciprocal standard
   // deviations): st_ff of LN2(x1) in front of the feed-forward, st_attn of LN1'(x2) in front of the next layer's k | v
   float* st_ff; float* st_attn;
+  // ... and the feed-forward pre-activation z = W1' LN2(x1) + b1' for the fused backward (layer_fused_bwd.hip), in a private
+  // TILED layout: per 32-token tile [M/32 chunks][2][64 lanes][8] -- lane (t, h)'s accumulator registers 8j .. 8j+7 of chunk c
+  // (hidden units 32c + 16h + 8j ..) at ((2c + j) * 64 + lane) * 16 bytes: every store instruction is one contiguous KB
+  bf16_t* zt;
   long long* ts;        // timing probe (wmz_debug_fused_timestamps): workgroup 0 writes s_memtime at stage boundaries
 };
 // stage-boundary probe: wave w of workgroup 0 stores the shader clock into ts[w * 64 + slot]
@@ -94,388 +67,6 @@ __device__ __forceinline__ long src_row(const FusedParams& P, long t) {
   if (P.rows_out == 0) return t;
   const int c = (int)t / P.rows_out;
   return (long)c * P.rows_in + P.row0 + ((int)t - c * P.rows_out);
-}
-
-// ---- weight stream: RING-slot LDS ring filled by LDS-DMA (global_load_lds), RING-1 slabs in flight.
-struct WStream {
-  int dbg;
-  const char* src;     // global address of the next slab to ISSUE (this lane's 16 bytes of piece 0 of its wave)
-  char* ring;          // LDS ring base + this wave's eighth of a slab
-  int issue_slot;      // ring slot the next issued slab goes to
-  int cur;             // ring slot of the slab being multiplied
-  int half;            // granule of that slab the next stage starts at
-  int wave;
-  int probe;           // timing probe slot base for the next slab (0 = off)
-  long long* ts;
-  // vmcnt bookkeeping: tot = every other VMEM op (row loads / stores) this wave has issued so far; t1..t3 = tot at the
-  // moment the last three slabs were issued, oldest first
-  int tot, t1, t2, t3;
-};
-
-__device__ __forceinline__ void ws_issue(WStream& ws) {
-  ws.t1 = ws.t2; ws.t2 = ws.t3; ws.t3 = ws.tot;
-  if (ws.dbg & 2) return;
-  char* dst = ws.ring + ws.issue_slot * SLAB;
-#pragma unroll
-  for (int i = 0; i < WPP; ++i)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws.src + i * 1024),
-                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-  ws.src += SLAB;
-  ws.issue_slot = ws.issue_slot == RING - 1 ? 0 : ws.issue_slot + 1;
-}
-
-// Before multiplying a slab: this wave's eighth of it has landed, then one barrier: every piece landed, and every wave is
-// done with the previous slab, whose slot the caller refills (ws_issue) once its first fragment reads are out (spreading
-// the requests over the stage instead measured slower).  vmcnt counts loads, stores and LDS-DMA together in issue
-// order: the oldest slab in flight has landed <=> at most [the WPP*(RING-2) pieces of the younger slabs + every other op
-// issued after its pieces (tot - its t)] is outstanding.
-__device__ __forceinline__ void ws_wait(WStream& ws) {
-  constexpr int YB = WPP * (RING - 2);
-  static_assert(YB == 4 || YB == 0, "literals below");
-  const int e = ws.tot - (RING == 4 ? ws.t1 : (RING == 3 ? ws.t2 : ws.t3));
-  if (!(ws.dbg & 2)) {
-#define WMZ_VMC(n) case n: if (YB == 4) asm volatile("s_waitcnt vmcnt(" #n " + 4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-    switch (e) {
-      WMZ_VMC(0) WMZ_VMC(1) WMZ_VMC(2) WMZ_VMC(3) WMZ_VMC(4) WMZ_VMC(5) WMZ_VMC(6) WMZ_VMC(7) WMZ_VMC(8) WMZ_VMC(9)
-      WMZ_VMC(10) WMZ_VMC(11) WMZ_VMC(12) WMZ_VMC(13) WMZ_VMC(14) WMZ_VMC(15) WMZ_VMC(16) WMZ_VMC(17) WMZ_VMC(18)
-      WMZ_VMC(19) WMZ_VMC(20) WMZ_VMC(21) WMZ_VMC(22) WMZ_VMC(23) WMZ_VMC(24) WMZ_VMC(25) WMZ_VMC(26) WMZ_VMC(27)
-      WMZ_VMC(28) WMZ_VMC(29) WMZ_VMC(30) WMZ_VMC(31) WMZ_VMC(32)
-      default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;      // more than 32: waits for the surplus (safe)
-    }
-#undef WMZ_VMC
-  }
-  if (ws.probe && ws.ts) ws.ts[ws.probe] = __builtin_readcyclecounter();
-  __builtin_amdgcn_s_barrier();
-  if (ws.probe && ws.ts) ws.ts[ws.probe + 1] = __builtin_readcyclecounter();
-}
-__device__ __forceinline__ void ws_release(WStream& ws) { ws.cur = ws.cur == RING - 1 ? 0 : ws.cur + 1; }
-__device__ __forceinline__ void ws_extra(WStream& ws, int n) { ws.tot += n; }
-
-// Side work of a GEMM stage: called once per group of AG MFMAs; kValuPerMfma tells the stage how many of its VALU
-// instructions the scheduler should place behind EACH MFMA (measured on MI355X at two waves per SIMD: up to ~2 VALU per
-// MFMA and wave hide completely, 4-8 cost about half their time, a block of VALU behind a block of MFMAs hides nothing).
-struct NoSide { static constexpr int kValuPerMfma = 0; __device__ __forceinline__ void operator()(int) const {} };
-template <int VPM, typename F> struct SideWork {
-  static constexpr int kValuPerMfma = VPM;
-  F f;
-  __device__ __forceinline__ void operator()(int g) const { f(g); }
-};
-template <int VPM, typename F> __device__ __forceinline__ SideWork<VPM, F> side_work(F f) { return SideWork<VPM, F>{f}; }
-
-// acc[NB blocks of 32 features x 32 tokens] += W . act^T over KS 16-deep k-steps; the stream holds the pieces in
-// (k-step, block) order, so a k-step's operand is used by NB independent accumulators.  bget(s) yields the B operand
-// of k-step s (a register array, or an LDS read issued one k-step ahead).
-template <int NB, int KS, typename BGet, typename Side = NoSide>
-__device__ __forceinline__ void gemm_stage_b(f32x16 (&acc)[NB], BGet bget, const char* ring0, WStream& ws, int lane,
-                                             Side side = Side()) {
-  constexpr int NP = NB * KS;
-  static_assert(NP % PIECES == 0, "a stage is a whole number of slabs");
-  constexpr int AG = 4, GPS = PIECES / AG;                 // fragments per group, groups per slab
-  Frag8<bf16_t> bcur, bnext = bget(0);
-  bcur = bnext;
-#pragma unroll
-  for (int sl = 0; sl < NP / PIECES; ++sl) {
-    if (ws.half == 0) ws_wait(ws);
-    const char* slab = ring0 + ws.cur * SLAB + ws.half * HALF + lane * 16;
-    // A operands: groups of AG, the next group's ds_reads in flight under this group's MFMAs (8 fragments live, no more:
-    // the scheduler is fenced so that it cannot hoist the whole slab's reads into registers the chain needs)
-    Frag8<bf16_t> af[2][AG];
-    if (!(ws.dbg & 1)) {
-#pragma unroll
-      for (int j = 0; j < AG; ++j) af[0][j].v = *reinterpret_cast<const s16x8*>(slab + j * 1024);
-    }
-    if (ws.half == 0) ws_issue(ws);                        // refill the retired slot while the first fragments arrive
-    if (ws.probe && ws.ts) ws.ts[ws.probe + 2] = __builtin_readcyclecounter();
-    if (!(ws.dbg & 1)) {
-#pragma unroll
-      for (int gq = 0; gq < GPS; ++gq) {
-        if (gq == 1 && ws.probe && ws.ts) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ws.ts[ws.probe + 3] = __builtin_readcyclecounter(); }
-        if (gq + 1 < GPS) {
-#pragma unroll
-          for (int j = 0; j < AG; ++j)
-            af[(gq + 1) & 1][j].v = *reinterpret_cast<const s16x8*>(slab + ((gq + 1) * AG + j) * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < AG; ++j) {
-          const int idx = sl * PIECES + gq * AG + j;
-          if (idx % NB == 0) {
-            bcur = bnext;
-            if (idx / NB + 1 < KS) bnext = bget(idx / NB + 1);
-          }
-          mma32(acc[idx % NB], af[gq & 1][j], bcur);
-        }
-        side(sl * GPS + gq);                               // VALU work that rides under this group's MFMAs,
-        // Order inside the group: the NEXT group's fragment reads go out first (left to itself the scheduler sinks them
-        // behind the MFMAs and the wave then waits a full LDS round trip per group), then the MFMAs, each followed by
-        // its share of the side work.
-        if (gq + 1 < GPS) __builtin_amdgcn_sched_group_barrier(0x100, AG, 0);
-        if constexpr (Side::kValuPerMfma > 0) {
-#pragma unroll
-          for (int j = 0; j < AG; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, Side::kValuPerMfma, 0);
-          }
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, AG, 0);
-        }
-        WMZ_FENCE();
-      }
-    }
-    if (ws.half == HPS - 1) { ws_release(ws); ws.half = 0; }
-    else ++ws.half;
-  }
-}
-template <int NB, int KS, typename Side = NoSide>
-__device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[KS], const char* ring0, WStream& ws,
-                                           int lane, Side side = Side()) {
-  gemm_stage_b<NB, KS>(acc, [&](int s) { return bop[s]; }, ring0, ws, lane, side);
-}
-
-__device__ __forceinline__ f32x16 lds_vec16(const float* p) {
-  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-  const f32x4 c = *reinterpret_cast<const f32x4*>(p + 8), d = *reinterpret_cast<const f32x4*>(p + 12);
-  f32x16 v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; v[8 + i] = c[i]; v[12 + i] = d[i]; }
-  return v;
-}
-template <int NB>
-__device__ __forceinline__ void add_vec(f32x16 (&acc)[NB], const float* vec /* + h*16*NB */) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b) acc[b] += lds_vec16(vec + 16 * b);
-}
-// accumulators that start at the bias: the add rides in the MFMA chain
-template <int NB>
-__device__ __forceinline__ void init_vec(f32x16 (&acc)[NB], const float* vec) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b) acc[b] = lds_vec16(vec + 16 * b);
-}
-
-// The empty asm pins the packed operand HERE: without it the compiler sinks the conversion arithmetic down to the MFMA
-// that consumes it and keeps the fp32 sources (and every gamma / beta / bias fetched for them) alive until then.
-__device__ __forceinline__ void pack8(Frag8<bf16_t>& f, const float (&y)[8]) {
-  s16x8 v;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (short)f32_to_bf16_bits(y[j]);
-  asm volatile("" : "+v"(v));
-  f.v = v;
-}
-
-// operand k-step s of a K-feature activation = features h*K/2 + 8*s .. +7 of the lane's token: the lane's half row.
-// Unconditional loads (rows past ntok are clamped by the caller to a valid row; their results are never stored): a
-// predicated load makes hipcc branch around it and wait for each one in turn -- one L2 round trip per 16 bytes.
-template <int KS>
-__device__ __forceinline__ void load_bop(Frag8<bf16_t> (&bop)[KS], const bf16_t* half_row) {
-#pragma unroll
-  for (int s = 0; s < KS; ++s) bop[s].v = *reinterpret_cast<const s16x8*>(half_row + 8 * s);
-}
-
-// A load the compiler does not know about: no automatic s_waitcnt (which, with LDS-DMA in flight, is always vmcnt(0)).
-// Its result may only be used behind wait_untracked().
-__device__ __forceinline__ s16x8 gload_untracked(const bf16_t* p) {
-  s16x8 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-// vmcnt is in issue order: once at most the ring's WPP*(RING-1) youngest pieces are outstanding, every older load is done.
-template <int KS>
-__device__ __forceinline__ void wait_untracked(Frag8<bf16_t> (&b)[KS]) {
-  if (WPP * (RING - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#pragma unroll
-  for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(b[s].v));       // uses stay behind the wait
-}
-// the 8 KB vector block by LDS-DMA: wave w moves KB w
-__device__ __forceinline__ void vec_dma(float* vecs, const float* src, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 8 / FW; ++i) {
-    const int kb = wave * (8 / FW) + i;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kb * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(vecs) + kb * 1024), 16, 0, 0);
-  }
-}
-template <int NB>
-__device__ __forceinline__ void add_bop(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[2 * NB]) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[b][i] += bf16_bits_to_f32((unsigned short)bop[2 * b + (i >> 3)].v[i & 7]);
-}
-
-template <int KS>
-__device__ __forceinline__ void load_bop_tiled(Frag8<bf16_t> (&bop)[KS], const bf16_t* tile, int lane) {
-#pragma unroll
-  for (int s = 0; s < KS; ++s) bop[s].v = *reinterpret_cast<const s16x8*>(tile + (s * 64 + lane) * 8);   // (2s+h)*32+t = 64s+lane
-}
-template <int KS>
-__device__ __forceinline__ void store_bop_tiled(bf16_t* tile, const Frag8<bf16_t> (&bop)[KS], int lane) {
-#pragma unroll
-  for (int s = 0; s < KS; ++s) *reinterpret_cast<s16x8*>(tile + (s * 64 + lane) * 8) = bop[s].v;
-}
-
-// Row stores through the wave's private 8 KB LDS buffer: a lane owns HALF A ROW of its token, so direct 16-byte stores
-// would scatter 64 pieces per instruction over 32 rows (measured: ~570 cycles per store instruction, and the LDS-DMA
-// weight stream queues behind them).  Instead: the lanes write their pieces into a [32 rows x 256 B] image (16-byte
-// chunk c of row r at chunk c ^ (r & 15): conflict-free both ways), then the wave copies the image out 1 KB per
-// instruction, whole 256-byte runs per row.
-// LDS-DMA a [32 tokens x 128 features] tile (rows of ROWF features, 256 B of each from column col0) into the wave's image,
-// same chunk swizzle as the store path (applied on the source address: the DMA writes lane-linear).
-__device__ __forceinline__ void stage_dma128(char* stg, const bf16_t* src, int rowf, long tok0, int ntok, int lane) {
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int r = p * 4 + (lane >> 4), pc = lane & 15;
-    const long row = tok0 + r < ntok ? tok0 + r : ntok - 1;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * rowf + ((pc ^ (r & 15)) << 3)),
-                                     (__attribute__((address_space(3))) void*)(stg + p * 1024), 16, 0, 0);
-  }
-}
-__device__ __forceinline__ Frag8<bf16_t> stage_get(const char* stg, int t, int c) {
-  Frag8<bf16_t> f;
-  f.v = *reinterpret_cast<const s16x8*>(stg + t * 256 + ((c ^ (t & 15)) << 4));
-  return f;
-}
-__device__ __forceinline__ void stage_put(char* stg, const s16x8& v, int t, int c) {
-  *reinterpret_cast<s16x8*>(stg + t * 256 + ((c ^ (t & 15)) << 4)) = v;
-}
-// copy the 8 KB image out: row r of the image -> dst + (tok0 + r) * ROWF + col0, 128 features (256 B) per row
-template <int ROWF>
-__device__ __forceinline__ void stage_flush(const char* stg, bf16_t* dst, long tok0, int ntok, int col0, int lane) {
-  asm volatile("" : "+s"(tok0), "+v"(lane));   // compute the store addresses HERE (hoisted / shared with the prologue's
-                                               // index math they only get spilled)
-  // all eight LDS reads first, unconditionally, then the predicated stores: with the read inside the predicate hipcc
-  // emits branch / read / wait / store per KB, eight LDS round trips in a row
-  s16x8 v[8];
-#pragma unroll
-  for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const s16x8*>(stg + p * 1024 + lane * 16);
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int r = p * 4 + (lane >> 4), pc = lane & 15;
-    const int c = pc ^ (r & 15);
-    if (tok0 + r < ntok) *reinterpret_cast<s16x8*>(dst + (tok0 + r) * ROWF + col0 + c * 8) = v[p];
-  }
-}
-// operand fragments parked in the wave's LDS image, lane-linear (each lane reads back what it wrote)
-__device__ __forceinline__ void frag_park(char* stg, int slot, const Frag8<bf16_t>& f, int lane) {
-  *reinterpret_cast<s16x8*>(stg + slot * 1024 + lane * 16) = f.v;
-}
-__device__ __forceinline__ Frag8<bf16_t> frag_unpark(const char* stg, int slot, int lane) {
-  Frag8<bf16_t> f;
-  f.v = *reinterpret_cast<const s16x8*>(stg + slot * 1024 + lane * 16);
-  return f;
-}
-
-// an I-feature tile (q, k, v: 128 features, every lane holds 8 chunks of its row): one pass
-__device__ __forceinline__ void store_tile128(char* stg, bf16_t* dst, int rowf, long tok0, int ntok, int col0,
-                                              const Frag8<bf16_t> (&b)[8], int lane) {
-  const int t = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) stage_put(stg, b[s].v, t, h * 8 + s);
-  if (rowf == 128) stage_flush<128>(stg, dst, tok0, ntok, col0, lane);
-  else stage_flush<256>(stg, dst, tok0, ntok, col0, lane);
-}
-// the D-feature stream (256 features, a lane holds 16 chunks = its whole 256-byte half row): one pass per lane half
-__device__ __forceinline__ void store_tile256(char* stg, bf16_t* dst, long tok0, int ntok, const Frag8<bf16_t> (&b)[16],
-                                              int lane) {
-  const int t = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    if (h == hh) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) stage_put(stg, b[s].v, t, s);
-    }
-    stage_flush<256>(stg, dst, tok0, ntok, hh * 128, lane);
-  }
-}
-
-template <int NB>
-__device__ __forceinline__ void acc_from_bop(f32x16 (&acc)[NB], const Frag8<bf16_t> (&bop)[2 * NB]) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[b][i] = bf16_bits_to_f32((unsigned short)bop[2 * b + (i >> 3)].v[i & 7]);
-}
-template <int NB>
-__device__ __forceinline__ void bop_from_acc(Frag8<bf16_t> (&bop)[2 * NB], const f32x16 (&acc)[NB]) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float y[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = acc[b][8 * m + j];
-      pack8(bop[2 * b + m], y);
-    }
-}
-
-// LayerNorm statistics of the lane pair's token (features split over the two lane halves): rstd and -mean*rstd
-template <int NB>
-__device__ __forceinline__ void ln_stats(const f32x16 (&acc)[NB], float eps, float& rstd, float& mr) {
-  constexpr int NF = NB * 32;
-  f32x16 sv = acc[0];
-#pragma unroll
-  for (int b = 1; b < NB; ++b) sv += acc[b];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s += sv[i];
-  s = wave_halves_sum(s);
-  const float mean = s / (float)NF;
-  f32x16 qv = (f32x16)(0.f);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) { const f32x16 d = acc[b] - mean; qv += d * d; }
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) q += qv[i];
-  q = wave_halves_sum(q);
-  rstd = rsqrtf(q / (float)NF + eps);
-  mr = -mean * rstd;
-}
-// one block: x*rstd - mean*rstd -> two bf16 operands (the LayerNorm affine lives in the weights that consume it).
-// Not (x - mean)*rstd: the variance pass used x - mean, and reusing it would keep a second copy of the row alive.
-__device__ __forceinline__ void ln_block(Frag8<bf16_t>& lo, Frag8<bf16_t>& hi, const f32x16& x, float rstd, float mr) {
-  const f32x16 y = x * rstd + mr;
-  float a[8], b[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { a[j] = y[j]; b[j] = y[8 + j]; }
-  pack8(lo, a);
-  pack8(hi, b);
-}
-// training: mean / rstd of the lane pair's token leave through the lower lane half (two wave-level stores)
-__device__ __forceinline__ void put_stats(float* st, long tok, int ntok, float rstd, float mr, int lane) {
-  if (lane < 32 && tok < ntok) {
-    st[tok] = -mr / rstd;
-    st[(long)ntok + tok] = rstd;
-  }
-}
-template <int NB>
-__device__ __forceinline__ void ln_to_bop(Frag8<bf16_t> (&bop)[2 * NB], const f32x16 (&acc)[NB], float eps, float* st = nullptr,
-                                          long tok = 0, int ntok = 0, int lane = 0) {
-  float rstd, mr;
-  ln_stats<NB>(acc, eps, rstd, mr);
-  if (st != nullptr) put_stats(st, tok, ntok, rstd, mr, lane);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) ln_block(bop[2 * b], bop[2 * b + 1], acc[b], rstd, mr);
-}
-// x2 (fp32) -> normalised operand and x2 itself as bf16, block by block (each block of xr dies as its operands appear)
-template <int NB>
-__device__ __forceinline__ void ln_and_pack(Frag8<bf16_t> (&lnb)[2 * NB], Frag8<bf16_t> (&xb)[2 * NB], const f32x16 (&acc)[NB],
-                                            float eps, float* st = nullptr, long tok = 0, int ntok = 0, int lane = 0) {
-  float rstd, mr;
-  ln_stats<NB>(acc, eps, rstd, mr);
-  if (st != nullptr) put_stats(st, tok, ntok, rstd, mr, lane);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    ln_block(lnb[2 * b], lnb[2 * b + 1], acc[b], rstd, mr);
-    float a[8], c[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { a[j] = acc[b][j]; c[j] = acc[b][8 + j]; }
-    pack8(xb[2 * b], a);
-    pack8(xb[2 * b + 1], c);
-  }
-}
-
-template <int N> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
-#pragma unroll
-  for (int b = 0; b < N; ++b) acc[b] = (f32x16)(0.f);
 }
 
 // token + 3-axis position embedding of the lane's half row, rounded to bf16 (the value the stream carries)
@@ -557,6 +148,18 @@ __device__ __forceinline__ void embed_coop(Frag8<bf16_t> (&bop)[F / 16], char* s
   }
 }
 
+__device__ __forceinline__ void store_z_tiled(bf16_t* zt, long tok0, int c, const f32x16& z, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = z[8 * j + i];
+    Frag8<bf16_t> f;
+    pack8(f, y);
+    *reinterpret_cast<s16x8*>(zt + tok0 * 256 + ((2 * c + j) * 64 + lane) * 8) = f.v;
+  }
+}
+
 template <int D, int I, int M, bool HEAD, bool TAIL>
 __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P) {
   static_assert(D == 256 && M == 256 && I == 128, "built for the default denoiser widths");
@@ -574,6 +177,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
   ws.cur = 0;
   ws.dbg = P.dbg;
   ws.tot = ws.t1 = ws.t2 = ws.t3 = 0;
+  ws.all = 0;
   ws.wave = wave;
   ws.probe = 0;
   ws.ts = (P.ts != nullptr && blockIdx.x == 0 && lane == 0) ? P.ts + wave * 64 : nullptr;
@@ -653,12 +257,15 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
       float y[8];
       init_vec<1>(zc, v_b1);
       gemm_stage_b<1, D / 16>(zc, lnb, ring0, ws, lane);                           // z0 = b1[0] + W1[0] LN2(x1)
+      const bool zsave = P.zt != nullptr && tile_ok;
+      if (zsave) { store_z_tiled(P.zt, tok0, 0, zc[0], lane); ws_extra(ws, 2); }
       WMZ_TS(5);
       init_vec<1>(zn, v_b1 + MC);
       gemm_stage_b<1, D / 16>(zn, lnb, ring0, ws, lane, side_work<9>([&](int g) {  // z1 | GELU(0), all of it
         gelu_n(y, zc[0], 4 * g, (g & 1) * 4, 4);
         if (g & 1) pack8(gb[g >> 1], y);
       }));
+      if (zsave) { store_z_tiled(P.zt, tok0, 1, zn[0], lane); ws_extra(ws, 2); }
       zc[0] = zn[0];
       WMZ_TS(6);
 #pragma unroll 1
@@ -677,6 +284,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
           if (g == 3) pack8(gn[1], y);
         }));
         ws.probe = 0;
+        if (zsave) { store_z_tiled(P.zt, tok0, c + 1, zn[0], lane); ws_extra(ws, 2); }
         WMZ_TS(7 + 3 * c);
         zc[0] = zn[0];
         gb[0] = gn[0];
@@ -785,7 +393,11 @@ extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, vo
 
 // ---- weight stream packer (host side of the kernel above used to be ~60 small torch launches per layer) ----------
 namespace {
-struct PackBlock { const float* w; long rs; int N, K; const float* gamma; long dst; };   // W[n*rs + k] (* gamma[k]) -> stream
+// element (f, k) of a block = w[f * rs + k * ks] (* gamma[k]) (* rgamma[f]); N output features, K contraction length.
+// gn / gk: ownership groups -- within every group of gn output features (gk contraction indices) lane half 0 owns the
+// first half and lane half 1 the second (forward: gn = N, gk = K: a lane owns one contiguous half row; the backward
+// kernels use groups of 128, the width of an LDS-staged row tile, and of 32 for the hidden axis walked in chunks).
+struct PackBlock { const float* w; long rs, ks; int N, K, gn, gk; const float* gamma; const float* rgamma; long dst; };
 struct PackParams {
   PackBlock blk[24]; int nblk; long total;          // total bf16 elements of the stream (without the padding)
   bf16_t* wpack; long padded;
@@ -804,12 +416,15 @@ __global__ __launch_bounds__(256) void fused_pack_kernel(PackParams P) {
     const int piece = (int)(e / 512), lane = (int)((e % 512) / 8);
     const int s = piece / NB, b = piece % NB;
     const int r = lane & 31, h = lane >> 5;
-    const int f = ((r >> 2) & 1) * (16 * NB) + 16 * b + (r & 3) + 4 * (r >> 3);     // output feature of MFMA row r of block b
-    const int k0 = h * (B.K / 2) + 8 * s;
+    const int bpg = B.gn / 32, spg = B.gk / 16;
+    // output feature of MFMA row r of block b (row r lands in lane half (r >> 2) & 1, accumulator register (r & 3) + 4 (r >> 3))
+    const int f = (b / bpg) * B.gn + ((r >> 2) & 1) * (B.gn / 2) + (b % bpg) * 16 + (r & 3) + 4 * (r >> 3);
+    const int k0 = (s / spg) * B.gk + h * (B.gk / 2) + (s % spg) * 8;
     s16x8 v;
+    const float rg = B.rgamma ? B.rgamma[f] : 1.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float x = B.w[(long)f * B.rs + k0 + j];
+      float x = B.w[(long)f * B.rs + (long)(k0 + j) * B.ks] * rg;
       if (B.gamma) x *= B.gamma[k0 + j];
       v[j] = (short)f32_to_bf16_bits(x);
     }
@@ -853,7 +468,8 @@ extern "C" int wmz_layer_fused_pack(const float* wout, const float* bout, const 
   int n = 0;
   long off = 0;
   auto add = [&](const float* w, long rs, int N, int K, const float* gamma) {
-    P.blk[n].w = w; P.blk[n].rs = rs; P.blk[n].N = N; P.blk[n].K = K; P.blk[n].gamma = gamma; P.blk[n].dst = off;
+    P.blk[n].w = w; P.blk[n].rs = rs; P.blk[n].ks = 1; P.blk[n].N = N; P.blk[n].K = K; P.blk[n].gn = N; P.blk[n].gk = K;
+    P.blk[n].gamma = gamma; P.blk[n].rgamma = nullptr; P.blk[n].dst = off;
     off += (long)N * K; ++n;
   };
   constexpr int MCH = 32;
@@ -881,9 +497,50 @@ extern "C" int wmz_layer_fused_pack(const float* wout, const float* bout, const 
   return WMZ_OK;
 }
 
+// Weight streams of the fused BACKWARD kernels (layer_fused_bwd.hip), TRANSPOSED blocks in consumption order:
+//   wpack_qkv:  Wk'^T | Wv'^T | Wq^T          ([D x I] each; ' = the attention LayerNorm's gamma folded in: rows scaled)
+//   wpack_ff:   W2^T[c] (c = 0 .. M/32-1: [32 x D]) | W1'^T [D x M] | Wout^T [I x D]
+// Either may be NULL.  Each stream is followed by 64 KB of zeros (the kernels' prefetch runs past the end).
+extern "C" int wmz_layer_fused_bwd_pack(const float* wq, const float* wk, const float* wv, const float* g1, const float* wout,
+                                        const float* w1, const float* g2, const float* w2, void* wpack_qkv, void* wpack_ff,
+                                        int D, int I, int M, void* stream) {
+  WMZ_REQUIRE(D == 256 && I == 128 && M == 256, "wmz_layer_fused_bwd_pack: built for dim 256 / inner 128 / mlp 256");
+  WMZ_REQUIRE(wpack_qkv || wpack_ff, "wmz_layer_fused_bwd_pack: nothing to do");
+  WMZ_REQUIRE(!wpack_qkv || (wq && wk && wv && g1), "wmz_layer_fused_bwd_pack: attention parameters missing");
+  WMZ_REQUIRE(!wpack_ff || (wout && w1 && g2 && w2), "wmz_layer_fused_bwd_pack: feed-forward parameters missing");
+  for (int which = 0; which < 2; ++which) {
+    void* dst = which == 0 ? wpack_qkv : wpack_ff;
+    if (dst == nullptr) continue;
+    PackParams P;
+    int n = 0;
+    long off = 0;
+    // element (f, k) = w[f + k * ld]: the transpose of a row-major [K, ld] matrix
+    auto addT = [&](const float* w, long ld, int N, int K, int gn, int gk, const float* rgamma) {
+      P.blk[n].w = w; P.blk[n].rs = 1; P.blk[n].ks = ld; P.blk[n].N = N; P.blk[n].K = K; P.blk[n].gn = gn; P.blk[n].gk = gk;
+      P.blk[n].gamma = nullptr; P.blk[n].rgamma = rgamma; P.blk[n].dst = off;
+      off += (long)N * K; ++n;
+    };
+    if (which == 0) {
+      addT(wk, D, D, I, 128, 128, g1);
+      addT(wv, D, D, I, 128, 128, g1);
+      addT(wq, D, D, I, 128, 128, nullptr);
+    } else {
+      for (int c = 0; c < M / 32; ++c) addT(w2 + c * 32, M, 32, D, 32, 128, nullptr);     // dg_c = W2[:, c]^T dy
+      addT(w1, D, D, M, 128, 32, g2);                                                      // dxhat = W1'^T dz
+      addT(wout, I, I, D, 128, 128, nullptr);                                              // do = Wout^T dx1
+    }
+    P.nblk = n; P.total = off; P.padded = off + 65536 / 2;
+    P.wpack = (bf16_t*)dst;
+    P.bout = P.b1 = P.w1 = P.be2 = P.b2 = P.wk = P.wv = P.be1 = P.bv = nullptr; P.vec = nullptr; P.D = D; P.I = I; P.M = M;
+    hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)wmz_cdiv(P.padded / 8, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  }
+  WMZ_LAUNCH_CHECK("wmz_layer_fused_bwd_pack");
+  return WMZ_OK;
+}
+
 extern "C" int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_out, void* x_out_rowmajor, void* x1_out,
                                          void* q_out, void* kv_out, float* ln_ff_stats, float* ln_attn_stats,
-                                         const void* wpack, const float* vec, int ntok, int D, int I,
+                                         void* z_tiled_out, const void* wpack, const float* vec, int ntok, int D, int I,
                                          int M, int has_head, int has_tail, int xflags, float eps, void* stream) {
   WMZ_REQUIRE(x && wpack && vec && ntok > 0, "wmz_layer_fused_fwd_train: bad arguments");
   WMZ_REQUIRE(has_head || has_tail, "wmz_layer_fused_fwd_train: nothing to do");
@@ -898,6 +555,8 @@ extern "C" int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_o
   P.xflags = xflags;
   P.x1o = (bf16_t*)x1_out; P.xo_rm = (bf16_t*)x_out_rowmajor; P.kv_combined = 1;
   P.st_ff = ln_ff_stats; P.st_attn = has_tail ? ln_attn_stats : nullptr;
+  WMZ_REQUIRE(z_tiled_out == nullptr || (has_head && ntok % 32 == 0), "wmz_layer_fused_fwd_train: z_tiled_out needs the head and whole 32-token tiles");
+  P.zt = (bf16_t*)z_tiled_out;
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
@@ -916,7 +575,7 @@ extern "C" int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb,
   P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
   P.xflags = xflags;
   P.x1o = nullptr; P.xo_rm = (bf16_t*)x_out_rowmajor; P.kv_combined = 1;
-  P.st_ff = nullptr; P.st_attn = ln_attn_stats;
+  P.st_ff = nullptr; P.st_attn = ln_attn_stats; P.zt = nullptr;
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 
@@ -942,7 +601,7 @@ extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_
   if (planes_out != planes_in) { P.rows_out = planes_out * HW; P.rows_in = planes_in * HW; P.row0 = (planes_in - planes_out) * HW; }
   P.xflags = xflags;
   P.x1o = nullptr; P.xo_rm = nullptr; P.kv_combined = 0;
-  P.st_ff = P.st_attn = nullptr;
+  P.st_ff = P.st_attn = nullptr; P.zt = nullptr;
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
@@ -972,7 +631,7 @@ extern "C" int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb
   P.z = z; P.emb = emb; P.pos_s = pos_s; P.pos_h = pos_h; P.pos_w = pos_w; P.S = S; P.H = H; P.W = W; P.num_classes = num_classes;
   P.xflags = xflags;
   P.x1o = nullptr; P.xo_rm = nullptr; P.kv_combined = 0;
-  P.st_ff = P.st_attn = nullptr;
+  P.st_ff = P.st_attn = nullptr; P.zt = nullptr;
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 

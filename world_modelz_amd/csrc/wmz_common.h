@@ -135,6 +135,24 @@ __device__ __forceinline__ float wmz_gelu_fast(float v) {
   return v * __builtin_amdgcn_rcpf(1.f + e);
 }
 
+// wmz_gelu_fast(v) and its derivative in one go (the backward of the fused feed-forward): with s = sigmoid(u(v)),
+// u = v (c1 + c3 v^2 + c5 v^4):  d/dv [v s] = s (1 + v (1 - s) u'(v)).  Max |error| against the exact-erf derivative
+// Phi(v) + v phi(v): 1.1e-4 (checked over [-12, 12]); beyond the clamp u' is the clamped polynomial itself.
+__device__ __forceinline__ void wmz_gelu_fast_both(float v, float& g, float& d) {
+  constexpr float LN2 = 0.6931471805599453f;
+  const float vv = v * v;
+  const float w = fminf(vv, 50.f);
+  float p = fmaf(-1.0148166e-3f, w, 0.10677913f);
+  p = fmaf(p, w, 2.3011176f);
+  const float e = __builtin_amdgcn_exp2f(-p * v);
+  const float s = __builtin_amdgcn_rcpf(1.f + e);
+  g = v * s;
+  float q = fmaf(-5.f * 1.0148166e-3f * LN2, w, 3.f * 0.10677913f * LN2);
+  q = fmaf(q, w, 2.3011176f * LN2);
+  q = vv < 50.f ? q : p * LN2;
+  d = s * fmaf(v * (1.f - s), q, 1.f);
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>) -- for bodies that need the index as a constant
 // expression (instruction immediates in inline asm)
 template <typename F, int... Is>

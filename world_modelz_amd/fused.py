@@ -2,7 +2,7 @@
 inference forward of Local3dAttentionTransformer (bf16, default widths)."""
 import torch
 
-from . import _cast, ops
+from . import _cast, config, ops
 from . import _lib as L
 
 D_, I_, M_ = 256, 128, 256
@@ -65,6 +65,24 @@ def _layer_pack(head, tail):
                D_, I_, M_, L.stream())
         return wpack, vec
     return _cast.cached(params, 'fusedpack', build)
+
+
+def _layer_pack_bwd(attn, ff):
+    """(wpack_qkv, wpack_ff): the TRANSPOSED weight streams of one layer for wmz_qkv_fused_bwd / wmz_ff_fused_bwd, built by
+    wmz_layer_fused_bwd_pack from the fp32 parameters (cached per parameter version like the forward streams)."""
+    a, f = attn.fn, ff.fn
+    params = [a.to_q.weight, a.to_k.weight, a.to_v.weight, attn.norm.weight, a.to_out[0].weight, f.net[0].weight,
+              ff.norm.weight, f.net[3].weight]
+
+    def build(*ps):
+        ps = [p.detach() for p in ps]
+        assert all(p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+        dev = ps[0].device
+        wq = torch.empty(3 * D_ * I_ + _PAD // 2, dtype=torch.bfloat16, device=dev)
+        wf = torch.empty(2 * M_ * D_ + D_ * I_ + _PAD // 2, dtype=torch.bfloat16, device=dev)
+        L.call('wmz_layer_fused_bwd_pack', *[L.ptr(t) for t in ps], L.ptr(wq), L.ptr(wf), D_, I_, M_, L.stream())
+        return wq, wf
+    return _cast.cached(params, 'fusedpackbwd', build)
 
 
 X_IN_TILED, X_OUT_TILED = 1, 2      # include/wmz.h WMZ_FUSED_X_*_TILED
@@ -181,10 +199,11 @@ def _embed_train(tr, z, tiled):
     return (x_t if tiled else x_rm), x_rm, q, kv, st_attn
 
 
-def _layer_train(o, x_in, head, tail, tiled):
+def _layer_train(o, x_in, head, tail, tiled, save_z):
     """x_in: the stream in the layout the previous launch left it in (tiled if `tiled`).  Returns (x_next, x_rm, x1, q, kv,
-    st_ff, st_attn): x_next in that same layout for the next launch (None after the last layer), x_rm / x1 row-major for the
-    backward, st_* the [2, ntok] LayerNorm statistics (feed-forward's norm; the next layer's attention norm or None)."""
+    st_ff, st_attn, zt): x_next in that same layout for the next launch (None after the last layer), x_rm / x1 row-major for
+    the backward, st_* the [2, ntok] LayerNorm statistics (feed-forward's norm; the next layer's attention norm or None), zt
+    the feed-forward pre-activation in the fused backward's tiled layout (None unless save_z)."""
     lead = o.shape[:-1]
     dev, bf = o.device, torch.bfloat16
     ntok = o.numel() // I_
@@ -198,10 +217,11 @@ def _layer_train(o, x_in, head, tail, tiled):
     xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if out_tiled else 0)
     st_ff = torch.empty((2, ntok), dtype=torch.float32, device=dev)
     st_attn = torch.empty((2, ntok), dtype=torch.float32, device=dev) if tail is not None else None
+    zt = torch.empty((ntok, M_), dtype=bf, device=dev) if save_z else None
     L.call('wmz_layer_fused_fwd_train', L.ptr(o), L.ptr(x_in), L.ptr(x_t if out_tiled else x_rm),
-           L.ptr(x_rm if out_tiled else None), L.ptr(x1), L.ptr(q), L.ptr(kv), L.ptr(st_ff), L.ptr(st_attn), L.ptr(wpack),
-           L.ptr(vec), ntok, D_, I_, M_, 1, 1 if tail is not None else 0, xflags, 1e-5, L.stream())
-    return (x_t if out_tiled else (x_rm if tail is not None else None)), x_rm, x1, q, kv, st_ff, st_attn
+           L.ptr(x_rm if out_tiled else None), L.ptr(x1), L.ptr(q), L.ptr(kv), L.ptr(st_ff), L.ptr(st_attn), L.ptr(zt),
+           L.ptr(wpack), L.ptr(vec), ntok, D_, I_, M_, 1, 1 if tail is not None else 0, xflags, 1e-5, L.stream())
+    return (x_t if out_tiled else (x_rm if tail is not None else None)), x_rm, x1, q, kv, st_ff, st_attn, zt
 
 
 def _layer_params(attn, ff):
@@ -209,6 +229,91 @@ def _layer_params(attn, ff):
     return [attn.norm.weight, attn.norm.bias, a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_v.bias,
             a.to_out[0].weight, a.to_out[0].bias, ff.norm.weight, ff.norm.bias,
             f.net[0].weight, f.net[0].bias, f.net[3].weight, f.net[3].bias]
+
+
+class _GradSink:
+    """Where a parameter's gradient goes: its slice of the flat gradient arena (parallel.FlatArena: the kernels accumulate
+    straight into it and the data-parallel reducer is told when the layer's last gradient has landed) or a fresh zero
+    tensor that is handed back to autograd."""
+
+    def __init__(self, *params):
+        self.params = params
+        self.bufs = [getattr(p, '_wmz_grad', None) for p in params]
+        self.direct = all(b is not None for b in self.bufs)
+        if not self.direct:
+            self.bufs = [torch.zeros(p.shape, dtype=torch.float32, device=p.device) for p in params]
+
+    def done(self):
+        """-> the tensors autograd receives (None in arena mode)."""
+        if self.direct:
+            for p in self.params:
+                ready = getattr(p, '_wmz_ready', None)
+                if ready is not None:
+                    ready()
+            return [None] * len(self.params)
+        return self.bufs
+
+
+def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt):
+    """One layer of the stack's backward on the fused per-token kernels: wmz_ff_fused_bwd -> attention backward ->
+    wmz_qkv_fused_bwd, the weight gradients as plain GEMMs over the operands those kernels write, the LayerNorm affine
+    gradients from the raw weight gradients (wmz_ln_affine_grads).  Returns (gradient w.r.t. the layer's input, the 14
+    parameter gradients in _layer_params order)."""
+    an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
+    dev, bf = dy.device, torch.bfloat16
+    lead = dy.shape[:-1]
+    ntok = dy.numel() // D_
+    wpack_qkv, wpack_ff = _layer_pack_bwd(attn, ff)
+    g = torch.empty((ntok, M_), dtype=bf, device=dev)
+    dz = torch.empty((ntok, M_), dtype=bf, device=dev)
+    xhat1 = torch.empty((ntok, D_), dtype=bf, device=dev)
+    dx1 = torch.empty((ntok, D_), dtype=bf, device=dev)
+    do = torch.empty(lead + (I_,), dtype=bf, device=dev)
+    L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
+           L.ptr(do), L.ptr(wpack_ff), ntok, D_, I_, M_, L.stream())
+    dy2 = dy.reshape(ntok, D_)
+    # ---- feed-forward and to_out weight gradients
+    s_ff2 = _GradSink(w2, b2)
+    ops.linear_wgrad(dy2, g, s_ff2.bufs[0], s_ff2.bufs[1])                    # dW2 = dy^T GELU(z), db2 = colsum(dy)
+    G1 = torch.zeros((M_, D_), dtype=torch.float32, device=dev)
+    c1 = torch.zeros((M_,), dtype=torch.float32, device=dev)
+    ops.linear_wgrad(dz, xhat1, G1, c1)                                       # against the NORMALISED input
+    s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
+    L.call('wmz_ln_affine_grads', L.ptr(G1), L.ptr(c1), L.ptr(w1.detach()), L.ptr(fn_g.detach()), L.ptr(fn_b.detach()),
+           L.ptr(s_ff1.bufs[0]), L.ptr(s_ff1.bufs[1]), L.ptr(s_ff1.bufs[2]), L.ptr(s_ff1.bufs[3]), M_, D_, 0, L.stream())
+    s_out = _GradSink(wout, bout)
+    ops.linear_wgrad(dx1, o.reshape(ntok, I_), s_out.bufs[0], s_out.bufs[1])
+    # ---- attention core
+    dq, dkv = ops.local3d_attention_bwd(q, kv[..., :I_], kv[..., I_:], o, lse, do, attn.fn.extents, attn.fn.heads)
+    # ---- to_q / to_k / to_v inputs
+    dx = torch.empty(lead + (D_,), dtype=bf, device=dev)
+    xhat = torch.empty((ntok, D_), dtype=bf, device=dev)
+    L.call('wmz_qkv_fused_bwd', L.ptr(dq), I_, L.ptr(dkv), 2 * I_, L.ptr(x_in), L.ptr(st_attn), L.ptr(dx1), L.ptr(dx),
+           L.ptr(xhat), L.ptr(wpack_qkv), ntok, D_, I_, L.stream())
+    s_q = _GradSink(wq)
+    ops.linear_wgrad(dq.reshape(ntok, I_), x_in.reshape(ntok, D_), s_q.bufs[0])
+    Gkv = torch.zeros((2 * I_, D_), dtype=torch.float32, device=dev)
+    ckv = torch.zeros((2 * I_,), dtype=torch.float32, device=dev)
+    ops.linear_wgrad(dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv)
+    s_kv = _GradSink(wk, wv, bv, an_g, an_b)
+    bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
+    adjacent = (wk.is_contiguous() and wv.is_contiguous() and bk_.is_contiguous() and bw_.is_contiguous()
+                and wv.data_ptr() == wk.data_ptr() + 4 * wk.numel() and bw_.data_ptr() == bk_.data_ptr() + 4 * bk_.numel())
+    if adjacent:                        # FlatArena: to_k.weight | to_v.weight (and their gradients) are one [2I, D] block
+        L.call('wmz_ln_affine_grads', L.ptr(Gkv), L.ptr(ckv), L.ptr(wk.detach()), L.ptr(an_g.detach()), L.ptr(an_b.detach()),
+               L.ptr(bk_), L.ptr(s_kv.bufs[2]), L.ptr(s_kv.bufs[3]), L.ptr(s_kv.bufs[4]), 2 * I_, D_, I_, L.stream())
+    else:
+        L.call('wmz_ln_affine_grads', L.ptr(Gkv[:I_]), L.ptr(ckv[:I_]), L.ptr(wk.detach()), L.ptr(an_g.detach()),
+               L.ptr(an_b.detach()), L.ptr(bk_), None, L.ptr(s_kv.bufs[3]), L.ptr(s_kv.bufs[4]), I_, D_, I_, L.stream())
+        L.call('wmz_ln_affine_grads', L.ptr(Gkv[I_:]), L.ptr(ckv[I_:]), L.ptr(wv.detach()), L.ptr(an_g.detach()),
+               L.ptr(an_b.detach()), L.ptr(bw_), L.ptr(s_kv.bufs[2]), L.ptr(s_kv.bufs[3]), L.ptr(s_kv.bufs[4]), I_, D_, 0,
+               L.stream())
+    g_wk, g_wv, g_bv, g_ag, g_ab = s_kv.done()
+    (g_wq,) = s_q.done()
+    g_wout, g_bout = s_out.done()
+    g_w1, g_b1, g_fg, g_fb = s_ff1.done()
+    g_w2, g_b2 = s_ff2.done()
+    return dx, [g_ag, g_ab, g_wq, g_wk, g_wv, g_bv, g_wout, g_bout, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]
 
 
 class _Ctx:                      # what backward.attention_block_backward / feed_forward_block_backward read off a ctx
@@ -227,16 +332,21 @@ class _TrainForward(torch.autograd.Function):
         layers = list(tr.layers)
         B, S, H, W = z.shape
         tiled = (H * W) % 32 == 0
+        # the fused backward kernels (layer_fused_bwd.hip) work on whole 32-token tiles and read the pre-activation the
+        # forward leaves behind; otherwise the op-by-op backward recomputes it
+        fused_bwd = config.fused_backward() and (B * S * H * W) % 32 == 0
         x_cur, x_rm, q, kv, st_attn = _embed_train(tr, z, tiled)
         saved = []
         for l, (attn, ff) in enumerate(layers):
             o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads, need_lse=True)
             x_in_rm = x_rm
-            x_cur, x_rm, x1, q_n, kv_n, st_ff, st_attn_n = _layer_train(o, x_cur, (attn, ff),
-                                                                       layers[l + 1] if l + 1 < len(layers) else None, tiled)
-            saved += [x_in_rm, q, kv, o, lse, x1, st_attn, st_ff]
+            x_cur, x_rm, x1, q_n, kv_n, st_ff, st_attn_n, zt = _layer_train(o, x_cur, (attn, ff),
+                                                                           layers[l + 1] if l + 1 < len(layers) else None,
+                                                                           tiled, fused_bwd)
+            saved += [x_in_rm, q, kv, o, lse, x1, st_attn, st_ff, zt if zt is not None else lse.new_empty(0)]
             q, kv, st_attn = q_n, kv_n, st_attn_n
         ctx.tr = tr
+        ctx.fused_bwd = fused_bwd
         ctx.save_for_backward(z, *saved)
         return x_rm
 
@@ -249,10 +359,15 @@ class _TrainForward(torch.autograd.Function):
         z, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         grads = [None] * (14 * len(layers))
         dy = dy.contiguous()
+        NS = 9
         for l in range(len(layers) - 1, -1, -1):
             attn, ff = layers[l]
-            x_in, q, kv, o, lse, x1, st_attn, st_ff = saved[8 * l:8 * l + 8]
+            x_in, q, kv, o, lse, x1, st_attn, st_ff, zt = saved[NS * l:NS * l + NS]
             an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
+            if ctx.fused_bwd:
+                dy, g = _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt)
+                grads[14 * l:14 * l + 14] = g
+                continue
             dt = x1.dtype
             # feed-forward block: y = W2 GELU(W1 LN(x1) + b1) + b2 + x1
             stats = (st_ff[0], st_ff[1])                   # computed by the fused forward: no extra pass over x1
