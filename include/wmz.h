@@ -97,12 +97,13 @@ int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long lda, float* d
 
 /* The same with a two-stage reduction instead of float atomics: the slices of M leave their 128 x 128 partial tiles in
  * `workspace` (fp32, at least wmz_linear_wgrad_workspace_floats(M, N, K, dtype) floats, contents undefined afterwards) and
- * a second launch adds their sum to dW / dbias -- deterministic summation order, no same-address atomics.  The caller
- * owns the workspace (the library never allocates); one workspace can serve every wgrad on a stream. */
+ * a second launch adds their sum to dW / dbias (overwrite != 0: stores it instead) -- deterministic summation order, no
+ * same-address atomics.  The caller owns the workspace (the library never allocates); one workspace can serve every wgrad
+ * on a stream. */
 long wmz_linear_wgrad_workspace_floats(int M, int N, int K, int dtype);
 int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N, int K,
                         const float* ln_gamma, const float* ln_beta, const float* ln_mean, const float* ln_rstd,
-                        int gelu_in, float* workspace, long workspace_floats, int dtype, void* stream);
+                        int gelu_in, int overwrite, float* workspace, long workspace_floats, int dtype, void* stream);
 /* nn.LayerNorm statistics (PreNorm, local_3d_attention.py:14): mean[M], rstd[M] over the K axis. */
 int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
                         void* stream);

@@ -329,29 +329,41 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
 }
 
 // dW[N, K] += G[n, k] gamma[k] + s[n] beta[k];  dgamma[k] += sum_n W[n, k] G[n, k];  dbeta[k] += sum_n W[n, k] s[n];
-// dbias[n] += s[n] for n >= bias_from (to_k has no bias: the k | v gradient shares one call).  One thread per column k.
+// dbias[n] += s[n] for n >= bias_from (to_k has no bias: the k | v gradient shares one call).  A workgroup owns 64 columns
+// x 32 rows: thread (row group rg = tid / 64, column) walks 8 rows, the four row groups meet in LDS, one atomic per column.
 __global__ __launch_bounds__(256) void ln_affine_grads_kernel(const float* __restrict__ G, const float* __restrict__ s,
                                                               const float* __restrict__ W, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ dW,
                                                               float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int N, int K, int bias_from, int rows_per) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  const int n0 = blockIdx.y * rows_per, n1 = min(N, n0 + rows_per);
+                                                              float* __restrict__ dbeta, int N, int K, int bias_from) {
+  __shared__ float red[2][4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + c;
+  const int n0 = blockIdx.y * 32 + rg * 8;
+  float ag = 0.f, ab = 0.f;
   if (k < K) {
     const float gk = gamma[k], bk = beta[k];
-    float ag = 0.f, ab = 0.f;
-    for (int n = n0; n < n1; ++n) {
-      const float g = G[(long)n * K + k], w = W[(long)n * K + k], sn = s[n];
-      dW[(long)n * K + k] += fmaf(g, gk, sn * bk);
-      ag = fmaf(w, g, ag);
-      ab = fmaf(w, sn, ab);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + i;
+      if (n < N) {
+        const float g = G[(long)n * K + k], w = W[(long)n * K + k], sn = s[n];
+        dW[(long)n * K + k] += fmaf(g, gk, sn * bk);
+        ag = fmaf(w, g, ag);
+        ab = fmaf(w, sn, ab);
+      }
     }
-    atomicAdd(dgamma + k, ag);
-    atomicAdd(dbeta + k, ab);
   }
-  if (dbias != nullptr && blockIdx.x == 0) {
-    for (int n = n0 + (int)threadIdx.x; n < n1; n += 256)
-      if (n >= bias_from) dbias[n - bias_from] += s[n];
+  red[0][rg][c] = ag;
+  red[1][rg][c] = ab;
+  __syncthreads();
+  if (rg == 0 && k < K) {
+    atomicAdd(dgamma + k, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+    atomicAdd(dbeta + k, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+  }
+  if (dbias != nullptr && blockIdx.x == 0 && threadIdx.x < 32) {
+    const int n = blockIdx.y * 32 + (int)threadIdx.x;
+    if (n < N && n >= bias_from) dbias[n - bias_from] += s[n];
   }
 }
 
@@ -414,9 +426,8 @@ extern "C" int wmz_ln_affine_grads(const float* G, const float* s, const float* 
                                    void* stream) {
   WMZ_REQUIRE(G && s && W && gamma && beta && dW && dgamma && dbeta && N > 0 && K > 0, "wmz_ln_affine_grads: bad arguments");
   WMZ_REQUIRE(bias_from >= 0 && bias_from <= N, "wmz_ln_affine_grads: bad bias_from");
-  const int rows_per = 16;
-  hipLaunchKernelGGL(ln_affine_grads_kernel, dim3((unsigned)wmz_cdiv(K, 256), (unsigned)wmz_cdiv(N, rows_per)), dim3(256), 0,
-                     (hipStream_t)stream, G, s, W, gamma, beta, dW, dbias, dgamma, dbeta, N, K, bias_from, rows_per);
+  hipLaunchKernelGGL(ln_affine_grads_kernel, dim3((unsigned)wmz_cdiv(K, 64), (unsigned)wmz_cdiv(N, 32)), dim3(256), 0,
+                     (hipStream_t)stream, G, s, W, gamma, beta, dW, dbias, dgamma, dbeta, N, K, bias_from);
   WMZ_LAUNCH_CHECK("wmz_ln_affine_grads");
   return WMZ_OK;
 }

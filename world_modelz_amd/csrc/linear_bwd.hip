@@ -410,7 +410,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
 // w + 16, ..: every load is a full coalesced KB and all of a wave's loads are in flight together; the partial sums meet
 // in LDS.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
-                                                            float* __restrict__ dbias, int nsplit, long NK, int N, int nblk_w) {
+                                                            float* __restrict__ dbias, int nsplit, long NK, int N, int nblk_w,
+                                                            int overwrite) {
   __shared__ f32x4 red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < nblk_w) {
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 #pragma unroll
       for (int w = 1; w < 16; ++w) t += red[w][lane];
       f32x4* d = reinterpret_cast<f32x4*>(dW + q);
-      *d = *d + t;
+      *d = overwrite ? t : *d + t;
     }
   } else if (dbias != nullptr) {
     // bias: 64 entries per workgroup, the slices spread over the 16 waves like above (a thread per entry walking all the
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 16; ++w) t += redf[w * 64 + lane];
-      dbias[n] += t;
+      dbias[n] = overwrite ? t : dbias[n] + t;
     }
   }
 }
@@ -677,8 +678,8 @@ extern "C" long wmz_linear_wgrad_workspace_floats(int M, int N, int K, int dtype
 
 extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N,
                                    int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
-                                   const float* ln_rstd, int gelu_in, float* workspace, long workspace_floats, int dtype,
-                                   void* stream) {
+                                   const float* ln_rstd, int gelu_in, int overwrite, float* workspace,
+                                   long workspace_floats, int dtype, void* stream) {
   WMZ_REQUIRE(dC && A && dW && workspace, "wmz_linear_wgrad_ws: null tensor");
   WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_wgrad_ws: bad shape");
   WMZ_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0, "wmz_linear_wgrad_ws: N, K and row strides must be multiples of 8");
@@ -702,7 +703,8 @@ extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long
 #undef WMZ_WG2
   const long NK = (long)N * K;
   const int nblk_w = wmz_cdiv(NK, 256), nblk_b = dbias != nullptr ? wmz_cdiv(N, 64) : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblk_w + nblk_b)), dim3(1024), 0, st, workspace, dW, dbias, P.nsplit, NK, N, nblk_w);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblk_w + nblk_b)), dim3(1024), 0, st, workspace, dW, dbias, P.nsplit, NK, N, nblk_w,
+                     overwrite);
   WMZ_LAUNCH_CHECK("wmz_linear_wgrad_ws");
   return WMZ_OK;
 }

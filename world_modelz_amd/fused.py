@@ -275,9 +275,9 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     # ---- feed-forward and to_out weight gradients
     s_ff2 = _GradSink(w2, b2)
     ops.linear_wgrad(dy2, g, s_ff2.bufs[0], s_ff2.bufs[1])                    # dW2 = dy^T GELU(z), db2 = colsum(dy)
-    G1 = torch.zeros((M_, D_), dtype=torch.float32, device=dev)
-    c1 = torch.zeros((M_,), dtype=torch.float32, device=dev)
-    ops.linear_wgrad(dz, xhat1, G1, c1)                                       # against the NORMALISED input
+    G1 = torch.empty((M_, D_), dtype=torch.float32, device=dev)
+    c1 = torch.empty((M_,), dtype=torch.float32, device=dev)
+    ops.linear_wgrad(dz, xhat1, G1, c1, overwrite=True)                       # against the NORMALISED input
     s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
     L.call('wmz_ln_affine_grads', L.ptr(G1), L.ptr(c1), L.ptr(w1.detach()), L.ptr(fn_g.detach()), L.ptr(fn_b.detach()),
            L.ptr(s_ff1.bufs[0]), L.ptr(s_ff1.bufs[1]), L.ptr(s_ff1.bufs[2]), L.ptr(s_ff1.bufs[3]), M_, D_, 0, L.stream())
@@ -292,9 +292,9 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
            L.ptr(xhat), L.ptr(wpack_qkv), ntok, D_, I_, L.stream())
     s_q = _GradSink(wq)
     ops.linear_wgrad(dq.reshape(ntok, I_), x_in.reshape(ntok, D_), s_q.bufs[0])
-    Gkv = torch.zeros((2 * I_, D_), dtype=torch.float32, device=dev)
-    ckv = torch.zeros((2 * I_,), dtype=torch.float32, device=dev)
-    ops.linear_wgrad(dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv)
+    Gkv = torch.empty((2 * I_, D_), dtype=torch.float32, device=dev)
+    ckv = torch.empty((2 * I_,), dtype=torch.float32, device=dev)
+    ops.linear_wgrad(dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv, overwrite=True)
     s_kv = _GradSink(wk, wv, bv, an_g, an_b)
     bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
     adjacent = (wk.is_contiguous() and wv.is_contiguous() and bk_.is_contiguous() and bw_.is_contiguous()

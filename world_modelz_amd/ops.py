@@ -203,9 +203,9 @@ def _workspace(device, floats):
     return w
 
 
-def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False):
-    """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc).  dw / dbias fp32, accumulated (two-stage reduction through a
-    per-device workspace: deterministic, no float atomics)."""
+def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, overwrite=False):
+    """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc) (overwrite: = instead of +=).  dw / dbias fp32 (two-stage reduction
+    through a per-device workspace: deterministic, no float atomics)."""
     dt = L.dtype_code(dc.dtype)
     dc, M, ldc = _rows(dc)
     a, Ma, lda = _rows(a)
@@ -218,7 +218,7 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False):
     need = L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
     ws = _workspace(dc.device, need)
     L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
-           L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, L.ptr(ws), ws.numel(), dt, L.stream())
+           L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, 1 if overwrite else 0, L.ptr(ws), ws.numel(), dt, L.stream())
 
 
 def layernorm_stats(x, eps=1e-5):

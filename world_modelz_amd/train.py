@@ -253,7 +253,12 @@ class _TrainerBase:
         if dt == torch.float32 or not self.arena.flat_param.is_cuda:
             return bulk                                  # parity mode: weights are used as they are, transposes per use
         tr = self.model.transformer
-        for attn, ff in tr.layers:
+        from . import config, fused
+        # the default-width denoiser trains on the fused per-token kernels in both directions: they read their own packed
+        # weight streams (fused._layer_pack / _layer_pack_bwd), none of the per-layer operand copies below
+        layers = [] if (hasattr(tr, 'pos_emb_s') and fused.supported(tr, dt) and config.get_fused_training()
+                        and config.fused_backward()) else list(tr.layers)
+        for attn, ff in layers:
             a, f = attn.fn, ff.fn
             if hasattr(a, 'to_qkv'):                     # config 5: lucidrains ViT block with one fused projection
                 bulk.add((a.to_qkv.weight,), dt, 'w')
