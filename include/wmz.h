@@ -217,6 +217,17 @@ int wmz_layer_fused_pack(const float* wout, const float* bout, const float* g2, 
                          const float* wq, const float* wk, const float* wv, const float* bv, void* wpack, float* vec,
                          int D, int I, int M, void* stream);
 
+/* Every weight stream / vector block of a model in two launches (training repacks them after each optimizer step).
+ * block_rows: DEVICE array of nblk + 1 rows of eleven 64-bit fields { w, rs, ks, N, K, gn, gk, gamma, rgamma, dst, start8 }:
+ * block element (f, k) = w[f * rs + k * ks] (* gamma[k]) (* rgamma[f]) for N output features x K contraction indices,
+ * ownership groups gn / gk (forward streams: gn = N, gk = K; backward streams: see wmz_layer_fused_bwd_pack), written as
+ * bf16 to dst in the kernels' piece order; start8 = index of the block's first 8-element group in the launch (row nblk:
+ * total8).  vec_jobs: DEVICE array of nvec rows of ten pointers { bout, b1, w1, be2, b2, wk, wv, be1, bv, vec } (the
+ * inputs and output of wmz_layer_fused_pack's vector block; absent parts NULL).  The streams' zero padding is the caller's
+ * (allocate the buffers zeroed once).  world_modelz_amd/fused.py::PackSet builds the tables. */
+int wmz_fused_pack_table(const void* block_rows, int nblk, long total8, const void* vec_jobs, int nvec, int D, int I, int M,
+                         void* stream);
+
 /* Training forward on the same kernels (replaces the five per-op GEMM launches per layer of the training forward).
  * Besides the inference outputs they write what the backward (wmz_linear_wgrad, wmz_layernorm_bwd, wmz_local3d_attn_bwd
  * ..) reads, row-major: x1_out [ntok, D] = the feed-forward block's input (x + to_out(o)), x_out_rowmajor [ntok, D] = a

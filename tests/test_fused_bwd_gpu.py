@@ -120,3 +120,37 @@ def test_ln_affine_grads_vs_torch():
            L.ptr(db), N, K, 128, L.stream())
     for a, b in zip((dW, dbias, dg, db), ref):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_pack_set_equals_the_per_stream_packers():
+    """fused.PackSet (one table-driven call for every stream of the model) fills exactly what wmz_layer_fused_pack /
+    wmz_layer_fused_bwd_pack produce stream by stream, and stamps the cache entries the forward / backward look up."""
+    from world_modelz_amd import _cast, fused
+    from world_modelz_amd.local_3d_attention import Local3dAttentionTransformer
+    torch.manual_seed(6)
+    tr = Local3dAttentionTransformer(data_shape=(2, 16, 16), dim=D, num_classes=32, extents=(1, 1, 1), depth=3, mlp_dim=M,
+                                     dim_head=I, heads=1).cuda()
+    with torch.no_grad():
+        for p in tr.parameters():
+            if p.dim() == 1:
+                p.add_(0.3 * torch.randn_like(p))
+    layers = list(tr.layers)
+    _cast.clear()
+    ref = []
+    for head, tail in [(None, layers[0])] + [(layers[l], layers[l + 1] if l + 1 < 3 else None) for l in range(3)]:
+        ref.append([t.clone() for t in fused._layer_pack(head, tail)])
+    for attn, ff in layers:
+        ref.append([t.clone() for t in fused._layer_pack_bwd(attn, ff)])
+    _cast.clear()
+    ps = fused.PackSet(tr)
+    ps.refresh()
+    torch.cuda.synchronize()
+    got = []
+    for head, tail in [(None, layers[0])] + [(layers[l], layers[l + 1] if l + 1 < 3 else None) for l in range(3)]:
+        got.append(fused._layer_pack(head, tail))          # cache hits: the PackSet's persistent buffers
+    for attn, ff in layers:
+        got.append(fused._layer_pack_bwd(attn, ff))
+    assert any(g[0].data_ptr() == e[2][0].data_ptr() for g in got for e in ps.entries)
+    for r, g in zip(ref, got):
+        for a, b in zip(r, g):
+            assert a.shape == b.shape and torch.equal(a, b)

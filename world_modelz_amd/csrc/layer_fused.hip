@@ -497,6 +497,81 @@ extern "C" int wmz_layer_fused_pack(const float* wout, const float* bout, const 
   return WMZ_OK;
 }
 
+// ---- every weight stream and vector block of a whole model in TWO launches (training: after each optimizer step) ----------
+// The per-boundary entry points above cost a launch pair per stream (13 + 5 launches of ~7 us per config-4 step).  Here the
+// block descriptors live in DEVICE memory, built once by the host (fused.PackSet): table rows of eleven 64-bit fields
+//   { w, rs, ks, N, K, gn, gk, gamma, rgamma, dst, start8 }      (PackBlock above; dst = the block's first stream element,
+//                                                                  start8 = first 8-element group of the block in the
+//                                                                  launch's global numbering; one extra row = the end)
+// and vector jobs of ten 64-bit fields { bout, b1, w1, be2, b2, wk, wv, be1, bv, vec } (fused_pack_vec_kernel's inputs).
+namespace {
+struct PackRowG { const float* w; long rs, ks, N, K, gn, gk; const float* gamma; const float* rgamma; bf16_t* dst; long start8; };
+struct VecJobG { const float *bout, *b1, *w1, *be2, *b2, *wk, *wv, *be1, *bv; float* vec; };
+static_assert(sizeof(PackRowG) == 88 && sizeof(VecJobG) == 80, "table layouts are part of the C ABI");
+
+__global__ __launch_bounds__(256) void fused_pack_table_kernel(const PackRowG* __restrict__ rows, int nblk, long total8) {
+  const long g8 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (g8 >= total8) return;
+  int lo = 0, hi = nblk - 1;                             // last block with start8 <= g8
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (rows[mid].start8 <= g8) lo = mid; else hi = mid - 1;
+  }
+  const PackRowG B = rows[lo];
+  const long e = (g8 - B.start8) * 8;
+  const int NB = (int)B.N / 32;
+  const int piece = (int)(e / 512), lane = (int)((e % 512) / 8);
+  const int s = piece / NB, b = piece % NB;
+  const int r = lane & 31, h = lane >> 5;
+  const int bpg = (int)B.gn / 32, spg = (int)B.gk / 16;
+  const int f = (b / bpg) * (int)B.gn + ((r >> 2) & 1) * ((int)B.gn / 2) + (b % bpg) * 16 + (r & 3) + 4 * (r >> 3);
+  const int k0 = (s / spg) * (int)B.gk + h * ((int)B.gk / 2) + (s % spg) * 8;
+  const float rg = B.rgamma ? B.rgamma[f] : 1.f;
+  s16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float x = B.w[(long)f * B.rs + (long)(k0 + j) * B.ks] * rg;
+    if (B.gamma) x *= B.gamma[k0 + j];
+    v[j] = (short)f32_to_bf16_bits(x);
+  }
+  *reinterpret_cast<s16x8*>(B.dst + e) = v;
+}
+
+__global__ __launch_bounds__(256) void fused_pack_vec_table_kernel(const VecJobG* __restrict__ jobs, int D, int I, int M) {
+  const VecJobG P = jobs[blockIdx.y];
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= 2048) return;
+  const float* row = nullptr; const float* vecb = nullptr; float base = 0.f;
+  if (t < D) base = P.bout ? P.bout[t] : 0.f;
+  else if (t < D + M) { if (P.b1) { base = P.b1[t - D]; row = P.w1 + (long)(t - D) * D; vecb = P.be2; } }
+  else if (t < 2 * D + M) base = P.b2 ? P.b2[t - D - M] : 0.f;
+  else if (t < 2 * D + M + I) { if (P.wk) { row = P.wk + (long)(t - 2 * D - M) * D; vecb = P.be1; } }
+  else if (t < 2 * D + M + 2 * I) { if (P.wv) { base = P.bv[t - 2 * D - M - I]; row = P.wv + (long)(t - 2 * D - M - I) * D; vecb = P.be1; } }
+  float acc = 0.f;
+  if (row != nullptr) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + lane * 4), b = *reinterpret_cast<const f32x4*>(vecb + lane * 4);
+    acc = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    acc = wave_sum(acc);
+  }
+  if (lane == 0) P.vec[t] = base + acc;
+}
+}  // namespace
+
+extern "C" int wmz_fused_pack_table(const void* block_rows, int nblk, long total8, const void* vec_jobs, int nvec, int D, int I,
+                                    int M, void* stream) {
+  WMZ_REQUIRE(nblk >= 0 && nvec >= 0 && (nblk == 0 || (block_rows && total8 > 0)) && (nvec == 0 || vec_jobs),
+              "wmz_fused_pack_table: bad arguments");
+  WMZ_REQUIRE(D == 256 && I == 128 && M == 256, "wmz_fused_pack_table: built for dim 256 / inner 128 / mlp 256");
+  if (nblk > 0)
+    hipLaunchKernelGGL(fused_pack_table_kernel, dim3((unsigned)wmz_cdiv(total8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const PackRowG*)block_rows, nblk, total8);
+  if (nvec > 0)
+    hipLaunchKernelGGL(fused_pack_vec_table_kernel, dim3(512, (unsigned)nvec), dim3(256), 0, (hipStream_t)stream,
+                       (const VecJobG*)vec_jobs, D, I, M);
+  WMZ_LAUNCH_CHECK("wmz_fused_pack_table");
+  return WMZ_OK;
+}
+
 // Weight streams of the fused BACKWARD kernels (layer_fused_bwd.hip), TRANSPOSED blocks in consumption order:
 //   wpack_qkv:  Wk'^T | Wv'^T | Wq^T          ([D x I] each; ' = the attention LayerNorm's gamma folded in: rows scaled)
 //   wpack_ff:   W2^T[c] (c = 0 .. M/32-1: [32 x D]) | W1'^T [D x M] | Wout^T [I x D]

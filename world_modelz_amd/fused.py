@@ -85,6 +85,107 @@ def _layer_pack_bwd(attn, ff):
     return _cast.cached(params, 'fusedpackbwd', build)
 
 
+class PackSet:
+    """Every packed weight stream / vector block the fused kernels of one transformer read -- the forward boundaries
+    (_layer_pack) and each layer's two backward streams (_layer_pack_bwd) -- rebuilt together by ONE call of
+    wmz_fused_pack_table (two launches) instead of a launch pair per stream.  The block descriptors are device-resident
+    tables built once (rebuilt if a parameter moves); refresh() fills the persistent buffers and stamps the very cache
+    entries _layer_pack / _layer_pack_bwd look up, so the forward and backward code is unchanged.  Training calls it after
+    every optimizer step (train.py), next to _cast.BulkOperands.refresh()."""
+
+    def __init__(self, tr, backward=True):
+        self.tr = tr
+        self.backward = backward
+        self._ptrs = None
+        self._build()
+
+    def _params(self):
+        return [p for p in self.tr.parameters()]
+
+    def _build(self):
+        import numpy as np
+        layers = list(self.tr.layers)
+        dev = layers[0][0].norm.weight.device
+        rows, jobs, self.entries = [], [], []
+        state = {'g8': 0}
+
+        def ptr(t, off=0):
+            return 0 if t is None else t.data_ptr() + 4 * off
+
+        def block(dst, doff, w, woff, rs, ks, N, K, gn, gk, gamma, rgamma):
+            rows.append([ptr(w, woff), rs, ks, N, K, gn, gk, ptr(gamma), ptr(rgamma), dst.data_ptr() + 2 * doff, state['g8']])
+            state['g8'] += N * K // 8
+            return doff + N * K
+
+        bounds = [(None, layers[0])] + [(layers[l], layers[l + 1] if l + 1 < len(layers) else None) for l in range(len(layers))]
+        for head, tail in bounds:
+            nw = (D_ * I_ + 2 * M_ * D_ if head is not None else 0) + (3 * I_ * D_ if tail is not None else 0)
+            wpack = torch.zeros(nw + _PAD // 2, dtype=torch.bfloat16, device=dev)
+            vec = torch.zeros(2048, dtype=torch.float32, device=dev)
+            params, off = [], 0
+            job = [0] * 10
+            if head is not None:
+                attn, ff = head
+                wout, bout, g2, be2 = attn.fn.to_out[0].weight, attn.fn.to_out[0].bias, ff.norm.weight, ff.norm.bias
+                w1, b1, w2, b2 = ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias
+                params += [wout, bout, g2, be2, w1, b1, w2, b2]
+                off = block(wpack, off, wout, 0, I_, 1, D_, I_, D_, I_, None, None)
+                off = block(wpack, off, w1, 0, D_, 1, MC_, D_, MC_, D_, g2, None)
+                for c in range(1, M_ // MC_):
+                    off = block(wpack, off, w1, c * MC_ * D_, D_, 1, MC_, D_, MC_, D_, g2, None)
+                    off = block(wpack, off, w2, (c - 1) * MC_, M_, 1, D_, MC_, D_, MC_, None, None)
+                off = block(wpack, off, w2, (M_ // MC_ - 1) * MC_, M_, 1, D_, MC_, D_, MC_, None, None)
+                job[0:5] = [ptr(bout), ptr(b1), ptr(w1), ptr(be2), ptr(b2)]
+            if tail is not None:
+                an = tail[0]
+                g1, be1 = an.norm.weight, an.norm.bias
+                wq, wk, wv, bv = an.fn.to_q.weight, an.fn.to_k.weight, an.fn.to_v.weight, an.fn.to_v.bias
+                params += [g1, be1, wq, wk, wv, bv]
+                off = block(wpack, off, wq, 0, D_, 1, I_, D_, I_, D_, None, None)
+                off = block(wpack, off, wk, 0, D_, 1, I_, D_, I_, D_, g1, None)
+                off = block(wpack, off, wv, 0, D_, 1, I_, D_, I_, D_, g1, None)
+                job[5:9] = [ptr(wk), ptr(wv), ptr(be1), ptr(bv)]
+            assert off == nw
+            job[9] = vec.data_ptr()
+            jobs.append(job)
+            self.entries.append((tuple(params), 'fusedpack', (wpack, vec)))
+        if self.backward:
+            for attn, ff in layers:
+                a, f = attn.fn, ff.fn
+                wq, wk, wv, g1 = a.to_q.weight, a.to_k.weight, a.to_v.weight, attn.norm.weight
+                wout, w1, g2, w2 = a.to_out[0].weight, f.net[0].weight, ff.norm.weight, f.net[3].weight
+                sq = torch.zeros(3 * D_ * I_ + _PAD // 2, dtype=torch.bfloat16, device=dev)
+                sf = torch.zeros(2 * M_ * D_ + D_ * I_ + _PAD // 2, dtype=torch.bfloat16, device=dev)
+                off = block(sq, 0, wk, 0, 1, D_, D_, I_, 128, 128, None, g1)
+                off = block(sq, off, wv, 0, 1, D_, D_, I_, 128, 128, None, g1)
+                off = block(sq, off, wq, 0, 1, D_, D_, I_, 128, 128, None, None)
+                off = 0
+                for c in range(M_ // 32):
+                    off = block(sf, off, w2, c * 32, 1, M_, 32, D_, 32, 128, None, None)
+                off = block(sf, off, w1, 0, 1, D_, D_, M_, 128, 32, None, g2)
+                off = block(sf, off, wout, 0, 1, I_, I_, D_, 128, 128, None, None)
+                self.entries.append(((wq, wk, wv, g1, wout, w1, g2, w2), 'fusedpackbwd', (sq, sf)))
+        self.nblk = len(rows)
+        self.total8 = state['g8']
+        rows.append([0] * 10 + [self.total8])
+        self.rows = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+        self.jobs = torch.from_numpy(np.asarray(jobs, dtype=np.int64)).to(dev)
+        self.njobs = len(jobs)
+        self._ptrs = [p.data_ptr() for p in self._params()]
+
+    def refresh(self):
+        import weakref
+        ps = self._params()
+        assert all(p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+        if [p.data_ptr() for p in ps] != self._ptrs:
+            self._build()                                  # a parameter moved (.to(), re-allocation): new tables
+        L.call('wmz_fused_pack_table', L.ptr(self.rows), self.nblk, self.total8, L.ptr(self.jobs), self.njobs, D_, I_, M_,
+               L.stream())
+        for params, tag, val in self.entries:
+            ver = (_cast._epoch,) + tuple((p._version, p.data_ptr()) for p in params)
+            _cast._cache[_cast._key(params, None, tag)] = (ver, val, tuple(weakref.ref(p) for p in params))
+
+
 X_IN_TILED, X_OUT_TILED = 1, 2      # include/wmz.h WMZ_FUSED_X_*_TILED
 
 

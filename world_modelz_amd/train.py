@@ -240,8 +240,9 @@ class _TrainerBase:
         self.sampler_gen = torch.Generator()
         self.sampler_gen.manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0x7FFFFFFFFFFFFFFF)
         self.sampler = LossAwareSamplerEma(num_histogram_buckets=100, uniform_p=0.01, alpha=0.9, warmup=10)
+        self.packs = None                  # fused.PackSet: the fused kernels' weight streams, rebuilt with the operands
         self.operands = self._register_operands()
-        self.operands.refresh()
+        self._refresh_operands()
         self._graph = None                 # captured training step (enable_graph)
 
     def _register_operands(self):
@@ -256,8 +257,10 @@ class _TrainerBase:
         from . import config, fused
         # the default-width denoiser trains on the fused per-token kernels in both directions: they read their own packed
         # weight streams (fused._layer_pack / _layer_pack_bwd), none of the per-layer operand copies below
-        layers = [] if (hasattr(tr, 'pos_emb_s') and fused.supported(tr, dt) and config.get_fused_training()
-                        and config.fused_backward()) else list(tr.layers)
+        layers = list(tr.layers)
+        if hasattr(tr, 'pos_emb_s') and fused.supported(tr, dt) and config.get_fused_training() and config.fused_backward():
+            layers = []
+            self.packs = fused.PackSet(tr)
         for attn, ff in layers:
             a, f = attn.fn, ff.fn
             if hasattr(a, 'to_qkv'):                     # config 5: lucidrains ViT block with one fused projection
@@ -293,8 +296,13 @@ class _TrainerBase:
         L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                float(lr), self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), st)
         _cast.invalidate()            # the kernel rewrote the arena behind torch's version counters
-        self.operands.refresh()       # ... and every operand copy of the weights is rebuilt by one launch
+        self._refresh_operands()      # ... and every operand copy of the weights is rebuilt by one launch
         return self.sq
+
+    def _refresh_operands(self):
+        self.operands.refresh()
+        if self.packs is not None:
+            self.packs.refresh()
 
 
 class DenoiserTrainer(_TrainerBase):
@@ -361,7 +369,7 @@ class DenoiserTrainer(_TrainerBase):
         # whatever is derived from the weights is rebuilt INSIDE the graph, every replay: the bulk operand copies by one
         # launch here, the fused kernels' weight streams by the forward (their cache entries are stale by construction)
         _cast.invalidate()
-        self.operands.refresh()
+        self._refresh_operands()
         per_sample, mean = self.forward_backward(zc, target)
         st = L.stream()
         self.sq.zero_()
