@@ -155,6 +155,21 @@ def test_untracked_loads_stay_untouched_until_their_wait():
     assert r.stdout.count('touches in between: 0') >= 2, r.stdout
 
 
+def test_fused_backward_kernels_are_straight_line_and_never_touch_loads_in_flight():
+    """layer_fused_bwd.hip retires its compiler-untracked operand loads with counted s_waitcnt vmcnt(n): that is only safe
+    for straight-line code without scratch traffic in which no instruction touches a load's destination registers before
+    the wait that retires it.  tools/check_untracked_bwd.py compiles the file to ISA and simulates the vmcnt queue."""
+    import os, shutil, subprocess, sys
+    if shutil.which('hipcc') is None:
+        import pytest
+        pytest.skip('hipcc not on PATH')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_untracked_bwd.py')], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('violations: 0') == 3, r.stdout
+
+
 def test_lazy_one_hot_behaves_like_the_dense_encodings():
     """VectorQuantizerEMA.forward returns `encodings` (reference vq.py:39) as a stand-in that materialises the dense one-hot
     only when it is read: torch functions, tensor methods, indexing."""
