@@ -210,9 +210,7 @@ def dense_attention_block_backward(ctx, dy):
     dwout = dbout = None
     if wout is not None:
         do = ops.linear_dgrad(dy, _wt(wout, dt, 'woutT'))
-        dwout = torch.zeros_like(wout, dtype=torch.float32)
-        dbout = torch.zeros_like(bout, dtype=torch.float32)
-        ops.linear_wgrad(dy, o, dwout, dbout)
+        dwout, dbout = _emit2(wout, bout, lambda w, b: ops.linear_wgrad(dy, o, w, b))
     else:
         do = dy
     (S, H, W), ext = _dense_grid(n)
@@ -220,18 +218,21 @@ def dense_attention_block_backward(ctx, dy):
     dqkv = torch.empty_like(qkv)
     ops.local3d_attention_bwd(g[..., :I], g[..., I:2 * I], g[..., 2 * I:], o.view(B, S, H, W, I), lse,
                               do.view(B, S, H, W, I), ext, ctx.heads, dqkv=dqkv.view(B, S, H, W, 3 * I))
-    dwqkv = torch.zeros_like(wqkv, dtype=torch.float32)
     dxhat = ops.linear_dgrad(dqkv, _wt(wqkv, dt, 'wqkvT'))
     dg = db = None
     fold = ctx.has_res and ctx.res_is_x
     if ln_g is not None:
         stats = ops.layernorm_stats(x, LN_EPS)
-        ops.linear_wgrad(dqkv, x, dwqkv, None, ln=(ln_g.detach(), ln_b.detach()), ln_stats=stats)
-        dg = torch.zeros_like(ln_g, dtype=torch.float32)
-        db = torch.zeros_like(ln_b, dtype=torch.float32)
-        dx = ops.layernorm_bwd(x, dxhat, ln_g.detach(), dg, db, skip=d_res if fold else None, eps=LN_EPS)
+        lnp = (ln_g.detach(), ln_b.detach())
+        dwqkv = _emit(wqkv, lambda w: ops.linear_wgrad(dqkv, x, w, None, ln=lnp, ln_stats=stats))
+        holder = {}
+
+        def fill_ln(gg, gb):
+            holder['dx'] = ops.layernorm_bwd(x, dxhat, ln_g.detach(), gg, gb, skip=d_res if fold else None, eps=LN_EPS)
+        dg, db = _emit2(ln_g, ln_b, fill_ln)
+        dx = holder['dx']
     else:
-        ops.linear_wgrad(dqkv, x, dwqkv, None)
+        dwqkv = _emit(wqkv, lambda w: ops.linear_wgrad(dqkv, x, w, None))
         dx = dxhat + d_res if fold else dxhat
     g_res = None if (not ctx.has_res or fold) else d_res
     return dx.reshape(x.shape), dg, db, dwqkv, dwout, dbout, g_res, None, None, None
