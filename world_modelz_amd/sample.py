@@ -43,6 +43,8 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
     batch_z = batch_z.clone()
     batch_z[:, -1] = mask_token                                   # destroy all information in the last frame (:62)
     fwd = GraphedForward(model, batch_z) if use_graph else None
+    if fwd is not None:
+        batch_z = fwd.static_in                                   # the loop edits the graph's own input buffer: no staging copy
     dev = batch_z.device
     if uniforms is not None:
         u_multi, u_mask = (t.to(dev) for t in uniforms)
@@ -73,4 +75,4 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
             logits = (fwd(batch_z) if fwd is not None else model(batch_z)).reshape(B * H * W, num_embeddings).float()
         out.append(denoised.view(B, H, W).clone())
         batch_z[:, :-1] = batch_z[:, 1:].clone()                  # shift frames (:115)
-    return out, batch_z
+    return out, (batch_z.clone() if fwd is not None else batch_z)   # (never hand out the graph's own buffer)
