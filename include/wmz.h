@@ -281,7 +281,7 @@ int wmz_ln_affine_grads(const float* G, const float* s, const float* W, const fl
  * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */
 int wmz_debug_fused_timestamps(void* buf);
 /* Ablation switches of the fused per-token kernel (timing experiments only, results are garbage): 1 = skip the MFMA loops,
- * 2 = skip the weight DMA and its waits; 0 = product behaviour. */
+ * 2 = skip the weight DMA and its waits, 4 = skip the per-slab workgroup barrier (bits combine); 0 = product behaviour. */
 int wmz_debug_fused_knobs(int dbg);
 /* Same for the 16-wide-plane attention forward kernel (16 waves x 64 int64). */
 int wmz_debug_attn_timestamps(void* buf);

@@ -87,7 +87,7 @@ __device__ __forceinline__ void ws_wait(WStream& ws) {
 #undef WMZ_VMC
   }
   if (ws.probe && ws.ts) ws.ts[ws.probe] = __builtin_readcyclecounter();
-  __builtin_amdgcn_s_barrier();
+  if (!(ws.dbg & 4)) __builtin_amdgcn_s_barrier();     // (dbg 4: timing experiment without the per-slab rendezvous; garbage results)
   if (ws.probe && ws.ts) ws.ts[ws.probe + 1] = __builtin_readcyclecounter();
 }
 __device__ __forceinline__ void ws_release(WStream& ws) { ws.cur = ws.cur == RING - 1 ? 0 : ws.cur + 1; }
