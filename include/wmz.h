@@ -104,6 +104,13 @@ long wmz_linear_wgrad_workspace_floats(int M, int N, int K, int dtype);
 int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N, int K,
                         const float* ln_gamma, const float* ln_beta, const float* ln_mean, const float* ln_rstd,
                         int gelu_in, int overwrite, float* workspace, long workspace_floats, int dtype, void* stream);
+/* n <= 6 independent weight gradients (no prologue) by ONE launch pair: HOST tables of n entries each, the arguments of
+ * wmz_linear_wgrad_ws per problem; the workspace must hold the sum of the problems' workspace sizes.  (The fused backward
+ * of a transformer layer has five such GEMMs whose launches are each one wave of workgroups: batched they share the ramp
+ * and the tail.) */
+int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
+                           float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
+                           const int* overwrite, float* workspace, long workspace_floats, int dtype, void* stream);
 /* nn.LayerNorm statistics (PreNorm, local_3d_attention.py:14): mean[M], rstd[M] over the K axis. */
 int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
                         void* stream);

@@ -54,6 +54,12 @@ struct WgParams {
   // PRO == 3: A is the implicit im2col of an NHWC tensor x[B,Hi,Wi,Cin] (row m = output pixel, k = (kh, kw, ci))
   int Hi, Wi, Cin, Ho, Wo, KW, cstride, cpad;
 };
+// several independent weight gradients in ONE launch pair (wgrad2_kernel + wgrad_reduce_kernel): the workgroups of problem
+// i are first[i] .. first[i+1]-1, its partial tiles live at workspace + wsoff[i]
+constexpr int WG_MAXB = 6;
+struct WgBatch { WgParams p[WG_MAXB]; int first[WG_MAXB + 1]; long wsoff[WG_MAXB]; int n; };
+struct RedProb { float* dW; float* dbias; long wsoff, NK; int nsplit, N, nblk_w, overwrite, first; };
+struct RedBatch { RedProb p[WG_MAXB]; int n; };
 
 constexpr int WG_BN = 128, WG_BK = 128, WG_MS = 32;
 
@@ -210,7 +216,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(WgParams P) {
 template <typename T> struct W2 { static constexpr int MS = sizeof(T) == 2 ? 64 : 32; };
 
 template <typename T, int PRO>
-__global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __restrict__ ws) {
+__global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restrict__ ws_base) {
+  int pi = 0;                                            // this workgroup's problem (uniform)
+#pragma unroll
+  for (int i = 1; i < WG_MAXB; ++i) if (i < B.n && (int)blockIdx.x >= B.first[i]) pi = i;
+  const WgParams P = B.p[pi];
+  float* __restrict__ ws = ws_base + B.wsoff[pi];
+  const int wg0 = B.first[pi], nwg = B.first[pi + 1] - B.first[pi];
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int ROWB = WG_BN * (int)sizeof(T);
   constexpr int CPR = ROWB / 16;
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
   __shared__ __attribute__((aligned(16))) char smem[4 * IMG];   // [buffer][dC image | A image]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);          // the tiles of one slice of M share an XCD: its L2 serves the operands' re-reads
+  int bid = xcd_remap((int)blockIdx.x - wg0, nwg);         // the tiles of one slice of M share an XCD: its L2 serves the operands' re-reads
   const int bk = bid % P.nbk; bid /= P.nbk;
   const int bn = bid % P.nbn; bid /= P.nbn;
   const int split = bid;
@@ -294,39 +306,6 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-#if 0
-          if constexpr (PRO == 1 || PRO == 2) {
-            float f[EPC];
-            unpack_chunk<T>(v, f);
-            if constexpr (PRO == 1) {
-              const float mu = P.mean[m], rs = P.rstd[m];
-#pragma unroll
-              for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k0 + c * EPC + e] + P.beta[k0 + c * EPC + e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
-            }
-            v = pack_chunk<T>(f);
-          }
-          ra[it] = v;
-        }
-      }
-    }
-  };
-  auto stash = [&](int buf) {
-    char* Cs = smem + buf * 2 * IMG;
-    char* As = Cs + IMG;
-#pragma unroll
-    for (int it = 0; it < PER_T; ++it) {
-      const int idx = tid + it * NT;
-      const int r = idx / CPR, c = idx - r * CPR;
-      const int off = r * ROWB + ((c << 4) ^ wswz<T>(r));
-      *reinterpret_cast<i32x4*>(Cs + off) = rc[it];
-      *reinterpret_cast<i32x4*>(As + off) = ra[it];
-    }
-  };
-
-#endif
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -394,14 +373,12 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
         const int n = n0 + wn + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
         if (n < P.N) {
           const long q = (long)n * P.K + kc;
-          if (ws != nullptr) ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[i][j][reg];
-          else atomicAdd(P.dW + q, acc[i][j][reg]);
+          ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[i][j][reg];
         }
       }
     }
   if (P.dbias != nullptr && bk == 0 && tid < WG_BN && n0 + tid < P.N) {
-    if (ws != nullptr) ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = bsum;
-    else atomicAdd(P.dbias + n0 + tid, bsum);
+    ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = bsum;
   }
 }
 
@@ -409,16 +386,24 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgParams P, float* __rest
 // consecutive floats of dW (64 lanes x float4 = one KB per wave instruction); its sixteen waves take the slices s = w,
 // w + 16, ..: every load is a full coalesced KB and all of a wave's loads are in flight together; the partial sums meet
 // in LDS.
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
-                                                            float* __restrict__ dbias, int nsplit, long NK, int N, int nblk_w,
-                                                            int overwrite) {
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws_base, RedBatch B) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXB; ++i) if (i < B.n && (int)blockIdx.x >= B.p[i].first) pi = i;
+  const RedProb R = B.p[pi];
+  const float* __restrict__ ws = ws_base + R.wsoff;
+  float* __restrict__ dW = R.dW;
+  float* __restrict__ dbias = R.dbias;
+  const int nsplit = R.nsplit, N = R.N, nblk_w = R.nblk_w, overwrite = R.overwrite;
+  const long NK = R.NK;
+  const int blk = (int)blockIdx.x - R.first;
   __shared__ f32x4 red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)blockIdx.x < nblk_w) {
-    const long q = ((long)blockIdx.x * 64 + lane) * 4;
+  if (blk < nblk_w) {
+    const long q = ((long)blk * 64 + lane) * 4;
     f32x4 a = (f32x4)(0.f);
     if (q < NK) {
-      const float* base = ws + ((long)blockIdx.x * nsplit << 8) + lane * 4;       // this block's [slice][256] run
+      const float* base = ws + ((long)blk * nsplit << 8) + lane * 4;       // this block's [slice][256] run
       int s = wave;
       for (; s + 48 < nsplit; s += 64) {
         f32x4 v[4];
@@ -440,7 +425,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   } else if (dbias != nullptr) {
     // bias: 64 entries per workgroup, the slices spread over the 16 waves like above (a thread per entry walking all the
     // slices serially costs one memory round trip per few slices: 20+ us for 128 slices)
-    const long n = ((long)blockIdx.x - nblk_w) * 64 + lane;
+    const long n = ((long)blk - nblk_w) * 64 + lane;
     const float* wb = ws + ((long)nblk_w * nsplit << 8);
     float a = 0.f;
     if (n < N) {
@@ -676,6 +661,40 @@ extern "C" long wmz_linear_wgrad_workspace_floats(int M, int N, int K, int dtype
   return (long)split * ((((long)N * K + 255) >> 8) * 256 + N);
 }
 
+namespace {
+// fills problem i of a batch; returns the workspace floats it needs
+long wg_batch_add(WgBatch& B, RedBatch& R, int i, const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias,
+                  int M, int N, int K, const float* g, const float* b, const float* mean, const float* rstd, int gelu_in,
+                  int overwrite, int dtype, long wsoff) {
+  WgParams& P = B.p[i];
+  P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
+  P.gamma = g; P.beta = b; P.mean = mean; P.rstd = rstd; P.gelu_in = gelu_in;
+  P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
+  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
+  P.nsplit = wgrad_split(M, N, K, dtype == WMZ_BF16 ? 64 : 32, &P.rows_per_wg);
+  B.first[i + 1] = B.first[i] + P.nbn * P.nbk * P.nsplit;
+  B.wsoff[i] = wsoff;
+  const long NK = (long)N * K;
+  RedProb& Q = R.p[i];
+  Q.dW = dW; Q.dbias = dbias; Q.wsoff = wsoff; Q.NK = NK; Q.nsplit = P.nsplit; Q.N = N;
+  Q.nblk_w = wmz_cdiv(NK, 256); Q.overwrite = overwrite;
+  Q.first = i == 0 ? 0 : R.p[i - 1].first + R.p[i - 1].nblk_w + (R.p[i - 1].dbias != nullptr ? wmz_cdiv(R.p[i - 1].N, 64) : 0);
+  return wmz_linear_wgrad_workspace_floats(M, N, K, dtype);
+}
+int wg_batch_launch(const WgBatch& B, const RedBatch& R, int pro, float* workspace, int dtype, hipStream_t st) {
+  const int n = B.n;
+  dim3 grid((unsigned)B.first[n]), block(NT);
+#define WMZ_WG2(T, PRO) hipLaunchKernelGGL((wgrad2_kernel<T, PRO>), grid, block, 0, st, B, workspace)
+  if (dtype == WMZ_BF16) { if (pro == 1) WMZ_WG2(bf16_t, 1); else if (pro == 2) WMZ_WG2(bf16_t, 2); else WMZ_WG2(bf16_t, 0); }
+  else { if (pro == 1) WMZ_WG2(float, 1); else if (pro == 2) WMZ_WG2(float, 2); else WMZ_WG2(float, 0); }
+#undef WMZ_WG2
+  const RedProb& L = R.p[n - 1];
+  const int nred = L.first + L.nblk_w + (L.dbias != nullptr ? wmz_cdiv(L.N, 64) : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nred), dim3(1024), 0, st, workspace, R);
+  return WMZ_OK;
+}
+}  // namespace
+
 extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N,
                                    int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
                                    const float* ln_rstd, int gelu_in, int overwrite, float* workspace,
@@ -688,24 +707,36 @@ extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long
   WMZ_REQUIRE(!ln || (ln_beta && ln_mean && ln_rstd), "wmz_linear_wgrad_ws: LayerNorm prologue needs gamma, beta, mean, rstd");
   WMZ_REQUIRE(!(ln && gelu_in), "wmz_linear_wgrad_ws: LayerNorm and GELU prologues are exclusive");
   WMZ_REQUIRE(workspace_floats >= wmz_linear_wgrad_workspace_floats(M, N, K, dtype), "wmz_linear_wgrad_ws: workspace too small (%ld floats)", workspace_floats);
-  WgParams P;
-  P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
-  P.gamma = ln_gamma; P.beta = ln_beta; P.mean = ln_mean; P.rstd = ln_rstd; P.gelu_in = gelu_in;
-  P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
-  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
-  P.nsplit = wgrad_split(M, N, K, dtype == WMZ_BF16 ? 64 : 32, &P.rows_per_wg);
-  dim3 grid((unsigned)(P.nbn * P.nbk * P.nsplit)), block(NT);
-  hipStream_t st = (hipStream_t)stream;
-  const int pro = ln ? 1 : (gelu_in ? 2 : 0);
-#define WMZ_WG2(T, PRO) hipLaunchKernelGGL((wgrad2_kernel<T, PRO>), grid, block, 0, st, P, workspace)
-  if (dtype == WMZ_BF16) { if (pro == 1) WMZ_WG2(bf16_t, 1); else if (pro == 2) WMZ_WG2(bf16_t, 2); else WMZ_WG2(bf16_t, 0); }
-  else { if (pro == 1) WMZ_WG2(float, 1); else if (pro == 2) WMZ_WG2(float, 2); else WMZ_WG2(float, 0); }
-#undef WMZ_WG2
-  const long NK = (long)N * K;
-  const int nblk_w = wmz_cdiv(NK, 256), nblk_b = dbias != nullptr ? wmz_cdiv(N, 64) : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblk_w + nblk_b)), dim3(1024), 0, st, workspace, dW, dbias, P.nsplit, NK, N, nblk_w,
-                     overwrite);
+  WgBatch B;
+  RedBatch R;
+  B.n = R.n = 1;
+  B.first[0] = 0;
+  wg_batch_add(B, R, 0, dC, ldc, A, lda, dW, dbias, M, N, K, ln_gamma, ln_beta, ln_mean, ln_rstd, gelu_in, overwrite, dtype, 0);
+  wg_batch_launch(B, R, ln ? 1 : (gelu_in ? 2 : 0), workspace, dtype, (hipStream_t)stream);
   WMZ_LAUNCH_CHECK("wmz_linear_wgrad_ws");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
+                                      float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
+                                      const int* overwrite, float* workspace, long workspace_floats, int dtype, void* stream) {
+  WMZ_REQUIRE(n >= 1 && n <= WG_MAXB, "wmz_linear_wgrad_batch: 1 .. %d problems per call (got %d)", WG_MAXB, n);
+  WMZ_REQUIRE(dC && ldc && A && lda && dW && dbias && M && N && K && overwrite && workspace, "wmz_linear_wgrad_batch: null table");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_wgrad_batch: bad dtype %d", dtype);
+  WgBatch B;
+  RedBatch R;
+  B.n = R.n = n;
+  B.first[0] = 0;
+  long off = 0;
+  for (int i = 0; i < n; ++i) {
+    WMZ_REQUIRE(dC[i] && A[i] && dW[i] && M[i] > 0 && N[i] > 0 && K[i] > 0, "wmz_linear_wgrad_batch: bad problem %d", i);
+    WMZ_REQUIRE(N[i] % 8 == 0 && K[i] % 8 == 0 && ldc[i] % 8 == 0 && lda[i] % 8 == 0, "wmz_linear_wgrad_batch: problem %d: N, K and row strides must be multiples of 8", i);
+    off += wg_batch_add(B, R, i, dC[i], ldc[i], A[i], lda[i], dW[i], dbias[i], M[i], N[i], K[i], nullptr, nullptr, nullptr,
+                        nullptr, 0, overwrite[i], dtype, off);
+  }
+  WMZ_REQUIRE(workspace_floats >= off, "wmz_linear_wgrad_batch: workspace too small (%ld floats needed)", off);
+  wg_batch_launch(B, R, 0, workspace, dtype, (hipStream_t)stream);
+  WMZ_LAUNCH_CHECK("wmz_linear_wgrad_batch");
   return WMZ_OK;
 }
 

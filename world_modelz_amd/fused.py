@@ -373,17 +373,6 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
            L.ptr(do), L.ptr(wpack_ff), ntok, D_, I_, M_, L.stream())
     dy2 = dy.reshape(ntok, D_)
-    # ---- feed-forward and to_out weight gradients
-    s_ff2 = _GradSink(w2, b2)
-    ops.linear_wgrad(dy2, g, s_ff2.bufs[0], s_ff2.bufs[1])                    # dW2 = dy^T GELU(z), db2 = colsum(dy)
-    G1 = torch.empty((M_, D_), dtype=torch.float32, device=dev)
-    c1 = torch.empty((M_,), dtype=torch.float32, device=dev)
-    ops.linear_wgrad(dz, xhat1, G1, c1, overwrite=True)                       # against the NORMALISED input
-    s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
-    L.call('wmz_ln_affine_grads', L.ptr(G1), L.ptr(c1), L.ptr(w1.detach()), L.ptr(fn_g.detach()), L.ptr(fn_b.detach()),
-           L.ptr(s_ff1.bufs[0]), L.ptr(s_ff1.bufs[1]), L.ptr(s_ff1.bufs[2]), L.ptr(s_ff1.bufs[3]), M_, D_, 0, L.stream())
-    s_out = _GradSink(wout, bout)
-    ops.linear_wgrad(dx1, o.reshape(ntok, I_), s_out.bufs[0], s_out.bufs[1])
     # ---- attention core
     dq, dkv = ops.local3d_attention_bwd(q, kv[..., :I_], kv[..., I_:], o, lse, do, attn.fn.extents, attn.fn.heads)
     # ---- to_q / to_k / to_v inputs
@@ -391,11 +380,22 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     xhat = torch.empty((ntok, D_), dtype=bf, device=dev)
     L.call('wmz_qkv_fused_bwd', L.ptr(dq), I_, L.ptr(dkv), 2 * I_, L.ptr(x_in), L.ptr(st_attn), L.ptr(dx1), L.ptr(dx),
            L.ptr(xhat), L.ptr(wpack_qkv), ntok, D_, I_, L.stream())
-    s_q = _GradSink(wq)
-    ops.linear_wgrad(dq.reshape(ntok, I_), x_in.reshape(ntok, D_), s_q.bufs[0])
+    # ---- the layer's five weight gradients: plain GEMMs over the token axis, ONE launch pair.  Those behind a LayerNorm
+    # are taken against the NORMALISED input (raw gradients G, column sums c) and turned into parameter gradients below.
+    s_ff2, s_out, s_q = _GradSink(w2, b2), _GradSink(wout, bout), _GradSink(wq)
+    G1 = torch.empty((M_, D_), dtype=torch.float32, device=dev)
+    c1 = torch.empty((M_,), dtype=torch.float32, device=dev)
     Gkv = torch.empty((2 * I_, D_), dtype=torch.float32, device=dev)
     ckv = torch.empty((2 * I_,), dtype=torch.float32, device=dev)
-    ops.linear_wgrad(dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv, overwrite=True)
+    ops.linear_wgrad_batch([
+        (dy2, g, s_ff2.bufs[0], s_ff2.bufs[1], False),                        # dW2 = dy^T GELU(z), db2 = colsum(dy)
+        (dz, xhat1, G1, c1, True),
+        (dx1, o.reshape(ntok, I_), s_out.bufs[0], s_out.bufs[1], False),
+        (dq.reshape(ntok, I_), x_in.reshape(ntok, D_), s_q.bufs[0], None, False),
+        (dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv, True)])
+    s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
+    L.call('wmz_ln_affine_grads', L.ptr(G1), L.ptr(c1), L.ptr(w1.detach()), L.ptr(fn_g.detach()), L.ptr(fn_b.detach()),
+           L.ptr(s_ff1.bufs[0]), L.ptr(s_ff1.bufs[1]), L.ptr(s_ff1.bufs[2]), L.ptr(s_ff1.bufs[3]), M_, D_, 0, L.stream())
     s_kv = _GradSink(wk, wv, bv, an_g, an_b)
     bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
     adjacent = (wk.is_contiguous() and wv.is_contiguous() and bk_.is_contiguous() and bw_.is_contiguous()

@@ -221,6 +221,29 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
            L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, 1 if overwrite else 0, L.ptr(ws), ws.numel(), dt, L.stream())
 
 
+def linear_wgrad_batch(problems):
+    """Up to 6 plain weight gradients by one launch pair (wmz_linear_wgrad_batch).  problems: (dc, a, dw, dbias | None,
+    overwrite) tuples with the meaning of linear_wgrad's arguments."""
+    import ctypes
+    n = len(problems)
+    dt = L.dtype_code(problems[0][0].dtype)
+    vp, ci, cl = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_long * n
+    pc, pa, pw, pb, lc, la, Ms, Ns, Ks, ov = vp(), vp(), vp(), vp(), cl(), cl(), ci(), ci(), ci(), ci()
+    keep, need = [], 0
+    for i, (dc, a, dw, dbias, overwrite) in enumerate(problems):
+        dc, M, ldc = _rows(dc)
+        a, Ma, lda = _rows(a)
+        assert Ma == M and a.dtype == dc.dtype and L.dtype_code(dc.dtype) == dt
+        assert dw.dtype == torch.float32 and dw.is_contiguous()
+        N, K = dw.shape
+        keep.append((dc, a))
+        pc[i], pa[i], pw[i], pb[i] = L.ptr(dc), L.ptr(a), L.ptr(dw), L.ptr(dbias)
+        lc[i], la[i], Ms[i], Ns[i], Ks[i], ov[i] = ldc, lda, M, N, K, 1 if overwrite else 0
+        need += L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
+    ws = _workspace(problems[0][0].device, need)
+    L.call('wmz_linear_wgrad_batch', n, pc, lc, pa, la, pw, pb, Ms, Ns, Ks, ov, L.ptr(ws), ws.numel(), dt, L.stream())
+
+
 def layernorm_stats(x, eps=1e-5):
     x, M, ldx = _rows(x)
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
