@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void embed_pos3d_bwd_kernel(const int64_t* __r
     for (int i = 0; i < H; ++i) sh[i * 256 + t] = 0.f;
     for (int i = 0; i < W; ++i) sw[i * 256 + t] = 0.f;
     float as = 0.f;
+    // the LAST class is the denoiser's mask token (main.py:27: the embedding has num_embeddings + 1 rows): in the corrupted
+    // frame about every other token carries it, and a thousand same-address atomics per element serialise in L2 -- its row
+    // is summed per workgroup first (any other class sees ~64 adds per element, spread over the launch)
+    float amask = 0.f;
     if (d < D) {
       for (int h = 0; h < H; ++h)
         for (int w = 0; w < W; ++w) {
@@ -75,15 +79,61 @@ __global__ __launch_bounds__(256) void embed_pos3d_bwd_kernel(const int64_t* __r
           const float v = Elem<T>::to_f32(dx[tok_i * D + d]);
           long tok = z[tok_i];
           tok = tok < 0 ? 0 : (tok >= num_classes ? num_classes - 1 : tok);
-          atomicAdd(demb + tok * D + d, v);
+          if (tok == num_classes - 1) amask += v;
+          else atomicAdd(demb + tok * D + d, v);
           as += v;
           sh[h * 256 + t] += v;
           sw[w * 256 + t] += v;
         }
+      if (amask != 0.f) atomicAdd(demb + (long)(num_classes - 1) * D + d, amask);
       atomicAdd(dps + (long)s * D + d, as);
       for (int h = 0; h < H; ++h) atomicAdd(dph + (long)h * D + d, sh[h * 256 + t]);
       for (int w = 0; w < W; ++w) atomicAdd(dpw + (long)w * D + d, sw[w * 256 + t]);
     }
+  }
+}
+
+// The same for W == 16 (the reference's latent planes): the per-column sums live in 16 registers and the per-row sum in
+// one (the general kernel keeps both in LDS and every token pays two dependent LDS read-modify-writes, ~300 cycles of its
+// ~430), the token ids of a plane row arrive by one load and are handed out by v_readlane, the row's 16 dx loads are
+// independent and in flight together.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_pos3d_bwd16_kernel(const int64_t* __restrict__ z, const T* __restrict__ dx,
+                                                                float* __restrict__ demb, float* __restrict__ dps,
+                                                                float* __restrict__ dph, float* __restrict__ dpw, int S,
+                                                                int H, int D, int num_classes) {
+  const int plane = blockIdx.x;
+  const int s = plane % S;
+  const int lane = threadIdx.x & 63;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float aw[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) aw[w] = 0.f;
+    float as = 0.f, amask = 0.f;
+    for (int h = 0; h < H; ++h) {
+      const long row = ((long)plane * H + h) * 16;
+      long tk = z[row + (lane & 15)];                                     // this row's 16 token ids, one per lane (mod 16)
+      tk = tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : tk);
+      const int tki = (int)tk;
+      float v[16];
+#pragma unroll
+      for (int w = 0; w < 16; ++w) v[w] = Elem<T>::to_f32(dx[(row + w) * D + d]);
+      float ah = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const int tok = __builtin_amdgcn_readlane(tki, w);
+        if (tok == num_classes - 1) amask += v[w];                        // the mask token's row: summed per workgroup first
+        else atomicAdd(demb + (long)tok * D + d, v[w]);
+        aw[w] += v[w];
+        ah += v[w];
+      }
+      as += ah;
+      atomicAdd(dph + (long)h * D + d, ah);
+    }
+    if (amask != 0.f) atomicAdd(demb + (long)(num_classes - 1) * D + d, amask);
+    atomicAdd(dps + (long)s * D + d, as);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) atomicAdd(dpw + (long)w * D + d, aw[w]);
   }
 }
 
@@ -189,6 +239,16 @@ extern "C" int wmz_embed_pos3d_bwd(const int64_t* z, const void* dx, float* demb
   const size_t smem = (size_t)(H + W) * 256 * sizeof(float);
   if (smem > 64 * 1024) { wmz_set_error("wmz_embed_pos3d_bwd: H + W = %d > 64 not built", H + W); return WMZ_ERR_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
+  if (W == 16) {
+    if (dtype == WMZ_BF16)
+      hipLaunchKernelGGL(embed_pos3d_bwd16_kernel<bf16_t>, dim3(B * S), dim3(256), 0, st, z, (const bf16_t*)dx, demb, dpos_s, dpos_h,
+                         dpos_w, S, H, D, num_classes);
+    else
+      hipLaunchKernelGGL(embed_pos3d_bwd16_kernel<float>, dim3(B * S), dim3(256), 0, st, z, (const float*)dx, demb, dpos_s, dpos_h,
+                         dpos_w, S, H, D, num_classes);
+    WMZ_LAUNCH_CHECK("wmz_embed_pos3d_bwd");
+    return WMZ_OK;
+  }
   if (dtype == WMZ_BF16)
     hipLaunchKernelGGL(embed_pos3d_bwd_kernel<bf16_t>, dim3(B * S), dim3(256), smem, st, z, (const bf16_t*)dx, demb, dpos_s,
                        dpos_h, dpos_w, S, H, W, D, num_classes);
