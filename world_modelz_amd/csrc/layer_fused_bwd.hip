@@ -330,7 +330,8 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
 
 // dW[N, K] += G[n, k] gamma[k] + s[n] beta[k];  dgamma[k] += sum_n W[n, k] G[n, k];  dbeta[k] += sum_n W[n, k] s[n];
 // dbias[n] += s[n] for n >= bias_from (to_k has no bias: the k | v gradient shares one call).  A workgroup owns 64 columns
-// x 32 rows: thread (row group rg = tid / 64, column) walks 8 rows, the four row groups meet in LDS, one atomic per column.
+// x 8 rows: thread (row group rg = tid / 64, column) walks 2 rows, the four row groups meet in LDS, one atomic per column
+// (128 workgroups for a 256 x 256 weight: the kernel is pure latency, short chains and many workgroups keep it at ~3 us).
 __global__ __launch_bounds__(256) void ln_affine_grads_kernel(const float* __restrict__ G, const float* __restrict__ s,
                                                               const float* __restrict__ W, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ dW,
@@ -339,12 +340,12 @@ __global__ __launch_bounds__(256) void ln_affine_grads_kernel(const float* __res
   __shared__ float red[2][4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + c;
-  const int n0 = blockIdx.y * 32 + rg * 8;
+  const int n0 = blockIdx.y * 8 + rg * 2;
   float ag = 0.f, ab = 0.f;
   if (k < K) {
     const float gk = gamma[k], bk = beta[k];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 2; ++i) {
       const int n = n0 + i;
       if (n < N) {
         const float g = G[(long)n * K + k], w = W[(long)n * K + k], sn = s[n];
@@ -361,8 +362,8 @@ __global__ __launch_bounds__(256) void ln_affine_grads_kernel(const float* __res
     atomicAdd(dgamma + k, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
     atomicAdd(dbeta + k, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
   }
-  if (dbias != nullptr && blockIdx.x == 0 && threadIdx.x < 32) {
-    const int n = blockIdx.y * 32 + (int)threadIdx.x;
+  if (dbias != nullptr && blockIdx.x == 0 && threadIdx.x < 8) {
+    const int n = blockIdx.y * 8 + (int)threadIdx.x;
     if (n < N && n >= bias_from) dbias[n - bias_from] += s[n];
   }
 }
@@ -426,7 +427,7 @@ extern "C" int wmz_ln_affine_grads(const float* G, const float* s, const float* 
                                    void* stream) {
   WMZ_REQUIRE(G && s && W && gamma && beta && dW && dgamma && dbeta && N > 0 && K > 0, "wmz_ln_affine_grads: bad arguments");
   WMZ_REQUIRE(bias_from >= 0 && bias_from <= N, "wmz_ln_affine_grads: bad bias_from");
-  hipLaunchKernelGGL(ln_affine_grads_kernel, dim3((unsigned)wmz_cdiv(K, 64), (unsigned)wmz_cdiv(N, 32)), dim3(256), 0,
+  hipLaunchKernelGGL(ln_affine_grads_kernel, dim3((unsigned)wmz_cdiv(K, 64), (unsigned)wmz_cdiv(N, 8)), dim3(256), 0,
                      (hipStream_t)stream, G, s, W, gamma, beta, dW, dbias, dgamma, dbeta, N, K, bias_from);
   WMZ_LAUNCH_CHECK("wmz_ln_affine_grads");
   return WMZ_OK;
