@@ -367,9 +367,10 @@ int wmz_grad_sqnorm(const float* g, long n, float scale, float* out, void* strea
 int wmz_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, long step, double grad_scale, void* stream);
 /* The same with the per-step scalars in device memory, hyper = [lr, 1 - beta1^t, sqrt(1 - beta2^t)] (fp32): a captured
- * training step is replayed with a new learning rate / bias correction each time. */
+ * training step is replayed with a new learning rate / bias correction each time.  sqnorm_out (optional): += the squared
+ * gradient norm sum (grad_scale g)^2, computed in the same pass (zero it first). */
 int wmz_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, double beta1, double beta2,
-                       double eps, double weight_decay, double grad_scale, void* stream);
+                       double eps, double weight_decay, double grad_scale, float* sqnorm_out, void* stream);
 
 #ifdef __cplusplus
 }

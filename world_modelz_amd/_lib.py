@@ -77,7 +77,7 @@ SIGNATURES = {
                            ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p],
     'wmz_corrupt_tokens_dev': [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
                                ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p],
-    'wmz_adamw_step_dev': [c_void_p] * 4 + [c_long, c_void_p] + [c_double] * 5 + [c_void_p],
+    'wmz_adamw_step_dev': [c_void_p] * 4 + [c_long, c_void_p] + [c_double] * 5 + [c_void_p, c_void_p],
     'wmz_ce_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     'wmz_ce_bwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     'wmz_grad_sqnorm': [c_void_p, c_long, c_float, c_void_p, c_void_p],

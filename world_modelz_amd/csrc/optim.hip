@@ -42,13 +42,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // The same with the per-step scalars in DEVICE memory (hyper = [lr, bc1, sqrt(bc2)]): a hipGraph of the training step is
 // captured once and replayed with a new learning rate / bias correction every step.
+// sqnorm (optional): += sum (grad_scale g)^2 -- the gradient norm the step body reports (main.py:188-193) rides along in
+// the same pass over g instead of a launch of its own.
 __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, const float* __restrict__ hyper, float b1,
-                                                        float b2, float eps, float wd, float grad_scale) {
+                                                        float b2, float eps, float wd, float grad_scale,
+                                                        float* __restrict__ sqnorm) {
+  __shared__ float red[4];
   const float lr = hyper[0], bc1 = hyper[1], sqrt_bc2 = hyper[2];
   const float step = lr / bc1;
+  float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
+    acc += gi * gi;
     float pi = p[i] * (1.f - lr * wd);
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -56,16 +62,24 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
     pi -= step * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
+  if (sqnorm != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sqnorm, (red[0] + red[1]) + (red[2] + red[3]));
+  }
 }
 
 }  // namespace
 
 extern "C" int wmz_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, double beta1,
-                                  double beta2, double eps, double weight_decay, double grad_scale, void* stream) {
+                                  double beta2, double eps, double weight_decay, double grad_scale, float* sqnorm_out,
+                                  void* stream) {
   WMZ_REQUIRE(p && g && m && v && hyper && n > 0, "wmz_adamw_step_dev: bad arguments");
   const long blocks = (n + 255) / 256;
   hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, p, g,
-                     m, v, n, hyper, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)grad_scale);
+                     m, v, n, hyper, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)grad_scale, sqnorm_out);
   WMZ_LAUNCH_CHECK("wmz_adamw_step_dev");
   return WMZ_OK;
 }

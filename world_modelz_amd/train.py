@@ -373,9 +373,8 @@ class DenoiserTrainer(_TrainerBase):
         per_sample, mean = self.forward_backward(zc, target)
         st = L.stream()
         self.sq.zero_()
-        L.call('wmz_grad_sqnorm', L.ptr(a.flat_grad), a.numel, 1.0, L.ptr(self.sq), st)
         L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
-               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, st)
+               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, L.ptr(self.sq), st)   # + grad norm
         return per_sample, mean, self.sq
 
     def train_step(self, batch_z, r=None, generator=None):
