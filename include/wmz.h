@@ -293,8 +293,8 @@ int wmz_debug_fused_knobs(int dbg);
 /* Same for the 16-wide-plane attention forward kernel (16 waves x 64 int64). */
 int wmz_debug_attn_timestamps(void* buf);
 /* development knobs of the attention forward: dbg = ablation switches (1 skip the per-tile compute, 2 skip the K/V
- * staging: timing experiments only, results are garbage), variant = A/B selector between kernel instantiations;
- * (0, 0) is the product behaviour. */
+ * staging: timing experiments only, results are garbage), variant = reserved (the library carries one instantiation per
+ * shape class; other schedules are separate builds, tools/build_variant.py); (0, 0) is the product behaviour. */
 int wmz_debug_attn_knobs(int dbg, int variant);
 
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----

@@ -1,5 +1,6 @@
 """Per-launch time of the 16-wide-plane attention forward at config-4 shapes (graph of 50 launches).
-WMZ_ATTN_VARIANTS="0,10,11": development A/B between kernel instantiations (wmz_debug_attn_knobs)."""
+A/B between kernel builds: tools/build_variant.py <tag> attn_fwd_row16.hip -DWMZ_ATTN_MODE=<0..15>, then
+WMZ_LIB_PATH=tools/variants/libwmz_<tag>.so python tools/time_attn.py (the product library carries one instantiation)."""
 import os, sys, torch
 sys.path.insert(0, '.')
 from world_modelz_amd import ops, _lib as L

@@ -493,16 +493,7 @@ int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, voi
                                 const AttnGeom& G, hipStream_t st) {
   if (dbg != nullptr) return by_dh<WMZ_ATTN_MODE, true, false>(q, k, v, out, lse, dbg, G, st);
   if (g_attn_ts != nullptr) return by_dh<WMZ_ATTN_MODE, false, true>(q, k, v, out, lse, nullptr, G, st);
-  switch (G.variant) {                                   // development A/B (wmz_debug_attn_knobs)
-    case 10: return by_dh<8 + 0, false, false>(q, k, v, out, lse, nullptr, G, st);
-    case 11: return by_dh<8 + 1, false, false>(q, k, v, out, lse, nullptr, G, st);
-    case 12: return by_dh<8 + 2, false, false>(q, k, v, out, lse, nullptr, G, st);
-    case 13: return by_dh<8 + 3, false, false>(q, k, v, out, lse, nullptr, G, st);
-    case 14: return by_dh<8 + 4, false, false>(q, k, v, out, lse, nullptr, G, st);
-    case 15: return by_dh<8 + 5, false, false>(q, k, v, out, lse, nullptr, G, st);
-    case 16: return by_dh<8 + 6, false, false>(q, k, v, out, lse, nullptr, G, st);
-    case 17: return by_dh<8 + 7, false, false>(q, k, v, out, lse, nullptr, G, st);
-    default: break;
-  }
+  // (the other LDS-DMA schedules / store widths of kSched are timing variants: build them with
+  //  tools/build_variant.py <tag> attn_fwd_row16.hip -DWMZ_ATTN_MODE=<0..15> and load the library through WMZ_LIB_PATH)
   return by_dh<WMZ_ATTN_MODE, false, false>(q, k, v, out, lse, nullptr, G, st);
 }
