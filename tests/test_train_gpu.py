@@ -68,6 +68,22 @@ def test_corruption_matches_reference_law(wmz):
         assert torch.allclose(cnt, expect, atol=0.02), (cnt, expect)
 
 
+def test_corruption_is_keyed_by_the_data_parallel_rank(wmz):
+    """Ranks started from the same torch seed must not apply one mask / redraw pattern to their different clips: the
+    Philox stream id carries the rank.  Same (seed, rank, call) -> same draw; another rank -> another draw."""
+    tr = wmz['train']
+    z = torch.randint(0, 16, (2, 3, 32, 32), device='cuda')
+    r = torch.tensor([0.5, 0.5])
+    outs = {}
+    for rank in (0, 1, 0):
+        tr._corrupt_calls = 41                                   # the same per-process call counter on every "rank"
+        zc, _ = tr.corrupt_last_frame(z, r, 16, seed=1234, rank=rank)
+        outs.setdefault(rank, []).append(zc[:, -1].clone())
+    assert torch.equal(outs[0][0], outs[0][1])
+    differ = float((outs[0][0] != outs[1][0]).float().mean())
+    assert differ > 0.3, differ                                  # ~half the positions are masked, independently per rank
+
+
 def test_training_reduces_loss(wmz):
     """A few full train_step() calls (corrupt -> fwd/bwd -> grad-norm -> AdamW) on a learnable toy task, bf16."""
     torch.manual_seed(1)
