@@ -428,6 +428,8 @@ def main():
         for _ in range(5):
             tstep()
         barrier()
+        if tr.reducer is not None:
+            tr.reducer.enable_timing()
         tt0 = time.perf_counter()
         for _ in range(a.train_steps):
             tstep()
@@ -453,6 +455,7 @@ def main():
                             'eager launches, per-layer RCCL gradient all-reduce overlapped on a side stream'),
                  'launch_mode': 'hipGraph' if graphed else 'eager',
                  'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0,
+                 'grad_allreduce_overlap': tr.reducer.timing_summary() if tr.reducer else None,
                  'train_roofline': {'algorithmic_flops_per_step': 3.0 * fwd_flops,
                                     'achieved_TFLOPs': 3.0 * fwd_flops / (tms * 1e-3) / 1e12, 'mfma_peak_TFLOPs': 2500.0,
                                     'frac_of_mfma_peak': 3.0 * fwd_flops / (tms * 1e-3) / 1e12 / 2500.0,

@@ -395,6 +395,7 @@ def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
                 launched_by_backward.append(list(red.order))      # what the hooks enqueued before finish() ran
                 return orig_finish()
             red.finish = finish
+            red.enable_timing()
             for _ in range(2):
                 ld, gd = td.train_step(z, r=r)
                 ls, gs = ts.train_step(z, r=r)
@@ -405,6 +406,9 @@ def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
             assert order[1:4] == [3, 2, 1]                        # layers back to front
         for (n, a), b in zip(md.named_parameters(), ms.parameters()):
             assert torch.allclose(a, b, rtol=0, atol=3e-3), n
+        torch.cuda.synchronize()
+        tm = red.timing_summary()                                 # what bench.py reports as grad_allreduce_overlap
+        assert tm['collectives'] == 2 * 5 and tm['allreduce_ms'] > 0 and 0.0 <= tm['overlap_fraction'] <= 1.0, tm
     finally:
         dist.destroy_process_group()
 

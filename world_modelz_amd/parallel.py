@@ -96,6 +96,7 @@ class BucketedAllReduce:
         self.handles = []
         self.launched = []
         self._hooks = []
+        self._timing = None                    # enable_timing(): [(start, end) events of every collective], [(w0, w1) of finish()]
         if self.active:
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(i)
@@ -124,7 +125,14 @@ class BucketedAllReduce:
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())      # the bucket's gradients are complete
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+                if self._timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+                    e1.record()
+                    self._timing[0].append((e0, e1))
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -136,13 +144,35 @@ class BucketedAllReduce:
                 if not self.launched[b]:
                     self._launch(b)
             if self.cuda:
-                torch.cuda.current_stream().wait_stream(self.stream)
+                if self._timing is not None:
+                    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    w0.record()
+                    torch.cuda.current_stream().wait_stream(self.stream)
+                    w1.record()
+                    self._timing[1].append((w0, w1))
+                else:
+                    torch.cuda.current_stream().wait_stream(self.stream)
             else:
                 for h in self.handles:
                     h.wait()
         self.last_order, self.order = self.order, []
         self.reset()
         return 1.0 / self.world
+
+    def enable_timing(self, on=True):
+        """Record HIP events around every collective (side stream) and around finish()'s wait (compute stream)."""
+        self._timing = ([], []) if on else None
+
+    def timing_summary(self):
+        """After a device synchronise: {'allreduce_ms': time the collectives took on the side stream, 'exposed_ms': time the
+        compute stream stood waiting for them in finish(), 'overlap_fraction': share of the collective time hidden under
+        the backward}, summed over the steps since enable_timing()."""
+        if not self._timing:
+            return None
+        total = sum(a.elapsed_time(b) for a, b in self._timing[0])
+        exposed = sum(a.elapsed_time(b) for a, b in self._timing[1])
+        return {'allreduce_ms': total, 'exposed_ms': exposed, 'collectives': len(self._timing[0]),
+                'overlap_fraction': (1.0 - min(exposed, total) / total) if total > 0 else None}
 
     def remove_hooks(self):
         for h in self._hooks:
