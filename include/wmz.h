@@ -267,6 +267,9 @@ int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const floa
  *   wmz_qkv_fused_bwd   dq [ntok, I], dk | dv [ntok, 2I], the layer's input x + statistics, res = dx1 ->
  *                         dx = res + dq Wq + LNbwd(dk Wk' + dv Wv')      gradient w.r.t. the layer's input
  *                         xhat_out = (x - mean) rstd                      operand of the to_k | to_v weight gradient
+ * wmz_ff_fused_bwd with dy_last_planes = S > 0 (the LAST layer under a last-frame loss, main.py:37): dy holds only the
+ * clips' last planes, [ntok / S, D] with dy_plane_tokens rows per clip; every other token's gradient is zero and is read
+ * from zero_row (D bf16 zeros) -- no [ntok, D] tensor of zeros is written or read.  0 / 0 / NULL: dy is [ntok, D].
  * wpack: the TRANSPOSED weight streams of wmz_layer_fused_bwd_pack (wpack_ff: 163 840 + 32 768 bf16, wpack_qkv: 98 304 +
  * 32 768 bf16; the LayerNorm gammas are folded in).  Replaces wmz_linear_fwd x5 (dgrad / recompute) and wmz_layernorm_bwd
  * x2 per layer; the weight gradients stay wmz_linear_wgrad calls on the operands written here, computed against the
@@ -278,7 +281,7 @@ int wmz_layer_fused_bwd_pack(const float* wq, const float* wk, const float* wv, 
                              int M, void* stream);
 int wmz_ff_fused_bwd(const void* dy, const void* z_tiled, const void* x1, const float* ln_stats, void* g_out, void* dz_out,
                      void* xhat_out, void* dx1_out, void* do_out, const void* wpack, int ntok, int D, int I, int M,
-                     void* stream);
+                     int dy_last_planes, int dy_plane_tokens, const void* zero_row, void* stream);
 int wmz_qkv_fused_bwd(const void* dq, long lddq, const void* dkv, long lddkv, const void* x, const float* ln_stats,
                       const void* res, void* dx, void* xhat_out, const void* wpack, int ntok, int D, int I, void* stream);
 int wmz_ln_affine_grads(const float* G, const float* s, const float* W, const float* gamma, const float* beta, float* dW,

@@ -59,8 +59,24 @@ def test_ff_fused_bwd_vs_torch(layer):
     outs = [torch.empty(n, w, dtype=torch.bfloat16, device='cuda') for w in (M, M, D, D, I)]
     g, dz, xhat1, dx1, do = outs
     L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
-           L.ptr(do), L.ptr(wpack_ff), n, D, I, M, L.stream())
+           L.ptr(do), L.ptr(wpack_ff), n, D, I, M, 0, 0, None, L.stream())
     torch.cuda.synchronize()
+    # last-plane mode (the denoiser's loss reads x[:, -1] only): dy restricted to the clips' last planes, every other row
+    # read from a zero row -- must equal the dense call on the zero-padded gradient to the bit
+    S_, HW_ = 3, 256
+    dy_pad = dy.clone().view(-1, S_, HW_, D)
+    dy_pad[:, :-1] = 0
+    outs_a = [torch.empty_like(t) for t in outs]
+    outs_b = [torch.empty_like(t) for t in outs]
+    L.call('wmz_ff_fused_bwd', L.ptr(dy_pad), L.ptr(zt), L.ptr(x1), L.ptr(st), *[L.ptr(t) for t in outs_a], L.ptr(wpack_ff),
+           n, D, I, M, 0, 0, None, L.stream())
+    dy_last = dy_pad[:, -1].contiguous()
+    zero_row = torch.zeros(D, dtype=torch.bfloat16, device='cuda')
+    L.call('wmz_ff_fused_bwd', L.ptr(dy_last), L.ptr(zt), L.ptr(x1), L.ptr(st), *[L.ptr(t) for t in outs_b], L.ptr(wpack_ff),
+           n, D, I, M, S_, HW_, L.ptr(zero_row), L.stream())
+    torch.cuda.synchronize()
+    for a_, b_ in zip(outs_a, outs_b):
+        assert torch.equal(a_, b_)
     zf = z.float().requires_grad_(True)
     gr = torch.nn.functional.gelu(zf)
     (dgelu,) = torch.autograd.grad(gr.sum(), zf)

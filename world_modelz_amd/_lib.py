@@ -52,7 +52,7 @@ SIGNATURES = {
     'wmz_layer_fused_fwd_train': [c_void_p] * 12 + [c_int] * 7 + [c_float, c_void_p],
     'wmz_fused_pack_table': [c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_layer_fused_bwd_pack': [c_void_p] * 10 + [c_int] * 3 + [c_void_p],
-    'wmz_ff_fused_bwd': [c_void_p] * 10 + [c_int] * 4 + [c_void_p],
+    'wmz_ff_fused_bwd': [c_void_p] * 10 + [c_int] * 6 + [c_void_p, c_void_p],
     'wmz_qkv_fused_bwd': [c_void_p, c_long, c_void_p, c_long] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p],
     'wmz_ln_affine_grads': [c_void_p] * 9 + [c_int] * 3 + [c_void_p],
     'wmz_embed_qkv_fused_fwd_train': [c_void_p] * 12 + [c_int] * 9 + [c_float, c_void_p],

@@ -35,7 +35,10 @@ struct BwdParams {
   bf16_t* dx;                           // [ntok, D]
   bf16_t* xhat;                         // [ntok, D]  or null
   // feed-forward + to_out backward
-  const bf16_t* dy;                     // [ntok, D]  gradient w.r.t. the block's output
+  const bf16_t* dy;                     // [ntok, D]  gradient w.r.t. the block's output (LASTDY: only the clips' LAST planes,
+                                        //            [ntok / dy_S, D]; every other row's gradient is zero)
+  int dy_S, dy_HW;                      // LASTDY: planes per clip, tokens per plane
+  const bf16_t* zero_row;               // LASTDY: D zeros
   const bf16_t* zt;                     // tiled pre-activation (layer_fused.hip FusedParams::zt)
   const bf16_t* x1;                     // [ntok, D]  the feed-forward block's input
   const float* st_ff;                   // [2, ntok]
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void qkv_bwd_kernel(BwdParams P) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the padding slabs still in flight target this workgroup's LDS
 }
 
-template <int D, int I, int M>
+template <int D, int I, int M, bool LASTDY>
 __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
   static_assert(D == 256 && I == 128 && M == 256, "built for the default denoiser widths");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,8 +244,18 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
 #pragma unroll
   for (int i = 0; i < RING - 1; ++i) ws_issue(ws);
 
+  // LASTDY: the loss reads the last plane only (main.py:37), so the last layer's dy is zero everywhere else -- those rows
+  // are read from one zero row instead of from a [ntok, D] tensor of zeros somebody had to write
+  const bf16_t* dyrow;
+  if constexpr (LASTDY) {
+    const int per = P.dy_S * P.dy_HW, tt = (int)tokc;
+    const int b = tt / per, rr = tt - b * per - (per - P.dy_HW);
+    dyrow = rr >= 0 ? P.dy + ((long)b * P.dy_HW + rr) * D + h * 64 : P.zero_row + h * 64;
+  } else {
+    dyrow = P.dy + tokc * D + h * 64;
+  }
   Frag8<bf16_t> dyb[D / 16];
-  load_row<D / 16>(dyb, P.dy + tokc * D + h * 64, ws);
+  load_row<D / 16>(dyb, dyrow, ws);
   const int m_dy = ws.all;
   const bf16_t* ztile = P.zt + tok0c * M + lane * 8;
   Frag8<bf16_t> zf[2][2];
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
   pin(xb);
   asm volatile("" : "+v"(mean), "+v"(rstd));
   ln_bwd_inplace(acc, xb, mean, rstd, stg, P.xhat1, tok0, P.ntok, lane, ws, []() {});
-  load_row<D / 16>(xb, P.dy + tokc * D + h * 64, ws);                  // the residual path (L2-hot: this wave read it above)
+  load_row<D / 16>(xb, dyrow, ws);                                     // the residual path (L2-hot: this wave read it above)
   const int m_r = ws.all;
   vm_wait_since(ws, m_r);
   pin(xb);
@@ -402,7 +415,7 @@ extern "C" int wmz_qkv_fused_bwd(const void* dq, long lddq, const void* dkv, lon
 
 extern "C" int wmz_ff_fused_bwd(const void* dy, const void* z_tiled, const void* x1, const float* ln_stats, void* g_out,
                                 void* dz_out, void* xhat_out, void* dx1_out, void* do_out, const void* wpack, int ntok, int D,
-                                int I, int M, void* stream) {
+                                int I, int M, int dy_last_planes, int dy_plane_tokens, const void* zero_row, void* stream) {
   WMZ_REQUIRE(dy && z_tiled && x1 && ln_stats && g_out && dz_out && xhat_out && dx1_out && do_out && wpack && ntok > 0,
               "wmz_ff_fused_bwd: null tensor");
   if (!(D == 256 && I == 128 && M == 256)) {
@@ -410,14 +423,25 @@ extern "C" int wmz_ff_fused_bwd(const void* dy, const void* z_tiled, const void*
     return WMZ_ERR_UNSUPPORTED;
   }
   WMZ_REQUIRE(ntok % 32 == 0, "wmz_ff_fused_bwd: the tiled pre-activation needs whole 32-token tiles");
+  const bool lastdy = dy_last_planes > 0;
+  WMZ_REQUIRE(!lastdy || (dy_plane_tokens > 0 && zero_row && ntok % (dy_last_planes * dy_plane_tokens) == 0),
+              "wmz_ff_fused_bwd: last-plane dy needs planes per clip, tokens per plane (ntok a multiple of their product) and a zero row");
   BwdParams P = {};
   P.wpack = (const char*)wpack; P.ntok = ntok;
   P.dy = (const bf16_t*)dy; P.zt = (const bf16_t*)z_tiled; P.x1 = (const bf16_t*)x1; P.st_ff = ln_stats;
+  P.dy_S = dy_last_planes; P.dy_HW = dy_plane_tokens; P.zero_row = (const bf16_t*)zero_row;
   P.g = (bf16_t*)g_out; P.dz = (bf16_t*)dz_out; P.xhat1 = (bf16_t*)xhat_out; P.dx1 = (bf16_t*)dx1_out; P.dout = (bf16_t*)do_out;
   const size_t smem = RING * SLAB + FW * 8192;
-  auto kern = ff_bwd_kernel<256, 128, 256>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(kern, dim3((unsigned)wmz_cdiv(ntok, TW * FW)), dim3(NTHR), smem, (hipStream_t)stream, P);
+  const dim3 grid((unsigned)wmz_cdiv(ntok, TW * FW)), block(NTHR);
+  if (lastdy) {
+    auto kern = ff_bwd_kernel<256, 128, 256, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);
+  } else {
+    auto kern = ff_bwd_kernel<256, 128, 256, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);
+  }
   WMZ_LAUNCH_CHECK("wmz_ff_fused_bwd");
   return WMZ_OK;
 }

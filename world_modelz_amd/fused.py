@@ -355,24 +355,43 @@ class _GradSink:
         return self.bufs
 
 
-def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt):
+_zero_rows = {}
+
+
+def _zero_row(dev):
+    z = _zero_rows.get(dev)
+    if z is None:
+        z = _zero_rows[dev] = torch.zeros(D_, dtype=torch.bfloat16, device=dev)
+    return z
+
+
+def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt, dy_last=None):
     """One layer of the stack's backward on the fused per-token kernels: wmz_ff_fused_bwd -> attention backward ->
     wmz_qkv_fused_bwd, the weight gradients as plain GEMMs over the operands those kernels write, the LayerNorm affine
-    gradients from the raw weight gradients (wmz_ln_affine_grads).  Returns (gradient w.r.t. the layer's input, the 14
+    gradients from the raw weight gradients (wmz_ln_affine_grads).  dy_last = (S, HW): dy holds only the clips' last planes
+    ([B, H, W, D], the last layer under the denoiser's last-frame loss).  Returns (gradient w.r.t. the layer's input, the 14
     parameter gradients in _layer_params order)."""
     an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
     dev, bf = dy.device, torch.bfloat16
-    lead = dy.shape[:-1]
-    ntok = dy.numel() // D_
+    lead = x1.shape[:-1]
+    ntok = x1.numel() // D_
     wpack_qkv, wpack_ff = _layer_pack_bwd(attn, ff)
     g = torch.empty((ntok, M_), dtype=bf, device=dev)
     dz = torch.empty((ntok, M_), dtype=bf, device=dev)
     xhat1 = torch.empty((ntok, D_), dtype=bf, device=dev)
     dx1 = torch.empty((ntok, D_), dtype=bf, device=dev)
     do = torch.empty(lead + (I_,), dtype=bf, device=dev)
-    L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
-           L.ptr(do), L.ptr(wpack_ff), ntok, D_, I_, M_, L.stream())
-    dy2 = dy.reshape(ntok, D_)
+    if dy_last is None:
+        L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
+               L.ptr(do), L.ptr(wpack_ff), ntok, D_, I_, M_, 0, 0, None, L.stream())
+        dy2, g2 = dy.reshape(ntok, D_), g
+    else:
+        S_, HW_ = dy_last
+        L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
+               L.ptr(do), L.ptr(wpack_ff), ntok, D_, I_, M_, S_, HW_, L.ptr(_zero_row(dev)), L.stream())
+        # dW2 = dy^T GELU(z) only has the last planes' rows to sum over
+        dy2 = dy.reshape(-1, D_)
+        g2 = g.view(-1, S_, HW_, M_)[:, -1].reshape(-1, M_)
     # ---- attention core
     dq, dkv = ops.local3d_attention_bwd(q, kv[..., :I_], kv[..., I_:], o, lse, do, attn.fn.extents, attn.fn.heads)
     # ---- to_q / to_k / to_v inputs
@@ -388,7 +407,7 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     Gkv = torch.empty((2 * I_, D_), dtype=torch.float32, device=dev)
     ckv = torch.empty((2 * I_,), dtype=torch.float32, device=dev)
     ops.linear_wgrad_batch([
-        (dy2, g, s_ff2.bufs[0], s_ff2.bufs[1], False),                        # dW2 = dy^T GELU(z), db2 = colsum(dy)
+        (dy2, g2, s_ff2.bufs[0], s_ff2.bufs[1], False),                       # dW2 = dy^T GELU(z), db2 = colsum(dy)
         (dz, xhat1, G1, c1, True),
         (dx1, o.reshape(ntok, I_), s_out.bufs[0], s_out.bufs[1], False),
         (dq.reshape(ntok, I_), x_in.reshape(ntok, D_), s_q.bufs[0], None, False),
@@ -429,7 +448,7 @@ class _TrainForward(torch.autograd.Function):
     feed-forward pre-activation is recomputed there by one LayerNorm-GEMM instead of being stored)."""
 
     @staticmethod
-    def forward(ctx, tr, z, *params):
+    def forward(ctx, tr, z, last_only, *params):
         layers = list(tr.layers)
         B, S, H, W = z.shape
         tiled = (H * W) % 32 == 0
@@ -448,8 +467,10 @@ class _TrainForward(torch.autograd.Function):
             q, kv, st_attn = q_n, kv_n, st_attn_n
         ctx.tr = tr
         ctx.fused_bwd = fused_bwd
+        ctx.last_only = bool(last_only)
         ctx.save_for_backward(z, *saved)
-        return x_rm
+        # last_only: the caller reads the last plane only (main.py:37) and hands back a gradient for it alone
+        return x_rm[:, -1].contiguous() if last_only else x_rm
 
     @staticmethod
     def backward(ctx, dy):
@@ -461,12 +482,22 @@ class _TrainForward(torch.autograd.Function):
         grads = [None] * (14 * len(layers))
         dy = dy.contiguous()
         NS = 9
+        dy_last = None
+        if ctx.last_only:
+            B, S, H, W = z.shape
+            if ctx.fused_bwd:
+                dy_last = (S, H * W)                       # the last layer's kernel reads the other planes' zeros from a zero row
+            else:
+                full = torch.zeros((B, S, H, W, D_), dtype=dy.dtype, device=dy.device)
+                full[:, -1] = dy
+                dy = full
         for l in range(len(layers) - 1, -1, -1):
             attn, ff = layers[l]
             x_in, q, kv, o, lse, x1, st_attn, st_ff, zt = saved[NS * l:NS * l + NS]
             an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
             if ctx.fused_bwd:
-                dy, g = _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt)
+                dy, g = _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt,
+                                              dy_last if l == len(layers) - 1 else None)
                 grads[14 * l:14 * l + 14] = g
                 continue
             dt = x1.dtype
@@ -484,11 +515,13 @@ class _TrainForward(torch.autograd.Function):
             grads[14 * l:14 * l + 14] = [r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]
         ce = _Ctx((z,), params=(tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight))
         ge = Bk.embed_backward(ce, dy)
-        return (None, None, ge[1], ge[2], ge[3], ge[4], *grads)
+        return (None, None, None, ge[1], ge[2], ge[3], ge[4], *grads)
 
 
-def transformer_forward_train(tr, z):
+def transformer_forward_train(tr, z, last_only=False):
+    """The stack's output [B, S, H, W, D] -- or, with last_only, its last plane [B, H, W, D] (what the denoiser's loss reads:
+    the backward then never materialises the zero gradient of the other planes)."""
     params = [tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight]
     for attn, ff in tr.layers:
         params += _layer_params(attn, ff)
-    return _TrainForward.apply(tr, z, *params)
+    return _TrainForward.apply(tr, z, last_only, *params)

@@ -149,16 +149,20 @@ class Local3dAttentionTransformer(nn.Module):
         """[B,S,H,W] int64 tokens -> [B,S,H,W,dim] in the parameters' dtype (see the module docstring's dtype rule)."""
         return self.forward_compute(img_z).to(self.embedding.weight.dtype)
 
-    def forward_compute(self, img_z):
-        """forward() without the boundary cast: the residual stream in the compute dtype (internal callers)."""
-        if not img_z.is_cuda:
-            raise Fw.ops.L.WmzError('Local3dAttentionTransformer runs on the GPU only (no CPU fallback)')
+    def check_grid(self, img_z):
+        """The errors the reference raises for a grid / token id its embeddings cannot index."""
         _, S, H, W = img_z.shape
         if S > self.pos_emb_s.num_embeddings or H > self.pos_emb_h.num_embeddings or W > self.pos_emb_w.num_embeddings:
             raise IndexError('token grid larger than the position-embedding tables')
         from .config import get_check_tokens
         if get_check_tokens() and (int(img_z.min()) < 0 or int(img_z.max()) >= self.embedding.num_embeddings):
             raise IndexError('index out of range in self')            # what nn.Embedding raises in the reference
+
+    def forward_compute(self, img_z):
+        """forward() without the boundary cast: the residual stream in the compute dtype (internal callers)."""
+        if not img_z.is_cuda:
+            raise Fw.ops.L.WmzError('Local3dAttentionTransformer runs on the GPU only (no CPU fallback)')
+        self.check_grid(img_z)
         if not torch.is_grad_enabled():
             from . import fused
             from .config import get_compute_dtype

@@ -311,7 +311,21 @@ class DenoiserTrainer(_TrainerBase):
     def forward_backward(self, batch_z, target, loss_scale=1.0):
         """Forward, per-sample CE over the last frame, backward of loss.mean() * loss_scale (gradient accumulation:
         main.py:274-278).  Returns (per_sample_loss[B], mean loss) on device."""
-        y = self.model(batch_z)
+        from . import config, fused
+        m = self.model
+        tr = m.transformer
+        dt = config.get_compute_dtype()
+        if (batch_z.is_cuda and hasattr(tr, 'pos_emb_s') and config.get_fused_training() and config.fused_backward()
+                and fused.supported(tr, dt) and batch_z.numel() % 32 == 0):
+            # fused stack in both directions: only the last plane leaves it (main.py:37), its logits and cross-entropy are
+            # one chunked linear + CE whose gradient is complete when the forward returns
+            tr.check_grid(batch_z)
+            last = fused.transformer_forward_train(tr, batch_z, last_only=True)              # [B, H, W, D]
+            mean, rows = linear_cross_entropy(last.reshape(-1, last.shape[-1]), m.logit_proj.weight, m.logit_proj.bias,
+                                              target.reshape(-1), chunk=4096)
+            (mean if loss_scale == 1.0 else mean * loss_scale).backward()
+            return rows.view(batch_z.shape[0], -1).mean(dim=1), mean.detach()
+        y = m(batch_z)
         loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
         per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
         mean = loss.mean()
