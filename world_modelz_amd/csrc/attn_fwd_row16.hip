@@ -28,7 +28,8 @@
 #include "attn_common.h"
 
 // Compile-time ablations for timing experiments (tools/variants builds; results are garbage): bit 0 no LDS fragment reads,
-// bit 1 no softmax arithmetic, bit 2 no MFMAs, bit 3 no V staging, bit 4 no K staging, bit 5 no slab loop at all, bit 6 one key plane only.  0 in the product.
+// bit 1 no softmax arithmetic, bit 2 no MFMAs, bit 3 no V staging, bit 4 no K staging, bit 5 no slab loop at all, bit 6 one key plane only,
+// bit 7 odd waves stage but do not compute.  0 in the product.
 #ifndef WMZ_ATTN_ABL
 #define WMZ_ATTN_ABL 0
 #endif
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   const int HW = G.HW, H = G.H;
   const int h0 = og * NW;                               // first query row of the workgroup
   const int hq = h0 + wave;                             // this wave's query row
-  const bool act = hq < H;
+  const bool act = hq < H && !((WMZ_ATTN_ABL & 128) && (wave & 1));   // (ablation bit 7: every other wave only stages)
   const long plane_q = ((long)b * G.S + s) * HW;
   const long plane_o = ((long)b * G.Sq + sq) * HW;
   const float c2 = G.scale * 1.4426950408889634f;
