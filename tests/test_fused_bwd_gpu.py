@@ -170,3 +170,28 @@ def test_pack_set_equals_the_per_stream_packers():
     for r, g in zip(ref, got):
         for a, b in zip(r, g):
             assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_linear_wgrad_batch_vs_torch():
+    """wmz_linear_wgrad_batch: several weight gradients of different shapes by one launch pair; accumulate vs overwrite,
+    with and without a bias gradient, against fp32 torch on the same bf16 operands."""
+    from world_modelz_amd import ops
+    torch.manual_seed(4)
+    n = 4096 + 64                                         # not a multiple of the slice length
+    shapes = [(256, 256, True, False), (256, 128, False, True), (128, 256, True, True), (64, 512, False, False)]
+    probs, refs = [], []
+    for N, K, bias, overwrite in shapes:
+        dc = torch.randn(n, N, device='cuda').bfloat16()
+        a = torch.randn(n, K, device='cuda').bfloat16()
+        dw0 = torch.randn(N, K, device='cuda')
+        db0 = torch.randn(N, device='cuda') if bias else None
+        g = dc.float().t() @ a.float()
+        s = dc.float().sum(0)
+        refs.append((g if overwrite else dw0 + g, None if db0 is None else (s if overwrite else db0 + s)))
+        probs.append((dc, a, dw0.clone(), None if db0 is None else db0.clone(), overwrite))
+    ops.linear_wgrad_batch(probs)
+    torch.cuda.synchronize()
+    for (dc, a, dw, db, ov), (rw, rb) in zip(probs, refs):
+        assert rel(dw, rw) < 2e-5, (dw.shape, rel(dw, rw))
+        if db is not None:
+            assert rel(db, rb) < 2e-5
