@@ -84,6 +84,38 @@ def test_corruption_is_keyed_by_the_data_parallel_rank(wmz):
     assert differ > 0.3, differ                                  # ~half the positions are masked, independently per rank
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gradient_accumulation_equals_the_big_batch(wmz, dtype):
+    """main.py:221, :274-280: gradients accumulate over `accumulation_steps` micro-batches, each micro-loss scaled by
+    1/acc_steps.  Two micro-batches of 2 clips must produce the gradient (and step) of one batch of 4 clips -- through the
+    fused stack, its last-plane-only backward and the fused linear + cross-entropy in bf16, the op-by-op path in fp32."""
+    tr = wmz['train']
+
+    def make():
+        torch.manual_seed(31)
+        return wmz['main'].VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=64, extents=(1, 1, 1), depth=2,
+                                                 dim_head=128, mlp_dim=256, heads=1).cuda()
+    z = torch.randint(0, 64, (4, 3, 16, 16), device='cuda')
+    tgt = z[:, -1].clone()
+    with wmz['config'].compute_dtype(dtype):
+        ma, mb = make(), make()
+        ta = tr.DenoiserTrainer(ma, 64, lr=1e-3, warmup=0, distributed=False, accumulation_steps=2)
+        tb = tr.DenoiserTrainer(mb, 64, lr=1e-3, warmup=0, distributed=False)
+        ta.arena.zero_grad()
+        tb.arena.zero_grad()
+        la = 0.0
+        for i in (0, 2):
+            _, m_ = ta.forward_backward(z[i:i + 2], tgt[i:i + 2], 0.5)
+            la += 0.5 * float(m_)
+        _, mb_ = tb.forward_backward(z, tgt, 1.0)
+        lb = float(mb_)
+    ga, gb = ta.arena.flat_grad, tb.arena.flat_grad
+    err = float((ga - gb).norm() / gb.norm())
+    print(f'[accumulation {dtype}] loss {la:.6f} vs {lb:.6f}, gradient rel {err:.2e}')
+    assert abs(la - lb) < (1e-5 if dtype == torch.float32 else 2e-3) * max(1.0, abs(lb)), (la, lb)
+    assert err < (1e-5 if dtype == torch.float32 else 6e-3), err
+
+
 def test_training_reduces_loss(wmz):
     """A few full train_step() calls (corrupt -> fwd/bwd -> grad-norm -> AdamW) on a learnable toy task, bf16."""
     torch.manual_seed(1)

@@ -85,7 +85,7 @@ class _LinearCrossEntropy(torch.autograd.Function):
     dgrad and wgrad -- so the gradient w.r.t. x, W and b is complete when the forward returns; backward() only scales it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, target, chunk):
+    def forward(ctx, x, w, b, target, chunk, grad_scale):
         from . import backward as Bk
         R, K = x.shape
         C = w.shape[0]
@@ -97,7 +97,9 @@ class _LinearCrossEntropy(torch.autograd.Function):
         direct = wbuf is not None and (b is None or bbuf is not None)
         dw = wbuf if direct else torch.zeros(w.shape, dtype=torch.float32, device=x.device)
         db = (bbuf if direct else torch.zeros(C, dtype=torch.float32, device=x.device)) if b is not None else None
-        ones = torch.full((min(chunk, R),), 1.0 / R, dtype=torch.float32, device=x.device)
+        # d(grad_scale * mean loss) / d(row loss): the scale of gradient accumulation (main.py:274-278) is applied HERE, the
+        # parameter gradients are final when forward() returns
+        ones = torch.full((min(chunk, R),), float(grad_scale) / R, dtype=torch.float32, device=x.device)
         target = target.contiguous()
         for r0 in range(0, R, chunk):
             r1 = min(R, r0 + chunk)
@@ -121,18 +123,19 @@ class _LinearCrossEntropy(torch.autograd.Function):
         dx, dw, db = ctx.saved_tensors
         w, b = ctx.params
         if ctx.direct:
-            # the arena already holds d(mean loss)/dW: only a plain `mean.backward()` (g == 1) is meaningful on this path
+            # the arena already holds grad_scale * d(mean loss)/dW: call `mean.backward()` as it is (g == 1) on this path
             for p in (w, b):
                 ready = getattr(p, '_wmz_ready', None) if p is not None else None
                 if ready is not None:
                     ready()
-            return dx * g.to(dx.dtype), None, None, None, None
-        return dx * g.to(dx.dtype), dw * g, (db * g if db is not None else None), None, None
+            return dx * g.to(dx.dtype), None, None, None, None, None
+        return dx * g.to(dx.dtype), dw * g, (db * g if db is not None else None), None, None, None
 
 
-def linear_cross_entropy(x, w, b, target, chunk=1024):
-    """(mean loss, per-row loss [R], detached) of CrossEntropy(x W^T + b, target) over rows x: [R, K]."""
-    return _LinearCrossEntropy.apply(x, w, b, target, chunk)
+def linear_cross_entropy(x, w, b, target, chunk=1024, grad_scale=1.0):
+    """(mean loss, per-row loss [R], detached) of CrossEntropy(x W^T + b, target) over rows x: [R, K].  The gradients it
+    produces are those of grad_scale * mean loss (gradient accumulation): call `.backward()` on the returned mean as it is."""
+    return _LinearCrossEntropy.apply(x, w, b, target, chunk, grad_scale)
 
 
 class _CrossEntropyRows(torch.autograd.Function):
@@ -322,8 +325,8 @@ class DenoiserTrainer(_TrainerBase):
             tr.check_grid(batch_z)
             last = fused.transformer_forward_train(tr, batch_z, last_only=True)              # [B, H, W, D]
             mean, rows = linear_cross_entropy(last.reshape(-1, last.shape[-1]), m.logit_proj.weight, m.logit_proj.bias,
-                                              target.reshape(-1), chunk=4096)
-            (mean if loss_scale == 1.0 else mean * loss_scale).backward()
+                                              target.reshape(-1), chunk=4096, grad_scale=loss_scale)
+            mean.backward()                                # (the accumulation scale is inside the fused gradient)
             return rows.view(batch_z.shape[0], -1).mean(dim=1), mean.detach()
         y = m(batch_z)
         loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
@@ -449,8 +452,9 @@ class SparseDenoiserTrainer(_TrainerBase):
         h = Fw.embed_tokens_indexed(tokens, indices, m.embedding.weight, m.pos_emb_s.weight, m.pos_emb_h.weight,
                                     m.pos_emb_w.weight, m.shape)
         h = m.transformer.forward_compute(h)
-        mean, rows = linear_cross_entropy(h.reshape(-1, h.shape[-1]), m.logit_proj.weight, m.logit_proj.bias, target.reshape(-1))
-        (mean if loss_scale == 1.0 else mean * loss_scale).backward()
+        mean, rows = linear_cross_entropy(h.reshape(-1, h.shape[-1]), m.logit_proj.weight, m.logit_proj.bias, target.reshape(-1),
+                                          grad_scale=loss_scale)
+        mean.backward()                                    # (the accumulation scale is inside the fused gradient)
         return rows.view(tokens.shape[0], -1).mean(dim=1), mean.detach()
 
     def train_step(self, batch_z, r=None, indices=None, generator=None):
