@@ -340,8 +340,9 @@ static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtyp
   const bool gin = (flags & WMZ_LIN_GELU_IN) != 0;
   WMZ_REQUIRE(!(ln && gin), "wmz_linear_fwd: LayerNorm and GELU prologues are exclusive");
   P.nbn = wmz_cdiv(P.N, BN);
-  // small-M GEMMs with fp32 output (the last-frame logits: M = B*H*W): 64-row tiles, so that the grid covers the chip
-  const bool small = P.out_f32 && !ln && !gin && (long)wmz_cdiv(P.M, 128) * P.nbn < 192;
+  // small-M GEMMs (the last-frame logits: M = B*H*W; config 5's 3 072 tokens per GPU): 64-row tiles, so that the grid covers
+  // the chip (a 16-bit output then leaves by per-lane stores: fine at these sizes)
+  const bool small = !ln && !gin && (long)wmz_cdiv(P.M, 128) * P.nbn < (P.out_f32 ? 192 : 320);
   const int bm = small ? 64 : 128;
   dim3 grid((unsigned)(wmz_cdiv(P.M, bm) * P.nbn)), block(NT);
   if (dtype == WMZ_BF16) {
