@@ -155,18 +155,19 @@ def main():
 
     log(f'model built ({"eager" if a.eager else "hipGraph"}), starting {a.warmup} warm-up steps')
     with torch.no_grad():
-        # untimed pre-warm: the first ~50 replays after an idle period run 5-10 % slow (clock / power ramp), whatever W is
+        # a generational collection of the interpreter (tens of ms once the model, its state_dict copy and the graph
+        # runner are alive) must not land between two enqueues of the timed region: collect now, hold the collector off.
+        # BEFORE the warm-up: the device idles while the collector runs, and the first ~50 replays after an idle period
+        # run 5-10 % slow (clock / power ramp) -- nothing but the barrier may sit between warm-up and timed region
+        import gc
+        gc.collect()
+        gc.disable()
+        # untimed pre-warm, whatever W is
         for _ in range(100):
             step()
         for _ in range(a.warmup):
             step()
         barrier()
-        log('warm-up done')
-        # a generational collection of the interpreter (tens of ms once the model, its state_dict copy and the graph
-        # runner are alive) must not land between two enqueues of the timed region: collect now, hold the collector off
-        import gc
-        gc.collect()
-        gc.disable()
         t0 = time.perf_counter()
         marks = []
         for _ in range(a.steps):
@@ -176,6 +177,7 @@ def main():
         barrier()
         t1 = time.perf_counter()
         gc.enable()
+        log('warm-up and timed region done')
         if os.environ.get('WMZ_BENCH_MARKS'):
             log('enqueue times per step (ms): ' + ' '.join(f'{(m - t0) * 1e3:.2f}' for m in marks) + f' | synced {(t1 - t0) * 1e3:.2f}')
     elapsed = t1 - t0

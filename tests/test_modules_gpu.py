@@ -294,6 +294,29 @@ def test_denoiser_full_size_properties(wmz):
     assert torch.isfinite(full).all() and full.shape == (8, 16, 16, 1024)
 
 
+def test_graph_runner_recaptures_when_the_weights_change(wmz):
+    """GraphedForward bakes the addresses of the packed weight streams into its hipGraph: an in-place update of any
+    parameter (optimizer step, load_state_dict, EMA copy) must make the next call re-capture, not replay stale weights."""
+    from world_modelz_amd.graph import GraphedForward
+    torch.manual_seed(43)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=64, extents=(1, 1, 1), depth=2,
+                                          dim_head=128, mlp_dim=256, heads=1).cuda().eval()
+    z = torch.randint(0, 65, (2, 3, 16, 16), device='cuda')
+    with wmz['config'].compute_dtype(torch.bfloat16), torch.no_grad():
+        g = GraphedForward(m, z)
+        y0 = g(z).clone()
+        assert torch.equal(y0, m(z)) and g.recaptures == 0
+        assert torch.equal(g(z), y0) and g.recaptures == 0               # nothing changed: plain replay
+        m.transformer.layers[1][1].fn.net[0].weight.mul_(1.5)            # in place: version counter bump
+        y1 = g(z).clone()
+        assert g.recaptures == 1 and torch.equal(y1, m(z)) and not torch.equal(y1, y0)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd['logit_proj.bias'] += 1.0
+        m.load_state_dict(sd)
+        y2 = g(z)
+        assert g.recaptures == 2 and torch.equal(y2, m(z)) and not torch.equal(y2, y1)
+
+
 def test_weight_stream_packer_matches_the_documented_order(wmz):
     """wmz_layer_fused_pack (one launch) against the tensor-op statement of the same layout (fused._pack_w + the folding
     rules in fused._layer_pack's docstring): bit-exact stream, vector block to fp32 round-off."""
