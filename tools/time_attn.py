@@ -10,8 +10,7 @@ q, k, v = qkv[..., :128], qkv[..., 128:256], qkv[..., 256:]
 ext = tuple(int(e) for e in os.environ.get('WMZ_EXT', '3,3,3').split(','))
 for _ in range(400): ops.local3d_attention_fwd(q, k, v, ext, 1)          # clocks / caches settled before the first timing
 torch.cuda.synchronize()
-for var in [int(x) for x in os.environ.get('WMZ_ATTN_VARIANTS', '0').split(',')]:
-    L.call('wmz_debug_attn_knobs', 0, var)
+for var in [os.environ.get('WMZ_LIB_PATH', 'product library')]:
     for _ in range(5): ops.local3d_attention_fwd(q, k, v, ext, 1)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -24,4 +23,3 @@ for var in [int(x) for x in os.environ.get('WMZ_ATTN_VARIANTS', '0').split(',')]
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1000 / 50)
     print(f'attn fwd variant {var} ext {ext}: {best:.2f} us per launch', flush=True)
-L.call('wmz_debug_attn_knobs', 0, 0)
