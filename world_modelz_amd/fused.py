@@ -419,6 +419,7 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
     adjacent = (wk.is_contiguous() and wv.is_contiguous() and bk_.is_contiguous() and bw_.is_contiguous()
                 and wv.data_ptr() == wk.data_ptr() + 4 * wk.numel() and bw_.data_ptr() == bk_.data_ptr() + 4 * bk_.numel())
+    # (the kernel only does pointer arithmetic on W and dW: two separately allocated neighbours are as good as one arena)
     if adjacent:                        # FlatArena: to_k.weight | to_v.weight (and their gradients) are one [2I, D] block
         L.call('wmz_ln_affine_grads', L.ptr(Gkv), L.ptr(ckv), L.ptr(wk.detach()), L.ptr(an_g.detach()), L.ptr(an_b.detach()),
                L.ptr(bk_), L.ptr(s_kv.bufs[2]), L.ptr(s_kv.bufs[3]), L.ptr(s_kv.bufs[4]), 2 * I_, D_, I_, L.stream())
