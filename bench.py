@@ -176,7 +176,8 @@ def main():
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
-        gc.enable()
+        # (the collector stays off for the secondary figures too; gc.collect() between the sections, in front of each one's
+        #  own warm-up, keeps the heap bounded)
         log('warm-up and timed region done')
         if os.environ.get('WMZ_BENCH_MARKS'):
             log('enqueue times per step (ms): ' + ' '.join(f'{(m - t0) * 1e3:.2f}' for m in marks) + f' | synced {(t1 - t0) * 1e3:.2f}')
@@ -304,6 +305,7 @@ def main():
                           'achieved_GBs': step_bytes / (ms_per_step * 1e-3) / 1e9,
                           'frac_of_8TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    gc.collect()
     # ---- secondary figure: the same forward with the dead planes elided (bit-identical logits; NOT the headline)
     cone = None
     if use_fused and not a.eager and not a.no_cone:
@@ -335,6 +337,7 @@ def main():
         wcfg.set_last_frame_cone(False)
         log(f'last-frame cone: {cone["ms_per_step"]:.3f} ms/step, identical={same}')
     out['last_frame_cone'] = cone
+    gc.collect()
     # ---- secondary figure: the same step with the reference's other published attention window, 7 x 3 x 3 (extents 3, 1, 1:
     # BASELINE.md run-03), full grid, same model otherwise
     win = None
@@ -364,6 +367,7 @@ def main():
         log(f'7x3x3 window: {win["ms_per_step"]:.3f} ms/step')
         del wrun, m2
     out['window_7x3x3'] = win
+    gc.collect()
     # ---- secondary figure: the stage in front of the denoiser: the frozen VQ auto-encoder turning frames into
     # latent tokens -- conv encoder (NHWC implicit GEMM, BatchNorm in train mode: quirk Q3) + codebook argmin.  B*S frames
     # of 64x64 RGB -> 16x16 tokens each (2 down-scale steps), codebook 1024 x 64.
@@ -407,6 +411,7 @@ def main():
                        'hbm_GBs': (Nq * Eq * 4 + Nq * 8) / (vq_ms * 1e-3) / 1e9})
         log('vq argmin: ' + ', '.join(f"C={v['C']} {v['ms'] * 1e3:.0f} us ({v['roofline']['frac']:.2f} of the f32 VALU)" for v in vq))
     out['vq_argmin'] = vq
+    gc.collect()
     # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand
     # re-pack), same shapes, same rules (barrier + sync both sides, max over ranks).  One GPU: the whole step is ONE hipGraph
     # replay (DenoiserTrainer.enable_graph) plus the loss-aware sampler's one host read-back per step.  n_gpus > 1: eager
@@ -466,6 +471,7 @@ def main():
                                     'frac_of_8TBs': 3 * step_bytes / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         log(f'train step {train["ms_per_step"]:.2f} ms ({train["launch_mode"]})')
     out['train_step'] = train
+    gc.collect()
     # ---- secondary figure: BASELINE configs[4], the sparse masked-denoise path (minecraft/sparse_diffusion.py): 64-frame clips of
     # 16x16 latents, codebook 8192, 512 context tokens per clip, dim 512 / 4 heads x 128 / depth 8 / mlp 1024, global batch 48 on
     # 8 GPUs = 6 clips per GPU; one full training step (position sampling, gather, corruption, forward, chunked 8192-way
