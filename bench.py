@@ -303,7 +303,9 @@ def main():
         'launch_mode': 'eager' if a.eager else 'hipGraph replay (1 graph = 1 forward step)',
         'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
                           'achieved_GBs': step_bytes / (ms_per_step * 1e-3) / 1e9,
-                          'frac_of_8TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          'frac_of_8TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          # both denominators -- the 8.0 TB/s specification and the 6.29 TB/s a float4 copy measures
+                          'frac_of_measured_copy_6.29TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / 6290.0},
     }
     gc.collect()
     # ---- secondary figure: the same forward with the dead planes elided (bit-identical logits; NOT the headline)
