@@ -38,11 +38,11 @@ def _ln_bwd(dxhat, x, mean, rstd):
     return rstd[:, None] * (dxhat - dxhat.mean(1, keepdim=True) - xh * (dxhat * xh).mean(1, keepdim=True)), xh
 
 
-def test_ff_fused_bwd_vs_torch(layer):
+@pytest.mark.parametrize('n', [2 * 16 * 16 * 3, 768 + 96])     # 1536 = 6 full workgroups; 864 = 3 + one with 3 of 8 waves
+def test_ff_fused_bwd_vs_torch(layer, n):
     from world_modelz_amd import _lib as L, fused
     attn, ff = layer
     torch.manual_seed(1)
-    n = 2 * 16 * 16 * 3                                    # 1536 tokens: 6 workgroups, the last one ragged (8 waves x 32)
     dy = torch.randn(n, D, device='cuda').bfloat16()
     x1 = (torch.randn(n, D, device='cuda') * 1.5 + 0.2).bfloat16()
     xf = x1.float()
@@ -63,7 +63,7 @@ def test_ff_fused_bwd_vs_torch(layer):
     torch.cuda.synchronize()
     # last-plane mode (the denoiser's loss reads x[:, -1] only): dy restricted to the clips' last planes, every other row
     # read from a zero row -- must equal the dense call on the zero-padded gradient to the bit
-    S_, HW_ = 3, 256
+    S_, HW_ = 3, n // 6
     dy_pad = dy.clone().view(-1, S_, HW_, D)
     dy_pad[:, :-1] = 0
     outs_a = [torch.empty_like(t) for t in outs]
@@ -91,12 +91,11 @@ def test_ff_fused_bwd_vs_torch(layer):
     assert all(v < 6e-3 for v in errs.values()), errs
 
 
-@pytest.mark.parametrize('with_res', [True, False])
-def test_qkv_fused_bwd_vs_torch(layer, with_res):
+@pytest.mark.parametrize('with_res,n', [(True, 1536), (False, 1536), (True, 864)])
+def test_qkv_fused_bwd_vs_torch(layer, with_res, n):
     from world_modelz_amd import _lib as L, fused
     attn, ff = layer
     torch.manual_seed(2)
-    n = 2 * 16 * 16 * 3
     dq = torch.randn(n, I, device='cuda').bfloat16()
     dkv = torch.randn(n, 2 * I, device='cuda').bfloat16()
     x = (torch.randn(n, D, device='cuda') * 0.7 - 0.1).bfloat16()
