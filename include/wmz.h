@@ -319,10 +319,11 @@ int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, const float
 /* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [C]). */
 int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream);
 /* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq, count), running stats updated with
- * `momentum` and the unbiased variance; training == 0: running stats.  Emits scale = gamma*rstd, shift = beta - mean*scale. */
+ * `momentum` and the unbiased variance, *num_batches_tracked (optional, int64) incremented; training == 0: running stats.
+ * Emits scale = gamma*rstd, shift = beta - mean*scale. */
 int wmz_bn_finalize(const float* sum, const float* sq, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, double momentum, double eps, int training, float* scale,
-                    float* shift, float* mean_out, float* rstd_out, int C, void* stream);
+                    float* shift, float* mean_out, float* rstd_out, int C, int64_t* num_batches_tracked, void* stream);
 /* y = act(a*sa + ta (+ b*sb + tb)) per channel on NHWC [M, C] (BatchNorm apply, skip add, LeakyReLU). */
 int wmz_affine_act_nhwc(const void* a, const float* sa, const float* ta, const void* b, const float* sb, const float* tb,
                         void* y, long M, int C, int leaky, float slope, int dtype, void* stream);

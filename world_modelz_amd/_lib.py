@@ -64,7 +64,7 @@ SIGNATURES = {
     'wmz_conv2d_nhwc_fwd_pre': [c_void_p] * 11 + [c_float] + [c_int] * 10 + [c_float, c_int, c_void_p],
     'wmz_channel_stats_nhwc': [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p],
     'wmz_bn_finalize': [c_void_p, c_void_p, c_double] + [c_void_p] * 4 + [c_double, c_double, c_int] + [c_void_p] * 4
-                       + [c_int, c_void_p],
+                       + [c_int, c_void_p, c_void_p],
     'wmz_conv2d_nhwc_wgrad': [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
     'wmz_bn_act_bwd_reduce': [c_void_p] * 8 + [c_long, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_bn_bwd_apply': [c_void_p] * 8 + [c_long, c_int, c_int, c_void_p],

@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128, CPR = 8, NT = 256;
+constexpr int ROWB = 128, CPR = 8, NT = 256;      // (tile sizes: template parameters of conv2d_kernel)
 
 struct ConvParams {
   const void* x; const void* w; void* out;
@@ -54,8 +54,13 @@ template <> __device__ __forceinline__ i32x4 f32_to_chunk<bf16_t>(const float* f
   return c;
 }
 
-template <typename T>
+// TALL = false: output tile 128 x 128, the four waves as 2 x 2.  TALL = true (Cout <= 64: conv_1, the 1x1 and the 2x2
+// down-sampling convolutions): output tile 256 x 64, the waves stacked -- no MFMA or weight-slab traffic spent on columns
+// that do not exist, and twice the rows per workgroup behind each (short: K = 72 .. 256) reduction and epilogue.
+template <typename T, bool TALL>
 __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
+  constexpr int BM = TALL ? 256 : 128, BN = TALL ? 64 : 128;
+  constexpr int AI = BM / 32, BI = BN / 32;             // A / B rows staged per thread and slab
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = CPR * EPC;
   constexpr int KSTEPS = BK / 16;
@@ -72,12 +77,12 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
   const T* Wt = reinterpret_cast<const T*>(P.w);
   const int K = P.K;
 
-  // the 4 output pixels this thread stages (rows rr + 32 i): decompose once
+  // the AI output pixels this thread stages (rows rr + 32 i): decompose once
   const int cc = tid & 7, rr = tid >> 3;
-  int pb[4], ph[4], pw[4];
-  bool pok[4];
+  int pb[AI], ph[AI], pw[AI];
+  bool pok[AI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AI; ++i) {
     const int m = m0 + rr + 32 * i;
     pok[i] = m < P.M;
     const int mm = pok[i] ? m : 0;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
     pb[i] = t / P.Ho;
   }
 
-  i32x4 ra[4], rb[4];
+  i32x4 ra[AI], rb[BI];
   auto pre = [&](i32x4 v, int k) {          // k = first input channel of the chunk (1x1 conv: k IS the channel)
     float f[EPC];
     chunk_to_f32<T>(v, f);
@@ -103,16 +108,19 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
     const int tap = k / P.Cin, ci = k - tap * P.Cin;
     const int kh = tap / P.KW, kw = tap - kh * P.KW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AI; ++i) {
       ra[i] = (i32x4)(0);
-      rb[i] = (i32x4)(0);
       if (k < K) {
         const int hi = ph[i] + kh, wi = pw[i] + kw;
         if (pok[i] && hi >= 0 && hi < P.Hi && wi >= 0 && wi < P.Wi)
           ra[i] = *reinterpret_cast<const i32x4*>(X + (((long)pb[i] * P.Hi + hi) * P.Wi + wi) * P.Cin + ci);
-        const int r = rr + 32 * i;
-        if (n0 + r < P.Cout) rb[i] = *reinterpret_cast<const i32x4*>(Wt + (long)(n0 + r) * K + k);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      rb[i] = (i32x4)(0);
+      const int r = rr + 32 * i;
+      if (k < K && n0 + r < P.Cout) rb[i] = *reinterpret_cast<const i32x4*>(Wt + (long)(n0 + r) * K + k);
     }
   };
 
@@ -121,20 +129,24 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int wr = TALL ? wave * 64 : (wave >> 1) * 64, wc = TALL ? 0 : (wave & 1) * 64;
   const int l31 = lane & 31, hh = lane >> 5;
 
   fetch(0);
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AI; ++i) {
       const int r = rr + 32 * i;
       const int off = r * ROWB + ((cc << 4) ^ swz128(r));
       i32x4 av = ra[i];
       if (P.in_scale != nullptr && k0 + cc * EPC < K && pok[i]) av = pre(av, k0 + cc * EPC);   // (rows past M stay zero)
       *reinterpret_cast<i32x4*>(As + off) = av;
-      *reinterpret_cast<i32x4*>(Bs + off) = rb[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int r = rr + 32 * i;
+      *reinterpret_cast<i32x4*>(Bs + r * ROWB + ((cc << 4) ^ swz128(r))) = rb[i];
     }
     __syncthreads();
     if (k0 + BK < K) fetch(k0 + BK);
@@ -172,15 +184,15 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
   if constexpr (sizeof(T) == 2) {
     if ((P.Cout & 7) == 0) {
       // 16-bit outputs: a lane owns ONE column of the accumulator tile, so direct stores (and residual loads) would be 2
-      // bytes each -- 64 of them per lane.  Stage the affine result in fp32 through LDS (64 rows per round = the 32 KB the
+      // bytes each -- 64 of them per lane.  Stage the affine result in fp32 through LDS (64 rows per round, in the space the
       // slabs occupied) and finish on whole 16-byte row chunks: residual add, LeakyReLU, the single rounding, the store,
       // and the per-channel statistics of what was stored (LDS partial sums, one global atomic per channel and workgroup).
-      float* stage = reinterpret_cast<float*>(tiles);                 // [64][128] fp32
+      float* stage = reinterpret_cast<float*>(tiles);                 // [64][BN] fp32
       if (tid < BN) { stat_l[0][tid] = 0.f; stat_l[1][tid] = 0.f; }
 #pragma unroll 1
-      for (int round = 0; round < 2; ++round) {
+      for (int round = 0; round < BM / 64; ++round) {
         __syncthreads();
-        if ((wave >> 1) == round) {
+        if ((TALL ? wave : (wave >> 1)) == round) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -199,15 +211,16 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
             }
         }
         __syncthreads();
-        // 64 rows x 16 chunks of 8 columns = 1024 chunks, 4 per thread; a thread keeps its chunk column (tid & 15)
-        const int ch = tid & 15, col = n0 + ch * 8;
+        // 64 rows x BN / 8 chunks of 8 columns, 4 (2 when TALL) per thread; a thread keeps its chunk column
+        constexpr int CH = BN / 8, RPI = NT / CH;            // chunk columns; rows covered per iteration
+        const int ch = tid & (CH - 1), col = n0 + ch * 8;
         float s1[8], s2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
         if (col < P.Cout) {
 #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int rl = (tid >> 4) + 16 * it;
+          for (int it = 0; it < 64 / RPI; ++it) {
+            const int rl = tid / CH + RPI * it;
             const int row = m0 + round * 64 + rl;
             if (row >= P.M) continue;
             const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * BN + ch * 8);
@@ -233,13 +246,13 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
             }
           }
           if (P.stat_sum != nullptr) {
-            // the 16 threads of a chunk column sit 16 lanes apart: fold lanes 16/32/48 of each wave first
+            // the threads of a chunk column sit CH lanes apart: fold them inside each wave first
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              s1[e] += __shfl_xor(s1[e], 16); s1[e] += __shfl_xor(s1[e], 32);
-              s2[e] += __shfl_xor(s2[e], 16); s2[e] += __shfl_xor(s2[e], 32);
+#pragma unroll
+              for (int o = CH; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o); s2[e] += __shfl_xor(s2[e], o); }
             }
-            if ((lane >> 4) == 0) {
+            if (lane < CH) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) { atomicAdd(&stat_l[0][ch * 8 + e], s1[e]); atomicAdd(&stat_l[1][ch * 8 + e], s2[e]); }
             }
@@ -317,8 +330,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                    float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_out, float* __restrict__ rstd_out, int C) {
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out, int C,
+                                   int64_t* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && num_batches_tracked != nullptr) *num_batches_tracked += 1;     // nn.BatchNorm2d's step counter
   if (c >= C) return;
   float mean, var;
   if (training) {
@@ -544,13 +559,20 @@ extern "C" int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, 
   P.Ho = (Hi + 2 * pad - KH) / stride + 1;
   P.Wo = (Wi + 2 * pad - KW) / stride + 1;
   WMZ_REQUIRE(P.Ho > 0 && P.Wo > 0, "wmz_conv2d_nhwc_fwd: empty output");
-  P.M = B * P.Ho * P.Wo; P.K = KH * KW * Cin; P.nbn = wmz_cdiv(Cout, BN);
+  const bool tall = Cout <= 64;
+  const int BMl = tall ? 256 : 128, BNl = tall ? 64 : 128;
+  P.M = B * P.Ho * P.Wo; P.K = KH * KW * Cin; P.nbn = wmz_cdiv(Cout, BNl);
   P.leaky = leaky; P.slope = slope;
   P.in_scale = in_scale; P.in_shift = in_shift; P.in_slope = in_slope;
-  dim3 grid((unsigned)(wmz_cdiv(P.M, BM) * P.nbn)), block(NT);
+  dim3 grid((unsigned)(wmz_cdiv(P.M, BMl) * P.nbn)), block(NT);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == WMZ_BF16) hipLaunchKernelGGL(conv2d_kernel<bf16_t>, grid, block, 0, st, P);
-  else hipLaunchKernelGGL(conv2d_kernel<float>, grid, block, 0, st, P);
+  if (dtype == WMZ_BF16) {
+    if (tall) hipLaunchKernelGGL((conv2d_kernel<bf16_t, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((conv2d_kernel<bf16_t, false>), grid, block, 0, st, P);
+  } else {
+    if (tall) hipLaunchKernelGGL((conv2d_kernel<float, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((conv2d_kernel<float, false>), grid, block, 0, st, P);
+  }
   WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_fwd");
   return WMZ_OK;
 }
@@ -568,11 +590,13 @@ extern "C" int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, 
 
 extern "C" int wmz_bn_finalize(const float* sum, const float* sq, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, double momentum, double eps, int training,
-                               float* scale, float* shift, float* mean_out, float* rstd_out, int C, void* stream) {
+                               float* scale, float* shift, float* mean_out, float* rstd_out, int C,
+                               int64_t* num_batches_tracked, void* stream) {
   WMZ_REQUIRE(running_mean && running_var && scale && shift && C > 0, "wmz_bn_finalize: bad arguments");
   WMZ_REQUIRE(!training || (sum && sq && count > 0), "wmz_bn_finalize: training mode needs the batch statistics");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(wmz_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sum, sq, (float)count,
-                     gamma, beta, running_mean, running_var, (float)momentum, (float)eps, training, scale, shift, mean_out, rstd_out, C);
+                     gamma, beta, running_mean, running_var, (float)momentum, (float)eps, training, scale, shift, mean_out, rstd_out, C,
+                     num_batches_tracked);
   WMZ_LAUNCH_CHECK("wmz_bn_finalize");
   return WMZ_OK;
 }

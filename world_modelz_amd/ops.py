@@ -293,8 +293,7 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
     out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     s = q = None
     if stats:
-        s = torch.zeros(Cout, dtype=torch.float32, device=x.device)
-        q = torch.zeros(Cout, dtype=torch.float32, device=x.device)
+        s, q = torch.zeros((2, Cout), dtype=torch.float32, device=x.device).unbind(0)      # one fill for both
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
     psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
@@ -307,8 +306,7 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
 def channel_stats_nhwc(x):
     C = x.shape[-1]
     M = x.numel() // C
-    s = torch.zeros(C, dtype=torch.float32, device=x.device)
-    q = torch.zeros(C, dtype=torch.float32, device=x.device)
+    s, q = torch.zeros((2, C), dtype=torch.float32, device=x.device).unbind(0)
     L.call('wmz_channel_stats_nhwc', L.ptr(x), M, C, L.ptr(s), L.ptr(q), L.dtype_code(x.dtype), L.stream())
     return s, q
 
@@ -323,11 +321,10 @@ def bn_finalize(bn, s, q, count, want_stats=False):
     mom = bn.momentum if bn.momentum is not None else 0.1
     mean = torch.empty(C, dtype=torch.float32, device=dev) if want_stats else None
     rstd = torch.empty(C, dtype=torch.float32, device=dev) if want_stats else None
+    nbt = bn.num_batches_tracked if (training and bn.num_batches_tracked is not None) else None    # counted by the kernel
     L.call('wmz_bn_finalize', L.ptr(s), L.ptr(q), float(count), L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()),
            L.ptr(bn.running_mean), L.ptr(bn.running_var), float(mom), float(bn.eps), 1 if training else 0,
-           L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(rstd), C, L.stream())
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+           L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(rstd), C, L.ptr(nbt), L.stream())
     return (scale, shift, mean, rstd) if want_stats else (scale, shift)
 
 
