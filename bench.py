@@ -176,6 +176,10 @@ def main():
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+        try:                                               # context for box-to-box spread: the shader clock right after the timed
+            sclk_mhz = int(torch.cuda.clock_rate())        # region (idle: ~100 MHz; the device ramps up under load)
+        except Exception:
+            sclk_mhz = None
         # (the collector stays off for the secondary figures too; gc.collect() between the sections, in front of each one's
         #  own warm-up, keeps the heap bounded)
         log('warm-up and timed region done')
@@ -301,6 +305,7 @@ def main():
         'roofline': fused_roof if dominant_fused else attn_roof,
         'roofline_other': attn_roof if dominant_fused else fused_roof,
         'launch_mode': 'eager' if a.eager else 'hipGraph replay (1 graph = 1 forward step)',
+        'sclk_mhz_after_timed_region': sclk_mhz,
         'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
                           'achieved_GBs': step_bytes / (ms_per_step * 1e-3) / 1e9,
                           'frac_of_8TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
