@@ -644,9 +644,13 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
 }
 
 // slices of M for a wgrad of these sizes (shared by the launch and by the workspace query)
+// target of workgroups per problem (set by the entry points around their own launches; host-side, single stream of calls):
+// a batch of n problems fills the chip together, and every slice a problem does NOT have is 2 x N x K x 4 bytes of partial
+// tiles not written and read back
+static thread_local int g_wgrad_target = 256;
 static int wgrad_split(int M, int N, int K, int ms, int* rows_per_wg) {
   const int tiles = wmz_cdiv(N, WG_BN) * wmz_cdiv(K, WG_BK);
-  constexpr int target = 256;                // measured: 512 slices double the partial-tile traffic and lose
+  const int target = g_wgrad_target;         // measured: 512 slices double the partial-tile traffic and lose
   int split = wmz_cdiv(target, tiles);         // two resident workgroups per CU
   const int max_split = wmz_cdiv(M, 4 * ms);
   if (split > max_split) split = max_split;
@@ -728,6 +732,8 @@ extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* 
   B.n = R.n = n;
   B.first[0] = 0;
   long off = 0;
+  struct TargetGuard { int saved; ~TargetGuard() { g_wgrad_target = saved; } } guard{g_wgrad_target};
+  g_wgrad_target = n >= 3 ? 96 : (n == 2 ? 128 : 256);       // measured at five problems: 96-128 best (2.12-2.14 vs 2.17 ms a step)
   for (int i = 0; i < n; ++i) {
     WMZ_REQUIRE(dC[i] && A[i] && dW[i] && M[i] > 0 && N[i] > 0 && K[i] > 0, "wmz_linear_wgrad_batch: bad problem %d", i);
     WMZ_REQUIRE(N[i] % 8 == 0 && K[i] % 8 == 0 && ldc[i] % 8 == 0 && lda[i] % 8 == 0, "wmz_linear_wgrad_batch: problem %d: N, K and row strides must be multiples of 8", i);
