@@ -284,3 +284,28 @@ def test_vqae_trainer_step_matches_torch_adamw_and_revives_dead_codes(wmz):
     assert abs(tr.lr_now() - 2e-4 * 0.25) < 1e-12               # epoch 7 // 3 = 2 halvings
     with pytest.raises(RuntimeError):
         train.VqaeTrainer(m, loss_fn='Huber')
+
+
+def test_direct_3x3_conv_equals_the_implicit_gemm_kernel(wmz):
+    """conv3x3s1_kernel (3x3, stride 1, pad 1, 64 -> 128 channels, bf16, planes of 8k x 32m pixels: the encoder's big layers)
+    against conv2d_kernel on the same data: same K order, same epilogue arithmetic -> the same bits, statistics included
+    (to fp32 summation order); and against torch."""
+    from world_modelz_amd import ops
+    torch.manual_seed(12)
+    B, H, W = 3, 16, 64
+    x = torch.randn(B, H, W, 64, device='cuda').bfloat16()
+    w = (torch.randn(128, 9 * 64, device='cuda') * 0.05).bfloat16()
+    bias = torch.randn(128, device='cuda')
+    res = torch.randn(B, H, W, 128, device='cuda').bfloat16()
+    y_d, s_d, q_d = ops.conv2d_nhwc(x, w, 3, 3, 1, 1, bias=bias, residual=res, leaky=True, stats=True)       # direct kernel
+    # the implicit-GEMM kernel takes any plane whose height is not a multiple of 8: rows 0..7 of a 12-row plane see the
+    # same inputs (rows 0..8) as rows 0..7 of the 16-row one
+    x12, r12 = x[:, :12].contiguous(), res[:, :12].contiguous()
+    y_g = ops.conv2d_nhwc(x12, w, 3, 3, 1, 1, bias=bias, residual=r12, leaky=True)
+    assert torch.equal(y_d[:, :8], y_g[:, :8])
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(128, 3, 3, 64).permute(0, 3, 1, 2),
+                                     bias=bias, padding=1).permute(0, 2, 3, 1) + res.float()
+    ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    assert float((y_d.float() - ref).norm() / ref.norm()) < 4e-3
+    assert torch.allclose(s_d, y_d.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(q_d, (y_d.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-2)

@@ -300,6 +300,171 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
   }
 }
 
+// 3 x 3, stride 1, pad 1, Cin = 64 -> Cout = 128 in bf16 on planes whose width is a multiple of 32 and height of 8 (the encoder's
+// big convolutions: autoencoder.py:29 conv3x3 inside Residual): a DIRECT form of the same GEMM.  The implicit-GEMM kernel
+// re-reads every input pixel nine times (once per tap) and the weights once per 128-pixel tile through L2 -- 2.4 GB for
+// the 64 x 64 layer.  Here a workgroup owns an 8 x 32 block of output pixels of one image: its 10 x 34 input patch goes
+// to LDS ONCE (43.5 KB) and the nine taps read it at shifted pixel addresses; the weights stream tap by tap through a
+// double-buffered 16 KB slab (register prefetch, one barrier per tap).  A wave owns two output rows (64 pixels) x all 128
+// channels.  Same K order (tap-major, channels inside) and the same epilogue arithmetic as conv2d_kernel: bit-identical.
+constexpr int D3_TH = 8, D3_TW = 32, D3_PH = D3_TH + 2, D3_PW = D3_TW + 2, D3_CIN = 64, D3_COUT = 128;
+__global__ __launch_bounds__(NT, 2) void conv3x3s1_kernel(ConvParams P) {
+  using T = bf16_t;
+  constexpr int PATCH = D3_PH * D3_PW * 128;                   // bytes: a pixel = 64 channels = 128 B = 8 chunks of 16 B
+  __shared__ __attribute__((aligned(16))) char patch[PATCH];     // chunk c of pixel p at p*128 + ((c ^ (p & 7)) << 4)
+  __shared__ __attribute__((aligned(16))) char Bs2[2][D3_COUT * ROWB];
+  __shared__ float stat_l[2][D3_COUT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int tw = P.Wo / D3_TW, th = P.Ho / D3_TH;
+  int bid = blockIdx.x;
+  const int bx = bid % tw; bid /= tw;
+  const int by = bid % th;
+  const int b = bid / th;
+  const int oy0 = by * D3_TH, ox0 = bx * D3_TW;
+  const T* X = reinterpret_cast<const T*>(P.x);
+  const T* Wt = reinterpret_cast<const T*>(P.w);
+  constexpr int K = 9 * D3_CIN;
+
+  // ---- input patch -> LDS (zeros outside the image)
+  for (int idx = tid; idx < D3_PH * D3_PW * 8; idx += NT) {
+    const int p = idx >> 3, c = idx & 7;
+    const int py = p / D3_PW, px = p - py * D3_PW;
+    const int hi = oy0 + py - 1, wi = ox0 + px - 1;
+    i32x4 v = (i32x4)(0);
+    if (hi >= 0 && hi < P.Hi && wi >= 0 && wi < P.Wi)
+      v = *reinterpret_cast<const i32x4*>(X + (((long)b * P.Hi + hi) * P.Wi + wi) * D3_CIN + c * 8);
+    *reinterpret_cast<i32x4*>(patch + p * 128 + ((c ^ (p & 7)) << 4)) = v;
+  }
+  // ---- weights: tap slab [128 n][64 k], 4 chunks per thread
+  const int cc = tid & 7, rr = tid >> 3;
+  i32x4 rb[4];
+  auto fetchB = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const i32x4*>(Wt + (long)(rr + 32 * i) * K + tap * D3_CIN + cc * 8);
+  };
+  auto stashB = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 32 * i;
+      *reinterpret_cast<i32x4*>(Bs2[buf] + r * ROWB + ((cc << 4) ^ swz128(r))) = rb[i];
+    }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x16)(0.f);
+  fetchB(0);
+  stashB(0);
+  fetchB(1);
+  __syncthreads();
+  for (int tap = 0; tap < 9; ++tap) {
+    const int cur = tap & 1;
+    if (tap + 1 < 9) stashB(cur ^ 1);                            // (its last readers passed the barrier that ended tap - 1)
+    if (tap + 2 < 9) fetchB(tap + 2);
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const char* Bs = Bs2[cur];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      Frag8<T> af[2], bf[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = (2 * wave + i + kh) * D3_PW + l31 + kw;    // the pixel this lane's output pixel reads at this tap
+        af[i].v = *reinterpret_cast<const s16x8*>(patch + p * 128 + (((kk * 2 + hh) ^ (p & 7)) << 4));
+      }
+      const int b0 = (kk * 16 + hh * 8) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rn = 32 * j + l31;
+        bf[j].v = *reinterpret_cast<const s16x8*>(Bs + rn * ROWB + (b0 ^ swz128(rn)));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma32(acc[i][j], af[i], bf[j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (as conv2d_kernel's staged form): a wave's 64 pixels x 128 channels per round through LDS in fp32, then
+  // 16-byte row chunks: residual, LeakyReLU, rounding, store, statistics
+  const T* R = reinterpret_cast<const T*>(P.res);
+  T* O = reinterpret_cast<T*>(P.out);
+  float* stage = reinterpret_cast<float*>(patch);               // [64][128] fp32 = 32 KB (the patch is dead)
+  static_assert(PATCH >= 64 * 128 * 4, "stage fits the patch");
+  if (tid < D3_COUT) { stat_l[0][tid] = 0.f; stat_l[1][tid] = 0.f; }
+#pragma unroll 1
+  for (int round = 0; round < 4; ++round) {
+    __syncthreads();
+    if (wave == round) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = 32 * j + l31;
+          const float bv = P.bias ? P.bias[col] : 0.f;
+          const float sc = P.scale ? P.scale[col] : 1.f;
+          const float sh = P.shift ? P.shift[col] : 0.f;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int rl = 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            stage[rl * D3_COUT + col] = (acc[i][j][reg] + bv) * sc + sh;
+          }
+        }
+    }
+    __syncthreads();
+    const int ch = tid & 15, col = ch * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = (tid >> 4) + 16 * it;                       // local pixel: row 2 round + rl / 32, column rl % 32
+      const long row = ((long)b * P.Ho + oy0 + 2 * round + (rl >> 5)) * P.Wo + ox0 + (rl & 31);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * D3_COUT + col);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(stage + rl * D3_COUT + col + 4);
+      float f[8] = {a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
+      if (R) {
+        float r8[8];
+        chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(R + row * D3_COUT + col), r8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += r8[e];
+      }
+      if (P.leaky) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * P.slope;
+      }
+      const i32x4 pk = f32_to_chunk<T>(f);
+      *reinterpret_cast<i32x4*>(O + row * D3_COUT + col) = pk;
+      if (P.stat_sum != nullptr) {
+        float q[8];
+        chunk_to_f32<T>(pk, q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+      }
+    }
+    if (P.stat_sum != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], 16); s1[e] += __shfl_xor(s1[e], 32);
+        s2[e] += __shfl_xor(s2[e], 16); s2[e] += __shfl_xor(s2[e], 32);
+      }
+      if ((lane >> 4) == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(&stat_l[0][col + e], s1[e]); atomicAdd(&stat_l[1][col + e], s2[e]); }
+      }
+    }
+  }
+  if (P.stat_sum != nullptr) {
+    __syncthreads();
+    if (tid < D3_COUT) {
+      atomicAdd(P.stat_sum + tid, stat_l[0][tid]);
+      atomicAdd(P.stat_sq + tid, stat_l[1][tid]);
+    }
+  }
+}
+
 // per-channel sum / sumsq of an NHWC tensor [M, C]: a wave sweeps 64 channels x a slice of rows
 template <typename T>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ sum,
@@ -566,6 +731,12 @@ extern "C" int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, 
   P.in_scale = in_scale; P.in_shift = in_shift; P.in_slope = in_slope;
   dim3 grid((unsigned)(wmz_cdiv(P.M, BMl) * P.nbn)), block(NT);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin == D3_CIN && Cout == D3_COUT &&
+      in_scale == nullptr && P.Wo % D3_TW == 0 && P.Ho % D3_TH == 0) {
+    hipLaunchKernelGGL(conv3x3s1_kernel, dim3((unsigned)(B * (P.Ho / D3_TH) * (P.Wo / D3_TW))), block, 0, st, P);
+    WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_fwd");
+    return WMZ_OK;
+  }
   if (dtype == WMZ_BF16) {
     if (tall) hipLaunchKernelGGL((conv2d_kernel<bf16_t, true>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((conv2d_kernel<bf16_t, false>), grid, block, 0, st, P);
