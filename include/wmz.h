@@ -129,6 +129,15 @@ int wmz_embed_pos3d_fwd(const int64_t* z, const float* emb, const float* pos_s, 
 /* its backward: scatter-add dx into the four fp32 tables (accumulated; zero them first). */
 int wmz_embed_pos3d_bwd(const int64_t* z, const void* dx, float* demb, float* dpos_s, float* dpos_h, float* dpos_w,
                         int B, int S, int H, int W, int D, int num_classes, int dtype, void* stream);
+/* The same gradients WITHOUT a float atomic per element (W = 16, D = 256, bf16, <= 12 288 classes; WMZ_ERR_UNSUPPORTED
+ * otherwise): the tokens are counting-sorted by class (histogram -> offsets -> list, int atomics only) and the embedding
+ * table's gradient is gathered, one wave per 64 list entries (csrc/embed_bwd.hip).  `workspace`: at least
+ * wmz_embed_pos3d_bwd_workspace_ints(...) ints, ZERO-FILLED by the caller before the first call; every call leaves the
+ * counters zeroed again (so a captured hipGraph can replay it), the rest is scratch. */
+long wmz_embed_pos3d_bwd_workspace_ints(int B, int S, int H, int W, int num_classes);
+int wmz_embed_pos3d_bwd_sorted(const int64_t* z, const void* dx, float* demb, float* dpos_s, float* dpos_h, float* dpos_w,
+                               int B, int S, int H, int W, int D, int num_classes, int* workspace, long workspace_ints,
+                               int dtype, void* stream);
 
 /* config 5, VqSparseDiffusionModel (minecraft/sparse_diffusion.py:91-111): ntok tokens at arbitrary flat grid positions:
  * x[t,:] = emb[tok[t]] + ((pos_s[p/(H*W)] + pos_h[(p/W)%H]) + pos_w[p%W]), p = pos[t]; and its backward (atomics, fp32). */

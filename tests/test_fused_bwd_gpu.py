@@ -194,3 +194,40 @@ def test_linear_wgrad_batch_vs_torch():
         assert rel(dw, rw) < 2e-5, (dw.shape, rel(dw, rw))
         if db is not None:
             assert rel(db, rb) < 2e-5
+
+
+@pytest.mark.parametrize('shape,classes,skew', [((1, 2, 3, 16), 7, 'uniform'), ((2, 3, 5, 16), 40, 'dominant'),
+                                                ((8, 32, 16, 16), 1025, 'last_frame_mask'), ((2, 3, 16, 16), 65, 'uniform')])
+def test_embed_backward_sorted_gather_vs_torch(shape, classes, skew):
+    """wmz_embed_pos3d_bwd_sorted (counting sort by class + gather) against index_add in fp32: the four tables, accumulation
+    into non-zero tables, two calls in a row (the counters must be back at zero), class distributions with a dominant class
+    (half of a frame masked; one code carrying most tokens), token counts that are not a multiple of the 64-entry wave tile,
+    out-of-range ids clamped like the forward does.  (The cases share ONE workspace, class counts going up and down: the
+    counters of a call must not sit in an earlier call's scratch.)"""
+    from world_modelz_amd import ops
+    torch.manual_seed(6)
+    B, S, H, W = shape
+    z = torch.randint(0, classes, shape, device='cuda')
+    if skew == 'last_frame_mask':
+        m = torch.rand(B, H, W, device='cuda') < 0.5
+        z[:, -1][m] = classes - 1
+    elif skew == 'dominant':
+        z[torch.rand(shape, device='cuda') < 0.7] = 3
+        z[0, 0, 0, 0], z[0, 0, 0, 1] = -5, classes + 9                   # clamped to 0 / classes - 1
+    dx = torch.randn(*shape, 256, device='cuda').bfloat16()
+    tabs0 = [torch.randn(n, 256, device='cuda') for n in (classes, S, H, W)]
+    tabs = [t.clone() for t in tabs0]
+    ops.embed_pos3d_bwd(z, dx, tabs)
+    ops.embed_pos3d_bwd(z, dx, tabs)                                     # second call: counters re-zeroed by the first
+    torch.cuda.synchronize()
+    f = dx.float().reshape(-1, 256).double()
+    zc = z.clamp(0, classes - 1).reshape(-1)
+    ref = [t.double().clone() for t in tabs0]
+    ref[0].index_add_(0, zc, 2 * f)
+    g5 = 2 * dx.double()
+    ref[1] += g5.sum((0, 2, 3))
+    ref[2] += g5.sum((0, 1, 3))
+    ref[3] += g5.sum((0, 1, 2))
+    for name, a, b in zip(('emb', 'pos_s', 'pos_h', 'pos_w'), tabs, ref):
+        err = float((a.double() - b).abs().max() / (b.abs().max() + 1e-30))
+        assert err < 2e-6, (name, err)

@@ -36,6 +36,8 @@ SIGNATURES = {
     'wmz_layernorm_bwd': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                           c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_embed_pos3d_bwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],
+    'wmz_embed_pos3d_bwd_workspace_ints': [c_int] * 5,                    # returns long
+    'wmz_embed_pos3d_bwd_sorted': [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_long, c_int, c_void_p],
     'wmz_linear_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
                        c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p],
     'wmz_linear_fwd_stats': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
@@ -109,7 +111,7 @@ def lib():
             if fn is None:
                 continue  # declared but not built yet: calling it raises below
             fn.argtypes = argtypes
-            fn.restype = c_long if name.endswith('_workspace_floats') else c_int
+            fn.restype = c_long if name.endswith(('_workspace_floats', '_workspace_ints')) else c_int
         _lib = L
     return _lib
 

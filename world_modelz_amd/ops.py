@@ -270,13 +270,26 @@ def layernorm_bwd(x, dyhat, gamma, dgamma, dbeta, skip=None, eps=1e-5, skip2=Non
     return dx
 
 
+_embed_ws = {}
+
+
 def embed_pos3d_bwd(z, dx, tabs):
-    """Accumulates into tabs = [demb, dpos_s, dpos_h, dpos_w] (fp32)."""
+    """Accumulates into tabs = [demb, dpos_s, dpos_h, dpos_w] (fp32).  The denoiser's shapes (W = 16, D = 256, bf16) take the
+    counting-sort + gather path (csrc/embed_bwd.hip: no float atomic per element), everything else the scatter kernels."""
     B, S, H, W = z.shape
     D = dx.shape[-1]
     dx = dx.contiguous()
+    C = tabs[0].shape[0]
+    if W == 16 and D == 256 and dx.dtype == torch.bfloat16 and C <= 12288:
+        need = L.lib().wmz_embed_pos3d_bwd_workspace_ints(B, S, H, W, C)
+        ws = _embed_ws.get(dx.device)
+        if ws is None or ws.numel() < need:
+            ws = _embed_ws[dx.device] = torch.zeros(need, dtype=torch.int32, device=dx.device)    # zeroed ONCE: calls re-zero the counters
+        L.call('wmz_embed_pos3d_bwd_sorted', L.ptr(z.contiguous()), L.ptr(dx), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]),
+               L.ptr(tabs[3]), B, S, H, W, D, C, L.ptr(ws), ws.numel(), L.dtype_code(dx.dtype), L.stream())
+        return tabs
     L.call('wmz_embed_pos3d_bwd', L.ptr(z.contiguous()), L.ptr(dx), L.ptr(tabs[0]), L.ptr(tabs[1]), L.ptr(tabs[2]),
-           L.ptr(tabs[3]), B, S, H, W, D, tabs[0].shape[0], L.dtype_code(dx.dtype), L.stream())
+           L.ptr(tabs[3]), B, S, H, W, D, C, L.dtype_code(dx.dtype), L.stream())
     return tabs
 
 

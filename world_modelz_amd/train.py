@@ -92,7 +92,7 @@ class _LinearCrossEntropy(torch.autograd.Function):
         dt = x.dtype
         w_c, wT = _cast.operand(w, dt), Bk._wt(w, dt, 'wT')
         loss = torch.empty(R, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if R > chunk else None
         wbuf, bbuf = getattr(w, '_wmz_grad', None), getattr(b, '_wmz_grad', None) if b is not None else None
         direct = wbuf is not None and (b is None or bbuf is not None)
         dw = wbuf if direct else torch.zeros(w.shape, dtype=torch.float32, device=x.device)
@@ -110,7 +110,10 @@ class _LinearCrossEntropy(torch.autograd.Function):
             d = torch.empty((r1 - r0, C), dtype=dt, device=x.device)
             L.call('wmz_ce_bwd', L.ptr(lg), lg.stride(0), L.ptr(target[r0:r1]), L.ptr(lse), L.ptr(ones), L.ptr(d), r1 - r0, C,
                    L.dtype_code(dt), L.stream())
-            dx[r0:r1] = ops.linear_dgrad(d, wT)
+            if r0 == 0 and r1 == R:
+                dx = ops.linear_dgrad(d, wT)               # one chunk (the denoiser's last frame): no staging copy
+            else:
+                dx[r0:r1] = ops.linear_dgrad(d, wT)
             ops.linear_wgrad(d, xs, dw, db)
         ctx.direct = direct
         ctx.params = (w, b)
@@ -123,12 +126,13 @@ class _LinearCrossEntropy(torch.autograd.Function):
         dx, dw, db = ctx.saved_tensors
         w, b = ctx.params
         if ctx.direct:
-            # the arena already holds grad_scale * d(mean loss)/dW: call `mean.backward()` as it is (g == 1) on this path
+            # the arena already holds grad_scale * d(mean loss)/dW, and dx is scaled the same way: `mean.backward()` is called
+            # as it is on this path (g == 1 by contract: a scale belongs in grad_scale, where it reaches every gradient)
             for p in (w, b):
                 ready = getattr(p, '_wmz_ready', None) if p is not None else None
                 if ready is not None:
                     ready()
-            return dx * g.to(dx.dtype), None, None, None, None, None
+            return dx, None, None, None, None, None
         return dx * g.to(dx.dtype), dw * g, (db * g if db is not None else None), None, None, None
 
 
