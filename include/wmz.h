@@ -312,8 +312,12 @@ int wmz_debug_attn_knobs(int dbg, int variant);
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]
  * (nn.Conv2d weight permuted (0,2,3,1)), Cin % 8 == 0 (zero-pad), act = LeakyReLU(slope) if leaky.  scale/shift carry a
- * folded eval-mode BatchNorm (autoencoder.py:21-25).  stat_sum / stat_sq (optional, fp32 [Cout], accumulated) receive
- * per-channel sum and sum of squares of the stored output: the batch statistics of a training-mode BatchNorm. */
+ * folded eval-mode BatchNorm (autoencoder.py:21-25).  stat_sum / stat_sq (optional, fp32 [WMZ_STAT_REPLICAS][Cout],
+ * accumulated; zero them first) receive per-channel sum and sum of squares of the stored output: the batch statistics of a
+ * training-mode BatchNorm.  REPLICATED: a workgroup adds into replica (its index mod WMZ_STAT_REPLICAS) and the consumer
+ * (wmz_bn_finalize) sums the replicas -- thousands of workgroups adding into ONE row is a chain of same-address atomics that
+ * complete ~15 ns apart, 60-120 us behind a 70-200 us convolution. */
+#define WMZ_STAT_REPLICAS 8
 int wmz_conv2d_nhwc_fwd(const void* x, const void* w, void* out, const float* bias, const float* scale,
                         const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int Hi, int Wi,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, int dtype,
@@ -325,9 +329,9 @@ int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, const float
                             const float* shift, const void* residual, float* stat_sum, float* stat_sq,
                             const float* in_scale, const float* in_shift, float in_slope, int B, int Hi, int Wi, int Cin,
                             int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, int dtype, void* stream);
-/* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [C]). */
+/* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [WMZ_STAT_REPLICAS][C]). */
 int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream);
-/* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq, count), running stats updated with
+/* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq: [WMZ_STAT_REPLICAS][C], summed here; count), running stats updated with
  * `momentum` and the unbiased variance, *num_batches_tracked (optional, int64) incremented; training == 0: running stats.
  * Emits scale = gamma*rstd, shift = beta - mean*scale. */
 int wmz_bn_finalize(const float* sum, const float* sq, double count, const float* gamma, const float* beta,

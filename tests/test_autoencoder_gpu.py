@@ -41,8 +41,8 @@ def test_conv_kernel_vs_torch(wmz):
         wop = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().cuda()
         out, s1, s2 = ops.conv2d_nhwc(xn, wop, k, k, s, p, bias=b.cuda(), stats=True)
         assert rel(out.permute(0, 3, 1, 2), ref) < 2e-6
-        assert torch.allclose(s1.cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4)
-        assert torch.allclose(s2.cpu(), (ref ** 2).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(s1.sum(0).cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4)      # [replicas, C] partial sums
+        assert torch.allclose(s2.sum(0).cpu(), (ref ** 2).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-4)
         outb = ops.conv2d_nhwc(xn.bfloat16(), wop.bfloat16(), k, k, s, p, bias=b.cuda(), leaky=True)
         refb = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.bfloat16().float(), w.bfloat16().float(), b,
                                                                          stride=s, padding=p), 0.01)
@@ -249,7 +249,7 @@ def test_conv1x1_input_prologue(dtype, tol):
     err = float((fused.float() - ref).norm() / ref.norm())
     assert err < tol, err
     assert float((fused.float() - two.float()).norm() / ref.norm()) < tol
-    assert torch.allclose(s1, fused.float().sum(dim=(0, 1, 2)), rtol=2e-3, atol=2e-2)
+    assert torch.allclose(s1.sum(0), fused.float().sum(dim=(0, 1, 2)), rtol=2e-3, atol=2e-2)
 
 
 def test_vqae_trainer_step_matches_torch_adamw_and_revives_dead_codes(wmz):
@@ -307,5 +307,5 @@ def test_direct_3x3_conv_equals_the_implicit_gemm_kernel(wmz):
                                      bias=bias, padding=1).permute(0, 2, 3, 1) + res.float()
     ref = torch.nn.functional.leaky_relu(ref, 0.01)
     assert float((y_d.float() - ref).norm() / ref.norm()) < 4e-3
-    assert torch.allclose(s_d, y_d.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
-    assert torch.allclose(q_d, (y_d.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s_d.sum(0), y_d.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(q_d.sum(0), (y_d.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-2)

@@ -8,6 +8,9 @@
 //          per-channel sum / sum-of-squares of the stored output (training-mode BatchNorm statistics).
 //   channel_stats / bn_finalize / affine_act / bilinear2x: the memory-bound companions.
 #include "wmz_common.h"
+#ifndef WMZ_ABL_NOSTAT
+#define WMZ_ABL_NOSTAT 0      // timing ablation (tools/build_variant.py): drop the global statistics atomics
+#endif
 
 namespace {
 
@@ -261,9 +264,10 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
       }
       if (P.stat_sum != nullptr) {
         __syncthreads();
-        if (tid < BN && n0 + tid < P.Cout) {
-          atomicAdd(P.stat_sum + n0 + tid, stat_l[0][tid]);
-          atomicAdd(P.stat_sq + n0 + tid, stat_l[1][tid]);
+        if (tid < BN && n0 + tid < P.Cout && !WMZ_ABL_NOSTAT) {
+          const long rep = (long)(blockIdx.x % WMZ_STAT_REPLICAS) * P.Cout;
+          atomicAdd(P.stat_sum + rep + n0 + tid, stat_l[0][tid]);
+          atomicAdd(P.stat_sq + rep + n0 + tid, stat_l[1][tid]);
         }
       }
       return;
@@ -295,7 +299,11 @@ __global__ __launch_bounds__(NT, 2) void conv2d_kernel(ConvParams P) {
     if (P.stat_sum != nullptr) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
-      if (hh == 0 && cok) { atomicAdd(P.stat_sum + col, s1); atomicAdd(P.stat_sq + col, s2); }
+      if (hh == 0 && cok) {
+        const long rep = (long)(blockIdx.x % WMZ_STAT_REPLICAS) * P.Cout;
+        atomicAdd(P.stat_sum + rep + col, s1);
+        atomicAdd(P.stat_sq + rep + col, s2);
+      }
     }
   }
 }
@@ -458,9 +466,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3s1_kernel(ConvParams P) {
   }
   if (P.stat_sum != nullptr) {
     __syncthreads();
-    if (tid < D3_COUT) {
-      atomicAdd(P.stat_sum + tid, stat_l[0][tid]);
-      atomicAdd(P.stat_sq + tid, stat_l[1][tid]);
+    if (tid < D3_COUT && !WMZ_ABL_NOSTAT) {
+      const int rep = (int)(blockIdx.x % WMZ_STAT_REPLICAS) * D3_COUT;
+      atomicAdd(P.stat_sum + rep + tid, stat_l[0][tid]);
+      atomicAdd(P.stat_sq + rep + tid, stat_l[1][tid]);
     }
   }
 }
@@ -484,8 +493,9 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
   __syncthreads();
   if (sub == 0 && c < C) {
     const int l = threadIdx.x;
-    atomicAdd(sum + c, r1[0][l] + r1[1][l] + r1[2][l] + r1[3][l]);
-    atomicAdd(sq + c, r2[0][l] + r2[1][l] + r2[2][l] + r2[3][l]);
+    const long rep = (long)(blockIdx.x % WMZ_STAT_REPLICAS) * C;
+    atomicAdd(sum + rep + c, r1[0][l] + r1[1][l] + r1[2][l] + r1[3][l]);
+    atomicAdd(sq + rep + c, r2[0][l] + r2[1][l] + r2[2][l] + r2[3][l]);
   }
 }
 
@@ -502,8 +512,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
   if (c >= C) return;
   float mean, var;
   if (training) {
-    mean = sum[c] / count;
-    var = fmaxf(sq[c] / count - mean * mean, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < WMZ_STAT_REPLICAS; ++r) { s1 += sum[r * C + c]; s2 += sq[r * C + c]; }
+    mean = s1 / count;
+    var = fmaxf(s2 / count - mean * mean, 0.f);
     const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;

@@ -295,9 +295,13 @@ def embed_pos3d_bwd(z, dx, tabs):
 
 # ------------------------------------------------------------------------------------------------ conv AE (NHWC)
 
+STAT_REPLICAS = 8          # include/wmz.h: WMZ_STAT_REPLICAS
+
+
 def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None, residual=None, leaky=False,
                 slope=0.01, stats=False, pre=None):
-    """x: [B,H,W,Cin] contiguous (Cin % 8 == 0), w_op: [Cout, KH*KW*Cin] in x's dtype -> [B,Ho,Wo,Cout] (+ sum, sq)."""
+    """x: [B,H,W,Cin] contiguous (Cin % 8 == 0), w_op: [Cout, KH*KW*Cin] in x's dtype -> [B,Ho,Wo,Cout] (+ sum, sq: fp32
+    [STAT_REPLICAS, Cout] partial sums, summed by bn_finalize)."""
     B, Hi, Wi, Cin = x.shape
     Cout = w_op.shape[0]
     assert x.is_contiguous() and w_op.is_contiguous() and w_op.shape[1] == KH * KW * Cin and w_op.dtype == x.dtype
@@ -306,7 +310,7 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
     out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     s = q = None
     if stats:
-        s, q = torch.zeros((2, Cout), dtype=torch.float32, device=x.device).unbind(0)      # one fill for both
+        s, q = torch.zeros((2, STAT_REPLICAS, Cout), dtype=torch.float32, device=x.device).unbind(0)      # one fill for both
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
     psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
@@ -319,7 +323,7 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
 def channel_stats_nhwc(x):
     C = x.shape[-1]
     M = x.numel() // C
-    s, q = torch.zeros((2, C), dtype=torch.float32, device=x.device).unbind(0)
+    s, q = torch.zeros((2, STAT_REPLICAS, C), dtype=torch.float32, device=x.device).unbind(0)
     L.call('wmz_channel_stats_nhwc', L.ptr(x), M, C, L.ptr(s), L.ptr(q), L.dtype_code(x.dtype), L.stream())
     return s, q
 
