@@ -204,6 +204,9 @@ int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const float* pos
  *               writes row-major. */
 #define WMZ_FUSED_X_IN_TILED 1
 #define WMZ_FUSED_X_OUT_TILED 2
+/* wmz_layer_fused_fwd_train only: x1_out receives the NORMALISED rows (x1 - mean) rstd of the feed-forward block's input
+ * instead of x1 itself -- everything the fused backward needs of x1 (wmz_ff_fused_bwd with xhat_out = NULL). */
+#define WMZ_FUSED_X1_NORMALISED 4
 int wmz_local3d_attn_fwd_planes(const void* q, const void* k, const void* v, void* out, float* lse, int B, int S, int H,
                                 int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
                                 int q_plane0, int q_planes, int dtype, void* stream);
@@ -269,7 +272,9 @@ int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const floa
  *                       block's input x1 and its LayerNorm statistics ->
  *                         g_out  = GELU(z)                 [ntok, M]   operand of dW2 = dy^T g
  *                         dz_out = (dy W2) GELU'(z)        [ntok, M]   operand of dW1
- *                         xhat_out = (x1 - mean) rstd      [ntok, D]   operand of dW1
+ *                         xhat_out = (x1 - mean) rstd      [ntok, D]   operand of dW1; NULL: `x1` already HOLDS these rows
+ *                                                                      (forward flag WMZ_FUSED_X1_NORMALISED) -- nothing is
+ *                                                                      recomputed or written, the forward's tensor is the operand
  *                         dx1_out = dy + LNbwd(dz W1')     [ntok, D]   gradient w.r.t. x1 (= to_out's output + residual)
  *                         do_out  = dx1 Wout               [ntok, I]   gradient w.r.t. the attention output
  *   wmz_local3d_attn_bwd  (do -> dq, dk | dv)

@@ -89,6 +89,18 @@ def test_ff_fused_bwd_vs_torch(layer, n):
     errs = dict(g=rel(g, gr), dz=rel(dz, dz_r), xhat=rel(xhat1, xh_r), dx1=rel(dx1, dx1_r), do=rel(do, do_r))
     print('[ff_fused_bwd]', {k: f'{v:.2e}' for k, v in errs.items()})
     assert all(v < 6e-3 for v in errs.values()), errs
+    # the training path: the forward stored the NORMALISED rows (WMZ_FUSED_X1_NORMALISED) -- they come in as `x1`, xhat_out is
+    # NULL, nothing is recomputed or written
+    outs_n = [torch.empty_like(t_) for t_ in outs]
+    ptrs = [L.ptr(t_) for t_ in outs_n]
+    ptrs[2] = None
+    L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(xh_r.bfloat16().contiguous()), L.ptr(st), *ptrs, L.ptr(wpack_ff),
+           n, D, I, M, 0, 0, None, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(outs_n[0], g) and torch.equal(outs_n[1], dz)
+    e_n = dict(dx1=rel(outs_n[3], dx1_r), do=rel(outs_n[4], do_r))
+    print('[ff_fused_bwd, normalised input]', {k: f'{v:.2e}' for k, v in e_n.items()})
+    assert all(v < 6e-3 for v in e_n.values()), e_n
 
 
 @pytest.mark.parametrize('with_res,n', [(True, 1536), (False, 1536), (True, 864)])

@@ -231,7 +231,8 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
     wait_untracked<D / 16>(xb);                                        // the residual rows are older than the ring's 6 pieces
     WMZ_TS(45);
     add_bop<D / 32>(xr, xb);                                           // + x  -> x1
-    if (P.x1o != nullptr) {                                            // training: the backward's LayerNorm / wgrad input
+    const bool x1_hat = (P.xflags & WMZ_FUSED_X1_NORMALISED) != 0;
+    if (P.x1o != nullptr && !x1_hat) {                                 // training, op-by-op backward: x1 itself
       bop_from_acc<D / 32>(xb, xr);
       store_tile256(stg, P.x1o, tok0, P.ntok, xb, lane);
       ws_extra(ws, 16);
@@ -239,6 +240,10 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
     WMZ_TS(3);
     ln_to_bop<D / 32>(xb, xr, P.eps, P.st_ff, tok, P.ntok, lane);   // LN2(x1)
     if (P.st_ff != nullptr) ws_extra(ws, 2);
+    if (P.x1o != nullptr && x1_hat) {                                  // training, fused backward: the NORMALISED rows -- all the
+      store_tile256(stg, P.x1o, tok0, P.ntok, xb, lane);               // backward needs of x1 (LayerNorm backward and the dW1
+      ws_extra(ws, 16);                                                // operand), already in registers as the W1 operand
+    }
     WMZ_TS(4);
     // feed-forward, MC hidden units at a time: W1[c] -> GELU -> W2[c], with the stream packed as W1[0], W1[1], W2[0], W1[2],
     // W2[1], .., W1[7], W2[6], W2[7]: GELU(c) is VALU work that rides under the MFMAs of the two stages between W1[c] and
@@ -621,7 +626,8 @@ extern "C" int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_o
   WMZ_REQUIRE(has_head || has_tail, "wmz_layer_fused_fwd_train: nothing to do");
   WMZ_REQUIRE(!has_head || (o && x_out), "wmz_layer_fused_fwd_train: head needs o and x_out");
   WMZ_REQUIRE(!has_tail || (q_out && kv_out), "wmz_layer_fused_fwd_train: tail needs q_out and kv_out");
-  WMZ_REQUIRE((xflags & ~3) == 0 && (xflags == 0 || ntok % 32 == 0), "wmz_layer_fused_fwd_train: bad layout flags");
+  WMZ_REQUIRE((xflags & ~7) == 0 && ((xflags & 3) == 0 || ntok % 32 == 0), "wmz_layer_fused_fwd_train: bad layout flags");
+  WMZ_REQUIRE(!(xflags & WMZ_FUSED_X1_NORMALISED) || (has_head && x1_out), "wmz_layer_fused_fwd_train: WMZ_FUSED_X1_NORMALISED needs the head and x1_out");
   FusedParams P;
   P.o = (const bf16_t*)o; P.x = (const bf16_t*)x; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
   P.wpack = (const char*)wpack; P.vec = vec; P.ntok = ntok; P.eps = eps;

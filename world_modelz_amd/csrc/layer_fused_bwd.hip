@@ -98,7 +98,8 @@ __device__ __forceinline__ void store_group(char* stg, bf16_t* dst, int rowf, lo
 // NOTHING may spill (see the kernels), so: the second pass recomputes xhat instead of keeping the first pass's values
 // (the empty asms make its inputs opaque to common-subexpression elimination; the compiler would otherwise hold -- and
 // spill -- 256 values), and the scheduler is fenced block by block.
-template <typename Mid>
+// XIN: xb already holds xhat (the forward stored the normalised rows): nothing is recomputed and nothing leaves.
+template <bool XIN, typename Mid>
 __device__ __forceinline__ void ln_bwd_inplace(f32x16 (&acc)[8], Frag8<bf16_t> (&xb)[16], float mean, float rstd, char* stg,
                                                bf16_t* xhat_out, long tok0, int ntok, int lane, WStream& ws, Mid mid) {
   const int t = lane & 31, h = lane >> 5;
@@ -108,7 +109,8 @@ __device__ __forceinline__ void ln_bwd_inplace(f32x16 (&acc)[8], Frag8<bf16_t> (
   for (int b = 0; b < 8; ++b) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float xh = fmaf(bf16_bits_to_f32((unsigned short)xb[2 * b + (i >> 3)].v[i & 7]), rstd, mr);
+      const float xv = bf16_bits_to_f32((unsigned short)xb[2 * b + (i >> 3)].v[i & 7]);
+      const float xh = XIN ? xv : fmaf(xv, rstd, mr);
       s1 += acc[b][i];
       s2 = fmaf(acc[b][i], xh, s2);
     }
@@ -128,17 +130,20 @@ __device__ __forceinline__ void ln_bwd_inplace(f32x16 (&acc)[8], Frag8<bf16_t> (
         s16x8 pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xh = fmaf(bf16_bits_to_f32((unsigned short)xb[2 * b + m].v[e]), rstd, mr);
+          const float xv = bf16_bits_to_f32((unsigned short)xb[2 * b + m].v[e]);
+          const float xh = XIN ? xv : fmaf(xv, rstd, mr);
           acc[b][8 * m + e] = rstd * (acc[b][8 * m + e] - s1 - xh * s2);
-          pk[e] = (short)f32_to_bf16_bits(xh);
+          if constexpr (!XIN) pk[e] = (short)f32_to_bf16_bits(xh);
         }
         asm volatile("" : "+v"(acc[b]));                    // the update of acc HERE (left alone it sinks to its use in the
-        stage_put(stg, pk, t, h * 8 + 2 * bb + m);          // next GEMM and every xhat stays alive -- in scratch -- until then)
+        if constexpr (!XIN) stage_put(stg, pk, t, h * 8 + 2 * bb + m);   // next GEMM and every xhat stays alive -- in scratch -- until then)
       }
       WMZ_FENCE();
     }
-    stage_flush<256>(stg, xhat_out, tok0, ntok, 128 * j, lane);
-    ws_extra(ws, 8);
+    if constexpr (!XIN) {
+      stage_flush<256>(stg, xhat_out, tok0, ntok, 128 * j, lane);
+      ws_extra(ws, 8);
+    }
     if (j == 0) mid();                                      // the first half of xb is dead from here on
   }
 }
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void qkv_bwd_kernel(BwdParams P) {
   asm volatile("" : "+v"(mean), "+v"(rstd));                           // (older than xb: landed)
   Frag8<bf16_t> dqb[I / 16];
   int m_q = 0;
-  ln_bwd_inplace(acc, xb, mean, rstd, stg, P.xhat, tok0, P.ntok, lane, ws, [&]() {
+  ln_bwd_inplace<false>(acc, xb, mean, rstd, stg, P.xhat, tok0, P.ntok, lane, ws, [&]() {
     load_row<I / 16>(dqb, P.dq + tokc * P.lddq + h * 64, ws);          // in flight under the second half of the LayerNorm pass
     m_q = ws.all;
   });
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void qkv_bwd_kernel(BwdParams P) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the padding slabs still in flight target this workgroup's LDS
 }
 
-template <int D, int I, int M, bool LASTDY>
+template <int D, int I, int M, bool LASTDY, bool XIN>
 __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
   static_assert(D == 256 && I == 128 && M == 256, "built for the default denoiser widths");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
   vm_wait_since(ws, m_x);
   pin(xb);
   asm volatile("" : "+v"(mean), "+v"(rstd));
-  ln_bwd_inplace(acc, xb, mean, rstd, stg, P.xhat1, tok0, P.ntok, lane, ws, []() {});
+  ln_bwd_inplace<XIN>(acc, xb, mean, rstd, stg, P.xhat1, tok0, P.ntok, lane, ws, []() {});
   load_row<D / 16>(xb, dyrow, ws);                                     // the residual path (L2-hot: this wave read it above)
   const int m_r = ws.all;
   vm_wait_since(ws, m_r);
@@ -416,7 +421,7 @@ extern "C" int wmz_qkv_fused_bwd(const void* dq, long lddq, const void* dkv, lon
 extern "C" int wmz_ff_fused_bwd(const void* dy, const void* z_tiled, const void* x1, const float* ln_stats, void* g_out,
                                 void* dz_out, void* xhat_out, void* dx1_out, void* do_out, const void* wpack, int ntok, int D,
                                 int I, int M, int dy_last_planes, int dy_plane_tokens, const void* zero_row, void* stream) {
-  WMZ_REQUIRE(dy && z_tiled && x1 && ln_stats && g_out && dz_out && xhat_out && dx1_out && do_out && wpack && ntok > 0,
+  WMZ_REQUIRE(dy && z_tiled && x1 && ln_stats && g_out && dz_out && dx1_out && do_out && wpack && ntok > 0,
               "wmz_ff_fused_bwd: null tensor");
   if (!(D == 256 && I == 128 && M == 256)) {
     wmz_set_error("wmz_ff_fused_bwd: built for dim 256 / inner 128 / mlp 256 (got %d/%d/%d); use the per-op backward", D, I, M);
@@ -433,15 +438,16 @@ extern "C" int wmz_ff_fused_bwd(const void* dy, const void* z_tiled, const void*
   P.g = (bf16_t*)g_out; P.dz = (bf16_t*)dz_out; P.xhat1 = (bf16_t*)xhat_out; P.dx1 = (bf16_t*)dx1_out; P.dout = (bf16_t*)do_out;
   const size_t smem = RING * SLAB + FW * 8192;
   const dim3 grid((unsigned)wmz_cdiv(ntok, TW * FW)), block(NTHR);
-  if (lastdy) {
-    auto kern = ff_bwd_kernel<256, 128, 256, true>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);
-  } else {
-    auto kern = ff_bwd_kernel<256, 128, 256, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);
-  }
+#define WMZ_FF_BWD(LAST_, XIN_)                                                                                            \
+  do {                                                                                                                     \
+    auto kern = ff_bwd_kernel<256, 128, 256, LAST_, XIN_>;                                                                 \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);                                                   \
+  } while (0)
+  const bool xin = xhat_out == nullptr;       // x1 already holds the normalised rows (WMZ_FUSED_X1_NORMALISED forward)
+  if (lastdy) { if (xin) WMZ_FF_BWD(true, true); else WMZ_FF_BWD(true, false); }
+  else { if (xin) WMZ_FF_BWD(false, true); else WMZ_FF_BWD(false, false); }
+#undef WMZ_FF_BWD
   WMZ_LAUNCH_CHECK("wmz_ff_fused_bwd");
   return WMZ_OK;
 }

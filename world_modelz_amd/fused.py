@@ -186,7 +186,7 @@ class PackSet:
             _cast._cache[_cast._key(params, None, tag)] = (ver, val, tuple(weakref.ref(p) for p in params))
 
 
-X_IN_TILED, X_OUT_TILED = 1, 2      # include/wmz.h WMZ_FUSED_X_*_TILED
+X_IN_TILED, X_OUT_TILED, X1_NORMALISED = 1, 2, 4      # include/wmz.h WMZ_FUSED_X_*_TILED, WMZ_FUSED_X1_NORMALISED
 
 
 def layer_fused(o, x, head, tail, eps=1e-5, xflags=0):
@@ -315,7 +315,9 @@ def _layer_train(o, x_in, head, tail, tiled, save_z):
     x_t = torch.empty(lead + (D_,), dtype=bf, device=dev) if out_tiled else None
     q = torch.empty(lead + (I_,), dtype=bf, device=dev) if tail is not None else None
     kv = torch.empty(lead + (2 * I_,), dtype=bf, device=dev) if tail is not None else None
-    xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if out_tiled else 0)
+    # the fused backward (save_z) needs x1 only as its NORMALISED rows (LayerNorm backward, dW1 operand): the kernel has them in
+    # registers as the W1 operand and stores those instead of x1
+    xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if out_tiled else 0) | (X1_NORMALISED if save_z else 0)
     st_ff = torch.empty((2, ntok), dtype=torch.float32, device=dev)
     st_attn = torch.empty((2, ntok), dtype=torch.float32, device=dev) if tail is not None else None
     zt = torch.empty((ntok, M_), dtype=bf, device=dev) if save_z else None
@@ -368,7 +370,8 @@ def _zero_row(dev):
 def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt, dy_last=None):
     """One layer of the stack's backward on the fused per-token kernels: wmz_ff_fused_bwd -> attention backward ->
     wmz_qkv_fused_bwd, the weight gradients as plain GEMMs over the operands those kernels write, the LayerNorm affine
-    gradients from the raw weight gradients (wmz_ln_affine_grads).  dy_last = (S, HW): dy holds only the clips' last planes
+    gradients from the raw weight gradients (wmz_ln_affine_grads).  x1: the NORMALISED rows of the feed-forward block's input, as
+    the forward stored them (WMZ_FUSED_X1_NORMALISED).  dy_last = (S, HW): dy holds only the clips' last planes
     ([B, H, W, D], the last layer under the denoiser's last-frame loss).  Returns (gradient w.r.t. the layer's input, the 14
     parameter gradients in _layer_params order)."""
     an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
@@ -378,16 +381,15 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     wpack_qkv, wpack_ff = _layer_pack_bwd(attn, ff)
     g = torch.empty((ntok, M_), dtype=bf, device=dev)
     dz = torch.empty((ntok, M_), dtype=bf, device=dev)
-    xhat1 = torch.empty((ntok, D_), dtype=bf, device=dev)
     dx1 = torch.empty((ntok, D_), dtype=bf, device=dev)
     do = torch.empty(lead + (I_,), dtype=bf, device=dev)
     if dy_last is None:
-        L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
+        L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), None, L.ptr(dx1),
                L.ptr(do), L.ptr(wpack_ff), ntok, D_, I_, M_, 0, 0, None, L.stream())
         dy2, g2 = dy.reshape(ntok, D_), g
     else:
         S_, HW_ = dy_last
-        L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), L.ptr(xhat1), L.ptr(dx1),
+        L.call('wmz_ff_fused_bwd', L.ptr(dy), L.ptr(zt), L.ptr(x1), L.ptr(st_ff), L.ptr(g), L.ptr(dz), None, L.ptr(dx1),
                L.ptr(do), L.ptr(wpack_ff), ntok, D_, I_, M_, S_, HW_, L.ptr(_zero_row(dev)), L.stream())
         # dW2 = dy^T GELU(z) only has the last planes' rows to sum over
         dy2 = dy.reshape(-1, D_)
@@ -408,7 +410,7 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     ckv = torch.empty((2 * I_,), dtype=torch.float32, device=dev)
     ops.linear_wgrad_batch([
         (dy2, g2, s_ff2.bufs[0], s_ff2.bufs[1], False),                       # dW2 = dy^T GELU(z), db2 = colsum(dy)
-        (dz, xhat1, G1, c1, True),
+        (dz, x1.reshape(ntok, D_), G1, c1, True),            # x1 = the NORMALISED rows the forward stored
         (dx1, o.reshape(ntok, I_), s_out.bufs[0], s_out.bufs[1], False),
         (dq.reshape(ntok, I_), x_in.reshape(ntok, D_), s_q.bufs[0], None, False),
         (dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv, True)])
