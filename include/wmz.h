@@ -107,10 +107,13 @@ int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float
 /* n <= 6 independent weight gradients (no prologue) by ONE launch pair: HOST tables of n entries each, the arguments of
  * wmz_linear_wgrad_ws per problem; the workspace must hold the sum of the problems' workspace sizes.  (The fused backward
  * of a transformer layer has five such GEMMs whose launches are each one wave of workgroups: batched they share the ramp
- * and the tail.) */
+ * and the tail.)  a_tiled: NULL, or a table whose non-zero entries say that problem i's A is the fused path's TILED stream
+ * (WMZ_FUSED_X_OUT_TILED: bf16, K = 256, M a multiple of 32; lda is ignored) -- the to_q weight gradient reads the raw
+ * stream where the forward left it. */
 int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
                            float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
-                           const int* overwrite, float* workspace, long workspace_floats, int dtype, void* stream);
+                           const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats, int dtype,
+                           void* stream);
 /* nn.LayerNorm statistics (PreNorm, local_3d_attention.py:14): mean[M], rstd[M] over the K axis. */
 int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
                         void* stream);
@@ -207,6 +210,11 @@ int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const float* pos
 /* wmz_layer_fused_fwd_train only: x1_out receives the NORMALISED rows (x1 - mean) rstd of the feed-forward block's input
  * instead of x1 itself -- everything the fused backward needs of x1 (wmz_ff_fused_bwd with xhat_out = NULL). */
 #define WMZ_FUSED_X1_NORMALISED 4
+/* wmz_layer_fused_fwd_train / wmz_embed_qkv_fused_fwd_train with a tail and a TILED x_out: x_out_rowmajor receives the
+ * NORMALISED rows (x - mean) rstd of the stream (the next layer's to_k | to_v input without the affine) instead of a copy of x:
+ * what wmz_qkv_fused_bwd (xhat_out = NULL) and the to_k | to_v weight gradient read; the raw stream -- the to_q weight
+ * gradient's operand -- is read from the tiled x_out (wmz_linear_wgrad_batch: a_tiled). */
+#define WMZ_FUSED_XRM_NORMALISED 8
 int wmz_local3d_attn_fwd_planes(const void* q, const void* k, const void* v, void* out, float* lse, int B, int S, int H,
                                 int W, int heads, int dh, int eS, int eH, int eW, long ldq, long ldk, long ldv, long ldo,
                                 int q_plane0, int q_planes, int dtype, void* stream);
@@ -280,7 +288,8 @@ int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb, const floa
  *   wmz_local3d_attn_bwd  (do -> dq, dk | dv)
  *   wmz_qkv_fused_bwd   dq [ntok, I], dk | dv [ntok, 2I], the layer's input x + statistics, res = dx1 ->
  *                         dx = res + dq Wq + LNbwd(dk Wk' + dv Wv')      gradient w.r.t. the layer's input
- *                         xhat_out = (x - mean) rstd                      operand of the to_k | to_v weight gradient
+ *                         xhat_out = (x - mean) rstd                      operand of the to_k | to_v weight gradient; NULL: `x`
+ *                                                                         already HOLDS these rows (WMZ_FUSED_XRM_NORMALISED)
  * wmz_ff_fused_bwd with dy_last_planes = S > 0 (the LAST layer under a last-frame loss, main.py:37): dy holds only the
  * clips' last planes, [ntok / S, D] with dy_plane_tokens rows per clip; every other token's gradient is zero and is read
  * from zero_row (D bf16 zeros) -- no [ntok, D] tensor of zeros is written or read.  0 / 0 / NULL: dy is [ntok, D].

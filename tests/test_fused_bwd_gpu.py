@@ -132,6 +132,14 @@ def test_qkv_fused_bwd_vs_torch(layer, with_res, n):
     e1, e2 = rel(dx, dx_r), rel(xhat, xh_r)
     print(f'[qkv_fused_bwd res={with_res}] dx {e1:.2e} xhat {e2:.2e}')
     assert e1 < 6e-3 and e2 < 6e-3
+    # the training path on a tiled stream: `x` holds the NORMALISED rows (WMZ_FUSED_XRM_NORMALISED), xhat_out is NULL
+    dx_n = torch.empty_like(dx)
+    L.call('wmz_qkv_fused_bwd', L.ptr(dq), I, L.ptr(dkv), 2 * I, L.ptr(xh_r.bfloat16().contiguous()), L.ptr(st), L.ptr(res),
+           L.ptr(dx_n), None, L.ptr(wpack_qkv), n, D, I, L.stream())
+    torch.cuda.synchronize()
+    e3 = rel(dx_n, dx_r)
+    print(f'[qkv_fused_bwd res={with_res}, normalised input] dx {e3:.2e}')
+    assert e3 < 6e-3
 
 
 def test_ln_affine_grads_vs_torch():
@@ -206,6 +214,27 @@ def test_linear_wgrad_batch_vs_torch():
         assert rel(dw, rw) < 2e-5, (dw.shape, rel(dw, rw))
         if db is not None:
             assert rel(db, rb) < 2e-5
+
+
+def test_linear_wgrad_batch_reads_the_tiled_stream():
+    """a_tiled: A in the fused path's stream layout (per 32-row tile [16 chunks][2 halves][32 rows][8 features]) gives the
+    gradient of the row-major A to the bit; an ordinary problem rides in the same launch."""
+    from world_modelz_amd import ops
+    torch.manual_seed(8)
+    n = 2048 + 96
+    a = torch.randn(n, 256, device='cuda').bfloat16()
+    dc = torch.randn(n, 128, device='cuda').bfloat16()
+    # row-major [n, 256] -> tiles: feature f = 128 h + 8 s + j of row 32 T + t  ->  [T][s][h][t][j]
+    a_t = a.view(n // 32, 32, 2, 16, 8).permute(0, 3, 2, 1, 4).contiguous()
+    g_rm, g_t = torch.empty(128, 256, device='cuda'), torch.empty(128, 256, device='cuda')
+    other = torch.zeros(64, 128, device='cuda')
+    dc2, a2 = torch.randn(n, 64, device='cuda').bfloat16(), torch.randn(n, 128, device='cuda').bfloat16()
+    ops.linear_wgrad_batch([(dc, a, g_rm, None, True)])
+    ops.linear_wgrad_batch([(dc, a_t.view(n, 256), g_t, None, True, True), (dc2, a2, other, None, False)])
+    torch.cuda.synchronize()
+    assert torch.equal(g_rm, g_t)
+    assert rel(g_t, dc.float().t() @ a.float()) < 2e-5
+    assert rel(other, dc2.float().t() @ a2.float()) < 2e-5
 
 
 @pytest.mark.parametrize('shape,classes,skew', [((1, 2, 3, 16), 7, 'uniform'), ((2, 3, 5, 16), 40, 'dominant'),

@@ -53,7 +53,7 @@ for name, body in re.findall(r'^(_ZN\S*(?:qkv_bwd_kernel|ff_bwd_kernel)\S*):\s*;
     for b in bad[:10]:
         print('   line', b[0], b[1])
     bad_total += len(bad)
-if kernels < 6:
-    print('expected 6 kernel instantiations, found', kernels)
+if kernels < 8:
+    print('expected 8 kernel instantiations, found', kernels)
     sys.exit(1)
 sys.exit(1 if bad_total else 0)

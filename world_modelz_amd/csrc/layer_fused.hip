@@ -313,7 +313,11 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
     if (P.xflags & WMZ_FUSED_X_OUT_TILED) { if (tile_ok) store_bop_tiled<D / 16>(P.xo + tok0 * D, x2b, lane); }
     else store_tile256(stg, P.xo, tok0, P.ntok, x2b, lane);
     ws_extra(ws, 16);
-    if (P.xo_rm != nullptr) { store_tile256(stg, P.xo_rm, tok0, P.ntok, x2b, lane); ws_extra(ws, 16); }
+    if (P.xo_rm != nullptr) {        // training: the row-major copy for the backward -- x2 itself, or (WMZ_FUSED_XRM_NORMALISED)
+      if (TAIL && (P.xflags & WMZ_FUSED_XRM_NORMALISED)) store_tile256(stg, P.xo_rm, tok0, P.ntok, xb, lane);   // LN1'(x2)'s rows
+      else store_tile256(stg, P.xo_rm, tok0, P.ntok, x2b, lane);
+      ws_extra(ws, 16);
+    }
     WMZ_TS(31);
     if constexpr (TAIL) {
       f32x16 qa[I / 32];
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
       if (P.xflags & WMZ_FUSED_X_OUT_TILED) { if (tile_ok) store_bop_tiled<D / 16>(P.xo + tok0 * D, xb, lane); }
       else store_tile256(stg, P.xo, tok0, P.ntok, xb, lane);
       ws_extra(ws, 16);
-      if (P.xo_rm != nullptr) { store_tile256(stg, P.xo_rm, tok0, P.ntok, xb, lane); ws_extra(ws, 16); }
+      if (P.xo_rm != nullptr && !(P.xflags & WMZ_FUSED_XRM_NORMALISED)) { store_tile256(stg, P.xo_rm, tok0, P.ntok, xb, lane); ws_extra(ws, 16); }
     }
     {
       f32x16 qa[I / 32];
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
     acc_from_bop<D / 32>(xr, xb);
     ln_to_bop<D / 32>(xb, xr, P.eps, P.st_attn, tok, P.ntok, lane);   // LN1'(x)
     if (P.st_attn != nullptr) ws_extra(ws, 2);
+    if (P.xo_rm != nullptr && (P.xflags & WMZ_FUSED_XRM_NORMALISED)) { store_tile256(stg, P.xo_rm, tok0, P.ntok, xb, lane); ws_extra(ws, 16); }
   }
   if constexpr (TAIL) {
     f32x16 ka[I / 32];
@@ -626,7 +631,9 @@ extern "C" int wmz_layer_fused_fwd_train(const void* o, const void* x, void* x_o
   WMZ_REQUIRE(has_head || has_tail, "wmz_layer_fused_fwd_train: nothing to do");
   WMZ_REQUIRE(!has_head || (o && x_out), "wmz_layer_fused_fwd_train: head needs o and x_out");
   WMZ_REQUIRE(!has_tail || (q_out && kv_out), "wmz_layer_fused_fwd_train: tail needs q_out and kv_out");
-  WMZ_REQUIRE((xflags & ~7) == 0 && ((xflags & 3) == 0 || ntok % 32 == 0), "wmz_layer_fused_fwd_train: bad layout flags");
+  WMZ_REQUIRE((xflags & ~15) == 0 && ((xflags & 3) == 0 || ntok % 32 == 0), "wmz_layer_fused_fwd_train: bad layout flags");
+  WMZ_REQUIRE(!(xflags & WMZ_FUSED_XRM_NORMALISED) || (has_tail && x_out_rowmajor && (xflags & WMZ_FUSED_X_OUT_TILED)),
+              "wmz_layer_fused_fwd_train: WMZ_FUSED_XRM_NORMALISED needs the tail, x_rm_out and a tiled x_out (the raw stream must survive somewhere)");
   WMZ_REQUIRE(!(xflags & WMZ_FUSED_X1_NORMALISED) || (has_head && x1_out), "wmz_layer_fused_fwd_train: WMZ_FUSED_X1_NORMALISED needs the head and x1_out");
   FusedParams P;
   P.o = (const bf16_t*)o; P.x = (const bf16_t*)x; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
@@ -648,7 +655,9 @@ extern "C" int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb,
                                              void* stream) {
   WMZ_REQUIRE(z && emb && pos_s && pos_h && pos_w && x_out && q_out && kv_out && wpack && vec, "wmz_embed_qkv_fused_fwd_train: null tensor");
   WMZ_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && num_classes > 0 && (long)B * S * H * W < (1L << 31), "wmz_embed_qkv_fused_fwd_train: bad shape");
-  WMZ_REQUIRE((xflags & ~WMZ_FUSED_X_OUT_TILED) == 0 && (xflags == 0 || ((long)S * H * W) % 32 == 0), "wmz_embed_qkv_fused_fwd_train: bad layout flags");
+  WMZ_REQUIRE((xflags & ~(WMZ_FUSED_X_OUT_TILED | WMZ_FUSED_XRM_NORMALISED)) == 0 && (xflags == 0 || ((long)S * H * W) % 32 == 0), "wmz_embed_qkv_fused_fwd_train: bad layout flags");
+  WMZ_REQUIRE(!(xflags & WMZ_FUSED_XRM_NORMALISED) || (x_out_rowmajor && (xflags & WMZ_FUSED_X_OUT_TILED)),
+              "wmz_embed_qkv_fused_fwd_train: WMZ_FUSED_XRM_NORMALISED needs x_out_rowmajor and a tiled x_out");
   FusedParams P;
   P.o = nullptr; P.x = nullptr; P.xo = (bf16_t*)x_out; P.q = (bf16_t*)q_out; P.kv = (bf16_t*)kv_out;
   P.wpack = (const char*)wpack; P.vec = vec; P.ntok = B * S * H * W; P.eps = eps;

@@ -162,7 +162,7 @@ __device__ __forceinline__ void ws_init(WStream& ws, char* smem, const char* wpa
   ws.ts = nullptr;
 }
 
-template <int D, int I, bool RES>
+template <int D, int I, bool RES, bool XIN>
 __global__ __launch_bounds__(NTHR, 8 / FW) void qkv_bwd_kernel(BwdParams P) {
   static_assert(D == 256 && I == 128, "built for the default denoiser widths");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void qkv_bwd_kernel(BwdParams P) {
   asm volatile("" : "+v"(mean), "+v"(rstd));                           // (older than xb: landed)
   Frag8<bf16_t> dqb[I / 16];
   int m_q = 0;
-  ln_bwd_inplace<false>(acc, xb, mean, rstd, stg, P.xhat, tok0, P.ntok, lane, ws, [&]() {
+  ln_bwd_inplace<XIN>(acc, xb, mean, rstd, stg, P.xhat, tok0, P.ntok, lane, ws, [&]() {
     load_row<I / 16>(dqb, P.dq + tokc * P.lddq + h * 64, ws);          // in flight under the second half of the LayerNorm pass
     m_q = ws.all;
   });
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void ln_affine_grads_kernel(const float* __res
 extern "C" int wmz_qkv_fused_bwd(const void* dq, long lddq, const void* dkv, long lddkv, const void* x, const float* ln_stats,
                                  const void* res, void* dx, void* xhat_out, const void* wpack, int ntok, int D, int I,
                                  void* stream) {
-  WMZ_REQUIRE(dq && dkv && x && ln_stats && dx && xhat_out && wpack && ntok > 0, "wmz_qkv_fused_bwd: null tensor");
+  WMZ_REQUIRE(dq && dkv && x && ln_stats && dx && wpack && ntok > 0, "wmz_qkv_fused_bwd: null tensor");
   if (!(D == 256 && I == 128)) {
     wmz_set_error("wmz_qkv_fused_bwd: built for dim 256 / inner 128 (got %d/%d); use the per-op backward", D, I);
     return WMZ_ERR_UNSUPPORTED;
@@ -405,15 +405,16 @@ extern "C" int wmz_qkv_fused_bwd(const void* dq, long lddq, const void* dkv, lon
   P.x = (const bf16_t*)x; P.st = ln_stats; P.res = (const bf16_t*)res; P.dx = (bf16_t*)dx; P.xhat = (bf16_t*)xhat_out;
   const size_t smem = RING * SLAB + FW * 8192;
   const dim3 grid((unsigned)wmz_cdiv(ntok, TW * FW)), block(NTHR);
-  if (res != nullptr) {
-    auto kern = qkv_bwd_kernel<256, 128, true>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);
-  } else {
-    auto kern = qkv_bwd_kernel<256, 128, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);
-  }
+#define WMZ_QKV_BWD(RES_, XIN_)                                                                                            \
+  do {                                                                                                                     \
+    auto kern = qkv_bwd_kernel<256, 128, RES_, XIN_>;                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)stream, P);                                                   \
+  } while (0)
+  const bool xin = xhat_out == nullptr;       // x already holds the normalised rows (WMZ_FUSED_XRM_NORMALISED forward)
+  if (res != nullptr) { if (xin) WMZ_QKV_BWD(true, true); else WMZ_QKV_BWD(true, false); }
+  else { if (xin) WMZ_QKV_BWD(false, true); else WMZ_QKV_BWD(false, false); }
+#undef WMZ_QKV_BWD
   WMZ_LAUNCH_CHECK("wmz_qkv_fused_bwd");
   return WMZ_OK;
 }

@@ -50,6 +50,7 @@ struct WgParams {
   int M, N, K;
   const float* gamma; const float* beta; const float* mean; const float* rstd;
   int gelu_in;
+  int a_tiled;      // A is the fused path's TILED stream (bf16, K = 256): per 32-row tile [16 chunks][2 halves][32 rows][8]
   int nbn, nbk, rows_per_wg, nsplit;
   // PRO == 3: A is the implicit im2col of an NHWC tensor x[B,Hi,Wi,Cin] (row m = output pixel, k = (kh, kw, ci))
   int Hi, Wi, Cin, Ho, Wo, KW, cstride, cpad;
@@ -260,7 +261,12 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restr
       if (m < m_end) {
         if (n0 + c * EPC < P.N) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * EPC);
         if (k0 + c * EPC < P.K) {
-          ra[it] = *reinterpret_cast<const i32x4*>(A + (long)m * P.lda + k0 + c * EPC);
+          // (tiled: 16-byte chunk cg = 16 h + s of row m sits at ((2 s + h) * 32 + m % 32) * 16 bytes of its 32-row tile:
+          //  a slab's rows of one chunk column are one contiguous 512-byte run)
+          const int cg = (k0 >> 3) + c;
+          const long aoff = P.a_tiled ? (long)(m >> 5) * (32 * 256) + ((((2 * (cg & 15) + (cg >> 4)) << 5) + (m & 31)) << 3)
+                                      : (long)m * P.lda + k0 + c * EPC;
+          ra[it] = *reinterpret_cast<const i32x4*>(A + aoff);
           if constexpr (PRO == 1) { lmu[S][it] = P.mean[m]; lrs[S][it] = P.rstd[m]; }
         }
       }
@@ -669,8 +675,9 @@ namespace {
 // fills problem i of a batch; returns the workspace floats it needs
 long wg_batch_add(WgBatch& B, RedBatch& R, int i, const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias,
                   int M, int N, int K, const float* g, const float* b, const float* mean, const float* rstd, int gelu_in,
-                  int overwrite, int dtype, long wsoff) {
+                  int overwrite, int dtype, long wsoff, int a_tiled = 0) {
   WgParams& P = B.p[i];
+  P.a_tiled = a_tiled;
   P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
   P.gamma = g; P.beta = b; P.mean = mean; P.rstd = rstd; P.gelu_in = gelu_in;
   P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
@@ -723,7 +730,8 @@ extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long
 
 extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
                                       float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
-                                      const int* overwrite, float* workspace, long workspace_floats, int dtype, void* stream) {
+                                      const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats,
+                                      int dtype, void* stream) {
   WMZ_REQUIRE(n >= 1 && n <= WG_MAXB, "wmz_linear_wgrad_batch: 1 .. %d problems per call (got %d)", WG_MAXB, n);
   WMZ_REQUIRE(dC && ldc && A && lda && dW && dbias && M && N && K && overwrite && workspace, "wmz_linear_wgrad_batch: null table");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_wgrad_batch: bad dtype %d", dtype);
@@ -737,8 +745,11 @@ extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* 
   for (int i = 0; i < n; ++i) {
     WMZ_REQUIRE(dC[i] && A[i] && dW[i] && M[i] > 0 && N[i] > 0 && K[i] > 0, "wmz_linear_wgrad_batch: bad problem %d", i);
     WMZ_REQUIRE(N[i] % 8 == 0 && K[i] % 8 == 0 && ldc[i] % 8 == 0 && lda[i] % 8 == 0, "wmz_linear_wgrad_batch: problem %d: N, K and row strides must be multiples of 8", i);
+    const int tiled = a_tiled != nullptr && a_tiled[i] != 0;
+    WMZ_REQUIRE(!tiled || (dtype == WMZ_BF16 && K[i] == 256 && M[i] % 32 == 0),
+                "wmz_linear_wgrad_batch: problem %d: a tiled A is bf16, 256 wide, whole 32-row tiles", i);
     off += wg_batch_add(B, R, i, dC[i], ldc[i], A[i], lda[i], dW[i], dbias[i], M[i], N[i], K[i], nullptr, nullptr, nullptr,
-                        nullptr, 0, overwrite[i], dtype, off);
+                        nullptr, 0, overwrite[i], dtype, off, tiled);
   }
   WMZ_REQUIRE(workspace_floats >= off, "wmz_linear_wgrad_batch: workspace too small (%ld floats needed)", off);
   wg_batch_launch(B, R, 0, workspace, dtype, (hipStream_t)stream);

@@ -186,7 +186,7 @@ class PackSet:
             _cast._cache[_cast._key(params, None, tag)] = (ver, val, tuple(weakref.ref(p) for p in params))
 
 
-X_IN_TILED, X_OUT_TILED, X1_NORMALISED = 1, 2, 4      # include/wmz.h WMZ_FUSED_X_*_TILED, WMZ_FUSED_X1_NORMALISED
+X_IN_TILED, X_OUT_TILED, X1_NORMALISED, XRM_NORMALISED = 1, 2, 4, 8      # include/wmz.h WMZ_FUSED_X*
 
 
 def layer_fused(o, x, head, tail, eps=1e-5, xflags=0):
@@ -284,7 +284,9 @@ def transformer_forward_last(tr, z):
 # training forward on the fused kernels (wmz_*_train): one attention launch + one per-token launch per layer, and the
 # tensors the op-by-op backward (backward.py) reads are written row-major on the way
 
-def _embed_train(tr, z, tiled):
+def _embed_train(tr, z, tiled, xhat_rm=False):
+    """xhat_rm (tiled only): the row-major output holds the NORMALISED rows (what the fused backward reads); the raw stream
+    lives in the tiled output."""
     B, S, H, W = z.shape
     dev, bf = z.device, torch.bfloat16
     wpack, vec = _layer_pack(None, tr.layers[0])
@@ -296,11 +298,12 @@ def _embed_train(tr, z, tiled):
     L.call('wmz_embed_qkv_fused_fwd_train', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
            L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
            L.ptr(x_t if tiled else x_rm), L.ptr(x_rm if tiled else None), L.ptr(q), L.ptr(kv), L.ptr(st_attn), L.ptr(wpack),
-           L.ptr(vec), B, S, H, W, D_, I_, M_, tr.embedding.num_embeddings, X_OUT_TILED if tiled else 0, 1e-5, L.stream())
+           L.ptr(vec), B, S, H, W, D_, I_, M_, tr.embedding.num_embeddings,
+           (X_OUT_TILED if tiled else 0) | (XRM_NORMALISED if (tiled and xhat_rm) else 0), 1e-5, L.stream())
     return (x_t if tiled else x_rm), x_rm, q, kv, st_attn
 
 
-def _layer_train(o, x_in, head, tail, tiled, save_z):
+def _layer_train(o, x_in, head, tail, tiled, save_z, xhat_rm=False):
     """x_in: the stream in the layout the previous launch left it in (tiled if `tiled`).  Returns (x_next, x_rm, x1, q, kv,
     st_ff, st_attn, zt): x_next in that same layout for the next launch (None after the last layer), x_rm / x1 row-major for
     the backward, st_* the [2, ntok] LayerNorm statistics (feed-forward's norm; the next layer's attention norm or None), zt
@@ -318,6 +321,8 @@ def _layer_train(o, x_in, head, tail, tiled, save_z):
     # the fused backward (save_z) needs x1 only as its NORMALISED rows (LayerNorm backward, dW1 operand): the kernel has them in
     # registers as the W1 operand and stores those instead of x1
     xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if out_tiled else 0) | (X1_NORMALISED if save_z else 0)
+    if xhat_rm and out_tiled:          # x_rm = the next layer's NORMALISED input rows; its raw input is x_t
+        xflags |= XRM_NORMALISED
     st_ff = torch.empty((2, ntok), dtype=torch.float32, device=dev)
     st_attn = torch.empty((2, ntok), dtype=torch.float32, device=dev) if tail is not None else None
     zt = torch.empty((ntok, M_), dtype=bf, device=dev) if save_z else None
@@ -367,11 +372,12 @@ def _zero_row(dev):
     return z
 
 
-def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt, dy_last=None):
+def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt, dy_last=None, x_in_tiled=None):
     """One layer of the stack's backward on the fused per-token kernels: wmz_ff_fused_bwd -> attention backward ->
     wmz_qkv_fused_bwd, the weight gradients as plain GEMMs over the operands those kernels write, the LayerNorm affine
     gradients from the raw weight gradients (wmz_ln_affine_grads).  x1: the NORMALISED rows of the feed-forward block's input, as
-    the forward stored them (WMZ_FUSED_X1_NORMALISED).  dy_last = (S, HW): dy holds only the clips' last planes
+    the forward stored them (WMZ_FUSED_X1_NORMALISED).  x_in_tiled given: x_in holds the layer input's NORMALISED rows too
+    (WMZ_FUSED_XRM_NORMALISED) and x_in_tiled the raw stream in the tiled layout.  dy_last = (S, HW): dy holds only the clips' last planes
     ([B, H, W, D], the last layer under the denoiser's last-frame loss).  Returns (gradient w.r.t. the layer's input, the 14
     parameter gradients in _layer_params order)."""
     an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
@@ -398,9 +404,16 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
     dq, dkv = ops.local3d_attention_bwd(q, kv[..., :I_], kv[..., I_:], o, lse, do, attn.fn.extents, attn.fn.heads)
     # ---- to_q / to_k / to_v inputs
     dx = torch.empty(lead + (D_,), dtype=bf, device=dev)
-    xhat = torch.empty((ntok, D_), dtype=bf, device=dev)
+    if x_in_tiled is None:
+        xhat = torch.empty((ntok, D_), dtype=bf, device=dev)
+        x_q, x_q_tiled = x_in.reshape(ntok, D_), False
+    else:
+        xhat = None
+        x_q, x_q_tiled = x_in_tiled, True
     L.call('wmz_qkv_fused_bwd', L.ptr(dq), I_, L.ptr(dkv), 2 * I_, L.ptr(x_in), L.ptr(st_attn), L.ptr(dx1), L.ptr(dx),
            L.ptr(xhat), L.ptr(wpack_qkv), ntok, D_, I_, L.stream())
+    if xhat is None:
+        xhat = x_in.reshape(ntok, D_)
     # ---- the layer's five weight gradients: plain GEMMs over the token axis, ONE launch pair.  Those behind a LayerNorm
     # are taken against the NORMALISED input (raw gradients G, column sums c) and turned into parameter gradients below.
     s_ff2, s_out, s_q = _GradSink(w2, b2), _GradSink(wout, bout), _GradSink(wq)
@@ -412,7 +425,7 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
         (dy2, g2, s_ff2.bufs[0], s_ff2.bufs[1], False),                       # dW2 = dy^T GELU(z), db2 = colsum(dy)
         (dz, x1.reshape(ntok, D_), G1, c1, True),            # x1 = the NORMALISED rows the forward stored
         (dx1, o.reshape(ntok, I_), s_out.bufs[0], s_out.bufs[1], False),
-        (dq.reshape(ntok, I_), x_in.reshape(ntok, D_), s_q.bufs[0], None, False),
+        (dq.reshape(ntok, I_), x_q, s_q.bufs[0], None, False, x_q_tiled),
         (dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv, True)])
     s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
     L.call('wmz_ln_affine_grads', L.ptr(G1), L.ptr(c1), L.ptr(w1.detach()), L.ptr(fn_g.detach()), L.ptr(fn_b.detach()),
@@ -458,15 +471,19 @@ class _TrainForward(torch.autograd.Function):
         # the fused backward kernels (layer_fused_bwd.hip) work on whole 32-token tiles and read the pre-activation the
         # forward leaves behind; otherwise the op-by-op backward recomputes it
         fused_bwd = config.fused_backward() and (B * S * H * W) % 32 == 0
-        x_cur, x_rm, q, kv, st_attn = _embed_train(tr, z, tiled)
+        # fused backward on a tiled stream: a layer's row-major input copy holds the NORMALISED rows (all the backward needs
+        # of them: LayerNorm backward, to_k | to_v weight gradient); the raw rows -- the to_q weight gradient's operand -- are
+        # read from the tiled stream the forward kernels hand each other
+        xhat_rm = fused_bwd and tiled
+        x_cur, x_rm, q, kv, st_attn = _embed_train(tr, z, tiled, xhat_rm)
         saved = []
         for l, (attn, ff) in enumerate(layers):
             o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I_], kv[..., I_:], attn.fn.extents, attn.fn.heads, need_lse=True)
-            x_in_rm = x_rm
+            x_in_rm, x_in_t = x_rm, (x_cur if xhat_rm else lse.new_empty(0))
             x_cur, x_rm, x1, q_n, kv_n, st_ff, st_attn_n, zt = _layer_train(o, x_cur, (attn, ff),
                                                                            layers[l + 1] if l + 1 < len(layers) else None,
-                                                                           tiled, fused_bwd)
-            saved += [x_in_rm, q, kv, o, lse, x1, st_attn, st_ff, zt if zt is not None else lse.new_empty(0)]
+                                                                           tiled, fused_bwd, xhat_rm)
+            saved += [x_in_rm, q, kv, o, lse, x1, st_attn, st_ff, zt if zt is not None else lse.new_empty(0), x_in_t]
             q, kv, st_attn = q_n, kv_n, st_attn_n
         ctx.tr = tr
         ctx.fused_bwd = fused_bwd
@@ -484,7 +501,7 @@ class _TrainForward(torch.autograd.Function):
         z, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         grads = [None] * (14 * len(layers))
         dy = dy.contiguous()
-        NS = 9
+        NS = 10
         dy_last = None
         if ctx.last_only:
             B, S, H, W = z.shape
@@ -496,11 +513,11 @@ class _TrainForward(torch.autograd.Function):
                 dy = full
         for l in range(len(layers) - 1, -1, -1):
             attn, ff = layers[l]
-            x_in, q, kv, o, lse, x1, st_attn, st_ff, zt = saved[NS * l:NS * l + NS]
+            x_in, q, kv, o, lse, x1, st_attn, st_ff, zt, x_in_t = saved[NS * l:NS * l + NS]
             an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
             if ctx.fused_bwd:
                 dy, g = _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt,
-                                              dy_last if l == len(layers) - 1 else None)
+                                              dy_last if l == len(layers) - 1 else None, x_in_t if x_in_t.numel() else None)
                 grads[14 * l:14 * l + 14] = g
                 continue
             dt = x1.dtype

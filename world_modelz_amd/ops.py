@@ -223,25 +223,32 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
 
 def linear_wgrad_batch(problems):
     """Up to 6 plain weight gradients by one launch pair (wmz_linear_wgrad_batch).  problems: (dc, a, dw, dbias | None,
-    overwrite) tuples with the meaning of linear_wgrad's arguments."""
+    overwrite[, a_tiled]) tuples with the meaning of linear_wgrad's arguments; a_tiled: `a` is the fused path's tiled stream
+    ([M, 256] bf16 in 32-row tiles) instead of row-major."""
     import ctypes
     n = len(problems)
     dt = L.dtype_code(problems[0][0].dtype)
     vp, ci, cl = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_long * n
-    pc, pa, pw, pb, lc, la, Ms, Ns, Ks, ov = vp(), vp(), vp(), vp(), cl(), cl(), ci(), ci(), ci(), ci()
+    pc, pa, pw, pb, lc, la, Ms, Ns, Ks, ov, tl = vp(), vp(), vp(), vp(), cl(), cl(), ci(), ci(), ci(), ci(), ci()
     keep, need = [], 0
-    for i, (dc, a, dw, dbias, overwrite) in enumerate(problems):
+    for i, prob in enumerate(problems):
+        dc, a, dw, dbias, overwrite = prob[:5]
+        tiled = len(prob) > 5 and bool(prob[5])
         dc, M, ldc = _rows(dc)
-        a, Ma, lda = _rows(a)
+        if tiled:
+            assert a.is_contiguous() and a.numel() == M * 256 and a.dtype == torch.bfloat16
+            Ma, lda = M, 256
+        else:
+            a, Ma, lda = _rows(a)
         assert Ma == M and a.dtype == dc.dtype and L.dtype_code(dc.dtype) == dt
         assert dw.dtype == torch.float32 and dw.is_contiguous()
         N, K = dw.shape
         keep.append((dc, a))
         pc[i], pa[i], pw[i], pb[i] = L.ptr(dc), L.ptr(a), L.ptr(dw), L.ptr(dbias)
-        lc[i], la[i], Ms[i], Ns[i], Ks[i], ov[i] = ldc, lda, M, N, K, 1 if overwrite else 0
+        lc[i], la[i], Ms[i], Ns[i], Ks[i], ov[i], tl[i] = ldc, lda, M, N, K, 1 if overwrite else 0, 1 if tiled else 0
         need += L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
     ws = _workspace(problems[0][0].device, need)
-    L.call('wmz_linear_wgrad_batch', n, pc, lc, pa, la, pw, pb, Ms, Ns, Ks, ov, L.ptr(ws), ws.numel(), dt, L.stream())
+    L.call('wmz_linear_wgrad_batch', n, pc, lc, pa, la, pw, pb, Ms, Ns, Ks, ov, tl, L.ptr(ws), ws.numel(), dt, L.stream())
 
 
 def layernorm_stats(x, eps=1e-5):
