@@ -20,6 +20,9 @@
 //   * the per-element arithmetic folds the constants: exponent = fma(s, c2, bias - lse2), dS = P * fma(dP, scale, -delta *
 //     scale) (MODE 0: both addends live in registers for the whole kernel).
 #include "attn_common.h"
+#ifndef WMZ_ABWD_ABL
+#define WMZ_ABWD_ABL 0      // timing ablations (tools/build_variant.py; results are garbage): 1 no compute, 2 no slab DMA
+#endif
 
 namespace {
 
@@ -229,10 +232,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
     const bool more = j + 1 < nslab;
     if (more) {
       if constexpr (MODE == 1) fetch_rows();
-      issue();
+      if (!(WMZ_ABWD_ABL & 2)) issue();
     }
     const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
-    if (active) {
+    if (active && !(WMZ_ABWD_ABL & 1)) {
       int t0 = lo;
       for (; t0 + 1 <= hi; t0 += 2) {
         // ---- two visiting rows: S^T and dP^T, then P, dS, then the accumulations

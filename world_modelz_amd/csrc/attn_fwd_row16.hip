@@ -44,9 +44,19 @@ __device__ __forceinline__ void mma16_abl(f32x4& acc, const A& a, const B& b) {
 // development probes (the only process-wide state of the library, see include/wmz.h): stamp buffer and A/B knobs
 long long* g_attn_ts = nullptr;     // 16 waves x 64 int64, wmz_debug_attn_timestamps
 
-constexpr int KC = 8;                 // key rows per slab
+#ifndef WMZ_ATTN_KC
+#define WMZ_ATTN_KC 8
+#endif
+// key rows per slab.  8 (product): two 74 KB slabs, one in flight.  4 (-DWMZ_ATTN_KC=4, tools/build_variant.py): four 37 KB
+// slabs, three in flight behind counted vmcnt waits -- measured SLOWER, 43.5 vs 37.3 us per launch on the same box: the
+// per-slab cost is the 16-wave rendezvous and the loop around it, not the latency of the slab's DMA.
+constexpr int KC = WMZ_ATTN_KC;
+constexpr int LOG_RS = KC == 8 ? 1 : 2;
+constexpr int RS = 1 << LOG_RS;       // a slab holds plane rows base, base + RS, ..: RS slabs ("phases") per 16-row chunk
+static_assert(KC * RS == 16, "a slab is one phase of a 16-row chunk");
 constexpr int NW = 16;                // waves per workgroup = query rows per workgroup
-constexpr int NBUF = 2;               // LDS slab ring: one slab in flight
+constexpr int NBUF = KC == 8 ? 2 : 4; // LDS slab ring
+constexpr int AHEAD = NBUF - 1;       // slabs in flight
 constexpr float DEFER = 8.f;          // log2 units
 
 template <int DH> struct Img {
@@ -88,8 +98,18 @@ __device__ __forceinline__ unsigned piece_voff(int piece, int lane, unsigned ld_
   const int r = off / ROWP;
   int c = (off - r * ROWP) >> 4;
   c = c < DH / 8 ? c : 0;
-  const int prow = min(2 * (r >> 4), row_lim);
+  const int prow = min(RS * (r >> 4), row_lim);
   return (unsigned)((prow << 4) + (r & 15)) * ld_bytes + (unsigned)c * 16u;
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n <= 12
+__device__ __forceinline__ void attn_vm_wait(int n) {
+#define WMZ_AVW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    WMZ_AVW(1) WMZ_AVW(2) WMZ_AVW(3) WMZ_AVW(4) WMZ_AVW(5) WMZ_AVW(6) WMZ_AVW(7) WMZ_AVW(8) WMZ_AVW(9) WMZ_AVW(10) WMZ_AVW(11) WMZ_AVW(12)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef WMZ_AVW
 }
 
 template <int DH, int MODE, bool ALIGNED, bool PROBE, bool TS>
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   const int t_lo = max(h0 - G.eH, 0), t_hi = min(min(h0 + NW - 1, H - 1) + G.eH, H - 1);
   const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
   const int c_first = t_lo >> 4, c_last = t_hi >> 4;
-  const int nch = (c_last - c_first + 1) * 2;               // slabs per key plane: (16-row chunk) x (row parity)
+  const int nch = (c_last - c_first + 1) * RS;              // slabs per key plane: (16-row chunk) x (row phase)
   const int nslab = (WMZ_ATTN_ABL & 32) ? 0 : (WMZ_ATTN_ABL & 64) ? nch : (sk_hi - sk_lo + 1) * nch;   // ablations: no slab loop / one key plane
 
   // ---- LDS-DMA descriptors: this wave's pieces are wave + 16 i; per-lane source offsets for planes of whole 16-row chunks
@@ -153,9 +173,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   unsigned kvo[I::NPK], vvo[I::NPV];
   if constexpr (ALIGNED) {
 #pragma unroll
-    for (int i = 0; i < I::NPK; ++i) kvo[i] = piece_voff<DH, I::KROW>(wave + NW * i, lane, ldk_b, 14);
+    for (int i = 0; i < I::NPK; ++i) kvo[i] = piece_voff<DH, I::KROW>(wave + NW * i, lane, ldk_b, 16 - RS);
 #pragma unroll
-    for (int i = 0; i < I::NPV; ++i) vvo[i] = piece_voff<DH, I::VROW>(wave + NW * i, lane, ldv_b, 14);
+    for (int i = 0; i < I::NPV; ++i) vvo[i] = piece_voff<DH, I::VROW>(wave + NW * i, lane, ldv_b, 16 - RS);
   }
 
   // Scalar state of the slab being prefetched.  It is advanced INCREMENTALLY (adds, one 32-bit multiply) and at the END of
@@ -182,10 +202,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   char* dbuf = nullptr;
   int dlim = 14;
   auto next_state = [&]() {                                              // descriptors of slab (pl_n, rem_n)
-    base_n = ((c_first + (rem_n >> 1)) << 4) + (rem_n & 1);
+    base_n = ((c_first + (rem_n >> LOG_RS)) << 4) + (rem_n & (RS - 1));
     kp = kpl + (unsigned)base_n * rsk;
     vp = vpl + (unsigned)base_n * rsv;
-    dbuf = smem + (jn & 1) * I::BUF;
+    dbuf = smem + (jn & (NBUF - 1)) * I::BUF;
     dlim = max(H - 1 - base_n, 0);
   };
   auto advance = [&]() {                                                 // step (pl_n, rem_n) to the following slab
@@ -245,28 +265,49 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
   };
 
   WMZ_ATS(1);
-  next_state();
-  if (nslab > 0 && staging) {
-    issue_k(C0{}); issue_k(C1{}); issue_k(C2{});
-    issue_v(C0{}); issue_v(C1{}); issue_v(C2{});
-  }
-  {
-    // Q after the first slab's requests: both are in flight together (rows past the plane load a valid row, never stored)
-    const bf16_t* qrow = Q + (plane_q + (act ? hq : 0) * 16 + li) * G.ldq + (long)head * DH;
+  // LDS-DMA pieces this wave issues per slab (wave-uniform): the counted wait below lets the younger slabs' pieces fly
+  int npc = 0;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) frag_load(qf[ks], qrow + ks * 32 + g * 8);
-  }
+  for (int i = 0; i < I::NPK; ++i) npc += (!(WMZ_ATTN_ABL & 16) && wave + NW * i < I::PK) ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < I::NPV; ++i) npc += (!(WMZ_ATTN_ABL & 8) && wave + NW * i < I::PV) ? 1 : 0;
+  // the first AHEAD slabs are requested up front; bq / pq: first plane row and key plane of the slabs in flight, oldest first
+  int bq[AHEAD], pq[AHEAD];
+  static_for<AHEAD>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    bq[i] = 0; pq[i] = 0;
+    if (i < nslab) {
+      next_state();
+      if (staging) {
+        issue_k(C0{}); issue_k(C1{}); issue_k(C2{});
+        issue_v(C0{}); issue_v(C1{}); issue_v(C2{});
+      }
+      bq[i] = base_n; pq[i] = pl_n;
+      advance();
+    }
+    if constexpr (i == 0) {
+      // Q right behind the first slab's requests (rows past the plane load a valid row, never stored)
+      const bf16_t* qrow = Q + (plane_q + (act ? hq : 0) * 16 + li) * G.ldq + (long)head * DH;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) frag_load(qf[ks], qrow + ks * 32 + g * 8);
+    }
+  });
+  next_state();                                          // descriptors of slab AHEAD
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks].v));   // Q is waited for HERE, once (the compiler's wait is vmcnt(0): inside
+                                                                       // the loop it would drain the slabs in flight at every iteration)
   WMZ_ATS(2);
-  int pl = pl_n, base = base_n;                            // current slab: key plane, plane row of slab row 0 (slab row r <-> base + 2r)
-  advance();
-  next_state();                                          // slab 1's descriptors
   for (int j = 0; j < nslab; ++j) {
-    const char* Sb = smem + (j & 1) * I::BUF;              // this slab's K image, V image behind it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of slab j landed ...
-    if (j < 15) WMZ_ATS(3 + 4 * j);
+    const char* Sb = smem + (j & (NBUF - 1)) * I::BUF;     // this slab's K image, V image behind it
+    const int pl = pq[0], base = bq[0];                    // current slab: key plane, plane row of slab row 0 (slab row r <-> base + RS r)
+    // this wave's pieces of slab j landed: everything but the pieces of the (up to AHEAD - 1) younger slabs.  (The probe / stamp
+    // instantiations store to global memory inside the loop, which the count does not know about: they drain the queue.)
+    if constexpr (PROBE || TS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else attn_vm_wait(min(AHEAD - 1, nslab - 1 - j) * npc);
+    if (j < 14) WMZ_ATS(3 + 4 * j);
     __builtin_amdgcn_s_barrier();                        // ... everyone's did, and slab j-1 is retired: refill its slot
-    if (j < 15) WMZ_ATS(4 + 4 * j);
-    const bool more = j + 1 < nslab && staging;
+    if (j < 14) WMZ_ATS(4 + 4 * j);
+    const bool more = j + AHEAD < nslab && staging;
     bool pend[6] = {more, more, more, more, more, more};                 // K0 K1 K2 V0 V1 V2 of slab j + 1 not requested yet
     auto issue_at = [&](auto pc, bool flush) {
       constexpr int pt = decltype(pc)::value;
@@ -279,8 +320,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
       });
     };
     issue_at(C0{}, false);
-    if (j < 15) WMZ_ATS(5 + 4 * j);
-    const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
+    if (j < 14) WMZ_ATS(5 + 4 * j);
+    const int lo = max(0, (my_lo - base + RS - 1) >> LOG_RS), hi = min(KC - 1, (my_hi - base) >> LOG_RS);   // slab rows this wave needs
     if (act && !(G.dbg & 1)) {
       int t0 = lo;
       for (; t0 + 1 <= hi; t0 += 2) {
@@ -321,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
             const int dw = 4 * g + r - li;
             if (dw <= G.eW && -dw <= G.eW) {
               const int ds = (sk_lo + pl) - s;
-              const int dh0 = base + 2 * t0 - hq, dh1 = dh0 + 2;
+              const int dh0 = base + RS * t0 - hq, dh1 = dh0 + RS;
               float* row = DBG + (qn * G.heads + head) * nk;
               row[((ds + G.eS) * kh + (dh0 + G.eH)) * kw + dw + G.eW] = sc0[r] * G.scale;
               row[((ds + G.eS) * kh + (dh1 + G.eH)) * kw + dw + G.eW] = sc1[r] * G.scale;
@@ -384,7 +425,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
             const int dw = 4 * g + r - li;
             if (dw <= G.eW && -dw <= G.eW) {
               const int ds = (sk_lo + pl) - s;
-              const int dh0 = base + 2 * t0 - hq;
+              const int dh0 = base + RS * t0 - hq;
               DBG[(qn * G.heads + head) * nk + ((ds + G.eS) * kh + (dh0 + G.eH)) * kw + dw + G.eW] = sc0[r] * G.scale;
             }
           }
@@ -409,14 +450,15 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t
         }
       }
     }
-    // whatever of slab j + 1 has not been requested yet
+    // whatever of slab j + AHEAD has not been requested yet
     issue_at(C3{}, true);
-    // the slab just requested becomes the current one; its successor's descriptors are worked out here, ahead of the barrier
-    pl = pl_n;
-    base = base_n;
+    // the slab just requested joins the queue; its successor's descriptors are worked out here, ahead of the barrier
+#pragma unroll
+    for (int i = 0; i + 1 < AHEAD; ++i) { bq[i] = bq[i + 1]; pq[i] = pq[i + 1]; }
+    bq[AHEAD - 1] = base_n; pq[AHEAD - 1] = pl_n;
     advance();
     next_state();
-    if (j < 15) WMZ_ATS(6 + 4 * j);
+    if (j < 14) WMZ_ATS(6 + 4 * j);
   }
   WMZ_ATS(63);
 
