@@ -132,23 +132,64 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
    }
   }
 
-  // this thread's 4 chunks of each slab: rows r_i = (tid>>3) + 32 i, chunk column cc = tid & 7
+  // this thread's 4 chunks of each slab: rows r_i = (tid>>3) + 32 i, chunk column cc = tid & 7.
+  // TWO register sets: the loads of slabs s + 1 and s + 2 are in flight while slab s is multiplied.  With few workgroups per CU
+  // (M = 3 072 rows at config 5: one) the K loop is a chain of memory round trips -- one slab ahead it ran at ~2 us per 64-wide
+  // slab, 32 us for a 3 072 x 1 024 x 512 GEMM.  The loads are UNCONDITIONAL (rows, weight rows and the chunk column clamped
+  // into the matrices): a branch around a load makes the compiler's wait-count pass fall back to vmcnt(0), which drains both
+  // sets.  Clamped rows only feed output rows / columns that are never stored; a chunk past K is zeroed in the WEIGHT slab
+  // when it is written to LDS (finite x 0).
   const int cc = tid & 7, rr = tid >> 3;
-  i32x4 ra[AI], rb[4];
+  i32x4 ras[2][AI], rbs[2][4];
   const T* arow[AI];
+  const T* brow[4];
 #pragma unroll
   for (int i = 0; i < AI; ++i) arow[i] = a_row<T>(P, min(m0 + rr + 32 * i, P.M - 1));
-  auto fetch = [&](int k0) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) brow[i] = Wt + (long)min(n0 + rr + 32 * i, P.N - 1) * K;
+  f32x4 lng[2][LN ? EPC / 4 : 1], lnb[2][LN ? EPC / 4 : 1];      // LN: the slab's gamma / beta of this thread's chunk column ride with it
+  auto fetch = [&](auto setc, int k0) {
+    constexpr int S = decltype(setc)::value;
+    const int k = min(k0 + cc * EPC, K - EPC);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < AI) ras[S][i < AI ? i : 0] = *reinterpret_cast<const i32x4*>(arow[i < AI ? i : 0] + k);
+      rbs[S][i] = *reinterpret_cast<const i32x4*>(brow[i] + k);
+    }
+    if constexpr (LN) {
+#pragma unroll
+      for (int q = 0; q < EPC / 4; ++q) {
+        lng[S][q] = *reinterpret_cast<const f32x4*>(P.gamma + k + 4 * q);
+        lnb[S][q] = *reinterpret_cast<const f32x4*>(P.beta + k + 4 * q);
+      }
+    }
+  };
+  auto stash = [&](auto setc, int k0) {
+    constexpr int S = decltype(setc)::value;
     const int k = k0 + cc * EPC;
+    const bool kok = k < K;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rr + 32 * i;
-      if (i < AI) ra[i < AI ? i : 0] = (i32x4)(0);
-      rb[i] = (i32x4)(0);
-      if (k < K) {
-        if (i < AI && m0 + r < P.M) ra[i < AI ? i : 0] = *reinterpret_cast<const i32x4*>(arow[i < AI ? i : 0] + k);
-        if (n0 + r < P.N) rb[i] = *reinterpret_cast<const i32x4*>(Wt + (long)(n0 + r) * K + k);
+      const int off = r * ROWB + ((cc << 4) ^ swz128(r));
+      *reinterpret_cast<i32x4*>(Bs + off) = kok ? rbs[S][i] : (i32x4)(0);
+      if (i >= AI) continue;
+      i32x4 va = ras[S][i < AI ? i : 0];
+      if constexpr (LN) {
+        float f[EPC];
+        chunk_to_f32<T>(va, f);
+        const float mu = mean_s[r], rs = rstd_s[r];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * lng[S][e >> 2][e & 3] + lnb[S][e >> 2][e & 3];
+        va = f32_to_chunk<T>(f);
+      } else if constexpr (PRO == 2) {
+        float f[EPC];
+        chunk_to_f32<T>(va, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
+        va = f32_to_chunk<T>(f);
       }
+      *reinterpret_cast<i32x4*>(As + off) = va;
     }
   };
 
@@ -161,73 +202,61 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   const int wr = BM == 128 ? (wave >> 1) * 64 : 0, wc = BM == 128 ? (wave & 1) * 64 : wave * 32;
   const int l31 = lane & 31, hh = lane >> 5;
 
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
-    const int k = k0 + cc * EPC;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = rr + 32 * i;
-      const int off = r * ROWB + ((cc << 4) ^ swz128(r));
-      *reinterpret_cast<i32x4*>(Bs + off) = rb[i];
-      if (i >= AI) continue;
-      i32x4 va = ra[i < AI ? i : 0];
-      if constexpr (LN) {
-        if (k < K) {
-          float f[EPC];
-          chunk_to_f32<T>(va, f);
-          const float mu = mean_s[r], rs = rstd_s[r];
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * P.gamma[k + e] + P.beta[k + e];
-          va = f32_to_chunk<T>(f);
-        }
-      } else if constexpr (PRO == 2) {
-        float f[EPC];
-        chunk_to_f32<T>(va, f);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) f[e] = gelu_erf(f[e]);
-        va = f32_to_chunk<T>(f);
-      }
-      *reinterpret_cast<i32x4*>(As + off) = va;
-    }
-    __syncthreads();
-    if (k0 + BK < K) fetch(k0 + BK);
+  auto compute = [&]() {
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
-      Frag8<T> af[2], bf[NJ];
+        Frag8<T> af[2], bf[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = wr + 32 * i + l31;
-        const char* row = As + r * ROWB;
-        const int sw = swz128(r);
-        const int b0 = (kk * 16 + hh * 8) * (int)sizeof(T);
-        if constexpr (sizeof(T) == 2) {
-          af[i].v = *reinterpret_cast<const s16x8*>(row + (b0 ^ sw));
-        } else {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(row + (b0 ^ sw));
-          const f32x4 y = *reinterpret_cast<const f32x4*>(row + ((b0 + 16) ^ sw));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { af[i].v[e] = x[e]; af[i].v[4 + e] = y[e]; }
-        }
-        if (i < NJ) {
-          const int rn = wc + 32 * i + l31;
-          const char* rowb = Bs + rn * ROWB;
-          const int swb = swz128(rn);
+        for (int i = 0; i < 2; ++i) {
+          const int r = wr + 32 * i + l31;
+          const char* row = As + r * ROWB;
+          const int sw = swz128(r);
+          const int b0 = (kk * 16 + hh * 8) * (int)sizeof(T);
           if constexpr (sizeof(T) == 2) {
-            bf[i < NJ ? i : 0].v = *reinterpret_cast<const s16x8*>(rowb + (b0 ^ swb));
+            af[i].v = *reinterpret_cast<const s16x8*>(row + (b0 ^ sw));
           } else {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(rowb + (b0 ^ swb));
-            const f32x4 y = *reinterpret_cast<const f32x4*>(rowb + ((b0 + 16) ^ swb));
+            const f32x4 x = *reinterpret_cast<const f32x4*>(row + (b0 ^ sw));
+            const f32x4 y = *reinterpret_cast<const f32x4*>(row + ((b0 + 16) ^ sw));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { bf[i < NJ ? i : 0].v[e] = x[e]; bf[i < NJ ? i : 0].v[4 + e] = y[e]; }
+            for (int e = 0; e < 4; ++e) { af[i].v[e] = x[e]; af[i].v[4 + e] = y[e]; }
+          }
+          if (i < NJ) {
+            const int rn = wc + 32 * i + l31;
+            const char* rowb = Bs + rn * ROWB;
+            const int swb = swz128(rn);
+            if constexpr (sizeof(T) == 2) {
+              bf[i < NJ ? i : 0].v = *reinterpret_cast<const s16x8*>(rowb + (b0 ^ swb));
+            } else {
+              const f32x4 x = *reinterpret_cast<const f32x4*>(rowb + (b0 ^ swb));
+              const f32x4 y = *reinterpret_cast<const f32x4*>(rowb + ((b0 + 16) ^ swb));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { bf[i < NJ ? i : 0].v[e] = x[e]; bf[i < NJ ? i : 0].v[4 + e] = y[e]; }
+            }
           }
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) mma32(acc[i][j], af[i], bf[j]);
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) mma32(acc[i][j], af[i], bf[j]);
-    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  fetch(S0{}, 0);
+  fetch(S1{}, BK);                                       // (a slab past K re-reads the last chunk column; it is never stashed)
+  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+    __syncthreads();
+    stash(S0{}, k0);
+    __syncthreads();
+    fetch(S0{}, k0 + 2 * BK);
+    compute();
+    // (no branch around the second half: a slab past K has its weight chunks zeroed and adds nothing -- a conditional region
+    //  with loads inside costs the counted waits)
+    __syncthreads();
+    stash(S1{}, k0 + BK);
+    __syncthreads();
+    fetch(S1{}, k0 + 3 * BK);
+    compute();
   }
 
   // epilogue: D col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
