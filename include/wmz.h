@@ -165,6 +165,13 @@ int wmz_vq_gather(const int64_t* idx, const float* codebook, void* out, long ldo
  * sqerr[c] += sum |codebook[c]-x[n]|^2.  Caller zeroes counts/dw (sqerr accumulates into accumulated_error). */
 int wmz_vq_ema_stats(const float* x, long ldx, const int64_t* idx, const float* codebook, float* counts,
                      float* dw, float* sqerr, int N, int C, int E, void* stream);
+/* The same accumulations as a counting sort by code + gather (<= 12 288 codes, E <= 256; csrc/class_sort.h, csrc/vq.hip):
+ * ~2 flushes per 64 rows instead of one atomic per element -- the scatter form serialises on sqerr[c] / dw[c] (1.8 ms at
+ * N = 65 536, C = 1 024, E = 64; 35 us here, whatever the code distribution).  `workspace`: >=
+ * wmz_vq_ema_stats_workspace_ints(N, C) ints, ZERO-FILLED by the caller before the first call; calls leave the counters zeroed. */
+long wmz_vq_ema_stats_workspace_ints(int N, int C);
+int wmz_vq_ema_stats_sorted(const float* x, long ldx, const int64_t* idx, const float* codebook, float* counts, float* dw,
+                            float* sqerr, int N, int C, int E, int* workspace, long workspace_ints, void* stream);
 /* EMA update (vq.py:53-65): cluster_size = g*cs + (1-g)*counts; n = sum(cs);
  * embedding = g*embedding + (1-g) * dw / ((cs+eps)/(n+C*eps)*n).   activation_count += counts (vq.py:44). */
 int wmz_vq_ema_update(float* embedding, float* cluster_size, float* activation_count, const float* counts,

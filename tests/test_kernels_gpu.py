@@ -361,3 +361,38 @@ def test_attention_full_size_properties(ops):
     e1 = float((shifted1[:, 3:S - 5] - o1[:, 4:S - 4]).norm() / o1[:, 4:S - 4].norm())
     print(f'[attention full size] shift by one plane: rel {e1:.2e} (P is rounded to bf16 against another running reference)')
     assert e1 < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,C,E,dominant', [(65536, 1024, 64, False), (5000, 37, 16, True), (777, 512, 96, True), (300, 8, 200, False)])
+def test_vq_ema_statistics_sorted_gather_vs_scatter_and_torch(N, C, E, dominant):
+    """wmz_vq_ema_stats_sorted (counting sort by code + gather) against index_add in float64 and against the scatter kernel:
+    counts exact, dw / sqerr to fp32 summation order; accumulates into non-zero buffers; two calls in a row (the sort's
+    counters must be back at zero); a dominant code; row counts that are not a multiple of the 64-entry wave tile; E that is
+    not a multiple of 64; out-of-range indices clamped."""
+    from world_modelz_amd import ops, _lib as L
+    torch.manual_seed(9)
+    x = torch.randn(N, E, device='cuda')
+    cb = torch.randn(C, E, device='cuda')
+    idx = torch.randint(0, C, (N,), device='cuda')
+    if dominant:
+        idx[torch.rand(N, device='cuda') < 0.6] = C // 3
+        idx[0], idx[1] = -4, C + 11
+    c0, d0, s0 = torch.rand(C, device='cuda'), torch.randn(C, E, device='cuda'), torch.rand(C, device='cuda')
+    counts, dw, sq = c0.clone(), d0.clone(), s0.clone()
+    ops.vq_ema_stats(x, idx, cb, counts, dw, sq)
+    ops.vq_ema_stats(x, idx, cb, counts, dw, sq)
+    ic = idx.clamp(0, C - 1)
+    rc = c0.double() + 2 * torch.bincount(ic, minlength=C).double()
+    rd = d0.double().index_add_(0, ic, 2 * x.double())
+    rs = s0.double().index_add_(0, ic, 2 * ((cb[ic].double() - x.double()) ** 2).sum(1))
+    assert torch.equal(counts.double(), rc) or float((counts.double() - rc).abs().max()) < 1e-3     # integers, + a random start
+    assert float((dw.double() - rd).abs().max() / rd.abs().max()) < 2e-6
+    assert float((sq.double() - rs).abs().max() / rs.abs().max()) < 2e-6
+    # the scatter kernel (> 12 288 codes) computes the same
+    counts2, dw2, sq2 = c0.clone(), d0.clone(), s0.clone()
+    for _ in range(2):
+        L.call('wmz_vq_ema_stats', L.ptr(x), E, L.ptr(idx), L.ptr(cb), L.ptr(counts2), L.ptr(dw2), L.ptr(sq2), N, C, E, L.stream())
+    torch.cuda.synchronize()
+    # (its thousands of sequential fp32 atomic adds into one dominant code's sums are the LESS accurate of the two)
+    assert float((dw2 - dw).abs().max() / rd.abs().max()) < 1e-5 and float((sq2 - sq).abs().max() / rs.abs().max()) < 1e-4

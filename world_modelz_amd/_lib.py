@@ -88,6 +88,9 @@ SIGNATURES = {
     'wmz_vq_gather': [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_vq_ema_stats': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_void_p],
+    'wmz_vq_ema_stats_workspace_ints': [c_int, c_int],                    # returns long
+    'wmz_vq_ema_stats_sorted': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_void_p, c_long, c_void_p],
     'wmz_vq_ema_update': [c_void_p] * 5 + [c_int, c_int, c_double, c_double, c_void_p],
 }
 

@@ -8,7 +8,7 @@
 // memory side at ~1.3 TB/s of added bytes: 77 us for a 33 MB read.  Here:
 //   A  embed_bwd_pos_hist_kernel   one workgroup per plane: the three position sums from registers (8-byte loads, one row
 //                                  of 256 features per wave instruction), and the class histogram (one int atomic per token)
-//   B  embed_bwd_fill_kernel       every workgroup scans the histogram (C <= 12 288 counters: cheaper than a launch) and
+//   B  class_fill_kernel       every workgroup scans the histogram (C <= 12 288 counters: cheaper than a launch) and
 //                                  drops its 256 tokens into their class's segment of the sorted list
 //   C  embed_bwd_gather_kernel     one wave per 64 consecutive entries of the sorted list: the 64 rows are requested at once
 //                                  (row addresses are wave-uniform: v_readlane), summed in list order, and a partial row is
@@ -16,18 +16,13 @@
 //                                  every wave has the same amount of work whatever the class distribution (a frame that is
 //                                  half mask tokens, real VQ codes with a few dominant classes); re-zeroes the counters.
 // Built for the denoiser's shapes: W = 16, D = 256, bf16 gradients; anything else stays on the scatter kernels.
-#include "wmz_common.h"
+#include "class_sort.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(2))) int i32x2;
-
 constexpr int EB_D = 256;
-constexpr int EB_MAXC = 12288;            // classes: the fill kernel's LDS image of the offsets is 48 KB
+constexpr int EB_MAXC = CS_MAXC;
 
-__device__ __forceinline__ int clamp_class(long tk, int num_classes) {
-  return (int)(tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : tk));
-}
 __device__ __forceinline__ f32x4 bf4_to_f32(const i32x2& p) {
   f32x4 v;
   v[0] = __builtin_bit_cast(float, p[0] << 16);
@@ -99,59 +94,6 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_hist_kernel(const int64_t* 
   for (int c = threadIdx.x; c < num_classes; c += 256) {
     const int n = lh[c];
     if (n > 0) atomicAdd(cnt + c, n);
-  }
-}
-
-// exclusive scan of one value per thread over the 256 threads of a workgroup
-__device__ __forceinline__ int block_exclusive_scan(int v, int* wsum /* [4] in LDS */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  int base = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) if (w < wave) base += wsum[w];
-  return base + inc - v;
-}
-
-// B: every workgroup scans the global histogram into class offsets (LDS), ranks its 256 tokens within their classes (LDS
-// atomics), reserves room for each class it holds by ONE returning global atomic (issued by the token ranked first), and drops
-// the tokens into the list.
-__global__ __launch_bounds__(256) void embed_bwd_fill_kernel(const int64_t* __restrict__ z, const int* __restrict__ cnt,
-                                                             int* __restrict__ fill, i32x2* __restrict__ sorted, long ntok,
-                                                             int num_classes) {
-  extern __shared__ int sm[];
-  int* lh = sm;                                                           // [C] local count, then the reserved base
-  int* lo = sm + num_classes;                                             // [C] class offset in the list
-  __shared__ int wsum[4];
-  const int tid = threadIdx.x;
-  for (int c = tid; c < num_classes; c += 256) lh[c] = 0;
-  __syncthreads();
-  const long t = (long)blockIdx.x * 256 + tid;
-  const bool ok = t < ntok;
-  const int ct = ok ? clamp_class(z[t], num_classes) : 0;
-  const int rank = ok ? atomicAdd(lh + ct, 1) : -1;
-  const int seg = (num_classes + 255) / 256;
-  const int c0 = tid * seg, c1 = min(num_classes, c0 + seg);
-  int sum = 0;
-  for (int c = c0; c < c1; ++c) sum += cnt[c];
-  int run = block_exclusive_scan(sum, wsum);                              // (its barrier also closes the ranking pass)
-  for (int c = c0; c < c1; ++c) { lo[c] = run; run += cnt[c]; }
-  int base = 0;
-  if (rank == 0) base = atomicAdd(fill + ct, lh[ct]);
-  __syncthreads();
-  if (rank == 0) lh[ct] = base;
-  __syncthreads();
-  if (ok) {
-    i32x2 e;
-    e[0] = (int)t;
-    e[1] = ct;
-    sorted[lo[ct] + lh[ct] + rank] = e;
   }
 }
 
@@ -254,10 +196,10 @@ extern "C" int wmz_embed_pos3d_bwd_sorted(const int64_t* z, const void* dx, floa
   hipStream_t st = (hipStream_t)stream;
   const int planes = B * S, gblocks = wmz_cdiv(ntok, 256L), rblocks = (17 + H) * wmz_cdiv(planes, 32);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_pos_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(class_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   hipLaunchKernelGGL(embed_bwd_pos_hist_kernel, dim3((unsigned)planes), dim3(256), (size_t)num_classes * 4, st, z,
                      (const bf16_t*)dx, part, cnt, H, num_classes);
-  hipLaunchKernelGGL(embed_bwd_fill_kernel, dim3((unsigned)gblocks), dim3(256), (size_t)num_classes * 8, st, z, cnt, fill, sorted,
+  hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)gblocks), dim3(256), (size_t)num_classes * 8, st, z, cnt, fill, sorted,
                      ntok, num_classes);
   hipLaunchKernelGGL(embed_bwd_gather_kernel, dim3((unsigned)(gblocks + rblocks)), dim3(256), 0, st, sorted, (const bf16_t*)dx,
                      demb, cnt, fill, ntok, num_classes, gblocks, part, dpos_s, dpos_h, dpos_w, planes, S, H);

@@ -133,11 +133,25 @@ def vq_gather(idx, codebook, dtype=torch.float32):
     return out.reshape(*idx.shape, E)
 
 
+_vq_ws = {}
+
+
 def vq_ema_stats(x, idx, codebook, counts=None, dw=None, sqerr=None):
+    """counts[c] += #rows of code c, dw[c] += their sum, sqerr[c] += their squared distance to the code (vq.py:35-36, :43-46):
+    rows counting-sorted by code, then gathered (no atomic per element; the scatter kernel stays for > 12 288 codes)."""
     x, N, ldx = _rows(x)
     C, E = codebook.shape
-    L.call('wmz_vq_ema_stats', L.ptr(x), ldx, L.ptr(idx.reshape(-1).contiguous()), L.ptr(codebook), L.ptr(counts),
-           L.ptr(dw), L.ptr(sqerr), N, C, E, L.stream())
+    idx = idx.reshape(-1).contiguous()
+    if C <= 12288 and E <= 256:
+        need = L.lib().wmz_vq_ema_stats_workspace_ints(N, C)
+        ws = _vq_ws.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _vq_ws[x.device] = torch.zeros(need, dtype=torch.int32, device=x.device)     # zeroed ONCE: calls re-zero the counters
+        L.call('wmz_vq_ema_stats_sorted', L.ptr(x), ldx, L.ptr(idx), L.ptr(codebook), L.ptr(counts), L.ptr(dw), L.ptr(sqerr),
+               N, C, E, L.ptr(ws), ws.numel(), L.stream())
+        return
+    L.call('wmz_vq_ema_stats', L.ptr(x), ldx, L.ptr(idx), L.ptr(codebook), L.ptr(counts), L.ptr(dw), L.ptr(sqerr), N, C, E,
+           L.stream())
 
 
 def vq_ema_update(embedding, cluster_size, activation_count, counts, dw, decay, eps):
