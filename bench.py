@@ -313,235 +313,243 @@ def main():
                           'frac_of_measured_copy_6.29TBs': step_bytes / (ms_per_step * 1e-3) / 1e9 / 6290.0},
     }
     gc.collect()
-    # ---- secondary figure: the same forward with the dead planes elided (bit-identical logits; NOT the headline)
-    cone = None
-    if use_fused and not a.eager and not a.no_cone:
-        wcfg.set_last_frame_cone(True)
-        with torch.no_grad():
-            crun = GraphedForward(model, z)
-            crun.static_in.copy_(z)
-            cz = crun.static_in
-            yc = crun(cz)
-            same = bool(torch.equal(yc, runner(runner.static_in)))
-            for _ in range(a.warmup):
-                crun(cz)
-            barrier()
-            c0 = time.perf_counter()
-            for _ in range(a.steps):
-                crun(cz)
-            torch.cuda.synchronize()
-            barrier()
-            cel = time.perf_counter() - c0
-        if world > 1:
-            t = torch.tensor([cel], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            cel = float(t.item())
-        need, src = fused.cone_planes(cfg['S'], cfg['extents'][0], cfg['depth'])
-        cone = {'value': frames / cel, 'unit': 'latent-frames/s', 'ms_per_step': cel / a.steps * 1e3,
-                'bit_identical_to_full_grid': same, 'query_planes_per_layer': need, 'source_planes_per_layer': src,
-                'what': 'same logits from the last frame\'s dependence cone only (library default for inference); '
-                        'latent-frames counted as for the headline (B*S per step)'}
-        wcfg.set_last_frame_cone(False)
-        log(f'last-frame cone: {cone["ms_per_step"]:.3f} ms/step, identical={same}')
-    out['last_frame_cone'] = cone
-    gc.collect()
-    # ---- secondary figure: the same step with the reference's other published attention window, 7 x 3 x 3 (extents 3, 1, 1:
-    # BASELINE.md run-03), full grid, same model otherwise
-    win = None
-    if use_fused and not a.eager and not a.no_cone:
-        torch.manual_seed(42)
-        m2 = VqVideoDiffusionModel(data_shape=(cfg['S'], cfg['H'], cfg['W']), dim=cfg['dim'], num_classes=cfg['C'],
-                                   extents=(3, 1, 1), depth=cfg['depth'], dim_head=cfg['dim_head'], mlp_dim=cfg['mlp_dim'],
-                                   heads=cfg['heads']).to(dev).eval()
-        with torch.no_grad():
-            wrun = GraphedForward(m2, z)
-            wz = wrun.static_in
-            for _ in range(50 + a.warmup):
-                wrun(wz)
-            barrier()
-            w0 = time.perf_counter()
-            for _ in range(a.steps):
-                wrun(wz)
-            torch.cuda.synchronize()
-            barrier()
-            wel = time.perf_counter() - w0
-        if world > 1:
-            t = torch.tensor([wel], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            wel = float(t.item())
-        win = {'value': frames / wel, 'unit': 'latent-frames/s', 'ms_per_step': wel / a.steps * 1e3,
-               'what': 'the headline step with the 7x3x3 window of the published run-03 (extents 3,1,1) instead of 7x7x7'}
-        log(f'7x3x3 window: {win["ms_per_step"]:.3f} ms/step')
-        del wrun, m2
-    out['window_7x3x3'] = win
-    gc.collect()
-    # ---- secondary figure: the reference's two PUBLISHED runs (results/README.md: dim 96 / mlp 256 / depth 12 and dim 384 /
-    # mlp 512 / depth 20, one head of 128, window 7x3x3), same clips.  Their widths are outside the fused per-token kernel
-    # (built for 256 / 128 / 256: DESIGN.md 4.2), so the per-token work runs on linear_kernel with LayerNorm / GELU / residual
-    # fused into its prologue and epilogue, the attention on the same row16 kernel; one hipGraph per step.
-    pub = None
-    if not a.eager and not a.no_cone and dtype == torch.bfloat16:
-        pub = []
-        for dim_, mlp_, depth_ in ((96, 256, 12), (384, 512, 20)):
-            torch.manual_seed(42)
-            m3 = VqVideoDiffusionModel(data_shape=(cfg['S'], cfg['H'], cfg['W']), dim=dim_, num_classes=cfg['C'], extents=(3, 1, 1),
-                                       depth=depth_, dim_head=128, mlp_dim=mlp_, heads=1).to(dev).eval()
+    # The secondary figures below must never cost the headline line: whatever one of them raises (every rank runs the same
+    # code on the same shapes, so a failure is the same on all ranks and no rank is left waiting in a collective) is recorded
+    # in `secondary_error` and the JSON line is printed with what was measured up to there.
+    try:
+        # ---- secondary figure: the same forward with the dead planes elided (bit-identical logits; NOT the headline)
+        cone = None
+        if use_fused and not a.eager and not a.no_cone:
+            wcfg.set_last_frame_cone(True)
             with torch.no_grad():
-                prun = GraphedForward(m3, z)
-                pz = prun.static_in
-                for _ in range(10):
-                    prun(pz)
+                crun = GraphedForward(model, z)
+                crun.static_in.copy_(z)
+                cz = crun.static_in
+                yc = crun(cz)
+                same = bool(torch.equal(yc, runner(runner.static_in)))
+                for _ in range(a.warmup):
+                    crun(cz)
                 barrier()
-                p0 = time.perf_counter()
-                for _ in range(10):
-                    prun(pz)
+                c0 = time.perf_counter()
+                for _ in range(a.steps):
+                    crun(cz)
                 torch.cuda.synchronize()
-                pel = (time.perf_counter() - p0) / 10
-            pub.append({'dim': dim_, 'mlp_dim': mlp_, 'depth': depth_, 'extents': [3, 1, 1], 'ms_per_step': pel * 1e3,
-                        'value': cfg['B'] * cfg['S'] / pel, 'unit': 'latent-frames/s',
-                        'params': sum(p.numel() for p in m3.parameters())})
-            log(f'published widths dim {dim_} depth {depth_}: {pel * 1e3:.3f} ms/step')
-            del prun, m3
-            gc.collect()
-    out['published_run_widths'] = pub
-    # ---- secondary figure: the stage in front of the denoiser: the frozen VQ auto-encoder turning frames into
-    # latent tokens -- conv encoder (NHWC implicit GEMM, BatchNorm in train mode: quirk Q3) + codebook argmin.  B*S frames
-    # of 64x64 RGB -> 16x16 tokens each (2 down-scale steps), codebook 1024 x 64.
-    frame_enc = None
-    if not a.no_cone:
-        from world_modelz_amd.train_vqae import VqAutoEncoder
-        torch.manual_seed(7)
-        ae = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
-        frames_in = torch.randn(cfg['B'] * cfg['S'], 3, 64, 64, device=dev)
-        with torch.no_grad():
-            for _ in range(2):
-                tok = ae.encode(frames_in)
-            barrier()
-            f0 = time.perf_counter()
+                barrier()
+                cel = time.perf_counter() - c0
+            if world > 1:
+                t = torch.tensor([cel], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                cel = float(t.item())
+            need, src = fused.cone_planes(cfg['S'], cfg['extents'][0], cfg['depth'])
+            cone = {'value': frames / cel, 'unit': 'latent-frames/s', 'ms_per_step': cel / a.steps * 1e3,
+                    'bit_identical_to_full_grid': same, 'query_planes_per_layer': need, 'source_planes_per_layer': src,
+                    'what': 'same logits from the last frame\'s dependence cone only (library default for inference); '
+                            'latent-frames counted as for the headline (B*S per step)'}
+            wcfg.set_last_frame_cone(False)
+            log(f'last-frame cone: {cone["ms_per_step"]:.3f} ms/step, identical={same}')
+        out['last_frame_cone'] = cone
+        gc.collect()
+        # ---- secondary figure: the same step with the reference's other published attention window, 7 x 3 x 3 (extents 3, 1, 1:
+        # BASELINE.md run-03), full grid, same model otherwise
+        win = None
+        if use_fused and not a.eager and not a.no_cone:
+            torch.manual_seed(42)
+            m2 = VqVideoDiffusionModel(data_shape=(cfg['S'], cfg['H'], cfg['W']), dim=cfg['dim'], num_classes=cfg['C'],
+                                       extents=(3, 1, 1), depth=cfg['depth'], dim_head=cfg['dim_head'], mlp_dim=cfg['mlp_dim'],
+                                       heads=cfg['heads']).to(dev).eval()
+            with torch.no_grad():
+                wrun = GraphedForward(m2, z)
+                wz = wrun.static_in
+                for _ in range(50 + a.warmup):
+                    wrun(wz)
+                barrier()
+                w0 = time.perf_counter()
+                for _ in range(a.steps):
+                    wrun(wz)
+                torch.cuda.synchronize()
+                barrier()
+                wel = time.perf_counter() - w0
+            if world > 1:
+                t = torch.tensor([wel], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                wel = float(t.item())
+            win = {'value': frames / wel, 'unit': 'latent-frames/s', 'ms_per_step': wel / a.steps * 1e3,
+                   'what': 'the headline step with the 7x3x3 window of the published run-03 (extents 3,1,1) instead of 7x7x7'}
+            log(f'7x3x3 window: {win["ms_per_step"]:.3f} ms/step')
+            del wrun, m2
+        out['window_7x3x3'] = win
+        gc.collect()
+        # ---- secondary figure: the reference's two PUBLISHED runs (results/README.md: dim 96 / mlp 256 / depth 12 and dim 384 /
+        # mlp 512 / depth 20, one head of 128, window 7x3x3), same clips.  Their widths are outside the fused per-token kernel
+        # (built for 256 / 128 / 256: DESIGN.md 4.2), so the per-token work runs on linear_kernel with LayerNorm / GELU / residual
+        # fused into its prologue and epilogue, the attention on the same row16 kernel; one hipGraph per step.
+        pub = None
+        if not a.eager and not a.no_cone and dtype == torch.bfloat16:
+            pub = []
+            for dim_, mlp_, depth_ in ((96, 256, 12), (384, 512, 20)):
+                torch.manual_seed(42)
+                m3 = VqVideoDiffusionModel(data_shape=(cfg['S'], cfg['H'], cfg['W']), dim=dim_, num_classes=cfg['C'], extents=(3, 1, 1),
+                                           depth=depth_, dim_head=128, mlp_dim=mlp_, heads=1).to(dev).eval()
+                with torch.no_grad():
+                    prun = GraphedForward(m3, z)
+                    pz = prun.static_in
+                    for _ in range(10):
+                        prun(pz)
+                    barrier()
+                    p0 = time.perf_counter()
+                    for _ in range(10):
+                        prun(pz)
+                    torch.cuda.synchronize()
+                    pel = (time.perf_counter() - p0) / 10
+                pub.append({'dim': dim_, 'mlp_dim': mlp_, 'depth': depth_, 'extents': [3, 1, 1], 'ms_per_step': pel * 1e3,
+                            'value': cfg['B'] * cfg['S'] / pel, 'unit': 'latent-frames/s',
+                            'params': sum(p.numel() for p in m3.parameters())})
+                log(f'published widths dim {dim_} depth {depth_}: {pel * 1e3:.3f} ms/step')
+                del prun, m3
+                gc.collect()
+        out['published_run_widths'] = pub
+        # ---- secondary figure: the stage in front of the denoiser: the frozen VQ auto-encoder turning frames into
+        # latent tokens -- conv encoder (NHWC implicit GEMM, BatchNorm in train mode: quirk Q3) + codebook argmin.  B*S frames
+        # of 64x64 RGB -> 16x16 tokens each (2 down-scale steps), codebook 1024 x 64.
+        frame_enc = None
+        if not a.no_cone:
+            from world_modelz_amd.train_vqae import VqAutoEncoder
+            torch.manual_seed(7)
+            ae = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
+            frames_in = torch.randn(cfg['B'] * cfg['S'], 3, 64, 64, device=dev)
+            with torch.no_grad():
+                for _ in range(2):
+                    tok = ae.encode(frames_in)
+                barrier()
+                f0 = time.perf_counter()
+                for _ in range(5):
+                    tok = ae.encode(frames_in)
+                torch.cuda.synchronize()
+                fel = (time.perf_counter() - f0) / 5
+            assert tok.shape == (cfg['B'] * cfg['S'], 16, 16)
+            frame_enc = {'value': cfg['B'] * cfg['S'] / fel, 'unit': 'frames/s', 'ms_per_batch': fel * 1e3,
+                         'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens (eager launches)"}
+            log(f'frame encoder: {fel * 1e3:.2f} ms per {cfg["B"] * cfg["S"]} frames')
+        out['frame_encoder'] = frame_enc
+        # ---- secondary figure: the VQ codebook nearest-neighbour micro-bench of SURVEY 8(d): x = randn(N, 64), codebook =
+        # randn(C, 64), N = 65 536, C in {512, 1024, 8192}, seed 0.  Bound: the fp32 vector ALU -- the bit-exact distance is three
+        # UN-fused lane operations per (n, c, e) (sub, mul, add in ATen's order), so the ceiling is the VALU's lane-op rate
+        # (half the 157.3 TFLOP/s FMA peak); HBM traffic (N*E*4 in, N*8 out, codebook resident) is two orders below its roof.
+        vq = None
+        if not a.no_cone:
+            vq = []
+            gvq = torch.Generator(device='cpu').manual_seed(0)
+            Nq, Eq = 65536, 64
+            xq = torch.randn(Nq, Eq, generator=gvq).to(dev)
+            for Cq in (512, 1024, 8192):
+                cbq = torch.randn(Cq, Eq, generator=gvq).to(dev)
+                vq_ms = time_kernel(lambda: ops.vq_argmin(xq, cbq), 10)
+                lane_ops = 3.0 * Nq * Cq * Eq
+                vq.append({'N': Nq, 'C': Cq, 'E': Eq, 'ms': vq_ms, 'rows_per_s': Nq / (vq_ms * 1e-3),
+                           'roofline': {'bound': 'valu-f32', 'achieved': lane_ops / (vq_ms * 1e-3) / 1e12, 'peak': 78.65,
+                                        'unit': 'T lane-op/s', 'frac': lane_ops / (vq_ms * 1e-3) / 1e12 / 78.65},
+                           'hbm_GBs': (Nq * Eq * 4 + Nq * 8) / (vq_ms * 1e-3) / 1e9})
+            log('vq argmin: ' + ', '.join(f"C={v['C']} {v['ms'] * 1e3:.0f} us ({v['roofline']['frac']:.2f} of the f32 VALU)" for v in vq))
+        out['vq_argmin'] = vq
+        gc.collect()
+        # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand
+        # re-pack), same shapes, same rules (barrier + sync both sides, max over ranks).  One GPU: the whole step is ONE hipGraph
+        # replay (DenoiserTrainer.enable_graph) plus the loss-aware sampler's one host read-back per step.  n_gpus > 1: eager
+        # launches with the per-layer gradient all-reduce buckets overlapped on a side stream.
+        train = None
+        if a.train_steps > 0:
+            from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame
+            model.train()
+            tr = DenoiserTrainer(model, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=world > 1)
+            rfix = torch.full((cfg['B'],), 0.5)
+            graphed = world == 1 and not a.eager
+            if graphed:
+                tr.enable_graph(z)
+                tstep = lambda: tr.train_step(z, r=rfix)  # noqa: E731
+            else:
+                def tstep():
+                    tr.arena.zero_grad()
+                    zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
+                    tr.forward_backward(zc, tgt)
+                    tr.optimizer_step()
             for _ in range(5):
-                tok = ae.encode(frames_in)
+                tstep()
+            barrier()
+            if tr.reducer is not None:
+                tr.reducer.enable_timing()
+            tt0 = time.perf_counter()
+            for _ in range(a.train_steps):
+                tstep()
             torch.cuda.synchronize()
-            fel = (time.perf_counter() - f0) / 5
-        assert tok.shape == (cfg['B'] * cfg['S'], 16, 16)
-        frame_enc = {'value': cfg['B'] * cfg['S'] / fel, 'unit': 'frames/s', 'ms_per_batch': fel * 1e3,
-                     'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens (eager launches)"}
-        log(f'frame encoder: {fel * 1e3:.2f} ms per {cfg["B"] * cfg["S"]} frames')
-    out['frame_encoder'] = frame_enc
-    # ---- secondary figure: the VQ codebook nearest-neighbour micro-bench of SURVEY 8(d): x = randn(N, 64), codebook =
-    # randn(C, 64), N = 65 536, C in {512, 1024, 8192}, seed 0.  Bound: the fp32 vector ALU -- the bit-exact distance is three
-    # UN-fused lane operations per (n, c, e) (sub, mul, add in ATen's order), so the ceiling is the VALU's lane-op rate
-    # (half the 157.3 TFLOP/s FMA peak); HBM traffic (N*E*4 in, N*8 out, codebook resident) is two orders below its roof.
-    vq = None
-    if not a.no_cone:
-        vq = []
-        gvq = torch.Generator(device='cpu').manual_seed(0)
-        Nq, Eq = 65536, 64
-        xq = torch.randn(Nq, Eq, generator=gvq).to(dev)
-        for Cq in (512, 1024, 8192):
-            cbq = torch.randn(Cq, Eq, generator=gvq).to(dev)
-            vq_ms = time_kernel(lambda: ops.vq_argmin(xq, cbq), 10)
-            lane_ops = 3.0 * Nq * Cq * Eq
-            vq.append({'N': Nq, 'C': Cq, 'E': Eq, 'ms': vq_ms, 'rows_per_s': Nq / (vq_ms * 1e-3),
-                       'roofline': {'bound': 'valu-f32', 'achieved': lane_ops / (vq_ms * 1e-3) / 1e12, 'peak': 78.65,
-                                    'unit': 'T lane-op/s', 'frac': lane_ops / (vq_ms * 1e-3) / 1e12 / 78.65},
-                       'hbm_GBs': (Nq * Eq * 4 + Nq * 8) / (vq_ms * 1e-3) / 1e9})
-        log('vq argmin: ' + ', '.join(f"C={v['C']} {v['ms'] * 1e3:.0f} us ({v['roofline']['frac']:.2f} of the f32 VALU)" for v in vq))
-    out['vq_argmin'] = vq
-    gc.collect()
-    # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand
-    # re-pack), same shapes, same rules (barrier + sync both sides, max over ranks).  One GPU: the whole step is ONE hipGraph
-    # replay (DenoiserTrainer.enable_graph) plus the loss-aware sampler's one host read-back per step.  n_gpus > 1: eager
-    # launches with the per-layer gradient all-reduce buckets overlapped on a side stream.
-    train = None
-    if a.train_steps > 0:
-        from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame
-        model.train()
-        tr = DenoiserTrainer(model, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=world > 1)
-        rfix = torch.full((cfg['B'],), 0.5)
-        graphed = world == 1 and not a.eager
-        if graphed:
-            tr.enable_graph(z)
-            tstep = lambda: tr.train_step(z, r=rfix)  # noqa: E731
-        else:
-            def tstep():
-                tr.arena.zero_grad()
-                zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
-                tr.forward_backward(zc, tgt)
-                tr.optimizer_step()
-        for _ in range(5):
-            tstep()
-        barrier()
-        if tr.reducer is not None:
-            tr.reducer.enable_timing()
-        tt0 = time.perf_counter()
-        for _ in range(a.train_steps):
-            tstep()
-        torch.cuda.synchronize()
-        barrier()
-        tel = time.perf_counter() - tt0
-        if world > 1:
-            t = torch.tensor([tel], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            tel = float(t.item())
-        tms = tel / a.train_steps * 1e3
-        # a training step is ~3x the forward's flops (no recompute of the attention core: the backward works
-        # from the saved log-sum-exp); bytes likewise ~3x the forward's algorithmic bytes (activations written once, read by
-        # the backward, gradients written once)
-        D_, I_, M_, L_ = cfg['dim'], cfg['dim_head'] * cfg['heads'], cfg['mlp_dim'], cfg['depth']
-        Kw = (2 * cfg['extents'][0] + 1) * (2 * cfg['extents'][1] + 1) * (2 * cfg['extents'][2] + 1)
-        fwd_flops = L_ * (6.0 * N * D_ * I_ + 4.0 * N * Kw * I_ + 2.0 * N * I_ * D_ + 4.0 * N * D_ * M_) \
-            + 2.0 * cfg['B'] * cfg['H'] * cfg['W'] * D_ * cfg['C']
-        train = {'value': cfg['B'] * cfg['S'] * world * a.train_steps / tel, 'unit': 'latent-frames/s',
-                 'ms_per_step': tms, 'steps': a.train_steps,
-                 'what': 'corrupt + forward + CE + backward + grad-norm + AdamW + operand re-pack: '
-                         + ('ONE hipGraph replay per step + the sampler\'s host read-back' if graphed else
-                            'eager launches, per-layer RCCL gradient all-reduce overlapped on a side stream'),
-                 'launch_mode': 'hipGraph' if graphed else 'eager',
-                 'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0,
-                 'grad_allreduce_overlap': tr.reducer.timing_summary() if tr.reducer else None,
-                 'train_roofline': {'algorithmic_flops_per_step': 3.0 * fwd_flops,
-                                    'achieved_TFLOPs': 3.0 * fwd_flops / (tms * 1e-3) / 1e12, 'mfma_peak_TFLOPs': 2500.0,
-                                    'frac_of_mfma_peak': 3.0 * fwd_flops / (tms * 1e-3) / 1e12 / 2500.0,
-                                    'algorithmic_bytes_per_step': 3 * step_bytes,
-                                    'achieved_GBs': 3 * step_bytes / (tms * 1e-3) / 1e9,
-                                    'frac_of_8TBs': 3 * step_bytes / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-        log(f'train step {train["ms_per_step"]:.2f} ms ({train["launch_mode"]})')
-    out['train_step'] = train
-    gc.collect()
-    # ---- secondary figure: BASELINE configs[4], the sparse masked-denoise path (minecraft/sparse_diffusion.py): 64-frame clips of
-    # 16x16 latents, codebook 8192, 512 context tokens per clip, dim 512 / 4 heads x 128 / depth 8 / mlp 1024, global batch 48 on
-    # 8 GPUs = 6 clips per GPU; one full training step (position sampling, gather, corruption, forward, chunked 8192-way
-    # linear + cross-entropy, backward, AdamW), eager launches.
-    sparse = None
-    if a.train_steps > 0 and not a.no_cone:
-        from world_modelz_amd.sparse_diffusion import VqSparseDiffusionModel
-        from world_modelz_amd.train import SparseDenoiserTrainer
-        del tr
-        torch.manual_seed(43)
-        sm = VqSparseDiffusionModel(shape=(64, 16, 16), dim=512, num_classes=8192, depth=8, dim_head=128, mlp_dim=1024, heads=4).to(dev)
-        st = SparseDenoiserTrainer(sm, 8192, num_context=512, lr=1e-4, warmup=500, distributed=world > 1)
-        zs = torch.randint(0, 8192, (6, 64, 16, 16), generator=gen).to(dev)
-        rs = torch.full((6,), 0.5)
-        for _ in range(3):
-            st.train_step(zs, r=rs)
-        barrier()
-        s0 = time.perf_counter()
-        nst = max(1, a.train_steps // 3)
-        for _ in range(nst):
-            st.train_step(zs, r=rs)
-        torch.cuda.synchronize()
-        barrier()
-        sel = time.perf_counter() - s0
-        if world > 1:
-            t = torch.tensor([sel], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            sel = float(t.item())
-        sparse = {'value': 6 * world * nst / sel, 'unit': 'clips/s', 'ms_per_step': sel / nst * 1e3, 'steps': nst,
-                  'tokens_per_s': 6 * 512 * world * nst / sel,
-                  'what': 'config 5 per GPU: 6 clips x 512 context tokens of 64x16x16 latents, codebook 8192, '
-                          'VqSparseDiffusionModel dim 512 / 4x128 / depth 8 / mlp 1024, full training step (eager launches)'}
-        log(f'sparse (config 5) train step {sparse["ms_per_step"]:.2f} ms')
-    out['sparse_step'] = sparse
+            barrier()
+            tel = time.perf_counter() - tt0
+            if world > 1:
+                t = torch.tensor([tel], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                tel = float(t.item())
+            tms = tel / a.train_steps * 1e3
+            # a training step is ~3x the forward's flops (no recompute of the attention core: the backward works
+            # from the saved log-sum-exp); bytes likewise ~3x the forward's algorithmic bytes (activations written once, read by
+            # the backward, gradients written once)
+            D_, I_, M_, L_ = cfg['dim'], cfg['dim_head'] * cfg['heads'], cfg['mlp_dim'], cfg['depth']
+            Kw = (2 * cfg['extents'][0] + 1) * (2 * cfg['extents'][1] + 1) * (2 * cfg['extents'][2] + 1)
+            fwd_flops = L_ * (6.0 * N * D_ * I_ + 4.0 * N * Kw * I_ + 2.0 * N * I_ * D_ + 4.0 * N * D_ * M_) \
+                + 2.0 * cfg['B'] * cfg['H'] * cfg['W'] * D_ * cfg['C']
+            train = {'value': cfg['B'] * cfg['S'] * world * a.train_steps / tel, 'unit': 'latent-frames/s',
+                     'ms_per_step': tms, 'steps': a.train_steps,
+                     'what': 'corrupt + forward + CE + backward + grad-norm + AdamW + operand re-pack: '
+                             + ('ONE hipGraph replay per step + the sampler\'s host read-back' if graphed else
+                                'eager launches, per-layer RCCL gradient all-reduce overlapped on a side stream'),
+                     'launch_mode': 'hipGraph' if graphed else 'eager',
+                     'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0,
+                     'grad_allreduce_overlap': tr.reducer.timing_summary() if tr.reducer else None,
+                     'train_roofline': {'algorithmic_flops_per_step': 3.0 * fwd_flops,
+                                        'achieved_TFLOPs': 3.0 * fwd_flops / (tms * 1e-3) / 1e12, 'mfma_peak_TFLOPs': 2500.0,
+                                        'frac_of_mfma_peak': 3.0 * fwd_flops / (tms * 1e-3) / 1e12 / 2500.0,
+                                        'algorithmic_bytes_per_step': 3 * step_bytes,
+                                        'achieved_GBs': 3 * step_bytes / (tms * 1e-3) / 1e9,
+                                        'frac_of_8TBs': 3 * step_bytes / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            log(f'train step {train["ms_per_step"]:.2f} ms ({train["launch_mode"]})')
+        out['train_step'] = train
+        gc.collect()
+        # ---- secondary figure: BASELINE configs[4], the sparse masked-denoise path (minecraft/sparse_diffusion.py): 64-frame clips of
+        # 16x16 latents, codebook 8192, 512 context tokens per clip, dim 512 / 4 heads x 128 / depth 8 / mlp 1024, global batch 48 on
+        # 8 GPUs = 6 clips per GPU; one full training step (position sampling, gather, corruption, forward, chunked 8192-way
+        # linear + cross-entropy, backward, AdamW), eager launches.
+        sparse = None
+        if a.train_steps > 0 and not a.no_cone:
+            from world_modelz_amd.sparse_diffusion import VqSparseDiffusionModel
+            from world_modelz_amd.train import SparseDenoiserTrainer
+            del tr
+            torch.manual_seed(43)
+            sm = VqSparseDiffusionModel(shape=(64, 16, 16), dim=512, num_classes=8192, depth=8, dim_head=128, mlp_dim=1024, heads=4).to(dev)
+            st = SparseDenoiserTrainer(sm, 8192, num_context=512, lr=1e-4, warmup=500, distributed=world > 1)
+            zs = torch.randint(0, 8192, (6, 64, 16, 16), generator=gen).to(dev)
+            rs = torch.full((6,), 0.5)
+            for _ in range(3):
+                st.train_step(zs, r=rs)
+            barrier()
+            s0 = time.perf_counter()
+            nst = max(1, a.train_steps // 3)
+            for _ in range(nst):
+                st.train_step(zs, r=rs)
+            torch.cuda.synchronize()
+            barrier()
+            sel = time.perf_counter() - s0
+            if world > 1:
+                t = torch.tensor([sel], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                sel = float(t.item())
+            sparse = {'value': 6 * world * nst / sel, 'unit': 'clips/s', 'ms_per_step': sel / nst * 1e3, 'steps': nst,
+                      'tokens_per_s': 6 * 512 * world * nst / sel,
+                      'what': 'config 5 per GPU: 6 clips x 512 context tokens of 64x16x16 latents, codebook 8192, '
+                              'VqSparseDiffusionModel dim 512 / 4x128 / depth 8 / mlp 1024, full training step (eager launches)'}
+            log(f'sparse (config 5) train step {sparse["ms_per_step"]:.2f} ms')
+        out['sparse_step'] = sparse
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out['secondary_error'] = ''.join(traceback.format_exception_only(type(e), e)).strip()[:500]
+        log('secondary figure failed: ' + out['secondary_error'])
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             log(f'cpu baseline on {usable_cores()} threads')
