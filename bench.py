@@ -431,6 +431,28 @@ def main():
                          'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens (eager launches)"}
             log(f'frame encoder: {fel * 1e3:.2f} ms per {cfg["B"] * cfg["S"]} frames')
         out['frame_encoder'] = frame_enc
+        # ---- secondary figure: one VQ-AE training step (train_vqae.py:125-164: encoder -> VectorQuantizerEMA incl. the EMA
+        # codebook update -> decoder, SmoothL1 + commitment loss, backward, AdamW) on 64 frames of 64x64, eager launches
+        vqae = None
+        if not a.no_cone and world == 1:
+            from world_modelz_amd.train import VqaeTrainer
+            torch.manual_seed(7)
+            ae2 = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
+            vt = VqaeTrainer(ae2, distributed=False)
+            fr = torch.rand(64, 3, 64, 64, device=dev)
+            for _ in range(3):
+                vt.train_step(fr)
+            torch.cuda.synchronize()
+            v0 = time.perf_counter()
+            for _ in range(5):
+                vt.train_step(fr)
+            torch.cuda.synchronize()
+            vel = (time.perf_counter() - v0) / 5
+            vqae = {'value': 64 / vel, 'unit': 'frames/s', 'ms_per_step': vel * 1e3,
+                    'what': 'VqaeTrainer.train_step on 64 RGB frames of 64x64 (codebook 1024 x 64, 2 down-scale steps, 128 planes), eager launches incl. 4 host read-backs'}
+            log(f'VQ-AE training step: {vel * 1e3:.2f} ms per 64 frames')
+            del vt, ae2
+        out['vqae_train_step'] = vqae
         # ---- secondary figure: the VQ codebook nearest-neighbour micro-bench of SURVEY 8(d): x = randn(N, 64), codebook =
         # randn(C, 64), N = 65 536, C in {512, 1024, 8192}, seed 0.  Bound: the fp32 vector ALU -- the bit-exact distance is three
         # UN-fused lane operations per (n, c, e) (sub, mul, add in ATen's order), so the ceiling is the VALU's lane-op rate

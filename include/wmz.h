@@ -369,6 +369,14 @@ int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int 
  * weight gradient: dW[Cout, KH*KW*Cin] += dy^T . im2col(x) (implicit), dbias[Cout] += colsum(dy); fp32, accumulated. */
 int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin, int Cout,
                           int KH, int KW, int stride, int pad, int dtype, void* stream);
+/* ... by the two-stage reduction of wmz_linear_wgrad_ws (caller-owned workspace of at least
+ * wmz_conv2d_nhwc_wgrad_workspace_floats(...) floats; deterministic, no float atomics; overwrite != 0: dW / dbias are stored,
+ * not accumulated -- no zero fill needed). */
+long wmz_conv2d_nhwc_wgrad_workspace_floats(int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                            int dtype);
+int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin, int Cout,
+                             int KH, int KW, int stride, int pad, int overwrite, float* workspace, long workspace_floats,
+                             int dtype, void* stream);
 /* training-mode BatchNorm + LeakyReLU backward, pass 1: g = dy * act'(y) (optional g_out), sum_g[C] += g,
  * sum_gx[C] += g * (x - mean) * rstd;  pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)  (dgamma = sum_gx, dbeta = sum_g). */
 int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, void* g_out,

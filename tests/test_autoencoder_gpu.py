@@ -309,3 +309,46 @@ def test_direct_3x3_conv_equals_the_implicit_gemm_kernel(wmz):
     assert float((y_d.float() - ref).norm() / ref.norm()) < 4e-3
     assert torch.allclose(s_d.sum(0), y_d.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(q_d.sum(0), (y_d.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('C,dtype', [(128, torch.bfloat16), (128, torch.float32), (16, torch.bfloat16), (24, torch.bfloat16),
+                                     (512, torch.float32), (2048, torch.bfloat16)])
+def test_training_elementwise_kernels_vector_and_scalar_forms(wmz, C, dtype):
+    """BatchNorm(+LeakyReLU) backward (reduce + apply), channel statistics and bilinear x2 forward / adjoint against fp32 torch
+    formulas on the same (rounded) inputs.  C = 24 is not a vector-form shape (its 3 channel groups do not divide the workgroup):
+    the scalar kernels; the others run the 16-byte kernels, C = 2048 with several channels per reducing thread."""
+    from world_modelz_amd import ops
+    torch.manual_seed(13)
+    B, H, W = 2, 5, 7
+    x = torch.randn(B, H, W, C, device='cuda').to(dtype)
+    dy = torch.randn(B, H, W, C, device='cuda').to(dtype)
+    y = torch.randn(B, H, W, C, device='cuda').to(dtype)
+    gamma = torch.rand(C, device='cuda') + 0.5
+    xf, dyf, yf = x.float(), dy.float(), y.float()
+    M = B * H * W
+    mean = xf.reshape(M, C).mean(0).contiguous()
+    rstd = (xf.reshape(M, C).var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    # statistics ([replicas, C] partial sums)
+    s, q = ops.channel_stats_nhwc(x)
+    assert torch.allclose(s.sum(0), xf.reshape(M, C).sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(q.sum(0), (xf.reshape(M, C) ** 2).sum(0), rtol=1e-4, atol=1e-3)
+    # BatchNorm + LeakyReLU backward
+    dx, sgx, sg, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma, True, 0.01)
+    g_ref = torch.where(yf <= 0, dyf * 0.01, dyf)
+    assert rel(g, g_ref) < tol
+    gr = g.float().reshape(M, C)                                   # the sums see the stored (rounded) g
+    xh = (xf.reshape(M, C) - mean) * rstd
+    assert torch.allclose(sg, gr.sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(sgx, (gr * xh).sum(0), rtol=1e-4, atol=1e-3)
+    dx_ref = gamma * rstd * (gr - sg / M - xh * sgx / M)
+    assert rel(dx.reshape(M, C), dx_ref) < tol
+    # bilinear x2 and its adjoint
+    up = ops.bilinear2x_nhwc(x)
+    up_ref = torch.nn.functional.interpolate(xf.permute(0, 3, 1, 2), scale_factor=2, mode='bilinear', align_corners=False)
+    assert rel(up.permute(0, 3, 1, 2), up_ref) < tol
+    dup = torch.randn(B, 2 * H, 2 * W, C, device='cuda').to(dtype)
+    xin = xf.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    (torch.nn.functional.interpolate(xin, scale_factor=2, mode='bilinear', align_corners=False)
+     * dup.float().permute(0, 3, 1, 2)).sum().backward()
+    assert rel(ops.bilinear2x_nhwc_bwd(dup).permute(0, 3, 1, 2), xin.grad) < tol

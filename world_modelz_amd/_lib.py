@@ -68,6 +68,8 @@ SIGNATURES = {
     'wmz_bn_finalize': [c_void_p, c_void_p, c_double] + [c_void_p] * 4 + [c_double, c_double, c_int] + [c_void_p] * 4
                        + [c_int, c_void_p, c_void_p],
     'wmz_conv2d_nhwc_wgrad': [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
+    'wmz_conv2d_nhwc_wgrad_workspace_floats': [c_int] * 10,                # returns long
+    'wmz_conv2d_nhwc_wgrad_ws': [c_void_p] * 4 + [c_int] * 10 + [c_void_p, c_long, c_int, c_void_p],
     'wmz_bn_act_bwd_reduce': [c_void_p] * 8 + [c_long, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_bn_bwd_apply': [c_void_p] * 8 + [c_long, c_int, c_int, c_void_p],
     'wmz_bilinear2x_nhwc_bwd': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -701,6 +701,198 @@ __global__ __launch_bounds__(256) void bilinear2x_bwd_kernel(const T* __restrict
   }
 }
 
+// ---- 16-byte versions of the training-path elementwise kernels (the scalar forms above move 2 bytes per access: 3-4x off the
+// HBM rate on the 8-270 MB tensors of a VQ-AE training step).  A thread keeps its channel group (VW channels) for the whole
+// launch -- the grid stride is a multiple of C / VW vectors, the host picks the grid that way (256 % (C / VW) == 0) -- so per-channel
+// constants are loaded once and per-channel sums stay in registers; the threads of a workgroup that share a channel group meet in
+// LDS, one atomic per channel and workgroup (<= 256 workgroups: chains of same-address atomics cost ~15 ns a link).
+constexpr int RED_NT = 512;      // threads per workgroup of the two reducing kernels: <= 256 workgroups (the atomic chain), 8 waves per CU
+template <typename T>
+__global__ __launch_bounds__(RED_NT) void bn_act_bwd_reduce_vec_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                    const T* __restrict__ dy, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, T* __restrict__ g_out,
+                                                                    float* __restrict__ sum_g, float* __restrict__ sum_gx,
+                                                                    long nvec, int C, int leaky, float slope) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int cv = C / VW;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(i % cv) * VW;
+  float mu[VW], rs[VW], s1[VW], s2[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { mu[e] = mean ? mean[c0 + e] : 0.f; rs[e] = rstd ? rstd[c0 + e] : 1.f; s1[e] = 0.f; s2[e] = 0.f; }
+  for (; i < nvec; i += stride) {
+    float g[VW];
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(dy + i * VW), g);
+    if (leaky) {
+      float yv[VW];
+      chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(y + i * VW), yv);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) g[e] = yv[e] <= 0.f ? g[e] * slope : g[e];
+    }
+    if (g_out) {
+      const i32x4 gv = f32_to_chunk<T>(g);
+      *reinterpret_cast<i32x4*>(g_out + i * VW) = gv;
+      chunk_to_f32<T>(gv, g);                           // the sums see what was stored (as the scalar kernel's do)
+    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) s1[e] += g[e];
+    if (x) {
+      float xv[VW];
+      chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(x + i * VW), xv);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) s2[e] += g[e] * (xv[e] - mu[e]) * rs[e];
+    }
+  }
+  if (sum_g == nullptr) return;
+  __shared__ float red[2][RED_NT][VW + 1];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < C; t += RED_NT) {       // channel t: its partners are the threads t / VW, t / VW + cv, ..
+    const int grp = t / VW, e = t - grp * VW;
+    float a = 0.f, b = 0.f;
+    for (int p = grp; p < RED_NT; p += cv) { a += red[0][p][e]; b += red[1][p][e]; }
+    atomicAdd(sum_g + t, a);
+    atomicAdd(sum_gx + t, b);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ sum_g,
+                                                               const float* __restrict__ sum_gx, T* __restrict__ dx, long nvec,
+                                                               int C, float invM) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int cv = C / VW;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(i % cv) * VW;
+  float mu[VW], rs[VW], gr[VW], sg[VW], sgx[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) {
+    mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; gr[e] = gamma[c0 + e] * rs[e];
+    sg[e] = sum_g[c0 + e] * invM; sgx[e] = sum_gx[c0 + e] * invM;
+  }
+  for (; i < nvec; i += stride) {
+    float xv[VW], gv[VW];
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(x + i * VW), xv);
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(g + i * VW), gv);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) gv[e] = gr[e] * (gv[e] - sg[e] - (xv[e] - mu[e]) * rs[e] * sgx[e]);
+    *reinterpret_cast<i32x4*>(dx + i * VW) = f32_to_chunk<T>(gv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(RED_NT) void channel_stats_vec_kernel(const T* __restrict__ x, long nvec, int C, float* __restrict__ sum,
+                                                                float* __restrict__ sq) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int cv = C / VW;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float s1[VW], s2[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (; i < nvec; i += stride) {
+    float v[VW];
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(x + i * VW), v);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+  }
+  __shared__ float red[2][RED_NT][VW + 1];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < C; t += RED_NT) {
+    const int grp = t / VW, e = t - grp * VW;
+    float a = 0.f, b = 0.f;
+    for (int p = grp; p < RED_NT; p += cv) { a += red[0][p][e]; b += red[1][p][e]; }
+    const long rep = (long)(blockIdx.x % WMZ_STAT_REPLICAS) * C;
+    atomicAdd(sum + rep + t, a);
+    atomicAdd(sq + rep + t, b);
+  }
+}
+
+// bilinear x2 forward / adjoint, one 16-byte channel vector of one output pixel per thread (same arithmetic and order as the
+// scalar kernels)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear2x_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int cv = C / VW, Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * Ho * Wo * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VW;
+    long t = i / cv;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float sh = fmaxf((ho + 0.5f) * 0.5f - 0.5f, 0.f), sw = fmaxf((wo + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int h0 = (int)sh, w0 = (int)sw;
+    const int h1 = min(h0 + 1, H - 1), w1 = min(w0 + 1, W - 1);
+    const float lh = sh - h0, lw = sw - w0;
+    const T* p = x + (long)b * H * W * C + c;
+    float v00[VW], v01[VW], v10[VW], v11[VW], o[VW];
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(p + ((long)h0 * W + w0) * C), v00);
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(p + ((long)h0 * W + w1) * C), v01);
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(p + ((long)h1 * W + w0) * C), v10);
+    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(p + ((long)h1 * W + w1) * C), v11);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const float top = (1.f - lw) * v00[e] + lw * v01[e], bot = (1.f - lw) * v10[e] + lw * v11[e];
+      o[e] = (1.f - lh) * top + lh * bot;
+    }
+    *reinterpret_cast<i32x4*>(y + i * VW) = f32_to_chunk<T>(o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear2x_bwd_vec_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
+                                                                 int C) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int cv = C / VW, Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * H * W * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VW;
+    long t = i / cv;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) acc[e] = 0.f;
+    for (int ho = max(2 * h - 2, 0); ho <= min(2 * h + 3, Ho - 1); ++ho) {
+      const float sh = fmaxf((ho + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int h0 = (int)sh, h1 = min(h0 + 1, H - 1);
+      const float lh = sh - h0;
+      const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+      if (wh == 0.f) continue;
+      for (int wo = max(2 * w - 2, 0); wo <= min(2 * w + 3, Wo - 1); ++wo) {
+        const float sw = fmaxf((wo + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int w0 = (int)sw, w1 = min(w0 + 1, W - 1);
+        const float lw = sw - w0;
+        const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+        if (ww != 0.f) {
+          float v[VW];
+          chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(dy + (((long)b * Ho + ho) * Wo + wo) * C + c), v);
+#pragma unroll
+          for (int e = 0; e < VW; ++e) acc[e] += wh * ww * v[e];
+        }
+      }
+    }
+    *reinterpret_cast<i32x4*>(dx + i * VW) = f32_to_chunk<T>(acc);
+  }
+}
+
+// vector forms apply: C a multiple of the vector width, channel groups dividing the workgroup, 16-byte aligned tensors
+static bool vec_ok(int C, int dtype, std::initializer_list<const void*> ptrs) {
+  const int VW = dtype == WMZ_BF16 ? 8 : 4;
+  if (C % VW != 0 || 256 % (C / VW) != 0) return false;
+  for (const void* q : ptrs) if (q != nullptr && (((uintptr_t)q) & 15) != 0) return false;
+  return true;
+}
+
 int grid_for(long total, int per_block, int cap) {
   long b = (total + per_block - 1) / per_block;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -764,6 +956,15 @@ extern "C" int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, 
 extern "C" int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream) {
   WMZ_REQUIRE(x && sum && sq && M > 0 && C > 0, "wmz_channel_stats_nhwc: bad arguments");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_channel_stats_nhwc: bad dtype %d", dtype);
+  if (vec_ok(C, dtype, {x})) {
+    const int VW = dtype == WMZ_BF16 ? 8 : 4;
+    const long nvec = M * C / VW;
+    const int gridv = grid_for(nvec, RED_NT * 4, 256);
+    if (dtype == WMZ_BF16) hipLaunchKernelGGL(channel_stats_vec_kernel<bf16_t>, dim3(gridv), dim3(RED_NT), 0, (hipStream_t)stream, (const bf16_t*)x, nvec, C, sum, sq);
+    else hipLaunchKernelGGL(channel_stats_vec_kernel<float>, dim3(gridv), dim3(RED_NT), 0, (hipStream_t)stream, (const float*)x, nvec, C, sum, sq);
+    WMZ_LAUNCH_CHECK("wmz_channel_stats_nhwc");
+    return WMZ_OK;
+  }
   dim3 grid((unsigned)grid_for(M, 64, 512), (unsigned)wmz_cdiv(C, 64));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == WMZ_BF16) hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, C, sum, sq);
@@ -819,6 +1020,14 @@ extern "C" int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, 
   WMZ_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "wmz_bilinear2x_nhwc: bad arguments");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bilinear2x_nhwc: bad dtype %d", dtype);
   const long total = (long)B * 4 * H * W * C;
+  if (vec_ok(C, dtype, {x, y})) {
+    const int VW = dtype == WMZ_BF16 ? 8 : 4;
+    const int gridv = grid_for(total / VW, 256, 8192);
+    if (dtype == WMZ_BF16) hipLaunchKernelGGL(bilinear2x_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    else hipLaunchKernelGGL(bilinear2x_vec_kernel<float>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, H, W, C);
+    WMZ_LAUNCH_CHECK("wmz_bilinear2x_nhwc");
+    return WMZ_OK;
+  }
   const int grid = grid_for(total, 256, 8192);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == WMZ_BF16) hipLaunchKernelGGL(bilinear2x_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
@@ -834,8 +1043,19 @@ extern "C" int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* d
   WMZ_REQUIRE(!leaky || y, "wmz_bn_act_bwd_reduce: LeakyReLU backward needs the stored output y");
   WMZ_REQUIRE((sum_g == nullptr) == (sum_gx == nullptr), "wmz_bn_act_bwd_reduce: sum_g and sum_gx go together");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bn_act_bwd_reduce: bad dtype %d", dtype);
-  dim3 grid((unsigned)grid_for(M, 64, 512), (unsigned)wmz_cdiv(C, 64));
   hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(C, dtype, {x, y, dy, g_out})) {
+    const int VW = dtype == WMZ_BF16 ? 8 : 4;
+    const long nvec = M * C / VW;
+    const int gridv = grid_for(nvec, RED_NT * 4, 256);                 // (a multiple of C / VW vectors per sweep: 256 is)
+    if (dtype == WMZ_BF16)
+      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridv), dim3(RED_NT), 0, st, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, (bf16_t*)g_out, sum_g, sum_gx, nvec, C, leaky, slope);
+    else
+      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridv), dim3(RED_NT), 0, st, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, (float*)g_out, sum_g, sum_gx, nvec, C, leaky, slope);
+    WMZ_LAUNCH_CHECK("wmz_bn_act_bwd_reduce");
+    return WMZ_OK;
+  }
+  dim3 grid((unsigned)grid_for(M, 64, 512), (unsigned)wmz_cdiv(C, 64));
   if (dtype == WMZ_BF16)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, (bf16_t*)g_out, sum_g, sum_gx, M, C, leaky, slope);
   else
@@ -848,8 +1068,19 @@ extern "C" int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean,
                                 const float* sum_g, const float* sum_gx, void* dx, long M, int C, int dtype, void* stream) {
   WMZ_REQUIRE(x && g && mean && rstd && gamma && sum_g && sum_gx && dx && M > 0 && C > 0, "wmz_bn_bwd_apply: bad arguments");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bn_bwd_apply: bad dtype %d", dtype);
-  const int grid = grid_for(M * C, 256, 4096);
   hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(C, dtype, {x, g, dx})) {
+    const int VW = dtype == WMZ_BF16 ? 8 : 4;
+    const long nvec = M * C / VW;
+    const int gridv = grid_for(nvec, 256, 8192);
+    if (dtype == WMZ_BF16)
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(gridv), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M);
+    WMZ_LAUNCH_CHECK("wmz_bn_bwd_apply");
+    return WMZ_OK;
+  }
+  const int grid = grid_for(M * C, 256, 4096);
   if (dtype == WMZ_BF16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, M, C);
   else
@@ -862,8 +1093,16 @@ extern "C" int wmz_bilinear2x_nhwc_bwd(const void* dy, void* dx, int B, int H, i
   WMZ_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "wmz_bilinear2x_nhwc_bwd: bad arguments");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bilinear2x_nhwc_bwd: bad dtype %d", dtype);
   const long total = (long)B * H * W * C;
-  const int grid = grid_for(total, 256, 8192);
   hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(C, dtype, {dy, dx})) {
+    const int VW = dtype == WMZ_BF16 ? 8 : 4;
+    const int gridv = grid_for(total / VW, 256, 8192);
+    if (dtype == WMZ_BF16) hipLaunchKernelGGL(bilinear2x_bwd_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
+    else hipLaunchKernelGGL(bilinear2x_bwd_vec_kernel<float>, dim3(gridv), dim3(256), 0, st, (const float*)dy, (float*)dx, B, H, W, C);
+    WMZ_LAUNCH_CHECK("wmz_bilinear2x_nhwc_bwd");
+    return WMZ_OK;
+  }
+  const int grid = grid_for(total, 256, 8192);
   if (dtype == WMZ_BF16) hipLaunchKernelGGL(bilinear2x_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
   else hipLaunchKernelGGL(bilinear2x_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (float*)dx, B, H, W, C);
   WMZ_LAUNCH_CHECK("wmz_bilinear2x_nhwc_bwd");

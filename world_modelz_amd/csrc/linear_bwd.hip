@@ -260,7 +260,19 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restr
       if constexpr (PRO == 1) { lmu[S][it] = 0.f; lrs[S][it] = 0.f; }
       if (m < m_end) {
         if (n0 + c * EPC < P.N) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * EPC);
-        if (k0 + c * EPC < P.K) {
+        if constexpr (PRO == 3) {
+          // implicit im2col of an NHWC tensor: row m = output pixel, k = (kh, kw, ci); taps outside the image are zero
+          const int k = k0 + c * EPC;
+          if (k < P.K) {
+            const int tap = k / P.Cin, ci = k - tap * P.Cin;
+            const int kh = tap / P.KW, kw = tap - kh * P.KW;
+            const int wo = m % P.Wo, t = m / P.Wo;
+            const int ho = t % P.Ho, b = t / P.Ho;
+            const int hi = ho * P.cstride - P.cpad + kh, wi = wo * P.cstride - P.cpad + kw;
+            if (hi >= 0 && hi < P.Hi && wi >= 0 && wi < P.Wi)
+              ra[it] = *reinterpret_cast<const i32x4*>(A + (((long)b * P.Hi + hi) * P.Wi + wi) * P.Cin + ci);
+          }
+        } else if (k0 + c * EPC < P.K) {
           // (tiled: 16-byte chunk cg = 16 h + s of row m sits at ((2 s + h) * 32 + m % 32) * 16 bytes of its 32-row tile:
           //  a slab's rows of one chunk column are one contiguous 512-byte run)
           const int cg = (k0 >> 3) + c;
@@ -696,8 +708,8 @@ int wg_batch_launch(const WgBatch& B, const RedBatch& R, int pro, float* workspa
   const int n = B.n;
   dim3 grid((unsigned)B.first[n]), block(NT);
 #define WMZ_WG2(T, PRO) hipLaunchKernelGGL((wgrad2_kernel<T, PRO>), grid, block, 0, st, B, workspace)
-  if (dtype == WMZ_BF16) { if (pro == 1) WMZ_WG2(bf16_t, 1); else if (pro == 2) WMZ_WG2(bf16_t, 2); else WMZ_WG2(bf16_t, 0); }
-  else { if (pro == 1) WMZ_WG2(float, 1); else if (pro == 2) WMZ_WG2(float, 2); else WMZ_WG2(float, 0); }
+  if (dtype == WMZ_BF16) { if (pro == 1) WMZ_WG2(bf16_t, 1); else if (pro == 2) WMZ_WG2(bf16_t, 2); else if (pro == 3) WMZ_WG2(bf16_t, 3); else WMZ_WG2(bf16_t, 0); }
+  else { if (pro == 1) WMZ_WG2(float, 1); else if (pro == 2) WMZ_WG2(float, 2); else if (pro == 3) WMZ_WG2(float, 3); else WMZ_WG2(float, 0); }
 #undef WMZ_WG2
   const RedProb& L = R.p[n - 1];
   const int nred = L.first + L.nblk_w + (L.dbias != nullptr ? wmz_cdiv(L.N, 64) : 0);
@@ -784,6 +796,39 @@ extern "C" int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, f
   if (dtype == WMZ_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3>), grid, block, 0, st, P);
   else hipLaunchKernelGGL((wgrad_kernel<float, 3>), grid, block, 0, st, P);
   WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_wgrad");
+  return WMZ_OK;
+}
+
+// The same gradient by the two-stage reduction of wmz_linear_wgrad_ws (partial tiles in a caller-owned workspace, summed in a
+// fixed order): no float atomics -- the split-K atomics above are chains of ~30 same-address adds per element of dW (93 us per
+// call on the VQ-AE's 3x3 layers) --, and `overwrite` saves the caller the zero fill.
+extern "C" long wmz_conv2d_nhwc_wgrad_workspace_floats(int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride,
+                                                       int pad, int dtype) {
+  const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  return wmz_linear_wgrad_workspace_floats(B * Ho * Wo, Cout, KH * KW * Cin, dtype);
+}
+extern "C" int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin,
+                                        int Cout, int KH, int KW, int stride, int pad, int overwrite, float* workspace,
+                                        long workspace_floats, int dtype, void* stream) {
+  WMZ_REQUIRE(x && dy && dW && workspace, "wmz_conv2d_nhwc_wgrad_ws: null tensor");
+  WMZ_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "wmz_conv2d_nhwc_wgrad_ws: bad shape");
+  WMZ_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "wmz_conv2d_nhwc_wgrad_ws: Cin and Cout must be multiples of 8 (zero-pad)");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_conv2d_nhwc_wgrad_ws: bad dtype %d", dtype);
+  const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;
+  WMZ_REQUIRE(Ho > 0 && Wo > 0, "wmz_conv2d_nhwc_wgrad_ws: empty output");
+  WMZ_REQUIRE((long)B * Ho * Wo < (1L << 31), "wmz_conv2d_nhwc_wgrad_ws: too many output pixels");
+  const int M = B * Ho * Wo, K = KH * KW * Cin;
+  WMZ_REQUIRE(workspace_floats >= wmz_linear_wgrad_workspace_floats(M, Cout, K, dtype), "wmz_conv2d_nhwc_wgrad_ws: workspace too small");
+  WgBatch Bt;
+  RedBatch R;
+  Bt.n = R.n = 1;
+  Bt.first[0] = 0;
+  wg_batch_add(Bt, R, 0, dy, Cout, x, 0, dW, dbias, M, Cout, K, nullptr, nullptr, nullptr, nullptr, 0, overwrite, dtype, 0);
+  WgParams& P = Bt.p[0];
+  P.Hi = Hi; P.Wi = Wi; P.Cin = Cin; P.KW = KW; P.cstride = stride; P.cpad = pad; P.Ho = Ho; P.Wo = Wo;
+  wg_batch_launch(Bt, R, 3, workspace, dtype, (hipStream_t)stream);
+  WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_wgrad_ws");
   return WMZ_OK;
 }
 

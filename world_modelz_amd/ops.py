@@ -409,10 +409,12 @@ def conv2d_nhwc_wgrad(x, dy, KH, KW, stride, pad, want_bias):
     B, Hi, Wi, Cin = x.shape
     Cout = dy.shape[-1]
     assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
-    dw = torch.zeros((Cout, KH * KW * Cin), dtype=torch.float32, device=x.device)
-    db = torch.zeros((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    L.call('wmz_conv2d_nhwc_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad,
-           L.dtype_code(x.dtype), L.stream())
+    dt = L.dtype_code(x.dtype)
+    dw = torch.empty((Cout, KH * KW * Cin), dtype=torch.float32, device=x.device)        # stored, not accumulated: no zero fill
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    ws = _workspace(x.device, L.lib().wmz_conv2d_nhwc_wgrad_workspace_floats(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dt))
+    L.call('wmz_conv2d_nhwc_wgrad_ws', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 1,
+           L.ptr(ws), ws.numel(), dt, L.stream())
     return dw, db
 
 
