@@ -316,6 +316,12 @@ int wmz_qkv_fused_bwd(const void* dq, long lddq, const void* dkv, long lddkv, co
                       const void* res, void* dx, void* xhat_out, const void* wpack, int ntok, int D, int I, void* stream);
 int wmz_ln_affine_grads(const float* G, const float* s, const float* W, const float* gamma, const float* beta, float* dW,
                         float* dbias, float* dgamma, float* dbeta, int N, int K, int bias_from, void* stream);
+/* n <= 4 such conversions by one launch (HOST tables of n entries; dbias[i] may be NULL): a layer's two -- the feed-forward's
+ * W1 and the k | v projection -- are each a grid of a few latency-bound workgroups. */
+int wmz_ln_affine_grads_batch(int n, const float* const* G, const float* const* s, const float* const* W,
+                              const float* const* gamma, const float* const* beta, float* const* dW, float* const* dbias,
+                              float* const* dgamma, float* const* dbeta, const int* N, const int* K, const int* bias_from,
+                              void* stream);
 
 /* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
  * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */

@@ -155,6 +155,19 @@ def test_ln_affine_grads_vs_torch():
            L.ptr(db), N, K, 128, L.stream())
     for a, b in zip((dW, dbias, dg, db), ref):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+    # the batched call: two problems of different shapes in one launch (the grid covers the larger; dbias may be NULL)
+    from world_modelz_amd import fused
+    N2, K2 = 72, 128
+    G2, W2 = torch.randn(N2, K2, device='cuda'), torch.randn(N2, K2, device='cuda')
+    s2, ga2, be2 = torch.randn(N2, device='cuda'), torch.randn(K2, device='cuda'), torch.randn(K2, device='cuda')
+    dW1, dbias1, dg1, db1 = (torch.zeros_like(t) for t in (dW, dbias, dg, db))
+    dW2, dg2, db2 = torch.zeros(N2, K2, device='cuda'), torch.zeros(K2, device='cuda'), torch.zeros(K2, device='cuda')
+    fused._ln_affine_grads_batch([(G, s, W, gamma, beta, dW1, dbias1, dg1, db1, N, K, 128),
+                                  (G2, s2, W2, ga2, be2, dW2, None, dg2, db2, N2, K2, 0)])
+    ref1 = (G * gamma + s[:, None] * beta, s[128:], (W * G).sum(0), W.t() @ s)
+    ref2 = (G2 * ga2 + s2[:, None] * be2, (W2 * G2).sum(0), W2.t() @ s2)
+    for a, b in zip((dW1, dbias1, dg1, db1, dW2, dg2, db2), ref1 + ref2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
 
 
 def test_pack_set_equals_the_per_stream_packers():

@@ -57,6 +57,7 @@ SIGNATURES = {
     'wmz_ff_fused_bwd': [c_void_p] * 10 + [c_int] * 6 + [c_void_p, c_void_p],
     'wmz_qkv_fused_bwd': [c_void_p, c_long, c_void_p, c_long] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p],
     'wmz_ln_affine_grads': [c_void_p] * 9 + [c_int] * 3 + [c_void_p],
+    'wmz_ln_affine_grads_batch': [c_int] + [c_void_p] * 12 + [c_void_p],
     'wmz_embed_qkv_fused_fwd_train': [c_void_p] * 12 + [c_int] * 9 + [c_float, c_void_p],
     'wmz_layer_fused_fwd_planes': [c_void_p] * 7 + [c_int] * 10 + [c_float, c_void_p],
     'wmz_embed_qkv_fused_fwd_planes': [c_void_p] * 10 + [c_int] * 10 + [c_float, c_void_p],

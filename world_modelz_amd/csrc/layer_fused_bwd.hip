@@ -350,11 +350,21 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void ff_bwd_kernel(BwdParams P) {
 // dbias[n] += s[n] for n >= bias_from (to_k has no bias: the k | v gradient shares one call).  A workgroup owns 64 columns
 // x 8 rows: thread (row group rg = tid / 64, column) walks 2 rows, the four row groups meet in LDS, one atomic per column
 // (128 workgroups for a 256 x 256 weight: the kernel is pure latency, short chains and many workgroups keep it at ~3 us).
-__global__ __launch_bounds__(256) void ln_affine_grads_kernel(const float* __restrict__ G, const float* __restrict__ s,
-                                                              const float* __restrict__ W, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ dW,
-                                                              float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int N, int K, int bias_from) {
+struct LnAffineProb { const float *G, *s, *W, *gamma, *beta; float *dW, *dbias, *dgamma, *dbeta; int N, K, bias_from; };
+struct LnAffineBatch { LnAffineProb p[4]; };      // blockIdx.z selects the problem (a layer has two: feed-forward and k | v)
+__global__ __launch_bounds__(256) void ln_affine_grads_kernel(LnAffineBatch Bt) {
+  const LnAffineProb& Q = Bt.p[blockIdx.z];
+  const float* __restrict__ G = Q.G;
+  const float* __restrict__ s = Q.s;
+  const float* __restrict__ W = Q.W;
+  const float* __restrict__ gamma = Q.gamma;
+  const float* __restrict__ beta = Q.beta;
+  float* __restrict__ dW = Q.dW;
+  float* __restrict__ dbias = Q.dbias;
+  float* __restrict__ dgamma = Q.dgamma;
+  float* __restrict__ dbeta = Q.dbeta;
+  const int N = Q.N, K = Q.K, bias_from = Q.bias_from;
+  if ((int)blockIdx.x * 64 >= K || (int)blockIdx.y * 8 >= N) return;       // (the grid covers the largest problem of the batch)
   __shared__ float red[2][4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + c;
@@ -458,8 +468,30 @@ extern "C" int wmz_ln_affine_grads(const float* G, const float* s, const float* 
                                    void* stream) {
   WMZ_REQUIRE(G && s && W && gamma && beta && dW && dgamma && dbeta && N > 0 && K > 0, "wmz_ln_affine_grads: bad arguments");
   WMZ_REQUIRE(bias_from >= 0 && bias_from <= N, "wmz_ln_affine_grads: bad bias_from");
-  hipLaunchKernelGGL(ln_affine_grads_kernel, dim3((unsigned)wmz_cdiv(K, 64), (unsigned)wmz_cdiv(N, 8)), dim3(256), 0,
-                     (hipStream_t)stream, G, s, W, gamma, beta, dW, dbias, dgamma, dbeta, N, K, bias_from);
+  LnAffineBatch Bt = {};
+  Bt.p[0] = LnAffineProb{G, s, W, gamma, beta, dW, dbias, dgamma, dbeta, N, K, bias_from};
+  hipLaunchKernelGGL(ln_affine_grads_kernel, dim3((unsigned)wmz_cdiv(K, 64), (unsigned)wmz_cdiv(N, 8), 1), dim3(256), 0,
+                     (hipStream_t)stream, Bt);
   WMZ_LAUNCH_CHECK("wmz_ln_affine_grads");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_ln_affine_grads_batch(int n, const float* const* G, const float* const* s, const float* const* W,
+                                         const float* const* gamma, const float* const* beta, float* const* dW,
+                                         float* const* dbias, float* const* dgamma, float* const* dbeta, const int* N,
+                                         const int* K, const int* bias_from, void* stream) {
+  WMZ_REQUIRE(n >= 1 && n <= 4, "wmz_ln_affine_grads_batch: 1 .. 4 problems per call (got %d)", n);
+  WMZ_REQUIRE(G && s && W && gamma && beta && dW && dbias && dgamma && dbeta && N && K && bias_from, "wmz_ln_affine_grads_batch: null table");
+  LnAffineBatch Bt = {};
+  int gx = 0, gy = 0;
+  for (int i = 0; i < n; ++i) {
+    WMZ_REQUIRE(G[i] && s[i] && W[i] && gamma[i] && beta[i] && dW[i] && dgamma[i] && dbeta[i] && N[i] > 0 && K[i] > 0 &&
+                bias_from[i] >= 0 && bias_from[i] <= N[i], "wmz_ln_affine_grads_batch: bad problem %d", i);
+    Bt.p[i] = LnAffineProb{G[i], s[i], W[i], gamma[i], beta[i], dW[i], dbias[i], dgamma[i], dbeta[i], N[i], K[i], bias_from[i]};
+    gx = gx > wmz_cdiv(K[i], 64) ? gx : wmz_cdiv(K[i], 64);
+    gy = gy > wmz_cdiv(N[i], 8) ? gy : wmz_cdiv(N[i], 8);
+  }
+  hipLaunchKernelGGL(ln_affine_grads_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)n), dim3(256), 0, (hipStream_t)stream, Bt);
+  WMZ_LAUNCH_CHECK("wmz_ln_affine_grads_batch");
   return WMZ_OK;
 }

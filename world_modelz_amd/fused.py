@@ -372,6 +372,21 @@ def _zero_row(dev):
     return z
 
 
+def _ln_affine_grads_batch(probs):
+    """wmz_ln_affine_grads_batch on a list of (G, s, W, gamma, beta, dW, dbias | None, dgamma, dbeta, N, K, bias_from)."""
+    import ctypes
+    n = len(probs)
+    vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+    cols = [vp() for _ in range(9)]
+    Ns, Ks, bf = ci(), ci(), ci()
+    for i, pr in enumerate(probs):
+        for j in range(9):
+            t = pr[j]
+            cols[j][i] = L.ptr(t.detach() if (t is not None and t.requires_grad) else t)
+        Ns[i], Ks[i], bf[i] = pr[9], pr[10], pr[11]
+    L.call('wmz_ln_affine_grads_batch', n, *cols, Ns, Ks, bf, L.stream())
+
+
 def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff, zt, dy_last=None, x_in_tiled=None):
     """One layer of the stack's backward on the fused per-token kernels: wmz_ff_fused_bwd -> attention backward ->
     wmz_qkv_fused_bwd, the weight gradients as plain GEMMs over the operands those kernels write, the LayerNorm affine
@@ -428,22 +443,19 @@ def _layer_backward_fused(attn, ff, dy, x_in, q, kv, o, lse, x1, st_attn, st_ff,
         (dq.reshape(ntok, I_), x_q, s_q.bufs[0], None, False, x_q_tiled),
         (dkv.reshape(ntok, 2 * I_), xhat, Gkv, ckv, True)])
     s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
-    L.call('wmz_ln_affine_grads', L.ptr(G1), L.ptr(c1), L.ptr(w1.detach()), L.ptr(fn_g.detach()), L.ptr(fn_b.detach()),
-           L.ptr(s_ff1.bufs[0]), L.ptr(s_ff1.bufs[1]), L.ptr(s_ff1.bufs[2]), L.ptr(s_ff1.bufs[3]), M_, D_, 0, L.stream())
     s_kv = _GradSink(wk, wv, bv, an_g, an_b)
     bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
     adjacent = (wk.is_contiguous() and wv.is_contiguous() and bk_.is_contiguous() and bw_.is_contiguous()
                 and wv.data_ptr() == wk.data_ptr() + 4 * wk.numel() and bw_.data_ptr() == bk_.data_ptr() + 4 * bk_.numel())
+    # one launch for the layer's LayerNorm-affine conversions: (G, s, W, gamma, beta, dW, dbias, dgamma, dbeta, N, K, bias_from)
+    probs = [(G1, c1, w1, fn_g, fn_b, s_ff1.bufs[0], s_ff1.bufs[1], s_ff1.bufs[2], s_ff1.bufs[3], M_, D_, 0)]
     # (the kernel only does pointer arithmetic on W and dW: two separately allocated neighbours are as good as one arena)
     if adjacent:                        # FlatArena: to_k.weight | to_v.weight (and their gradients) are one [2I, D] block
-        L.call('wmz_ln_affine_grads', L.ptr(Gkv), L.ptr(ckv), L.ptr(wk.detach()), L.ptr(an_g.detach()), L.ptr(an_b.detach()),
-               L.ptr(bk_), L.ptr(s_kv.bufs[2]), L.ptr(s_kv.bufs[3]), L.ptr(s_kv.bufs[4]), 2 * I_, D_, I_, L.stream())
+        probs.append((Gkv, ckv, wk, an_g, an_b, bk_, s_kv.bufs[2], s_kv.bufs[3], s_kv.bufs[4], 2 * I_, D_, I_))
     else:
-        L.call('wmz_ln_affine_grads', L.ptr(Gkv[:I_]), L.ptr(ckv[:I_]), L.ptr(wk.detach()), L.ptr(an_g.detach()),
-               L.ptr(an_b.detach()), L.ptr(bk_), None, L.ptr(s_kv.bufs[3]), L.ptr(s_kv.bufs[4]), I_, D_, I_, L.stream())
-        L.call('wmz_ln_affine_grads', L.ptr(Gkv[I_:]), L.ptr(ckv[I_:]), L.ptr(wv.detach()), L.ptr(an_g.detach()),
-               L.ptr(an_b.detach()), L.ptr(bw_), L.ptr(s_kv.bufs[2]), L.ptr(s_kv.bufs[3]), L.ptr(s_kv.bufs[4]), I_, D_, 0,
-               L.stream())
+        probs.append((Gkv[:I_], ckv[:I_], wk, an_g, an_b, bk_, None, s_kv.bufs[3], s_kv.bufs[4], I_, D_, I_))
+        probs.append((Gkv[I_:], ckv[I_:], wv, an_g, an_b, bw_, s_kv.bufs[2], s_kv.bufs[3], s_kv.bufs[4], I_, D_, 0))
+    _ln_affine_grads_batch(probs)
     g_wk, g_wv, g_bv, g_ag, g_ab = s_kv.done()
     (g_wq,) = s_q.done()
     g_wout, g_bout = s_out.done()
