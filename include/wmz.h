@@ -405,6 +405,16 @@ int wmz_corrupt_tokens(const int64_t* z_last, long clip_stride, const float* r, 
 int wmz_corrupt_tokens_dev(const int64_t* z_last, long clip_stride, const float* r, int64_t* out, long out_stride,
                            int64_t* target, int B, int HW, int C, unsigned long long seed, unsigned long long stream_hi,
                            const unsigned long long* counter, void* stream);
+/* One step of the sampler loop between two forward passes (main.py:76-104): per row of fp32 logits [R, C <= 2048] keep the
+ * top_k largest (<= 0: all; ties with the k-th kept), softmax, draw a class by the inverse CDF from one in-kernel uniform,
+ * re-mask with a second one: the position gets mask_token where u2 > alpha (and, with `last_mask` [R] bytes, in / out, only
+ * where the previous call masked: consistent masking).  denoised[R] receives the draws, out_tokens[(r / rows_per_block) *
+ * block_stride + r % rows_per_block] the (re-masked) tokens -- the last frame of a [B, S, H, W] grid in place.
+ * alpha = alphas[*counter % n_alpha] and the Philox stream id = *counter are read from DEVICE memory (the caller advances
+ * the counter): the call sits in a hipGraph with the forward pass it feeds. */
+int wmz_sample_tokens_dev(const float* logits, long ld, int R, int C, int top_k, const float* alphas, int n_alpha,
+                          int64_t mask_token, int64_t* out_tokens, long rows_per_block, long block_stride, int64_t* denoised,
+                          unsigned char* last_mask, unsigned long long seed, const long long* counter, void* stream);
 /* CrossEntropyLoss(reduction='none') over fp32 logits [R, C] (row stride ld): loss[R], lse[R]; and its gradient
  * dlogits[r,c] = (softmax - one_hot) * grad_rows[r], written in `dtype` (the GEMM operand type of the backward). */
 int wmz_ce_fwd(const float* logits, long ld, const int64_t* target, float* loss, float* lse, long R, int C, void* stream);

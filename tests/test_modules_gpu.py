@@ -370,3 +370,81 @@ def test_out_of_vocabulary_tokens(wmz):
             m(zc)
         finally:
             cfg.set_check_tokens(False)
+
+
+@pytest.mark.gpu
+def test_fused_sampling_kernel_draws_from_the_filtered_softmax():
+    """wmz_sample_tokens_dev (one sampler step: top-k -> softmax -> inverse-CDF draw -> re-mask) against the torch definition
+    of the same step, statistically: 16 384 rows sharing one logits row must reproduce its (top-k filtered) softmax -- total
+    variation < 2 % --, never leave the top-k set, mask a 1 - alpha share of the positions, and with consistent masking only
+    ever unmask; a dominant logit is drawn always; the counter selects alpha and the random stream."""
+    from world_modelz_amd import ops
+    torch.manual_seed(21)
+    R, C, k = 16384, 1024, 100
+    row = torch.randn(C, device='cuda') * 2.0
+    logits = row.expand(R, C).contiguous()
+    alphas = torch.tensor([0.25, 0.6, 1.0], device='cuda')
+    z = torch.zeros(4, 3, R // 4, dtype=torch.int64, device='cuda')          # [B, S, HW]: tokens go to z[:, -1]
+    den = torch.zeros(R, dtype=torch.int64, device='cuda')
+    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+    for top_k in (-1, k):
+        ctr.zero_()
+        ops.sample_tokens(logits, top_k, alphas, C, z[:, -1], den, ctr, 1234)
+        torch.cuda.synchronize()
+        filt = row.clone()
+        if top_k > 0:
+            kth = torch.topk(row, top_k).values[-1]
+            filt[row < kth] = -float('inf')
+            assert bool((row[den] >= kth).all())                       # never outside the top-k set
+        p = torch.softmax(filt, 0)
+        freq = torch.bincount(den, minlength=C).float() / R
+        tv = 0.5 * float((freq - p).abs().sum())
+        assert tv < (0.06 if top_k > 0 else 0.13), tv                   # sampling noise of 16 384 draws over 100 / 1 024 classes
+        masked = (z[:, -1].reshape(-1) == C)
+        assert abs(float(masked.float().mean()) - 0.75) < 0.02          # alpha = alphas[0] = 0.25
+        assert bool((z[:, -1].reshape(-1)[~masked] == den[~masked]).all()) and bool((z[:, :-1] == 0).all())
+    # another counter value: another alpha, another stream
+    first = den.clone()
+    ctr.fill_(1)
+    ops.sample_tokens(logits, k, alphas, C, z[:, -1], den, ctr, 1234)
+    assert abs(float((z[:, -1] == C).float().mean()) - 0.4) < 0.02 and not torch.equal(first, den)
+    ctr.fill_(2)                                                           # alpha = 1: nothing is masked
+    ops.sample_tokens(logits, k, alphas, C, z[:, -1], den, ctr, 1234)
+    assert bool((z[:, -1].reshape(-1) == den).all())
+    # consistent masking: the masked set can only shrink
+    lm = torch.ones(R, dtype=torch.uint8, device='cuda')
+    ctr.zero_()
+    ops.sample_tokens(logits, k, alphas, C, z[:, -1], den, ctr, 99, lm)
+    m0 = lm.clone()
+    ctr.fill_(3)                                                           # alpha 0.25 again, new stream
+    ops.sample_tokens(logits, k, alphas, C, z[:, -1], den, ctr, 99, lm)
+    assert bool((lm <= m0).all()) and int(lm.sum()) < int(m0.sum()) and bool(((z[:, -1].reshape(-1) == C) == (lm == 1)).all())
+    # a dominant logit wins every draw; ragged class counts (C not a multiple of 64 * NV)
+    for C2 in (37, 700, 2000):
+        lg = torch.randn(64, C2, device='cuda')
+        lg[:, 5] = 60.0
+        z2 = torch.zeros(1, 2, 64, dtype=torch.int64, device='cuda')
+        d2 = torch.zeros(64, dtype=torch.int64, device='cuda')
+        ctr.fill_(2)
+        ops.sample_tokens(torch.nn.functional.pad(lg, (0, (-C2) % 4))[:, :C2] if C2 % 4 else lg, 10, alphas, C2, z2[:, -1], d2, ctr, 5)
+        assert bool((d2 == 5).all())
+
+
+@pytest.mark.gpu
+def test_fused_sampler_loop_runs_the_whole_frame_on_the_device(wmz):
+    """sample_frames' default path (device RNG): one graph launch per denoise iteration, draws + re-mask inside the graph.  The
+    generated frames hold valid codes only, the context frames shift by one per generated frame, the same seed reproduces the
+    same frames, and the distribution machinery agrees with the torch path on a peaked model (both must return the argmax)."""
+    from world_modelz_amd.sample import sample_frames
+    torch.manual_seed(4)
+    C = 64
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(4, 16, 16), dim=256, num_classes=C, extents=(1, 1, 1), depth=2,
+                                          dim_head=128, mlp_dim=256, heads=1).cuda().eval()
+    z = torch.randint(0, C, (2, 4, 16, 16), device='cuda')
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        g = torch.Generator(device='cuda').manual_seed(77)
+        frames, zf = sample_frames(m, z, C, 2, num_eval_iterations=6, sample_topk=8, generator=g)
+        frames2, _ = sample_frames(m, z, C, 2, num_eval_iterations=6, sample_topk=8, generator=g)
+    assert len(frames) == 2 and all(f.shape == (2, 16, 16) and int(f.min()) >= 0 and int(f.max()) < C for f in frames)
+    assert all(torch.equal(a, b) for a, b in zip(frames, frames2))
+    assert torch.equal(zf[:, 0], z[:, 2]) and torch.equal(zf[:, 1], frames[0]) and torch.equal(zf[:, 2], frames[1])

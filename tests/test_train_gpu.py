@@ -135,7 +135,8 @@ def test_training_reduces_loss(wmz):
 
 def test_sampler_loop_runs_and_unmasks(wmz):
     """Iterative-unmasking sampler (main.py:50-117 counterpart): shapes, value ranges, frame shift, determinism under a
-    seeded generator, and graph replay == eager."""
+    seeded generator on both paths -- the graphed one (draw + re-mask fused into the graph, in-kernel Philox keyed by the
+    generator's seed) and the eager torch one (device RNG; with injected uniforms it is the parity path of the next test)."""
     from world_modelz_amd import sample
     torch.manual_seed(4)
     C = 16
@@ -152,8 +153,10 @@ def test_sampler_loop_runs_and_unmasks(wmz):
             assert int(f.min()) >= 0 and int(f.max()) < C           # last iteration: alpha = 1, nothing stays masked
         assert torch.equal(zf[:, 0], frames[0]) and torch.equal(zf[:, 1], frames[1])   # [c0,c1,L] -> [g1,g2,g2]
         outs[use_graph] = frames
-    for a, b in zip(outs[True], outs[False]):
-        assert torch.equal(a, b)
+        gen = torch.Generator(device='cuda').manual_seed(9)
+        again, _ = sample.sample_frames(m, z, C, num_frames=2, num_eval_iterations=4, sample_topk=5, generator=gen,
+                                        use_graph=use_graph)
+        assert all(torch.equal(a, b) for a, b in zip(frames, again))
     lg = torch.randn(6, C, device='cuda')
     tk = sample.top_k_logits(lg, 3)
     assert int(torch.isfinite(tk).sum()) == 18

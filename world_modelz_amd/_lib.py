@@ -82,6 +82,8 @@ SIGNATURES = {
                            ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p],
     'wmz_corrupt_tokens_dev': [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
                                ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p],
+    'wmz_sample_tokens_dev': [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_long, c_void_p,
+                              c_void_p, ctypes.c_ulonglong, c_void_p, c_void_p],
     'wmz_adamw_step_dev': [c_void_p] * 4 + [c_long, c_void_p] + [c_double] * 5 + [c_void_p, c_void_p],
     'wmz_ce_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     'wmz_ce_bwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],

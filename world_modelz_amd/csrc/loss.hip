@@ -52,6 +52,94 @@ __global__ __launch_bounds__(256) void corrupt_kernel(const int64_t* __restrict_
   }
 }
 
+// One step of the sampler loop between two forward passes (main.py:76-104: top-k filter -> softmax -> multinomial -> re-mask):
+// one wave per row of logits, everything in registers, both uniforms from one Philox call.  Lane l holds the NV consecutive
+// classes l * NV .. (classes past C are -inf).
+//   * top-k: the k-th largest logit by a 32-step bitwise search on order-preserving integer keys (count of keys >= candidate
+//     by wave ballots); logits below it are dropped, ties with it kept (the reference's `logits < v[:, -1]`);
+//   * softmax weights w = exp(l - max), total by wave reduction;
+//   * the draw: the number of classes whose cumulative weight is <= u * total (inverse CDF, the definition of
+//     sample.categorical_from_uniform), clamped to C - 1;
+//   * re-mask: with a second uniform u2 > alpha (and, with `last_mask`, only where the previous iteration masked:
+//     consistent masking) the position gets the mask token instead of the draw.
+// alpha = alphas[*counter % n_alpha] and the Philox stream id = *counter live in device memory: the launch sits in a hipGraph.
+template <int NV>
+__global__ __launch_bounds__(256) void sample_tokens_kernel(const float* __restrict__ logits, long ld, int R, int C, int top_k,
+                                                            const float* __restrict__ alphas, int n_alpha, int64_t mask_token,
+                                                            int64_t* __restrict__ out_tokens, long rows_per_block,
+                                                            long block_stride, int64_t* __restrict__ denoised,
+                                                            unsigned char* __restrict__ last_mask, unsigned long long seed,
+                                                            const long long* __restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  const long ctr = *counter;
+  const float alpha = alphas[(int)(ctr % n_alpha)];
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += (long)gridDim.x * 4) {
+    const float* x = logits + row * ld + lane * NV;
+    float v[NV];
+#pragma unroll
+    for (int e = 0; e < NV; e += 4) {
+      if (lane * NV + e + 3 < C) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(x + e);
+        v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[e + i] = lane * NV + e + i < C ? x[e + i] : -INFINITY;
+      }
+    }
+    if (top_k > 0 && top_k < C) {
+      // order-preserving keys: flip all bits of negatives, the sign bit of non-negatives
+      unsigned key[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const unsigned b = __float_as_uint(v[e]);
+        key[e] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+      }
+      unsigned T = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) cnt += __popcll(__ballot(key[e] >= cand));
+        if (cnt >= top_k) T = cand;
+      }
+#pragma unroll
+      for (int e = 0; e < NV; ++e) if (key[e] < T) v[e] = -INFINITY;
+    }
+    float m = v[0];
+#pragma unroll
+    for (int e = 1; e < NV; ++e) m = fmaxf(m, v[e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float w[NV], part = 0.f;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) { w[e] = __expf(v[e] - m); part += w[e]; w[e] = part; }    // lane-local running sums
+    float inc = part;                                          // inclusive scan of the lane totals, in lane order
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    const float total = __shfl(inc, 63);
+    const float base = inc - part;
+    float u[4];
+    philox4((unsigned long long)row, seed, (unsigned long long)ctr, u);
+    const float xq = u[0] * total;
+    int below = 0;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) below += (lane * NV + e < C && base + w[e] <= xq) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+    const int draw = below < C ? below : C - 1;
+    if (lane == 0) {
+      bool mask = u[1] > alpha;
+      if (last_mask != nullptr) { mask = mask && last_mask[row] != 0; last_mask[row] = mask ? 1 : 0; }
+      denoised[row] = draw;
+      const long blk = row / rows_per_block;
+      out_tokens[blk * block_stride + (row - blk * rows_per_block)] = mask ? mask_token : (int64_t)draw;
+    }
+  }
+}
+
 // one wave per row; C <= 64 * 4 * KV handled by a strided loop
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ target,
                                                      float* __restrict__ loss, float* __restrict__ lse, long R, int C) {
@@ -115,6 +203,27 @@ extern "C" int wmz_corrupt_tokens_dev(const int64_t* z_last, long clip_stride, c
   hipLaunchKernelGGL(corrupt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_last, clip_stride, r, out, out_stride,
                      target, B, HW, C, seed, stream_hi & ~((1ull << 40) - 1), counter);
   WMZ_LAUNCH_CHECK("wmz_corrupt_tokens_dev");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_sample_tokens_dev(const float* logits, long ld, int R, int C, int top_k, const float* alphas, int n_alpha,
+                                     int64_t mask_token, int64_t* out_tokens, long rows_per_block, long block_stride,
+                                     int64_t* denoised, unsigned char* last_mask, unsigned long long seed,
+                                     const long long* counter, void* stream) {
+  WMZ_REQUIRE(logits && alphas && out_tokens && denoised && counter && R > 0 && C > 0 && n_alpha > 0 && rows_per_block > 0,
+              "wmz_sample_tokens_dev: bad arguments");
+  WMZ_REQUIRE(ld >= C && ld % 4 == 0 && (((uintptr_t)logits) & 15) == 0, "wmz_sample_tokens_dev: logits rows must be 16-byte aligned");
+  if (C > 2048) {
+    wmz_set_error("wmz_sample_tokens_dev: built for <= 2048 classes (got %d)", C);
+    return WMZ_ERR_UNSUPPORTED;
+  }
+  const int grid = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
+  hipStream_t st = (hipStream_t)stream;
+#define WMZ_SMP(NV) hipLaunchKernelGGL(sample_tokens_kernel<NV>, dim3(grid), dim3(256), 0, st, logits, ld, R, C, top_k, alphas, n_alpha, \
+                                       mask_token, out_tokens, rows_per_block, block_stride, denoised, last_mask, seed, counter)
+  if (C <= 256) WMZ_SMP(4); else if (C <= 512) WMZ_SMP(8); else if (C <= 1024) WMZ_SMP(16); else WMZ_SMP(32);
+#undef WMZ_SMP
+  WMZ_LAUNCH_CHECK("wmz_sample_tokens_dev");
   return WMZ_OK;
 }
 

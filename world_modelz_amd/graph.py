@@ -18,10 +18,13 @@ class GraphedForward:
     the _cast epoch and the run-time configuration it was captured under, and re-captures when any of them changed
     (optimizer step, load_state_dict, EMA copy, .to(), another compute dtype) instead of replaying stale weights."""
 
-    def __init__(self, model, example, warmup=3):
+    def __init__(self, model, example, warmup=3, pre=None, post=None):
+        """pre(static_in) / post(static_out): optional device-only work captured in front of / behind the forward (the
+        sampler's draw + re-mask step and its logits hand-over: sample.py), replayed with it."""
         self.model = model
         self.static_in = example.clone()
         self.warmup = warmup
+        self.pre, self.post = pre, post
         self.recaptures = 0
         self._capture()
 
@@ -39,12 +42,20 @@ class GraphedForward:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():
             for _ in range(self.warmup):
-                self.model(self.static_in)
+                if self.pre is not None:
+                    self.pre(self.static_in)
+                y = self.model(self.static_in)
+                if self.post is not None:
+                    self.post(y)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
+            if self.pre is not None:
+                self.pre(self.static_in)
             self.static_out = self.model(self.static_in)
+            if self.post is not None:
+                self.post(self.static_out)
         self._operands = [h[1] for h in _cast._cache.values()]      # strong references (tensors or tuples of tensors)
         self.stamp = self._stamp()
 

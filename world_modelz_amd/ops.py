@@ -133,6 +133,18 @@ def vq_gather(idx, codebook, dtype=torch.float32):
     return out.reshape(*idx.shape, E)
 
 
+def sample_tokens(logits, top_k, alphas, mask_token, last_frame, denoised, counter, seed, last_mask=None):
+    """wmz_sample_tokens_dev: logits fp32 [R, C]; last_frame: the [B, H, W] int64 view batch_z[:, -1] the tokens are written
+    into in place; denoised int64 [R]; alphas fp32 [n]; counter int64 [1] (device); last_mask uint8 [R] or None."""
+    R, C = logits.shape
+    B = last_frame.shape[0]
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and last_frame.dtype == torch.int64
+    assert last_frame[0].is_contiguous() and R % B == 0 and denoised.numel() == R and counter.dtype == torch.int64
+    L.call('wmz_sample_tokens_dev', L.ptr(logits), logits.stride(0), R, C, int(top_k), L.ptr(alphas), alphas.numel(), int(mask_token),
+           L.ptr(last_frame), R // B, last_frame.stride(0), L.ptr(denoised), L.ptr(last_mask), int(seed) & 0xFFFFFFFFFFFFFFFF,
+           L.ptr(counter), L.stream())
+
+
 _vq_ws = {}
 
 

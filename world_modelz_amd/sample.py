@@ -42,6 +42,9 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
     mask_token = num_embeddings
     batch_z = batch_z.clone()
     batch_z[:, -1] = mask_token                                   # destroy all information in the last frame (:62)
+    if use_graph and uniforms is None and trace is None and num_embeddings <= 2048:
+        return _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_iterations, sample_topk, noise_schedule,
+                                    consistent_masking, generator)
     fwd = GraphedForward(model, batch_z) if use_graph else None
     if fwd is not None:
         batch_z = fwd.static_in                                   # the loop edits the graph's own input buffer: no staging copy
@@ -76,3 +79,46 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
         out.append(denoised.view(B, H, W).clone())
         batch_z[:, :-1] = batch_z[:, 1:].clone()                  # shift frames (:115)
     return out, (batch_z.clone() if fwd is not None else batch_z)   # (never hand out the graph's own buffer)
+
+
+def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_iterations, sample_topk, noise_schedule,
+                         consistent_masking, generator):
+    """The same loop with NO host work inside a frame but one graph launch per iteration: the draw + re-mask step is one
+    kernel (wmz_sample_tokens_dev: top-k, softmax, inverse-CDF draw and re-mask per row, uniforms from in-kernel Philox keyed by
+    the generator's seed and a device-side iteration counter) captured in FRONT of the forward it feeds, the logits hand-over and
+    the counter increment behind it.  Same distribution as the torch path (which stays for injected uniforms: the parity
+    fixtures), different random stream."""
+    from . import ops
+    B, S, H, W = batch_z.shape
+    dev = batch_z.device
+    R, C = B * H * W, num_embeddings
+    alphas = torch.tensor([min(max(noise_schedule((i + 1) / num_eval_iterations) if noise_schedule is not None
+                                   else (i + 1) / num_eval_iterations, 0.0), 1.0) for i in range(num_eval_iterations)],
+                          dtype=torch.float32, device=dev)
+    logits = torch.zeros(R, C, dtype=torch.float32, device=dev)
+    denoised = torch.zeros(R, dtype=torch.int64, device=dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    last_mask = torch.ones(R, dtype=torch.uint8, device=dev) if consistent_masking else None
+    seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+
+    def pre(z):                                                   # draw from the previous logits into the last frame, in place
+        ops.sample_tokens(logits, sample_topk, alphas, num_embeddings, z[:, -1], denoised, counter, seed, last_mask)
+
+    def post(y):
+        logits.copy_(y.reshape(R, C))
+        counter.add_(1)
+
+    fwd = GraphedForward(model, batch_z, pre=pre, post=post)
+    z = fwd.static_in
+    z.copy_(batch_z)                                              # (capture and warm-up drew into the last frame: start over)
+    counter.zero_()
+    out = []
+    for f in range(num_frames):
+        logits.zero_()                                            # flat start (:71)
+        if last_mask is not None:
+            last_mask.fill_(1)
+        for i in range(num_eval_iterations):
+            fwd(z)
+        out.append(denoised.view(B, H, W).clone())
+        z[:, :-1] = z[:, 1:].clone()                              # shift frames (:115)
+    return out, z.clone()
