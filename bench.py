@@ -408,6 +408,23 @@ def main():
                 del prun, m3
                 gc.collect()
         out['published_run_widths'] = pub
+        # ---- secondary figure: the sampler loop (main.py:50-117): one denoise iteration = draw + re-mask + forward
+        # on the last frame's dependence cone, ONE hipGraph launch (sample.py); B clips, top-k 100
+        smp = None
+        if use_fused and not a.eager and not a.no_cone:
+            from world_modelz_amd.sample import sample_frames
+            wcfg.set_last_frame_cone(True)
+            sample_frames(model, z.clamp(max=cfg['C'] - 1), cfg['C'], 1, num_eval_iterations=4, sample_topk=100)     # packs / clocks
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            sample_frames(model, z.clamp(max=cfg['C'] - 1), cfg['C'], 2, num_eval_iterations=30, sample_topk=100)
+            torch.cuda.synchronize()
+            sel = (time.perf_counter() - s0) / 60
+            wcfg.set_last_frame_cone(False)
+            smp = {'ms_per_iteration': sel * 1e3, 'value': cfg['B'] / (30 * sel), 'unit': 'generated latent-frames/s (30 iterations each)',
+                   'what': f"sample_frames: 2 frames x 30 denoise iterations for {cfg['B']} clips, top-k 100, graph capture included"}
+            log(f'sampler: {sel * 1e3:.3f} ms per denoise iteration')
+        out['sampler_iteration'] = smp
         # ---- secondary figure: the stage in front of the denoiser: the frozen VQ auto-encoder turning frames into
         # latent tokens -- conv encoder (NHWC implicit GEMM, BatchNorm in train mode: quirk Q3) + codebook argmin.  B*S frames
         # of 64x64 RGB -> 16x16 tokens each (2 down-scale steps), codebook 1024 x 64.
