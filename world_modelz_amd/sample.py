@@ -95,7 +95,7 @@ def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_it
     alphas = torch.tensor([min(max(noise_schedule((i + 1) / num_eval_iterations) if noise_schedule is not None
                                    else (i + 1) / num_eval_iterations, 0.0), 1.0) for i in range(num_eval_iterations)],
                           dtype=torch.float32, device=dev)
-    logits = torch.zeros(R, C, dtype=torch.float32, device=dev)
+    logits = torch.zeros(R, (C + 3) // 4 * 4, dtype=torch.float32, device=dev)[:, :C]     # rows 16-byte aligned whatever C is
     denoised = torch.zeros(R, dtype=torch.int64, device=dev)
     counter = torch.zeros(1, dtype=torch.int64, device=dev)
     last_mask = torch.ones(R, dtype=torch.uint8, device=dev) if consistent_masking else None
