@@ -377,12 +377,14 @@ int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, float* dbias
                           int KH, int KW, int stride, int pad, int dtype, void* stream);
 /* ... by the two-stage reduction of wmz_linear_wgrad_ws (caller-owned workspace of at least
  * wmz_conv2d_nhwc_wgrad_workspace_floats(...) floats; deterministic, no float atomics; overwrite != 0: dW / dbias are stored,
- * not accumulated -- no zero fill needed). */
+ * not accumulated -- no zero fill needed).  conv_layout_co > 0: dW is nn.Conv2d's own weight (gradient) tensor
+ * [conv_layout_co, conv_layout_ci, KH, KW] -- the channel padding of the operands cropped, the taps transposed -- and dbias has
+ * conv_layout_co entries: the gradient lands in the parameter's .grad without a permute / copy / add pass. */
 long wmz_conv2d_nhwc_wgrad_workspace_floats(int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                             int dtype);
 int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin, int Cout,
-                             int KH, int KW, int stride, int pad, int overwrite, float* workspace, long workspace_floats,
-                             int dtype, void* stream);
+                             int KH, int KW, int stride, int pad, int overwrite, int conv_layout_co, int conv_layout_ci,
+                             float* workspace, long workspace_floats, int dtype, void* stream);
 /* training-mode BatchNorm + LeakyReLU backward, pass 1: g = dy * act'(y) (optional g_out), sum_g[C] += g,
  * sum_gx[C] += g * (x - mean) * rstd;  pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)  (dgamma = sum_gx, dbeta = sum_g). */
 int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, void* g_out,

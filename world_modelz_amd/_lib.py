@@ -70,7 +70,7 @@ SIGNATURES = {
                        + [c_int, c_void_p, c_void_p],
     'wmz_conv2d_nhwc_wgrad': [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
     'wmz_conv2d_nhwc_wgrad_workspace_floats': [c_int] * 10,                # returns long
-    'wmz_conv2d_nhwc_wgrad_ws': [c_void_p] * 4 + [c_int] * 10 + [c_void_p, c_long, c_int, c_void_p],
+    'wmz_conv2d_nhwc_wgrad_ws': [c_void_p] * 4 + [c_int] * 12 + [c_void_p, c_long, c_int, c_void_p],
     'wmz_bn_act_bwd_reduce': [c_void_p] * 8 + [c_long, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_bn_bwd_apply': [c_void_p] * 8 + [c_long, c_int, c_int, c_void_p],
     'wmz_bilinear2x_nhwc_bwd': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],

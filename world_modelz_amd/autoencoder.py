@@ -105,6 +105,7 @@ class _Conv2dFn(torch.autograd.Function):
         y = ops.conv2d_nhwc(x, _cast.operand((weight,), dt, 'conv', build), k, k, stride, pad,
                             bias=None if bias is None else bias.detach())
         ctx.save_for_backward(x, weight)
+        ctx.bias = bias
         ctx.geom = (k, stride, pad, bias is not None)
         return y
 
@@ -117,9 +118,21 @@ class _Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous()
         if cop != co:
             dy = F.pad(dy, (0, cop - co))
-        dwf, dbf = ops.conv2d_nhwc_wgrad(x, dy, k, k, stride, pad, has_bias)
-        dw = dwf.view(cop, k, k, cip)[:co, :, :, :ci].permute(0, 3, 1, 2).contiguous()
-        db = dbf[:co].contiguous() if has_bias else None
+        gw = getattr(weight, '_wmz_grad', None)
+        gb = getattr(ctx.bias, '_wmz_grad', None) if has_bias else None
+        if gw is not None and (not has_bias or gb is not None):
+            # FlatArena (VqaeTrainer): the reduction kernel adds straight into the parameters' gradient slots, in nn.Conv2d's own
+            # layout -- no [Cout8, K] temporary, no permute copy, no autograd accumulation pass
+            ops.conv2d_nhwc_wgrad(x, dy, k, k, stride, pad, has_bias, into=(gw, gb))
+            for prm in (weight, ctx.bias):
+                ready = getattr(prm, '_wmz_ready', None) if prm is not None else None
+                if ready is not None:
+                    ready()
+            dw = db = None
+        else:
+            dwf, dbf = ops.conv2d_nhwc_wgrad(x, dy, k, k, stride, pad, has_bias)
+            dw = dwf.view(cop, k, k, cip)[:co, :, :, :ci].permute(0, 3, 1, 2).contiguous()
+            db = dbf[:co].contiguous() if has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
             B, Hi, Wi, _ = x.shape

@@ -59,7 +59,12 @@ struct WgParams {
 // i are first[i] .. first[i+1]-1, its partial tiles live at workspace + wsoff[i]
 constexpr int WG_MAXB = 6;
 struct WgBatch { WgParams p[WG_MAXB]; int first[WG_MAXB + 1]; long wsoff[WG_MAXB]; int n; };
-struct RedProb { float* dW; float* dbias; long wsoff, NK; int nsplit, N, nblk_w, overwrite, first; };
+struct RedProb {
+  float* dW; float* dbias; long wsoff, NK; int nsplit, N, nblk_w, overwrite, first;
+  // conv weight gradients stored in nn.Conv2d's layout: element (n, k = tap * cin_p + c) of the [N, K] result goes to
+  // dW[(n * ci + c) * taps + tap] when n < co and c < ci (channel padding cropped); taps == 0: plain [N, K]
+  int taps, cin_p, co, ci;
+};
 struct RedBatch { RedProb p[WG_MAXB]; int n; };
 
 constexpr int WG_BN = 128, WG_BK = 128, WG_MS = 32;
@@ -437,8 +442,22 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
       f32x4 t = red[0][lane];
 #pragma unroll
       for (int w = 1; w < 16; ++w) t += red[w][lane];
-      f32x4* d = reinterpret_cast<f32x4*>(dW + q);
-      *d = overwrite ? t : *d + t;
+      if (R.taps == 0) {
+        f32x4* d = reinterpret_cast<f32x4*>(dW + q);
+        *d = overwrite ? t : *d + t;
+      } else {
+        const int K = R.taps * R.cin_p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const long qe = q + e;
+          const int n = (int)(qe / K), k = (int)(qe - (long)n * K);
+          const int tap = k / R.cin_p, c = k - tap * R.cin_p;
+          if (n < R.co && c < R.ci) {
+            float* d = dW + ((long)n * R.ci + c) * R.taps + tap;
+            *d = overwrite ? t[e] : *d + t[e];
+          }
+        }
+      }
     }
   } else if (dbias != nullptr) {
     // bias: 64 entries per workgroup, the slices spread over the 16 waves like above (a thread per entry walking all the
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     float* redf = reinterpret_cast<float*>(red);
     redf[wave * 64 + lane] = a;
     __syncthreads();
-    if (wave == 0 && n < N) {
+    if (wave == 0 && n < (R.taps == 0 ? N : R.co)) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 16; ++w) t += redf[w * 64 + lane];
@@ -701,6 +720,7 @@ long wg_batch_add(WgBatch& B, RedBatch& R, int i, const void* dC, long ldc, cons
   RedProb& Q = R.p[i];
   Q.dW = dW; Q.dbias = dbias; Q.wsoff = wsoff; Q.NK = NK; Q.nsplit = P.nsplit; Q.N = N;
   Q.nblk_w = wmz_cdiv(NK, 256); Q.overwrite = overwrite;
+  Q.taps = 0; Q.cin_p = 0; Q.co = 0; Q.ci = 0;
   Q.first = i == 0 ? 0 : R.p[i - 1].first + R.p[i - 1].nblk_w + (R.p[i - 1].dbias != nullptr ? wmz_cdiv(R.p[i - 1].N, 64) : 0);
   return wmz_linear_wgrad_workspace_floats(M, N, K, dtype);
 }
@@ -809,8 +829,8 @@ extern "C" long wmz_conv2d_nhwc_wgrad_workspace_floats(int B, int Hi, int Wi, in
   return wmz_linear_wgrad_workspace_floats(B * Ho * Wo, Cout, KH * KW * Cin, dtype);
 }
 extern "C" int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin,
-                                        int Cout, int KH, int KW, int stride, int pad, int overwrite, float* workspace,
-                                        long workspace_floats, int dtype, void* stream) {
+                                        int Cout, int KH, int KW, int stride, int pad, int overwrite, int conv_layout_co,
+                                        int conv_layout_ci, float* workspace, long workspace_floats, int dtype, void* stream) {
   WMZ_REQUIRE(x && dy && dW && workspace, "wmz_conv2d_nhwc_wgrad_ws: null tensor");
   WMZ_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "wmz_conv2d_nhwc_wgrad_ws: bad shape");
   WMZ_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "wmz_conv2d_nhwc_wgrad_ws: Cin and Cout must be multiples of 8 (zero-pad)");
@@ -827,6 +847,10 @@ extern "C" int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW
   wg_batch_add(Bt, R, 0, dy, Cout, x, 0, dW, dbias, M, Cout, K, nullptr, nullptr, nullptr, nullptr, 0, overwrite, dtype, 0);
   WgParams& P = Bt.p[0];
   P.Hi = Hi; P.Wi = Wi; P.Cin = Cin; P.KW = KW; P.cstride = stride; P.cpad = pad; P.Ho = Ho; P.Wo = Wo;
+  if (conv_layout_co > 0) {
+    WMZ_REQUIRE(conv_layout_co <= Cout && conv_layout_ci > 0 && conv_layout_ci <= Cin, "wmz_conv2d_nhwc_wgrad_ws: bad nn.Conv2d layout sizes");
+    R.p[0].taps = KH * KW; R.p[0].cin_p = Cin; R.p[0].co = conv_layout_co; R.p[0].ci = conv_layout_ci;
+  }
   wg_batch_launch(Bt, R, 3, workspace, dtype, (hipStream_t)stream);
   WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_wgrad_ws");
   return WMZ_OK;

@@ -416,17 +416,26 @@ def embed_indexed_bwd(tok, pos, dx, shape, table_shapes):
     return tabs
 
 
-def conv2d_nhwc_wgrad(x, dy, KH, KW, stride, pad, want_bias):
-    """x [B,Hi,Wi,Cin8], dy [B,Ho,Wo,Cout8] -> dW fp32 [Cout8, KH*KW*Cin8] (+ dbias fp32 [Cout8])."""
+def conv2d_nhwc_wgrad(x, dy, KH, KW, stride, pad, want_bias, into=None):
+    """x [B,Hi,Wi,Cin8], dy [B,Ho,Wo,Cout8] -> dW fp32 [Cout8, KH*KW*Cin8] (+ dbias fp32 [Cout8]).
+    into = (weight_grad [Co, Ci, KH, KW], bias_grad [Co] | None): ACCUMULATE into nn.Conv2d's own gradient tensors instead
+    (channel padding cropped, taps transposed by the reduction kernel); returns (None, None)."""
     B, Hi, Wi, Cin = x.shape
     Cout = dy.shape[-1]
     assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
     dt = L.dtype_code(x.dtype)
+    ws = _workspace(x.device, L.lib().wmz_conv2d_nhwc_wgrad_workspace_floats(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dt))
+    if into is not None:
+        gw, gb = into
+        co, ci = gw.shape[:2]
+        assert gw.is_contiguous() and gw.dtype == torch.float32 and gw.shape[2:] == (KH, KW) and co <= Cout and ci <= Cin
+        L.call('wmz_conv2d_nhwc_wgrad_ws', L.ptr(x), L.ptr(dy), L.ptr(gw), L.ptr(gb), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 0,
+               co, ci, L.ptr(ws), ws.numel(), dt, L.stream())
+        return None, None
     dw = torch.empty((Cout, KH * KW * Cin), dtype=torch.float32, device=x.device)        # stored, not accumulated: no zero fill
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    ws = _workspace(x.device, L.lib().wmz_conv2d_nhwc_wgrad_workspace_floats(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dt))
     L.call('wmz_conv2d_nhwc_wgrad_ws', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 1,
-           L.ptr(ws), ws.numel(), dt, L.stream())
+           0, 0, L.ptr(ws), ws.numel(), dt, L.stream())
     return dw, db
 
 
