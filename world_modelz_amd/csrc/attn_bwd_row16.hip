@@ -21,7 +21,7 @@
 //     scale) (MODE 0: both addends live in registers for the whole kernel).
 #include "attn_common.h"
 #ifndef WMZ_ABWD_ABL
-#define WMZ_ABWD_ABL 0      // timing ablations (tools/build_variant.py; results are garbage): 1 no compute, 2 no slab DMA
+#define WMZ_ABWD_ABL 0      // timing ablations (tools/build_variant.py; results are garbage): 1 no compute, 2 no slab DMA, 4 no LDS fragment reads, 8 no MFMAs, 16 no exp / dS arithmetic
 #endif
 
 namespace {
@@ -245,32 +245,48 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           Frag8<bf16_t> a0, a1, b0, b1;
-          a0.v = *reinterpret_cast<const s16x8*>(Y1s + ro0 + ks * 64);
-          a1.v = *reinterpret_cast<const s16x8*>(Y1s + ro1 + ks * 64);
-          b0.v = *reinterpret_cast<const s16x8*>(Y2s + ro0 + ks * 64);
-          b1.v = *reinterpret_cast<const s16x8*>(Y2s + ro1 + ks * 64);
-          mma16(s0, a0, x1f[ks]);
-          mma16(s1, a1, x1f[ks]);
-          mma16(d0, b0, x2f[ks]);
-          mma16(d1, b1, x2f[ks]);
+          if constexpr (WMZ_ABWD_ABL & 4) { a0.v = x1f[ks].v; a1.v = x2f[ks].v; b0.v = x1f[ks].v; b1.v = x2f[ks].v; }
+          else {
+            a0.v = *reinterpret_cast<const s16x8*>(Y1s + ro0 + ks * 64);
+            a1.v = *reinterpret_cast<const s16x8*>(Y1s + ro1 + ks * 64);
+            b0.v = *reinterpret_cast<const s16x8*>(Y2s + ro0 + ks * 64);
+            b1.v = *reinterpret_cast<const s16x8*>(Y2s + ro1 + ks * 64);
+          }
+          if constexpr (WMZ_ABWD_ABL & 8) { asm volatile("" :: "v"(a0.v), "v"(a1.v), "v"(b0.v), "v"(b1.v)); }
+          else {
+            mma16(s0, a0, x1f[ks]);
+            mma16(s1, a1, x1f[ks]);
+            mma16(d0, b0, x2f[ks]);
+            mma16(d1, b1, x2f[ks]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         // transposed fragments of Y1 requested now (inline asm: the builtin makes hipcc drain the LDS-DMA in front of each)
         const unsigned ya0 = lds_addr(Y1s + to0), ya1 = ya0 + 16 * I::ROWP;
         s16x4 x0[MT], x1[MT];
-        static_for<MT>([&](auto mt) {
-          x0[mt] = ds_read_tr16_asm<mt * 32>(ya0);
-          x1[mt] = ds_read_tr16_asm<mt * 32>(ya1);
-        });
+        if constexpr (WMZ_ABWD_ABL & 4) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) { x0[mt] = (s16x4)((short)ya0); x1[mt] = (s16x4)((short)ya1); }
+        } else {
+          static_for<MT>([&](auto mt) {
+            x0[mt] = ds_read_tr16_asm<mt * 32>(ya0);
+            x1[mt] = ds_read_tr16_asm<mt * 32>(ya1);
+          });
+        }
         // MODE 1 (two waves per SIMD, 256 registers): Y2's transposed fragments are requested here as well, so that BOTH
         // accumulations run back to back behind one wait instead of read -> wait -> MFMA twice
         s16x4 z0[MODE == 1 ? MT : 1], z1[MODE == 1 ? MT : 1];
         if constexpr (MODE == 1) {
           const unsigned yb0 = lds_addr(Y2s + to0), yb1 = yb0 + 16 * I::ROWP;
-          static_for<MT>([&](auto mt) {
-            z0[mt] = ds_read_tr16_asm<mt * 32>(yb0);
-            z1[mt] = ds_read_tr16_asm<mt * 32>(yb1);
-          });
+          if constexpr (WMZ_ABWD_ABL & 4) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { z0[mt] = (s16x4)((short)yb0); z1[mt] = (s16x4)((short)yb1); }
+          } else {
+            static_for<MT>([&](auto mt) {
+              z0[mt] = ds_read_tr16_asm<mt * 32>(yb0);
+              z1[mt] = ds_read_tr16_asm<mt * 32>(yb1);
+            });
+          }
         }
         float pv[8], dsv[8];
         if constexpr (MODE == 1) {
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           asm volatile("" : "+v"(x0[mt]), "+v"(x1[mt]));
           Frag8<bf16_t> yf;
           yf.v = __builtin_shufflevector(x0[mt], x1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
-          mma16(acc1[mt], yf, dsf);
+          if constexpr (WMZ_ABWD_ABL & 8) { asm volatile("" :: "v"(yf.v), "v"(dsf.v)); } else mma16(acc1[mt], yf, dsf);
         }
         if constexpr (MODE == 1) {
 #pragma unroll
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
             asm volatile("" : "+v"(z0[mt]), "+v"(z1[mt]));
             Frag8<bf16_t> yf;
             yf.v = __builtin_shufflevector(z0[mt], z1[mt], 0, 1, 2, 3, 4, 5, 6, 7);
-            mma16(acc2[mt], yf, pf);
+            if constexpr (WMZ_ABWD_ABL & 8) { asm volatile("" :: "v"(yf.v), "v"(pf.v)); } else mma16(acc2[mt], yf, pf);
           }
         }
       }
