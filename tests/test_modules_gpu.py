@@ -96,6 +96,36 @@ def test_default_config_vs_oracle_bf16(wmz):
     assert e16 < 1e-2                                    # measured 4.0e-3
 
 
+@pytest.mark.parametrize('dim,mlp', [(96, 256), (384, 512)])
+def test_published_run_widths_vs_oracle(wmz, dim, mlp):
+    """The reference's two published models (results/README.md: dim 96 / mlp 256 and dim 384 / mlp 512, one head of 128, window
+    7x3x3) run on the per-op path (their widths are outside the fused per-token kernel): fp32 parity with the oracle, bounded
+    bf16 error, and the last-frame cone bit-identical to the full grid -- the configurations `bench.py` times as
+    `published_run_widths`."""
+    torch.manual_seed(42)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(5, 16, 16), dim=dim, num_classes=1024, extents=(3, 1, 1), depth=3,
+                                          dim_head=128, mlp_dim=mlp, heads=1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    z = torch.randint(0, 1025, (2, 5, 16, 16))
+    ref = oden.denoiser_forward(sd, z, (3, 1, 1), 1)
+    m = m.cuda()
+    with torch.no_grad():
+        with wmz['config'].compute_dtype(torch.float32):
+            y32 = m(z.cuda())
+        with wmz['config'].compute_dtype(torch.bfloat16):
+            y16 = m(z.cuda())
+            wmz['config'].set_last_frame_cone(False)
+            try:
+                y16_full = m(z.cuda())
+            finally:
+                wmz['config'].set_last_frame_cone(True)
+    assert rel(y32, ref) < 1e-5
+    e16 = rel(y16, ref)
+    print(f'dim {dim}: bf16 end-to-end logits error vs fp32 oracle: {e16:.3e}')
+    assert e16 < 1e-2
+    assert torch.equal(y16, y16_full)
+
+
 def test_cpu_input_is_refused(wmz):
     m = wmz['main'].VqVideoDiffusionModel(data_shape=(2, 4, 4), dim=16, num_classes=8, extents=(1, 1, 1), depth=1,
                                           dim_head=8, mlp_dim=16, heads=2).cuda()
