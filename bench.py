@@ -101,10 +101,32 @@ def main():
     ap.add_argument('--train-steps', type=int, default=30, help='timed full training steps reported as train_step (0 = skip)')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes of torch.distributed.run, BEFORE
+        # anything in this process has touched the GPU (torch.cuda.device_count() does not initialise it); rank 0 of the children
+        # prints the JSON line on the stdout they inherit.  Fewer visible cards than ranks = a rehearsal: the ranks share cards
+        # and the collectives run over gloo (RCCL refuses two ranks on one device); the JSON line says so.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if torch.cuda.device_count() < a.gpus:
+            env.setdefault('WMZ_DIST_BACKEND', 'gloo')
+            log(f'{torch.cuda.device_count()} device(s) visible for {a.gpus} ranks: rehearsal over {env["WMZ_DIST_BACKEND"]}, ranks share cards')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log('self-launch: ' + ' '.join(cmd))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks')
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)      # one rank per GPU on a full node; rehearsals may stack ranks on one card
     torch.cuda.set_device(dev_index)
@@ -117,6 +139,15 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+        # one real collective before anything is timed: the communicator exists, and the rank count the JSON line reports
+        # (`rccl_ranks`) is what the collective saw, not what the environment said
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        ranks_seen = int(probe.item())
+        assert ranks_seen == world, (ranks_seen, world)
+    else:
+        backend, ranks_seen = None, 1
 
     from world_modelz_amd import config, ops
     from world_modelz_amd.main import VqVideoDiffusionModel
@@ -270,8 +301,6 @@ def main():
     # measured; otherwise traffic stays null (and `traffic_stale` says why) instead of going stale silently.
     try:
         import hashlib
-        with open(os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')) as f:
-            pmc = json.load(f)
 
         def src_hash(names):
             h = hashlib.sha256()
@@ -279,15 +308,37 @@ def main():
                 with open(os.path.join(ROOT, 'world_modelz_amd', 'csrc', n), 'rb') as fh:
                     h.update(fh.read())
             return h.hexdigest()[:16]
+
+        def newest(fname):
+            """(path relative to the repository, parsed JSON) of the newest profiles/rNN/<fname>, or (None, {})."""
+            for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, 'profiles')) if d.startswith('r')), reverse=True):
+                pth = os.path.join(ROOT, 'profiles', rnd, fname)
+                if os.path.exists(pth):
+                    with open(pth) as f:
+                        return f'profiles/{rnd}/{fname}', json.load(f)
+            return None, {}
+        tpath, pmc = newest('pmc_traffic.json')
+        ipath, pmi = newest('pmc_issue.json')
         for roof, key in ((attn_roof, 'attn_fwd_row16_kernel'), (fused_roof, 'layer_fused_kernel<head,tail>')):
-            if roof is None or key not in pmc:
+            if roof is None:
                 continue
-            ent = pmc[key]
-            if src_hash(ent['sources']) == ent['source_sha16']:
-                roof['traffic'] = ent['traffic_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/r02/pmc_traffic.json (rocprofv3 PMC passes, same kernel source and shapes)'
-            else:
-                roof['traffic_stale'] = 'kernel source changed since profiles/r02/pmc_traffic.json was measured'
+            ent = pmc.get(key)
+            if ent is not None:
+                if src_hash(ent['sources']) == ent['source_sha16']:
+                    roof['traffic'] = ent['traffic_bytes_per_launch']
+                    roof['traffic_source'] = f'{tpath} (rocprofv3 PMC passes, same kernel source and shapes)'
+                else:
+                    roof['traffic_stale'] = f'kernel source changed since {tpath} was measured'
+            # MFMA-busy share of the launch (SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), tools/pmc_issue.py), same rule
+            ent = pmi.get(key)
+            if ent is not None and 'mfma_busy' in ent:
+                if src_hash(ent['sources']) == ent['source_sha16']:
+                    roof['mfma_busy'] = ent['mfma_busy']
+                    roof['issue_counters'] = {k2: ent[k2] for k2 in ('wait_inst_any_share_of_wave_cycles', 'wait_any_share_of_wave_cycles',
+                                                                      'active_inst_any_share_of_wave_cycles') if k2 in ent}
+                    roof['mfma_busy_source'] = ipath
+                else:
+                    roof['mfma_busy_stale'] = f'kernel source changed since {ipath} was measured'
     except (OSError, KeyError, ValueError):
         pass
     # `roofline` = the kernel with the larger share of the step
@@ -302,6 +353,9 @@ def main():
                                'depth 4, mlp 256',
                    'clips_per_gpu': cfg['B'], 'latent_shape': [cfg['S'], cfg['H'], cfg['W']], 'codebook': cfg['C'],
                    'parallelism': f'clips sharded over {world} rank(s), no data-path collective'},
+        'rccl_ranks': ranks_seen if backend in (None, 'nccl') else 0,
+        'dist_backend': {None: None, 'nccl': 'nccl (RCCL)'}.get(backend, f'{backend} (REHEARSAL: ranks share cards, not an RCCL/xGMI figure)'),
+        'devices_visible': ndev,
         'roofline': fused_roof if dominant_fused else attn_roof,
         'roofline_other': attn_roof if dominant_fused else fused_roof,
         'launch_mode': 'eager' if a.eager else 'hipGraph replay (1 graph = 1 forward step)',
@@ -491,41 +545,135 @@ def main():
             log('vq argmin: ' + ', '.join(f"C={v['C']} {v['ms'] * 1e3:.0f} us ({v['roofline']['frac']:.2f} of the f32 VALU)" for v in vq))
         out['vq_argmin'] = vq
         gc.collect()
+        # ---- secondary figure: BASELINE configs[1] -- ONE Local3dAttention.forward on an 8x8x8 latent grid, d = 256, one head of
+        # 128, bf16 (SURVEY 8d inputs: x = LN(randn(1,8,8,8,256)), q = randn(same), seed 0), window 7x7x7 and 7x3x3.  512 tokens:
+        # two workgroups' worth of attention and four small GEMMs, so the figure is launch latency, not throughput; one hipGraph
+        # of 20 forwards, HIP events around the replay.
+        cfg2 = None
+        if not a.no_cone and dtype == torch.bfloat16:
+            from world_modelz_amd.local_3d_attention import Local3dAttention
+            cfg2 = []
+            for ext2 in ((3, 3, 3), (3, 1, 1)):
+                torch.manual_seed(0)
+                att = Local3dAttention(ext2, 256, heads=1, dim_head=128).to(dev).eval()
+                x2 = torch.nn.functional.layer_norm(torch.randn(1, 8, 8, 8, 256), (256,)).to(dev)
+                q2 = torch.randn(1, 8, 8, 8, 256).to(dev)
+                with torch.no_grad():
+                    us = time_kernel(lambda: att(x2, q2), 20) * 1e3
+                cfg2.append({'extents': list(ext2), 'us_per_forward': us, 'value': 8 / (us * 1e-6), 'unit': 'latent-frames/s',
+                             'what': 'Local3dAttention.forward(x, q): to_q / to_k / to_v, local 3D attention core, to_out; fp32 in / out at '
+                                     'the module boundary, bf16 inside; B=1, 8x8x8 grid, dim 256, 1 head x 128'})
+            log('config 2: ' + ', '.join(f"{c['extents']} {c['us_per_forward']:.1f} us" for c in cfg2))
+        out['config2_attention'] = cfg2
+        # ---- secondary figure: BASELINE configs[2] -- the training step of vq-video-diffusion/main.py on B = 16 clips of 16x16x16
+        # latents (same token count per step as the headline, shorter clips: more border planes), codebook 1024; one hipGraph per step
+        cfg3 = None
+        if a.train_steps > 0 and not a.no_cone and world == 1 and not a.eager:
+            from world_modelz_amd.train import DenoiserTrainer as _DT
+            torch.manual_seed(42)
+            m3 = VqVideoDiffusionModel(data_shape=(16, 16, 16), dim=cfg['dim'], num_classes=cfg['C'], extents=cfg['extents'],
+                                       depth=cfg['depth'], dim_head=cfg['dim_head'], mlp_dim=cfg['mlp_dim'], heads=cfg['heads']).to(dev)
+            z3 = torch.randint(0, cfg['C'], (16, 16, 16, 16), generator=gen).to(dev)
+            t3 = _DT(m3, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=False)
+            r3 = torch.full((16,), 0.5)
+            t3.enable_graph(z3)
+            for _ in range(5):
+                t3.train_step(z3, r=r3)
+            torch.cuda.synchronize()
+            c0_ = time.perf_counter()
+            n3 = max(5, a.train_steps // 2)
+            for _ in range(n3):
+                t3.train_step(z3, r=r3)
+            torch.cuda.synchronize()
+            c3 = (time.perf_counter() - c0_) / n3
+            with torch.no_grad():
+                m3.eval()
+                wcfg.set_last_frame_cone(False)
+                f3run = GraphedForward(m3, z3)
+                for _ in range(20):
+                    f3run(f3run.static_in)
+                torch.cuda.synchronize()
+                c0_ = time.perf_counter()
+                for _ in range(a.steps):
+                    f3run(f3run.static_in)
+                torch.cuda.synchronize()
+                f3 = (time.perf_counter() - c0_) / a.steps
+            cfg3 = {'train_ms_per_step': c3 * 1e3, 'train_value': 16 * 16 / c3, 'forward_ms_per_step': f3 * 1e3,
+                    'forward_value': 16 * 16 / f3, 'unit': 'latent-frames/s',
+                    'what': 'B=16 clips of 16x16x16 latents, codebook 1024, default model: full training step (one hipGraph) and the '
+                            'forward denoise step (full grid)'}
+            log(f'config 3: train {c3 * 1e3:.2f} ms/step, forward {f3 * 1e3:.3f} ms/step')
+            del t3, m3, f3run
+            gc.collect()
+        out['config3_train_step'] = cfg3
         # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand
         # re-pack), same shapes, same rules (barrier + sync both sides, max over ranks).  One GPU: the whole step is ONE hipGraph
-        # replay (DenoiserTrainer.enable_graph) plus the loss-aware sampler's one host read-back per step.  n_gpus > 1: eager
-        # launches with the per-layer gradient all-reduce buckets overlapped on a side stream.
+        # replay (DenoiserTrainer.enable_graph) plus the loss-aware sampler's one host read-back per step.  n_gpus > 1: the same
+        # graph with the per-layer gradient all-reduce buckets captured on a side stream (the eager path is timed beside it).
         train = None
         if a.train_steps > 0:
             from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame
             model.train()
             tr = DenoiserTrainer(model, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=world > 1)
             rfix = torch.full((cfg['B'],), 0.5)
-            graphed = world == 1 and not a.eager
+            # hipGraph replay is the launch mode at every world size: the per-layer RCCL all-reduces are captured with the step
+            # (side-stream fork / join inside the graph).  gloo (rehearsals on shared cards) cannot be captured: eager there.
+            graphed = not a.eager and (world == 1 or backend == 'nccl')
+
+            def eager_step():
+                tr.arena.zero_grad()
+                zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
+                tr.forward_backward(zc, tgt)
+                tr.optimizer_step()
+
+            def timed(fn, n):
+                for _ in range(5):
+                    fn()
+                barrier()
+                t_0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                barrier()
+                el = time.perf_counter() - t_0
+                if world > 1:
+                    tt = torch.tensor([el], device=dev, dtype=torch.float64)
+                    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                    el = float(tt.item())
+                return el
+
+            eager_ms, overlap = None, None
+            if world > 1 or not graphed:
+                # the eager launch path (host-bound at ~80 launches per step): timed for the record, and the only mode in which
+                # HIP events can bracket the collectives on the side stream (grad_allreduce_overlap)
+                if tr.reducer is not None:
+                    tr.reducer.enable_timing()
+                n_e = max(5, a.train_steps // 3)
+                eager_ms = timed(eager_step, n_e) / n_e * 1e3
+                if tr.reducer is not None:
+                    overlap = tr.reducer.timing_summary()
+                    tr.reducer.enable_timing(False)
+            graph_error = None
             if graphed:
-                tr.enable_graph(z)
-                tstep = lambda: tr.train_step(z, r=rfix)  # noqa: E731
+                try:
+                    tr.enable_graph(z)
+                except Exception as e:  # noqa: BLE001  (a rank whose capture failed must not leave the others in a collective)
+                    graph_error = f'{type(e).__name__}: {e}'[:300]
+                if world > 1:
+                    ok = torch.tensor([0.0 if graph_error else 1.0], device=dev)
+                    torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+                    if float(ok.item()) == 0.0:
+                        graph_error = graph_error or 'capture failed on another rank'
+                if graph_error:
+                    log('hipGraph capture of the data-parallel step failed, eager launches instead: ' + graph_error)
+                    tr._graph = None
+                    graphed = False
+            if graphed:
+                tel = timed(lambda: tr.train_step(z, r=rfix), a.train_steps)
+            elif eager_ms is None:
+                tel = timed(eager_step, a.train_steps)
             else:
-                def tstep():
-                    tr.arena.zero_grad()
-                    zc, tgt = corrupt_last_frame(z, rfix, cfg['C'])
-                    tr.forward_backward(zc, tgt)
-                    tr.optimizer_step()
-            for _ in range(5):
-                tstep()
-            barrier()
-            if tr.reducer is not None:
-                tr.reducer.enable_timing()
-            tt0 = time.perf_counter()
-            for _ in range(a.train_steps):
-                tstep()
-            torch.cuda.synchronize()
-            barrier()
-            tel = time.perf_counter() - tt0
-            if world > 1:
-                t = torch.tensor([tel], device=dev, dtype=torch.float64)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                tel = float(t.item())
+                tel = eager_ms * 1e-3 * a.train_steps
             tms = tel / a.train_steps * 1e3
             # a training step is ~3x the forward's flops (no recompute of the attention core: the backward works
             # from the saved log-sum-exp); bytes likewise ~3x the forward's algorithmic bytes (activations written once, read by
@@ -537,11 +685,13 @@ def main():
             train = {'value': cfg['B'] * cfg['S'] * world * a.train_steps / tel, 'unit': 'latent-frames/s',
                      'ms_per_step': tms, 'steps': a.train_steps,
                      'what': 'corrupt + forward + CE + backward + grad-norm + AdamW + operand re-pack: '
-                             + ('ONE hipGraph replay per step + the sampler\'s host read-back' if graphed else
-                                'eager launches, per-layer RCCL gradient all-reduce overlapped on a side stream'),
+                             + ('ONE hipGraph replay per step + the sampler\'s host read-back' if graphed else 'eager launches')
+                             + ('' if world == 1 else '; per-layer gradient all-reduce buckets on a side stream, overlapped with the '
+                                'backward' + (' (captured in the graph)' if graphed else '')),
                      'launch_mode': 'hipGraph' if graphed else 'eager',
+                     'eager_ms_per_step': eager_ms, 'graph_capture_error': graph_error,
                      'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0,
-                     'grad_allreduce_overlap': tr.reducer.timing_summary() if tr.reducer else None,
+                     'grad_allreduce_overlap': overlap,
                      'train_roofline': {'algorithmic_flops_per_step': 3.0 * fwd_flops,
                                         'achieved_TFLOPs': 3.0 * fwd_flops / (tms * 1e-3) / 1e12, 'mfma_peak_TFLOPs': 2500.0,
                                         'frac_of_mfma_peak': 3.0 * fwd_flops / (tms * 1e-3) / 1e12 / 2500.0,

@@ -75,6 +75,43 @@ def test_attention_module_forward(wmz, tag):
     assert out.shape == g['out'].shape and rel(out, g['out']) < 1e-5
 
 
+@pytest.mark.parametrize('ext', [(3, 3, 3), (3, 1, 1)])
+def test_config2_attention_module_vs_oracle(wmz, ext):
+    """BASELINE configs[1] at the module level: ONE Local3dAttention.forward(x, q) on the 8x8x8 latent grid, d = 256, one head
+    of 128 (SURVEY 8d inputs: x = LN(randn(1,8,8,8,256)), q = randn(same), seed 0; reference local_3d_attention.py:102-118)
+    against the oracle's module restatement: fp32 mode to 1e-5, bf16 (the benched mode: bench.py config2_attention) to the
+    rounding of its bf16 operands; and the bf16 attention CORE on bf16-representable q, k, v to 1e-3 on the logits' scale."""
+    from oracle import attention as oatt
+    torch.manual_seed(0)
+    m = wmz['l3a'].Local3dAttention(ext, 256, heads=1, dim_head=128)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.nn.functional.layer_norm(torch.randn(1, 8, 8, 8, 256), (256,))
+    q = torch.randn(1, 8, 8, 8, 256)
+    ref = oatt.attention_module(sd, '', x, q, ext, 1)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        with wmz['config'].compute_dtype(torch.float32):
+            y32 = m(x.cuda(), q=q.cuda())
+        with wmz['config'].compute_dtype(torch.bfloat16):
+            y16 = m(x.cuda(), q=q.cuda())
+    assert y32.shape == ref.shape == (1, 8, 8, 8, 256) and y32.dtype == y16.dtype == torch.float32
+    assert rel(y32, ref) < 1e-5, rel(y32, ref)
+    assert rel(y16, ref) < 1e-2, rel(y16, ref)
+    # the core on identical bf16-representable operands: out and the masked logits (probe) within 1e-3
+    from world_modelz_amd import ops
+    bf = lambda t: t.bfloat16().float()                                                    # noqa: E731
+    kk = bf(torch.nn.functional.linear(x, sd['to_k.weight']))
+    vv = bf(torch.nn.functional.linear(x, sd['to_v.weight'], sd['to_v.bias']))
+    qq = bf(torch.nn.functional.linear(q, sd['to_q.weight']))
+    ref_out, ref_logits = oatt.local_attention(kk, vv, qq, ext, 1, return_logits=True)
+    out, _, dbg = ops.local3d_attention_fwd(qq.cuda().bfloat16(), kk.cuda().bfloat16(), vv.cuda().bfloat16(), ext, 1, logits_dbg=True)
+    lg, rl = dbg.cpu().reshape(-1), ref_logits.reshape(-1)
+    live = rl > -1e8
+    assert torch.equal(live, lg > -1e8)                                                    # the same slots are masked (-1e9)
+    assert float((lg[live] - rl[live]).abs().max()) < 1e-3 * max(1.0, float(rl[live].abs().max()))
+    assert rel(out.reshape(ref_out.shape), ref_out) < 5e-3                                 # bf16 rounding of P and of the output
+
+
 def test_default_config_vs_oracle_bf16(wmz):
     """Default denoiser (dim 256, dh 128, extents 3,3,3, depth 4, mlp 256) on a 2x6x16x16 grid, bf16 run dtype,
     against the fp32 oracle: end-to-end bf16 error is reported and bounded (not a parity gate)."""
@@ -474,7 +511,19 @@ def test_fused_sampler_loop_runs_the_whole_frame_on_the_device(wmz):
     with wmz['config'].compute_dtype(torch.bfloat16):
         g = torch.Generator(device='cuda').manual_seed(77)
         frames, zf = sample_frames(m, z, C, 2, num_eval_iterations=6, sample_topk=8, generator=g)
+        frames_next, _ = sample_frames(m, z, C, 2, num_eval_iterations=6, sample_topk=8, generator=g)     # generator state advanced
+        g.manual_seed(77)
         frames2, _ = sample_frames(m, z, C, 2, num_eval_iterations=6, sample_topk=8, generator=g)
+        gc = torch.Generator().manual_seed(5)                                                             # a CPU generator works too
+        fa, _ = sample_frames(m, z, C, 1, num_eval_iterations=4, sample_topk=8, generator=gc)
+        fb, _ = sample_frames(m, z, C, 1, num_eval_iterations=4, sample_topk=8, generator=gc)
+        torch.manual_seed(11)
+        fc, _ = sample_frames(m, z, C, 1, num_eval_iterations=4, sample_topk=8)                           # global generator
+        fd, _ = sample_frames(m, z, C, 1, num_eval_iterations=4, sample_topk=8)
+        torch.manual_seed(11)
+        fe, _ = sample_frames(m, z, C, 1, num_eval_iterations=4, sample_topk=8)
     assert len(frames) == 2 and all(f.shape == (2, 16, 16) and int(f.min()) >= 0 and int(f.max()) < C for f in frames)
-    assert all(torch.equal(a, b) for a, b in zip(frames, frames2))
+    assert all(torch.equal(a, b) for a, b in zip(frames, frames2))            # same seed -> same frames
+    assert not all(torch.equal(a, b) for a, b in zip(frames, frames_next))    # no reseed -> the generator moved on: fresh noise
+    assert not torch.equal(fa[0], fb[0]) and not torch.equal(fc[0], fd[0]) and torch.equal(fc[0], fe[0])
     assert torch.equal(zf[:, 0], z[:, 2]) and torch.equal(zf[:, 1], frames[0]) and torch.equal(zf[:, 2], frames[1])

@@ -184,3 +184,105 @@ def test_lazy_one_hot_behaves_like_the_dense_encodings():
     x = torch.randn(5, 8)
     assert torch.allclose(torch.matmul(e.squeeze(1).t(), x), dense.squeeze(1).t() @ x)
     assert torch.equal(e * 2.0, dense * 2.0) and float(e.sum()) == 5.0
+
+
+# ------------------------------------------------------------------------------------------------ VQ EMA statistics under DDP
+class _TorchVqOps:
+    """torch restatement of the four VQ entry points the module calls (the HIP kernels need a GPU); what this test exercises is
+    the MODULE's data-parallel logic: VectorQuantizerEMA.forward all-reducing counts / dw before the EMA update (sync_stats)."""
+
+    @staticmethod
+    def vq_argmin(x, cb):
+        return (x[:, None, :] - cb[None]).pow(2).sum(-1).argmin(-1)
+
+    @staticmethod
+    def vq_gather(idx, cb):
+        return cb[idx]
+
+    @staticmethod
+    def vq_ema_stats(x, idx, cb, counts=None, dw=None, sqerr=None):
+        counts.index_add_(0, idx, torch.ones_like(idx, dtype=counts.dtype))
+        if dw is not None:
+            dw.index_add_(0, idx, x)
+        if sqerr is not None:
+            sqerr.index_add_(0, idx, (cb[idx] - x).pow(2).sum(-1))
+
+    @staticmethod
+    def vq_ema_update(embedding, cluster_size, activation_count, counts, dw, decay, eps):
+        C = embedding.shape[-2]                                     # vq.py:44, :53-65 (laplace smoothing, batch sum / EMA count)
+        activation_count[0] += counts
+        cluster_size[0].mul_(decay).add_(counts, alpha=1 - decay)
+        n = cluster_size[0].sum()
+        cs = (cluster_size[0] + eps) / (n + C * eps) * n
+        embedding[0].mul_(decay).add_(dw / cs.unsqueeze(-1), alpha=1 - decay)
+
+
+def _vq_on_cpu():
+    from world_modelz_amd import vq as vq_mod
+    vq_mod.ops = _TorchVqOps
+    vq_mod.VectorQuantizerEMA._flat = lambda self, x: x.reshape(-1, self.embedding_dim).float()
+    return vq_mod
+
+
+def _vq_inputs():
+    g = torch.Generator().manual_seed(3)
+    return [torch.randn(2, 6, 4, 8, generator=g) for _ in range(3)]           # three steps of [B=2, 6, 4, E=8] latents
+
+
+def _vq_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    vq_mod = _vq_on_cpu()
+    torch.manual_seed(11)
+    q = vq_mod.VectorQuantizerEMA(8, 16)
+    q.sync_stats = True
+    q.train()
+    perp = []
+    for x in _vq_inputs():
+        out = q(x[rank:rank + 1])                                    # each rank quantises its own clip
+        perp.append(float(out[3]))
+    ret[rank] = ({k: v.clone() for k, v in q.state_dict().items()}, q.activation_count.clone(), q.accumulated_error.clone(), perp)
+    dist.destroy_process_group()
+
+
+def test_vq_ema_statistics_allreduce_world2():
+    """under data parallelism VectorQuantizerEMA.forward must all-reduce the batch statistics (counts, dw) before
+    the EMA update of vq.py:53-65, or the codebooks diverge silently.  Two gloo ranks with sync_stats, each quantising half of
+    the batch: both end with IDENTICAL codebooks, equal to the single-process module fed the whole batch."""
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_vq_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        (sd0, act0, err0, perp0), (sd1, act1, err1, perp1) = ret[0], ret[1]
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k                        # replicas identical, bit for bit
+    assert torch.equal(act0, act1)
+    from world_modelz_amd import vq as vq_real
+    saved = (vq_real.ops, vq_real.VectorQuantizerEMA._flat)          # (this process's module is patched only for the test)
+    try:
+        _check_vq_against_single_process(sd0, act0, err0, err1, perp0, perp1)
+    finally:
+        vq_real.ops, vq_real.VectorQuantizerEMA._flat = saved
+
+
+def _check_vq_against_single_process(sd0, act0, err0, err1, perp0, perp1):
+    vq_mod = _vq_on_cpu()
+    torch.manual_seed(11)
+    q = vq_mod.VectorQuantizerEMA(8, 16)
+    q.train()
+    for x in _vq_inputs():
+        q(x)                                                         # the union batch in one process, no process group
+    assert torch.allclose(sd0['embedding'], q.embedding, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sd0['cluster_size'], q.cluster_size, rtol=1e-6, atol=1e-7)
+    assert torch.equal(act0, q.activation_count)                     # global usage counts on every rank (dead-code revival agrees)
+    assert torch.allclose(err0 + err1, q.accumulated_error, rtol=1e-5, atol=1e-6)   # the error statistic stays per rank
+    assert perp0 != perp1                                            # perplexity is this rank's batch (vq.py:72-73)
+    # and WITHOUT the all-reduce the replicas would have diverged: the check above is not vacuous
+    torch.manual_seed(11)
+    qa, qb = vq_mod.VectorQuantizerEMA(8, 16), vq_mod.VectorQuantizerEMA(8, 16)
+    qb.load_state_dict(qa.state_dict())
+    for x in _vq_inputs():
+        qa(x[0:1]); qb(x[1:2])
+    assert not torch.equal(qa.embedding, qb.embedding)

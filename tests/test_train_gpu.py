@@ -215,15 +215,17 @@ def test_graphed_training_step_matches_eager(wmz, dtype):
         me, mg = make(), make()
         te = wmz['train'].DenoiserTrainer(me, C, lr=1e-3, warmup=2, max_steps=100, distributed=False)
         tg = wmz['train'].DenoiserTrainer(mg, C, lr=1e-3, warmup=2, max_steps=100, distributed=False)
-        # enable_graph's warm-up steps are real steps: give the eager trainer the same ones (r = 0 via a stub sampler)
+        # enable_graph's warm-up steps run the real step body, then the weights / moments / step count they moved are put
+        # back: the graphed trainer starts where the eager one does (r = 0 via a stub sampler)
         class Zero:
             def sample(self, n, generator=None): return torch.zeros(n)
             def update_with_losses(self, *a): pass
         te.sampler, tg.sampler = Zero(), Zero()
+        p_before = tg.arena.flat_param.clone()
         tg.enable_graph(z, warmup=2)
-        for _ in range(2):
-            te.train_step(z, r=r0)
-        for it in range(3):
+        assert torch.equal(tg.arena.flat_param, p_before) and tg.step_count == 0
+        assert float(tg.m.abs().sum()) == 0 and float(tg.v.abs().sum()) == 0
+        for it in range(5):
             le, ge = te.train_step(z, r=r0)
             lg, gg = tg.train_step(z, r=r0)
             assert abs(le - lg) < (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, abs(le)), (it, le, lg)
@@ -241,6 +243,16 @@ def test_graphed_training_step_matches_eager(wmz, dtype):
         c1 = int(tg._g_ctr)
         l2, _ = tg.train_step(z, r=r1)
         assert int(tg._g_ctr) == c1 + 1 and l1 != l2
+        assert c1 >= (1 << 39)                            # replays count in their own range of Philox stream ids
+        # a library workspace replaced under the graph (a larger eager call grew it) triggers a re-capture, not a stale replay
+        from world_modelz_amd import ops
+        g_before = tg._graph
+        dev = z.device
+        old = ops._wgrad_ws.get(dev)
+        if old is not None:
+            ops._wgrad_ws[dev] = torch.empty(old.numel() + 1024, dtype=torch.float32, device=dev)
+            l3, _ = tg.train_step(z, r=r0)
+            assert tg._graph is not g_before and l3 == l3
 
 
 def test_training_step_full_size_properties(wmz):
@@ -444,44 +456,107 @@ def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
         torch.cuda.synchronize()
         tm = red.timing_summary()                                 # what bench.py reports as grad_allreduce_overlap
         assert tm['collectives'] == 2 * 5 and tm['allreduce_ms'] > 0 and 0.0 <= tm['overlap_fraction'] <= 1.0, tm
+        red.enable_timing(False)
+        # ---- the same data-parallel step as ONE hipGraph: the RCCL all-reduces are captured on the reducer's side stream
+        # (fork at the bucket's last gradient, join in finish()); trajectory == the eager data-parallel trainer's
+        import time
+        with config.compute_dtype(torch.bfloat16):
+            me, mg = make(), make()
+            te = train.DenoiserTrainer(me, 64, lr=1e-3, warmup=0, distributed=True)
+            tg = train.DenoiserTrainer(mg, 64, lr=1e-3, warmup=0, distributed=True)
+            assert tg.reducer is not None and tg.reducer.active
+            tg.enable_graph(z)
+            assert tg._graph is not None and tg.step_count == 0
+            for it in range(3):
+                le, ge = te.train_step(z, r=r)
+                lg, gg = tg.train_step(z, r=r)
+                assert abs(le - lg) < 2e-2 * max(1.0, abs(le)), (it, le, lg)
+                assert abs(ge - gg) < 5e-2 * max(1.0, abs(ge)), (it, ge, gg)
+            for (n, a), b in zip(me.named_parameters(), mg.parameters()):
+                assert torch.allclose(a, b, rtol=0, atol=3e-3), n
+            # every bucket's collective sits inside the captured step (the hooks launched all five during the capture)
+            assert sorted(tg.reducer.last_order) == list(range(5)) and tg.reducer.last_order[0] == 4
+            wall = {}
+            for name, t in (('eager', te), ('graph', tg)):
+                for _ in range(5):
+                    t.train_step(z, r=r)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    t.train_step(z, r=r)
+                torch.cuda.synchronize()
+                wall[name] = (time.perf_counter() - t0) / 30 * 1e3
+        print(f'[ddp world-of-one, reducer on] eager {wall["eager"]:.3f} ms/step, hipGraph {wall["graph"]:.3f} ms/step')
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        if os.path.isdir(out_dir):
+            import json
+            with open(os.path.join(out_dir, 'ddp_graph_world1.json'), 'w') as f:
+                json.dump({'shape': 'B=2 x 3x16x16, depth 3, default widths, bf16, RCCL world of one, 5 buckets',
+                           'eager_ms_per_step': wall['eager'], 'graph_ms_per_step': wall['graph']}, f)
+        assert wall['graph'] <= wall['eager'] * 1.05
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver\'s multi-GPU tier)')
-def test_two_rank_rccl_training_matches_single_process(tmp_path):
-    """Two ranks over RCCL: replicas stay bit-identical and the reduced gradient equals the single-process mean-loss
-    gradient (ranks are started as fresh child processes: nothing here has touched the GPU in them before)."""
+def _two_rank_training(tmp_path, backend, port):
+    """Two data-parallel ranks as fresh child processes (nothing has touched the GPU in them before), `backend` 'nccl' (= RCCL,
+    one card per rank) or 'gloo' (both ranks on cuda:0: the in-place gradient writes, the `_wmz_ready` notifications, the
+    bucket order and the VQ statistics all-reduce run with the real HIP kernels at world 2 on a ONE-GPU box).  Checked in the
+    ranks: replicas bit-identical after 3 steps, both codebooks identical; here: equal to the single-process run on the union
+    batch (gradient = mean over the two shards; VQ statistics = those of the whole batch)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'rank.py'
     script.write_text(f'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
-rank = int(os.environ['RANK']); torch.cuda.set_device(rank)
-dist.init_process_group('nccl', device_id=torch.device('cuda', rank))
+rank = int(os.environ['RANK'])
+dev = rank if {backend!r} == 'nccl' else 0
+torch.cuda.set_device(dev)
+if {backend!r} == 'nccl':
+    dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+else:
+    dist.init_process_group('gloo')
 from world_modelz_amd import config, main, train
+from world_modelz_amd.vq import VectorQuantizerEMA
 torch.manual_seed(5)
 m = main.VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=64, extents=(1, 1, 1), depth=2, dim_head=128, mlp_dim=256, heads=1).cuda()
 torch.manual_seed(6)
 z = torch.randint(0, 64, (4, 3, 16, 16), device='cuda')
 with config.compute_dtype(torch.bfloat16):
     tr = train.DenoiserTrainer(m, 64, lr=1e-3, warmup=0, distributed=True)
+    assert tr.reducer.world == 2 and len(tr.reducer.buckets) == 4
     for _ in range(3):
         tr.train_step(z[2 * rank:2 * rank + 2], r=torch.zeros(2))
+        assert sorted(tr.reducer.last_order) == [0, 1, 2, 3] and tr.reducer.last_order[0] == 3, tr.reducer.last_order
 flat = tr.arena.flat_param.clone()
 other = [torch.empty_like(flat) for _ in range(2)]
 dist.all_gather(other, flat)
 assert torch.equal(other[0], other[1]), 'replicas diverged'
+# VQ EMA statistics (vq.py:42-65) all-reduced before the update
+torch.manual_seed(12)
+q = VectorQuantizerEMA(16, 32).cuda()
+q.sync_stats = True
+q.train()
+g = torch.Generator().manual_seed(13)
+for _ in range(3):
+    x = torch.randn(2, 8, 8, 16, generator=g).cuda()
+    q(x[rank:rank + 1])
+cb = q.embedding.clone()
+both = [torch.empty_like(cb) for _ in range(2)]
+dist.all_gather(both, cb)
+assert torch.equal(both[0], both[1]), 'codebooks diverged'
 if rank == 0:
-    torch.save(flat.cpu(), {str(tmp_path / "dp.pt")!r})
+    torch.save({{'flat': flat.cpu(), 'embedding': cb.cpu(), 'cluster_size': q.cluster_size.cpu(), 'act': q.activation_count.cpu()}},
+               {str(tmp_path / "dp.pt")!r})
 dist.destroy_process_group()
 ''')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29541', str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+                        '--master-port', str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     from world_modelz_amd import config, main, train
+    from world_modelz_amd.vq import VectorQuantizerEMA
     torch.manual_seed(5)
     m = main.VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=64, extents=(1, 1, 1), depth=2, dim_head=128,
                                    mlp_dim=256, heads=1).cuda()
@@ -492,4 +567,25 @@ dist.destroy_process_group()
         for _ in range(3):
             tr.train_step(z, r=torch.zeros(4))
     dp = torch.load(str(tmp_path / 'dp.pt'))
-    assert torch.allclose(tr.arena.flat_param.cpu(), dp, rtol=0, atol=3e-3)
+    assert torch.allclose(tr.arena.flat_param.cpu(), dp['flat'], rtol=0, atol=3e-3)
+    torch.manual_seed(12)
+    q = VectorQuantizerEMA(16, 32).cuda()
+    q.train()
+    g = torch.Generator().manual_seed(13)
+    for _ in range(3):
+        q(torch.randn(2, 8, 8, 16, generator=g).cuda())
+    assert torch.allclose(q.embedding.cpu(), dp['embedding'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(q.cluster_size.cpu(), dp['cluster_size'], rtol=1e-6, atol=1e-7)
+    assert torch.equal(q.activation_count.cpu(), dp['act'])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver\'s multi-GPU tier)')
+def test_two_rank_rccl_training_matches_single_process(tmp_path):
+    """Two ranks over RCCL, one card each."""
+    _two_rank_training(tmp_path, 'nccl', 29541)
+
+
+def test_two_rank_training_on_one_card_matches_single_process(tmp_path):
+    """The same two-rank run with both ranks on cuda:0 and gloo carrying the collectives: everything of the data-parallel path
+    except RCCL itself, on the one-GPU box."""
+    _two_rank_training(tmp_path, 'gloo', 29543)

@@ -1,4 +1,7 @@
-"""Micro-driver for profiling single kernels under rocprofv3 (not part of the product)."""
+"""Micro-driver for profiling single kernels under rocprofv3 (not part of the product).
+
+    python3 tools/prof_kernels.py {fused|attn|attn_bwd|vq} N        config-4 shapes (65 536 tokens, dh 128, window 7x7x7)
+"""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -15,9 +18,20 @@ x = torch.randn(8, 32, 16, 16, 256, device='cuda').bfloat16()
 o = torch.randn(8, 32, 16, 16, 128, device='cuda').bfloat16()
 layers = list(m.transformer.layers)
 qkv = torch.randn(8, 32, 16, 16, 384, device='cuda').bfloat16()
+q, k, v = qkv[..., :128], qkv[..., 128:256], qkv[..., 256:]
+if which == 'attn_bwd':
+    out, lse, _ = ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1, need_lse=True)
+    dout = torch.randn_like(out)
+if which == 'vq':
+    xq = torch.randn(65536, 64, device='cuda')
+    cb = torch.randn(1024, 64, device='cuda')
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):
     if which == 'fused':
         fused.layer_fused(o, x, layers[0], layers[1])
     elif which == 'attn':
-        ops.local3d_attention_fwd(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], (3, 3, 3), 1)
+        ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1)
+    elif which == 'attn_bwd':
+        ops.local3d_attention_bwd(q, k, v, out, lse, dout, (3, 3, 3), 1)
+    elif which == 'vq':
+        ops.vq_argmin(xq, cb)
 torch.cuda.synchronize()

@@ -218,6 +218,19 @@ def linear_dgrad(dc, weight_t, dgelu_z=None):
     return out
 
 
+def workspace_snapshot(device):
+    """The per-device library workspaces as they are now (strong references): a captured hipGraph bakes their addresses in,
+    so its owner holds this tuple and re-captures when workspace_same() says one was replaced by a larger one."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    return (_wgrad_ws.get(device), _embed_ws.get(device), _vq_ws.get(device))
+
+
+def workspace_same(a, b):
+    return all(x is y for x, y in zip(a, b))
+
+
 _wgrad_ws = {}          # device -> fp32 scratch for the two-stage weight-gradient reduction (grown on demand, never shrunk)
 
 

@@ -125,7 +125,9 @@ class BucketedAllReduce:
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())      # the bucket's gradients are complete
             with torch.cuda.stream(self.stream):
-                if self._timing is not None:
+                # (under hipGraph capture the side stream has just joined the capture through wait_stream: the collective
+                #  becomes a graph node behind the bucket's last backward kernel; timing events are an eager-mode probe)
+                if self._timing is not None and not torch.cuda.is_current_stream_capturing():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
@@ -144,7 +146,7 @@ class BucketedAllReduce:
                 if not self.launched[b]:
                     self._launch(b)
             if self.cuda:
-                if self._timing is not None:
+                if self._timing is not None and not torch.cuda.is_current_stream_capturing():
                     w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     w0.record()
                     torch.cuda.current_stream().wait_stream(self.stream)

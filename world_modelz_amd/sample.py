@@ -85,7 +85,7 @@ def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_it
                          consistent_masking, generator):
     """The same loop with NO host work inside a frame but one graph launch per iteration: the draw + re-mask step is one
     kernel (wmz_sample_tokens_dev: top-k, softmax, inverse-CDF draw and re-mask per row, uniforms from in-kernel Philox keyed by
-    the generator's seed and a device-side iteration counter) captured in FRONT of the forward it feeds, the logits hand-over and
+    one draw from the caller's generator per call and a device-side iteration counter) captured in FRONT of the forward it feeds, the logits hand-over and
     the counter increment behind it.  Same distribution as the torch path (which stays for injected uniforms: the parity
     fixtures), different random stream."""
     from . import ops
@@ -99,7 +99,11 @@ def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_it
     denoised = torch.zeros(R, dtype=torch.int64, device=dev)
     counter = torch.zeros(1, dtype=torch.int64, device=dev)
     last_mask = torch.ones(R, dtype=torch.uint8, device=dev) if consistent_masking else None
-    seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+    # The in-kernel Philox is keyed per CALL by one 62-bit draw from the caller's generator (the global CPU generator when none
+    # is passed), which advances that generator like the reference's torch.multinomial / torch.rand do: two calls in a row see
+    # different noise, and reseeding the generator reproduces a call.  (A CUDA generator costs one device sync per call here.)
+    seed = int(torch.randint(0, 1 << 62, (1,), generator=generator,
+                             device=generator.device if generator is not None else 'cpu').item())
 
     def pre(z):                                                   # draw from the previous logits into the last frame, in place
         ops.sample_tokens(logits, sample_topk, alphas, num_embeddings, z[:, -1], denoised, counter, seed, last_mask)

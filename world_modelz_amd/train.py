@@ -340,19 +340,29 @@ class DenoiserTrainer(_TrainerBase):
         return per_sample.detach(), mean.detach()
 
     # ------------------------------------------------------------------------------------------------ hipGraph
-    def enable_graph(self, example_batch, warmup=3):
-        """Capture corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand re-pack as ONE hipGraph and replay
-        it from train_step() (single micro-batch, no data parallelism: the overlapped all-reduce path stays eager).
+    def enable_graph(self, example_batch, warmup=3, keep_warmup_updates=False):
+        """Capture corrupt -> forward -> CE -> backward -> [gradient all-reduce] -> grad-norm -> AdamW -> operand re-pack as ONE
+        hipGraph and replay it from train_step() (single micro-batch).  With a data-parallel reducer the per-layer RCCL
+        all-reduces are captured too: the reducer's side stream forks from the capturing stream when a bucket's last gradient
+        has landed and joins it again in finish(), so inside the graph every collective is a node whose only dependencies are
+        the backward kernels that produced its bucket -- the overlap of the eager path, without the host between the launches.
         What changes per step lives in device memory: the clips and their noise levels (static input tensors), the
         corruption's stream counter (advanced inside the graph), the learning rate and AdamW bias corrections (`hyper`).
-        The warm-up steps are REAL optimizer steps on `example_batch`."""
-        assert self.reducer is None and self.acc_steps == 1, 'the graphed step is single-process, one micro-batch'
+        The warm-up steps run the real step body on `example_batch` (RCCL creates its communicator and the kernels their
+        caches outside the capture); unless keep_warmup_updates, the weights, moments and step count they moved are restored,
+        so a run starts from the same state whether or not it is graphed."""
+        assert self.acc_steps == 1, 'the graphed step is one micro-batch per optimizer step'
         dev = self.arena.flat_param.device
         self._g_z = example_batch.contiguous().clone()
         self._g_r = torch.zeros(example_batch.shape[0], dtype=torch.float32, device=dev)
-        self._g_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        # the per-call part of the corruption's Philox stream id: graph replays count on the device, eager calls on the host
+        # (_corrupt_calls).  Bit 39 keeps the two ranges apart, so a run that mixes replays with eager fallbacks (another batch
+        # shape) or with corrupt_tokens never draws one stream twice.
+        self._g_ctr = torch.full((1,), 1 << 39, dtype=torch.int64, device=dev)
         self._g_hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self._g_seed = torch.initial_seed()
+        snap = None if keep_warmup_updates else (self.arena.flat_param.clone(), self.m.clone(), self.v.clone(), self.step_count,
+                                                 self.sampler_gen.get_state())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -366,7 +376,20 @@ class DenoiserTrainer(_TrainerBase):
         with torch.cuda.graph(g):
             self._g_out = self._graph_body()
         self.step_count -= 1               # capturing records the launches, it does not run a step
+        if snap is not None:
+            self.arena.flat_param.copy_(snap[0])
+            self.m.copy_(snap[1])
+            self.v.copy_(snap[2])
+            self.step_count = snap[3]
+            self.sampler_gen.set_state(snap[4])
+            _cast.invalidate()
+            self._refresh_operands()
         self._graph = g
+        # the graph bakes in the addresses of the library workspaces it was captured with (split-K partial tiles, counting-sort
+        # counters): hold them, and re-capture when ops replaced one (a later, larger eager call grows them)
+        self._g_ws = ops.workspace_snapshot(dev)
+        self._g_example = example_batch
+        self._g_warmup = warmup
         return self
 
     def _set_step_inputs(self, r):
@@ -392,10 +415,13 @@ class DenoiserTrainer(_TrainerBase):
         _cast.invalidate()
         self._refresh_operands()
         per_sample, mean = self.forward_backward(zc, target)
+        # data parallel: buckets the backward did not launch itself, then the compute stream joins the reducer's side stream
+        # (under capture: the fork / join edges of the graph); the 1/world of the gradient MEAN rides in the AdamW pass
+        scale = self.reducer.finish() if self.reducer is not None else 1.0
         st = L.stream()
         self.sq.zero_()
         L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
-               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, L.ptr(self.sq), st)   # + grad norm
+               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, float(scale), L.ptr(self.sq), st)   # + grad norm
         return per_sample, mean, self.sq
 
     def train_step(self, batch_z, r=None, generator=None):
@@ -403,6 +429,8 @@ class DenoiserTrainer(_TrainerBase):
         batch_z: one micro-batch [B,S,H,W], or a list of `accumulation_steps` of them (main.py:221-280: gradients
         accumulate over the micro-batches, each micro-loss scaled by 1/acc_steps, loss_sum is their sum)."""
         if self._graph is not None and not isinstance(batch_z, (list, tuple)) and batch_z.shape == self._g_z.shape:
+            if not ops.workspace_same(self._g_ws, ops.workspace_snapshot(self._g_z.device)):
+                self.enable_graph(self._g_example, self._g_warmup)           # a workspace moved under the captured graph
             self._g_z.copy_(batch_z, non_blocking=True)
             self._set_step_inputs(r)
             self._graph.replay()
