@@ -54,8 +54,14 @@ constexpr int KC = WMZ_ATTN_KC;
 constexpr int LOG_RS = KC == 8 ? 1 : 2;
 constexpr int RS = 1 << LOG_RS;       // a slab holds plane rows base, base + RS, ..: RS slabs ("phases") per 16-row chunk
 static_assert(KC * RS == 16, "a slab is one phase of a 16-row chunk");
-constexpr int NW = 16;                // waves per workgroup = query rows per workgroup
-constexpr int NBUF = KC == 8 ? 2 : 4; // LDS slab ring
+#ifndef WMZ_ATTN_NW
+#define WMZ_ATTN_NW 16
+#endif
+#ifndef WMZ_ATTN_NBUF
+#define WMZ_ATTN_NBUF (WMZ_ATTN_KC == 8 ? 2 : 4)
+#endif
+constexpr int NW = WMZ_ATTN_NW;       // waves per workgroup = query rows per workgroup
+constexpr int NBUF = WMZ_ATTN_NBUF;   // LDS slab ring
 constexpr int AHEAD = NBUF - 1;       // slabs in flight
 constexpr float DEFER = 8.f;          // log2 units
 
@@ -113,7 +119,7 @@ __device__ __forceinline__ void attn_vm_wait(int n) {
 }
 
 template <int DH, int MODE, bool ALIGNED, bool PROBE, bool TS>
-__global__ __launch_bounds__(NW * 64, 1) void attn_fwd_row16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                   const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                   float* __restrict__ LSE, float* __restrict__ DBG,
                                                                   AttnGeom G, long long* ts) {
