@@ -247,8 +247,11 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
 
 }  // namespace
 
-// fast path for 16-wide planes (attn_fwd_row16.hip)
+// fast paths for 16-wide planes: two query rows per wave (attn_fwd_row32.hip; planes with an even number of rows) and one
+// query row per wave (attn_fwd_row16.hip; odd H, and wmz_debug_attn_knobs variant 16 for A/B timing)
 int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
+                                const AttnGeom& G, hipStream_t st);
+int wmz_attn_fwd_row32_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
                                 const AttnGeom& G, hipStream_t st);
 
 // development knobs (wmz_debug_attn_knobs): ablation switches and kernel-variant selector, 0 / 0 in production
@@ -301,8 +304,10 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
   G.dbg = g_attn_dbg;
   G.variant = g_attn_variant;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !general)
+  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !general) {
+    if ((H & 1) == 0 && g_attn_variant != 16) return wmz_attn_fwd_row32_dispatch(q, k, v, out, lse, logits_dbg, G, st);
     return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G, st);
+  }
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {
     if (DHp == 32) return launch<bf16_t, 32, 1, 8, 16>(q, k, v, out, lse, logits_dbg, G, st);

@@ -174,6 +174,16 @@ __device__ __forceinline__ s16x4 ds_read_tr16_asm(unsigned addr) {
   return r;
 }
 __device__ __forceinline__ void ds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// ds_read_b128 as inline asm + a counted wait that names the value it releases (the consumer cannot be scheduled above it): a
+// hand-ordered queue of LDS reads, retired one by one while the younger ones are still in flight.
+template <int OFF>
+__device__ __forceinline__ s16x8 ds_read_b128_asm(unsigned addr) {
+  s16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_for(s16x8& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
 
 // Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48 -> the same result in all four) with the
 // gfx950 row / half swaps: two VALU instructions per level, no LDS round trip (__shfl_xor is a ds_bpermute: ~100+ cycles
