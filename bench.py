@@ -359,6 +359,7 @@ def main():
         'roofline': fused_roof if dominant_fused else attn_roof,
         'roofline_other': attn_roof if dominant_fused else fused_roof,
         'launch_mode': 'eager' if a.eager else 'hipGraph replay (1 graph = 1 forward step)',
+        'clip_streams': wcfg.get_clip_streams(),
         'sclk_mhz_after_timed_region': sclk_mhz,
         'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
                           'achieved_GBs': step_bytes / (ms_per_step * 1e-3) / 1e9,

@@ -282,6 +282,36 @@ def test_last_frame_cone_is_bit_identical(wmz, S, extents, depth, B, HW):
     assert rel(cone, ref) < 1e-2                        # measured 3-5e-3 (bf16 operands, fp32 accumulation)
 
 
+def test_clip_groups_on_parallel_streams_are_bit_identical(wmz):
+    """config.clip_streams: the inference forward cuts the batch into groups whose launch chains run on parallel streams
+    (clips are independent).  Logits must be bit-identical to the single-chain forward, eager and under hipGraph capture,
+    for even and uneven groupings."""
+    from world_modelz_amd.graph import GraphedForward
+    cfg = wmz['config']
+    torch.manual_seed(3)
+    C = 64
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(24, 16, 16), dim=256, num_classes=C, extents=(1, 2, 1), depth=2,
+                                          dim_head=128, mlp_dim=256, heads=1).cuda().eval()
+    z = torch.randint(0, C + 1, (6, 24, 16, 16), device='cuda')          # 6 clips x 24 planes: 144 workgroups per launch
+    prev = cfg.get_clip_streams()
+    try:
+        with cfg.compute_dtype(torch.bfloat16), cfg.last_frame_cone(False), torch.no_grad():
+            cfg.set_clip_streams(1)
+            ref = m(z).clone()
+            for n in (2, 3):
+                cfg.set_clip_streams(n)
+                assert torch.equal(m(z), ref), n
+            cfg.set_clip_streams(2)
+            g = GraphedForward(m, z)
+            assert torch.equal(g(z), ref)
+            z2 = torch.randint(0, C + 1, (6, 24, 16, 16), device='cuda')
+            y2 = g(z2).clone()
+            cfg.set_clip_streams(1)
+            assert torch.equal(m(z2), y2)
+    finally:
+        cfg.set_clip_streams(prev)
+
+
 def test_fused_kernel_stays_inside_its_buffers(wmz):
     """384 tokens = 1.5 workgroups of the fused per-token kernel: the waves past the end must neither read nor write
     (tiled stream layout: a whole 32-token tile per wave).  Every output is carved out of a larger canary-filled tensor."""

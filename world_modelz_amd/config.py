@@ -104,3 +104,20 @@ def get_check_tokens():
 def set_check_tokens(on):
     global _check_tokens
     _check_tokens = bool(on)
+
+
+# Inference forward of the denoiser on the fused kernels: clips are independent, so the batch can be cut into groups whose
+# launch chains run on parallel HIP streams (forked from / joined to the caller's stream; inside a hipGraph capture they become
+# parallel branches of the graph).  Every kernel of the step is one workgroup per CU and a single wave of workgroups, so a
+# full-batch launch pays its prologue burst, its critical path and its store tail with nothing to overlap them; two half-batch
+# chains fill the chip with 128 workgroups each and overlap one chain's bursts and tails with the other's compute.  1 = off.
+_clip_streams = int(os.environ.get('WMZ_CLIP_STREAMS', '2'))
+
+
+def get_clip_streams():
+    return _clip_streams
+
+
+def set_clip_streams(n):
+    global _clip_streams
+    _clip_streams = max(1, int(n))

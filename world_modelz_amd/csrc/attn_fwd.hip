@@ -305,7 +305,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
   G.variant = g_attn_variant;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !general) {
-    if ((H & 1) == 0 && g_attn_variant != 16) return wmz_attn_fwd_row32_dispatch(q, k, v, out, lse, logits_dbg, G, st);
+    if ((H & 1) == 0 && (g_attn_variant & 64)) return wmz_attn_fwd_row32_dispatch(q, k, v, out, lse, logits_dbg, G, st);
     return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G, st);
   }
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);

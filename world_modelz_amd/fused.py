@@ -217,8 +217,51 @@ def cone_planes(S, eS, depth):
     return need, src
 
 
+_side_streams = {}
+
+
 def _run(tr, z, cone):
-    """embedding -> depth x [attention launch, per-token launch].  cone: only the planes the last frame depends on."""
+    """embedding -> depth x [attention launch, per-token launch].  cone: only the planes the last frame depends on.
+    With config.clip_streams > 1 the clips are cut into that many groups, each group's chain on its own stream."""
+    from . import config
+    B = z.shape[0]
+    layers = list(tr.layers)
+    eS = int(layers[0][0].fn.extents[0])
+    use_cone = cone and all(int(a.fn.extents[0]) == eS for a, _ in layers)
+    planes = cone_planes(z.shape[1], eS, len(layers))[1][0] if use_cone else z.shape[1]
+    groups = min(config.get_clip_streams(), B)
+    # (a chain needs at least half a chip of workgroups -- one per plane -- to be worth its own stream: the dependence cone of
+    #  a small batch does not)
+    while groups > 1 and (B // groups) * planes < 128:
+        groups -= 1
+    if groups <= 1:
+        return _run_chain(tr, z, cone, None)
+    n_out = (cone_planes(z.shape[1], eS, len(layers))[0][-1]) if use_cone else z.shape[1]
+    out = torch.empty((B, n_out) + tuple(z.shape[2:]) + (D_,), dtype=torch.bfloat16, device=z.device)
+    cur = torch.cuda.current_stream()
+    pool = _side_streams.setdefault(z.device, [])
+    while len(pool) < groups - 1:
+        pool.append(torch.cuda.Stream(device=z.device))
+    z = z.contiguous()
+    bounds = [(g * B) // groups for g in range(groups + 1)]
+    # the weight streams are packed (cached per parameter version) on the caller's stream BEFORE the fork: every chain reads them
+    for l in range(len(layers)):
+        _layer_pack(None if l == 0 else layers[l - 1], layers[l])
+    _layer_pack(layers[-1], None)
+    for g in range(1, groups):
+        st = pool[g - 1]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            _run_chain(tr, z[bounds[g]:bounds[g + 1]], cone, out[bounds[g]:bounds[g + 1]])
+    _run_chain(tr, z[bounds[0]:bounds[1]], cone, out[bounds[0]:bounds[1]])
+    for g in range(1, groups):
+        cur.wait_stream(pool[g - 1])
+    return out
+
+
+def _run_chain(tr, z, cone, out):
+    """One chain of launches over the clips z on the current stream; the last launch writes into `out` (a batch slice of the
+    caller's result) when given."""
     layers = list(tr.layers)
     depth = len(layers)
     B, S, H, W = z.shape
@@ -251,7 +294,7 @@ def _run(tr, z, cone):
             ops._profile_hook('wmz_local3d_attn_fwd', False)
         tail = layers[l + 1] if l + 1 < depth else None
         wpack, vec = _layer_pack((attn, ff), tail)
-        xo = torch.empty((B, n_q, H, W, D_), dtype=bf, device=dev)
+        xo = out if (tail is None and out is not None) else torch.empty((B, n_q, H, W, D_), dtype=bf, device=dev)
         q = torch.empty((B, n_q, H, W, I_), dtype=bf, device=dev) if tail is not None else None
         kv = torch.empty((2, B, n_q, H, W, I_), dtype=bf, device=dev) if tail is not None else None
         xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if tiled and tail is not None else 0)
