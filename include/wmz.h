@@ -158,6 +158,19 @@ int wmz_embed_indexed_bwd(const int64_t* tok, const int64_t* pos, const void* dx
  * reference.  idx int64 [N]; dist_min (optional) fp32 [N]. */
 int wmz_vq_argmin(const float* x, long ldx, const float* codebook, int64_t* idx, float* dist_min,
                   int N, int C, int E, void* stream);
+
+/*
+ * wmz_vq_argmin_screened: the same result as wmz_vq_argmin (indices AND minimum distances bit-identical: the reference's fp32
+ * summation order decides), computed by screening on the matrix cores + exact re-check (csrc/vq_screen.hip): bf16 head / tail
+ * split products with a proven error bound pick each row's code; rows whose two best codes are closer than twice the bound
+ * (equal codes, near ties) are re-scanned over the whole codebook in the pinned arithmetic.  Built for embedding_dim 64 and a
+ * multiple of 64 codes: wmz_vq_argmin_screened_workspace_bytes returns 0 for any other shape (use wmz_vq_argmin).
+ * workspace: caller-allocated device scratch of that many bytes (contents irrelevant; rewritten by every call).
+ * Replaces: vq.py:30-33, :77-87 (codebook_distance + argmin), as wmz_vq_argmin does.
+ */
+long wmz_vq_argmin_screened_workspace_bytes(int N, int C, int E);
+int wmz_vq_argmin_screened(const float* x, long ldx, const float* codebook, int64_t* idx, float* dist_min, int N, int C, int E,
+                           void* workspace, long workspace_bytes, void* stream);
 /* decode (vq.py:89-94): out[n,:] = codebook[idx[n],:]; out in `dtype` (row stride ldo). */
 int wmz_vq_gather(const int64_t* idx, const float* codebook, void* out, long ldo, int N, int C, int E,
                   int dtype, void* stream);

@@ -226,6 +226,53 @@ def test_vq_argmin_vs_oracle(ops, N, C, E):
     assert torch.equal(dmin.cpu(), ref.min(-1).values)
 
 
+@pytest.mark.parametrize('case', ['gauss', 'duplicates', 'clustered', 'tiny', 'huge', 'rows_on_codes', 'nan_row', 'mixed_scale'])
+def test_vq_screened_argmin_equals_the_exact_scan(ops, case):
+    """embedding_dim 64 / multiple-of-64 codes take the screened search (matrix-core screening with a proven error bound +
+    exact re-check of undecided rows, csrc/vq_screen.hip).  It must return EXACTLY what the full scan in the pinned fp32 order
+    returns -- indices and minimum distances, ties to the lowest index -- on data built to stress the bound: duplicated codes,
+    codebooks clustered far tighter than the bound, rows lying on codes, tiny / huge magnitudes, a NaN row."""
+    g = torch.Generator().manual_seed(11)
+    N, C, E = 5000, 256, 64
+    x, cb = torch.randn(N, E, generator=g), torch.randn(C, E, generator=g)
+    if case == 'duplicates':
+        cb[100] = cb[7]; cb[200] = cb[7]; cb[201] = cb[13]
+        x[:64] = cb[7] + 1e-3 * torch.randn(64, E, generator=g)
+    elif case == 'clustered':                    # 8 clusters of 32 codes 1e-4 apart: every row's best codes are near ties
+        centers = torch.randn(8, E, generator=g)
+        cb = centers.repeat_interleave(32, 0) + 1e-4 * torch.randn(C, E, generator=g)
+    elif case == 'tiny':
+        x, cb = x * 1e-3, cb * 1e-3
+    elif case == 'huge':
+        x, cb = x * 300.0, cb * 300.0
+    elif case == 'rows_on_codes':
+        x[:C] = cb
+    elif case == 'nan_row':
+        x[5, 3] = float('nan')
+    elif case == 'mixed_scale':                  # one huge code sets emax: the bound widens for every row
+        cb[9] = cb[9] * 1e3
+    xd, cbd = dev(x), dev(cb)
+    idx_s, d_s = ops.vq_argmin(xd, cbd, need_dist=True)
+    idx_e, d_e = ops.vq_argmin(xd, cbd, need_dist=True, exact_scan=True)
+    assert torch.equal(idx_s, idx_e)
+    assert torch.equal(torch.nan_to_num(d_s, nan=-1.0), torch.nan_to_num(d_e, nan=-1.0))
+    if case not in ('nan_row',):
+        ref = ovq.distances(x, cb[None])[:, 0]
+        assert torch.equal(idx_s.cpu(), ref.argmin(-1)) and torch.equal(d_s.cpu(), ref.min(-1).values)
+
+
+def test_vq_screened_argmin_rechecks_few_rows_on_gaussian_data(ops):
+    """The share of rows the screening cannot decide (they cost a whole-codebook scan each) on the SURVEY 8(d) micro-bench data."""
+    from world_modelz_amd import ops as O
+    g = torch.Generator().manual_seed(0)
+    x, cb = dev(torch.randn(65536, 64, generator=g)), dev(torch.randn(1024, 64, generator=g))
+    O.vq_argmin(x, cb)
+    torch.cuda.synchronize()
+    nflag = int(O._vq_screen_ws[x.device][4:8].view(torch.int32).item())       # workspace header: [emax^2 bits, flag count]
+    print(f'[vq screened] {nflag} of 65536 rows re-scanned ({100.0 * nflag / 65536:.2f} %)')
+    assert nflag < 65536 // 50
+
+
 def test_vq_ties_and_duplicates(ops):
     torch.manual_seed(7)
     cb = torch.randn(40, 16)

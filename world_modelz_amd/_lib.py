@@ -90,6 +90,8 @@ SIGNATURES = {
     'wmz_grad_sqnorm': [c_void_p, c_long, c_float, c_void_p, c_void_p],
     'wmz_adamw_step': [c_void_p] * 4 + [c_long] + [c_double] * 5 + [c_long, c_double, c_void_p],
     'wmz_vq_argmin': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'wmz_vq_argmin_screened_workspace_bytes': [c_int, c_int, c_int],        # returns long
+    'wmz_vq_argmin_screened': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p],
     'wmz_vq_gather': [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_vq_ema_stats': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_void_p],
@@ -119,7 +121,7 @@ def lib():
             if fn is None:
                 continue  # declared but not built yet: calling it raises below
             fn.argtypes = argtypes
-            fn.restype = c_long if name.endswith(('_workspace_floats', '_workspace_ints')) else c_int
+            fn.restype = c_long if name.endswith(('_workspace_floats', '_workspace_ints', '_workspace_bytes')) else c_int
         _lib = L
     return _lib
 

@@ -111,15 +111,28 @@ def embed_pos3d_fwd(z, emb, pos_s, pos_h, pos_w, dtype):
     return x
 
 
-def vq_argmin(x, codebook, need_dist=False):
-    """x: [N,E] fp32, codebook: [C,E] fp32 -> int64 [N] (+ fp32 min distance)."""
+_vq_screen_ws = {}      # device -> byte scratch of the screened nearest-code search (grown on demand)
+
+
+def vq_argmin(x, codebook, need_dist=False, exact_scan=False):
+    """x: [N,E] fp32, codebook: [C,E] fp32 -> int64 [N] (+ fp32 min distance), bit-identical to the reference's CPU result.
+    embedding_dim 64 with a multiple of 64 codes: screening on the matrix cores + exact re-check (wmz_vq_argmin_screened);
+    anything else, or exact_scan=True: every (row, code) distance in the pinned fp32 order (wmz_vq_argmin)."""
     assert x.dtype == torch.float32 and codebook.dtype == torch.float32
     x, N, ldx = _rows(x)
     codebook = codebook.contiguous()
     C, E = codebook.shape
     idx = torch.empty((N,), dtype=torch.int64, device=x.device)
     dmin = torch.empty((N,), dtype=torch.float32, device=x.device) if need_dist else None
-    L.call('wmz_vq_argmin', L.ptr(x), ldx, L.ptr(codebook), L.ptr(idx), L.ptr(dmin), N, C, E, L.stream())
+    need = 0 if (exact_scan or N == 0 or ldx % 4 or x.data_ptr() % 16) else L.lib().wmz_vq_argmin_screened_workspace_bytes(N, C, E)
+    if need > 0:
+        ws = _vq_screen_ws.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _vq_screen_ws[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        L.call('wmz_vq_argmin_screened', L.ptr(x), ldx, L.ptr(codebook), L.ptr(idx), L.ptr(dmin), N, C, E, L.ptr(ws), ws.numel(),
+               L.stream())
+    else:
+        L.call('wmz_vq_argmin', L.ptr(x), ldx, L.ptr(codebook), L.ptr(idx), L.ptr(dmin), N, C, E, L.stream())
     return (idx, dmin) if need_dist else idx
 
 
@@ -224,7 +237,7 @@ def workspace_snapshot(device):
     device = torch.device(device)
     if device.type == 'cuda' and device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    return (_wgrad_ws.get(device), _embed_ws.get(device), _vq_ws.get(device))
+    return (_wgrad_ws.get(device), _embed_ws.get(device), _vq_ws.get(device), _vq_screen_ws.get(device))
 
 
 def workspace_same(a, b):
