@@ -512,6 +512,8 @@ def main():
             ae2 = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
             vt = VqaeTrainer(ae2, distributed=False)
             fr = torch.rand(64, 3, 64, 64, device=dev)
+            if not a.eager:
+                vt.enable_graph(fr)
             for _ in range(3):
                 vt.train_step(fr)
             torch.cuda.synchronize()
@@ -521,7 +523,8 @@ def main():
             torch.cuda.synchronize()
             vel = (time.perf_counter() - v0) / 5
             vqae = {'value': 64 / vel, 'unit': 'frames/s', 'ms_per_step': vel * 1e3,
-                    'what': 'VqaeTrainer.train_step on 64 RGB frames of 64x64 (codebook 1024 x 64, 2 down-scale steps, 128 planes), eager launches incl. 4 host read-backs'}
+                    'launch_mode': 'eager' if a.eager else 'hipGraph',
+                    'what': 'VqaeTrainer.train_step on 64 RGB frames of 64x64 (codebook 1024 x 64, 2 down-scale steps, 128 planes): one hipGraph replay + one host read-back per step'}
             log(f'VQ-AE training step: {vel * 1e3:.2f} ms per 64 frames')
             del vt, ae2
         out['vqae_train_step'] = vqae
@@ -724,6 +727,9 @@ def main():
             st = SparseDenoiserTrainer(sm, 8192, num_context=512, lr=1e-4, warmup=500, distributed=world > 1)
             zs = torch.randint(0, 8192, (6, 64, 16, 16), generator=gen).to(dev)
             rs = torch.full((6,), 0.5)
+            sparse_graphed = not a.eager and (world == 1 or backend == 'nccl')
+            if sparse_graphed:
+                st.enable_graph(zs)
             for _ in range(3):
                 st.train_step(zs, r=rs)
             barrier()
@@ -741,7 +747,8 @@ def main():
             sparse = {'value': 6 * world * nst / sel, 'unit': 'clips/s', 'ms_per_step': sel / nst * 1e3, 'steps': nst,
                       'tokens_per_s': 6 * 512 * world * nst / sel,
                       'what': 'config 5 per GPU: 6 clips x 512 context tokens of 64x16x16 latents, codebook 8192, '
-                              'VqSparseDiffusionModel dim 512 / 4x128 / depth 8 / mlp 1024, full training step (eager launches)'}
+                              'VqSparseDiffusionModel dim 512 / 4x128 / depth 8 / mlp 1024, full training step ('
+                              + ('one hipGraph replay per step)' if sparse_graphed else 'eager launches)'), 'launch_mode': 'hipGraph' if sparse_graphed else 'eager'}
             log(f'sparse (config 5) train step {sparse["ms_per_step"]:.2f} ms')
         out['sparse_step'] = sparse
     except Exception as e:  # noqa: BLE001

@@ -286,6 +286,58 @@ def test_vqae_trainer_step_matches_torch_adamw_and_revives_dead_codes(wmz):
         train.VqaeTrainer(m, loss_fn='Huber')
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_vqae_graphed_training_step_matches_eager(wmz, dtype):
+    """VqaeTrainer.enable_graph: the whole VQ-AE training step (encoder, VectorQuantizerEMA with its in-place EMA update, decoder,
+    losses, backward, AdamW) as ONE hipGraph.  The step has no randomness, so a graphed and an eager trainer started from the
+    same weights and fed the same batches walk the same trajectory: losses, codebook, every weight; the dead-code revival on
+    its interval still runs (between replays)."""
+    from world_modelz_amd import train
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    def make():
+        torch.manual_seed(31)
+        return VqAutoEncoder(embedding_dim=64, num_embeddings=128, downscale_steps=2, hidden_planes=32).cuda()
+    torch.manual_seed(32)
+    batches = [torch.rand(8, 3, 32, 32, device='cuda') for _ in range(5)]
+    with wmz['config'].compute_dtype(dtype):
+        me, mg = make(), make()
+        mg.load_state_dict(me.state_dict())
+        te = train.VqaeTrainer(me, lr=2e-4, vq_reuse_interval=4, distributed=False)
+        tg = train.VqaeTrainer(mg, lr=2e-4, vq_reuse_interval=4, distributed=False)
+        tg.enable_graph(batches[0], warmup=2)
+        assert tg.step_count == 2                               # the graph's warm-up steps are real steps
+        # ONE step from identical state: the eager trainer takes over the graphed one's weights, moments, BatchNorm and VQ buffers
+        def sync_state():
+            me.load_state_dict(mg.state_dict())
+            me.vq.activation_count.copy_(mg.vq.activation_count); me.vq.accumulated_error.copy_(mg.vq.accumulated_error)
+            te.m.copy_(tg.m); te.v.copy_(tg.v); te.step_count = tg.step_count
+            from world_modelz_amd import _cast
+            _cast.invalidate()
+        tol = 1e-4 if dtype == torch.float32 else 1e-2
+        for b in batches[:3]:
+            sync_state()
+            le = te.train_step(b)
+            lg = tg.train_step(b)
+            for a_, b_ in zip(le, lg):
+                assert abs(a_ - b_) <= tol * max(1.0, abs(a_)), (le, lg)
+            ptol = dict(rtol=0, atol=2.5 * 2e-4 + (0 if dtype == torch.float32 else 1e-2))      # (Adam: a sign flip of a ~0 gradient = 2 lr)
+            for (n, a_), b_ in zip(me.named_parameters(), mg.parameters()):
+                assert torch.allclose(a_, b_, **ptol), n
+            if dtype == torch.float32:
+                assert torch.allclose(me.vq.embedding, mg.vq.embedding, rtol=1e-4, atol=1e-5)
+                assert torch.equal(me.vq.activation_count, mg.vq.activation_count)
+            else:                               # bf16 activations: a latent at a near-tie may pick the other code in one of the runs
+                assert torch.allclose(me.vq.embedding, mg.vq.embedding, rtol=0, atol=0.1)
+                assert float((me.vq.activation_count - mg.vq.activation_count).abs().sum()) <= 0.02 * 8 * 64 * 2
+        # ... and on: the interval-4 dead-code revival runs between replays; the loss stays finite and falls on a repeated batch
+        hist = [tg.train_step(batches[0])[0] for _ in range(8)]
+        assert tg.step_count == 13 and all(v == v for v in hist) and hist[-1] < hist[0]
+        assert float(mg.vq.activation_count.sum()) <= 8 * 64    # reset at step 12, one batch counted since
+        # another batch shape falls back to eager launches
+        out = tg.train_step(torch.rand(4, 3, 32, 32, device='cuda'))
+        assert len(out) == 4 and all(v == v for v in out)
+
+
 def test_direct_3x3_conv_equals_the_implicit_gemm_kernel(wmz):
     """conv3x3s1_kernel (3x3, stride 1, pad 1, 64 -> 128 channels, bf16, planes of 8k x 32m pixels: the encoder's big layers)
     against conv2d_kernel on the same data: same K order, same epilogue arithmetic -> the same bits, statistics included

@@ -176,3 +176,36 @@ def test_sparse_step_config5_size_properties(wmz):
         losses = [tr.train_step(z, r=torch.full((B,), 0.3), indices=idx)[0] for _ in range(6)]
     print('[config-5 step] loss over 6 steps on one batch:', [f'{v:.3f}' for v in losses])
     assert all(l == l for l in losses) and losses[-1] < losses[0]
+
+
+def test_sparse_graphed_training_step(wmz):
+    """SparseDenoiserTrainer.enable_graph (config 5's step as ONE hipGraph: position sampling from torch's capture-aware device
+    RNG, gather, corruption from the device-counted Philox stream, forward, chunked linear + CE, backward, AdamW).  Every replay
+    draws fresh positions and a fresh corruption; training on one batch reduces the loss like the eager trainer does; with the
+    positions given (`indices=`) the trainer still takes the eager path."""
+    from world_modelz_amd import train
+    from world_modelz_amd.sparse_diffusion import VqSparseDiffusionModel
+    C, B, n = 512, 3, 512
+    def make():
+        torch.manual_seed(41)
+        return VqSparseDiffusionModel(shape=(16, 16, 16), dim=512, num_classes=C, depth=2, dim_head=128, mlp_dim=1024, heads=4).cuda()
+    torch.manual_seed(42)
+    z = torch.randint(0, C, (B, 16, 16, 16), device='cuda')
+    r = torch.full((B,), 0.3)
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        mg, me = make(), make()
+        tg = train.SparseDenoiserTrainer(mg, C, num_context=n, lr=3e-4, warmup=0, distributed=False)
+        te = train.SparseDenoiserTrainer(me, C, num_context=n, lr=3e-4, warmup=0, distributed=False)
+        p0 = tg.arena.flat_param.clone()
+        tg.enable_graph(z)
+        assert torch.equal(tg.arena.flat_param, p0) and tg.step_count == 0      # warm-up updates rolled back
+        lg = [tg.train_step(z, r=r)[0] for _ in range(12)]
+        le = [te.train_step(z, r=r)[0] for _ in range(12)]
+        assert tg._graph is not None and tg.step_count == 12
+        print('[config-5 graphed] loss', [f'{v:.3f}' for v in lg], 'eager', [f'{v:.3f}' for v in le])
+        assert all(v == v for v in lg) and lg[-1] < lg[0]
+        assert abs(lg[-1] - le[-1]) < 0.15 * le[0]              # same law, different random streams
+        assert len({round(v, 6) for v in lg[:4]}) == 4           # fresh positions / corruption on every replay
+        idx = tg.sample_positions(B, r, z.device)
+        out = tg.train_step(z, r=r, indices=idx)                 # injected positions: eager path
+        assert out[0] == out[0] and tg.step_count == 13

@@ -59,9 +59,10 @@ def corrupt_last_frame(batch_z, r, num_embeddings, generator=None, seed=None, ra
     return out, target
 
 
-def corrupt_tokens(tokens, r, num_embeddings, generator=None, seed=None, rank=None):
+def corrupt_tokens(tokens, r, num_embeddings, generator=None, seed=None, rank=None, counter=None):
     """The same corruption law on a [B, n] token matrix (minecraft/sparse_diffusion.py:440-449: every gathered context token
-    is perturbed).  Returns (corrupted [B, n], target [B, n])."""
+    is perturbed).  Returns (corrupted [B, n], target [B, n]).  counter: device int64 [1] holding the per-call part of the Philox
+    stream id (hipGraph replays: the caller advances it inside the graph)."""
     global _corrupt_calls
     assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.dim() == 2
     B, n = tokens.shape
@@ -72,6 +73,10 @@ def corrupt_tokens(tokens, r, num_embeddings, generator=None, seed=None, rank=No
     if seed is None:
         seed = generator.initial_seed() if generator is not None else torch.initial_seed()
     rank = _dp_rank() if rank is None else int(rank)
+    if counter is not None:
+        L.call('wmz_corrupt_tokens_dev', L.ptr(src), n, L.ptr(r), L.ptr(out), n, L.ptr(target), B, n, int(num_embeddings),
+               int(seed) & 0xFFFFFFFFFFFFFFFF, rank << 40, L.ptr(counter), L.stream())
+        return out, target
     _corrupt_calls += 1
     L.call('wmz_corrupt_tokens', L.ptr(src), n, L.ptr(r), L.ptr(out), n, L.ptr(target), B, n, int(num_embeddings),
            int(seed) & 0xFFFFFFFFFFFFFFFF, (rank << 40) | (_corrupt_calls & ((1 << 40) - 1)), L.stream())
@@ -312,34 +317,7 @@ class _TrainerBase:
             self.packs.refresh()
 
 
-class DenoiserTrainer(_TrainerBase):
-    """The step body of vq-video-diffusion/main.py:train on [B,S,H,W] token clips (last frame corrupted and predicted)."""
-
-    def forward_backward(self, batch_z, target, loss_scale=1.0):
-        """Forward, per-sample CE over the last frame, backward of loss.mean() * loss_scale (gradient accumulation:
-        main.py:274-278).  Returns (per_sample_loss[B], mean loss) on device."""
-        from . import config, fused
-        m = self.model
-        tr = m.transformer
-        dt = config.get_compute_dtype()
-        if (batch_z.is_cuda and hasattr(tr, 'pos_emb_s') and config.get_fused_training() and config.fused_backward()
-                and fused.supported(tr, dt) and batch_z.numel() % 32 == 0):
-            # fused stack in both directions: only the last plane leaves it (main.py:37), its logits and cross-entropy are
-            # one chunked linear + CE whose gradient is complete when the forward returns
-            tr.check_grid(batch_z)
-            last = fused.transformer_forward_train(tr, batch_z, last_only=True)              # [B, H, W, D]
-            mean, rows = linear_cross_entropy(last.reshape(-1, last.shape[-1]), m.logit_proj.weight, m.logit_proj.bias,
-                                              target.reshape(-1), chunk=4096, grad_scale=loss_scale)
-            mean.backward()                                # (the accumulation scale is inside the fused gradient)
-            return rows.view(batch_z.shape[0], -1).mean(dim=1), mean.detach()
-        y = m(batch_z)
-        loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
-        per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
-        mean = loss.mean()
-        (mean if loss_scale == 1.0 else mean * loss_scale).backward()
-        return per_sample.detach(), mean.detach()
-
-    # ------------------------------------------------------------------------------------------------ hipGraph
+    # ------------------------------------------------------------------------------------------------ hipGraph (every trainer)
     def enable_graph(self, example_batch, warmup=3, keep_warmup_updates=False):
         """Capture corrupt -> forward -> CE -> backward -> [gradient all-reduce] -> grad-norm -> AdamW -> operand re-pack as ONE
         hipGraph and replay it from train_step() (single micro-batch).  With a data-parallel reducer the per-layer RCCL
@@ -347,7 +325,8 @@ class DenoiserTrainer(_TrainerBase):
         has landed and joins it again in finish(), so inside the graph every collective is a node whose only dependencies are
         the backward kernels that produced its bucket -- the overlap of the eager path, without the host between the launches.
         What changes per step lives in device memory: the clips and their noise levels (static input tensors), the
-        corruption's stream counter (advanced inside the graph), the learning rate and AdamW bias corrections (`hyper`).
+        corruption's stream counter (advanced inside the graph), the learning rate and AdamW bias corrections (`hyper`);
+        torch's device RNG (config 5's position sampling) is capture-aware and advances per replay by itself.
         The warm-up steps run the real step body on `example_batch` (RCCL creates its communicator and the kernels their
         caches outside the capture); unless keep_warmup_updates, the weights, moments and step count they moved are restored,
         so a run starts from the same state whether or not it is graphed."""
@@ -408,13 +387,12 @@ class DenoiserTrainer(_TrainerBase):
     def _graph_body(self):
         a = self.arena
         a.flat_grad.zero_()
-        zc, target = corrupt_last_frame(self._g_z, self._g_r, self.C, seed=self._g_seed, rank=self.rank, counter=self._g_ctr)
-        self._g_ctr += 1
         # whatever is derived from the weights is rebuilt INSIDE the graph, every replay: the bulk operand copies by one
         # launch here, the fused kernels' weight streams by the forward (their cache entries are stale by construction)
         _cast.invalidate()
         self._refresh_operands()
-        per_sample, mean = self.forward_backward(zc, target)
+        per_sample, mean = self._graph_step(self._g_z, self._g_r)      # subclass: corruption (device counter) -> forward / backward
+        self._g_ctr += 1
         # data parallel: buckets the backward did not launch itself, then the compute stream joins the reducer's side stream
         # (under capture: the fork / join edges of the graph); the 1/world of the gradient MEAN rides in the AdamW pass
         scale = self.reducer.finish() if self.reducer is not None else 1.0
@@ -424,21 +402,59 @@ class DenoiserTrainer(_TrainerBase):
                L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, float(scale), L.ptr(self.sq), st)   # + grad norm
         return per_sample, mean, self.sq
 
+
+    def _replay(self, batch_z, r):
+        """One graphed step: inputs into the static buffers, one hipGraph launch, ONE host read-back (loss, grad-norm, per-sample
+        losses for the loss-aware sampler).  Returns (mean loss, grad norm)."""
+        if not ops.workspace_same(self._g_ws, ops.workspace_snapshot(self._g_z.device)):
+            self.enable_graph(self._g_example, self._g_warmup)           # a workspace moved under the captured graph
+        self._g_z.copy_(batch_z, non_blocking=True)
+        self._set_step_inputs(r)
+        self._graph.replay()
+        _cast.invalidate()             # the replay rewrote the weights: eager consumers rebuild their operand copies
+        per_sample, mean, sq = self._g_out
+        out = torch.cat([mean.reshape(1), sq.reshape(1), per_sample]).cpu()     # the step's one host sync
+        self.sampler.update_with_losses(self._g_r_host, out[2:])
+        return float(out[0]), math.sqrt(float(out[1]))
+
+
+class DenoiserTrainer(_TrainerBase):
+    """The step body of vq-video-diffusion/main.py:train on [B,S,H,W] token clips (last frame corrupted and predicted)."""
+
+    def forward_backward(self, batch_z, target, loss_scale=1.0):
+        """Forward, per-sample CE over the last frame, backward of loss.mean() * loss_scale (gradient accumulation:
+        main.py:274-278).  Returns (per_sample_loss[B], mean loss) on device."""
+        from . import config, fused
+        m = self.model
+        tr = m.transformer
+        dt = config.get_compute_dtype()
+        if (batch_z.is_cuda and hasattr(tr, 'pos_emb_s') and config.get_fused_training() and config.fused_backward()
+                and fused.supported(tr, dt) and batch_z.numel() % 32 == 0):
+            # fused stack in both directions: only the last plane leaves it (main.py:37), its logits and cross-entropy are
+            # one chunked linear + CE whose gradient is complete when the forward returns
+            tr.check_grid(batch_z)
+            last = fused.transformer_forward_train(tr, batch_z, last_only=True)              # [B, H, W, D]
+            mean, rows = linear_cross_entropy(last.reshape(-1, last.shape[-1]), m.logit_proj.weight, m.logit_proj.bias,
+                                              target.reshape(-1), chunk=4096, grad_scale=loss_scale)
+            mean.backward()                                # (the accumulation scale is inside the fused gradient)
+            return rows.view(batch_z.shape[0], -1).mean(dim=1), mean.detach()
+        y = m(batch_z)
+        loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
+        per_sample = loss.view(batch_z.shape[0], -1).mean(dim=1)
+        mean = loss.mean()
+        (mean if loss_scale == 1.0 else mean * loss_scale).backward()
+        return per_sample.detach(), mean.detach()
+
+    def _graph_step(self, z, r):
+        zc, target = corrupt_last_frame(z, r, self.C, seed=self._g_seed, rank=self.rank, counter=self._g_ctr)
+        return self.forward_backward(zc, target)
+
     def train_step(self, batch_z, r=None, generator=None):
         """corrupt -> forward/backward (all-reduce overlapped) -> grad-norm -> AdamW; sampler update on the host.
         batch_z: one micro-batch [B,S,H,W], or a list of `accumulation_steps` of them (main.py:221-280: gradients
         accumulate over the micro-batches, each micro-loss scaled by 1/acc_steps, loss_sum is their sum)."""
         if self._graph is not None and not isinstance(batch_z, (list, tuple)) and batch_z.shape == self._g_z.shape:
-            if not ops.workspace_same(self._g_ws, ops.workspace_snapshot(self._g_z.device)):
-                self.enable_graph(self._g_example, self._g_warmup)           # a workspace moved under the captured graph
-            self._g_z.copy_(batch_z, non_blocking=True)
-            self._set_step_inputs(r)
-            self._graph.replay()
-            _cast.invalidate()             # the replay rewrote the weights: eager consumers rebuild their operand copies
-            per_sample, mean, sq = self._g_out
-            out = torch.cat([mean.reshape(1), sq.reshape(1), per_sample]).cpu()     # the step's one host sync
-            self.sampler.update_with_losses(self._g_r_host, out[2:])
-            return float(out[0]), math.sqrt(float(out[1]))
+            return self._replay(batch_z, r)
         micro = list(batch_z) if isinstance(batch_z, (list, tuple)) else [batch_z]
         assert len(micro) == self.acc_steps, f'expected {self.acc_steps} micro-batches, got {len(micro)}'
         rs = list(r) if isinstance(r, (list, tuple)) else [r] * len(micro)
@@ -489,8 +505,19 @@ class SparseDenoiserTrainer(_TrainerBase):
         mean.backward()                                    # (the accumulation scale is inside the fused gradient)
         return rows.view(tokens.shape[0], -1).mean(dim=1), mean.detach()
 
+    def _graph_step(self, z, r):
+        """The device side of one step on static inputs (captured by enable_graph): position sampling (torch's capture-aware
+        device RNG), gather, corruption from the in-kernel Philox stream counted on the device, forward / backward."""
+        B = z.shape[0]
+        indices = self.sample_positions(B, r, z.device)
+        gathered = torch.gather(z.reshape(B, -1), 1, indices)
+        tokens, target = corrupt_tokens(gathered, r, self.C, seed=self._g_seed, rank=self.rank, counter=self._g_ctr)
+        return self.forward_backward(tokens, indices, target)
+
     def train_step(self, batch_z, r=None, indices=None, generator=None):
         """batch_z: [B,S,H,W] token clips (the frozen VQ-AE's output).  Returns (mean loss, grad norm)."""
+        if self._graph is not None and indices is None and batch_z.shape == self._g_z.shape:
+            return self._replay(batch_z, r)
         B = batch_z.shape[0]
         if r is None:
             r = self.sampler.sample(B, generator=self.sampler_gen)
@@ -541,22 +568,84 @@ class VqaeTrainer:
             return self.lr
         return self.lr * 0.5 ** ((self.step_count // self.steps_per_epoch) // 3)
 
-    def train_step(self, batch):
-        """batch: [B, C, H, W] frames on the GPU.  Returns (loss, reconstruction loss, latent loss, perplexity) as floats."""
-        self.model.train()
-        self.arena.zero_grad()
+    def _forward_backward(self, batch):
+        """model -> reconstruction + commitment loss -> backward (gradients land in the arena).  Returns the four scalars of the
+        step as ONE device tensor [loss, reconstruction loss, latent loss, perplexity]."""
         recon, latent_loss, perplexity = self.model(batch)
         r_loss = self.loss_fn(recon, batch)
         loss = r_loss + self.latent_loss_weight * latent_loss
         loss.backward()
+        return torch.stack([loss.detach(), r_loss.detach(), latent_loss.detach().reshape(()), perplexity.detach().reshape(())])
+
+    def enable_graph(self, example_batch, warmup=2):
+        """Capture zero-grad -> encoder -> VectorQuantizerEMA (incl. the in-place EMA codebook update, vq.py:42-65) -> decoder ->
+        losses -> backward -> AdamW as ONE hipGraph, replayed by train_step() for batches of this shape: ~460 launches with the
+        autograd bookkeeping between them become one launch, the step's four scalars come back in one read.  The learning rate
+        and AdamW's bias corrections live in device memory (wmz_adamw_step_dev); the dead-code revival (train_vqae.py:160-164,
+        host-driven, every vq_reuse_interval steps) runs between replays.  The warm-up steps are real training steps."""
+        assert self.reducer is None, 'the graphed VQ-AE step is single-process (gloo / RCCL statistics sync stays eager)'
+        dev = self.arena.flat_param.device
+        self.model.train()
+        self._g_x = example_batch.contiguous().clone()
+        self._g_hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._g_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._set_hyper()
+                self._graph_body()
+                self._after_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._g_out = self._graph_body()
+        self._graph = g
+        self._g_ws = ops.workspace_snapshot(dev)
+        return self
+
+    def _set_hyper(self):
+        lr = self.lr_now()
+        self.step_count += 1
+        bc1 = 1.0 - self.betas[0] ** self.step_count
+        bc2 = 1.0 - self.betas[1] ** self.step_count
+        self._g_hyper.copy_(torch.tensor([lr, bc1, math.sqrt(bc2)], dtype=torch.float32), non_blocking=True)
+
+    def _graph_body(self):
+        a = self.arena
+        a.flat_grad.zero_()
+        _cast.invalidate()                 # (the conv / codebook operand copies are rebuilt from the weights inside the graph)
+        out = self._forward_backward(self._g_x)
+        self._g_sq.zero_()
+        L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
+               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, L.ptr(self._g_sq), L.stream())
+        return out
+
+    def _after_step(self):
+        _cast.invalidate()
+        if self.vq_reuse_interval and self.step_count % self.vq_reuse_interval == 0:
+            self.reused = self.model.vq.reuse_inactive()
+            self.model.vq.reset_stats()
+
+    def train_step(self, batch):
+        """batch: [B, C, H, W] frames on the GPU.  Returns (loss, reconstruction loss, latent loss, perplexity) as floats."""
+        self.model.train()
+        if getattr(self, '_graph', None) is not None and batch.shape == self._g_x.shape and \
+                ops.workspace_same(self._g_ws, ops.workspace_snapshot(batch.device)):
+            self._g_x.copy_(batch, non_blocking=True)
+            self._set_hyper()
+            self._graph.replay()
+            vals = self._g_out.cpu()                                  # the step's one host sync
+            self._after_step()
+            return tuple(float(v) for v in vals)
+        self.arena.zero_grad()
+        out = self._forward_backward(batch)
         scale = self.reducer.finish() if self.reducer is not None else 1.0
         lr = self.lr_now()
         self.step_count += 1
         a = self.arena
         L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel, float(lr),
                self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), L.stream())
-        _cast.invalidate()
-        if self.vq_reuse_interval and self.step_count % self.vq_reuse_interval == 0:
-            self.reused = self.model.vq.reuse_inactive()
-            self.model.vq.reset_stats()
-        return float(loss), float(r_loss), float(latent_loss), float(perplexity)
+        self._after_step()
+        return tuple(float(v) for v in out.cpu())
