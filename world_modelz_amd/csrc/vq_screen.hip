@@ -52,6 +52,10 @@ __device__ __forceinline__ float dist_pinned64(XF xf, CF cf) {
   return fin;
 }
 
+// workspace header (max |e|^2 bits, flagged-row count) back to zero: a kernel, not hipMemsetAsync -- the call is captured into
+// hipGraphs (training steps), where a memset node in front of kernels that read its target proved unreliable on replay
+__global__ void vq_header_zero_kernel(unsigned* hdr) { if (threadIdx.x < 4) hdr[threadIdx.x] = 0u; }
+
 // codebook -> bf16 head / tail rows, -|e|^2 / 2, max |e|^2 (as uint bits: positive floats order like integers)
 __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ CB, unsigned short* __restrict__ EH,
                                                       unsigned short* __restrict__ EL, float* __restrict__ NH,
@@ -251,7 +255,7 @@ extern "C" int wmz_vq_argmin_screened(const float* x, long ldx, const float* cod
   unsigned short* EL = EH + (long)C * E;
   float* NH = (float*)(EL + (long)C * E);
   int* flagged = (int*)(NH + C);
-  if (hipMemsetAsync(ws, 0, 16, st) != hipSuccess) { wmz_set_error("wmz_vq_argmin_screened: memset failed"); return WMZ_ERR_HIP; }
+  hipLaunchKernelGGL(vq_header_zero_kernel, dim3(1), dim3(64), 0, st, (unsigned*)ws);
   hipLaunchKernelGGL(vq_prep_kernel, dim3(wmz_cdiv(C, 4)), dim3(256), 0, st, codebook, EH, EL, NH, emax2, C);
   hipLaunchKernelGGL(vq_screen_kernel, dim3(wmz_cdiv(N, ROWS_WG)), dim3(ROWS_WG * 2), 0, st, x, ldx, codebook, EH, EL, NH, emax2, idx,
                      dist_min, nflag, flagged, N, C);
