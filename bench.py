@@ -435,9 +435,9 @@ def main():
         out['window_7x3x3'] = win
         gc.collect()
         # ---- secondary figure: the reference's two PUBLISHED runs (results/README.md: dim 96 / mlp 256 / depth 12 and dim 384 /
-        # mlp 512 / depth 20, one head of 128, window 7x3x3), same clips.  Their widths are outside the fused per-token kernel
-        # (built for 256 / 128 / 256: DESIGN.md 4.2), so the per-token work runs on linear_kernel with LayerNorm / GELU / residual
-        # fused into its prologue and epilogue, the attention on the same row16 kernel; one hipGraph per step.
+        # mlp 512 / depth 20, one head of 128, window 7x3x3), same clips.  Their widths are outside the default-width per-token
+        # kernel (register-chained 32-token waves: DESIGN.md 4.2) and run on csrc/layer_chain.hip (16-token waves, same fusion: one
+        # attention launch + one per-token launch per layer); one hipGraph per step.
         pub = None
         if not a.eager and not a.no_cone and dtype == torch.bfloat16:
             pub = []

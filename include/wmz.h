@@ -241,6 +241,20 @@ int wmz_local3d_attn_fwd_planes(const void* q, const void* k, const void* v, voi
 int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                const float* vec, int B, int planes_out, int planes_in, int HW, int D, int I, int M,
                                int has_head, int has_tail, int xflags, float eps, void* stream);
+/*
+ * The same fusion for widths the default-width kernel cannot hold in registers (csrc/layer_chain.hip: 16-token waves, MFMA
+ * 16x16x32, fp32 residual stream in registers, activations chained lane-locally, weights by an LDS-DMA ring): the reference's
+ * published runs (dim 96 / mlp 256, dim 384 / mlp 512; results/README.md).
+ * wmz_layer_chain_supported: 1 when (D, I, M) is instantiated, *mc = the hidden-chunk size the weight packer must use.
+ * Tensors as wmz_layer_fused_fwd_planes (row-major only); wpack / vec in the order of world_modelz_amd/fused.py::_chain_pack,
+ * wpack followed by two slabs of readable padding.  Replaces: local_3d_attention.py:11-31, :46-53, :106-108, :159-161.
+ */
+int wmz_layer_chain_supported(int D, int I, int M, int* mc);
+int wmz_layer_chain_slab_pieces(void);     /* pieces (KB) per weight slab: the packer pads every stage to a multiple of it */
+int wmz_layer_chain_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                               const float* vec, int B, int n_q, int n_in, int HW, int D, int I, int M, int head, int tail,
+                               float eps, void* stream);
+
 int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                    const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                    const float* vec, int B, int S, int H, int W, int planes_out, int D, int I, int M,

@@ -136,9 +136,9 @@ def test_default_config_vs_oracle_bf16(wmz):
 @pytest.mark.parametrize('dim,mlp', [(96, 256), (384, 512)])
 def test_published_run_widths_vs_oracle(wmz, dim, mlp):
     """The reference's two published models (results/README.md: dim 96 / mlp 256 and dim 384 / mlp 512, one head of 128, window
-    7x3x3) run on the per-op path (their widths are outside the fused per-token kernel): fp32 parity with the oracle, bounded
-    bf16 error, and the last-frame cone bit-identical to the full grid -- the configurations `bench.py` times as
-    `published_run_widths`."""
+    7x3x3): fp32 parity with the oracle on the per-op path, bounded bf16 error on the chain kernel (csrc/layer_chain.hip: their
+    widths are outside the default-width fused kernel), and the last-frame cone setting changing nothing -- the configurations
+    `bench.py` times as `published_run_widths`."""
     torch.manual_seed(42)
     m = wmz['main'].VqVideoDiffusionModel(data_shape=(5, 16, 16), dim=dim, num_classes=1024, extents=(3, 1, 1), depth=3,
                                           dim_head=128, mlp_dim=mlp, heads=1)
@@ -161,6 +161,36 @@ def test_published_run_widths_vs_oracle(wmz, dim, mlp):
     print(f'dim {dim}: bf16 end-to-end logits error vs fp32 oracle: {e16:.3e}')
     assert e16 < 1e-2
     assert torch.equal(y16, y16_full)
+
+
+@pytest.mark.parametrize('dim,mlp,shape', [(96, 256, (3, 5, 5)), (384, 512, (2, 7, 9)), (96, 256, (4, 16, 16))])
+def test_chain_kernel_ragged_grids_vs_oracle(wmz, dim, mlp, shape):
+    """csrc/layer_chain.hip (the per-token kernel of the published widths) on token counts that are not whole 128-token
+    workgroups / 16-token waves, and through the hipGraph runner: logits against the fp32 oracle within the bf16 error of the
+    per-op path, and equal to the per-op path's within the two paths' rounding differences."""
+    from world_modelz_amd import fused
+    from world_modelz_amd.graph import GraphedForward
+    torch.manual_seed(5)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=shape, dim=dim, num_classes=200, extents=(1, 1, 1), depth=2, dim_head=128,
+                                          mlp_dim=mlp, heads=1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    z = torch.randint(0, 201, (3,) + shape)
+    ref = oden.denoiser_forward(sd, z, (1, 1, 1), 1)
+    m = m.cuda().eval()
+    assert fused.chain_supported(m.transformer, torch.bfloat16)
+    with torch.no_grad(), wmz['config'].compute_dtype(torch.bfloat16):
+        y = m(z.cuda())
+        yg = GraphedForward(m, z.cuda())(z.cuda()).clone()
+        orig = fused.chain_supported
+        fused.chain_supported = lambda *a: False
+        try:
+            y_ops = m(z.cuda())
+        finally:
+            fused.chain_supported = orig
+    assert torch.equal(y, yg)
+    e, e_ops = rel(y, ref), rel(y_ops, ref)
+    print(f'dim {dim} grid {shape}: chain kernel {e:.3e}, per-op path {e_ops:.3e} vs fp32 oracle')
+    assert e < 1e-2 and e < 2.0 * e_ops + 2e-3 and rel(y, y_ops) < 2e-2
 
 
 def test_cpu_input_is_refused(wmz):

@@ -37,6 +37,128 @@ def supported(transformer, x_dtype):
     return True
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# other widths: csrc/layer_chain.hip (16-token waves, MFMA 16x16x32, lane-group-major activations)
+
+def chain_widths(transformer):
+    """(D, I, M, MC) when every layer of `transformer` has the same widths and wmz_layer_chain_fwd_planes is built for them,
+    else None."""
+    import ctypes
+    layers = list(transformer.layers)
+    if not layers:
+        return None
+    a0, f0 = layers[0][0].fn, layers[0][1].fn
+    if isinstance(a0.to_out, torch.nn.Identity) or not hasattr(a0, 'to_q'):
+        return None
+    I, D = a0.to_q.weight.shape
+    M = f0.net[0].weight.shape[0]
+    for attn, ff in layers:
+        a, f = attn.fn, ff.fn
+        if isinstance(a.to_out, torch.nn.Identity) or a.dropout > 0 or f.dropout > 0:
+            return None
+        if a.to_q.weight.shape != (I, D) or f.net[0].weight.shape != (M, D):
+            return None
+    mc = ctypes.c_int(0)
+    if not L.lib().wmz_layer_chain_supported(D, I, M, ctypes.byref(mc)):
+        return None
+    return D, I, M, mc.value
+
+
+def chain_supported(transformer, x_dtype):
+    return x_dtype == torch.bfloat16 and hasattr(transformer, 'pos_emb_s') and chain_widths(transformer) is not None
+
+
+def _chain_pieces(w):
+    """[N, K] fp32 -> the kernel's 1 KB MFMA 16x16x32 A operands in (k-step, 16-feature block) order, lane-linear:
+    piece (ks, b), lane l = 16 ga + m, element j = W[(m >> 2) N/4 + 4 b + (m & 3)][ga K/4 + 8 ks + j] -- output feature and k
+    axis both "lane-group-major" (csrc/layer_chain.hip), padded with zero pieces to whole slabs."""
+    N, K = w.shape
+    NB, KS = N // 16, K // 32
+    dev = w.device
+    m = torch.arange(16, device=dev)
+    rows = (m >> 2)[None, :] * (N // 4) + 4 * torch.arange(NB, device=dev)[:, None] + (m & 3)[None, :]            # [NB, 16]
+    ga = torch.arange(4, device=dev)
+    cols = (ga[None, :, None] * (K // 4) + 8 * torch.arange(KS, device=dev)[:, None, None]
+            + torch.arange(8, device=dev)[None, None, :])                                                             # [KS, 4, 8]
+    t = w[rows.reshape(-1)][:, cols.reshape(-1)].reshape(NB, 16, KS, 4, 8).permute(2, 0, 3, 1, 4).reshape(-1, 512)   # [pieces, 512]
+    pad = (-t.shape[0]) % L.lib().wmz_layer_chain_slab_pieces()
+    if pad:
+        t = torch.cat([t, t.new_zeros(pad, 512)], 0)
+    return t
+
+
+def _chain_pack(head, tail, D, I, M, MC):
+    """(wpack bf16, vec fp32) for one launch of wmz_layer_chain_fwd_planes: stages to_out | MC-wide feed-forward chunks (W1'
+    rows, then W2 columns) | q | k | v, LayerNorm affines folded in (W1' = W1 diag(g2), b1' = b1 + W1 be2; to_k / to_v likewise
+    with the next layer's norm); vec = bout | b1' | b2 | bk' | bv'.  Cached per parameter version."""
+    params = []
+    if head is not None:
+        attn, ff = head
+        params += [attn.fn.to_out[0].weight, attn.fn.to_out[0].bias, ff.norm.weight, ff.norm.bias,
+                   ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias]
+    if tail is not None:
+        an = tail[0]
+        params += [an.norm.weight, an.norm.bias, an.fn.to_q.weight, an.fn.to_k.weight, an.fn.to_v.weight, an.fn.to_v.bias]
+
+    def build(*ps):
+        ps = [p.detach().float() for p in ps]
+        dev = ps[0].device
+        parts = []
+        vec = torch.zeros(2 * D + M + 2 * I, dtype=torch.float32, device=dev)
+        if head is not None:
+            wout, bout, g2, be2, w1, b1, w2, b2 = ps[:8]
+            parts.append(_chain_pieces(wout))
+            w1f = w1 * g2[None, :]
+            vec[:D] = bout
+            vec[D:D + M] = b1 + w1 @ be2
+            vec[D + M:2 * D + M] = b2
+            for c in range(M // MC):
+                parts.append(_chain_pieces(w1f[c * MC:(c + 1) * MC]))
+                parts[-1] = parts[-1][:(MC // 16) * (D // 32)]                   # (no padding inside a chunk: its two GEMMs share slabs)
+                parts.append(_chain_pieces(w2[:, c * MC:(c + 1) * MC])[:(D // 16) * (MC // 32)])
+        if tail is not None:
+            g1, be1, wq, wk, wv, bv = ps[-6:]
+            parts.append(_chain_pieces(wq))
+            parts.append(_chain_pieces(wk * g1[None, :]))
+            parts.append(_chain_pieces(wv * g1[None, :]))
+            vec[2 * D + M:2 * D + M + I] = wk @ be1
+            vec[2 * D + M + I:] = bv + wv @ be1
+        stream = torch.cat(parts, 0)
+        sp = L.lib().wmz_layer_chain_slab_pieces()
+        assert stream.shape[0] % sp == 0
+        wpack = torch.cat([stream.reshape(-1), stream.new_zeros(3 * sp * 512)]).to(torch.bfloat16).contiguous()
+        return wpack, vec
+    return _cast.cached(params, f'chainpack{D}_{I}_{M}', build)
+
+
+def transformer_forward_chain(tr, z):
+    """Inference forward of Local3dAttentionTransformer on the chain kernel (bf16, widths of chain_widths): embedding launch,
+    then per layer ONE attention launch + ONE per-token launch.  Returns the stream [B, S, H, W, D] (row-major)."""
+    from . import functional as Fw
+    D, I, M, MC = chain_widths(tr)
+    layers = list(tr.layers)
+    B, S, H, W = z.shape
+    HW = H * W
+    dev, bf = z.device, torch.bfloat16
+    x = Fw.embed_tokens(z, tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight)
+    assert x.dtype == bf and x.is_contiguous()
+
+    def launch(o, x_in, head, tail):
+        wpack, vec = _chain_pack(head, tail, D, I, M, MC)
+        xo = torch.empty((B, S, H, W, D), dtype=bf, device=dev) if head is not None else None
+        q = torch.empty((B, S, H, W, I), dtype=bf, device=dev) if tail is not None else None
+        kv = torch.empty((2, B, S, H, W, I), dtype=bf, device=dev) if tail is not None else None
+        L.call('wmz_layer_chain_fwd_planes', L.ptr(o), L.ptr(x_in), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
+               B, S, S, HW, D, I, M, 1 if head is not None else 0, 1 if tail is not None else 0, 1e-5, L.stream())
+        return xo, q, kv
+    _, q, kv = launch(None, x, None, layers[0])
+    for l, (attn, ff) in enumerate(layers):
+        heads, ext = attn.fn.heads, attn.fn.extents
+        o, _, _ = ops.local3d_attention_fwd(q, kv[0], kv[1], ext, heads)
+        x, q, kv = launch(o, x, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None)
+    return x
+
+
 def _layer_pack(head, tail):
     """head / tail: (attn PreNorm, ff PreNorm) of the layer whose to_out+FF run, and of the layer whose q|k|v run.
     Returns (wpack bf16, vec fp32) built by ONE launch of wmz_layer_fused_pack from the fp32 parameters: the weights in

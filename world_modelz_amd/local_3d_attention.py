@@ -170,6 +170,9 @@ class Local3dAttentionTransformer(nn.Module):
                 # inference, bf16, default widths: one attention launch + one per-token launch per layer, the
                 # embedding fused into the first one
                 return fused.transformer_forward(self, z=img_z)
+            if fused.chain_supported(self, get_compute_dtype()):
+                # the reference's published widths: the same fusion on csrc/layer_chain.hip
+                return fused.transformer_forward_chain(self, img_z)
         else:
             from . import config, fused
             if config.get_fused_training() and fused.supported(self, config.get_compute_dtype()):
