@@ -148,32 +148,20 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
         __builtin_amdgcn_global_load_lds((gptr_t)(y2p + c), (lptr_t)(dbuf + I::IMG + piece * 1024), 16, 0, 0);
       }
     }
-  };
-  // MODE 1: per-visitor (query) lse2 / delta of a slab (slab row r = 16 t + w <-> plane row base + 2 t, column w): plain
-  // loads issued BEFORE that slab's DMA (waiting for them never waits for the DMA), parked in registers during the previous
-  // slab's compute, written to LDS at its end
-  float vl = 0.f, vd = 0.f;
-  auto fetch_rows = [&]() {
-    vl = 0.f; vd = 0.f;
-    if (tid < KC * 16) {
-      const int prow = 2 * (tid >> 4);
-      if (prow <= dlim) {
-        const long row = vrow_n + (long)prow * 16 + (tid & 15);
-        vl = P.lse[row * G.heads + head] * L2E;
-        vd = P.delta[row * G.heads + head];
+    if constexpr (MODE == 1) {
+      // per-visitor (query) lse / delta of the slab (slab row r = 16 t + w <-> plane row base + 2 t, column w) ride the same
+      // DMA queue, one dword per lane: waves 0, 1 bring the 128 lse values, waves 2, 3 the 128 deltas.  (As plain loads parked
+      // in registers they made hipcc drain vmcnt(0) -- i.e. the slab just requested -- at the first LDS read of every step.)
+      if (wave < 4) {
+        const int idx = (wave & 1) * 64 + lane;             // slab key 0 .. 127
+        const int prow = min(2 * (idx >> 4), dlim);
+        const long row = vrow_n + (long)prow * 16 + (idx & 15);
+        const float* src = (wave < 2 ? P.lse : P.delta) + row * G.heads + head;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dbuf + 2 * I::IMG + (wave >> 1) * (KC * 16 * 4) + (wave & 1) * 256), 4, 0, 0);
       }
     }
   };
-  auto put_rows = [&](int slot) {
-    if (tid < KC * 16) {
-      float* vt = reinterpret_cast<float*>(smem + slot * I::BUF + 2 * I::IMG);
-      vt[tid] = vl;
-      vt[KC * 16 + tid] = vd;
-    }
-  };
-
   next_state();
-  if constexpr (MODE == 1) { if (nslab > 0) { fetch_rows(); put_rows(0); } }
   if (nslab > 0) issue();
 
   // ---- owner rows (after the first slab's requests: both are in flight together)
@@ -231,7 +219,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
     __builtin_amdgcn_s_barrier();
     const bool more = j + 1 < nslab;
     if (more) {
-      if constexpr (MODE == 1) fetch_rows();
       if (!(WMZ_ABWD_ABL & 2)) issue();
     }
     const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
@@ -295,8 +282,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           const f32x4 e0 = *reinterpret_cast<const f32x4*>(vdel + r0), e1 = *reinterpret_cast<const f32x4*>(vdel + r1);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bias[r] - l0[r]));
-            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, bias[r] - l1[r]));
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, fmaf(l0[r], -L2E, bias[r])));     // (lse arrives in natural-log units)
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, fmaf(l1[r], -L2E, bias[r])));
             pv[r] = p0;
             pv[4 + r] = p1;
             dsv[r] = p0 * ((d0[r] - e0[r]) * G.scale);
@@ -355,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           const f32x4 l0 = *reinterpret_cast<const f32x4*>(vlse + r0), e0 = *reinterpret_cast<const f32x4*>(vdel + r0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pv[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bias[r] - l0[r]));
+            pv[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, fmaf(l0[r], -L2E, bias[r])));
             dsv[r] = pv[r] * ((d0[r] - e0[r]) * G.scale);
           }
         } else {
@@ -385,9 +372,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           }
         }
       }
-    }
-    if constexpr (MODE == 1) {
-      if (more) put_rows((j + 1) & 1);
     }
     base = base_n;
     advance();
