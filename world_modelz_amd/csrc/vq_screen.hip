@@ -52,33 +52,49 @@ __device__ __forceinline__ float dist_pinned64(XF xf, CF cf) {
   return fin;
 }
 
-// workspace header (max |e|^2 bits, flagged-row count) back to zero: a kernel, not hipMemsetAsync -- the call is captured into
-// hipGraphs (training steps), where a memset node in front of kernels that read its target proved unreliable on replay
-__global__ void vq_header_zero_kernel(unsigned* hdr) { if (threadIdx.x < 4) hdr[threadIdx.x] = 0u; }
-
-// codebook -> bf16 head / tail rows, -|e|^2 / 2, max |e|^2 (as uint bits: positive floats order like integers)
+// codebook -> bf16 head / tail rows, -|e|^2 / 2, and the largest |e|^2 of every block of 64 codes (the screening kernel takes
+// the maximum of those: no same-address atomic chain); block 0 also puts the flagged-row count back to zero.
+// One wave per 16 codes: lane = (code, quarter row), 16 elements each.
 __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ CB, unsigned short* __restrict__ EH,
                                                       unsigned short* __restrict__ EL, float* __restrict__ NH,
-                                                      unsigned* __restrict__ emax2, int C) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
-  const float v = CB[(long)c * E + lane];
-  const unsigned short h = f32_to_bf16_bits(v);
-  const float r = v - bf16_bits_to_f32(h);
-  EH[(long)c * E + lane] = h;
-  EL[(long)c * E + lane] = f32_to_bf16_bits(r);
-  const float s = wave_sum(v * v);
-  if (lane == 0) {
-    NH[c] = -0.5f * s;
-    atomicMax(emax2, __float_as_uint(s));
+                                                      float* __restrict__ emax2_blk, int* __restrict__ nflag, int C) {
+  __shared__ float wmax[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.x * 64 + (tid >> 2), q = tid & 3;            // C is a multiple of 64
+  const float* row = CB + (long)c * E + q * 16;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    s16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned short hb = f32_to_bf16_bits(v[j]);
+      h[j] = (short)hb;
+      l[j] = (short)f32_to_bf16_bits(v[j] - bf16_bits_to_f32(hb));
+      s = fmaf(v[j], v[j], s);
+    }
+    *reinterpret_cast<s16x4*>(EH + (long)c * E + q * 16 + i) = h;
+    *reinterpret_cast<s16x4*>(EL + (long)c * E + q * 16 + i) = l;
+  }
+  s += __shfl_xor(s, 1);                                    // the code's four lanes are neighbours: lanes 4k .. 4k + 3
+  s += __shfl_xor(s, 2);
+  if (q == 0) NH[c] = -0.5f * s;
+  float m = s;
+#pragma unroll
+  for (int d = 4; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if (lane == 0) wmax[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    emax2_blk[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (blockIdx.x == 0) *nflag = 0;
   }
 }
 
 __global__ __launch_bounds__(ROWS_WG * 2) void vq_screen_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ CB,
                                                                 const unsigned short* __restrict__ EH,
                                                                 const unsigned short* __restrict__ EL, const float* __restrict__ NH,
-                                                                const unsigned* __restrict__ emax2, int64_t* __restrict__ IDX,
+                                                                const float* __restrict__ emax2_blk, int64_t* __restrict__ IDX,
                                                                 float* __restrict__ DMIN, int* __restrict__ nflag,
                                                                 int* __restrict__ flagged, int N, int C) {
   __shared__ __attribute__((aligned(16))) char sm[2 * TILE_B];
@@ -124,8 +140,10 @@ __global__ __launch_bounds__(ROWS_WG * 2) void vq_screen_kernel(const float* __r
     if (tid < 16) *reinterpret_cast<f32x4*>(buf + 2 * CT * CROW + tid * 16) = rn;
   };
 
+  // best, runner-up, and WHERE the best was seen: accumulator register (rsel) and 32-code group (gsel) -- the code index is put
+  // together once, at the end (a per-element index costs as much vector ALU time as the comparison itself)
   float M1 = -INFINITY, M2 = -INFINITY;
-  int c1 = INT_MAX;
+  int rsel = 0, gsel = -1;
   i32x4 rh[2], rl[2];
   f32x4 rn = (f32x4)(0.f);
   stage_load(0, rh, rl, rn);
@@ -155,18 +173,20 @@ __global__ __launch_bounds__(ROWS_WG * 2) void vq_screen_kernel(const float* __r
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el, xh[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, xl[ks], acc, 0, 0, 0);
       }
-      const int cb = t * CT + 32 * g + 4 * hi;
+      const float m_before = M1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[r];
         M2 = __builtin_amdgcn_fmed3f(M1, v, M2);           // the runner-up: M1 <= .. is kept, v in between replaces it
-        c1 = v > M1 ? cb + (r & 3) + 8 * (r >> 2) : c1;
-        M1 = fmaxf(M1, v);
+        rsel = v > M1 ? r : rsel;
+        M1 = __builtin_amdgcn_fmed3f(M1, v, INFINITY);     // max(M1, v) as one instruction (fmaxf adds two canonicalising ops)
       }
+      gsel = M1 != m_before ? 2 * t + g : gsel;
     }
     if (t + 1 < ntile) stage_store(sm + ((t + 1) & 1) * TILE_B, rh, rl, rn);
     __syncthreads();
   }
+  int c1 = gsel < 0 ? INT_MAX : 32 * gsel + 4 * hi + (rsel & 3) + 8 * (rsel >> 2);
   // the row's two lanes (hi = 0 / 1 saw disjoint codes) merge: best, runner-up, index (lower index on equal values)
   {
     const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(M1), __float_as_uint(M1), false, false);
@@ -180,7 +200,9 @@ __global__ __launch_bounds__(ROWS_WG * 2) void vq_screen_kernel(const float* __r
     M1 = best; M2 = second;
   }
   if (hi == 0 && rok) {
-    const float xn = sqrtf(x2) * 1.0001f, em = sqrtf(__uint_as_float(*emax2)) * 1.0001f;
+    float e2 = 0.f;
+    for (int i = 0; i < C / 64; ++i) e2 = fmaxf(e2, emax2_blk[i]);   // (wave-uniform addresses: scalar loads)
+    const float xn = sqrtf(x2) * 1.0001f, em = sqrtf(e2) * 1.0001f;
     const float eps = 8e-5f * xn * em + 1e-5f * (xn + em) * (xn + em);
     const bool sure = (M1 - M2) > 2.f * eps && M1 < INFINITY && x2 < INFINITY;   // (false for NaN / inf anywhere)
     if (sure) {
@@ -195,29 +217,39 @@ __global__ __launch_bounds__(ROWS_WG * 2) void vq_screen_kernel(const float* __r
   }
 }
 
-// rows the screening could not decide: the whole codebook in the pinned arithmetic, one wave per row (lane = code, stride 64),
-// lexicographic (distance, index) minimum over the wave: exactly what vq_argmin_kernel computes for the row
+// rows the screening could not decide: the whole codebook in the pinned arithmetic -- exactly what vq_argmin_kernel computes for
+// the row.  A block takes 4 flagged rows (one per wave); tiles of 64 codes go through LDS (coalesced 16-byte loads, rows pitched
+// 65 floats: lane = code reads its row conflict-free) and are shared by the 4 waves; lexicographic (distance, index) minimum
+// over the wave at the end.
 __global__ __launch_bounds__(256) void vq_recheck_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ CB,
                                                          int64_t* __restrict__ IDX, float* __restrict__ DMIN,
                                                          const int* __restrict__ nflag, const int* __restrict__ flagged, int C) {
-  const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  __shared__ float tile[64 * 65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = *nflag;
-  for (int i = gw; i < n; i += nw) {
-    const int row = __builtin_amdgcn_readfirstlane(flagged[i]);
-    const float* xrow = X + (long)row * ldx;               // wave-uniform: scalar loads
+  for (int i0 = blockIdx.x * 4; i0 < n; i0 += gridDim.x * 4) {          // block-uniform trip count: barriers inside are safe
+    const int i = i0 + wave;
+    const bool have = i < n;
+    const int row = __builtin_amdgcn_readfirstlane(flagged[have ? i : i0]);
+    const float* xrow = X + (long)row * ldx;                              // wave-uniform: scalar loads
+    float xr[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) xr[e] = xrow[e];
     float bd = INFINITY;
     int bc = INT_MAX;
-    for (int c = lane; c < C; c += 64) {
-      const float* crow = CB + (long)c * E;
-      float cr[E];
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      __syncthreads();
 #pragma unroll
-      for (int e = 0; e < E; e += 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(crow + e);
-        cr[e] = v[0]; cr[e + 1] = v[1]; cr[e + 2] = v[2]; cr[e + 3] = v[3];
+      for (int k = 0; k < 4; ++k) {                                       // 64 codes x 16 chunks of 16 bytes, 4 per thread
+        const int q = tid + 256 * k, code = q >> 4, ch = q & 15;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(CB + (long)(c0 + code) * E + ch * 4);
+        float* d = tile + code * 65 + ch * 4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
       }
-      const float d = dist_pinned64([&](int e) { return xrow[e]; }, [&](int e) { return cr[e]; });
-      if (d < bd) { bd = d; bc = c; }
+      __syncthreads();
+      const float* cr = tile + lane * 65;
+      const float d = dist_pinned64([&](int e) { return xr[e]; }, [&](int e) { return cr[e]; });
+      if (d < bd) { bd = d; bc = c0 + lane; }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -225,7 +257,7 @@ __global__ __launch_bounds__(256) void vq_recheck_kernel(const float* __restrict
       const int oc = __shfl_xor(bc, m);
       if (od < bd || (od == bd && oc < bc)) { bd = od; bc = oc; }
     }
-    if (lane == 0) {
+    if (lane == 0 && have) {
       IDX[row] = bc == INT_MAX ? 0 : bc;
       if (DMIN != nullptr) DMIN[row] = bd;
     }
@@ -234,10 +266,11 @@ __global__ __launch_bounds__(256) void vq_recheck_kernel(const float* __restrict
 
 }  // namespace
 
-// Workspace layout: [16 B: emax^2 bits, flag count] [C x 64 bf16 heads] [C x 64 bf16 tails] [C floats -|e|^2/2] [N ints flagged rows]
+// Workspace layout: [16 B: flag count at +4] [C x 64 bf16 heads] [C x 64 bf16 tails] [C floats -|e|^2/2] [C/64 floats: block maxima of
+// |e|^2] [N ints flagged rows]
 extern "C" long wmz_vq_argmin_screened_workspace_bytes(int N, int C, int E) {
   if (E != 64 || C < 64 || C % 64 != 0 || N <= 0) return 0;            // 0: shape not built, use wmz_vq_argmin
-  return 16 + (long)C * E * 2 * 2 + (long)C * 4 + (long)N * 4;
+  return 16 + (long)C * E * 2 * 2 + (long)C * 4 + (long)(C / 64) * 4 + (long)N * 4;
 }
 
 extern "C" int wmz_vq_argmin_screened(const float* x, long ldx, const float* codebook, int64_t* idx, float* dist_min, int N, int C,
@@ -249,16 +282,17 @@ extern "C" int wmz_vq_argmin_screened(const float* x, long ldx, const float* cod
   WMZ_REQUIRE(ldx % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0, "wmz_vq_argmin_screened: x rows must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  unsigned* emax2 = (unsigned*)ws;
   int* nflag = (int*)(ws + 4);
   unsigned short* EH = (unsigned short*)(ws + 16);
   unsigned short* EL = EH + (long)C * E;
   float* NH = (float*)(EL + (long)C * E);
-  int* flagged = (int*)(NH + C);
-  hipLaunchKernelGGL(vq_header_zero_kernel, dim3(1), dim3(64), 0, st, (unsigned*)ws);
-  hipLaunchKernelGGL(vq_prep_kernel, dim3(wmz_cdiv(C, 4)), dim3(256), 0, st, codebook, EH, EL, NH, emax2, C);
-  hipLaunchKernelGGL(vq_screen_kernel, dim3(wmz_cdiv(N, ROWS_WG)), dim3(ROWS_WG * 2), 0, st, x, ldx, codebook, EH, EL, NH, emax2, idx,
-                     dist_min, nflag, flagged, N, C);
+  float* emax2_blk = NH + C;
+  int* flagged = (int*)(emax2_blk + C / 64);
+  // (no hipMemsetAsync here: the call is captured into hipGraphs, where a memset node in front of kernels reading its target
+  //  proved unreliable on replay -- the prep kernel zeroes the flag count)
+  hipLaunchKernelGGL(vq_prep_kernel, dim3(C / 64), dim3(256), 0, st, codebook, EH, EL, NH, emax2_blk, nflag, C);
+  hipLaunchKernelGGL(vq_screen_kernel, dim3(wmz_cdiv(N, ROWS_WG)), dim3(ROWS_WG * 2), 0, st, x, ldx, codebook, EH, EL, NH, emax2_blk,
+                     idx, dist_min, nflag, flagged, N, C);
   hipLaunchKernelGGL(vq_recheck_kernel, dim3(256), dim3(256), 0, st, x, ldx, codebook, idx, dist_min, nflag, flagged, C);
   WMZ_LAUNCH_CHECK("wmz_vq_argmin_screened");
   return WMZ_OK;
