@@ -406,6 +406,82 @@ def test_bulk_operand_refresh_is_exact():
     assert torch.equal(_cast.operand(w1, bf), w1.detach().to(bf))
 
 
+def test_optimizer_state_and_ema_round_trip_through_the_reference_layout(wmz, tmp_path):
+    """Checkpoint state of the trainers (main.py:302-309): `optimizer_state_dict()` is torch.optim.AdamW's layout
+    -- loaded into a REAL torch AdamW over copies of the weights it continues the trainer's trajectory (same next step from the
+    same gradients); `load_optimizer_state_dict` resumes a second trainer identically; `enable_ema` follows ModelEmaV2's law
+    (model_ema_v2.py:33-41), eager and graphed; the file written by save_denoiser_checkpoint reads back."""
+    from world_modelz_amd import checkpoint
+    C = 64
+    def make():
+        torch.manual_seed(77)
+        return wmz['main'].VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=256, num_classes=C, extents=(1, 1, 1), depth=2,
+                                                 dim_head=128, mlp_dim=256, heads=1).cuda()
+    torch.manual_seed(78)
+    z = torch.randint(0, C, (2, 3, 16, 16), device='cuda')
+    r0 = torch.zeros(2)
+    with wmz['config'].compute_dtype(torch.float32):
+        ma = make()
+        ta = wmz['train'].DenoiserTrainer(ma, C, lr=1e-3, warmup=0, max_steps=100, distributed=False).enable_ema(0.9)
+        w0 = ta.arena.flat_param.clone()
+        ema_ref = w0.clone()
+        for _ in range(3):
+            ta.train_step(z, r=r0)
+            ema_ref = 0.9 * ema_ref + 0.1 * ta.arena.flat_param
+        assert torch.allclose(ta.ema_flat, ema_ref, rtol=1e-5, atol=1e-7)
+        osd = ta.optimizer_state_dict()
+        assert set(osd) == {'state', 'param_groups'} and len(osd['state']) == len(list(ma.parameters()))
+        assert float(osd['state'][0]['step']) == 3.0 and osd['param_groups'][0]['betas'] == (0.9, 0.999)
+        # (a) a real torch AdamW continues from it
+        ref_params = [p.detach().clone().requires_grad_(True) for p in ma.parameters()]
+        opt = torch.optim.AdamW(ref_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7)
+        opt.load_state_dict({'state': {i: {k: (v.cuda() if k != 'step' else v) for k, v in st.items()} for i, st in osd['state'].items()},
+                             'param_groups': osd['param_groups']})
+        # (b) a second trainer resumes from it
+        mb = make()
+        mb.load_state_dict(ma.state_dict())
+        tb = wmz['train'].DenoiserTrainer(mb, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
+        tb.load_optimizer_state_dict(osd)
+        assert tb.step_count == 3
+        # one more step everywhere, same gradients (r = 0: no corruption randomness)
+        ta.arena.zero_grad()
+        from world_modelz_amd.train import corrupt_last_frame
+        zc, tgt = corrupt_last_frame(z, r0, C)
+        ta.forward_backward(zc, tgt)
+        grads = [p.grad.detach().clone() for p in ma.parameters()]
+        lr4 = wmz['train'].lr_at(4, 1e-3, 0, 100)
+        for g_ in opt.param_groups:
+            g_['lr'] = lr4
+        for p, g in zip(ref_params, grads):
+            p.grad = g
+        opt.step()
+        ta.optimizer_step()
+        tb.train_step(z, r=r0)
+        for p, q, w in zip(ma.parameters(), ref_params, mb.parameters()):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+            assert torch.allclose(p, w, rtol=1e-4, atol=1e-6)
+        # the checkpoint file in the reference's layout
+        import argparse
+        path = str(tmp_path / 'd_checkpoint_0000004.pth')
+        checkpoint.save_denoiser_checkpoint(path, step=4, lr=[lr4], model=ma, opt=argparse.Namespace(dim=256), ema_model=None,
+                                            optimizer_state=ta.optimizer_state_dict())
+        data = checkpoint.read(path)
+        assert data['step'] == 4 and float(data['optimizer_state_dict']['state'][0]['step']) == 4.0
+        esd = ta.ema_state_dict()
+        assert set(esd) == set(ma.state_dict()) and not torch.equal(esd['logit_proj.weight'], ma.logit_proj.weight.cpu())
+    # EMA inside the captured step
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        mg = make()
+        tg = wmz['train'].DenoiserTrainer(mg, C, lr=1e-3, warmup=0, max_steps=100, distributed=False).enable_ema(0.5)
+        tg.enable_graph(z)
+        e = tg.arena.flat_param.clone()
+        assert torch.equal(tg.ema_flat, e)
+        for _ in range(2):
+            tg.train_step(z, r=r0)
+            e = 0.5 * e + 0.5 * tg.arena.flat_param
+        assert torch.allclose(tg.ema_flat, e, rtol=1e-5, atol=1e-7)
+
+
 def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
     """SURVEY 8(e) on ONE GPU: a world-1 `nccl` (= RCCL) process group, DenoiserTrainer(distributed=True).  The HIP backward
     accumulates straight into the flat gradient arena and tells the reducer (`_wmz_ready`), which all-reduces each per-layer

@@ -99,7 +99,10 @@ class _LinearCrossEntropy(torch.autograd.Function):
         loss = torch.empty(R, dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if R > chunk else None
         wbuf, bbuf = getattr(w, '_wmz_grad', None), getattr(b, '_wmz_grad', None) if b is not None else None
-        direct = wbuf is not None and (b is None or bbuf is not None)
+        # (the arena shortcut is only taken when a backward will follow: under no_grad, or for callers that do not ask for the
+        #  parameter gradients, nothing may be accumulated into the arena behind autograd's back)
+        direct = (wbuf is not None and (b is None or bbuf is not None) and torch.is_grad_enabled()
+                  and ctx.needs_input_grad[1])
         dw = wbuf if direct else torch.zeros(w.shape, dtype=torch.float32, device=x.device)
         db = (bbuf if direct else torch.zeros(C, dtype=torch.float32, device=x.device)) if b is not None else None
         # d(grad_scale * mean loss) / d(row loss): the scale of gradient accumulation (main.py:274-278) is applied HERE, the
@@ -219,7 +222,73 @@ def lr_at(step, base_lr, warmup, max_steps):
     return 0.5 * base_lr * (1 + math.cos(math.pi * max(e - warmup - 1, 0) / max_steps))
 
 
-class _TrainerBase:
+class _AdamState:
+    """Checkpoint view of a trainer's flat-arena optimizer state and weight EMA (model, arena, m, v, step_count, betas, eps,
+    wd are the host class's)."""
+
+    # ------------------------------------------------------------------------------------------------ checkpoint state
+    def optimizer_state_dict(self):
+        """The AdamW state of the flat arena in torch.optim.AdamW's state_dict layout (what main.py:302-309 /
+        train_vqae.py:172-179 store as `optimizer_state_dict`): per parameter `step`, `exp_avg`, `exp_avg_sq` in
+        `model.parameters()` order, one param group with this trainer's hyper-parameters.  CPU tensors."""
+        a = self.arena
+        state = {}
+        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.step_count)),
+                        'exp_avg': self.m[o:o + n].view_as(p).detach().cpu().clone(),
+                        'exp_avg_sq': self.v[o:o + n].view_as(p).detach().cpu().clone()}
+        group = {'lr': float(self._current_lr()),
+                 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(a.params)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """Inverse of optimizer_state_dict(): moments and step count from a torch.optim.AdamW state_dict (a reference checkpoint's
+        `optimizer_state_dict`, or one written by this trainer)."""
+        a = self.arena
+        steps = set()
+        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+            st = sd['state'].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.m[o:o + n].view_as(p).copy_(st['exp_avg'])
+            self.v[o:o + n].view_as(p).copy_(st['exp_avg_sq'])
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('per-parameter step counts differ: not an AdamW state this trainer can resume')
+        if steps:
+            self.step_count = steps.pop()
+
+    def enable_ema(self, decay):
+        """Weight EMA with ModelEmaV2's law e = decay e + (1 - decay) w after every optimizer step (model_ema_v2.py:33-41,
+        main.py:286-287): one lerp over the flat arena, captured with the step when it is graphed.  Call before enable_graph."""
+        self.ema_decay = float(decay)
+        self.ema_flat = self.arena.flat_param.detach().clone()
+        return self
+
+    def _ema_update(self):
+        if getattr(self, 'ema_flat', None) is not None:
+            self.ema_flat.lerp_(self.arena.flat_param, 1.0 - self.ema_decay)
+
+    def ema_state_dict(self):
+        """name -> EMA weights (CPU), the reference's `ema_model_state_dict` (non-parameter entries of the model's state_dict
+        -- buffers -- are copied from the live model, as ModelEmaV2 does)."""
+        if getattr(self, 'ema_flat', None) is None:
+            return None
+        a = self.arena
+        by_id = {id(p): self.ema_flat[o:o + p.numel()].view_as(p) for p, o in zip(a.params, a.offsets)}
+        named = dict(self.model.named_parameters())
+        out = {}
+        for k, v in self.model.state_dict().items():
+            p = named.get(k)
+            out[k] = (by_id[id(p)] if p is not None and id(p) in by_id else v).detach().cpu().clone()
+        return out
+
+
+class _TrainerBase(_AdamState):
     """One object = model + flat arenas + AdamW state + (optional) data-parallel reducer; subclasses supply the step body
     (DenoiserTrainer: main.py:216-287 on token grids; SparseDenoiserTrainer: minecraft/sparse_diffusion.py:398-467)."""
 
@@ -307,9 +376,13 @@ class _TrainerBase:
         L.call('wmz_grad_sqnorm', L.ptr(a.flat_grad), a.numel, float(scale), L.ptr(self.sq), st)
         L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                float(lr), self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), st)
+        self._ema_update()
         _cast.invalidate()            # the kernel rewrote the arena behind torch's version counters
         self._refresh_operands()      # ... and every operand copy of the weights is rebuilt by one launch
         return self.sq
+
+    def _current_lr(self):
+        return lr_at(max(self.step_count, 1), self.lr, self.warmup, self.max_steps)
 
     def _refresh_operands(self):
         self.operands.refresh()
@@ -341,7 +414,8 @@ class _TrainerBase:
         self._g_hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self._g_seed = torch.initial_seed()
         snap = None if keep_warmup_updates else (self.arena.flat_param.clone(), self.m.clone(), self.v.clone(), self.step_count,
-                                                 self.sampler_gen.get_state())
+                                                 self.sampler_gen.get_state(),
+                                                 None if getattr(self, 'ema_flat', None) is None else self.ema_flat.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -356,6 +430,8 @@ class _TrainerBase:
             self._g_out = self._graph_body()
         self.step_count -= 1               # capturing records the launches, it does not run a step
         if snap is not None:
+            if snap[5] is not None:
+                self.ema_flat.copy_(snap[5])
             self.arena.flat_param.copy_(snap[0])
             self.m.copy_(snap[1])
             self.v.copy_(snap[2])
@@ -400,6 +476,7 @@ class _TrainerBase:
         self.sq.zero_()
         L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, float(scale), L.ptr(self.sq), st)   # + grad norm
+        self._ema_update()
         return per_sample, mean, self.sq
 
 
@@ -532,7 +609,7 @@ class SparseDenoiserTrainer(_TrainerBase):
         return float(mean), math.sqrt(float(sq))
 
 
-class VqaeTrainer:
+class VqaeTrainer(_AdamState):
     """The step body of vq-video-diffusion/train_vqae.py:train (:125-164) for the drop-in VqAutoEncoder: reconstruction loss
     (SmoothL1 / MSE / L1, :264-271) + latent_loss_weight x commitment loss (:148), AdamW (lr 2e-4, weight decay 0: :254-256)
     with the per-epoch StepLR(step_size 3, gamma 0.5) schedule (:262), and every `vq_reuse_interval` steps the dead-code
@@ -561,6 +638,9 @@ class VqaeTrainer:
             broadcast_parameters(self.arena)
             model.vq.sync_stats = True
         self.reused = 0
+
+    def _current_lr(self):
+        return self.lr_now()
 
     def lr_now(self):
         """StepLR(step_size=3, gamma=0.5) stepped once per epoch (train_vqae.py:192, :262)."""
@@ -620,6 +700,7 @@ class VqaeTrainer:
         self._g_sq.zero_()
         L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, L.ptr(self._g_sq), L.stream())
+        self._ema_update()
         return out
 
     def _after_step(self):
@@ -647,5 +728,6 @@ class VqaeTrainer:
         a = self.arena
         L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel, float(lr),
                self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), L.stream())
+        self._ema_update()
         self._after_step()
         return tuple(float(v) for v in out.cpu())
