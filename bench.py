@@ -99,6 +99,8 @@ def main():
     ap.add_argument('--no-cone', action='store_true', help='skip the secondary last-frame-cone figure (cleaner kernel traces)')
     ap.add_argument('--eager', action='store_true', help='replay the Python launch path instead of the hipGraph')
     ap.add_argument('--train-steps', type=int, default=30, help='timed full training steps reported as train_step (0 = skip)')
+    ap.add_argument('--secondary-timeout', type=int, default=420,
+                    help='n_gpus > 1: seconds after which a hung secondary figure is abandoned and the headline line printed (0 = never)')
     a = ap.parse_args()
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -370,7 +372,45 @@ def main():
     gc.collect()
     # The secondary figures below must never cost the headline line: whatever one of them raises (every rank runs the same
     # code on the same shapes, so a failure is the same on all ranks and no rank is left waiting in a collective) is recorded
-    # in `secondary_error` and the JSON line is printed with what was measured up to there.
+    # in `secondary_error` and the JSON line is printed with what was measured up to there.  With more than one rank a
+    # secondary figure can also HANG (a rank waiting in a collective the others never reach): a watchdog then prints the
+    # headline line as measured and ends the rank, so that the launcher sees N clean exits and the line is not lost.
+    import threading
+    printed = threading.Lock()
+
+    def secondary_watchdog():
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            out['secondary_error'] = (f'secondary figures did not finish within {a.secondary_timeout} s on {world} ranks '
+                                      '(a collective hung?); the headline above was measured before them')
+            out.setdefault('cpu_baseline', None)
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = None
+    if world > 1 and a.secondary_timeout > 0:
+        watchdog = threading.Timer(a.secondary_timeout, secondary_watchdog)
+        watchdog.daemon = True
+        watchdog.start()
+
+    def capture_agreed(trainer, example):
+        """enable_graph on every rank; None when ALL ranks captured, else the reason (and every rank drops its graph, so that
+        no rank replays collectives the others launch eagerly)."""
+        err = None
+        try:
+            trainer.enable_graph(example)
+        except Exception as e:  # noqa: BLE001  (a rank whose capture failed must not leave the others in a collective)
+            err = f'{type(e).__name__}: {e}'[:300]
+        if world > 1:
+            ok = torch.tensor([0.0 if err else 1.0], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if float(ok.item()) == 0.0:
+                err = err or 'capture failed on another rank'
+        if err:
+            trainer._graph = None
+        return err
+
     try:
         # ---- secondary figure: the same forward with the dead planes elided (bit-identical logits; NOT the headline)
         cone = None
@@ -667,18 +707,9 @@ def main():
                     tr.reducer.enable_timing(False)
             graph_error = None
             if graphed:
-                try:
-                    tr.enable_graph(z)
-                except Exception as e:  # noqa: BLE001  (a rank whose capture failed must not leave the others in a collective)
-                    graph_error = f'{type(e).__name__}: {e}'[:300]
-                if world > 1:
-                    ok = torch.tensor([0.0 if graph_error else 1.0], device=dev)
-                    torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-                    if float(ok.item()) == 0.0:
-                        graph_error = graph_error or 'capture failed on another rank'
+                graph_error = capture_agreed(tr, z)
                 if graph_error:
                     log('hipGraph capture of the data-parallel step failed, eager launches instead: ' + graph_error)
-                    tr._graph = None
                     graphed = False
             if graphed:
                 tel = timed(lambda: tr.train_step(z, r=rfix), a.train_steps)
@@ -727,9 +758,10 @@ def main():
             st = SparseDenoiserTrainer(sm, 8192, num_context=512, lr=1e-4, warmup=500, distributed=world > 1)
             zs = torch.randint(0, 8192, (6, 64, 16, 16), generator=gen).to(dev)
             rs = torch.full((6,), 0.5)
-            sparse_graphed = not a.eager and (world == 1 or backend == 'nccl')
-            if sparse_graphed:
-                st.enable_graph(zs)
+            # (a data-parallel step whose capture failed above is not tried again here)
+            sparse_graphed = not a.eager and (world == 1 or (backend == 'nccl' and train is not None and train['launch_mode'] == 'hipGraph'))
+            if sparse_graphed and capture_agreed(st, zs):
+                sparse_graphed = False
             for _ in range(3):
                 st.train_step(zs, r=rs)
             barrier()
@@ -755,13 +787,17 @@ def main():
         import traceback
         out['secondary_error'] = ''.join(traceback.format_exception_only(type(e), e)).strip()[:500]
         log('secondary figure failed: ' + out['secondary_error'])
+    if watchdog is not None:
+        watchdog.cancel()
+    if not printed.acquire(blocking=False):
+        time.sleep(3600)            # the watchdog is printing / ending this rank
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             log(f'cpu baseline on {usable_cores()} threads')
             out['cpu_baseline'] = cpu_baseline(cfg, sd_cpu)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
