@@ -1,4 +1,5 @@
-"""Micro-driver: a few training steps at config 4 for rocprofv3 (not part of the product)."""
+"""Micro-driver: a few training steps at config 4 for rocprofv3 (not part of the product).
+prof_train.py [steps [dim mlp depth eS eH eW]] -- e.g. `8 384 512 20 3 1 1` = the reference's published dim-384 run."""
 import sys, torch
 sys.path.insert(0, '.')
 from world_modelz_amd import config
@@ -6,7 +7,8 @@ from world_modelz_amd.main import VqVideoDiffusionModel
 from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame
 torch.manual_seed(42)
 config.set_compute_dtype(torch.bfloat16)
-m = VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=256, num_classes=1024, extents=(3, 3, 3), depth=4, dim_head=128, mlp_dim=256, heads=1).cuda()
+dim, mlp, depth, eS, eH, eW = (int(v) for v in sys.argv[2:8]) if len(sys.argv) >= 8 else (256, 256, 4, 3, 3, 3)
+m = VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=dim, num_classes=1024, extents=(eS, eH, eW), depth=depth, dim_head=128, mlp_dim=mlp, heads=1).cuda()
 tr = DenoiserTrainer(m, 1024, distributed=False)
 z = torch.randint(0, 1025, (8, 32, 16, 16), device='cuda')
 r = torch.full((8,), 0.5)

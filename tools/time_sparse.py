@@ -1,0 +1,21 @@
+"""Config-5 (sparse model) training step, graph replay and eager (tools/prof_sparse.py is the rocprofv3 driver)."""
+import sys, time, torch
+sys.path.insert(0, '.')
+from world_modelz_amd import config
+from world_modelz_amd.sparse_diffusion import VqSparseDiffusionModel
+from world_modelz_amd.train import SparseDenoiserTrainer
+torch.manual_seed(43)
+config.set_compute_dtype(torch.bfloat16)
+sm = VqSparseDiffusionModel(shape=(64, 16, 16), dim=512, num_classes=8192, depth=8, dim_head=128, mlp_dim=1024, heads=4).cuda()
+st = SparseDenoiserTrainer(sm, 8192, num_context=512, lr=1e-4, warmup=500, distributed=False)
+zs = torch.randint(0, 8192, (6, 64, 16, 16), device='cuda')
+rs = torch.full((6,), 0.5)
+for mode in ('eager', 'graph'):
+    if mode == 'graph':
+        st.enable_graph(zs)
+    for _ in range(3): st.train_step(zs, r=rs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20): st.train_step(zs, r=rs)
+    torch.cuda.synchronize()
+    print(f'config 5 {mode}: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/step  (wgrad side stream {config.get_wgrad_stream()})', flush=True)

@@ -129,6 +129,9 @@ def lib():
     return _lib
 
 
+after_call = None      # ops: launches deferred until the compute stream's NEXT launch has been issued (ops._flush_deferred)
+
+
 def call(name, *args):
     L = lib()
     fn = getattr(L, name, None)
@@ -137,6 +140,8 @@ def call(name, *args):
     rc = fn(*args)
     if rc != 0:
         raise WmzError(f'{name} failed (code {rc}): {L.wmz_last_error().decode()}')
+    if after_call is not None:
+        after_call()
 
 
 def dtype_code(dt):

@@ -25,7 +25,8 @@ def _emit(param, fill):
         return None
     buf = getattr(param, '_wmz_grad', None)
     if buf is not None:
-        fill(buf)
+        with ops.arena_fill():              # (weight gradients may go to the side stream: ops.linear_wgrad)
+            fill(buf)
         ready = getattr(param, '_wmz_ready', None)
         if ready is not None:
             ready()
@@ -43,7 +44,11 @@ def _emit2(p1, p2, fill):
     if not direct:
         b1 = torch.zeros(p1.shape, dtype=torch.float32, device=p1.device)
         b2 = torch.zeros(p2.shape, dtype=torch.float32, device=p2.device) if p2 is not None else None
-    fill(b1, b2)
+    if direct:
+        with ops.arena_fill():
+            fill(b1, b2)
+    else:
+        fill(b1, b2)
     if direct:
         for p in (p1, p2):
             ready = getattr(p, '_wmz_ready', None) if p is not None else None
@@ -89,6 +94,11 @@ def _wgrad_kv(wk, wv, bv, dkv, x_kv, lnp, stats):
 
 
 def attention_block_backward(ctx, dy):
+    with ops.side_blocked(ctx.has_res and not ctx.res_is_xkv):      # dy itself goes back to autograd as the residual gradient
+        return _attention_block_backward(ctx, dy)
+
+
+def _attention_block_backward(ctx, dy):
     x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse = ctx.saved_tensors
     dt = x_kv.dtype
     I = wq.shape[0]
@@ -139,6 +149,12 @@ def attention_block_backward(ctx, dy):
 
 
 def feed_forward_block_backward(ctx, dy):
+    fold = ctx.has_res and ctx.res_is_x and ctx.saved_tensors[1] is not None
+    with ops.side_blocked(ctx.has_res and not fold):
+        return _feed_forward_block_backward(ctx, dy)
+
+
+def _feed_forward_block_backward(ctx, dy):
     x, ln_g, ln_b, w1, b1, w2, b2, z = ctx.saved_tensors
     dt = x.dtype
     dy = dy.contiguous()
@@ -200,6 +216,11 @@ def linear_backward(ctx, dy):
 
 
 def dense_attention_block_backward(ctx, dy):
+    with ops.side_blocked(ctx.has_res and not ctx.res_is_x):
+        return _dense_attention_block_backward(ctx, dy)
+
+
+def _dense_attention_block_backward(ctx, dy):
     from .functional import _dense_grid
     x, ln_g, ln_b, wqkv, wout, bout, qkv, o, lse = ctx.saved_tensors
     dt = x.dtype

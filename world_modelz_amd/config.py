@@ -114,6 +114,20 @@ def set_check_tokens(on):
 _clip_streams = int(os.environ.get('WMZ_CLIP_STREAMS', '2'))
 
 
+# Training: weight gradients that land in the flat gradient arena are launched on a side stream (ops.linear_wgrad): they
+# have no consumer inside the backward.  0 = on the compute stream.
+_wgrad_stream = int(os.environ.get('WMZ_WGRAD_STREAM', '1'))
+
+
+def get_wgrad_stream():
+    return bool(_wgrad_stream)
+
+
+def set_wgrad_stream(on):
+    global _wgrad_stream
+    _wgrad_stream = 1 if on else 0
+
+
 def get_clip_streams():
     return _clip_streams
 

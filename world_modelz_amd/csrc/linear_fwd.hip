@@ -69,7 +69,7 @@ template <> __device__ __forceinline__ i32x4 f32_to_chunk<bf16_t>(const float* f
 
 // PRO: 0 = A as is, 1 = LayerNorm(A) over K, 2 = GELU(A) (FeedForward second GEMM reading the saved pre-activation)
 // BM = 128: 4 waves as 2 x 2, each 64 x 64.  BM = 64 (small-M GEMMs that would otherwise leave CUs idle: the last-frame logits,
-// M = B*H*W): 4 waves side by side, each 64 rows x 32 columns; generic (per-lane) epilogue only.
+// M = B*H*W; config 5's 3 072 rows per GPU): 4 waves side by side, each 64 rows x 32 columns.
 template <typename T, int PRO, int BM>
 __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   constexpr bool LN = PRO == 1;
@@ -263,39 +263,42 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   const bool gelu = (P.flags & WMZ_LIN_GELU) != 0;
   const bool dgelu = (P.flags & WMZ_LIN_DGELU) != 0;
   const T* R = reinterpret_cast<const T*>(P.res);
-  if constexpr (sizeof(T) == 2 && BM == 128) {
+  if constexpr (sizeof(T) == 2) {
     if (!P.out_f32 && (P.ldc % 8) == 0 && (R == nullptr || (P.ldr % 8) == 0)) {
       // 16-bit outputs: a lane owns ONE column, so direct stores would be 2 bytes each.  Stage the fp32 tile through LDS
-      // (64 rows per round = the 32 KB the slabs occupied) and leave as whole 16-byte row chunks; the residual / gelu'
-      // operand is read the same way and applied in fp32 before the single rounding.
-      float* stage = reinterpret_cast<float*>(tiles);                 // [64][128] fp32
+      // (BM / 2 rows per round: it fits the bytes the slabs occupied) and leave as whole 16-byte row chunks; the residual /
+      // gelu' operand is read the same way and applied in fp32 before the single rounding.
+      constexpr int RR = BM / 2;                                       // rows per round
+      float* stage = reinterpret_cast<float*>(tiles);                 // [RR][128] fp32
 #pragma unroll 1
       for (int round = 0; round < 2; ++round) {
         __syncthreads();
-        if ((wave >> 1) == round) {
+        if (BM == 64 || (wave >> 1) == round) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i) {
+            if (BM == 64 && i != round) continue;                     // BM = 64: every wave holds rows 32 i .. 32 i + 31 in acc[i]
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
               const int cl = wc + 32 * j + l31;
               const int col = n0 + cl;
               const float bv = (P.bias && col < P.N) ? P.bias[col] : 0.f;
 #pragma unroll
               for (int reg = 0; reg < 16; ++reg) {
-                const int rl = 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int rl = (BM == 64 ? 0 : 32 * i) + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
                 float v = acc[i][j][reg] + bv;
                 if (gelu) v = gelu_erf(v);
                 stage[rl * BN + cl] = v;
               }
             }
+          }
         }
         __syncthreads();
-        // 64 rows x 16 chunks of 8 columns = 1024 chunks, 4 per thread
+        // RR rows x 16 chunks of 8 columns, RR / 16 per thread
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < RR / 16; ++it) {
           const int idx = tid + it * NT;
           const int rl = idx >> 4, ch = idx & 15;
-          const int row = m0 + round * 64 + rl, col = n0 + ch * 8;
+          const int row = m0 + round * RR + rl, col = n0 + ch * 8;
           if (row >= P.M || col >= P.N) continue;
           const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * BN + ch * 8);
           const f32x4 b = *reinterpret_cast<const f32x4*>(stage + rl * BN + ch * 8 + 4);
@@ -371,11 +374,13 @@ static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtyp
   P.nbn = wmz_cdiv(P.N, BN);
   // small-M GEMMs (the last-frame logits: M = B*H*W; config 5's 3 072 tokens per GPU): 64-row tiles, so that the grid covers
   // the chip (a 16-bit output then leaves by per-lane stores: fine at these sizes)
-  const bool small = !ln && !gin && (long)wmz_cdiv(P.M, 128) * P.nbn < (P.out_f32 ? 192 : 320);
+  const bool small = (long)wmz_cdiv(P.M, 128) * P.nbn < (P.out_f32 ? 192 : 320) && (dtype == WMZ_BF16 || (!ln && !gin));
   const int bm = small ? 64 : 128;
   dim3 grid((unsigned)(wmz_cdiv(P.M, bm) * P.nbn)), block(NT);
   if (dtype == WMZ_BF16) {
-    if (small) hipLaunchKernelGGL((linear_kernel<bf16_t, 0, 64>), grid, block, 0, st, P);
+    if (small && ln) hipLaunchKernelGGL((linear_kernel<bf16_t, 1, 64>), grid, block, 0, st, P);
+    else if (small && gin) hipLaunchKernelGGL((linear_kernel<bf16_t, 2, 64>), grid, block, 0, st, P);
+    else if (small) hipLaunchKernelGGL((linear_kernel<bf16_t, 0, 64>), grid, block, 0, st, P);
     else if (ln) hipLaunchKernelGGL((linear_kernel<bf16_t, 1, 128>), grid, block, 0, st, P);
     else if (gin) hipLaunchKernelGGL((linear_kernel<bf16_t, 2, 128>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((linear_kernel<bf16_t, 0, 128>), grid, block, 0, st, P);

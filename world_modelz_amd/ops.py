@@ -1,4 +1,6 @@
 """Tensor-level wrappers over the C ABI (shape/stride checks, output allocation).  No autograd here."""
+import contextlib
+
 import torch
 
 from . import _lib as L
@@ -237,7 +239,9 @@ def workspace_snapshot(device):
     device = torch.device(device)
     if device.type == 'cuda' and device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    return (_wgrad_ws.get(device), _embed_ws.get(device), _vq_ws.get(device), _vq_screen_ws.get(device))
+    side = _wgrad_side.get(device)
+    return (_wgrad_ws.get(device), _embed_ws.get(device), _vq_ws.get(device), _vq_screen_ws.get(device),
+            None if side is None else side[2])
 
 
 def workspace_same(a, b):
@@ -255,6 +259,125 @@ def _workspace(device, floats):
     return w
 
 
+# ---- weight gradients on a side stream ------------------------------------------------------------------------------
+# A weight gradient that goes straight into the flat gradient arena (backward._emit*) has ONE consumer, the optimizer: nothing
+# of the backward's dependency chain (dgrad -> attention backward -> dgrad ...) waits for it.  With config.wgrad_stream on,
+# those launches go to a per-device side stream that forks from the compute stream at the launch (its operands are complete
+# there) and joins it again when the autograd pass ends (an engine callback; under hipGraph capture these are the fork / join
+# edges of the graph).  At small token counts (config 5: 3 072 rows per GPU) every kernel of the backward is a partial wave of
+# latency-bound workgroups, and the weight gradients -- a third of the step's kernel time -- run beside the chain instead of
+# inside it.  The data-parallel reducer waits for this stream as well before it all-reduces a bucket (parallel._launch).
+_wgrad_side = {}          # device -> [stream, launches pending a join, its own reduction workspace]
+_arena_depth = 0          # > 0 inside backward._emit*: the gradient being produced lands in the arena
+_side_blocked = 0         # > 0: a block backward whose incoming gradient is handed on to autograd as it is (see side_blocked)
+
+
+@contextlib.contextmanager
+def arena_fill():
+    global _arena_depth
+    _arena_depth += 1
+    try:
+        yield
+    finally:
+        _arena_depth -= 1
+
+
+@contextlib.contextmanager
+def side_blocked(block=True):
+    """A block backward that returns its incoming gradient tensor unchanged (an un-folded residual path) keeps its weight
+    gradients on the compute stream: autograd may accumulate INTO that tensor in place right after the function returns,
+    while a side-stream weight gradient would still be reading it."""
+    global _side_blocked
+    _side_blocked += 1 if block else 0
+    try:
+        yield
+    finally:
+        _side_blocked -= 1 if block else 0
+
+
+# A side-stream launch is ISSUED only after the compute stream's next library launch: under hipGraph capture the order in
+# which a node's successors are recorded decides which of them the runtime keeps on the node's own queue -- recorded first,
+# the weight gradient stayed there and the backward's dependency chain hopped to another queue at every fork (a ~10 us
+# cross-queue hand-over each, and the chain's next node queued behind the weight gradient: measured on config 5).
+_deferred = []
+_flushing = False
+
+
+def _flush_deferred():
+    global _flushing
+    if _flushing or not _deferred:
+        return
+    _flushing = True
+    try:
+        while _deferred:
+            _deferred.pop(0)()
+    finally:
+        _flushing = False
+        if not _deferred:
+            L.after_call = None
+
+
+def _defer(launch):
+    if _flushing:                      # (a deferred launch's own L.call)
+        launch()
+        return
+    _deferred.append(launch)
+    L.after_call = _flush_deferred
+
+
+def wgrad_join():
+    """The current stream waits for every weight gradient launched on the side stream (no-op when there is none)."""
+    _flush_deferred()
+    for dev, ent in _wgrad_side.items():
+        if ent[1]:
+            torch.cuda.current_stream(dev).wait_stream(ent[0])
+            ent[1] = False
+
+
+def wgrad_side_wait(stream):
+    """`stream` (the reducer's) waits for the side-stream weight gradients launched so far; they stay pending for the join."""
+    _flush_deferred()
+    for ent in _wgrad_side.values():
+        if ent[1]:
+            stream.wait_stream(ent[0])
+
+
+def _wgrad_side_enter(device, tensors):
+    """None (launch on the current stream), or the side-stream entry: forked from the current stream, `tensors` (allocated on
+    the compute stream) marked as in use there."""
+    from . import config
+    # (hipGraph capture only: in eager launches the step is host-bound and the extra stream / event calls cost more than the
+    #  overlap returns -- config 5: 4.8 -> 5.9 ms per step eager, 4.06 -> 3.38 as a graph)
+    if (_arena_depth == 0 or _side_blocked > 0 or not config.get_wgrad_stream()
+            or not torch.cuda.is_current_stream_capturing()):
+        return None
+    try:
+        # (one callback per launch, each a no-op once the first has joined: no state that a failed pass could leave behind)
+        torch.autograd.Variable._execution_engine.queue_callback(wgrad_join)
+    except RuntimeError:                # not inside an autograd pass (a block backward called by hand): stay on the stream
+        return None
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    ent = _wgrad_side.get(device)
+    if ent is None:
+        ent = _wgrad_side[device] = [torch.cuda.Stream(device=device), False, None]
+    for t in tensors:
+        if t is not None:
+            t.record_stream(ent[0])
+    ent[1] = True
+    fork = torch.cuda.Event()
+    fork.record(torch.cuda.current_stream(device))      # the operands are complete here
+    return ent, fork
+
+
+def _side_workspace(ent, device, floats):
+    w = ent[2]
+    if w is None or w.numel() < floats:
+        w = ent[2] = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+    return w
+
+
 def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, overwrite=False):
     """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc) (overwrite: = instead of +=).  dw / dbias fp32 (two-stage reduction
     through a per-device workspace: deterministic, no float atomics)."""
@@ -268,9 +391,21 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
         g, b = ln
         mean, rstd = ln_stats
     need = L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
-    ws = _workspace(dc.device, need)
-    L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
-           L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, 1 if overwrite else 0, L.ptr(ws), ws.numel(), dt, L.stream())
+    side = _wgrad_side_enter(dc.device, (dc, a, g, b, mean, rstd))
+    if side is None:
+        ws = _workspace(dc.device, need)
+        L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
+               L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, 1 if overwrite else 0, L.ptr(ws), ws.numel(), dt, L.stream())
+        return
+    ent, fork = side
+
+    def launch():                       # (the closure keeps the operands alive until the launch has been issued)
+        ent[0].wait_event(fork)
+        with torch.cuda.stream(ent[0]):
+            ws = _side_workspace(ent, dc.device, need)
+            L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
+                   L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, 1 if overwrite else 0, L.ptr(ws), ws.numel(), dt, L.stream())
+    _defer(launch)
 
 
 def linear_wgrad_batch(problems):

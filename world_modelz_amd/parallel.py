@@ -124,6 +124,8 @@ class BucketedAllReduce:
         self.order.append(b)
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())      # the bucket's gradients are complete
+            from . import ops
+            ops.wgrad_side_wait(self.stream)                          # ... including those launched on the wgrad side stream
             with torch.cuda.stream(self.stream):
                 # (under hipGraph capture the side stream has just joined the capture through wait_stream: the collective
                 #  becomes a graph node behind the bucket's last backward kernel; timing events are an eager-mode probe)

@@ -366,6 +366,7 @@ class _TrainerBase(_AdamState):
 
     def optimizer_step(self, lr=None):
         """Finish the all-reduce, grad-norm (device scalar, no sync), AdamW.  Returns the squared grad-norm tensor."""
+        ops.wgrad_join()
         scale = self.reducer.finish() if self.reducer is not None else 1.0
         self.step_count += 1
         if lr is None:
@@ -469,6 +470,7 @@ class _TrainerBase(_AdamState):
         self._refresh_operands()
         per_sample, mean = self._graph_step(self._g_z, self._g_r)      # subclass: corruption (device counter) -> forward / backward
         self._g_ctr += 1
+        ops.wgrad_join()                   # (already joined by the autograd pass's end-of-backward callback)
         # data parallel: buckets the backward did not launch itself, then the compute stream joins the reducer's side stream
         # (under capture: the fork / join edges of the graph); the 1/world of the gradient MEAN rides in the AdamW pass
         scale = self.reducer.finish() if self.reducer is not None else 1.0
@@ -577,8 +579,10 @@ class SparseDenoiserTrainer(_TrainerBase):
         h = Fw.embed_tokens_indexed(tokens, indices, m.embedding.weight, m.pos_emb_s.weight, m.pos_emb_h.weight,
                                     m.pos_emb_w.weight, m.shape)
         h = m.transformer.forward_compute(h)
+        # (config 5: 3 072 rows per GPU = ONE chunk -- 100 MB of fp32 logits is nothing on a 288 GB card, and a 1 024-row chunk
+        #  leaves the 8 192-deep dgrad on 64 workgroups)
         mean, rows = linear_cross_entropy(h.reshape(-1, h.shape[-1]), m.logit_proj.weight, m.logit_proj.bias, target.reshape(-1),
-                                          grad_scale=loss_scale)
+                                          chunk=4096, grad_scale=loss_scale)
         mean.backward()                                    # (the accumulation scale is inside the fused gradient)
         return rows.view(tokens.shape[0], -1).mean(dim=1), mean.detach()
 
