@@ -71,9 +71,12 @@ def _wgrad_kv(wk, wv, bv, dkv, x_kv, lnp, stats):
         dw = torch.as_strided(bk_, (2 * I, wk.shape[1]), (wk.shape[1], 1))
     else:
         dw = torch.zeros((2 * I, wk.shape[1]), dtype=torch.float32, device=dkv.device)
-    ops.linear_wgrad(dkv, x_kv, dw, db, ln=lnp, ln_stats=stats)
     if direct:
-        bb_ += db[I:]
+        with ops.arena_fill():          # (db is a scratch row: its to_v half joins the arena behind the launch, on the same stream)
+            ops.linear_wgrad(dkv, x_kv, dw, db, ln=lnp, ln_stats=stats, then=lambda: bb_.add_(db[I:]))
+    else:
+        ops.linear_wgrad(dkv, x_kv, dw, db, ln=lnp, ln_stats=stats)
+    if direct:
         for p in (wk, wv, bv):
             ready = getattr(p, '_wmz_ready', None)
             if ready is not None:
@@ -243,7 +246,7 @@ def _dense_attention_block_backward(ctx, dy):
     dg = db = None
     fold = ctx.has_res and ctx.res_is_x
     if ln_g is not None:
-        stats = ops.layernorm_stats(x, LN_EPS)
+        stats = ctx.ln_stats if getattr(ctx, 'ln_stats', None) is not None else ops.layernorm_stats(x, LN_EPS)
         lnp = (ln_g.detach(), ln_b.detach())
         dwqkv = _emit(wqkv, lambda w: ops.linear_wgrad(dqkv, x, w, None, ln=lnp, ln_stats=stats))
         holder = {}

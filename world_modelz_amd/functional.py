@@ -161,10 +161,13 @@ class _DenseAttentionBlock(torch.autograd.Function):
         B, n, _ = x.shape
         I = wqkv.shape[0] // 3
         ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
-        qkv = ops.linear_fwd(x, _cast.operand(wqkv, dt), ln=ln, ln_eps=LN_EPS)                    # [B, n, 3I]
+        need_bwd = grad_on and any(ctx.needs_input_grad)
+        # training: the LayerNorm statistics are computed ONCE (the GEMM's twelve column tiles would each redo the two passes
+        # over their rows) and kept for the backward
+        stats = ops.layernorm_stats(x, LN_EPS) if (ln is not None and need_bwd) else None
+        qkv = ops.linear_fwd(x, _cast.operand(wqkv, dt), ln=ln, ln_eps=LN_EPS, ln_stats=stats)    # [B, n, 3I]
         (S, H, W), ext = _dense_grid(n)
         g = qkv.view(B, S, H, W, 3 * I)
-        need_bwd = grad_on and any(ctx.needs_input_grad)
         o, lse, _ = ops.local3d_attention_fwd(g[..., :I], g[..., I:2 * I], g[..., 2 * I:], ext, heads, need_lse=need_bwd)
         o = o.view(B, n, I)
         if wout is not None:
@@ -173,6 +176,7 @@ class _DenseAttentionBlock(torch.autograd.Function):
             y = o if residual is None else o + residual
         if need_bwd:
             ctx.save_for_backward(x, ln_g, ln_b, wqkv, wout, bout, qkv, o, lse)
+            ctx.ln_stats = stats
             ctx.heads, ctx.has_res = heads, residual is not None
             ctx.res_is_x = bool(res_is_x)
         return y

@@ -378,9 +378,10 @@ def _side_workspace(ent, device, floats):
     return w
 
 
-def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, overwrite=False):
+def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, overwrite=False, then=None):
     """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc) (overwrite: = instead of +=).  dw / dbias fp32 (two-stage reduction
-    through a per-device workspace: deterministic, no float atomics)."""
+    through a per-device workspace: deterministic, no float atomics).  then(): follow-up work on the result, issued behind the
+    launch on whichever stream it went to."""
     dt = L.dtype_code(dc.dtype)
     dc, M, ldc = _rows(dc)
     a, Ma, lda = _rows(a)
@@ -391,11 +392,13 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
         g, b = ln
         mean, rstd = ln_stats
     need = L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
-    side = _wgrad_side_enter(dc.device, (dc, a, g, b, mean, rstd))
+    side = _wgrad_side_enter(dc.device, (dc, a, g, b, mean, rstd, dbias))
     if side is None:
         ws = _workspace(dc.device, need)
         L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
                L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, 1 if overwrite else 0, L.ptr(ws), ws.numel(), dt, L.stream())
+        if then is not None:
+            then()
         return
     ent, fork = side
 
@@ -405,13 +408,16 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
             ws = _side_workspace(ent, dc.device, need)
             L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),
                    L.ptr(mean), L.ptr(rstd), 1 if gelu_in else 0, 1 if overwrite else 0, L.ptr(ws), ws.numel(), dt, L.stream())
+            if then is not None:
+                then()
     _defer(launch)
 
 
 def linear_wgrad_batch(problems):
     """Up to 6 plain weight gradients by one launch pair (wmz_linear_wgrad_batch).  problems: (dc, a, dw, dbias | None,
     overwrite[, a_tiled]) tuples with the meaning of linear_wgrad's arguments; a_tiled: `a` is the fused path's tiled stream
-    ([M, 256] bf16 in 32-row tiles) instead of row-major."""
+    ([M, 256] bf16 in 32-row tiles) instead of row-major.  (Stays on the compute stream: at config 4 these launches fill the
+    chip, a side branch measured 1.91 vs 1.90 ms per step.)"""
     import ctypes
     n = len(problems)
     dt = L.dtype_code(problems[0][0].dtype)
