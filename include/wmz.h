@@ -82,6 +82,14 @@ int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, const float* b
                          const float* ln_mean, const float* ln_rstd, float ln_eps, int flags, int out_f32, int dtype,
                          void* stream);
 
+/* FeedForward's first GEMM as the training forward wants it (local_3d_attention.py:24-25: nn.Linear -> nn.GELU): the
+ * pre-activation Z = LN?(A) Wt^T + bias (what gelu' needs in the backward) AND the activation H = GELU(Z), both [M, N] in the
+ * activation dtype (ldz / ldh row strides), from one accumulator.  The second GEMM and its weight gradient read H as it is
+ * instead of re-evaluating the erf of their operand panel once per output column tile. */
+int wmz_linear_fwd_gelu_pair(const void* A, long lda, const void* Wt, const float* bias, void* Z, long ldz, void* H, long ldh,
+                             int M, int N, int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
+                             const float* ln_rstd, float ln_eps, int dtype, void* stream);
+
 /* logit_proj on the LAST FRAME of every clip, read in place (main.py:35-36: x[:, -1] -> nn.Linear): C[M,N] = A' Wt^T + bias
  * where row m of A' is A + (m / rows_per_block) * block_stride + (m % rows_per_block) * lda (elements); rows_per_block =
  * H*W, block_stride = S*H*W*D selects the last plane of each clip of a [B,S,H,W,D] stream without a gather copy. */

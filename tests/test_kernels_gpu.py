@@ -145,6 +145,36 @@ def test_linear_plain_bias_gelu_residual(ops, M, N, K, dtype):
     assert y.dtype == torch.float32 and rel(y, af @ wf.t() + b) < (2e-6 if dtype == torch.float32 else 1e-5)
 
 
+@pytest.mark.parametrize('M,N,K', [(3072, 1024, 512), (300, 96, 64), (4096, 512, 384), (77, 50, 24), (20000, 256, 256)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_gelu_pair_and_small_row_tiles(ops, M, N, K, dtype):
+    """wmz_linear_fwd_gelu_pair (pre-activation + GELU of it from one accumulator; FeedForward's first GEMM in training) and the
+    LayerNorm / GELU-prologue GEMMs on 64-row tiles (few rows: config 5) against torch; the pair's second output equals the
+    single-output GELU epilogue bit for bit, its first the plain GEMM."""
+    torch.manual_seed(41)
+    a = (torch.randn(M, K) * 1.5 + 0.3).to(dtype)
+    w = (torch.randn(N, K) / K ** 0.5).to(dtype)
+    b = torch.randn(N)
+    g, be = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+    af, wf = a.float(), w.float()
+    tol = 3e-6 if dtype == torch.float32 else 8e-3
+    for ln in (None, (dev(g), dev(be))):
+        xin = af if ln is None else torch.nn.functional.layer_norm(af, (K,), g, be, 1e-5)
+        pre = xin @ wf.t() + b
+        stats = None if ln is None else ops.layernorm_stats(dev(a), 1e-5)
+        z, h = ops.linear_fwd_gelu_pair(dev(a), dev(w), bias=dev(b), ln=ln, ln_stats=stats)
+        assert z.dtype == dtype and h.dtype == dtype
+        assert rel(z, pre) < tol and rel(h, torch.nn.functional.gelu(pre)) < tol
+        assert torch.equal(z, ops.linear_fwd(dev(a), dev(w), bias=dev(b), ln=ln, ln_stats=stats))
+        assert torch.equal(h, ops.linear_fwd(dev(a), dev(w), bias=dev(b), ln=ln, ln_stats=stats, gelu=True))
+    # GELU in the loader (the backward's fallback when the activation was not kept) on both tile heights
+    if N % 8 == 0:
+        w2 = (torch.randn(K, N) / N ** 0.5).to(dtype)
+        zz = (torch.randn(M, N)).to(dtype)
+        y = ops.linear_fwd(dev(zz), dev(w2), gelu_in=True)
+        assert rel(y, torch.nn.functional.gelu(zz.float()) @ w2.float().t()) < tol
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,S,HW,D,N', [(8, 5, 256, 256, 1024), (3, 4, 20, 32, 50), (2, 1, 77, 64, 130)])
 def test_linear_on_last_frame_blocks(ops, dtype, B, S, HW, D, N):

@@ -158,12 +158,16 @@ def feed_forward_block_backward(ctx, dy):
 
 
 def _feed_forward_block_backward(ctx, dy):
-    x, ln_g, ln_b, w1, b1, w2, b2, z = ctx.saved_tensors
+    x, ln_g, ln_b, w1, b1, w2, b2, z = ctx.saved_tensors[:8]
+    h = ctx.saved_tensors[8] if len(ctx.saved_tensors) > 8 else None      # GELU(z) as the forward stored it (or recompute in the loader)
     dt = x.dtype
     dy = dy.contiguous()
     d_res = dy if ctx.has_res else None
     # y = GELU(z) W2^T + b2 (+ residual)
-    dw2, db2 = _emit2(w2, b2, lambda w, b: ops.linear_wgrad(dy, z, w, b, gelu_in=True))
+    if h is not None:
+        dw2, db2 = _emit2(w2, b2, lambda w, b: ops.linear_wgrad(dy, h, w, b))
+    else:
+        dw2, db2 = _emit2(w2, b2, lambda w, b: ops.linear_wgrad(dy, z, w, b, gelu_in=True))
     dz = ops.linear_dgrad(dy, _wt(w2, dt, 'w2T'), dgelu_z=z)        # (dy W2) * gelu'(z)
     # z = LN(x) W1^T + b1
     dxhat = ops.linear_dgrad(dz, _wt(w1, dt, 'w1T'))

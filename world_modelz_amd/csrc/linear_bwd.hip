@@ -562,67 +562,88 @@ __global__ __launch_bounds__(1024 / KG) void ln_bwd_kernel(const T* __restrict__
       const int k = c * 256 + lane * 4 + e;
       gam[c][e] = k < K ? gamma[k] : 0.f;
     }
-  for (int m = blockIdx.x * (NTL / 64) + wave; m < M; m += gridDim.x * (NTL / 64)) {
-    float xv[KG][4], dy[KG][4];
-    float s = 0.f;
+  // TWO rows per wave and iteration: both rows' loads (x, dy, the skips) are in flight before the first reduction (one row in
+  // flight: 72 us per call at 65 536 x 384, two: 58, four: 84 -- 154 registers, a third of the waves).  The second row of a
+  // wave's last pair may lie past M: it is clamped for the loads, its dy zeroed (exact zeros into the column sums), no store.
+  constexpr int U = 2;
+  const int stride = gridDim.x * (NTL / 64);
+  for (int m0 = blockIdx.x * (NTL / 64) + wave; m0 < M; m0 += U * stride) {
+    float xv[U][KG][4], dy[U][KG][4], sk[U][KG][4];
+    int mr[U];
+    bool live[U];
 #pragma unroll
-    for (int c = 0; c < KG; ++c) {
-      const int k0 = c * 256 + lane * 4;
-      if (k0 < K) {
-        load4<T>(X + (long)m * ldx + k0, xv[c]);
-        load4<T>(DY + (long)m * lddy + k0, dy[c]);
-      } else {
+    for (int u = 0; u < U; ++u) {
+      live[u] = m0 + u * stride < M;
+      mr[u] = live[u] ? m0 + u * stride : m0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { xv[c][e] = 0.f; dy[c][e] = 0.f; }
-      }
-      s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
-    }
-    s = wave_sum(s);
-    const float mu = s / (float)K;
-    float q = 0.f;
+      for (int c = 0; c < KG; ++c) {
+        const int k0 = c * 256 + lane * 4;
 #pragma unroll
-    for (int c = 0; c < KG; ++c)
+        for (int e = 0; e < 4; ++e) { xv[u][c][e] = 0.f; dy[u][c][e] = 0.f; sk[u][c][e] = 0.f; }
+        if (k0 < K) {
+          load4<T>(X + (long)mr[u] * ldx + k0, xv[u][c]);
+          load4<T>(DY + (long)mr[u] * lddy + k0, dy[u][c]);
+          if (!live[u]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = c * 256 + lane * 4 + e;
-        const float d = k < K ? xv[c][e] - mu : 0.f;
-        q += d * d;
-      }
-    q = wave_sum(q);
-    const float rs = rsqrtf(q / (float)K + eps);
-    float c1 = 0.f, c2 = 0.f;
+            for (int e = 0; e < 4; ++e) dy[u][c][e] = 0.f;
+          }
+          if (SKIP) load4<T>(SKIP + (long)mr[u] * ldskip + k0, sk[u][c]);
+          if (SKIP2) {
+            float s2[4];
+            load4<T>(SKIP2 + (long)mr[u] * ldskip2 + k0, s2);
 #pragma unroll
-    for (int c = 0; c < KG; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = c * 256 + lane * 4 + e;
-        const float xh = k < K ? (xv[c][e] - mu) * rs : 0.f;
-        xv[c][e] = xh;
-        const float gd = gam[c][e] * dy[c][e];
-        c1 += gd;
-        c2 += gd * xh;
-        gsum[c][e] += dy[c][e] * xh;
-        bsum[c][e] += dy[c][e];
-      }
-    c1 = wave_sum(c1);
-    c2 = wave_sum(c2);
-    c1 /= (float)K;
-    c2 /= (float)K;
-#pragma unroll
-    for (int c = 0; c < KG; ++c) {
-      const int k0 = c * 256 + lane * 4;
-      if (k0 < K) {
-        float sk[4] = {0.f, 0.f, 0.f, 0.f}, out[4];
-        if (SKIP) load4<T>(SKIP + (long)m * ldskip + k0, sk);
-        if (SKIP2) {
-          float s2[4];
-          load4<T>(SKIP2 + (long)m * ldskip2 + k0, s2);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sk[e] += s2[e];
+            for (int e = 0; e < 4; ++e) sk[u][c][e] += s2[e];
+          }
         }
+      }
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = rs * (gam[c][e] * dy[c][e] - c1 - xv[c][e] * c2) + sk[e];
-        store4<T>(DX + (long)m * lddx + k0, out);
+    for (int u = 0; u < U; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < KG; ++c) s += (xv[u][c][0] + xv[u][c][1]) + (xv[u][c][2] + xv[u][c][3]);
+      s = wave_sum(s);
+      const float mu = s / (float)K;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < KG; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = c * 256 + lane * 4 + e;
+          const float d = k < K ? xv[u][c][e] - mu : 0.f;
+          q += d * d;
+        }
+      q = wave_sum(q);
+      const float rs = rsqrtf(q / (float)K + eps);
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < KG; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = c * 256 + lane * 4 + e;
+          const float xh = k < K ? (xv[u][c][e] - mu) * rs : 0.f;
+          xv[u][c][e] = xh;
+          const float gd = gam[c][e] * dy[u][c][e];
+          c1 += gd;
+          c2 += gd * xh;
+          gsum[c][e] += dy[u][c][e] * xh;
+          bsum[c][e] += dy[u][c][e];
+        }
+      c1 = wave_sum(c1);
+      c2 = wave_sum(c2);
+      c1 /= (float)K;
+      c2 /= (float)K;
+      if (live[u]) {
+#pragma unroll
+        for (int c = 0; c < KG; ++c) {
+          const int k0 = c * 256 + lane * 4;
+          if (k0 < K) {
+            float out[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = rs * (gam[c][e] * dy[u][c][e] - c1 - xv[u][c][e] * c2) + sk[u][c][e];
+            store4<T>(DX + (long)mr[u] * lddx + k0, out);
+          }
+        }
       }
     }
   }

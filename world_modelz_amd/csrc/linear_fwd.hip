@@ -20,6 +20,7 @@ struct LinParams {
   const float* bias;
   const void* res; long ldr;
   void* C; long ldc;
+  void* C2; long ldc2;                       // optional second output: GELU(C) (C then holds the pre-activation); no residual
   int M, N, K;
   const float* gamma; const float* beta; float eps;
   const float* mean; const float* rstd;      // optional precomputed LayerNorm statistics (wmz_layernorm_stats)
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   const bool dgelu = (P.flags & WMZ_LIN_DGELU) != 0;
   const T* R = reinterpret_cast<const T*>(P.res);
   if constexpr (sizeof(T) == 2) {
-    if (!P.out_f32 && (P.ldc % 8) == 0 && (R == nullptr || (P.ldr % 8) == 0)) {
+    if (!P.out_f32 && (P.ldc % 8) == 0 && (R == nullptr || (P.ldr % 8) == 0) && (P.C2 == nullptr || (P.ldc2 % 8) == 0)) {
       // 16-bit outputs: a lane owns ONE column, so direct stores would be 2 bytes each.  Stage the fp32 tile through LDS
       // (BM / 2 rows per round: it fits the bytes the slabs occupied) and leave as whole 16-byte row chunks; the residual /
       // gelu' operand is read the same way and applied in fp32 before the single rounding.
@@ -315,6 +316,11 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
               }
             }
             *reinterpret_cast<i32x4*>(dst) = f32_to_chunk<T>(f);
+            if (P.C2) {                                                // the activation next to the pre-activation
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] = gelu_erf(f[e]);
+              *reinterpret_cast<i32x4*>(reinterpret_cast<T*>(P.C2) + (long)row * P.ldc2 + col) = f32_to_chunk<T>(f);
+            }
           } else {
             for (int e = 0; e < 8 && col + e < P.N; ++e) {
               float v = f[e];
@@ -324,6 +330,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
                 else v += rv;
               }
               dst[e] = Elem<T>::from_f32(v);
+              if (P.C2) reinterpret_cast<T*>(P.C2)[(long)row * P.ldc2 + col + e] = Elem<T>::from_f32(gelu_erf(v));
             }
           }
         }
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
         }
         if (P.out_f32) reinterpret_cast<float*>(P.C)[(long)row * P.ldc + col] = v;
         else reinterpret_cast<T*>(P.C)[(long)row * P.ldc + col] = Elem<T>::from_f32(v);
+        if (P.C2) reinterpret_cast<T*>(P.C2)[(long)row * P.ldc2 + col] = Elem<T>::from_f32(gelu_erf(v));
       }
     }
 }
@@ -411,7 +419,32 @@ extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, con
   P.mean = ln_mean; P.rstd = ln_rstd;
   P.out_f32 = out_f32;
   P.rpb = 0; P.bstride = 0;
+  P.C2 = nullptr; P.ldc2 = 0;
   return linear_launch(P, ln_gamma, flags, dtype, (hipStream_t)stream);
+}
+
+// FeedForward's first GEMM in training (local_3d_attention.py:24-25: Linear -> GELU): Z = LN?(A) Wt^T + bias AND H = GELU(Z),
+// both in the activation dtype, from one accumulator (H rounds GELU of the fp32 sum, as the inference epilogue does).  The
+// second GEMM and its weight gradient then read H as it is -- with the activation recomputed in their loaders every column
+// tile of the output repeats the erf of its whole operand panel (dim 384: three times; the 512-wide mlp of config 5: four).
+extern "C" int wmz_linear_fwd_gelu_pair(const void* A, long lda, const void* Wt, const float* bias, void* Z, long ldz, void* H,
+                                        long ldh, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
+                                        const float* ln_mean, const float* ln_rstd, float ln_eps, int dtype, void* stream) {
+  WMZ_REQUIRE(A && Wt && Z && H, "wmz_linear_fwd_gelu_pair: null tensor");
+  WMZ_REQUIRE((ln_mean == nullptr) == (ln_rstd == nullptr), "wmz_linear_fwd_gelu_pair: ln_mean and ln_rstd go together");
+  WMZ_REQUIRE(ln_mean == nullptr || ln_gamma != nullptr, "wmz_linear_fwd_gelu_pair: statistics without a LayerNorm prologue");
+  WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_fwd_gelu_pair: bad shape M=%d N=%d K=%d", M, N, K);
+  WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0, "wmz_linear_fwd_gelu_pair: K and lda must be multiples of 8 (K=%d lda=%ld)", K, lda);
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd_gelu_pair: bad dtype %d", dtype);
+  WMZ_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "wmz_linear_fwd_gelu_pair: ln_gamma and ln_beta go together");
+  LinParams P;
+  P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = nullptr; P.ldr = 0; P.C = Z; P.ldc = ldz;
+  P.M = M; P.N = N; P.K = K; P.gamma = ln_gamma; P.beta = ln_beta; P.eps = ln_eps; P.flags = 0;
+  P.mean = ln_mean; P.rstd = ln_rstd;
+  P.out_f32 = 0;
+  P.rpb = 0; P.bstride = 0;
+  P.C2 = H; P.ldc2 = ldh;
+  return linear_launch(P, ln_gamma, 0, dtype, (hipStream_t)stream);
 }
 
 // logit_proj on the LAST FRAME of every clip (main.py:35-36: x[:, -1] -> nn.Linear), read in place: A's rows come in blocks of
@@ -429,5 +462,6 @@ extern "C" int wmz_linear_fwd_blocked(const void* A, long lda, int rows_per_bloc
   P.mean = nullptr; P.rstd = nullptr;
   P.out_f32 = out_f32;
   P.rpb = rows_per_block; P.bstride = block_stride;
+  P.C2 = nullptr; P.ldc2 = 0;
   return linear_launch(P, nullptr, 0, dtype, (hipStream_t)stream);
 }

@@ -61,11 +61,12 @@ class _FeedForwardBlock(torch.autograd.Function):
         need_bwd = grad_on and any(ctx.needs_input_grad)
         w1_c, w2_c = _cast.operand(w1, dt), _cast.operand(w2, dt)
         if need_bwd:
-            # keep the pre-activation; GELU is applied while the second GEMM stages its A operand
+            # keep the pre-activation z (gelu' in the backward) AND the activation h = GELU(z) (the second GEMM's operand here,
+            # its weight gradient's operand in the backward): one launch writes both
             stats = ops.layernorm_stats(x, LN_EPS) if ln is not None else None
-            z = ops.linear_fwd(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, ln_stats=stats)
-            y = ops.linear_fwd(z, w2_c, bias=b2.detach(), residual=residual, gelu_in=True)
-            ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z)
+            z, h = ops.linear_fwd_gelu_pair(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, ln_stats=stats)
+            y = ops.linear_fwd(h, w2_c, bias=b2.detach(), residual=residual)
+            ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z, h)
             ctx.ln_stats = stats
             ctx.has_res = residual is not None
             ctx.res_is_x = bool(res_is_x)

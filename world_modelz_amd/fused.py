@@ -700,9 +700,9 @@ class _TrainForward(torch.autograd.Function):
             dt = x1.dtype
             # feed-forward block: y = W2 GELU(W1 LN(x1) + b1) + b2 + x1
             stats = (st_ff[0], st_ff[1])                   # computed by the fused forward: no extra pass over x1
-            zpre = ops.linear_fwd(x1, _cast.operand(w1, dt), bias=b1.detach(), ln=(fn_g.detach(), fn_b.detach()), ln_eps=LN_EPS,
-                                  ln_stats=stats)
-            cf = _Ctx((x1, fn_g, fn_b, w1, b1, w2, b2, zpre), has_res=True, res_is_x=True, ln_stats=stats)
+            zpre, hact = ops.linear_fwd_gelu_pair(x1, _cast.operand(w1, dt), bias=b1.detach(), ln=(fn_g.detach(), fn_b.detach()),
+                                                  ln_eps=LN_EPS, ln_stats=stats)
+            cf = _Ctx((x1, fn_g, fn_b, w1, b1, w2, b2, zpre, hact), has_res=True, res_is_x=True, ln_stats=stats)
             dx1, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2 = Bk.feed_forward_block_backward(cf, dy)[:7]
             # attention block: x1 = to_out(attn(LN(x), q = x)) + x
             ca = _Ctx((x_in, x_in, an_g, an_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse), extents=attn.fn.extents,

@@ -91,6 +91,29 @@ def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=F
     return out
 
 
+def linear_fwd_gelu_pair(a, weight, bias=None, ln=None, ln_eps=1e-5, ln_stats=None):
+    """(z, h) = (LN?(a) @ weight^T + bias, GELU(z)), both in a's dtype, from one launch (wmz_linear_fwd_gelu_pair)."""
+    K = a.shape[-1]
+    N = weight.shape[0]
+    dt = L.dtype_code(a.dtype)
+    assert weight.dtype == a.dtype and weight.is_contiguous() and weight.shape[1] == K
+    a, M, lda = _rows(a)
+    lead = a.shape[:-1]
+    z = torch.empty(lead + (N,), dtype=a.dtype, device=a.device)
+    h = torch.empty(lead + (N,), dtype=a.dtype, device=a.device)
+    g = b = mean = rstd = None
+    if ln is not None:
+        g, b = ln
+        assert g.dtype == torch.float32 and b.dtype == torch.float32
+    if ln_stats is not None:
+        mean, rstd = ln_stats
+        assert ln is not None and mean.numel() == M and rstd.numel() == M
+    assert bias is None or bias.dtype == torch.float32
+    L.call('wmz_linear_fwd_gelu_pair', L.ptr(a), lda, L.ptr(weight), L.ptr(bias), L.ptr(z), N, L.ptr(h), N, M, N, K,
+           L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(rstd), float(ln_eps), dt, L.stream())
+    return z, h
+
+
 def linear_fwd_blocks(a, weight, bias=None, out_f32=False):
     """a: [Bk, R, K] with contiguous rows inside each block and an arbitrary block stride (x[:, -1] of a [B,S,H,W,D]
     stream, flattened to [B, H*W, D]) -> [Bk, R, N] = a @ weight^T + bias, the blocks read in place."""
