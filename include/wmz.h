@@ -457,6 +457,10 @@ int wmz_sample_tokens_dev(const float* logits, long ld, int R, int C, int top_k,
 int wmz_ce_fwd(const float* logits, long ld, const int64_t* target, float* loss, float* lse, long R, int C, void* stream);
 int wmz_ce_bwd(const float* logits, long ld, const int64_t* target, const float* lse, const float* grad_rows, void* dlogits,
                long R, int C, int dtype, void* stream);
+/* Both in one pass over the logits (a wave keeps its row in registers; C <= 8192, else the two launches above): what the
+ * training step's fused linear + cross-entropy calls. */
+int wmz_ce_fwd_bwd(const float* logits, long ld, const int64_t* target, float* loss, float* lse, const float* grad_rows,
+                   void* dlogits, long R, int C, int dtype, void* stream);
 
 /* ---- training-step tail over flat fp32 arenas (one launch each) ----
  * grad_norm (main.py:188-193): out[0] += scale^2 * sum g^2 (caller zeroes out[0]; no host sync). */

@@ -302,7 +302,7 @@ def test_training_step_full_size_properties(wmz):
 def test_fused_cross_entropy_vs_torch(wmz):
     tr = wmz['train']
     torch.manual_seed(5)
-    for R, C in [(2048, 1024), (77, 50), (33, 8192)]:
+    for R, C in [(2048, 1024), (77, 50), (33, 8192), (301, 2000), (5, 4096), (9, 9000)]:
         logits = (torch.randn(R, C, device='cuda') * 3).requires_grad_(True)
         target = torch.randint(0, C, (R,), device='cuda')
         ref = torch.nn.functional.cross_entropy(logits, target, reduction='none')
@@ -319,6 +319,14 @@ def test_fused_cross_entropy_vs_torch(wmz):
         L.call('wmz_ce_bwd', L.ptr(logits.detach()), C, L.ptr(target), L.ptr(lse), L.ptr(w), L.ptr(g16), R, C, L.WMZ_BF16,
                L.stream())
         assert torch.allclose(g16.float(), gref, rtol=2e-2, atol=1e-4)
+        # the one-pass form the training step calls (row in registers; C > 8192 falls back to the two launches)
+        for dt_code, dt_t, rt in ((L.WMZ_BF16, torch.bfloat16, 2e-2), (L.WMZ_F32, torch.float32, 1e-4)):
+            lo, ls = torch.empty(R, device='cuda'), torch.empty(R, device='cuda')
+            gg = torch.empty(R, C, dtype=dt_t, device='cuda')
+            L.call('wmz_ce_fwd_bwd', L.ptr(logits.detach()), C, L.ptr(target), L.ptr(lo), L.ptr(ls), L.ptr(w), L.ptr(gg), R, C,
+                   dt_code, L.stream())
+            assert torch.allclose(lo, ref.detach(), rtol=1e-5, atol=1e-5) and torch.allclose(ls, lse, rtol=1e-5, atol=1e-5)
+            assert torch.allclose(gg.float(), gref, rtol=rt, atol=1e-4 if dt_t == torch.bfloat16 else 1e-7)
 
 
 @pytest.mark.parametrize('shape,depth', [((2, 4, 16, 16), 3), ((1, 3, 8, 8), 2), ((2, 2, 5, 5), 2)])

@@ -92,6 +92,7 @@ SIGNATURES = {
     'wmz_adamw_step_dev': [c_void_p] * 4 + [c_long, c_void_p] + [c_double] * 5 + [c_void_p, c_void_p],
     'wmz_ce_fwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     'wmz_ce_bwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    'wmz_ce_fwd_bwd': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     'wmz_grad_sqnorm': [c_void_p, c_long, c_float, c_void_p, c_void_p],
     'wmz_adamw_step': [c_void_p] * 4 + [c_long] + [c_double] * 5 + [c_long, c_double, c_void_p],
     'wmz_vq_argmin': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

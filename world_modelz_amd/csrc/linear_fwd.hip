@@ -265,7 +265,9 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   const bool dgelu = (P.flags & WMZ_LIN_DGELU) != 0;
   const T* R = reinterpret_cast<const T*>(P.res);
   if constexpr (sizeof(T) == 2) {
-    if (!P.out_f32 && (P.ldc % 8) == 0 && (R == nullptr || (P.ldr % 8) == 0) && (P.C2 == nullptr || (P.ldc2 % 8) == 0)) {
+    // (fp32 outputs -- the logits -- leave the same way, as two 16-byte stores per chunk, when there is no residual operand)
+    const bool f32_staged = P.out_f32 && R == nullptr && P.C2 == nullptr && (P.ldc % 4) == 0;
+    if (f32_staged || (!P.out_f32 && (P.ldc % 8) == 0 && (R == nullptr || (P.ldr % 8) == 0) && (P.C2 == nullptr || (P.ldc2 % 8) == 0))) {
       // 16-bit outputs: a lane owns ONE column, so direct stores would be 2 bytes each.  Stage the fp32 tile through LDS
       // (BM / 2 rows per round: it fits the bytes the slabs occupied) and leave as whole 16-byte row chunks; the residual /
       // gelu' operand is read the same way and applied in fp32 before the single rounding.
@@ -304,6 +306,16 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(stage + rl * BN + ch * 8);
           const f32x4 b = *reinterpret_cast<const f32x4*>(stage + rl * BN + ch * 8 + 4);
           float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+          if (f32_staged) {
+            float* dstf = reinterpret_cast<float*>(P.C) + (long)row * P.ldc + col;
+            if (col + 8 <= P.N) {
+              *reinterpret_cast<f32x4*>(dstf) = a;
+              *reinterpret_cast<f32x4*>(dstf + 4) = b;
+            } else {
+              for (int e = 0; e < 8 && col + e < P.N; ++e) dstf[e] = f[e];
+            }
+            continue;
+          }
           T* dst = reinterpret_cast<T*>(P.C) + (long)row * P.ldc + col;
           if (col + 8 <= P.N) {
             if (R) {

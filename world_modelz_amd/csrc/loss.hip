@@ -178,6 +178,77 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
+template <typename T> __device__ __forceinline__ void ce_store4(T* p, const float (&f)[4]);
+template <> __device__ __forceinline__ void ce_store4<float>(float* p, const float (&f)[4]) {
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = f[e];
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+template <> __device__ __forceinline__ void ce_store4<bf16_t>(bf16_t* p, const float (&f)[4]) {
+  s16x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (short)f32_to_bf16_bits(f[e]);
+  *reinterpret_cast<s16x4*>(p) = v;
+}
+
+// Both of the above in ONE pass: a wave holds its row in registers (NCH float4 per lane, C <= 256 NCH), so the [R, C] logits
+// are read once instead of three times (max / sum-exp / gradient) and every access is 16 bytes (8 for the 16-bit gradient).
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ target,
+                                                       float* __restrict__ loss, float* __restrict__ lse,
+                                                       const float* __restrict__ grow, T* __restrict__ dlogits, long R, int C) {
+  const int lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += (long)gridDim.x * 4) {
+    const float* x = logits + row * ld;
+    f32x4 v[NCH];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = q * 256 + lane * 4;
+      if (c + 4 <= C) {
+        v[q] = *reinterpret_cast<const f32x4*>(x + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][e] = c + e < C ? x[c + e] : -INFINITY;
+      }
+      m = fmaxf(fmaxf(m, fmaxf(v[q][0], v[q][1])), fmaxf(v[q][2], v[q][3]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += __expf(v[q][e] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float l = m + logf(s);
+    long t = target[row];
+    const int tc = (int)(t < 0 ? 0 : (t >= C ? C - 1 : t));
+    if (lane == 0) {
+      lse[row] = l;
+      loss[row] = l - x[tc];
+    }
+    const float g = grow[row];
+    const int tt = (int)t;                      // (an out-of-range target matches no column, as in ce_bwd_kernel)
+    T* d = dlogits + row * (long)C;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = q * 256 + lane * 4;
+      float o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = (__expf(v[q][e] - l) - (c + e == tt ? 1.f : 0.f)) * g;
+      if (c + 4 <= C && (C & 3) == 0) {
+        ce_store4<T>(d + c, o4);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (c + e < C) d[c + e] = Elem<T>::from_f32(o4[e]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int wmz_corrupt_tokens(const int64_t* z_last, long clip_stride, const float* r, int64_t* out, long out_stride,
@@ -233,6 +304,27 @@ extern "C" int wmz_ce_fwd(const float* logits, long ld, const int64_t* target, f
   const int grid = (int)((R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, ld, target, loss, lse, R, C);
   WMZ_LAUNCH_CHECK("wmz_ce_fwd");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_ce_fwd_bwd(const float* logits, long ld, const int64_t* target, float* loss, float* lse, const float* grad_rows,
+                              void* dlogits, long R, int C, int dtype, void* stream) {
+  WMZ_REQUIRE(logits && target && loss && lse && grad_rows && dlogits && R > 0 && C > 0, "wmz_ce_fwd_bwd: bad arguments");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_ce_fwd_bwd: bad dtype %d", dtype);
+  if (C > 8192 || (ld & 3) != 0) {               // rows that do not fit a wave's registers / unaligned rows: the two passes
+    const int rc = wmz_ce_fwd(logits, ld, target, loss, lse, R, C, stream);
+    return rc != WMZ_OK ? rc : wmz_ce_bwd(logits, ld, target, lse, grad_rows, dlogits, R, C, dtype, stream);
+  }
+  const int grid = (int)((R + 3) / 4 < 4096 ? (R + 3) / 4 : 4096);
+  hipStream_t st = (hipStream_t)stream;
+#define WMZ_CEF(T, NCH) hipLaunchKernelGGL((ce_fused_kernel<T, NCH>), dim3(grid), dim3(256), 0, st, logits, ld, target, loss, lse, \
+                                           grad_rows, (T*)dlogits, R, C)
+#define WMZ_CEF_T(T) do { if (C <= 1024) WMZ_CEF(T, 4); else if (C <= 2048) WMZ_CEF(T, 8); else if (C <= 4096) WMZ_CEF(T, 16); \
+                          else WMZ_CEF(T, 32); } while (0)
+  if (dtype == WMZ_BF16) WMZ_CEF_T(bf16_t); else WMZ_CEF_T(float);
+#undef WMZ_CEF_T
+#undef WMZ_CEF
+  WMZ_LAUNCH_CHECK("wmz_ce_fwd_bwd");
   return WMZ_OK;
 }
 

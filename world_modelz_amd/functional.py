@@ -194,11 +194,21 @@ class _EmbedIndexed(torch.autograd.Function):
         x = ops.embed_indexed_fwd(tok, pos, emb.detach(), pos_s.detach(), pos_h.detach(), pos_w.detach(), shape, dtype)
         ctx.save_for_backward(tok, pos)
         ctx.shape3, ctx.shapes = shape, (emb.shape, pos_s.shape, pos_h.shape, pos_w.shape)
+        ctx.params = (emb, pos_s, pos_h, pos_w)
         return x
 
     @staticmethod
     def backward(ctx, dx):
         tok, pos = ctx.saved_tensors
+        bufs = [getattr(p, '_wmz_grad', None) for p in ctx.params]
+        if all(b is not None for b in bufs):
+            # flat gradient arena: the kernel's atomics land in the parameters' slices (as embed_backward does for the grid model)
+            ops.embed_indexed_bwd(tok, pos, dx, ctx.shape3, ctx.shapes, into=bufs)
+            for p in ctx.params:
+                ready = getattr(p, '_wmz_ready', None)
+                if ready is not None:
+                    ready()
+            return None, None, None, None, None, None, None, None
         demb, dps, dph, dpw = ops.embed_indexed_bwd(tok, pos, dx, ctx.shape3, ctx.shapes)
         return None, None, demb, dps, dph, dpw, None, None
 

@@ -595,11 +595,17 @@ def embed_indexed_fwd(tok, pos, emb, pos_s, pos_h, pos_w, shape, dtype):
     return x
 
 
-def embed_indexed_bwd(tok, pos, dx, shape, table_shapes):
+def embed_indexed_bwd(tok, pos, dx, shape, table_shapes, into=None):
+    """-> the four table gradients (fp32).  into: four fp32 tensors of those shapes the kernel ACCUMULATES into instead (the
+    parameters' slices of the flat gradient arena: no zero fills, no `grad += g` passes)."""
     S, H, W = shape
     dx = dx.contiguous()
     D = dx.shape[-1]
-    tabs = [torch.zeros(s, dtype=torch.float32, device=dx.device) for s in table_shapes]
+    if into is not None:
+        tabs = list(into)
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(s) for t, s in zip(tabs, table_shapes))
+    else:
+        tabs = [torch.zeros(s, dtype=torch.float32, device=dx.device) for s in table_shapes]
     L.call('wmz_embed_indexed_bwd', L.ptr(tok.contiguous()), L.ptr(pos.contiguous()), L.ptr(dx), L.ptr(tabs[0]),
            L.ptr(tabs[1]), L.ptr(tabs[2]), L.ptr(tabs[3]), tok.numel(), S, H, W, D, table_shapes[0][0],
            L.dtype_code(dx.dtype), L.stream())

@@ -114,10 +114,9 @@ class _LinearCrossEntropy(torch.autograd.Function):
             xs = x[r0:r1]
             lg = ops.linear_fwd(xs, w_c, bias=None if b is None else b.detach(), out_f32=True)
             lse = torch.empty(r1 - r0, dtype=torch.float32, device=x.device)
-            L.call('wmz_ce_fwd', L.ptr(lg), lg.stride(0), L.ptr(target[r0:r1]), L.ptr(loss[r0:r1]), L.ptr(lse), r1 - r0, C, L.stream())
             d = torch.empty((r1 - r0, C), dtype=dt, device=x.device)
-            L.call('wmz_ce_bwd', L.ptr(lg), lg.stride(0), L.ptr(target[r0:r1]), L.ptr(lse), L.ptr(ones), L.ptr(d), r1 - r0, C,
-                   L.dtype_code(dt), L.stream())
+            L.call('wmz_ce_fwd_bwd', L.ptr(lg), lg.stride(0), L.ptr(target[r0:r1]), L.ptr(loss[r0:r1]), L.ptr(lse), L.ptr(ones),
+                   L.ptr(d), r1 - r0, C, L.dtype_code(dt), L.stream())
             if r0 == 0 and r1 == R:
                 dx = ops.linear_dgrad(d, wT)               # one chunk (the denoiser's last frame): no staging copy
             else:
