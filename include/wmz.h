@@ -122,6 +122,14 @@ int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* ldc, const 
                            float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
                            const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats, int dtype,
                            void* stream);
+/* The same with an optional LayerNorm prologue per problem (tables of n pointers; a NULL ln_gamma[i] = plain problem, else
+ * ln_beta[i], ln_mean[i], ln_rstd[i] as for wmz_linear_wgrad_ws): the weight gradients of one transformer layer on the
+ * op-by-op path as one launch pair. */
+int wmz_linear_wgrad_batch_ln(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
+                              float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
+                              const int* overwrite, const float* const* ln_gamma, const float* const* ln_beta,
+                              const float* const* ln_mean, const float* const* ln_rstd, float* workspace, long workspace_floats,
+                              int dtype, void* stream);
 /* nn.LayerNorm statistics (PreNorm, local_3d_attention.py:14): mean[M], rstd[M] over the K axis. */
 int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
                         void* stream);

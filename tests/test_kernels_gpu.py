@@ -175,6 +175,41 @@ def test_linear_gelu_pair_and_small_row_tiles(ops, M, N, K, dtype):
         assert rel(y, torch.nn.functional.gelu(zz.float()) @ w2.float().t()) < tol
 
 
+@pytest.mark.parametrize('M', [3072, 20000, 333])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_batch_with_per_problem_layernorm(ops, M, dtype):
+    """wmz_linear_wgrad_batch_ln (the op-by-op path's weight gradients of a layer as one launch pair: LayerNorm-prologue and
+    plain problems mixed) equals the one-problem launches bit for bit where the slicing of M is the same, and torch in any
+    case; few rows take the unsplit form (every tile one workgroup, added straight into dW, accumulate and overwrite)."""
+    torch.manual_seed(43)
+    shapes = [(512, 512, True), (1536, 512, True), (512, 1024, False), (1024, 512, False), (128, 264, False)]
+    probs, refs, singles = [], [], []
+    for N, K, ln in shapes:
+        dc = (torch.randn(M, N) * 0.3).to(dtype)
+        a = (torch.randn(M, K) * 1.3 + 0.2).to(dtype)
+        g, b = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+        init = torch.randn(N, K)
+        binit = torch.randn(N)
+        an = torch.nn.functional.layer_norm(a.float(), (K,), g, b, 1e-5) if ln else a.float()
+        if ln and dtype == torch.bfloat16:
+            an = an.bfloat16().float()                      # the prologue rounds LN(a) to the operand type
+        over = N == 1024
+        refs.append(((0 if over else init) + dc.float().t() @ an, (0 if over else binit) + dc.float().sum(0)))
+        dcd, ad = dev(dc), dev(a)
+        stats = ops.layernorm_stats(ad, 1e-5) if ln else (None, None)
+        dw, db = dev(init).clone(), dev(binit).clone()
+        probs.append(dict(dc=dcd, ldc=N, a=ad, lda=K, dw=dw, dbias=db, M=M, N=N, K=K, g=dev(g) if ln else None,
+                          b=dev(b) if ln else None, mean=stats[0], rstd=stats[1], overwrite=over))
+        dw1, db1 = dev(init).clone(), dev(binit).clone()
+        ops.linear_wgrad(dcd, ad, dw1, db1, ln=(dev(g), dev(b)) if ln else None, ln_stats=stats if ln else None, overwrite=over)
+        singles.append((dw1, db1))
+    ops.linear_wgrad_batch_ln(probs)
+    tol = 3e-5 if dtype == torch.float32 else 2e-3
+    for q, (rw, rb), (sw, sb) in zip(probs, refs, singles):
+        assert rel(q['dw'], rw) < tol and rel(q['dbias'], rb) < tol
+        assert rel(q['dw'], sw.cpu()) < 1e-5 and rel(q['dbias'], sb.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,S,HW,D,N', [(8, 5, 256, 256, 1024), (3, 4, 20, 32, 50), (2, 1, 77, 64, 130)])
 def test_linear_on_last_frame_blocks(ops, dtype, B, S, HW, D, N):

@@ -32,6 +32,7 @@ SIGNATURES = {
     'wmz_linear_wgrad_ws': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                            + [c_int, c_int, c_void_p, c_long, c_int, c_void_p],
     'wmz_linear_wgrad_batch': [c_int] + [c_void_p] * 12 + [c_long, c_int, c_void_p],
+    'wmz_linear_wgrad_batch_ln': [c_int] + [c_void_p] * 14 + [c_void_p, c_long, c_int, c_void_p],
     'wmz_layernorm_stats': [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_layernorm_bwd': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p,
                           c_void_p, c_int, c_int, c_float, c_int, c_void_p],

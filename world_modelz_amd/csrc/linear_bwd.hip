@@ -52,6 +52,7 @@ struct WgParams {
   int gelu_in;
   int a_tiled;      // A is the fused path's TILED stream (bf16, K = 256): per 32-row tile [16 chunks][2 halves][32 rows][8]
   int nbn, nbk, rows_per_wg, nsplit;
+  int direct;       // nsplit == 1 and nobody else writes the tile: dW (+)= acc straight from the registers (1: +=, 2: =), no workspace
   // PRO == 3: A is the implicit im2col of an NHWC tensor x[B,Hi,Wi,Cin] (row m = output pixel, k = (kh, kw, ci))
   int Hi, Wi, Cin, Ho, Wo, KW, cstride, cpad;
 };
@@ -284,17 +285,23 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restr
           const long aoff = P.a_tiled ? (long)(m >> 5) * (32 * 256) + ((((2 * (cg & 15) + (cg >> 4)) << 5) + (m & 31)) << 3)
                                       : (long)m * P.lda + k0 + c * EPC;
           ra[it] = *reinterpret_cast<const i32x4*>(A + aoff);
-          if constexpr (PRO == 1) { lmu[S][it] = P.mean[m]; lrs[S][it] = P.rstd[m]; }
+          if constexpr (PRO == 1) { if (P.mean != nullptr) { lmu[S][it] = P.mean[m]; lrs[S][it] = P.rstd[m]; } }
         }
       }
     }
   };
   // a thread always lands on the same chunk column (NT is a multiple of CPR): its LayerNorm affine lives in registers
   float gam[EPC], bet[EPC];
+  // (a batch may mix problems with and without the LayerNorm prologue: the PRO == 1 instantiation then runs them all, the
+  //  plain ones -- P.mean == NULL, uniform per workgroup -- skipping the arithmetic)
+  const bool has_ln = PRO == 1 && P.mean != nullptr;
   if constexpr (PRO == 1) {
     const int kc0 = k0 + (tid % CPR) * EPC;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { gam[e] = kc0 + e < P.K ? P.gamma[kc0 + e] : 0.f; bet[e] = kc0 + e < P.K ? P.beta[kc0 + e] : 0.f; }
+    for (int e = 0; e < EPC; ++e) {
+      gam[e] = (has_ln && kc0 + e < P.K) ? P.gamma[kc0 + e] : 0.f;
+      bet[e] = (has_ln && kc0 + e < P.K) ? P.beta[kc0 + e] : 0.f;
+    }
   }
   // the prologue arithmetic runs when the slab goes to LDS, not when it is requested: the loads stay in flight
   auto stash = [&](auto setc, int buf) {
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restr
       const int off = r * ROWB + ((c << 4) ^ wswz<T>(r));
       i32x4 v = ras[S][it];
       if constexpr (PRO == 1 || PRO == 2) {
-        if (k0 + c * EPC < P.K) {
+        if (k0 + c * EPC < P.K && (PRO != 1 || has_ln)) {
           float f[EPC];
           unpack_chunk<T>(v, f);
           if constexpr (PRO == 1) {
@@ -396,12 +403,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restr
         const int n = n0 + wn + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
         if (n < P.N) {
           const long q = (long)n * P.K + kc;
-          ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[i][j][reg];
+          if (P.direct == 0) ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[i][j][reg];
+          else if (P.direct == 1) P.dW[q] += acc[i][j][reg];          // (the tile's only writer)
+          else P.dW[q] = acc[i][j][reg];
         }
       }
     }
   if (P.dbias != nullptr && bk == 0 && tid < WG_BN && n0 + tid < P.N) {
-    ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = bsum;
+    if (P.direct == 0) ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = bsum;
+    else if (P.direct == 1) P.dbias[n0 + tid] += bsum;
+    else P.dbias[n0 + tid] = bsum;
   }
 }
 
@@ -681,7 +692,7 @@ extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long ld
   P.dC = dC; P.ldc = ldc; P.A = A; P.lda = lda; P.dW = dW; P.dbias = dbias; P.M = M; P.N = N; P.K = K;
   P.gamma = ln_gamma; P.beta = ln_beta; P.mean = ln_mean; P.rstd = ln_rstd; P.gelu_in = gelu_in;
   P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
-  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK); P.nsplit = 0;
+  P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK); P.nsplit = 0; P.direct = 0;
   const int tiles = P.nbn * P.nbk;
   constexpr int wg_target = 256;             // ~one workgroup per CU (measured optimum)
   int split = wmz_cdiv(wg_target, tiles);    // ~one workgroup per CU: every extra split is another 64 KB of float atomics
@@ -734,6 +745,7 @@ long wg_batch_add(WgBatch& B, RedBatch& R, int i, const void* dC, long ldc, cons
   P.gamma = g; P.beta = b; P.mean = mean; P.rstd = rstd; P.gelu_in = gelu_in;
   P.Hi = P.Wi = P.Cin = P.Ho = P.Wo = P.KW = P.cstride = P.cpad = 0;
   P.nbn = wmz_cdiv(N, WG_BN); P.nbk = wmz_cdiv(K, WG_BK);
+  P.direct = 0;
   P.nsplit = wgrad_split(M, N, K, dtype == WMZ_BF16 ? 64 : 32, &P.rows_per_wg);
   B.first[i + 1] = B.first[i] + P.nbn * P.nbk * P.nsplit;
   B.wsoff[i] = wsoff;
@@ -754,7 +766,7 @@ int wg_batch_launch(const WgBatch& B, const RedBatch& R, int pro, float* workspa
 #undef WMZ_WG2
   const RedProb& L = R.p[n - 1];
   const int nred = L.first + L.nblk_w + (L.dbias != nullptr ? wmz_cdiv(L.N, 64) : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nred), dim3(1024), 0, st, workspace, R);
+  if (nred > 0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nred), dim3(1024), 0, st, workspace, R);
   return WMZ_OK;
 }
 }  // namespace
@@ -810,6 +822,60 @@ extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* 
   return WMZ_OK;
 }
 
+// The same with an optional LayerNorm prologue PER PROBLEM (tables of n pointers, NULL entries = plain): the four weight
+// gradients of a transformer layer on the op-by-op path -- to_qkv and the feed-forward's first GEMM behind their PreNorm, to_out
+// and the second GEMM plain -- by one launch pair.
+extern "C" int wmz_linear_wgrad_batch_ln(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
+                                         float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
+                                         const int* overwrite, const float* const* ln_gamma, const float* const* ln_beta,
+                                         const float* const* ln_mean, const float* const* ln_rstd, float* workspace,
+                                         long workspace_floats, int dtype, void* stream) {
+  WMZ_REQUIRE(n >= 1 && n <= WG_MAXB, "wmz_linear_wgrad_batch_ln: 1 .. %d problems per call (got %d)", WG_MAXB, n);
+  WMZ_REQUIRE(dC && ldc && A && lda && dW && dbias && M && N && K && overwrite && workspace && ln_gamma && ln_beta && ln_mean && ln_rstd,
+              "wmz_linear_wgrad_batch_ln: null table");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_wgrad_batch_ln: bad dtype %d", dtype);
+  WgBatch B;
+  RedBatch R;
+  B.n = R.n = n;
+  B.first[0] = 0;
+  long off = 0;
+  struct TargetGuard { int saved; ~TargetGuard() { g_wgrad_target = saved; } } guard{g_wgrad_target};
+  g_wgrad_target = n >= 3 ? 96 : (n == 2 ? 128 : 256);
+  bool any_ln = false;
+  int tiles_total = 0;
+  for (int i = 0; i < n; ++i) {
+    WMZ_REQUIRE(dC[i] && A[i] && dW[i] && M[i] > 0 && N[i] > 0 && K[i] > 0, "wmz_linear_wgrad_batch_ln: bad problem %d", i);
+    WMZ_REQUIRE(N[i] % 8 == 0 && K[i] % 8 == 0 && ldc[i] % 8 == 0 && lda[i] % 8 == 0, "wmz_linear_wgrad_batch_ln: problem %d: N, K and row strides must be multiples of 8", i);
+    const bool ln = ln_gamma[i] != nullptr;
+    WMZ_REQUIRE(!ln || (ln_beta[i] && ln_mean[i] && ln_rstd[i]), "wmz_linear_wgrad_batch_ln: problem %d: the LayerNorm prologue needs gamma, beta, mean, rstd", i);
+    any_ln = any_ln || ln;
+    off += wg_batch_add(B, R, i, dC[i], ldc[i], A[i], lda[i], dW[i], dbias[i], M[i], N[i], K[i], ln ? ln_gamma[i] : nullptr,
+                        ln ? ln_beta[i] : nullptr, ln ? ln_mean[i] : nullptr, ln ? ln_rstd[i] : nullptr, 0, overwrite[i], dtype, off, 0);
+    tiles_total += B.p[i].nbn * B.p[i].nbk;
+  }
+  // Few rows (config 5: 3 072 per GPU) and the batch's tiles alone cover half the chip: no slices of M at all -- every tile has
+  // ONE workgroup, which adds its registers straight into dW (no partial tiles written and read back, no reduction launch;
+  // at 2-6 slices the reduction kernel ran at a few hundred GB/s and cost as much as the GEMMs).
+  bool same_m = true;
+  for (int i = 1; i < n; ++i) same_m = same_m && M[i] == M[0];
+  if (same_m && M[0] <= 8192 && tiles_total >= 128) {
+    for (int i = 0; i < n; ++i) {
+      WgParams& P = B.p[i];
+      P.nsplit = 1;
+      P.rows_per_wg = wmz_cdiv(M[i], 64) * 64;
+      P.direct = overwrite[i] ? 2 : 1;
+      B.first[i + 1] = B.first[i] + P.nbn * P.nbk;
+      RedProb& Q = R.p[i];
+      Q.nsplit = 1; Q.nblk_w = 0; Q.dbias = nullptr;
+      Q.first = i == 0 ? 0 : R.p[i - 1].first;
+    }
+  }
+  WMZ_REQUIRE(workspace_floats >= off, "wmz_linear_wgrad_batch_ln: workspace too small (%ld floats needed)", off);
+  wg_batch_launch(B, R, any_ln ? 1 : 0, workspace, dtype, (hipStream_t)stream);
+  WMZ_LAUNCH_CHECK("wmz_linear_wgrad_batch_ln");
+  return WMZ_OK;
+}
+
 extern "C" int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin,
                                      int Cout, int KH, int KW, int stride, int pad, int dtype, void* stream) {
   WMZ_REQUIRE(x && dy && dW, "wmz_conv2d_nhwc_wgrad: null tensor");
@@ -824,7 +890,7 @@ extern "C" int wmz_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dW, f
   P.dC = dy; P.ldc = Cout; P.A = x; P.lda = 0; P.dW = dW; P.dbias = dbias;
   P.M = B * P.Ho * P.Wo; P.N = Cout; P.K = KH * KW * Cin;
   P.gamma = P.beta = P.mean = P.rstd = nullptr; P.gelu_in = 0;
-  P.nbn = wmz_cdiv(P.N, WG_BN); P.nbk = wmz_cdiv(P.K, WG_BK); P.nsplit = 0;
+  P.nbn = wmz_cdiv(P.N, WG_BN); P.nbk = wmz_cdiv(P.K, WG_BK); P.nsplit = 0; P.direct = 0;
   const int tiles = P.nbn * P.nbk;
   int split = wmz_cdiv(256, tiles);
   const int max_split = wmz_cdiv(P.M, 4 * WG_MS);

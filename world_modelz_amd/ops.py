@@ -322,22 +322,71 @@ def side_blocked(block=True):
 # which a node's successors are recorded decides which of them the runtime keeps on the node's own queue -- recorded first,
 # the weight gradient stayed there and the backward's dependency chain hopped to another queue at every fork (a ~10 us
 # cross-queue hand-over each, and the chain's next node queued behind the weight gradient: measured on config 5).
-_deferred = []
+_deferred = []            # launches to issue behind the compute stream's next library call
+_pending = []             # plain / LayerNorm-prologue weight gradients waiting to leave as ONE batched launch pair
 _flushing = False
+WGRAD_BATCH = 6           # problems per wmz_linear_wgrad_batch_ln call (the library's limit)
 
 
-def _flush_deferred():
+def linear_wgrad_batch_ln(problems, side=None):
+    """Up to 6 weight gradients, each with an optional LayerNorm prologue, by one launch pair (wmz_linear_wgrad_batch_ln).
+    problems: dicts with dc, a (2-D views, row strides ldc / lda), dw, dbias | None, M, N, K, g, b, mean, rstd (None = plain),
+    overwrite.  side: the side-stream entry whose workspace to use."""
+    import ctypes
+    n = len(problems)
+    vp, ci, cl = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_long * n
+    pc, pa, pw, pb, pg, pbe, pm, pr = vp(), vp(), vp(), vp(), vp(), vp(), vp(), vp()
+    lc, la, Ms, Ns, Ks, ov = cl(), cl(), ci(), ci(), ci(), ci()
+    need = 0
+    dt = L.dtype_code(problems[0]['dc'].dtype)
+    for i, q in enumerate(problems):
+        assert L.dtype_code(q['dc'].dtype) == dt and q['a'].dtype == q['dc'].dtype and q['dw'].dtype == torch.float32
+        pc[i], pa[i], pw[i], pb[i] = L.ptr(q['dc']), L.ptr(q['a']), L.ptr(q['dw']), L.ptr(q['dbias'])
+        pg[i], pbe[i], pm[i], pr[i] = L.ptr(q['g']), L.ptr(q['b']), L.ptr(q['mean']), L.ptr(q['rstd'])
+        lc[i], la[i], Ms[i], Ns[i], Ks[i], ov[i] = q['ldc'], q['lda'], q['M'], q['N'], q['K'], 1 if q['overwrite'] else 0
+        need += L.lib().wmz_linear_wgrad_workspace_floats(q['M'], q['N'], q['K'], dt)
+    dev = problems[0]['dc'].device
+    ws = _workspace(dev, need) if side is None else _side_workspace(side, dev, need)
+    L.call('wmz_linear_wgrad_batch_ln', n, pc, lc, pa, la, pw, pb, Ms, Ns, Ks, ov, pg, pbe, pm, pr, L.ptr(ws), ws.numel(), dt,
+           L.stream())
+
+
+def _issue_pending():
+    """The queued weight gradients as one launch pair on the side stream (behind the LAST one's fork point: the compute stream
+    is in order, so the earlier operands are complete there too).  At few tokens the captured step is a chain of launches each
+    of which the host has to enqueue (~9 us a graph node on this stack) and the device to start: config 5's 32 weight gradients
+    x 2 launches become 6 launches."""
+    global _pending
+    if not _pending:
+        return
+    batch, _pending = _pending, []
+    ent = batch[0]['ent']
+    ent[0].wait_event(batch[-1]['fork'])
+    with torch.cuda.stream(ent[0]):
+        linear_wgrad_batch_ln(batch, side=ent)
+        for q in batch:
+            if q['then'] is not None:
+                q['then']()
+
+
+def _flush_deferred(force=True):
     global _flushing
-    if _flushing or not _deferred:
+    if _flushing or not (_deferred or _pending):
         return
     _flushing = True
     try:
         while _deferred:
             _deferred.pop(0)()
+        if force or len(_pending) >= WGRAD_BATCH:
+            _issue_pending()
     finally:
         _flushing = False
-        if not _deferred:
+        if not (_deferred or _pending):
             L.after_call = None
+
+
+def _after_call():
+    _flush_deferred(force=False)
 
 
 def _defer(launch):
@@ -345,7 +394,7 @@ def _defer(launch):
         launch()
         return
     _deferred.append(launch)
-    L.after_call = _flush_deferred
+    L.after_call = _after_call
 
 
 def wgrad_join():
@@ -424,6 +473,14 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
             then()
         return
     ent, fork = side
+    if not gelu_in:
+        # batchable: queued (the queue keeps the operands alive), issued when WGRAD_BATCH problems wait or at the join
+        if _pending and (_pending[0]['dt'] != dt or _pending[0]['ent'] is not ent or len(_pending) >= WGRAD_BATCH):
+            _flush_deferred()
+        _pending.append(dict(dc=dc, ldc=ldc, a=a, lda=lda, dw=dw, dbias=dbias, M=M, N=N, K=K, g=g, b=b, mean=mean, rstd=rstd,
+                             overwrite=overwrite, need=need, dt=dt, ent=ent, fork=fork, then=then))
+        L.after_call = _after_call
+        return
 
     def launch():                       # (the closure keeps the operands alive until the launch has been issued)
         ent[0].wait_event(fork)
