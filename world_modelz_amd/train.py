@@ -406,12 +406,16 @@ class _TrainerBase(_AdamState):
         assert self.acc_steps == 1, 'the graphed step is one micro-batch per optimizer step'
         dev = self.arena.flat_param.device
         self._g_z = example_batch.contiguous().clone()
-        self._g_r = torch.zeros(example_batch.shape[0], dtype=torch.float32, device=dev)
+        # the step's host-written scalars live in ONE device buffer fed from ONE pinned host buffer: noise levels | lr, bias corrections
+        nb = example_batch.shape[0]
+        self._g_in = torch.zeros(nb + 3, dtype=torch.float32, device=dev)
+        self._g_in_host = torch.zeros(nb + 3, dtype=torch.float32).pin_memory()
+        self._g_r = self._g_in[:nb]
         # the per-call part of the corruption's Philox stream id: graph replays count on the device, eager calls on the host
         # (_corrupt_calls).  Bit 39 keeps the two ranges apart, so a run that mixes replays with eager fallbacks (another batch
         # shape) or with corrupt_tokens never draws one stream twice.
         self._g_ctr = torch.full((1,), 1 << 39, dtype=torch.int64, device=dev)
-        self._g_hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._g_hyper = self._g_in[nb:]
         self._g_seed = torch.initial_seed()
         snap = None if keep_warmup_updates else (self.arena.flat_param.clone(), self.m.clone(), self.v.clone(), self.step_count,
                                                  self.sampler_gen.get_state(),
@@ -453,12 +457,20 @@ class _TrainerBase(_AdamState):
         if r is None:
             r = self.sampler.sample(B, generator=self.sampler_gen)
         self._g_r_host = r
-        self._g_r.copy_(r.to(torch.float32), non_blocking=True)
         self.step_count += 1
         lr = lr_at(self.step_count, self.lr, self.warmup, self.max_steps)
         bc1 = 1.0 - self.betas[0] ** self.step_count
         bc2 = 1.0 - self.betas[1] ** self.step_count
-        self._g_hyper.copy_(torch.tensor([lr, bc1, math.sqrt(bc2)], dtype=torch.float32), non_blocking=True)
+        h = self._g_in_host
+        ev = getattr(self, '_g_in_ev', None)
+        if ev is not None:
+            ev.synchronize()               # the last copy out of the pinned buffer is done (a no-op behind a step's read-back)
+        h[:B] = r.to(torch.float32)
+        h[B], h[B + 1], h[B + 2] = lr, bc1, math.sqrt(bc2)
+        self._g_in.copy_(h, non_blocking=True)
+        if ev is None:
+            ev = self._g_in_ev = torch.cuda.Event()
+        ev.record()
 
     def _graph_body(self):
         a = self.arena
@@ -478,7 +490,7 @@ class _TrainerBase(_AdamState):
         L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, float(scale), L.ptr(self.sq), st)   # + grad norm
         self._ema_update()
-        return per_sample, mean, self.sq
+        return torch.cat([mean.reshape(1), self.sq.reshape(1), per_sample.reshape(-1)])     # the step's one read-back, packed in the graph
 
 
     def _replay(self, batch_z, r):
@@ -490,8 +502,7 @@ class _TrainerBase(_AdamState):
         self._set_step_inputs(r)
         self._graph.replay()
         _cast.invalidate()             # the replay rewrote the weights: eager consumers rebuild their operand copies
-        per_sample, mean, sq = self._g_out
-        out = torch.cat([mean.reshape(1), sq.reshape(1), per_sample]).cpu()     # the step's one host sync
+        out = self._g_out.cpu()                                                  # the step's one host sync
         self.sampler.update_with_losses(self._g_r_host, out[2:])
         return float(out[0]), math.sqrt(float(out[1]))
 
