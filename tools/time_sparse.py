@@ -19,3 +19,24 @@ for mode in ('eager', 'graph'):
     for _ in range(20): st.train_step(zs, r=rs)
     torch.cuda.synchronize()
     print(f'config 5 {mode}: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/step  (wgrad side stream {config.get_wgrad_stream()})', flush=True)
+
+# where a replayed step's wall time goes: device time between two events around the replay vs the wall period
+g = st._graph
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+orig = g.replay
+acc = {'dev': 0.0, 'launch': 0.0, 'n': 0}
+def replay():
+    ev0.record()
+    t = time.perf_counter()
+    orig()
+    acc['launch'] += time.perf_counter() - t
+    ev1.record()
+g.replay = replay
+import types
+t0 = time.perf_counter()
+for _ in range(20):
+    st.train_step(zs, r=rs)
+    acc['dev'] += ev0.elapsed_time(ev1); acc['n'] += 1
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / 20 * 1e3
+print(f'config 5 replay: wall {wall:.2f} ms/step, device time inside the replay {acc["dev"] / acc["n"]:.2f} ms, host time inside hipGraphLaunch {acc["launch"] / acc["n"] * 1e3:.2f} ms', flush=True)

@@ -676,6 +676,41 @@ __global__ __launch_bounds__(1024 / KG) void ln_bwd_kernel(const T* __restrict__
   }
 }
 
+// The same sums for FEW slices (<= 8) of plain [N, K] gradients: one WAVE per 256-float block (all of its slices' loads in
+// flight at once), four blocks per workgroup -- the 16-wave form above spends a 1024-thread workgroup on two or three KB here.
+// Same summation order (slice 0, 1, ..): the same bits.
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ ws_base, RedBatch B, int nred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = (int)blockIdx.x * 4 + wave;
+  if (g >= nred) return;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXB; ++i) if (i < B.n && g >= B.p[i].first) pi = i;
+  const RedProb R = B.p[pi];
+  const float* __restrict__ ws = ws_base + R.wsoff;
+  const int nsplit = R.nsplit, blk = g - R.first;
+  if (blk < R.nblk_w) {
+    const long q = ((long)blk * 64 + lane) * 4;
+    if (q >= R.NK) return;
+    const float* base = ws + ((long)blk * nsplit << 8) + lane * 4;
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = u < nsplit ? *reinterpret_cast<const f32x4*>(base + ((long)u << 8)) : (f32x4)(0.f);
+    f32x4 t = v[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) if (u < nsplit) t += v[u];
+    f32x4* d = reinterpret_cast<f32x4*>(R.dW + q);
+    *d = R.overwrite ? t : *d + t;
+  } else if (R.dbias != nullptr) {
+    const long n = ((long)blk - R.nblk_w) * 64 + lane;
+    if (n >= R.N) return;
+    const float* wb = ws + ((long)R.nblk_w * nsplit << 8);
+    float t = 0.f;
+    for (int u = 0; u < nsplit; ++u) t += wb[(long)u * R.N + n];
+    R.dbias[n] = R.overwrite ? t : R.dbias[n] + t;
+  }
+}
+
 }  // namespace
 
 extern "C" int wmz_linear_wgrad(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N,
@@ -766,7 +801,10 @@ int wg_batch_launch(const WgBatch& B, const RedBatch& R, int pro, float* workspa
 #undef WMZ_WG2
   const RedProb& L = R.p[n - 1];
   const int nred = L.first + L.nblk_w + (L.dbias != nullptr ? wmz_cdiv(L.N, 64) : 0);
-  if (nred > 0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nred), dim3(1024), 0, st, workspace, R);
+  bool small = true;
+  for (int i = 0; i < n; ++i) small = small && R.p[i].nsplit <= 8 && R.p[i].taps == 0;
+  if (nred > 0 && small) hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)wmz_cdiv(nred, 4)), dim3(256), 0, st, workspace, R, nred);
+  else if (nred > 0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nred), dim3(1024), 0, st, workspace, R);
   return WMZ_OK;
 }
 }  // namespace
@@ -859,16 +897,27 @@ extern "C" int wmz_linear_wgrad_batch_ln(int n, const void* const* dC, const lon
   bool same_m = true;
   for (int i = 1; i < n; ++i) same_m = same_m && M[i] == M[0];
   if (same_m && M[0] <= 8192 && tiles_total >= 128) {
+    // (1 .. 4 slices measured the same step time at config 5, 3.05-3.16 ms: the launches sit on a side branch of the graph)
+    int split = wmz_cdiv(256, tiles_total);
+    const int ms = dtype == WMZ_BF16 ? 64 : 32;
+    const int max_split = M[0] / 1024 > 0 ? M[0] / 1024 : 1;
+    if (split > max_split) split = max_split;
+    if (split > 8) split = 8;
+    off = 0;
     for (int i = 0; i < n; ++i) {
       WgParams& P = B.p[i];
-      P.nsplit = 1;
-      P.rows_per_wg = wmz_cdiv(M[i], 64) * 64;
-      P.direct = overwrite[i] ? 2 : 1;
-      B.first[i + 1] = B.first[i] + P.nbn * P.nbk;
+      P.rows_per_wg = wmz_cdiv(wmz_cdiv(M[i], split), ms) * ms;
+      P.nsplit = wmz_cdiv(M[i], P.rows_per_wg);
+      P.direct = P.nsplit == 1 ? (overwrite[i] ? 2 : 1) : 0;
+      B.first[i + 1] = B.first[i] + P.nbn * P.nbk * P.nsplit;
+      B.wsoff[i] = off;
       RedProb& Q = R.p[i];
-      Q.nsplit = 1; Q.nblk_w = 0; Q.dbias = nullptr;
-      Q.first = i == 0 ? 0 : R.p[i - 1].first;
+      Q.nsplit = P.nsplit; Q.wsoff = off;
+      if (P.direct) { Q.nblk_w = 0; Q.dbias = nullptr; }
+      Q.first = i == 0 ? 0 : R.p[i - 1].first + R.p[i - 1].nblk_w + (R.p[i - 1].dbias != nullptr ? wmz_cdiv(R.p[i - 1].N, 64) : 0);
+      off += (long)P.nsplit * ((((long)N[i] * K[i] + 255) >> 8) * 256 + N[i]);
     }
+    WMZ_REQUIRE(workspace_floats >= off, "wmz_linear_wgrad_batch_ln: workspace too small (%ld floats needed)", off);
   }
   WMZ_REQUIRE(workspace_floats >= off, "wmz_linear_wgrad_batch_ln: workspace too small (%ld floats needed)", off);
   wg_batch_launch(B, R, any_ln ? 1 : 0, workspace, dtype, (hipStream_t)stream);
