@@ -496,11 +496,32 @@ def main():
                         prun(pz)
                     torch.cuda.synchronize()
                     pel = (time.perf_counter() - p0) / 10
-                pub.append({'dim': dim_, 'mlp_dim': mlp_, 'depth': depth_, 'extents': [3, 1, 1], 'ms_per_step': pel * 1e3,
-                            'value': cfg['B'] * cfg['S'] / pel, 'unit': 'latent-frames/s',
-                            'params': sum(p.numel() for p in m3.parameters())})
+                entry = {'dim': dim_, 'mlp_dim': mlp_, 'depth': depth_, 'extents': [3, 1, 1], 'ms_per_step': pel * 1e3,
+                         'value': cfg['B'] * cfg['S'] / pel, 'unit': 'latent-frames/s',
+                         'params': sum(p.numel() for p in m3.parameters())}
                 log(f'published widths dim {dim_} depth {depth_}: {pel * 1e3:.3f} ms/step')
-                del prun, m3
+                del prun
+                if a.train_steps > 0 and world == 1:
+                    # ... and their TRAINING step (the reference's published runs are training runs): op-by-op GEMM path -- no
+                    # fused per-token kernels at these widths --, one hipGraph per step
+                    from world_modelz_amd.train import DenoiserTrainer as _PT
+                    m3.train()
+                    ptr = _PT(m3, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=False)
+                    ptr.enable_graph(z)
+                    pr = torch.full((cfg['B'],), 0.5)
+                    for _ in range(2):
+                        ptr.train_step(z, r=pr)
+                    torch.cuda.synchronize()
+                    p0 = time.perf_counter()
+                    for _ in range(5):
+                        ptr.train_step(z, r=pr)
+                    torch.cuda.synchronize()
+                    entry['train_ms_per_step'] = (time.perf_counter() - p0) / 5 * 1e3
+                    entry['train_launch_mode'] = 'hipGraph (op-by-op path: GEMM launches per layer, weight gradients batched on a side branch)'
+                    log(f'published widths dim {dim_} depth {depth_}: training step {entry["train_ms_per_step"]:.2f} ms')
+                    del ptr
+                pub.append(entry)
+                del m3
                 gc.collect()
         out['published_run_widths'] = pub
         # ---- secondary figure: the sampler loop (main.py:50-117): one denoise iteration = draw + re-mask + forward
