@@ -677,14 +677,30 @@ def conv2d_nhwc_wgrad(x, dy, KH, KW, stride, pad, want_bias, into=None):
     Cout = dy.shape[-1]
     assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
     dt = L.dtype_code(x.dtype)
-    ws = _workspace(x.device, L.lib().wmz_conv2d_nhwc_wgrad_workspace_floats(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dt))
+    need = L.lib().wmz_conv2d_nhwc_wgrad_workspace_floats(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dt)
     if into is not None:
         gw, gb = into
         co, ci = gw.shape[:2]
         assert gw.is_contiguous() and gw.dtype == torch.float32 and gw.shape[2:] == (KH, KW) and co <= Cout and ci <= Cin
+        # arena-bound (VqaeTrainer): under capture a side branch of the graph, like the linear weight gradients
+        with arena_fill():
+            side = _wgrad_side_enter(x.device, (x, dy))
+        if side is not None:
+            ent, fork = side
+
+            def launch():
+                ent[0].wait_event(fork)
+                with torch.cuda.stream(ent[0]):
+                    wss = _side_workspace(ent, x.device, need)
+                    L.call('wmz_conv2d_nhwc_wgrad_ws', L.ptr(x), L.ptr(dy), L.ptr(gw), L.ptr(gb), B, Hi, Wi, Cin, Cout, KH, KW, stride,
+                           pad, 0, co, ci, L.ptr(wss), wss.numel(), dt, L.stream())
+            _defer(launch)
+            return None, None
+        ws = _workspace(x.device, need)
         L.call('wmz_conv2d_nhwc_wgrad_ws', L.ptr(x), L.ptr(dy), L.ptr(gw), L.ptr(gb), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 0,
                co, ci, L.ptr(ws), ws.numel(), dt, L.stream())
         return None, None
+    ws = _workspace(x.device, need)
     dw = torch.empty((Cout, KH * KW * Cin), dtype=torch.float32, device=x.device)        # stored, not accumulated: no zero fill
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     L.call('wmz_conv2d_nhwc_wgrad_ws', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 1,

@@ -711,6 +711,7 @@ class VqaeTrainer(_AdamState):
         a.flat_grad.zero_()
         _cast.invalidate()                 # (the conv / codebook operand copies are rebuilt from the weights inside the graph)
         out = self._forward_backward(self._g_x)
+        ops.wgrad_join()                   # (the conv weight gradients' side branch; already joined when the autograd pass ended)
         self._g_sq.zero_()
         L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, L.ptr(self._g_sq), L.stream())
