@@ -284,6 +284,12 @@ int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const flo
 #define WMZ_OPERAND_F32 2
 int wmz_operands_refresh(const void* const* src0, const void* const* src1, const int* rows0, const int* rows1,
                          const int* cols, void* const* dst, const int* flags, int n, void* stream);
+/* The conv encoder / decoder's GEMM operands from nn.Conv2d's fp32 weights [Co, Ci, KH, KW] (kk = KH*KW), every layer in one
+ * launch (n <= 48 entries): mode 0 = the forward / weight-gradient layout [Co, kk * Ci8] (tap-major, channels fastest,
+ * zero-padded to a multiple of 8), mode 1 = the data-gradient layout [Ci8, kk * Co8] with the taps flipped
+ * (autoencoder.py:_w_op / _wT_op); dst in `dtype`. */
+int wmz_conv_operands_refresh(const void* const* weight, void* const* dst, const int* co, const int* ci, const int* kk,
+                              const int* mode, int n, int dtype, void* stream);
 
 /* Builds the packed weight stream and the vector block of wmz_layer_fused_fwd* from the layer's fp32 parameters in one
  * launch (the LayerNorm affines g2/be2 -- the feed-forward's norm -- and g1/be1 -- the NEXT layer's attention norm -- are

@@ -408,3 +408,27 @@ def test_training_elementwise_kernels_vector_and_scalar_forms(wmz, C, dtype):
     (torch.nn.functional.interpolate(xin, scale_factor=2, mode='bilinear', align_corners=False)
      * dup.float().permute(0, 3, 1, 2)).sum().backward()
     assert rel(ops.bilinear2x_nhwc_bwd(dup).permute(0, 3, 1, 2), xin.grad) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_operands_bulk_refresh_equals_the_tensor_op_builds(wmz, dtype):
+    """_cast.ConvOperands (wmz_conv_operands_refresh: every conv layer's forward and data-gradient GEMM operands by one launch)
+    == autoencoder._w_op / _wT_op's permute / pad / flip / cast builds, bit for bit, incl. channel counts that are not multiples
+    of 8 (the RGB input, an odd width) and 1x1 / 3x3 / 4x4 taps; afterwards the cache serves them without a rebuild."""
+    from world_modelz_amd import _cast, autoencoder
+    torch.manual_seed(3)
+    convs = [torch.nn.Conv2d(3, 32, 4, 2, 1), torch.nn.Conv2d(32, 20, 3, 1, 1), torch.nn.Conv2d(20, 64, 1), torch.nn.Conv2d(64, 3, 3, 1, 1)]
+    convs = [c.cuda() for c in convs]
+    _cast.clear()
+    ref = [(autoencoder._w_op(c, dtype).clone(), autoencoder._wT_op(c.weight, dtype).clone()) for c in convs]
+    _cast.clear()
+    bulk = _cast.ConvOperands(convs, dtype)
+    bulk.refresh()
+    for c, (rw, rt) in zip(convs, ref):
+        w, t = autoencoder._w_op(c, dtype), autoencoder._wT_op(c.weight, dtype)
+        assert any(w.data_ptr() == e[3].data_ptr() for e in bulk.entries)          # served from the bulk buffers (a cache hit)
+        assert w.shape == rw.shape and t.shape == rt.shape and torch.equal(w, rw) and torch.equal(t, rt)
+    with torch.no_grad():
+        convs[1].weight.mul_(2.0)                                                # a new version: the stale entry must not be served
+    assert torch.equal(autoencoder._w_op(convs[1], dtype), (ref[1][0].float() * 2).to(dtype))

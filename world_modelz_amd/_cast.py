@@ -102,3 +102,37 @@ class BulkOperands:
         for params, dtype, tag, tr, zf, dst in self.entries:
             ver = (_epoch,) + tuple((p._version, p.data_ptr()) for p in params)
             _cache[_key(params, dtype, tag)] = (ver, dst, tuple(weakref.ref(p) for p in params))
+
+
+class ConvOperands:
+    """The conv encoder / decoder's GEMM operands (autoencoder.py: tags 'conv' and 'convT'), rebuilt together by ONE launch of
+    wmz_conv_operands_refresh after every optimizer step; refresh() stamps the cache entries valid for the current weights, so
+    the forward / backward's operand() calls hit (built with tensor ops: permute, pad, flip, cast -- ~6 launches per layer)."""
+
+    def __init__(self, convs, dtype):
+        self.dtype = dtype
+        self.entries = []          # (weight, tag, mode, dst)
+        for conv in convs:
+            w = conv.weight
+            co, ci, kh, kw = w.shape
+            ci8, co8 = (ci + 7) // 8 * 8, (co + 7) // 8 * 8
+            self.entries.append((w, 'conv', 0, torch.empty((co, kh * kw * ci8), dtype=dtype, device=w.device)))
+            self.entries.append((w, 'convT', 1, torch.empty((ci8, kh * kw * co8), dtype=dtype, device=w.device)))
+
+    def refresh(self):
+        import ctypes
+        from . import _lib as L
+        for i0 in range(0, len(self.entries), 48):
+            ent = self.entries[i0:i0 + 48]
+            n = len(ent)
+            vp, ci_ = ctypes.c_void_p * n, ctypes.c_int * n
+            ws, ds, cos, cis, kks, ms = vp(), vp(), ci_(), ci_(), ci_(), ci_()
+            for i, (w, tag, mode, dst) in enumerate(ent):
+                wd = w.detach()
+                assert wd.dtype == torch.float32 and wd.is_contiguous()
+                ws[i], ds[i] = wd.data_ptr(), dst.data_ptr()
+                cos[i], cis[i], kks[i], ms[i] = w.shape[0], w.shape[1], w.shape[2] * w.shape[3], mode
+            L.call('wmz_conv_operands_refresh', ws, ds, cos, cis, kks, ms, n, L.dtype_code(self.dtype), L.stream())
+        for w, tag, mode, dst in self.entries:
+            ver = (_epoch, (w._version, w.data_ptr()))
+            _cache[_key((w,), self.dtype, tag)] = (ver, dst, (weakref.ref(w),))

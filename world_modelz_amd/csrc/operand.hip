@@ -54,7 +54,63 @@ __global__ __launch_bounds__(256) void operands_refresh_kernel(OpTable T) {
   }
 }
 
+// The conv encoder / decoder's GEMM operands (autoencoder.py:_w_op / _wT_op), every layer in ONE launch:
+//   mode 0  forward / weight-gradient layout  [Co, KH*KW*Ci8]: element (co, tap, c) = w[co, c, tap]          (c >= Ci: 0)
+//   mode 1  data-gradient layout              [Ci8, KH*KW*Co8]: element (ci, tap', co) = w[co, ci, KK-1-tap'] (taps flipped)
+// from nn.Conv2d's fp32 weight [Co, Ci, KH, KW].  Built with tensor ops these were ~6 launches per convolution and step.
+struct ConvOpDesc { const float* w; void* dst; int co, ci, kk, mode, f32; long start, count; };
+struct ConvOpTable { ConvOpDesc d[48]; int n; long total; };
+
+__global__ __launch_bounds__(256) void conv_operands_refresh_kernel(ConvOpTable T) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < T.total; i += (long)gridDim.x * 256) {
+    int lo = 0, hi = T.n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (T.d[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const ConvOpDesc D = T.d[lo];
+    const long e = i - D.start;
+    const int ci8 = (D.ci + 7) & ~7, co8 = (D.co + 7) & ~7;
+    float v = 0.f;
+    if (D.mode == 0) {
+      const int rowlen = D.kk * ci8;
+      const int n = (int)(e / rowlen), rem = (int)(e - (long)n * rowlen);
+      const int tap = rem / ci8, c = rem - tap * ci8;
+      if (c < D.ci) v = D.w[((long)n * D.ci + c) * D.kk + tap];
+    } else {
+      const int rowlen = D.kk * co8;
+      const int r = (int)(e / rowlen), rem = (int)(e - (long)r * rowlen);
+      const int tap = rem / co8, co = rem - tap * co8;
+      if (r < D.ci && co < D.co) v = D.w[((long)co * D.ci + r) * D.kk + (D.kk - 1 - tap)];
+    }
+    if (D.f32) reinterpret_cast<float*>(D.dst)[e] = v; else reinterpret_cast<bf16_t*>(D.dst)[e] = __float2bfloat16(v);
+  }
+}
+
 }  // namespace
+
+extern "C" int wmz_conv_operands_refresh(const void* const* weight, void* const* dst, const int* co, const int* ci, const int* kk,
+                                         const int* mode, int n, int dtype, void* stream) {
+  WMZ_REQUIRE(n >= 0 && n <= 48, "wmz_conv_operands_refresh: at most 48 operands per call (got %d)", n);
+  if (n == 0) return WMZ_OK;
+  WMZ_REQUIRE(weight && dst && co && ci && kk && mode, "wmz_conv_operands_refresh: null table");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_conv_operands_refresh: bad dtype %d", dtype);
+  ConvOpTable T;
+  long off = 0;
+  for (int i = 0; i < n; ++i) {
+    WMZ_REQUIRE(weight[i] && dst[i] && co[i] > 0 && ci[i] > 0 && kk[i] > 0 && (mode[i] == 0 || mode[i] == 1), "wmz_conv_operands_refresh: bad entry %d", i);
+    const int ci8 = (ci[i] + 7) & ~7, co8 = (co[i] + 7) & ~7;
+    T.d[i].w = (const float*)weight[i]; T.d[i].dst = dst[i]; T.d[i].co = co[i]; T.d[i].ci = ci[i]; T.d[i].kk = kk[i];
+    T.d[i].mode = mode[i]; T.d[i].f32 = dtype == WMZ_F32; T.d[i].start = off;
+    T.d[i].count = mode[i] == 0 ? (long)co[i] * kk[i] * ci8 : (long)ci8 * kk[i] * co8;
+    off += T.d[i].count;
+  }
+  T.n = n; T.total = off;
+  const long blocks = (off + 255) / 256;
+  hipLaunchKernelGGL(conv_operands_refresh_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, T);
+  WMZ_LAUNCH_CHECK("wmz_conv_operands_refresh");
+  return WMZ_OK;
+}
 
 extern "C" int wmz_operands_refresh(const void* const* src0, const void* const* src1, const int* rows0, const int* rows1,
                                     const int* cols, void* const* dst, const int* flags, int n, void* stream) {

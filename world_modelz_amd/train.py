@@ -652,6 +652,16 @@ class VqaeTrainer(_AdamState):
             broadcast_parameters(self.arena)
             model.vq.sync_stats = True
         self.reused = 0
+        self._conv_ops = {}            # compute dtype -> _cast.ConvOperands (every conv layer's GEMM operands, one launch a step)
+
+    def _refresh_conv_operands(self):
+        from . import config
+        dt = config.get_compute_dtype()
+        co = self._conv_ops.get(dt)
+        if co is None:
+            convs = [m for m in self.model.modules() if isinstance(m, torch.nn.Conv2d)]
+            co = self._conv_ops[dt] = _cast.ConvOperands(convs, dt)
+        co.refresh()
 
     def _current_lr(self):
         return self.lr_now()
@@ -710,6 +720,7 @@ class VqaeTrainer(_AdamState):
         a = self.arena
         a.flat_grad.zero_()
         _cast.invalidate()                 # (the conv / codebook operand copies are rebuilt from the weights inside the graph)
+        self._refresh_conv_operands()
         out = self._forward_backward(self._g_x)
         ops.wgrad_join()                   # (the conv weight gradients' side branch; already joined when the autograd pass ended)
         self._g_sq.zero_()
@@ -736,6 +747,7 @@ class VqaeTrainer(_AdamState):
             self._after_step()
             return tuple(float(v) for v in vals)
         self.arena.zero_grad()
+        self._refresh_conv_operands()
         out = self._forward_backward(batch)
         scale = self.reducer.finish() if self.reducer is not None else 1.0
         lr = self.lr_now()
