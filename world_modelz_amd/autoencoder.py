@@ -158,12 +158,24 @@ class _BnActFn(torch.autograd.Function):
         scale, shift, mean, rstd = ops.bn_finalize(bn, s, q, _count(x), want_stats=True)
         y = ops.affine_act_nhwc(x, scale, shift, b=r, leaky=leaky, slope=LEAKY)
         ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.beta = beta
         ctx.leaky, ctx.has_r = leaky, r is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, rstd, gamma = ctx.saved_tensors
+        beta = ctx.beta
+        gg, gb = getattr(gamma, '_wmz_grad', None), getattr(beta, '_wmz_grad', None)
+        if gg is not None and gb is not None and getattr(gamma, '_wmz_single_use', False):
+            # VqaeTrainer's arena: zeroed at the start of the step, this layer its slots' only writer -- the reduction's
+            # atomics land there (28 zero fills and 28 `grad += g` launches fewer per step)
+            dx, _, _, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, into=(gg, gb))
+            for prm in (gamma, beta):
+                ready = getattr(prm, '_wmz_ready', None)
+                if ready is not None:
+                    ready()
+            return dx, None, None, (g if ctx.has_r else None), None, None
         dx, dgamma, dbeta, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY)
         return dx, dgamma, dbeta, (g if ctx.has_r else None), None, None
 

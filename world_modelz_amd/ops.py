@@ -708,14 +708,20 @@ def conv2d_nhwc_wgrad(x, dy, KH, KW, stride, pad, want_bias, into=None):
     return dw, db
 
 
-def bn_act_bwd(x, y, dy, mean, rstd, gamma, leaky, slope=0.01):
-    """Training-mode BatchNorm (+ LeakyReLU) backward -> (dx, dgamma, dbeta, g) ; g = dy * act'(y)."""
+def bn_act_bwd(x, y, dy, mean, rstd, gamma, leaky, slope=0.01, into=None):
+    """Training-mode BatchNorm (+ LeakyReLU) backward -> (dx, dgamma, dbeta, g) ; g = dy * act'(y).
+    into = (dgamma, dbeta): fp32 [C] buffers that are ZERO on entry and receive the two column sums in place (the parameters'
+    slots of a freshly zeroed gradient arena, each written once per step: no zero fills here, no `grad += g` afterwards)."""
     C = dy.shape[-1]
     M = dy.numel() // C
     dy = dy.contiguous()
     g = torch.empty_like(dy)
-    sg = torch.zeros(C, dtype=torch.float32, device=dy.device)
-    sgx = torch.zeros(C, dtype=torch.float32, device=dy.device)
+    if into is not None:
+        sgx, sg = into
+        assert sg.dtype == torch.float32 and sgx.dtype == torch.float32 and sg.numel() == C and sgx.numel() == C
+    else:
+        sg = torch.zeros(C, dtype=torch.float32, device=dy.device)
+        sgx = torch.zeros(C, dtype=torch.float32, device=dy.device)
     L.call('wmz_bn_act_bwd_reduce', L.ptr(x), L.ptr(y), L.ptr(dy), L.ptr(mean), L.ptr(rstd), L.ptr(g), L.ptr(sg),
            L.ptr(sgx), M, C, 1 if leaky else 0, float(slope), L.dtype_code(dy.dtype), L.stream())
     dx = torch.empty_like(dy)

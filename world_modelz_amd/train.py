@@ -652,6 +652,11 @@ class VqaeTrainer(_AdamState):
             broadcast_parameters(self.arena)
             model.vq.sync_stats = True
         self.reused = 0
+        # (this trainer zeroes the arena every step and runs one backward per step: BatchNorm's column sums may land straight
+        #  in the parameters' gradient slots, autoencoder._BnActFn.backward)
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d) and mod.weight is not None:
+                mod.weight._wmz_single_use = True
         self._conv_ops = {}            # compute dtype -> _cast.ConvOperands (every conv layer's GEMM operands, one launch a step)
 
     def _refresh_conv_operands(self):
