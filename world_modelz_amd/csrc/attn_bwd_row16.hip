@@ -413,7 +413,10 @@ template <int DH>
 int launch_both(const RBwdPtrs& PQ, const RBwdPtrs& PK, const AttnGeom& G, hipStream_t st) {
   int rc = launch_one<DH, 0, 16>(PQ, G, st);
   if (rc != WMZ_OK) return rc;
-  return launch_one<DH, 1, 8>(PK, G, st);
+#ifndef WMZ_ABWD_NWK
+#define WMZ_ABWD_NWK 8      // waves (= owner key rows) per workgroup of the dk | dv pass; 16 (a whole plane, 128 registers per wave)
+#endif                      // is a timing experiment of tools/build_variant.py
+  return launch_one<DH, 1, WMZ_ABWD_NWK>(PK, G, st);
 }
 
 }  // namespace
