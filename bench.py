@@ -343,8 +343,10 @@ def main():
                     roof['mfma_busy_stale'] = f'kernel source changed since {ipath} was measured'
     except (OSError, KeyError, ValueError):
         pass
-    # `roofline` = the kernel with the larger share of the step
-    dominant_fused = fused_roof is not None and fused_ms * (cfg['depth'] - 1) > attn_ms * cfg['depth']
+    # `roofline` = the kernel with the larger share of the step.  The per-token kernel runs depth + 1 times per step: depth - 1
+    # head + tail launches (the one timed here), the embedding + tail launch and the last layer's head-only launch, which take
+    # ~0.6 and ~0.7 of a head + tail launch (profiles/r03/headline_by_grid.csv: 30 and 36 us beside 48-52); attention: depth times.
+    dominant_fused = fused_roof is not None and fused_ms * (cfg['depth'] - 1 + 1.3) > attn_ms * cfg['depth']
     out = {
         'metric': 'denoise-step latent-frames/sec (forward, 32x16x16 latent clips)',
         'value': frames / elapsed, 'unit': 'latent-frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
