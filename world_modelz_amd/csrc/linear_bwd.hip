@@ -416,6 +416,150 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restr
   }
 }
 
+// ---- wgrad, version 3 (bf16, plain operands): a 256 x 256 output tile per 8-wave workgroup, each wave 64 (n) x 128 (k').
+// Version 2 runs at 13 % of the MFMA rate at config 4 for two reasons this tile removes: (i) a 64 x 64 wave tile reads one
+// 1 KB LDS fragment per MFMA and waits for it -- the chain read -> wait -> MFMA bounds a wave, and at two waves per SIMD there
+// is nobody to fill the gaps; with 64 x 128 wave tiles six fragments feed eight MFMAs; (ii) every operand row is re-read from
+// L2 once per 128-wide output tile in the other dimension (536 MB per layer's launch against 300 MB of operands); at the
+// default widths (N, K <= 256) a problem is ONE tile and each operand element enters the CU exactly once.
+// Slabs of 64 rows in a double-buffered LDS image (128 KB), ONE register set in flight (the accumulators take 128 registers);
+// the partial tiles go through the same workspace layout and reduction kernel as version 2's.
+constexpr int W3_NT = 512, W3_T = 256, W3_MS = 64, W3_ROWB = W3_T * 2, W3_IMG = W3_MS * W3_ROWB;   // 32 KB per operand image
+
+// transposed 32x32x16 operand from a 512-byte-row image: element j = img[m0 + 8*(lane>>5) + j][c0 + (lane&31)]
+__device__ __forceinline__ void w3_col_frag(Frag8<bf16_t>& f, const char* img, int m0, int c0, int lane) {
+  const int gi = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int ra = m0 + 8 * (gi >> 1) + q, rb = ra + 4;
+  const int cb = (c0 + 16 * (gi & 1) + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + ra * W3_ROWB + (cb ^ ((ra & 3) << 6))));
+  const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rb * W3_ROWB + (cb ^ ((rb & 3) << 6))));
+  f.v = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(W3_NT, 1) void wgrad3_kernel(WgBatch B, float* __restrict__ ws_base) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXB; ++i) if (i < B.n && (int)blockIdx.x >= B.first[i]) pi = i;
+  const WgParams P = B.p[pi];
+  float* __restrict__ ws = ws_base + B.wsoff[pi];
+  const int wg0 = B.first[pi], nwg = B.first[pi + 1] - B.first[pi];
+  __shared__ __attribute__((aligned(16))) char w3_smem[4 * W3_IMG];     // [buffer][dC image | A image]: 4 x 32 KB
+  constexpr int CPR = W3_ROWB / 16;                                     // 32 chunks of 8 elements per image row
+  constexpr int PER_T = W3_MS * CPR / W3_NT;                            // 4 chunks per thread and image
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = xcd_remap((int)blockIdx.x - wg0, nwg);
+  const int bk = bid % P.nbk; bid /= P.nbk;
+  const int bn = bid % P.nbn; bid /= P.nbn;
+  const int split = bid;
+  const int n0 = bn * W3_T, k0 = bk * W3_T;
+  const int m_begin = split * P.rows_per_wg, m_end = min(P.M, m_begin + P.rows_per_wg);
+  const bf16_t* dC = reinterpret_cast<const bf16_t*>(P.dC);
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
+
+  // a thread always lands on chunk column c = tid % 32 of rows r = tid / 32 + 16 it: column guards are loop invariants
+  const int c = tid & (CPR - 1), rbase = tid / CPR;
+  const bool c_ok = n0 + c * 8 < P.N, a_ok = k0 + c * 8 < P.K;
+  const int cg = (k0 >> 3) + c;                                         // tiled A: 16-byte chunk index of the 256-wide row
+  i32x4 rc[PER_T], ra[PER_T];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+      const int m = m0 + rbase + 16 * it;
+      rc[it] = (i32x4)(0);
+      ra[it] = (i32x4)(0);
+      if (m < m_end) {
+        if (c_ok) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * 8);
+        if (a_ok) {
+          const long aoff = P.a_tiled ? (long)(m >> 5) * (32 * 256) + ((((2 * (cg & 15) + (cg >> 4)) << 5) + (m & 31)) << 3)
+                                      : (long)m * P.lda + k0 + c * 8;
+          ra[it] = *reinterpret_cast<const i32x4*>(A + aoff);
+        }
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    char* Cs = w3_smem + buf * 2 * W3_IMG;
+    char* As = Cs + W3_IMG;
+#pragma unroll
+    for (int it = 0; it < PER_T; ++it) {
+      const int r = rbase + 16 * it;
+      const int off = r * W3_ROWB + ((c << 4) ^ ((r & 3) << 6));
+      *reinterpret_cast<i32x4*>(Cs + off) = rc[it];
+      *reinterpret_cast<i32x4*>(As + off) = ra[it];
+    }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x16)(0.f);
+  float bsum = 0.f;                                    // threads 0..255 of the bk == 0 workgroups: column sums of dC
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+
+  auto compute = [&](int cur) {
+    const char* Cs = w3_smem + cur * 2 * W3_IMG;
+    const char* As = Cs + W3_IMG;
+    if (P.dbias != nullptr && bk == 0 && tid < W3_T) {
+#pragma unroll 8
+      for (int r = 0; r < W3_MS; ++r) {
+        const char* p = Cs + r * W3_ROWB + ((tid * 2) ^ ((r & 3) << 6));
+        bsum += Elem<bf16_t>::to_f32(*reinterpret_cast<const bf16_t*>(p));
+      }
+    }
+#pragma unroll
+    for (int ms = 0; ms < W3_MS; ms += 16) {
+      Frag8<bf16_t> cf[2], af[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w3_col_frag(cf[i], Cs, ms, wn + 32 * i, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w3_col_frag(af[j], As, ms, wk + 32 * j, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma32(acc[i][j], cf[i], af[j]);
+    }
+  };
+  // slab s lives in LDS buffer s & 1; the register set carries slab s + 1 on its way in while slab s is multiplied
+  if (m_begin < m_end) {
+    fetch(m_begin);
+    stash(0);
+    fetch(m_begin + W3_MS);                            // (rows past m_end come back as zeros)
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int m0 = m_begin; m0 < m_end; m0 += W3_MS) {
+    compute(cur);
+    stash(cur ^ 1);                                    // slab s + 1 (buffer last read before the previous barrier)
+    fetch(m0 + 2 * W3_MS);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // D: row (n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (k') = lane&31
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long nblk256 = ((long)P.N * P.K + 255) >> 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kc = k0 + wk + 32 * j + l31;
+      if (kc >= P.K) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = n0 + wn + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (n < P.N) {
+          const long q = (long)n * P.K + kc;
+          ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[i][j][reg];
+        }
+      }
+    }
+  if (P.dbias != nullptr && bk == 0 && tid < W3_T && n0 + tid < P.N) {
+    ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = bsum;
+  }
+}
+
 // dW[n, k] += sum over the slices; dbias[n] += sum over the slices (fixed order: deterministic).  A workgroup owns 256
 // consecutive floats of dW (64 lanes x float4 = one KB per wave instruction); its sixteen waves take the slices s = w,
 // w + 16, ..: every load is a full coalesced KB and all of a wave's loads are in flight together; the partial sums meet
@@ -855,6 +999,50 @@ extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* 
                         nullptr, 0, overwrite[i], dtype, off, tiled);
   }
   WMZ_REQUIRE(workspace_floats >= off, "wmz_linear_wgrad_batch: workspace too small (%ld floats needed)", off);
+  // bf16 problems that fill at least half of a 256 x 256 tile (the fused path's five: 256 x 256, 256 x 128, 128 x 256): version 3
+  bool v3 = dtype == WMZ_BF16 && n >= 2;
+  int tiles3 = 0;
+  for (int i = 0; i < n && v3; ++i) {
+    const int tn = wmz_cdiv(N[i], W3_T), tk = wmz_cdiv(K[i], W3_T);
+    v3 = (long)N[i] * K[i] * 2 >= (long)tn * tk * W3_T * W3_T && M[i] >= 4 * W3_MS;
+    tiles3 += tn * tk;
+  }
+  if (v3 && tiles3 <= 256) {
+    long off3 = 0;
+    const int per = 256 / tiles3;                    // ~one workgroup per CU in all (8 waves, 128 KB of LDS: one fits)
+    for (int i = 0; i < n; ++i) {
+      WgParams& P = B.p[i];
+      P.nbn = wmz_cdiv(N[i], W3_T); P.nbk = wmz_cdiv(K[i], W3_T);
+      int split = per < 1 ? 1 : per;
+      const int max_split = M[i] / (4 * W3_MS);
+      if (split > max_split) split = max_split;
+      P.rows_per_wg = wmz_cdiv(wmz_cdiv(M[i], split), W3_MS) * W3_MS;
+      P.nsplit = wmz_cdiv(M[i], P.rows_per_wg);
+      P.direct = 0;
+      B.first[i + 1] = B.first[i] + P.nbn * P.nbk * P.nsplit;
+      B.wsoff[i] = off3;
+      RedProb& Q = R.p[i];
+      Q.nsplit = P.nsplit; Q.wsoff = off3;
+      Q.first = i == 0 ? 0 : R.p[i - 1].first + R.p[i - 1].nblk_w + (R.p[i - 1].dbias != nullptr ? wmz_cdiv(R.p[i - 1].N, 64) : 0);
+      off3 += (long)P.nsplit * ((((long)N[i] * K[i] + 255) >> 8) * 256 + N[i]);
+    }
+    if (off3 <= workspace_floats) {
+      hipStream_t st = (hipStream_t)stream;
+      hipLaunchKernelGGL(wgrad3_kernel, dim3((unsigned)B.first[n]), dim3(W3_NT), 0, st, B, workspace);
+      const RedProb& Lp = R.p[n - 1];
+      const int nred = Lp.first + Lp.nblk_w + (Lp.dbias != nullptr ? wmz_cdiv(Lp.N, 64) : 0);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nred), dim3(1024), 0, st, workspace, R);
+      WMZ_LAUNCH_CHECK("wmz_linear_wgrad_batch");
+      return WMZ_OK;
+    }
+    // (workspace sized for version 2's slicing only: fall through to it -- rebuild the tables)
+    off = 0;
+    for (int i = 0; i < n; ++i) {
+      const int tiled = a_tiled != nullptr && a_tiled[i] != 0;
+      off += wg_batch_add(B, R, i, dC[i], ldc[i], A[i], lda[i], dW[i], dbias[i], M[i], N[i], K[i], nullptr, nullptr, nullptr,
+                          nullptr, 0, overwrite[i], dtype, off, tiled);
+    }
+  }
   wg_batch_launch(B, R, 0, workspace, dtype, (hipStream_t)stream);
   WMZ_LAUNCH_CHECK("wmz_linear_wgrad_batch");
   return WMZ_OK;
