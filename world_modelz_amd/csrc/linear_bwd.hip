@@ -469,7 +469,10 @@ __global__ __launch_bounds__(W3_NT, 1) void wgrad3_kernel(WgBatch B, float* __re
       const int m = m0 + rbase + 16 * it;
       rc[it] = (i32x4)(0);
       ra[it] = (i32x4)(0);
-      if (m < m_end) {
+#ifndef WMZ_W3_ABL            // timing ablations (tools/build_variant.py): 1 = no operand loads, 2 = no MFMA loops
+#define WMZ_W3_ABL 0
+#endif
+      if (m < m_end && !(WMZ_W3_ABL & 1)) {
         if (c_ok) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * 8);
         if (a_ok) {
           const long aoff = P.a_tiled ? (long)(m >> 5) * (32 * 256) + ((((2 * (cg & 15) + (cg >> 4)) << 5) + (m & 31)) << 3)
@@ -508,6 +511,7 @@ __global__ __launch_bounds__(W3_NT, 1) void wgrad3_kernel(WgBatch B, float* __re
         bsum += Elem<bf16_t>::to_f32(*reinterpret_cast<const bf16_t*>(p));
       }
     }
+    if (WMZ_W3_ABL & 2) return;
 #pragma unroll
     for (int ms = 0; ms < W3_MS; ms += 16) {
       Frag8<bf16_t> cf[2], af[4];
