@@ -210,6 +210,33 @@ def test_wgrad_batch_with_per_problem_layernorm(ops, M, dtype):
         assert rel(q['dw'], sw.cpu()) < 1e-5 and rel(q['dbias'], sb.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize('M', [65536, 4099, 300])
+def test_wgrad_batch_on_256_wide_tiles(ops, M):
+    """wmz_linear_wgrad_batch's bf16 path (wgrad3_kernel: 256 x 256 output tiles, 64 x 128 per wave) against torch and against the
+    one-problem launches (version 2's 128 x 128 tiles): the fused path's five shapes, a two-tile problem, a tile used to three
+    quarters; ragged M (the last slab of a slice is partly zero rows), accumulate and overwrite, with and without a bias; M too
+    small for the big tiles falls back to version 2."""
+    torch.manual_seed(47)
+    shapes = [(256, 256, True, False), (256, 256, True, True), (256, 128, True, False), (128, 256, False, False), (512, 256, True, False),
+              (256, 384, False, True)]
+    probs, refs, singles = [], [], []
+    for N, K, bias, over in shapes:
+        dc = (torch.randn(M, N) * 0.3).bfloat16()
+        a = (torch.randn(M, K) * 1.1 + 0.1).bfloat16()
+        init, binit = torch.randn(N, K), torch.randn(N)
+        refs.append(((0 if over else init) + dc.float().t() @ a.float(), (0 if over else binit) + dc.float().sum(0)))
+        dcd, ad = dev(dc), dev(a)
+        probs.append((dcd, ad, dev(init).clone(), dev(binit).clone() if bias else None, over))
+        dw1, db1 = dev(init).clone(), dev(binit).clone() if bias else None
+        ops.linear_wgrad(dcd, ad, dw1, db1, overwrite=over)
+        singles.append((dw1, db1))
+    ops.linear_wgrad_batch(probs)
+    for (dcd, ad, dw, db, over), (rw, rb), (sw, sb) in zip(probs, refs, singles):
+        assert rel(dw, rw) < 2e-3 and rel(dw, sw) < 1e-5
+        if db is not None:
+            assert rel(db, rb) < 2e-3 and rel(db, sb) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,S,HW,D,N', [(8, 5, 256, 256, 1024), (3, 4, 20, 32, 50), (2, 1, 77, 64, 130)])
 def test_linear_on_last_frame_blocks(ops, dtype, B, S, HW, D, N):
