@@ -89,6 +89,12 @@ int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, const float* b
 int wmz_linear_fwd_gelu_pair(const void* A, long lda, const void* Wt, const float* bias, void* Z, long ldz, void* H, long ldh,
                              int M, int N, int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
                              const float* ln_rstd, float ln_eps, int dtype, void* stream);
+/* The training forward's PreNorm GEMM in full: C = LN(A) Wt^T + bias; H (optional) = GELU(C); An (optional) = LN(A) [M, K] as the
+ * GEMM consumed it, i.e. the operand of the layer's weight gradient -- which then needs no LayerNorm prologue
+ * (wmz_linear_wgrad_batch*'s 256-wide tiles take plain operands only).  ln_mean / ln_rstd: supplied or NULL (computed). */
+int wmz_linear_fwd_train(const void* A, long lda, const void* Wt, const float* bias, void* C, long ldc, void* H, long ldh,
+                         void* An, long ldan, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
+                         const float* ln_mean, const float* ln_rstd, float ln_eps, int dtype, void* stream);
 
 /* logit_proj on the LAST FRAME of every clip, read in place (main.py:35-36: x[:, -1] -> nn.Linear): C[M,N] = A' Wt^T + bias
  * where row m of A' is A + (m / rows_per_block) * block_stride + (m % rows_per_block) * lda (elements); rows_per_block =

@@ -167,6 +167,14 @@ def test_linear_gelu_pair_and_small_row_tiles(ops, M, N, K, dtype):
         assert rel(z, pre) < tol and rel(h, torch.nn.functional.gelu(pre)) < tol
         assert torch.equal(z, ops.linear_fwd(dev(a), dev(w), bias=dev(b), ln=ln, ln_stats=stats))
         assert torch.equal(h, ops.linear_fwd(dev(a), dev(w), bias=dev(b), ln=ln, ln_stats=stats, gelu=True))
+    # the PreNorm GEMM of the training forward in full: + LN(a) as the GEMM consumed it (the weight gradient's plain operand)
+    st = ops.layernorm_stats(dev(a), 1e-5)
+    c3, h3, an3 = ops.linear_fwd_train(dev(a), dev(w), dev(b), (dev(g), dev(be)), 1e-5, st, want_gelu=True, want_norm=True)
+    z3, h3b = ops.linear_fwd_gelu_pair(dev(a), dev(w), bias=dev(b), ln=(dev(g), dev(be)), ln_stats=st)
+    assert torch.equal(c3, z3) and torch.equal(h3, h3b) and an3.shape == (M, K) and an3.dtype == dtype
+    assert rel(an3, torch.nn.functional.layer_norm(af, (K,), g, be, 1e-5)) < (3e-6 if dtype == torch.float32 else 4e-3)
+    c4, h4, an4 = ops.linear_fwd_train(dev(a), dev(w), dev(b), (dev(g), dev(be)), 1e-5, None, want_norm=True)   # statistics computed inside
+    assert h4 is None and rel(c4, z3) < tol and rel(an4, an3) < tol
     # GELU in the loader (the backward's fallback when the activation was not kept) on both tile heights
     if N % 8 == 0:
         w2 = (torch.randn(K, N) / N ** 0.5).to(dtype)

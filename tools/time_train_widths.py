@@ -2,7 +2,10 @@
 config-4 clips, graph replay and eager, plus the default widths for comparison."""
 import sys, time, torch
 sys.path.insert(0, '.')
-from world_modelz_amd import config
+from world_modelz_amd import config, ops
+import os
+if os.environ.get('KEEP_NORM') == '0':
+    ops.KEEP_NORM_MIN_ROWS = 1 << 30     # A/B: weight gradients re-normalise their operand (no LN(x) kept, 128-wide tiles)
 from world_modelz_amd.main import VqVideoDiffusionModel
 from world_modelz_amd.train import DenoiserTrainer
 config.set_compute_dtype(torch.bfloat16)

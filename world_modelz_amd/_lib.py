@@ -45,6 +45,8 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p],
     'wmz_linear_fwd_gelu_pair': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p],
+    'wmz_linear_fwd_train': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
+                             c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p],
     'wmz_linear_fwd_blocked': [c_void_p, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
                                c_int, c_int, c_void_p],
     'wmz_embed_pos3d_fwd': [c_void_p] * 6 + [c_int] * 7 + [c_void_p],

@@ -132,7 +132,11 @@ def _attention_block_backward(ctx, dy):
     if ln_g is not None:
         stats = ctx.ln_stats if getattr(ctx, 'ln_stats', None) is not None else ops.layernorm_stats(x_kv, LN_EPS)
         lnp = (ln_g.detach(), ln_b.detach())
-        g_wk, g_wv, g_bv = _wgrad_kv(wk, wv, bv, dkv, x_kv, lnp, stats)
+        xn = getattr(ctx, 'xn', None)
+        if xn is not None:
+            g_wk, g_wv, g_bv = _wgrad_kv(wk, wv, bv, dkv, xn, None, None)         # plain operand: LN(x_kv) kept by the forward
+        else:
+            g_wk, g_wv, g_bv = _wgrad_kv(wk, wv, bv, dkv, x_kv, lnp, stats)
         holder = {}
 
         def fill_ln(gg, gb):
@@ -160,6 +164,7 @@ def feed_forward_block_backward(ctx, dy):
 def _feed_forward_block_backward(ctx, dy):
     x, ln_g, ln_b, w1, b1, w2, b2, z = ctx.saved_tensors[:8]
     h = ctx.saved_tensors[8] if len(ctx.saved_tensors) > 8 else None      # GELU(z) as the forward stored it (or recompute in the loader)
+    xn = ctx.saved_tensors[9] if len(ctx.saved_tensors) > 9 else None     # LN(x) as the first GEMM consumed it (many rows only)
     dt = x.dtype
     dy = dy.contiguous()
     d_res = dy if ctx.has_res else None
@@ -175,7 +180,10 @@ def _feed_forward_block_backward(ctx, dy):
     if ln_g is not None:
         stats = ctx.ln_stats if getattr(ctx, 'ln_stats', None) is not None else ops.layernorm_stats(x, LN_EPS)
         lnp = (ln_g.detach(), ln_b.detach())
-        dw1, db1 = _emit2(w1, b1, lambda w, b: ops.linear_wgrad(dz, x, w, b, ln=lnp, ln_stats=stats))
+        if xn is not None:
+            dw1, db1 = _emit2(w1, b1, lambda w, b: ops.linear_wgrad(dz, xn, w, b))
+        else:
+            dw1, db1 = _emit2(w1, b1, lambda w, b: ops.linear_wgrad(dz, x, w, b, ln=lnp, ln_stats=stats))
         # the transformer passes residual = x: fold the skip gradient into the LayerNorm backward
         fold = ctx.has_res and ctx.res_is_x
         holder = {}

@@ -979,10 +979,28 @@ extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long
   return WMZ_OK;
 }
 
+static int wgrad_batch_plain(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
+                             float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
+                             const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats,
+                             int dtype, void* stream, bool single_v3);
+
 extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
                                       float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
                                       const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats,
                                       int dtype, void* stream) {
+  return wgrad_batch_plain(n, dC, ldc, A, lda, dW, dbias, M, N, K, overwrite, a_tiled, workspace, workspace_floats, dtype, stream, false);
+}
+
+// 256-wide tiles (wgrad3_kernel) pay off for a bf16 problem that fills at least half of its tiles and has rows to slice
+static bool wgrad3_eligible(int M, int N, int K, int dtype) {
+  const int tn = wmz_cdiv(N, W3_T), tk = wmz_cdiv(K, W3_T);
+  return dtype == WMZ_BF16 && (long)N * K * 2 >= (long)tn * tk * W3_T * W3_T && M >= 4 * W3_MS;
+}
+
+static int wgrad_batch_plain(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
+                             float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
+                             const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats,
+                             int dtype, void* stream, bool single_v3) {
   WMZ_REQUIRE(n >= 1 && n <= WG_MAXB, "wmz_linear_wgrad_batch: 1 .. %d problems per call (got %d)", WG_MAXB, n);
   WMZ_REQUIRE(dC && ldc && A && lda && dW && dbias && M && N && K && overwrite && workspace, "wmz_linear_wgrad_batch: null table");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_wgrad_batch: bad dtype %d", dtype);
@@ -1004,12 +1022,11 @@ extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* 
   }
   WMZ_REQUIRE(workspace_floats >= off, "wmz_linear_wgrad_batch: workspace too small (%ld floats needed)", off);
   // bf16 problems that fill at least half of a 256 x 256 tile (the fused path's five: 256 x 256, 256 x 128, 128 x 256): version 3
-  bool v3 = dtype == WMZ_BF16 && n >= 2;
+  bool v3 = dtype == WMZ_BF16 && (n >= 2 || single_v3);
   int tiles3 = 0;
   for (int i = 0; i < n && v3; ++i) {
-    const int tn = wmz_cdiv(N[i], W3_T), tk = wmz_cdiv(K[i], W3_T);
-    v3 = (long)N[i] * K[i] * 2 >= (long)tn * tk * W3_T * W3_T && M[i] >= 4 * W3_MS;
-    tiles3 += tn * tk;
+    v3 = wgrad3_eligible(M[i], N[i], K[i], dtype);
+    tiles3 += wmz_cdiv(N[i], W3_T) * wmz_cdiv(K[i], W3_T);
   }
   if (v3 && tiles3 <= 256) {
     long off3 = 0;
@@ -1064,6 +1081,36 @@ extern "C" int wmz_linear_wgrad_batch_ln(int n, const void* const* dC, const lon
   WMZ_REQUIRE(dC && ldc && A && lda && dW && dbias && M && N && K && overwrite && workspace && ln_gamma && ln_beta && ln_mean && ln_rstd,
               "wmz_linear_wgrad_batch_ln: null table");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_wgrad_batch_ln: bad dtype %d", dtype);
+  // Many rows (the published widths' training step: 65 536 tokens): the plain problems that suit the 256-wide tiles leave as
+  // their own launch pair on wgrad3_kernel, the rest (LayerNorm prologue, narrow shapes) as before.  One stream, in order: the
+  // second pair may reuse the workspace.
+  if (dtype == WMZ_BF16 && n >= 2) {
+    int e_idx[WG_MAXB], r_idx[WG_MAXB], ne = 0, nr = 0;
+    for (int i = 0; i < n; ++i) {
+      const bool plain = ln_gamma[i] == nullptr;
+      if (plain && M[i] >= 16384 && wgrad3_eligible(M[i], N[i], K[i], dtype)) e_idx[ne++] = i; else r_idx[nr++] = i;
+    }
+    if (ne > 0 && nr > 0) {
+      const void* sdC[WG_MAXB]; const void* sA[WG_MAXB]; long sldc[WG_MAXB], slda[WG_MAXB]; float* sdW[WG_MAXB]; float* sdb[WG_MAXB];
+      int sM[WG_MAXB], sN[WG_MAXB], sK[WG_MAXB], sov[WG_MAXB];
+      const float* sg[WG_MAXB]; const float* sb[WG_MAXB]; const float* sm[WG_MAXB]; const float* sr[WG_MAXB];
+      auto gather = [&](const int* idx, int cnt) {
+        for (int j = 0; j < cnt; ++j) {
+          const int i = idx[j];
+          sdC[j] = dC[i]; sA[j] = A[i]; sldc[j] = ldc[i]; slda[j] = lda[i]; sdW[j] = dW[i]; sdb[j] = dbias[i];
+          sM[j] = M[i]; sN[j] = N[i]; sK[j] = K[i]; sov[j] = overwrite[i];
+          sg[j] = ln_gamma[i]; sb[j] = ln_beta[i]; sm[j] = ln_mean[i]; sr[j] = ln_rstd[i];
+        }
+      };
+      gather(e_idx, ne);
+      int rc = wgrad_batch_plain(ne, sdC, sldc, sA, slda, sdW, sdb, sM, sN, sK, sov, nullptr, workspace, workspace_floats, dtype, stream, true);
+      if (rc != WMZ_OK) return rc;
+      gather(r_idx, nr);
+      return wmz_linear_wgrad_batch_ln(nr, sdC, sldc, sA, slda, sdW, sdb, sM, sN, sK, sov, sg, sb, sm, sr, workspace, workspace_floats, dtype, stream);
+    }
+    if (ne == n)
+      return wgrad_batch_plain(n, dC, ldc, A, lda, dW, dbias, M, N, K, overwrite, nullptr, workspace, workspace_floats, dtype, stream, true);
+  }
   WgBatch B;
   RedBatch R;
   B.n = R.n = n;

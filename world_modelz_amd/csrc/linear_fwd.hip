@@ -21,6 +21,7 @@ struct LinParams {
   const void* res; long ldr;
   void* C; long ldc;
   void* C2; long ldc2;                       // optional second output: GELU(C) (C then holds the pre-activation); no residual
+  void* An; long ldan;                       // optional, LayerNorm prologue: the normalised rows LN(A) [M, K] as the GEMM consumed them
   int M, N, K;
   const float* gamma; const float* beta; float eps;
   const float* mean; const float* rstd;      // optional precomputed LayerNorm statistics (wmz_layernorm_stats)
@@ -183,6 +184,10 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * rs * lng[S][e >> 2][e & 3] + lnb[S][e >> 2][e & 3];
         va = f32_to_chunk<T>(f);
+        // (training: the rows as normalised here are what the weight gradient multiplies -- column tile 0 keeps them, so the
+        //  backward's GEMM reads a plain operand instead of re-normalising per output tile)
+        if (P.An != nullptr && bn == 0 && kok && m0 + r < P.M)
+          *reinterpret_cast<i32x4*>(reinterpret_cast<T*>(P.An) + (long)(m0 + r) * P.ldan + k) = va;
       } else if constexpr (PRO == 2) {
         float f[EPC];
         chunk_to_f32<T>(va, f);
@@ -432,6 +437,7 @@ extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, con
   P.out_f32 = out_f32;
   P.rpb = 0; P.bstride = 0;
   P.C2 = nullptr; P.ldc2 = 0;
+  P.An = nullptr; P.ldan = 0;
   return linear_launch(P, ln_gamma, flags, dtype, (hipStream_t)stream);
 }
 
@@ -456,6 +462,30 @@ extern "C" int wmz_linear_fwd_gelu_pair(const void* A, long lda, const void* Wt,
   P.out_f32 = 0;
   P.rpb = 0; P.bstride = 0;
   P.C2 = H; P.ldc2 = ldh;
+  P.An = nullptr; P.ldan = 0;
+  return linear_launch(P, ln_gamma, 0, dtype, (hipStream_t)stream);
+}
+
+// The training forward's PreNorm GEMM in full: C = LN(A) Wt^T + bias, optionally H = GELU(C) next to it (FeedForward's first
+// GEMM) and optionally An = LN(A) [M, K] as the GEMM consumed it -- the operand of the layer's weight gradient, which then is a
+// plain GEMM (the LayerNorm prologue in the weight gradient re-normalises the operand panel once per output column tile and
+// keeps it off the 256-wide tiles of wgrad3_kernel).  Statistics: supplied (ln_mean / ln_rstd) or computed by the prologue.
+extern "C" int wmz_linear_fwd_train(const void* A, long lda, const void* Wt, const float* bias, void* C, long ldc, void* H, long ldh,
+                                    void* An, long ldan, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
+                                    const float* ln_mean, const float* ln_rstd, float ln_eps, int dtype, void* stream) {
+  WMZ_REQUIRE(A && Wt && C && ln_gamma && ln_beta, "wmz_linear_fwd_train: null tensor (a LayerNorm prologue is required)");
+  WMZ_REQUIRE((ln_mean == nullptr) == (ln_rstd == nullptr), "wmz_linear_fwd_train: ln_mean and ln_rstd go together");
+  WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_fwd_train: bad shape M=%d N=%d K=%d", M, N, K);
+  WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0 && (An == nullptr || ldan % 8 == 0), "wmz_linear_fwd_train: K, lda, ldan must be multiples of 8");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd_train: bad dtype %d", dtype);
+  LinParams P;
+  P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = nullptr; P.ldr = 0; P.C = C; P.ldc = ldc;
+  P.M = M; P.N = N; P.K = K; P.gamma = ln_gamma; P.beta = ln_beta; P.eps = ln_eps; P.flags = 0;
+  P.mean = ln_mean; P.rstd = ln_rstd;
+  P.out_f32 = 0;
+  P.rpb = 0; P.bstride = 0;
+  P.C2 = H; P.ldc2 = ldh;
+  P.An = An; P.ldan = ldan;
   return linear_launch(P, ln_gamma, 0, dtype, (hipStream_t)stream);
 }
 
@@ -475,5 +505,6 @@ extern "C" int wmz_linear_fwd_blocked(const void* A, long lda, int rows_per_bloc
   P.out_f32 = out_f32;
   P.rpb = rows_per_block; P.bstride = block_stride;
   P.C2 = nullptr; P.ldc2 = 0;
+  P.An = nullptr; P.ldan = 0;
   return linear_launch(P, nullptr, 0, dtype, (hipStream_t)stream);
 }

@@ -32,7 +32,11 @@ class _AttentionBlock(torch.autograd.Function):
         # training: the LayerNorm statistics are computed once, handed to the GEMM prologue and kept for the backward
         stats = ops.layernorm_stats(x_kv, LN_EPS) if (need_bwd and ln is not None) else None
         q = ops.linear_fwd(x_q, wq_c)                                           # to_q: no bias, raw input (Q1)
-        kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS, ln_stats=stats)   # to_k | to_v on LN(x)
+        xn = None
+        if stats is not None and x_kv.numel() // x_kv.shape[-1] >= ops.KEEP_NORM_MIN_ROWS:
+            kv, _, xn = ops.linear_fwd_train(x_kv, wkv_c, bkv, ln, LN_EPS, stats, want_norm=True)     # (+ LN(x) for the weight gradient)
+        else:
+            kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS, ln_stats=stats)   # to_k | to_v on LN(x)
         o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], extents, heads, need_lse=need_bwd)
         if wout is not None:
             y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual)
@@ -42,6 +46,7 @@ class _AttentionBlock(torch.autograd.Function):
             ctx.save_for_backward(x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse)
             ctx.extents, ctx.heads, ctx.has_res = extents, heads, residual is not None
             ctx.ln_stats = stats
+            ctx.xn = xn                    # LN(x_kv) as the k | v GEMM consumed it (None: the weight gradient re-normalises)
             # gradient folding is decided by autograd identity of the caller's tensors (attention_block), never by
             # storage: attn(x, q=x.detach()) or an aliased residual must get separate gradients
             ctx.same_src, ctx.res_is_xkv = bool(same_src), bool(res_is_xkv)
@@ -64,9 +69,14 @@ class _FeedForwardBlock(torch.autograd.Function):
             # keep the pre-activation z (gelu' in the backward) AND the activation h = GELU(z) (the second GEMM's operand here,
             # its weight gradient's operand in the backward): one launch writes both
             stats = ops.layernorm_stats(x, LN_EPS) if ln is not None else None
-            z, h = ops.linear_fwd_gelu_pair(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, ln_stats=stats)
+            xn = None
+            if ln is not None and x.numel() // x.shape[-1] >= ops.KEEP_NORM_MIN_ROWS:
+                # many rows: LN(x) is kept as well -- the first GEMM's weight gradient then is a plain GEMM (256-wide tiles)
+                z, h, xn = ops.linear_fwd_train(x, w1_c, b1.detach(), ln, LN_EPS, stats, want_gelu=True, want_norm=True)
+            else:
+                z, h = ops.linear_fwd_gelu_pair(x, w1_c, bias=b1.detach(), ln=ln, ln_eps=LN_EPS, ln_stats=stats)
             y = ops.linear_fwd(h, w2_c, bias=b2.detach(), residual=residual)
-            ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z, h)
+            ctx.save_for_backward(x, ln_g, ln_b, w1, b1, w2, b2, z, h, xn)
             ctx.ln_stats = stats
             ctx.has_res = residual is not None
             ctx.res_is_x = bool(res_is_x)

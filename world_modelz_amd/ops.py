@@ -91,6 +91,33 @@ def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=F
     return out
 
 
+KEEP_NORM_MIN_ROWS = 16384    # from here on the training forward's PreNorm GEMMs also write LN(a): the weight gradients then read
+                              # a plain operand and take the 256-wide tiles (fewer rows: they sit on the graph's side branch anyway)
+
+
+def linear_fwd_train(a, weight, bias, ln, ln_eps=1e-5, ln_stats=None, want_gelu=False, want_norm=False):
+    """The training forward's PreNorm GEMM (wmz_linear_fwd_train): c = LN(a) @ weight^T + bias, and on request h = GELU(c) and
+    an = LN(a) as the GEMM consumed it -> (c, h | None, an | None)."""
+    K = a.shape[-1]
+    N = weight.shape[0]
+    dt = L.dtype_code(a.dtype)
+    assert weight.dtype == a.dtype and weight.is_contiguous() and weight.shape[1] == K and ln is not None
+    a, M, lda = _rows(a)
+    lead = a.shape[:-1]
+    c = torch.empty(lead + (N,), dtype=a.dtype, device=a.device)
+    h = torch.empty(lead + (N,), dtype=a.dtype, device=a.device) if want_gelu else None
+    an = torch.empty(lead + (K,), dtype=a.dtype, device=a.device) if want_norm else None
+    g, b = ln
+    mean = rstd = None
+    if ln_stats is not None:
+        mean, rstd = ln_stats
+        assert mean.numel() == M and rstd.numel() == M
+    assert bias is None or bias.dtype == torch.float32
+    L.call('wmz_linear_fwd_train', L.ptr(a), lda, L.ptr(weight), L.ptr(bias), L.ptr(c), N, L.ptr(h), N, L.ptr(an), K, M, N, K,
+           L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(rstd), float(ln_eps), dt, L.stream())
+    return c, h, an
+
+
 def linear_fwd_gelu_pair(a, weight, bias=None, ln=None, ln_eps=1e-5, ln_stats=None):
     """(z, h) = (LN?(a) @ weight^T + bias, GELU(z)), both in a's dtype, from one launch (wmz_linear_fwd_gelu_pair)."""
     K = a.shape[-1]
@@ -272,12 +299,15 @@ def workspace_same(a, b):
 
 
 _wgrad_ws = {}          # device -> fp32 scratch for the two-stage weight-gradient reduction (grown on demand, never shrunk)
+# at least 128 MB: the 256-wide tiles (wgrad3_kernel) write one 256 KB partial tile per workgroup, ~one workgroup per CU -- up to
+# ~70 MB per launch whatever the problems are; the library falls back to the 128-wide tiles when the workspace is smaller
+WGRAD_WS_MIN_FLOATS = 1 << 25
 
 
 def _workspace(device, floats):
     w = _wgrad_ws.get(device)
     if w is None or w.numel() < floats:
-        w = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+        w = torch.empty(max(floats, WGRAD_WS_MIN_FLOATS), dtype=torch.float32, device=device)
         _wgrad_ws[device] = w
     return w
 
@@ -446,7 +476,7 @@ def _wgrad_side_enter(device, tensors):
 def _side_workspace(ent, device, floats):
     w = ent[2]
     if w is None or w.numel() < floats:
-        w = ent[2] = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+        w = ent[2] = torch.empty(max(floats, WGRAD_WS_MIN_FLOATS), dtype=torch.float32, device=device)
     return w
 
 
