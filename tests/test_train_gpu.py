@@ -612,6 +612,15 @@ def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
             for (n, a), b, c in zip(me.named_parameters(), mg.parameters(), ms.parameters()):
                 assert torch.allclose(a, b, rtol=0, atol=3e-3) and torch.allclose(c, b, rtol=0, atol=3e-3), n
     finally:
+        # (captured graphs hold RCCL kernels: let go of them and drain the device before the communicator is torn down -- a
+        #  failing assertion above must surface as that assertion, not as an abort inside destroy_process_group)
+        import gc
+        for name in ('tg', 'te', 'td', 'ts'):
+            t = locals().get(name)
+            if t is not None and getattr(t, '_graph', None) is not None:
+                t._graph = None
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
