@@ -822,7 +822,14 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.destroy_process_group()
+        # Leave without tearing the communicator down by hand: trainers of this process hold captured hipGraphs with RCCL kernels
+        # in them, and a destroy_process_group() that aborts would turn a measured run into a failed one.  Everything is drained
+        # and every rank has passed the barrier; the process exit frees the rest.
+        torch.cuda.synchronize()
+        barrier()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':
