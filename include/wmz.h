@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 101
+#define WMZ_VERSION 102
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
@@ -56,8 +56,10 @@ int wmz_local3d_attn_fwd_general(const void* q, const void* k, const void* v, vo
                                  long ldq, long ldk, long ldv, long ldo, int dtype, void* stream);
 
 /* Backward of the above given the saved lse: dq, dk, dv.  Gather form, no atomics (the window relation is
- * symmetric): one query-owner pass (dq, and delta = rowsum(dout*out) into delta_ws, fp32 [N, heads]) and one
- * key-owner pass (dk, dv).  Replaces the checkpoint re-run + autograd of local_3d_attention.py:110-111. */
+ * symmetric): one query-owner pass (dq; it leaves delta = rowsum(dout*out) and -lse / scale per token in delta_ws) and
+ * one key-owner pass (dk, dv) that starts its accumulators from those.  delta_ws: caller-allocated scratch of
+ * 2 * N * heads floats (N = B*S*H*W), contents unspecified on return.  Replaces the checkpoint re-run + autograd of
+ * local_3d_attention.py:110-111. */
 int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                          const void* dout, void* dq, void* dk, void* dv, float* delta_ws,
                          int B, int S, int H, int W, int heads, int dh, int eS, int eH, int eW,

@@ -192,7 +192,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) bl[r] = bias[r] - own_lse;
       nde = -dsum * G.scale;
-      if (active && g == 0) P.delta[row * G.heads + head] = dsum;
+      if (active && g == 0) {
+        // workspace for the dk | dv pass: delta, and behind it (one row of [tokens, heads] further) -lse / scale -- the initial
+        // values of its dP and S accumulators
+        P.delta[row * G.heads + head] = dsum;
+        P.delta[(long)G.B * G.S * HW * G.heads + row * G.heads + head] = -P.lse[row * G.heads + head] / G.scale;
+      }
     }
   }
   f32x4 acc1[MT];
@@ -399,6 +404,292 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dk | dv pass, whole-plane form (round 4): 16 waves = the 16 key rows of one (b, head, s) plane IN ONE WORKGROUP, written
+// for the 128 registers a wave has at four waves per SIMD (the 8-wave form above holds 229: one workgroup per CU, a plane's
+// two half-plane workgroups each stage every visiting plane, the launch runs as two rounds of workgroups).
+// Register plan at dim_head 128: dK^T / dV^T accumulators 64, the owner's K and (negated) V fragments 32, three running LDS
+// addresses 3 -- 99 resident, which leaves 29 for a step.  What makes a step fit:
+//   * the per-visitor row constants are the INITIAL VALUE of the S and dP accumulators, read from LDS straight into them: the dq
+//     pass leaves delta and -lse / scale per token (ws), so S' = Q.K - lse / scale needs only exp2(c2 S') and, with the owner's V
+//     negated, D' = delta - dO.V = -(dP - delta): dS = -scale P D' and the -scale waits for the epilogue.  No lse / delta
+//     registers, no subtract, no second multiply per element;
+//   * the window's column mask is four lane masks in scalar registers (v_cndmask on P), not four bias registers;
+//   * the LDS-DMA source offsets of a wave's pieces live in an LDS table (12 KB of the 14 KB the two slab buffers leave), read back
+//     per slab, not in registers;
+//   * one visitor operand's fragments at a time: row fragments four in flight (16 registers), transposed fragments as a
+//     double-buffered pair of 2-feature-tile chunks (16 registers); every LDS read is inline asm retired by a counted lgkmcnt
+//     wait that names what it releases, every MFMA result is pinned at its program point (the scheduler may not widen a live range).
+// Requires whole 16-row chunks (H % 16 == 0) and one row stride for both visiting tensors; everything else takes the 8-wave form.
+template <int DH>
+__global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, AttnGeom G, const float* ws, float c2) {   // c2 = scale * log2(e): a kernel argument stays scalar
+  using I = BImg<DH>;
+  constexpr int NW = 16, KS = DH / 32, MT = DH / 16;
+  constexpr int NP = (I::PIECES + NW - 1) / NW;
+  constexpr int HDR = 2 * KC * 16 * 4;                   // delta | -lse / scale of the slab's 128 visitors
+  constexpr int BUFB = HDR + 2 * I::IMG;
+  constexpr int R16 = 16 * I::ROWP;                      // one slab row = 16 visitors
+  constexpr int Y2O = I::IMG;
+  constexpr int TAB = 2 * BUFB;
+  static_assert(HDR + Y2O + R16 + DH * 2 < 65536, "fragment offsets must fit the ds_read immediate");
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUFB + NW * NP * 256];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int og = lid % G.qgroups; lid /= G.qgroups;
+  const int s = lid % G.S; lid /= G.S;
+  const int head = lid % G.heads;
+  const int b = lid / G.heads;
+  const int HW = G.HW, H = G.H;
+  const int h0 = og * NW;
+  const int h = h0 + wave;                               // H % 16 == 0: every wave owns a key row
+  const long NH = (long)G.B * G.S * HW * G.heads;
+
+  // ---- slab geometry (as above)
+  const int my_lo = max(h - G.eH, 0), my_hi = min(h + G.eH, H - 1);
+  const int t_lo = max(h0 - G.eH, 0), t_hi = min(h0 + NW - 1 + G.eH, H - 1);
+  const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
+  const int c_first = t_lo >> 4, c_last = t_hi >> 4;
+  const int nch = (c_last - c_first + 1) * 2;
+  const int nslab = (sk_hi - sk_lo + 1) * nch;
+  const unsigned ld_b = (unsigned)P.ldy1 * 2u;           // == ldy2 (checked by the launcher)
+  const unsigned rs = 16u * ld_b;
+  const long ps = (long)HW * (long)ld_b;
+  const int nwin = 2 * G.eS + 1;
+  int p_first = s - G.eS;
+  { const int a = (((G.S - 1 - p_first) % nwin) + nwin) % nwin; p_first += a; }
+  if (p_first > sk_hi || p_first < sk_lo) p_first = sk_lo;
+  const char* y1pl = (const char*)(P.y1 + ((long)b * G.S + p_first) * HW * P.ldy1 + (long)head * DH);
+  const char* y2pl = (const char*)(P.y2 + ((long)b * G.S + p_first) * HW * P.ldy2 + (long)head * DH);
+  long vrow_pl = ((long)b * G.S + p_first) * HW;
+  int pl_n = p_first - sk_lo, rem_n = 0, base_n = 0, jn = 0;
+  const char* y1p = nullptr;
+  const char* y2p = nullptr;
+  char* dbuf = nullptr;
+  long vrow_n = 0;
+  auto next_state = [&]() {
+    base_n = ((c_first + (rem_n >> 1)) << 4) + (rem_n & 1);
+    y1p = y1pl + (unsigned)base_n * rs;
+    y2p = y2pl + (unsigned)base_n * rs;
+    dbuf = smem + (jn & 1) * BUFB;
+    vrow_n = vrow_pl + (long)base_n * 16;
+  };
+  auto advance = [&]() {
+    ++jn;
+    if (++rem_n == nch) {
+      rem_n = 0;
+      if (sk_lo + pl_n == sk_hi) { y1pl -= (long)pl_n * ps; y2pl -= (long)pl_n * ps; vrow_pl -= (long)pl_n * HW; pl_n = 0; }
+      else { ++pl_n; y1pl += ps; y2pl += ps; vrow_pl += HW; }
+    }
+  };
+  auto issue = [&]() {
+    const unsigned la = lds_addr(smem + TAB + wave * NP * 256) + lane_id_volatile() * 4u;
+    unsigned vo[NP];
+    static_for<NP>([&](auto i) { vo[i] = ds_read_u32_asm<i * 256>(la); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = wave + NW * i;
+      if (i * NW + NW <= I::PIECES || piece < I::PIECES) {
+        asm volatile("" : "+v"(vo[i]));
+        __builtin_amdgcn_global_load_lds((gptr_t)(y1p + vo[i]), (lptr_t)(dbuf + HDR + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(y2p + vo[i]), (lptr_t)(dbuf + HDR + Y2O + piece * 1024), 16, 0, 0);
+      }
+    }
+    if (wave < 4) {                                        // the slab's 128 deltas (waves 0, 1) and -lse / scale (waves 2, 3)
+      const int idx = (wave & 1) * 64 + (int)lane_id_volatile();
+      const long row = vrow_n + (long)(2 * (idx >> 4)) * 16 + (idx & 15);
+      const float* src = ws + (wave >> 1) * NH + row * G.heads + head;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dbuf + (wave >> 1) * (KC * 16 * 4) + (wave & 1) * 256), 4, 0, 0);
+    }
+  };
+
+  // ---- the table of DMA source offsets, then the first slab's requests
+  {
+    const int lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      *reinterpret_cast<unsigned*>(smem + TAB + (wave * NP + i) * 256 + lane * 4) = bpiece_voff<DH>(wave + NW * i, lane, ld_b, 14);
+  }
+  next_state();
+  if (nslab > 0) issue();
+
+  // ---- owner rows: K as it is, V negated (sign flip of a bf16 is exact)
+  s16x8 kf[KS], vf[KS];
+  bool in0, in1, in2, in3;
+  unsigned arow, atr, alse;                               // running LDS addresses of the step's three read patterns
+  {
+    const int lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const long row = ((long)b * G.S + s) * HW + h * 16 + li;
+    const bf16_t* r1 = P.x1 + row * P.ldx1 + (long)head * DH;
+    const bf16_t* r2 = P.x2 + row * P.ldx2 + (long)head * DH;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = *reinterpret_cast<const s16x8*>(r1 + ks * 32 + g * 8);
+      vf[ks] = *reinterpret_cast<const s16x8*>(r2 + ks * 32 + g * 8) ^ (s16x8)((short)0x8000);
+    }
+    const int d0 = 4 * g - li;
+    in0 = (d0 <= G.eW) && (-d0 <= G.eW);
+    in1 = (d0 + 1 <= G.eW) && (-d0 - 1 <= G.eW);
+    in2 = (d0 + 2 <= G.eW) && (-d0 - 2 <= G.eW);
+    in3 = (d0 + 3 <= G.eW) && (-d0 - 3 <= G.eW);
+    const unsigned base = lds_addr(smem);
+    arow = base + li * I::ROWP + g * 16;
+    atr = base + (4 * g + (li >> 2)) * I::ROWP + (li & 3) * 8;
+    alse = base + g * 16;
+  }
+  f32x4 acc1[MT], acc2[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { acc1[mt] = (f32x4)(0.f); acc2[mt] = (f32x4)(0.f); }
+
+  // S' and D' of one visiting row (XO = its byte offset inside the slab image pair: 0 or R16; LO = the same in the header).
+  // Row fragments travel in pairs: two in flight (8 registers) beside the two accumulators.
+  auto sdp_row = [&](auto XO, auto LO, f32x4& sv, f32x4& dv) {
+    constexpr int X = decltype(XO)::value, L = decltype(LO)::value;
+    sv = ds_read_f32x4_asm<KC * 16 * 4 + L>(alse);
+    if constexpr (KS >= 2) {
+      static_for<KS / 2>([&](auto PR) {
+        constexpr int k0 = 2 * decltype(PR)::value;
+        s16x8 f0 = ds_read_b128_asm<HDR + X + k0 * 64>(arow), f1 = ds_read_b128_asm<HDR + X + k0 * 64 + 64>(arow);
+        lgkm_wait_for2<1>(sv, f0);
+        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, kf[k0], sv, 0, 0, 0);
+        lgkm_wait_for2<0>(sv, f1);
+        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, kf[k0 + 1], sv, 0, 0, 0);
+        asm volatile("" : "+v"(sv));
+      });
+      dv = ds_read_f32x4_asm<L>(alse);
+      static_for<KS / 2>([&](auto PR) {
+        constexpr int k0 = 2 * decltype(PR)::value;
+        s16x8 g0 = ds_read_b128_asm<HDR + Y2O + X + k0 * 64>(arow), g1 = ds_read_b128_asm<HDR + Y2O + X + k0 * 64 + 64>(arow);
+        lgkm_wait_for2<1>(dv, g0);
+        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g0, vf[k0], dv, 0, 0, 0);
+        lgkm_wait_for2<0>(dv, g1);
+        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g1, vf[k0 + 1], dv, 0, 0, 0);
+        asm volatile("" : "+v"(dv));
+      });
+    } else {
+      dv = ds_read_f32x4_asm<L>(alse);
+      s16x8 f0 = ds_read_b128_asm<HDR + X>(arow), g0 = ds_read_b128_asm<HDR + Y2O + X>(arow);
+      lgkm_wait_for2<1>(sv, f0);
+      sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, kf[0], sv, 0, 0, 0);
+      lgkm_wait_for2<0>(dv, g0);
+      dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g0, vf[0], dv, 0, 0, 0);
+      asm volatile("" : "+v"(sv), "+v"(dv));
+    }
+  };
+  // P (masked) and P * D' of one row, packed to bf16: two registers each
+  auto pds_row = [&](const f32x4& sv, const f32x4& dv, s16x4& pk, s16x4& dk) {
+    float p0 = __builtin_amdgcn_exp2f(sv[0] * c2), p1 = __builtin_amdgcn_exp2f(sv[1] * c2);
+    float p2 = __builtin_amdgcn_exp2f(sv[2] * c2), p3 = __builtin_amdgcn_exp2f(sv[3] * c2);
+    p0 = in0 ? p0 : 0.f; p1 = in1 ? p1 : 0.f; p2 = in2 ? p2 : 0.f; p3 = in3 ? p3 : 0.f;
+    pk = cvt_pk4_bf16(p0, p1, p2, p3);
+    dk = cvt_pk4_bf16(p0 * dv[0], p1 * dv[1], p2 * dv[2], p3 * dv[3]);
+  };
+
+  int base = base_n;
+  advance();
+  next_state();
+  for (int j = 0; j < nslab; ++j) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + 1 < nslab) issue();
+    const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
+    if (lo <= hi) {
+      const unsigned off0 = (unsigned)((j & 1) * BUFB + lo * R16), hoff0 = (unsigned)((j & 1) * BUFB + lo * 64);
+      arow += off0; atr += off0; alse += hoff0;
+      int t0 = lo;
+      for (; t0 + 1 <= hi; t0 += 2) {
+        // ---- two visiting rows (32 visitors): S', D' -> P, P D' -> dK^T += Q^T (P D'), dV^T += dO^T P on MFMA 16x16x32
+        s16x8 pf, df;
+        {
+          f32x4 sv, dv;
+          s16x4 pa, da, pb, db;
+          sdp_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sv, dv);
+          pds_row(sv, dv, pa, da);
+          asm volatile("" : "+v"(pa), "+v"(da));
+          sdp_row(std::integral_constant<int, R16>{}, std::integral_constant<int, 64>{}, sv, dv);
+          pds_row(sv, dv, pb, db);
+          pf = __builtin_shufflevector(pa, pb, 0, 1, 2, 3, 4, 5, 6, 7);
+          df = __builtin_shufflevector(da, db, 0, 1, 2, 3, 4, 5, 6, 7);
+          asm volatile("" : "+v"(pf), "+v"(df));
+        }
+        // 2 MT feature tiles, one transposed fragment pair (rows A | B: 4 registers) each, a ring of three in flight: tiles
+        // 0 .. MT-1 read Q (-> acc1 with P D'), the rest dO (-> acc2 with P)
+        s16x4 ca[3], cbb[3];
+        auto rd_tile = [&](auto C) {
+          constexpr int c = decltype(C)::value;
+          constexpr int YO = HDR + (c >= MT ? Y2O : 0) + (c % MT) * 32;
+          ca[c % 3] = ds_read_tr16_asm<YO>(atr);
+          cbb[c % 3] = ds_read_tr16_asm<YO + R16>(atr);
+        };
+        rd_tile(std::integral_constant<int, 0>{});
+        rd_tile(std::integral_constant<int, 1>{});
+        rd_tile(std::integral_constant<int, 2>{});
+        static_for<2 * MT>([&](auto C) {
+          constexpr int c = decltype(C)::value;
+          constexpr int behind = (2 * MT - 1 - c) < 2 ? (2 * MT - 1 - c) : 2;      // younger tiles still in flight
+          lgkm_wait_for2<2 * behind>(ca[c % 3], cbb[c % 3]);
+          const s16x8 ya = __builtin_shufflevector(ca[c % 3], cbb[c % 3], 0, 1, 2, 3, 4, 5, 6, 7);
+          if constexpr (c < MT) {
+            acc1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya, df, acc1[c], 0, 0, 0);
+            asm volatile("" : "+v"(acc1[c]));
+          } else {
+            acc2[c - MT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya, pf, acc2[c - MT], 0, 0, 0);
+            asm volatile("" : "+v"(acc2[c - MT]));
+          }
+          if constexpr (c + 3 < 2 * MT) rd_tile(std::integral_constant<int, c + 3>{});
+        });
+        arow += 2 * R16; atr += 2 * R16; alse += 128;
+      }
+      if (t0 <= hi) {
+        // ---- odd last visiting row of the slab: 16 visitors, the accumulations on MFMA 16x16x16
+        s16x4 pa, da;
+        {
+          f32x4 sv, dv;
+          sdp_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sv, dv);
+          pds_row(sv, dv, pa, da);
+          asm volatile("" : "+v"(pa), "+v"(da));
+        }
+        s16x4 ca[4];
+        auto rd_tile = [&](auto C) {
+          constexpr int c = decltype(C)::value;
+          ca[c % 4] = ds_read_tr16_asm<HDR + (c >= MT ? Y2O : 0) + (c % MT) * 32>(atr);
+        };
+        static_for<(2 * MT < 4 ? 2 * MT : 4)>([&](auto C) { rd_tile(C); });
+        static_for<2 * MT>([&](auto C) {
+          constexpr int c = decltype(C)::value;
+          constexpr int behind = (2 * MT - 1 - c) < 3 ? (2 * MT - 1 - c) : 3;
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ca[c % 4]) : "n"(behind) : "memory");
+          f32x4& acc = c < MT ? acc1[c % MT] : acc2[c % MT];
+          acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ca[c % 4], c < MT ? da : pa, acc, 0, 0, 0);
+          asm volatile("" : "+v"(acc));
+          if constexpr (c + 4 < 2 * MT) rd_tile(std::integral_constant<int, c + 4>{});
+        });
+      }
+      const unsigned back = (unsigned)((j & 1) * BUFB + t0 * R16), hback = (unsigned)((j & 1) * BUFB + t0 * 64);
+      arow -= back; atr -= back; alse -= hback;
+    }
+    base = base_n;
+    advance();
+    next_state();
+  }
+  // ---- dK = -scale * acc1 (the sign of the negated V, the scale of dS), dV = acc2
+  const int lane = (int)lane_id_volatile(), g = lane >> 4, li = lane & 15;
+  const long orow = ((long)b * G.S + s) * HW + h * 16 + li;
+  bf16_t* g1 = P.g1 + orow * P.ldg1 + (long)head * DH;
+  bf16_t* g2 = P.g2 + orow * P.ldg2 + (long)head * DH;
+  const float ns = -G.scale;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    s16x4 pk, pv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pk[r] = (short)f32_to_bf16_bits(acc1[mt][r] * ns); pv[r] = (short)f32_to_bf16_bits(acc2[mt][r]); }
+    *reinterpret_cast<s16x4*>(g1 + mt * 16 + 4 * g) = pk;
+    *reinterpret_cast<s16x4*>(g2 + mt * 16 + 4 * g) = pv;
+  }
+}
+
 template <int DH, int MODE, int NW>
 int launch_one(const RBwdPtrs& P, AttnGeom G, hipStream_t st) {
   G.qgroups = wmz_cdiv(G.H, NW);
@@ -416,6 +707,18 @@ int launch_both(const RBwdPtrs& PQ, const RBwdPtrs& PK, const AttnGeom& G, hipSt
 #ifndef WMZ_ABWD_NWK
 #define WMZ_ABWD_NWK 8      // waves (= owner key rows) per workgroup of the dk | dv pass; 16 (a whole plane, 128 registers per wave)
 #endif                      // is a timing experiment of tools/build_variant.py
+#ifndef WMZ_ABWD_PLANE
+#define WMZ_ABWD_PLANE 1    // 1: the whole-plane 16-wave dk | dv kernel where its preconditions hold; 0: always the 8-wave form
+#endif
+  if (WMZ_ABWD_PLANE && (G.H & 15) == 0 && PK.ldy1 == PK.ldy2) {
+    AttnGeom Gp = G;
+    Gp.qgroups = G.H / 16;
+    const long nwg = (long)G.B * G.heads * G.S * Gp.qgroups;
+    hipLaunchKernelGGL((attn_bwd_kvplane_kernel<DH>), dim3((unsigned)nwg), dim3(1024), 0, st, PK, Gp, (const float*)PK.delta,
+                       G.scale * 1.4426950408889634f);
+    WMZ_LAUNCH_CHECK("wmz_local3d_attn_bwd(row16, dk|dv plane)");
+    return WMZ_OK;
+  }
   return launch_one<DH, 1, WMZ_ABWD_NWK>(PK, G, st);
 }
 

@@ -49,6 +49,16 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return *reinterpret_cast<unsigned short*>(&h);
 }
 
+// four floats -> four bf16 (round-to-nearest-even) in two registers: two v_cvt_pk_bf16_f32, nothing else
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ s16x4 cvt_pk4_bf16(float a, float b, float c, float d) {
+  const bf16x2_t lo = __builtin_convertvector((f32x2){a, b}, bf16x2_t), hi = __builtin_convertvector((f32x2){c, d}, bf16x2_t);
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const u32x2 w = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, w);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kDtype = WMZ_F32;
@@ -184,6 +194,32 @@ __device__ __forceinline__ s16x8 ds_read_b128_asm(unsigned addr) {
 }
 template <int N>
 __device__ __forceinline__ void lgkm_wait_for(s16x8& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
+// the same queue discipline for the other shapes a hand-ordered LDS queue carries: four floats (an accumulator's initial
+// value), one dword, and a wait that releases two / four values at once
+template <int OFF>
+__device__ __forceinline__ f32x4 ds_read_f32x4_asm(unsigned addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ unsigned ds_read_u32_asm(unsigned addr) {
+  unsigned r;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int N, typename A, typename B>
+__device__ __forceinline__ void lgkm_wait_for2(A& a, B& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N, typename A>
+__device__ __forceinline__ void lgkm_wait_for4(A& a, A& b, A& c, A& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+// lane id (0..63) that the optimiser can neither hoist out of a loop nor keep alive across it
+__device__ __forceinline__ unsigned lane_id_volatile() {
+  unsigned r;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(r));
+  return r;
+}
 
 // Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48 -> the same result in all four) with the
 // gfx950 row / half swaps: two VALU instructions per level, no LDS round trip (__shfl_xor is a ds_bpermute: ~100+ cycles

@@ -250,7 +250,7 @@ def local3d_attention_bwd(q, k, v, out, lse, dout, extents, heads, dqkv=None):
     v, _, ldv = _rows(v)
     out, _, ldo = _rows(out)
     dout, _, lddo = _rows(dout)
-    delta = torch.empty((B * S * H * W, heads), dtype=torch.float32, device=q.device)
+    delta = torch.empty((2, B * S * H * W, heads), dtype=torch.float32, device=q.device)   # delta | -lse / scale (wmz.h)
     if dqkv is None:
         dq = torch.empty((B, S, H, W, I), dtype=q.dtype, device=q.device)
         dkv = torch.empty((B, S, H, W, 2 * I), dtype=q.dtype, device=q.device)
