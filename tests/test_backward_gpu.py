@@ -146,3 +146,9 @@ def test_attention_backward_row16_fast_path(wmz, shape, heads, dh, ext):
     assert rel(dq, qr.grad) < 2e-2
     assert rel(dkv[..., :I], kr.grad) < 2e-2
     assert rel(dkv[..., I:], vr.grad) < 2e-2
+    # q | k | v as the column thirds of one [.., 3I] buffer (the fused to_qkv of config 5): the visiting tensors of the dk | dv pass
+    # (q and dout) then have different row strides, and the gradients land in the thirds of one buffer
+    qkv = torch.cat([qd, kd, vd], dim=-1)
+    dqkv = torch.empty_like(qkv)
+    ops.local3d_attention_bwd(qkv[..., :I], qkv[..., I:2 * I], qkv[..., 2 * I:], out, lse, dod, ext, heads, dqkv=dqkv)
+    assert torch.equal(dqkv[..., :I], dq) and torch.equal(dqkv[..., I:], dkv)

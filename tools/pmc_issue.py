@@ -21,7 +21,7 @@ PASSES = [['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'GRBM
 KERNELS = [   # key, prof_kernels.py driver, kernel-name substring, sources
     ('attn_fwd_row16_kernel', 'attn', 'attn_fwd_row16_kernel', ['attn_fwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
     ('attn_bwd_row16_kernel<dq>', 'attn_bwd', 'attn_bwd_row16_kernel<128, 0', ['attn_bwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
-    ('attn_bwd_row16_kernel<dk|dv>', 'attn_bwd', 'attn_bwd_row16_kernel<128, 1', ['attn_bwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
+    ('attn_bwd_kvplane_kernel<dk|dv>', 'attn_bwd', 'attn_bwd_kvplane_kernel<128', ['attn_bwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
     ('layer_fused_kernel<head,tail>', 'fused', 'layer_fused_kernel<256, 128, 256, true, true>', ['layer_fused.hip', 'fused_common.h', 'wmz_common.h']),
 ]
 
@@ -54,9 +54,11 @@ def one_pass(which, counters, n=8):
 
 def main():
     out = {}
-    drivers = sorted({k[1] for k in KERNELS})
+    only = os.environ.get('PMC_ONLY')                     # e.g. PMC_ONLY=attn_bwd: just that driver's kernels
+    kernels = [k for k in KERNELS if not only or k[1] == only]
+    drivers = sorted({k[1] for k in kernels})
     data = {w: [one_pass(w, p) for p in PASSES] for w in drivers}
-    for key, which, match, sources in KERNELS:
+    for key, which, match, sources in kernels:
         ent = {}
         for rows in data[which]:
             for name, ctrs in rows.items():

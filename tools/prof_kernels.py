@@ -17,8 +17,10 @@ N = 65536
 x = torch.randn(8, 32, 16, 16, 256, device='cuda').bfloat16()
 o = torch.randn(8, 32, 16, 16, 128, device='cuda').bfloat16()
 layers = list(m.transformer.layers)
-qkv = torch.randn(8, 32, 16, 16, 384, device='cuda').bfloat16()
-q, k, v = qkv[..., :128], qkv[..., 128:256], qkv[..., 256:]
+# the layouts of the training step: q its own [N, I] buffer, k | v the two column halves of one [N, 2I] buffer
+q = torch.randn(8, 32, 16, 16, 128, device='cuda').bfloat16()
+kv = torch.randn(8, 32, 16, 16, 256, device='cuda').bfloat16()
+k, v = kv[..., :128], kv[..., 128:]
 if which == 'attn_bwd':
     out, lse, _ = ops.local3d_attention_fwd(q, k, v, (3, 3, 3), 1, need_lse=True)
     dout = torch.randn_like(out)

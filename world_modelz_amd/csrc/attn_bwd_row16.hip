@@ -20,6 +20,12 @@
 //   * the per-element arithmetic folds the constants: exponent = fma(s, c2, bias - lse2), dS = P * fma(dP, scale, -delta *
 //     scale) (MODE 0: both addends live in registers for the whole kernel).
 #include "attn_common.h"
+#ifndef WMZ_KV_RING
+#define WMZ_KV_RING 2       // dk | dv plane kernel: row fragments in flight per wave (2 or 3) ...
+#endif
+#ifndef WMZ_KV_TRING
+#define WMZ_KV_TRING 3      // ... and transposed fragment pairs in flight
+#endif
 #ifndef WMZ_ABWD_ABL
 #define WMZ_ABWD_ABL 0      // timing ablations (tools/build_variant.py; results are garbage): 1 no compute, 2 no slab DMA, 4 no LDS fragment reads, 8 no MFMAs, 16 no exp / dS arithmetic
 #endif
@@ -50,6 +56,32 @@ __device__ __forceinline__ unsigned bpiece_voff(int piece, int lane, unsigned ld
   c = c < DH / 8 ? c : 0;
   const int prow = min(2 * (r >> 4), row_lim);
   return (unsigned)((prow << 4) + (r & 15)) * ld_bytes + (unsigned)c * 16u;
+}
+
+// Epilogue store of an owner row's accumulators acc[mt][r] = G^T[feature 16 mt + 4 g + r][owner li] (times mul) as bf16: lanes
+// g and g ^ 1 exchange halves (v_permlane16_swap) so that every lane stores 16 contiguous bytes -- per wave instruction 64
+// contiguous bytes per owner row instead of 32, half as many stores (the forward kernel's epilogue, attn_fwd_row16.hip).
+template <int MT>
+__device__ __forceinline__ void store_owner_rows(bf16_t* row, const f32x4 (&acc)[MT], float mul, int g) {
+  if constexpr (MT % 2 == 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt += 2) {
+      const s16x4 a = cvt_pk4_bf16(acc[mt][0] * mul, acc[mt][1] * mul, acc[mt][2] * mul, acc[mt][3] * mul);
+      const s16x4 b = cvt_pk4_bf16(acc[mt + 1][0] * mul, acc[mt + 1][1] * mul, acc[mt + 1][2] * mul, acc[mt + 1][3] * mul);
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      const u32x2 au = __builtin_bit_cast(u32x2, a), bu = __builtin_bit_cast(u32x2, b);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], bu[0], false, false);     // odd rows of a <-> even rows of b
+      const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], bu[1], false, false);
+      i32x4 pk;
+      pk[0] = (int)s0[0]; pk[1] = (int)s1[0]; pk[2] = (int)s0[1]; pk[3] = (int)s1[1];
+      const int col = (g & 1) ? (mt + 1) * 16 + 4 * (g - 1) : mt * 16 + 4 * g;
+      *reinterpret_cast<i32x4*>(row + col) = pk;
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      *reinterpret_cast<s16x4*>(row + mt * 16 + 4 * g) = cvt_pk4_bf16(acc[mt][0] * mul, acc[mt][1] * mul, acc[mt][2] * mul, acc[mt][3] * mul);
+  }
 }
 
 struct RBwdPtrs {
@@ -166,7 +198,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
 
   // ---- owner rows (after the first slab's requests: both are in flight together)
   Frag8<bf16_t> x1f[KS], x2f[KS];
-  float bl[4], nde = 0.f;                                // MODE 0: bias - own lse2 per column; -own delta * scale
+  float bl[4], nde = 0.f;                                // MODE 0: the accumulators' initial values -- (bias - own lse2) / c2 per
+                                                         // column (S' = Q.K + that, exponent = c2 S') and -own delta (D' = dP - delta)
   {
     const long row = plane_o + (active ? h : 0) * 16 + li;
     const bf16_t* r1 = P.x1 + row * P.ldx1 + (long)head * DH;
@@ -190,8 +223,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
       dsum = wave_groups_sum(dsum);
       const float own_lse = P.lse[row * G.heads + head] * L2E;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bl[r] = bias[r] - own_lse;
-      nde = -dsum * G.scale;
+      for (int r = 0; r < 4; ++r) bl[r] = (bias[r] - own_lse) / c2;
+      nde = -dsum;
       if (active && g == 0) {
         // workspace for the dk | dv pass: delta, and behind it (one row of [tokens, heads] further) -lse / scale -- the initial
         // values of its dP and S accumulators
@@ -234,6 +267,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
         const int ro0 = rbase + t0 * 16 * I::ROWP, ro1 = ro0 + 16 * I::ROWP;
         const int to0 = tbase + t0 * 16 * I::ROWP;
         f32x4 s0 = (f32x4)(0.f), s1 = (f32x4)(0.f), d0 = (f32x4)(0.f), d1 = (f32x4)(0.f);
+        if constexpr (MODE == 0) { s0 = s1 = (f32x4){bl[0], bl[1], bl[2], bl[3]}; d0 = d1 = (f32x4)(nde); }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           Frag8<bf16_t> a0, a1, b0, b1;
@@ -297,10 +331,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bl[r]));
-            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, bl[r]));
-            dsv[r] = p0 * fmaf(d0[r], G.scale, nde);
-            dsv[4 + r] = p1 * fmaf(d1[r], G.scale, nde);
+            dsv[r] = __builtin_amdgcn_exp2f(s0[r] * c2) * d0[r];          // dS / scale: the scale waits for the epilogue
+            dsv[4 + r] = __builtin_amdgcn_exp2f(s1[r] * c2) * d1[r];
           }
         }
         Frag8<bf16_t> dsf, pf;
@@ -329,6 +361,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
         const int ro0 = rbase + t0 * 16 * I::ROWP;
         const int to0 = tbase + t0 * 16 * I::ROWP;
         f32x4 s0 = (f32x4)(0.f), d0 = (f32x4)(0.f);
+        if constexpr (MODE == 0) { s0 = (f32x4){bl[0], bl[1], bl[2], bl[3]}; d0 = (f32x4)(nde); }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           Frag8<bf16_t> a0, b0;
@@ -352,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dsv[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, bl[r])) * fmaf(d0[r], G.scale, nde);
+          for (int r = 0; r < 4; ++r) dsv[r] = __builtin_amdgcn_exp2f(s0[r] * c2) * d0[r];
         }
         s16x4 dsf, pf;
 #pragma unroll
@@ -385,23 +418,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
   if (!active) return;
   const long orow = plane_o + h * 16 + li;
   bf16_t* g1 = P.g1 + orow * P.ldg1 + (long)head * DH;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    s16x4 pk;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(acc1[mt][r]);
-    *reinterpret_cast<s16x4*>(g1 + mt * 16 + 4 * g) = pk;
-  }
-  if constexpr (MODE == 1) {
-    bf16_t* g2 = P.g2 + orow * P.ldg2 + (long)head * DH;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      s16x4 pk;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_bits(acc2[mt][r]);
-      *reinterpret_cast<s16x4*>(g2 + mt * 16 + 4 * g) = pk;
-    }
-  }
+  store_owner_rows<MT>(g1, acc1, MODE == 0 ? G.scale : 1.f, g);
+  if constexpr (MODE == 1) store_owner_rows<MT>(P.g2 + orow * P.ldg2 + (long)head * DH, acc2, 1.f, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -420,8 +438,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
 //   * one visitor operand's fragments at a time: row fragments four in flight (16 registers), transposed fragments as a
 //     double-buffered pair of 2-feature-tile chunks (16 registers); every LDS read is inline asm retired by a counted lgkmcnt
 //     wait that names what it releases, every MFMA result is pinned at its program point (the scheduler may not widen a live range).
-// Requires whole 16-row chunks (H % 16 == 0) and one row stride for both visiting tensors; everything else takes the 8-wave form.
-template <int DH>
+// Requires whole 16-row chunks (H % 16 == 0); everything else takes the 8-wave form.  SAME_LD: both visiting tensors have one row
+// stride and the table holds the byte offsets themselves (otherwise row and column, two multiply-adds per piece and tensor).
+template <int DH, bool SAME_LD>
 __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, AttnGeom G, const float* ws, float c2) {   // c2 = scale * log2(e): a kernel argument stays scalar
   using I = BImg<DH>;
   constexpr int NW = 16, KS = DH / 32, MT = DH / 16;
@@ -453,9 +472,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
   const int c_first = t_lo >> 4, c_last = t_hi >> 4;
   const int nch = (c_last - c_first + 1) * 2;
   const int nslab = (sk_hi - sk_lo + 1) * nch;
-  const unsigned ld_b = (unsigned)P.ldy1 * 2u;           // == ldy2 (checked by the launcher)
-  const unsigned rs = 16u * ld_b;
-  const long ps = (long)HW * (long)ld_b;
+  const unsigned ld1_b = (unsigned)P.ldy1 * 2u, ld2_b = (unsigned)P.ldy2 * 2u;      // SAME_LD: equal
+  const unsigned rs1 = 16u * ld1_b, rs2 = 16u * ld2_b;
+  const long ps1 = (long)HW * (long)ld1_b, ps2 = (long)HW * (long)ld2_b;
   const int nwin = 2 * G.eS + 1;
   int p_first = s - G.eS;
   { const int a = (((G.S - 1 - p_first) % nwin) + nwin) % nwin; p_first += a; }
@@ -470,8 +489,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
   long vrow_n = 0;
   auto next_state = [&]() {
     base_n = ((c_first + (rem_n >> 1)) << 4) + (rem_n & 1);
-    y1p = y1pl + (unsigned)base_n * rs;
-    y2p = y2pl + (unsigned)base_n * rs;
+    y1p = y1pl + (unsigned)base_n * rs1;
+    y2p = y2pl + (unsigned)base_n * rs2;
     dbuf = smem + (jn & 1) * BUFB;
     vrow_n = vrow_pl + (long)base_n * 16;
   };
@@ -479,8 +498,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
     ++jn;
     if (++rem_n == nch) {
       rem_n = 0;
-      if (sk_lo + pl_n == sk_hi) { y1pl -= (long)pl_n * ps; y2pl -= (long)pl_n * ps; vrow_pl -= (long)pl_n * HW; pl_n = 0; }
-      else { ++pl_n; y1pl += ps; y2pl += ps; vrow_pl += HW; }
+      if (sk_lo + pl_n == sk_hi) { y1pl -= (long)pl_n * ps1; y2pl -= (long)pl_n * ps2; vrow_pl -= (long)pl_n * HW; pl_n = 0; }
+      else { ++pl_n; y1pl += ps1; y2pl += ps2; vrow_pl += HW; }
     }
   };
   auto issue = [&]() {
@@ -493,8 +512,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
       const int piece = wave + NW * i;
       if (i * NW + NW <= I::PIECES || piece < I::PIECES) {
         asm volatile("" : "+v"(vo[i]));
-        __builtin_amdgcn_global_load_lds((gptr_t)(y1p + vo[i]), (lptr_t)(dbuf + HDR + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(y2p + vo[i]), (lptr_t)(dbuf + HDR + Y2O + piece * 1024), 16, 0, 0);
+        unsigned a1 = vo[i], a2 = vo[i];
+        if constexpr (!SAME_LD) {                          // table entry = slab-image row << 8 | byte offset inside the row
+          a1 = (vo[i] >> 8) * ld1_b + (vo[i] & 0xffu);
+          a2 = (vo[i] >> 8) * ld2_b + (vo[i] & 0xffu);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(y1p + a1), (lptr_t)(dbuf + HDR + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(y2p + a2), (lptr_t)(dbuf + HDR + Y2O + piece * 1024), 16, 0, 0);
       }
     }
     if (wave < 4) {                                        // the slab's 128 deltas (waves 0, 1) and -lse / scale (waves 2, 3)
@@ -510,7 +534,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
     const int lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-      *reinterpret_cast<unsigned*>(smem + TAB + (wave * NP + i) * 256 + lane * 4) = bpiece_voff<DH>(wave + NW * i, lane, ld_b, 14);
+      *reinterpret_cast<unsigned*>(smem + TAB + (wave * NP + i) * 256 + lane * 4) =
+          SAME_LD ? bpiece_voff<DH>(wave + NW * i, lane, ld1_b, 14) : bpiece_voff<DH>(wave + NW * i, lane, 256u, 14);
   }
   next_state();
   if (nslab > 0) issue();
@@ -549,24 +574,29 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
     constexpr int X = decltype(XO)::value, L = decltype(LO)::value;
     sv = ds_read_f32x4_asm<KC * 16 * 4 + L>(alse);
     if constexpr (KS >= 2) {
-      static_for<KS / 2>([&](auto PR) {
-        constexpr int k0 = 2 * decltype(PR)::value;
-        s16x8 f0 = ds_read_b128_asm<HDR + X + k0 * 64>(arow), f1 = ds_read_b128_asm<HDR + X + k0 * 64 + 64>(arow);
-        lgkm_wait_for2<1>(sv, f0);
-        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, kf[k0], sv, 0, 0, 0);
-        lgkm_wait_for2<0>(sv, f1);
-        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, kf[k0 + 1], sv, 0, 0, 0);
-        asm volatile("" : "+v"(sv));
-      });
+      // the two chains alternate (consecutive MFMAs never depend on each other); fragments Q0 dO0 Q1 dO1 ... in a ring of
+      // WMZ_KV_RING (2 or 3) in flight
       dv = ds_read_f32x4_asm<L>(alse);
-      static_for<KS / 2>([&](auto PR) {
-        constexpr int k0 = 2 * decltype(PR)::value;
-        s16x8 g0 = ds_read_b128_asm<HDR + Y2O + X + k0 * 64>(arow), g1 = ds_read_b128_asm<HDR + Y2O + X + k0 * 64 + 64>(arow);
-        lgkm_wait_for2<1>(dv, g0);
-        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g0, vf[k0], dv, 0, 0, 0);
-        lgkm_wait_for2<0>(dv, g1);
-        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g1, vf[k0 + 1], dv, 0, 0, 0);
-        asm volatile("" : "+v"(dv));
+      constexpr int NF = 2 * KS, RING = WMZ_KV_RING;
+      s16x8 fr[RING];
+      auto rd = [&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        fr[i % RING] = ds_read_b128_asm<HDR + X + (i & 1) * Y2O + (i >> 1) * 64>(arow);
+      };
+      static_for<RING>([&](auto Ic) { rd(Ic); });
+      static_for<NF>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        constexpr int behind = (NF - 1 - i) < (RING - 1) ? (NF - 1 - i) : (RING - 1);
+        if constexpr ((i & 1) == 0) {
+          lgkm_wait_for2<behind>(sv, fr[i % RING]);
+          sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i % RING], kf[i >> 1], sv, 0, 0, 0);
+          asm volatile("" : "+v"(sv));
+        } else {
+          lgkm_wait_for2<behind>(dv, fr[i % RING]);
+          dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i % RING], vf[i >> 1], dv, 0, 0, 0);
+          asm volatile("" : "+v"(dv));
+        }
+        if constexpr (i + RING < NF) rd(std::integral_constant<int, i + RING>{});
       });
     } else {
       dv = ds_read_f32x4_asm<L>(alse);
@@ -593,9 +623,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
   for (int j = 0; j < nslab; ++j) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (j + 1 < nslab) issue();
+    if (j + 1 < nslab && !(WMZ_ABWD_ABL & 2)) issue();
     const int lo = max(0, (my_lo - base + 1) >> 1), hi = min(KC - 1, (my_hi - base) >> 1);   // slab rows this wave needs
-    if (lo <= hi) {
+    if (lo <= hi && !(WMZ_ABWD_ABL & 1)) {
       const unsigned off0 = (unsigned)((j & 1) * BUFB + lo * R16), hoff0 = (unsigned)((j & 1) * BUFB + lo * 64);
       arow += off0; atr += off0; alse += hoff0;
       int t0 = lo;
@@ -616,21 +646,20 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
         }
         // 2 MT feature tiles, one transposed fragment pair (rows A | B: 4 registers) each, a ring of three in flight: tiles
         // 0 .. MT-1 read Q (-> acc1 with P D'), the rest dO (-> acc2 with P)
-        s16x4 ca[3], cbb[3];
+        constexpr int TR = WMZ_KV_TRING < 2 * MT ? WMZ_KV_TRING : 2 * MT;
+        s16x4 ca[TR], cbb[TR];
         auto rd_tile = [&](auto C) {
           constexpr int c = decltype(C)::value;
           constexpr int YO = HDR + (c >= MT ? Y2O : 0) + (c % MT) * 32;
-          ca[c % 3] = ds_read_tr16_asm<YO>(atr);
-          cbb[c % 3] = ds_read_tr16_asm<YO + R16>(atr);
+          ca[c % TR] = ds_read_tr16_asm<YO>(atr);
+          cbb[c % TR] = ds_read_tr16_asm<YO + R16>(atr);
         };
-        rd_tile(std::integral_constant<int, 0>{});
-        rd_tile(std::integral_constant<int, 1>{});
-        rd_tile(std::integral_constant<int, 2>{});
+        static_for<TR>([&](auto C) { rd_tile(C); });
         static_for<2 * MT>([&](auto C) {
           constexpr int c = decltype(C)::value;
-          constexpr int behind = (2 * MT - 1 - c) < 2 ? (2 * MT - 1 - c) : 2;      // younger tiles still in flight
-          lgkm_wait_for2<2 * behind>(ca[c % 3], cbb[c % 3]);
-          const s16x8 ya = __builtin_shufflevector(ca[c % 3], cbb[c % 3], 0, 1, 2, 3, 4, 5, 6, 7);
+          constexpr int behind = (2 * MT - 1 - c) < (TR - 1) ? (2 * MT - 1 - c) : (TR - 1);      // younger tiles still in flight
+          lgkm_wait_for2<2 * behind>(ca[c % TR], cbb[c % TR]);
+          const s16x8 ya = __builtin_shufflevector(ca[c % TR], cbb[c % TR], 0, 1, 2, 3, 4, 5, 6, 7);
           if constexpr (c < MT) {
             acc1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya, df, acc1[c], 0, 0, 0);
             asm volatile("" : "+v"(acc1[c]));
@@ -638,7 +667,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
             acc2[c - MT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya, pf, acc2[c - MT], 0, 0, 0);
             asm volatile("" : "+v"(acc2[c - MT]));
           }
-          if constexpr (c + 3 < 2 * MT) rd_tile(std::integral_constant<int, c + 3>{});
+          if constexpr (c + TR < 2 * MT) rd_tile(std::integral_constant<int, c + TR>{});
         });
         arow += 2 * R16; atr += 2 * R16; alse += 128;
       }
@@ -679,15 +708,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
   const long orow = ((long)b * G.S + s) * HW + h * 16 + li;
   bf16_t* g1 = P.g1 + orow * P.ldg1 + (long)head * DH;
   bf16_t* g2 = P.g2 + orow * P.ldg2 + (long)head * DH;
-  const float ns = -G.scale;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    s16x4 pk, pv;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pk[r] = (short)f32_to_bf16_bits(acc1[mt][r] * ns); pv[r] = (short)f32_to_bf16_bits(acc2[mt][r]); }
-    *reinterpret_cast<s16x4*>(g1 + mt * 16 + 4 * g) = pk;
-    *reinterpret_cast<s16x4*>(g2 + mt * 16 + 4 * g) = pv;
-  }
+  store_owner_rows<MT>(g1, acc1, -G.scale, g);
+  store_owner_rows<MT>(g2, acc2, 1.f, g);
 }
 
 template <int DH, int MODE, int NW>
@@ -710,12 +732,15 @@ int launch_both(const RBwdPtrs& PQ, const RBwdPtrs& PK, const AttnGeom& G, hipSt
 #ifndef WMZ_ABWD_PLANE
 #define WMZ_ABWD_PLANE 1    // 1: the whole-plane 16-wave dk | dv kernel where its preconditions hold; 0: always the 8-wave form
 #endif
-  if (WMZ_ABWD_PLANE && (G.H & 15) == 0 && PK.ldy1 == PK.ldy2) {
+  if (WMZ_ABWD_PLANE && (G.H & 15) == 0) {
     AttnGeom Gp = G;
     Gp.qgroups = G.H / 16;
     const long nwg = (long)G.B * G.heads * G.S * Gp.qgroups;
-    hipLaunchKernelGGL((attn_bwd_kvplane_kernel<DH>), dim3((unsigned)nwg), dim3(1024), 0, st, PK, Gp, (const float*)PK.delta,
-                       G.scale * 1.4426950408889634f);
+    const float c2 = G.scale * 1.4426950408889634f;
+    if (PK.ldy1 == PK.ldy2)
+      hipLaunchKernelGGL((attn_bwd_kvplane_kernel<DH, true>), dim3((unsigned)nwg), dim3(1024), 0, st, PK, Gp, (const float*)PK.delta, c2);
+    else
+      hipLaunchKernelGGL((attn_bwd_kvplane_kernel<DH, false>), dim3((unsigned)nwg), dim3(1024), 0, st, PK, Gp, (const float*)PK.delta, c2);
     WMZ_LAUNCH_CHECK("wmz_local3d_attn_bwd(row16, dk|dv plane)");
     return WMZ_OK;
   }
