@@ -379,16 +379,29 @@ def main():
     # headline line as measured and ends the rank, so that the launcher sees N clean exits and the line is not lost.
     import threading
     printed = threading.Lock()
+    # what the watchdog prints is a COPY of the line taken before the secondary figures start: the main thread goes on
+    # adding keys to `out`, and a dict that changes under json.dumps raises
+    import copy
+    headline_snapshot = copy.deepcopy(out)
+    WATCHDOG_EXIT = 3
 
     def secondary_watchdog():
+        """A secondary figure hung (a rank waiting in a collective the others never reach): print the headline as measured and
+        end THIS process with a non-zero status -- the launcher and CI must see the hang.  Every rank runs the same timer and it
+        stays armed through the final barrier, so the healthy ranks (blocked in that barrier against the one that hung) end the
+        same way instead of waiting for the collective's own timeout.  Nothing is restarted or re-executed."""
         if not printed.acquire(blocking=False):
             return
         if rank == 0:
-            out['secondary_error'] = (f'secondary figures did not finish within {a.secondary_timeout} s on {world} ranks '
-                                      '(a collective hung?); the headline above was measured before them')
-            out.setdefault('cpu_baseline', None)
-            print(json.dumps(out), flush=True)
-        os._exit(0)
+            line = headline_snapshot
+            line['secondary_error'] = (f'secondary figures did not finish within {a.secondary_timeout} s on {world} ranks '
+                                       '(a collective hung?); the headline above was measured before them; exit status '
+                                       f'{WATCHDOG_EXIT}')
+            line.setdefault('cpu_baseline', None)
+            print(json.dumps(line), flush=True)
+        sys.stderr.write(f'[bench] rank {rank}: secondary-figure watchdog fired after {a.secondary_timeout} s\n')
+        sys.stderr.flush()
+        os._exit(WATCHDOG_EXIT)
 
     watchdog = None
     if world > 1 and a.secondary_timeout > 0:
@@ -689,8 +702,33 @@ def main():
         if a.train_steps > 0:
             from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame
             model.train()
-            tr = DenoiserTrainer(model, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=world > 1)
             rfix = torch.full((cfg['B'],), 0.5)
+            single_ms = None
+            if world > 1 and not a.eager:
+                # the SAME step without the data-parallel reducer, in this process, on a copy of the model, before the reducer
+                # exists: what one rank does alone on its B clips.  Per-GPU work is fixed (weak scaling), so
+                # scaling_efficiency = single-rank step time / data-parallel step time is the fraction of N x the single-GPU
+                # throughput the N ranks reach together (north_star: >= 6x at 8 GPUs <=> efficiency >= 0.75).
+                import copy as _copy
+                m1 = _copy.deepcopy(model)
+                t1 = DenoiserTrainer(m1, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=False)
+                t1.enable_graph(z)
+                for _ in range(5):
+                    t1.train_step(z, r=rfix)
+                barrier()
+                s0_ = time.perf_counter()
+                for _ in range(a.train_steps):
+                    t1.train_step(z, r=rfix)
+                torch.cuda.synchronize()
+                barrier()
+                sel_ = time.perf_counter() - s0_
+                tt = torch.tensor([sel_], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                single_ms = float(tt.item()) / a.train_steps * 1e3
+                log(f'single-rank reference training step (no reducer): {single_ms:.3f} ms')
+                del t1, m1
+                gc.collect()
+            tr = DenoiserTrainer(model, cfg['C'], lr=1e-4, warmup=500, max_steps=200000, distributed=world > 1)
             # hipGraph replay is the launch mode at every world size: the per-layer RCCL all-reduces are captured with the step
             # (side-stream fork / join inside the graph).  gloo (rehearsals on shared cards) cannot be captured: eager there.
             graphed = not a.eager and (world == 1 or backend == 'nccl')
@@ -758,6 +796,11 @@ def main():
                      'eager_ms_per_step': eager_ms, 'graph_capture_error': graph_error,
                      'grad_allreduce_buckets': len(tr.reducer.buckets) if tr.reducer else 0,
                      'grad_allreduce_overlap': overlap,
+                     # n_gpus > 1: the same graphed step without the reducer, timed in this process (max over ranks), and
+                     # single / data-parallel = the weak-scaling efficiency of the training step (x n_gpus = the speed-up)
+                     'single_rank_ms_per_step': single_ms,
+                     'scaling_efficiency': (single_ms / tms) if single_ms else None,
+                     'speedup_over_one_gpu': (single_ms / tms * world) if single_ms else None,
                      'train_roofline': {'algorithmic_flops_per_step': 3.0 * fwd_flops,
                                         'achieved_TFLOPs': 3.0 * fwd_flops / (tms * 1e-3) / 1e12, 'mfma_peak_TFLOPs': 2500.0,
                                         'frac_of_mfma_peak': 3.0 * fwd_flops / (tms * 1e-3) / 1e12 / 2500.0,
@@ -810,23 +853,30 @@ def main():
         import traceback
         out['secondary_error'] = ''.join(traceback.format_exception_only(type(e), e)).strip()[:500]
         log('secondary figure failed: ' + out['secondary_error'])
-    if watchdog is not None:
-        watchdog.cancel()
-    if not printed.acquire(blocking=False):
-        time.sleep(3600)            # the watchdog is printing / ending this rank
-    if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
-            log(f'cpu baseline on {usable_cores()} threads')
+    if rank == 0 and not a.no_cpu_baseline:
+        # the oracle timed on this host's cores, on rank 0 at EVERY world size (the other ranks wait in the barrier below; their
+        # watchdogs stay armed)
+        log(f'cpu baseline on {usable_cores()} threads')
+        try:
             out['cpu_baseline'] = cpu_baseline(cfg, sd_cpu)
-        else:
+        except Exception as e:  # noqa: BLE001
             out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
+            out['cpu_baseline_error'] = f'{type(e).__name__}: {e}'[:300]
+    elif rank == 0:
+        out['cpu_baseline'] = None
     if world > 1:
         # Leave without tearing the communicator down by hand: trainers of this process hold captured hipGraphs with RCCL kernels
         # in them, and a destroy_process_group() that aborts would turn a measured run into a failed one.  Everything is drained
-        # and every rank has passed the barrier; the process exit frees the rest.
+        # and every rank passes the barrier; the process exit frees the rest.
         torch.cuda.synchronize()
         barrier()
+    if watchdog is not None:
+        watchdog.cancel()                  # only now: a rank that hung above must take the others down with it, not strand them
+    if not printed.acquire(blocking=False):
+        time.sleep(3600)                   # the watchdog is printing / ending this rank
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)

@@ -74,6 +74,85 @@ def test_bucketed_allreduce_world2():
     assert buckets[0][0] == 0 and buckets[-1][1] == arena.numel
 
 
+class _DirectLinear(torch.autograd.Function):
+    """y = x W^T whose backward writes dW straight into the parameter's arena slice and announces it (`_wmz_ready`), returning
+    None to autograd -- what the HIP backward kernels do (backward._emit)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w = ctx.w
+        w._wmz_grad.add_(dy.t() @ x)
+        ready = getattr(w, '_wmz_ready', None)
+        if ready is not None:
+            ready()
+        return dy @ w.detach(), None
+
+
+class _TwoNodeBlock(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(11)
+        self.a = torch.nn.Parameter(torch.randn(16, 8) * 0.3)
+        self.b = torch.nn.Parameter(torch.randn(16, 16) * 0.3)
+        self.c = torch.nn.Parameter(torch.randn(4, 16) * 0.3)
+
+    def forward(self, x):
+        h = torch.tanh(_DirectLinear.apply(x, self.a))
+        h = torch.tanh(_DirectLinear.apply(h, self.b))
+        return _DirectLinear.apply(h, self.c)
+
+
+def _worker_direct(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from world_modelz_amd.parallel import BucketedAllReduce, FlatArena
+    torch.set_num_threads(1)
+    model = _TwoNodeBlock()
+    arena = FlatArena(model)
+    red = BucketedAllReduce(arena, group_of=lambda name: 'all')         # ONE bucket fed by three autograd nodes
+    assert len(red.buckets) == 1
+    torch.manual_seed(100)
+    x = torch.randn(8, 8)
+    launched_with = []
+    orig = red._launch
+    red._launch = lambda b: (launched_with.append([float(p._wmz_grad.abs().sum()) > 0 for p in arena.params]), orig(b))[1]
+    for it in range(2):
+        arena.zero_grad()
+        model(x[rank * 4:(rank + 1) * 4]).square().mean().backward()
+        scale = red.finish()
+    ret[rank] = ((arena.flat_grad * scale).clone(), launched_with)
+    dist.destroy_process_group()
+
+
+def test_bucket_waits_for_every_autograd_node_that_writes_in_place():
+    """A bucket whose gradients are written in place by SEVERAL autograd nodes (the op-by-op HIP backward: feed-forward node, then
+    attention node of one layer) is reduced once ALL of them have written: torch runs a parameter's post-accumulate hooks even
+    for the None an in-place node returns, and counting that echo launched the collective after the first node (replicas
+    diverged on the GPU in fp32; this is the CPU restatement)."""
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_direct, args=(2, _free_port(), ret), nprocs=2, join=True)
+        (g0, l0), (g1, _) = ret[0], ret[1]
+    assert torch.equal(g0, g1)
+    assert len(l0) == 2 and all(all(flags) for flags in l0), l0          # one launch per step, every gradient already written
+    model = _TwoNodeBlock()
+    from world_modelz_amd.parallel import FlatArena
+    arena = FlatArena(model)
+    torch.manual_seed(100)
+    x = torch.randn(8, 8)
+    (0.5 * (model(x[:4]).square().mean() + model(x[4:]).square().mean())).backward()
+    assert torch.allclose(g0, arena.flat_grad, rtol=1e-5, atol=1e-7)
+
+
 def test_flat_arena_views_and_zero_grad():
     from world_modelz_amd.parallel import FlatArena
     model = _model()

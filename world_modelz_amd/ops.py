@@ -285,7 +285,7 @@ def linear_dgrad(dc, weight_t, dgelu_z=None):
 
 def workspace_snapshot(device):
     """The per-device library workspaces as they are now (strong references): a captured hipGraph bakes their addresses in,
-    so its owner holds this tuple and re-captures when workspace_same() says one was replaced by a larger one."""
+    so its owner holds this tuple: when ops later replaces one by a larger allocation, the graph goes on using the one it holds."""
     device = torch.device(device)
     if device.type == 'cuda' and device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
@@ -320,7 +320,7 @@ def _workspace(device, floats):
 # edges of the graph).  At small token counts (config 5: 3 072 rows per GPU) every kernel of the backward is a partial wave of
 # latency-bound workgroups, and the weight gradients -- a third of the step's kernel time -- run beside the chain instead of
 # inside it.  The data-parallel reducer waits for this stream as well before it all-reduces a bucket (parallel._launch).
-_wgrad_side = {}          # device -> [stream, launches pending a join, its own reduction workspace]
+_wgrad_side = {}          # device -> [stream, launches pending a join, its own reduction workspace, operands held until the join]
 _arena_depth = 0          # > 0 inside backward._emit*: the gradient being produced lands in the arena
 _side_blocked = 0         # > 0: a block backward whose incoming gradient is handed on to autograd as it is (see side_blocked)
 
@@ -434,6 +434,23 @@ def wgrad_join():
         if ent[1]:
             torch.cuda.current_stream(dev).wait_stream(ent[0])
             ent[1] = False
+        # only now may the operands go: until the join the side stream may still be READING them, and while this list holds a
+        # reference autograd cannot take a gradient buffer for an in-place accumulation (its storage is shared)
+        del ent[3][:]
+
+
+def wgrad_reset():
+    """Forget every queued / deferred side-stream launch and the bookkeeping around them: called before a step is captured and
+    after a capture or a backward pass failed, so that nothing stale is flushed into the next step."""
+    global _pending, _arena_depth, _side_blocked, _flushing
+    _pending = []
+    del _deferred[:]
+    _arena_depth = _side_blocked = 0
+    _flushing = False
+    L.after_call = None
+    for ent in _wgrad_side.values():
+        ent[1] = False
+        del ent[3][:]
 
 
 def wgrad_side_wait(stream):
@@ -463,10 +480,11 @@ def _wgrad_side_enter(device, tensors):
         device = torch.device('cuda', torch.cuda.current_device())
     ent = _wgrad_side.get(device)
     if ent is None:
-        ent = _wgrad_side[device] = [torch.cuda.Stream(device=device), False, None]
+        ent = _wgrad_side[device] = [torch.cuda.Stream(device=device), False, None, []]
     for t in tensors:
         if t is not None:
             t.record_stream(ent[0])
+            ent[3].append(t)                # alive (and not uniquely owned) until wgrad_join()
     ent[1] = True
     fork = torch.cuda.Event()
     fork.record(torch.cuda.current_stream(device))      # the operands are complete here

@@ -97,25 +97,44 @@ class BucketedAllReduce:
         self.launched = []
         self._hooks = []
         self._timing = None                    # enable_timing(): [(start, end) events of every collective], [(w0, w1) of finish()]
+        self._direct = [False] * len(arena.params)
         if self.active:
             for i, p in enumerate(arena.params):
-                hook = self._make_hook(i)
-                self._hooks.append(p.register_post_accumulate_grad_hook(hook))     # gradients arriving through autograd
-                p._wmz_ready = (lambda h=hook, q=p: h(q))                          # ... and those written in place
+                from_autograd, from_kernel = self._make_hooks(i)
+                self._hooks.append(p.register_post_accumulate_grad_hook(from_autograd))   # gradients arriving through autograd
+                p._wmz_ready = from_kernel                                             # ... and those written in place
         self.reset()
 
     def reset(self):
         self.pending = [len(idxs) * self.rounds for (_, _, idxs) in self.buckets]
         self.handles = []
         self.launched = [False] * len(self.buckets)
+        self._direct = [False] * len(self._direct)
 
-    def _make_hook(self, i):
-        def hook(_param):
+    def _make_hooks(self, i):
+        """A parameter's gradient is counted ONCE per backward pass, whichever way it arrives.  A backward kernel that wrote it
+        straight into the arena says so itself (`_wmz_ready`, inside the autograd node's backward) and hands autograd None --
+        and torch (2.10) then still runs the parameter's post-accumulate hooks for that undefined gradient when the node
+        returns: that echo must not count a second time (with several autograd nodes per bucket -- the op-by-op path: a
+        layer's feed-forward node, then its attention node -- the doubled counts of the first node's parameters launched the
+        bucket's all-reduce before the second node had written its gradients: replicas diverged; found by the fp32 two-rank
+        test of round 4)."""
+        def count():
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
                 self._launch(b)
-        return hook
+
+        def from_autograd(_param):
+            if self._direct[i]:                # the echo of a gradient the kernel already announced
+                self._direct[i] = False
+                return
+            count()
+
+        def from_kernel():
+            self._direct[i] = True
+            count()
+        return from_autograd, from_kernel
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]

@@ -232,12 +232,13 @@ class _AdamState:
         `model.parameters()` order, one param group with this trainer's hyper-parameters.  CPU tensors."""
         a = self.arena
         state = {}
-        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
-            n = p.numel()
-            state[i] = {'step': torch.tensor(float(self.step_count)),
-                        'exp_avg': self.m[o:o + n].view_as(p).detach().cpu().clone(),
-                        'exp_avg_sq': self.v[o:o + n].view_as(p).detach().cpu().clone()}
-        group = {'lr': float(self._current_lr()),
+        if self.step_count > 0:            # (torch's AdamW has an EMPTY state before its first step)
+            for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+                n = p.numel()
+                state[i] = {'step': torch.tensor(float(self.step_count)),
+                            'exp_avg': self.m[o:o + n].view_as(p).detach().cpu().clone(),
+                            'exp_avg_sq': self.v[o:o + n].view_as(p).detach().cpu().clone()}
+        group = {'lr': float(self._current_lr()), 'initial_lr': float(self.lr),      # initial_lr: what a scheduler resumes from
                  'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False, 'maximize': False,
                  'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
                  'params': list(range(len(a.params)))}
@@ -263,18 +264,29 @@ class _AdamState:
 
     def enable_ema(self, decay):
         """Weight EMA with ModelEmaV2's law e = decay e + (1 - decay) w after every optimizer step (model_ema_v2.py:33-41,
-        main.py:286-287): one lerp over the flat arena, captured with the step when it is graphed.  Call before enable_graph."""
+        main.py:286-287): one lerp over the flat arena, captured with the step when it is graphed.  ModelEmaV2 averages EVERY
+        state_dict value, so the model's persistent buffers (BatchNorm running statistics, the VQ codebook and cluster sizes of
+        the VQ auto-encoder; the denoiser has none) get shadow copies under the same law.  Call before enable_graph."""
         self.ema_decay = float(decay)
         self.ema_flat = self.arena.flat_param.detach().clone()
+        named = {id(p) for p in self.model.parameters()}
+        self._ema_live = {k: v for k, v in self.model.state_dict(keep_vars=True).items() if id(v) not in named}
+        self.ema_bufs = {k: v.detach().clone() for k, v in self._ema_live.items()}
         return self
 
     def _ema_update(self):
         if getattr(self, 'ema_flat', None) is not None:
             self.ema_flat.lerp_(self.arena.flat_param, 1.0 - self.ema_decay)
+            for k, e in self.ema_bufs.items():
+                live = self._ema_live[k]
+                if e.is_floating_point():
+                    e.lerp_(live.detach(), 1.0 - self.ema_decay)
+                else:                      # (num_batches_tracked: the reference computes the average in float and copies it back)
+                    e.copy_(self.ema_decay * e + (1.0 - self.ema_decay) * live)
 
     def ema_state_dict(self):
-        """name -> EMA weights (CPU), the reference's `ema_model_state_dict` (non-parameter entries of the model's state_dict
-        -- buffers -- are copied from the live model, as ModelEmaV2 does)."""
+        """name -> EMA values (CPU), the reference's `ema_model_state_dict`: parameters from the flat shadow arena, persistent
+        buffers from their own shadow copies (ModelEmaV2._update walks the whole state_dict, model_ema_v2.py:33-41)."""
         if getattr(self, 'ema_flat', None) is None:
             return None
         a = self.arena
@@ -283,7 +295,10 @@ class _AdamState:
         out = {}
         for k, v in self.model.state_dict().items():
             p = named.get(k)
-            out[k] = (by_id[id(p)] if p is not None and id(p) in by_id else v).detach().cpu().clone()
+            if p is not None and id(p) in by_id:
+                out[k] = by_id[id(p)].detach().cpu().clone()
+            else:
+                out[k] = self.ema_bufs.get(k, v).detach().cpu().clone()
         return out
 
 
@@ -414,24 +429,32 @@ class _TrainerBase(_AdamState):
         # the per-call part of the corruption's Philox stream id: graph replays count on the device, eager calls on the host
         # (_corrupt_calls).  Bit 39 keeps the two ranges apart, so a run that mixes replays with eager fallbacks (another batch
         # shape) or with corrupt_tokens never draws one stream twice.
-        self._g_ctr = torch.full((1,), 1 << 39, dtype=torch.int64, device=dev)
+        # (created once: capturing again -- another batch shape, a caller's second enable_graph -- must go on counting, or the
+        #  steps after it would replay the noise and mask streams of the run's first steps)
+        if getattr(self, '_g_ctr', None) is None:
+            self._g_ctr = torch.full((1,), 1 << 39, dtype=torch.int64, device=dev)
+            self._g_seed = torch.initial_seed()
         self._g_hyper = self._g_in[nb:]
-        self._g_seed = torch.initial_seed()
         snap = None if keep_warmup_updates else (self.arena.flat_param.clone(), self.m.clone(), self.v.clone(), self.step_count,
                                                  self.sampler_gen.get_state(),
                                                  None if getattr(self, 'ema_flat', None) is None else self.ema_flat.clone())
+        ops.wgrad_reset()                  # nothing queued by an earlier (failed) pass may flush into this capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._set_step_inputs(None)
-                self._graph_body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._set_step_inputs(None)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._g_out = self._graph_body()
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._set_step_inputs(None)
+                    self._graph_body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._set_step_inputs(None)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._g_out = self._graph_body()
+        except BaseException:
+            ops.wgrad_reset()
+            raise
         self.step_count -= 1               # capturing records the launches, it does not run a step
         if snap is not None:
             if snap[5] is not None:
@@ -445,10 +468,11 @@ class _TrainerBase(_AdamState):
             self._refresh_operands()
         self._graph = g
         # the graph bakes in the addresses of the library workspaces it was captured with (split-K partial tiles, counting-sort
-        # counters): hold them, and re-capture when ops replaced one (a later, larger eager call grows them)
+        # counters): it HOLDS them.  When a later, larger eager call makes ops replace one, the eager path moves on to the new
+        # allocation and the graph keeps replaying on the old one, which stays alive (and self-consistent: only the graph uses it)
+        # through this reference.  Nothing is captured again behind the caller's back: a rank-local re-capture would run warm-up
+        # steps with real all-reduces while its peers replay one step.
         self._g_ws = ops.workspace_snapshot(dev)
-        self._g_example = example_batch
-        self._g_warmup = warmup
         return self
 
     def _set_step_inputs(self, r):
@@ -496,8 +520,6 @@ class _TrainerBase(_AdamState):
     def _replay(self, batch_z, r):
         """One graphed step: inputs into the static buffers, one hipGraph launch, ONE host read-back (loss, grad-norm, per-sample
         losses for the loss-aware sampler).  Returns (mean loss, grad norm)."""
-        if not ops.workspace_same(self._g_ws, ops.workspace_snapshot(self._g_z.device)):
-            self.enable_graph(self._g_example, self._g_warmup)           # a workspace moved under the captured graph
         self._g_z.copy_(batch_z, non_blocking=True)
         self._set_step_inputs(r)
         self._graph.replay()
@@ -743,8 +765,7 @@ class VqaeTrainer(_AdamState):
     def train_step(self, batch):
         """batch: [B, C, H, W] frames on the GPU.  Returns (loss, reconstruction loss, latent loss, perplexity) as floats."""
         self.model.train()
-        if getattr(self, '_graph', None) is not None and batch.shape == self._g_x.shape and \
-                ops.workspace_same(self._g_ws, ops.workspace_snapshot(batch.device)):
+        if getattr(self, '_graph', None) is not None and batch.shape == self._g_x.shape:      # (the graph holds its workspaces)
             self._g_x.copy_(batch, non_blocking=True)
             self._set_hyper()
             self._graph.replay()
