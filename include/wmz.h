@@ -10,9 +10,9 @@
  *  - `dtype` selects the element type of activations: WMZ_F32 or WMZ_BF16 (accumulation is always fp32);
  *    parameters marked `float*` are always fp32, indices are int64 like the reference's LongTensors;
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued;
- *  - no allocation, no host sync, no global state (the wmz_debug_* development probes at the end of this file are the
- *    one exception: process-wide switches that production callers never touch): safe to capture in a hipGraph,
- *    re-entrant per stream;
+ *  - no allocation, no host sync, no global state: safe to capture in a hipGraph, re-entrant per stream (the library also
+ *    exports a few wmz_debug_* development probes -- process-wide timing switches declared in the private header
+ *    world_modelz_amd/csrc/wmz_debug.h, not part of this interface);
  *  - return 0 on success, WMZ_ERR_* otherwise; wmz_last_error() gives the message (thread-local).
  */
 #ifndef WMZ_H_
@@ -379,19 +379,6 @@ int wmz_ln_affine_grads_batch(int n, const float* const* G, const float* const* 
                               const float* const* gamma, const float* const* beta, float* const* dW, float* const* dbias,
                               float* const* dgamma, float* const* dbeta, const int* N, const int* K, const int* bias_from,
                               void* stream);
-
-/* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
- * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */
-int wmz_debug_fused_timestamps(void* buf);
-/* Ablation switches of the fused per-token kernel (timing experiments only, results are garbage): 1 = skip the MFMA loops,
- * 2 = skip the weight DMA and its waits, 4 = skip the per-slab workgroup barrier (bits combine); 0 = product behaviour. */
-int wmz_debug_fused_knobs(int dbg);
-/* Same for the 16-wide-plane attention forward kernel (16 waves x 64 int64). */
-int wmz_debug_attn_timestamps(void* buf);
-/* development knobs of the attention forward: dbg = ablation switches (1 skip the per-tile compute, 2 skip the K/V
- * staging: timing experiments only, results are garbage), variant = reserved (the library carries one instantiation per
- * shape class; other schedules are separate builds, tools/build_variant.py); (0, 0) is the product behaviour. */
-int wmz_debug_attn_knobs(int dbg, int variant);
 
 /* ---- conv encoder / decoder (autoencoder.py:8-152), NHWC, implicit GEMM on MFMA ----
  * out[b,ho,wo,co] = act( (conv(x, w)[..] + bias[co]) * scale[co] + shift[co] + residual ), w as [Cout, KH, KW, Cin]

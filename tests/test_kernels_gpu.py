@@ -449,41 +449,6 @@ def test_attention_row16_fast_path(ops, shape, heads, dh, ext):
     assert torch.allclose(lse_f.cpu(), lse_g.cpu(), rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('shape,heads,dh,ext', [
-    ((2, 5, 16, 16), 1, 128, (3, 3, 3)),       # BASELINE plane shape
-    ((1, 4, 16, 16), 2, 64, (1, 3, 2)),
-    ((1, 3, 10, 16), 1, 32, (1, 0, 3)),        # ragged chunk, eH = 0: a query row sees only its own key row (a lane of the
-                                               # pair starts on an empty tile: the un-initialised-maximum path)
-    ((1, 3, 36, 16), 1, 128, (2, 5, 1)),       # three 16-row chunks, odd row counts per slab
-])
-def test_attention_row32_experimental_kernel(ops, shape, heads, dh, ext):
-    """attn_fwd_row32.hip (two query rows per wave, MFMA 32x32x16; wmz_debug_attn_knobs variant 64, with and without its half-tile
-    stagger) is NOT the product path (measured slower than row16) but stays parity-tested: logits probe against
-    the fp32 oracle, out / lse against the oracle and against row16."""
-    from world_modelz_amd import _lib as L
-    torch.manual_seed(23)
-    B, S, H, W = shape
-    I = heads * dh
-    q, k, v = (torch.randn(B, S, H, W, I).bfloat16() for _ in range(3))
-    ref, ref_logits = oat.local_attention(k.float(), v.float(), q.float(), ext, heads, return_logits=True)
-    base, lse_b, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True)
-    try:
-        for variant in (64, 96):
-            L.call('wmz_debug_attn_knobs', 0, variant)
-            out, lse, dbg = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True, logits_dbg=True)
-            plain, _, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads)
-            assert torch.equal(out, plain)
-            logits = dbg.cpu().reshape(ref_logits.shape)
-            live = ref_logits != -1e9
-            assert torch.equal(logits == -1e9, ~live)
-            assert float((logits[live] - ref_logits[live]).abs().max() / ref_logits[live].abs().max()) < 1e-3
-            assert rel(out, ref) < 3e-3 and rel(out, base) < 3e-3
-            lse_ref = torch.logsumexp(ref_logits, -1).reshape(-1, heads)
-            assert torch.allclose(lse.cpu(), lse_ref, rtol=1e-4, atol=1e-4)
-    finally:
-        L.call('wmz_debug_attn_knobs', 0, 0)
-
-
 def test_attention_row16_deferred_max_branch(ops):
     """Force both sides of the deferred-rescale decision: a key far above the running max late in the walk (rescale
     must fire) and logits that creep up by < 2^8 per step (rescale deferred; P may exceed 1)."""

@@ -23,9 +23,6 @@ PER_FILE = {
     # distance arithmetic must round like the reference's separate sub/mul/add tensor ops
     'vq.hip': ['-ffp-contract=off'],
     'vq_screen.hip': ['-ffp-contract=off'],
-    # adjacent scalar f32 ops packed into v_pk_*_f32 are slower beside MFMAs (MI355X_MICROARCH.md, cycle constants): the softmax
-    # of the attention kernels is placed instruction by instruction between the MFMAs
-    'attn_fwd_row32.hip': ['-fno-slp-vectorize'],
 }
 
 

@@ -14,6 +14,7 @@
 //                                                  accumulator layout: no cross-lane movement)
 // The reference's zero-padded, -1e9-masked slots have probability exactly 0, so they are simply not visited.
 #include "attn_common.h"
+#include "wmz_debug.h"
 #include <stdlib.h>
 
 namespace {
@@ -247,11 +248,8 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
 
 }  // namespace
 
-// fast paths for 16-wide planes: two query rows per wave (attn_fwd_row32.hip; planes with an even number of rows) and one
-// query row per wave (attn_fwd_row16.hip; odd H, and wmz_debug_attn_knobs variant 16 for A/B timing)
+// fast path for 16-wide planes: one query row per wave (attn_fwd_row16.hip)
 int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
-                                const AttnGeom& G, hipStream_t st);
-int wmz_attn_fwd_row32_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
                                 const AttnGeom& G, hipStream_t st);
 
 // development knobs (wmz_debug_attn_knobs): ablation switches and kernel-variant selector, 0 / 0 in production
@@ -305,7 +303,6 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
   G.variant = g_attn_variant;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !general) {
-    if ((H & 1) == 0 && (g_attn_variant & 64)) return wmz_attn_fwd_row32_dispatch(q, k, v, out, lse, logits_dbg, G, st);
     return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G, st);
   }
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);

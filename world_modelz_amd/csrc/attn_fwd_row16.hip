@@ -26,6 +26,7 @@
 //     one scalar base and one instruction, and the pieces are spread over the step instead of queueing at the texture
 //     addresser right behind the barrier (SPLIT).
 #include "attn_common.h"
+#include "wmz_debug.h"
 
 // Compile-time ablations for timing experiments (tools/variants builds; results are garbage): bit 0 no LDS fragment reads,
 // bit 1 no softmax arithmetic, bit 2 no MFMAs, bit 3 no V staging, bit 4 no K staging, bit 5 no slab loop at all, bit 6 one key plane only,

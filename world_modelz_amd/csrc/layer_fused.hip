@@ -22,6 +22,7 @@
 //   * the feed-forward is walked 32 hidden units at a time (W1 rows -> GELU -> W2 columns), so its activation never
 //     exists in full and the chunk's accumulator (16 registers) is converted in place to the next operand.
 #include "fused_common.h"
+#include "wmz_debug.h"
 
 namespace {
 

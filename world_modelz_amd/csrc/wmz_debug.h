@@ -1,0 +1,24 @@
+// Development probes of libwmz_hip.so: process-wide switches for kernel timing experiments (tools/), NOT part of the product
+// interface (include/wmz.h) -- production callers never touch them, and with all of them at their defaults (NULL / 0) the library
+// has no global state.
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Kernel-development probe: workgroup 0 of the fused layer kernel writes the shader clock at its stage boundaries into
+ * buf (device, 8 waves x 64 int64); NULL (default) switches the probe off. */
+int wmz_debug_fused_timestamps(void* buf);
+/* Ablation switches of the fused per-token kernel (timing experiments only, results are garbage): 1 = skip the MFMA loops,
+ * 2 = skip the weight DMA and its waits, 4 = skip the per-slab workgroup barrier (bits combine); 0 = product behaviour. */
+int wmz_debug_fused_knobs(int dbg);
+/* Same for the 16-wide-plane attention forward kernel (16 waves x 64 int64). */
+int wmz_debug_attn_timestamps(void* buf);
+/* development knobs of the attention forward: dbg = ablation switches (1 skip the per-tile compute, 2 skip the K/V
+ * staging: timing experiments only, results are garbage), variant = reserved (the library carries one instantiation per
+ * shape class; other schedules are separate builds, tools/build_variant.py); (0, 0) is the product behaviour. */
+int wmz_debug_attn_knobs(int dbg, int variant);
+
+#ifdef __cplusplus
+}
+#endif
