@@ -449,6 +449,42 @@ def test_attention_row16_fast_path(ops, shape, heads, dh, ext):
     assert torch.allclose(lse_f.cpu(), lse_g.cpu(), rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('shape,heads,dh,ext', [
+    ((1, 8, 8, 8), 1, 128, (3, 3, 3)),         # BASELINE configs[1]: 8x8x8 latent grid
+    ((2, 6, 8, 8), 1, 128, (3, 1, 1)),         # the reference's own geometry (main.py:394) with the published window (7,3,3)
+    ((1, 3, 8, 8), 2, 64, (1, 2, 2)),          # even row extent: both rim rows admit two of the three sub-row offsets
+    ((1, 2, 8, 8), 1, 32, (1, 0, 3)),          # eH = 0: the only tile row is a rim row
+    ((1, 3, 16, 8), 1, 128, (1, 3, 1)),        # 8 tile rows: two 4-wave workgroups per plane
+    ((1, 2, 24, 8), 1, 64, (0, 5, 2)),         # 12 tile rows: the 16-wave shape with 8-wide planes
+    ((1, 2, 6, 8), 1, 128, (1, 1, 1)),         # 3 tile rows: a ragged chunk
+    ((1, 2, 8, 8), 1, 128, (1, 9, 9)),         # window larger than the plane
+])
+def test_attention_8_wide_planes_fast_path(ops, shape, heads, dh, ext):
+    """bf16, W == 8 with an even number of rows takes attn_fwd_row16.hip too (round 4): the plane is read as H / 2 tile rows of 16,
+    the window test runs in tile coordinates with per-lane sub-row masks in the rim rows.  Same bar as the 16-wide test: the
+    kernel's own logits dump against the fp32 oracle (<= 1e-3, masked slots the literal -1e9), lse, out, and the general kernel."""
+    torch.manual_seed(23)
+    B, S, H, W = shape
+    I = heads * dh
+    q, k, v = (torch.randn(B, S, H, W, I).bfloat16() for _ in range(3))
+    ref, ref_logits = oat.local_attention(k.float(), v.float(), q.float(), ext, heads, return_logits=True)
+    fast, lse_f, dbg = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True, logits_dbg=True)
+    plain, _, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads)
+    gen, lse_g, _ = ops.local3d_attention_fwd(dev(q), dev(k), dev(v), ext, heads, need_lse=True, general=True)
+    assert torch.equal(fast, plain)
+    logits = dbg.cpu().reshape(ref_logits.shape)
+    live = ref_logits != -1e9
+    assert torch.equal(logits == -1e9, ~live)
+    err = float((logits[live] - ref_logits[live]).abs().max() / ref_logits[live].abs().max())
+    assert err < 1e-3 and rel(logits[live], ref_logits[live]) < 1e-3, err
+    e_out, e_gen = rel(fast, ref), rel(fast, gen)
+    print(f'[8-wide {shape} {ext}] logits max err {err:.1e}, out vs oracle {e_out:.2e}, vs general kernel {e_gen:.2e}')
+    assert e_out < 3e-3 and e_gen < 3e-3
+    lse_ref = torch.logsumexp(ref_logits, -1).reshape(-1, heads)
+    assert torch.allclose(lse_f.cpu(), lse_ref, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(lse_f.cpu(), lse_g.cpu(), rtol=1e-5, atol=2e-5)
+
+
 def test_attention_row16_deferred_max_branch(ops):
     """Force both sides of the deferred-rescale decision: a key far above the running max late in the walk (rescale
     must fire) and logits that creep up by < 2^8 per step (rescale deferred; P may exceed 1)."""

@@ -321,7 +321,7 @@ extern "C" int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v,
   G.ldq = ldq; G.ldk = ldk; G.ldv = ldv; G.ldo = ldo;
   G.HW = H * W; G.tiles = (G.HW + 15) / 16; G.qgroups = 0;
   G.scale = 1.0f / sqrtf((float)dh);
-  G.dbg = 0; G.qs0 = 0; G.Sq = S;
+  G.dbg = 0; G.qs0 = 0; G.Sq = S; G.variant = 0; G.w8 = 0;
   BwdPtrs PQ, PK;
   PQ.x1 = q; PQ.x2 = dout; PQ.y1 = k; PQ.y2 = v; PQ.o = out; PQ.lse = lse; PQ.delta = delta_ws; PQ.g1 = dq; PQ.g2 = nullptr;
   PQ.ldx1 = ldq; PQ.ldx2 = lddo; PQ.ldy1 = ldk; PQ.ldy2 = ldv; PQ.ldo = ldo; PQ.ldg1 = lddq; PQ.ldg2 = 0;

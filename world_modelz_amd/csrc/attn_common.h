@@ -20,6 +20,7 @@ struct AttnGeom {
   int qs0, Sq;   // query planes [qs0, qs0+Sq) only; out / lse are compact [B, Sq, H, W, ..] (forward; full grid: 0, S)
   int dbg;       // ablation switches for timing experiments: 1 = skip the per-tile compute, 2 = skip the K/V staging
   int variant;   // development A/B switch between kernel instantiations (wmz_debug_attn_knobs); 0 = product default
+  int w8;        // row kernels: the plane is 8 wide and handed over as H / 2 tile rows of 16 (attn_fwd_row16.hip)
 };
 
 struct TileInfo { int hlo, hhi, wlo, whi; };

@@ -301,9 +301,17 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
   G.scale = 1.0f / sqrtf((float)dh);
   G.dbg = g_attn_dbg;
   G.variant = g_attn_variant;
+  G.w8 = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) && !general) {
-    return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G, st);
+  if (dtype == WMZ_BF16 && (dh == 32 || dh == 64 || dh == 128) && !general) {
+    if (W == 16) return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G, st);
+    if (W == 8 && (H & 1) == 0) {
+      // an 8-wide plane with an even number of rows is a 16-wide plane of H / 2 tile rows in memory (the reference's own 8x8
+      // latents, main.py:394): the row kernel with its window test in tile coordinates
+      AttnGeom G8 = G;
+      G8.w8 = 1; G8.H = H / 2; G8.W = 16;
+      return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G8, st);
+    }
   }
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {

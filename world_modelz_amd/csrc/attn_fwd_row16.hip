@@ -45,31 +45,27 @@ __device__ __forceinline__ void mma16_abl(f32x4& acc, const A& a, const B& b) {
 // development probes (the only process-wide state of the library, see include/wmz.h): stamp buffer and A/B knobs
 long long* g_attn_ts = nullptr;     // 16 waves x 64 int64, wmz_debug_attn_timestamps
 
-#ifndef WMZ_ATTN_KC
-#define WMZ_ATTN_KC 8
-#endif
-// key rows per slab.  8 (product): two 74 KB slabs, one in flight.  4 (-DWMZ_ATTN_KC=4, tools/build_variant.py): four 37 KB
-// slabs, three in flight behind counted vmcnt waits -- measured SLOWER, 43.5 vs 37.3 us per launch on the same box: the
-// per-slab cost is the 16-wave rendezvous and the loop around it, not the latency of the slab's DMA.
-constexpr int KC = WMZ_ATTN_KC;
-constexpr int LOG_RS = KC == 8 ? 1 : 2;
-constexpr int RS = 1 << LOG_RS;       // a slab holds plane rows base, base + RS, ..: RS slabs ("phases") per 16-row chunk
-static_assert(KC * RS == 16, "a slab is one phase of a 16-row chunk");
-#ifndef WMZ_ATTN_NW
-#define WMZ_ATTN_NW 16
-#endif
-#ifndef WMZ_ATTN_NBUF
-#define WMZ_ATTN_NBUF (WMZ_ATTN_KC == 8 ? 2 : 4)
-#endif
-constexpr int NW = WMZ_ATTN_NW;       // waves per workgroup = query rows per workgroup
-constexpr int NBUF = WMZ_ATTN_NBUF;   // LDS slab ring
-constexpr int AHEAD = NBUF - 1;       // slabs in flight
+// Workgroup shapes.  A plane is cut into chunks of CH rows, a slab holds every RS-th row of a chunk (KC = CH / RS rows: plane
+// row = base + RS * slab row), two slabs (K and V images each) in LDS, one in flight.
+//   Big   (NW 16, CH 16, KC 8): a workgroup = 16 query rows = a whole 16x16 plane, two 74 KB slabs, one workgroup per CU;
+//   Small (NW  4, CH  4, KC 2): a workgroup = 4 query rows, two 18 KB slabs, four workgroups per CU -- planes of up to 8 tile rows
+//         (8-wide planes, below), where the big shape would run a quarter full and stage 8-row slabs holding 2 rows.
+// (Round 2 / 3 measured and dropped, now removed: 4-row slabs in a ring of four with three in flight, two 8-wave half-plane
+//  workgroups per CU, a two-query-rows-per-wave kernel on MFMA 32x32x16: all equal or slower.)
+template <int NW_, int CH_, int KC_> struct Shape {
+  static constexpr int NW = NW_, CH = CH_, KC = KC_, RS = CH_ / KC_, LOG_RS = RS == 2 ? 1 : (RS == 1 ? 0 : 2);
+  static_assert(KC_ * RS == CH_ && (1 << LOG_RS) == RS, "a slab is one phase of a chunk");
+};
+using Big = Shape<16, 16, 8>;
+using Small = Shape<4, 4, 2>;
+constexpr int NBUF = 2;               // LDS slab pair
 constexpr float DEFER = 8.f;          // log2 units
 
-template <int DH> struct Img {
+template <int DH, typename SH> struct Img {
 #ifndef WMZ_ATTN_KPAD
 #define WMZ_ATTN_KPAD 32
 #endif
+  static constexpr int NW = SH::NW, KC = SH::KC;
   static constexpr int KROW = DH * 2 + WMZ_ATTN_KPAD, VROW = DH * 2 + 32;
   static constexpr int KIMG = KC * 16 * KROW, VIMG = KC * 16 * VROW;
   static constexpr int BUF = KIMG + VIMG;
@@ -99,7 +95,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // a padded image: the lane landing on (slab row, 16-byte chunk) fetches that chunk of plane row base + 2 * (slab row / 16),
 // key column slab row % 16; pad chunks fetch chunk 0 (never read).  `row_lim`: rows past the plane are redirected to the
 // last valid one (never read either).
-template <int DH, int ROWP>
+template <int DH, int ROWP, int RS>
 __device__ __forceinline__ unsigned piece_voff(int piece, int lane, unsigned ld_bytes, int row_lim) {
   const int off = piece * 1024 + lane * 16;
   const int r = off / ROWP;
@@ -109,22 +105,21 @@ __device__ __forceinline__ unsigned piece_voff(int piece, int lane, unsigned ld_
   return (unsigned)((prow << 4) + (r & 15)) * ld_bytes + (unsigned)c * 16u;
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n <= 12
-__device__ __forceinline__ void attn_vm_wait(int n) {
-#define WMZ_AVW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    WMZ_AVW(1) WMZ_AVW(2) WMZ_AVW(3) WMZ_AVW(4) WMZ_AVW(5) WMZ_AVW(6) WMZ_AVW(7) WMZ_AVW(8) WMZ_AVW(9) WMZ_AVW(10) WMZ_AVW(11) WMZ_AVW(12)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef WMZ_AVW
-}
-
-template <int DH, int MODE, bool ALIGNED, bool PROBE, bool TS>
-__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                                  float* __restrict__ LSE, float* __restrict__ DBG,
-                                                                  AttnGeom G, long long* ts) {
-  using I = Img<DH>;
+// W8: planes 8 wide.  A plane [H, 8] (H even) IS a plane [H / 2, 16] in memory: tile row R = plane rows 2R, 2R + 1, tile column
+// c = 8 (row & 1) + w.  Staging, fragments, Q / O rows are those of a 16-wide plane with H / 2 rows (G.H holds H / 2); what changes
+// is the window: key tile row R + D is visited for |D| <= eHv = ceil(eH / 2), the column mask compares c & 7, and in the two
+// OUTERMOST tile rows (|D| = eHv) a (query, key) pair is inside the window only if |2 D + (c_k >> 3) - (c_q >> 3)| <= eH -- a
+// per-lane condition (a lane's four key columns share one sub-row), applied as one select per logit in those steps only.  There a
+// query can have nothing visible in a whole step, so the deferred running maximum is started per lane (firstl).
+template <int DH, typename SH, int MODE, bool ALIGNED, bool PROBE, bool TS, bool W8>
+__global__ __launch_bounds__(SH::NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                      const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                                      float* __restrict__ LSE, float* __restrict__ DBG,
+                                                                      AttnGeom G, long long* ts) {
+  using I = Img<DH, SH>;
+  constexpr int NW = SH::NW, CH = SH::CH, KC = SH::KC, RS = SH::RS, LOG_RS = SH::LOG_RS;
+  constexpr int LOG_CH = CH == 16 ? 4 : (CH == 8 ? 3 : 2);
+  static_assert((1 << LOG_CH) == CH, "chunk of 4, 8 or 16 rows");
   constexpr int KS = DH / 32, MT = DH / 16;
   constexpr int SPLIT = MODE & 7;                        // where the LDS-DMA pieces of the next slab are issued (kSched)
   constexpr bool EPI16 = (MODE & 8) != 0;                // 16-byte output stores (lane pairs swap halves)
@@ -154,7 +149,15 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
   // bm[r] = column-window bias of this lane's key column (w = 4g + r) against its query (w = li), minus the running max
   float bm[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { const int d = 4 * g + r - li; bm[r] = (d <= G.eW && -d <= G.eW) ? 0.f : -INFINITY; }
+  for (int r = 0; r < 4; ++r) {
+    const int d = W8 ? ((4 * g + r) & 7) - (li & 7) : 4 * g + r - li;
+    bm[r] = (d <= G.eW && -d <= G.eW) ? 0.f : -INFINITY;
+  }
+  const int eHv = W8 ? (G.eH + 1) >> 1 : G.eH;          // window extent in tile rows
+  const int dp = (g >> 1) - (li >> 3);                  // W8: sub-row of the lane's key columns minus sub-row of its query
+  const bool ok_lo = (2 * eHv - dp <= G.eH) && (dp - 2 * eHv <= G.eH);    // W8: pair inside the window at D = -eHv / D = +eHv
+  const bool ok_hi = (2 * eHv + dp <= G.eH) && (-2 * eHv - dp <= G.eH);
+  bool firstl = true;                                   // W8: this lane's query has not seen a logit yet
 
   Frag8<bf16_t> qf[KS];
   f32x4 o[MT];
@@ -165,12 +168,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
 
   const int kbase = li * I::KROW + g * 16;
   const int vbase = I::KIMG + (4 * g + (li >> 2)) * I::VROW + (li & 3) * 8;
-  const int my_lo = max(hq - G.eH, 0), my_hi = min(hq + G.eH, H - 1);
+  const int my_lo = max(hq - eHv, 0), my_hi = min(hq + eHv, H - 1);
   // key rows the workgroup stages
-  const int t_lo = max(h0 - G.eH, 0), t_hi = min(min(h0 + NW - 1, H - 1) + G.eH, H - 1);
+  const int t_lo = max(h0 - eHv, 0), t_hi = min(min(h0 + NW - 1, H - 1) + eHv, H - 1);
   const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
-  const int c_first = t_lo >> 4, c_last = t_hi >> 4;
-  const int nch = (c_last - c_first + 1) * RS;              // slabs per key plane: (16-row chunk) x (row phase)
+  const int c_first = t_lo >> LOG_CH, c_last = t_hi >> LOG_CH;
+  const int nch = (c_last - c_first + 1) * RS;              // slabs per key plane: (chunk) x (row phase)
   const int nslab = (WMZ_ATTN_ABL & 32) ? 0 : (WMZ_ATTN_ABL & 64) ? nch : (sk_hi - sk_lo + 1) * nch;   // ablations: no slab loop / one key plane
 
   // ---- LDS-DMA descriptors: this wave's pieces are wave + 16 i; per-lane source offsets for planes of whole 16-row chunks
@@ -180,9 +183,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
   unsigned kvo[I::NPK], vvo[I::NPV];
   if constexpr (ALIGNED) {
 #pragma unroll
-    for (int i = 0; i < I::NPK; ++i) kvo[i] = piece_voff<DH, I::KROW>(wave + NW * i, lane, ldk_b, 16 - RS);
+    for (int i = 0; i < I::NPK; ++i) kvo[i] = piece_voff<DH, I::KROW, RS>(wave + NW * i, lane, ldk_b, CH - RS);
 #pragma unroll
-    for (int i = 0; i < I::NPV; ++i) vvo[i] = piece_voff<DH, I::VROW>(wave + NW * i, lane, ldv_b, 16 - RS);
+    for (int i = 0; i < I::NPV; ++i) vvo[i] = piece_voff<DH, I::VROW, RS>(wave + NW * i, lane, ldv_b, CH - RS);
   }
 
   // Scalar state of the slab being prefetched.  It is advanced INCREMENTALLY (adds, one 32-bit multiply) and at the END of
@@ -207,9 +210,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
   const char* kp = nullptr;
   const char* vp = nullptr;
   char* dbuf = nullptr;
-  int dlim = 14;
+  int dlim = CH - RS;
   auto next_state = [&]() {                                              // descriptors of slab (pl_n, rem_n)
-    base_n = ((c_first + (rem_n >> LOG_RS)) << 4) + (rem_n & (RS - 1));
+    base_n = ((c_first + (rem_n >> LOG_RS)) << LOG_CH) + (rem_n & (RS - 1));
     kp = kpl + (unsigned)base_n * rsk;
     vp = vpl + (unsigned)base_n * rsv;
     dbuf = smem + (jn & (NBUF - 1)) * I::BUF;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
       const int piece = wave + NW * i;
       if (i * NW + NW <= I::PK || piece < I::PK) {       // wave-uniform
         unsigned vo;
-        if constexpr (ALIGNED) vo = kvo[i]; else vo = piece_voff<DH, I::KROW>(piece, lane, ldk_b, dlim);
+        if constexpr (ALIGNED) vo = kvo[i]; else vo = piece_voff<DH, I::KROW, RS>(piece, lane, ldk_b, dlim);
         __builtin_amdgcn_global_load_lds((gptr_t)(kp + vo), (lptr_t)(dbuf + piece * 1024), 16, 0, 0);
       }
     }
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
       const int piece = wave + NW * i;
       if (i * NW + NW <= I::PV || piece < I::PV) {
         unsigned vo;
-        if constexpr (ALIGNED) vo = vvo[i]; else vo = piece_voff<DH, I::VROW>(piece, lane, ldv_b, dlim);
+        if constexpr (ALIGNED) vo = vvo[i]; else vo = piece_voff<DH, I::VROW, RS>(piece, lane, ldv_b, dlim);
         __builtin_amdgcn_global_load_lds((gptr_t)(vp + vo), (lptr_t)(dbuf + I::KIMG + piece * 1024), 16, 0, 0);
       }
     }
@@ -256,65 +259,76 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
   auto rescale = [&](float mx, auto& t) {
     constexpr int nt = (int)(sizeof(t) / sizeof(float));
     float gm = wave_groups_max(mx);
-    if (!first) {
-      gm = fmaxf(gm, 0.f);                               // the reference only moves up
-      const float alpha = __builtin_amdgcn_exp2f(-gm);
+    if constexpr (W8) {
+      // per lane: a query with nothing visible in this step (gm = -inf) neither moves nor starts its reference
+      const bool dead = gm == -INFINITY;
+      gm = dead ? 0.f : (firstl ? gm : fmaxf(gm, 0.f));
+      const float alpha = firstl ? 1.f : __builtin_amdgcn_exp2f(-gm);     // (o and l of a lane that starts here are still zero)
       l_run *= alpha;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) o[mt] *= alpha;
+      firstl = firstl && dead;
+      first = __any(firstl);
+    } else {
+      if (!first) {
+        gm = fmaxf(gm, 0.f);                               // the reference only moves up
+        const float alpha = __builtin_amdgcn_exp2f(-gm);
+        l_run *= alpha;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) o[mt] *= alpha;
+      }
+      first = false;
     }
     m_run += gm;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bm[r] = (bm[r] == -INFINITY) ? -INFINITY : -m_run;
 #pragma unroll
     for (int r = 0; r < nt; ++r) t[r] -= gm;
-    first = false;
+  };
+  // W8: the logits of a key tile row at the window's rim (D = -eHv or +eHv) that this lane's query does not see
+  auto rim_mask = [&](int D, float* t4) {
+    if constexpr (W8) {
+      if (D == -eHv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] = ok_lo ? t4[r] : -INFINITY;
+      } else if (D == eHv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] = ok_hi ? t4[r] : -INFINITY;
+      }
+    }
   };
 
   WMZ_ATS(1);
-  // LDS-DMA pieces this wave issues per slab (wave-uniform): the counted wait below lets the younger slabs' pieces fly
-  int npc = 0;
-#pragma unroll
-  for (int i = 0; i < I::NPK; ++i) npc += (!(WMZ_ATTN_ABL & 16) && wave + NW * i < I::PK) ? 1 : 0;
-#pragma unroll
-  for (int i = 0; i < I::NPV; ++i) npc += (!(WMZ_ATTN_ABL & 8) && wave + NW * i < I::PV) ? 1 : 0;
-  // the first AHEAD slabs are requested up front; bq / pq: first plane row and key plane of the slabs in flight, oldest first
-  int bq[AHEAD], pq[AHEAD];
-  static_for<AHEAD>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    bq[i] = 0; pq[i] = 0;
-    if (i < nslab) {
-      next_state();
-      if (staging) {
-        issue_k(C0{}); issue_k(C1{}); issue_k(C2{});
-        issue_v(C0{}); issue_v(C1{}); issue_v(C2{});
-      }
-      bq[i] = base_n; pq[i] = pl_n;
-      advance();
+  // the first slab is requested up front; bq / pq: first plane row and key plane of the slab in flight
+  int bq = 0, pq = 0;
+  if (0 < nslab) {
+    next_state();
+    if (staging) {
+      issue_k(C0{}); issue_k(C1{}); issue_k(C2{});
+      issue_v(C0{}); issue_v(C1{}); issue_v(C2{});
     }
-    if constexpr (i == 0) {
-      // Q right behind the first slab's requests (rows past the plane load a valid row, never stored)
-      const bf16_t* qrow = Q + (plane_q + (act ? hq : 0) * 16 + li) * G.ldq + (long)head * DH;
+    bq = base_n; pq = pl_n;
+    advance();
+  }
+  {
+    // Q right behind the first slab's requests (rows past the plane load a valid row, never stored)
+    const bf16_t* qrow = Q + (plane_q + (act ? hq : 0) * 16 + li) * G.ldq + (long)head * DH;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) frag_load(qf[ks], qrow + ks * 32 + g * 8);
-    }
-  });
-  next_state();                                          // descriptors of slab AHEAD
+    for (int ks = 0; ks < KS; ++ks) frag_load(qf[ks], qrow + ks * 32 + g * 8);
+  }
+  next_state();                                          // descriptors of slab 1
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks].v));   // Q is waited for HERE, once (the compiler's wait is vmcnt(0): inside
                                                                        // the loop it would drain the slabs in flight at every iteration)
   WMZ_ATS(2);
   for (int j = 0; j < nslab; ++j) {
     const char* Sb = smem + (j & (NBUF - 1)) * I::BUF;     // this slab's K image, V image behind it
-    const int pl = pq[0], base = bq[0];                    // current slab: key plane, plane row of slab row 0 (slab row r <-> base + RS r)
-    // this wave's pieces of slab j landed: everything but the pieces of the (up to AHEAD - 1) younger slabs.  (The probe / stamp
-    // instantiations store to global memory inside the loop, which the count does not know about: they drain the queue.)
-    if constexpr (PROBE || TS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else attn_vm_wait(min(AHEAD - 1, nslab - 1 - j) * npc);
+    const int pl = pq, base = bq;                          // current slab: key plane, plane row of slab row 0 (slab row r <-> base + RS r)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of slab j landed
     if (j < 14) WMZ_ATS(3 + 4 * j);
     __builtin_amdgcn_s_barrier();                        // ... everyone's did, and slab j-1 is retired: refill its slot
     if (j < 14) WMZ_ATS(4 + 4 * j);
-    const bool more = j + AHEAD < nslab && staging;
+    const bool more = j + 1 < nslab && staging;
     bool pend[6] = {more, more, more, more, more, more};                 // K0 K1 K2 V0 V1 V2 of slab j + 1 not requested yet
     auto issue_at = [&](auto pc, bool flush) {
       constexpr int pt = decltype(pc)::value;
@@ -366,13 +380,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
           const int nk = (2 * G.eS + 1) * kh * kw;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int dw = 4 * g + r - li;
+            const int dw = W8 ? ((4 * g + r) & 7) - (li & 7) : 4 * g + r - li;
             if (dw <= G.eW && -dw <= G.eW) {
               const int ds = (sk_lo + pl) - s;
-              const int dh0 = base + RS * t0 - hq, dh1 = dh0 + RS;
+              const int D0 = base + RS * t0 - hq;
+              const int dh0 = W8 ? 2 * D0 + dp : D0, dh1 = W8 ? dh0 + 2 * RS : dh0 + RS;      // in plane rows
               float* row = DBG + (qn * G.heads + head) * nk;
-              row[((ds + G.eS) * kh + (dh0 + G.eH)) * kw + dw + G.eW] = sc0[r] * G.scale;
-              row[((ds + G.eS) * kh + (dh1 + G.eH)) * kw + dw + G.eW] = sc1[r] * G.scale;
+              if (dh0 <= G.eH && -dh0 <= G.eH) row[((ds + G.eS) * kh + (dh0 + G.eH)) * kw + dw + G.eW] = sc0[r] * G.scale;
+              if (dh1 <= G.eH && -dh1 <= G.eH) row[((ds + G.eS) * kh + (dh1 + G.eH)) * kw + dw + G.eW] = sc1[r] * G.scale;
             }
           }
         }
@@ -382,6 +397,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
         for (int r = 0; r < 4; ++r) {
           t[r] = fmaf(sc0[r], c2, bm[r]);
           t[4 + r] = fmaf(sc1[r], c2, bm[r]);
+        }
+        if constexpr (W8) {
+          const int D0 = base + RS * t0 - hq;
+          rim_mask(D0, t);
+          rim_mask(D0 + RS, t + 4);
         }
         const float mx = fmaxf(__builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
                                __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
@@ -429,17 +449,20 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
           const int nk = (2 * G.eS + 1) * kh * kw;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int dw = 4 * g + r - li;
+            const int dw = W8 ? ((4 * g + r) & 7) - (li & 7) : 4 * g + r - li;
             if (dw <= G.eW && -dw <= G.eW) {
               const int ds = (sk_lo + pl) - s;
-              const int dh0 = base + RS * t0 - hq;
-              DBG[(qn * G.heads + head) * nk + ((ds + G.eS) * kh + (dh0 + G.eH)) * kw + dw + G.eW] = sc0[r] * G.scale;
+              const int D0 = base + RS * t0 - hq;
+              const int dh0 = W8 ? 2 * D0 + dp : D0;
+              if (dh0 <= G.eH && -dh0 <= G.eH)
+                DBG[(qn * G.heads + head) * nk + ((ds + G.eS) * kh + (dh0 + G.eH)) * kw + dw + G.eW] = sc0[r] * G.scale;
             }
           }
         }
         float t[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = fmaf(sc0[r], c2, bm[r]);
+        if constexpr (W8) rim_mask(base + RS * t0 - hq, t);
         const float mx = __builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3]));
         if (first || __any(mx > DEFER)) rescale(mx, t);
         float p[4];
@@ -457,12 +480,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
         }
       }
     }
-    // whatever of slab j + AHEAD has not been requested yet
+    // whatever of slab j + 1 has not been requested yet
     issue_at(C3{}, true);
-    // the slab just requested joins the queue; its successor's descriptors are worked out here, ahead of the barrier
-#pragma unroll
-    for (int i = 0; i + 1 < AHEAD; ++i) { bq[i] = bq[i + 1]; pq[i] = pq[i + 1]; }
-    bq[AHEAD - 1] = base_n; pq[AHEAD - 1] = pl_n;
+    // the slab just requested becomes the current one; its successor's descriptors are worked out here, ahead of the barrier
+    bq = base_n; pq = pl_n;
     advance();
     next_state();
     if (j < 14) WMZ_ATS(6 + 4 * j);
@@ -505,26 +526,26 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_row16_kernel(const bf16_t
 #undef WMZ_ATS
 }
 
-template <int DH, int MODE, bool ALIGNED, bool PROBE, bool TS>
+template <int DH, typename SH, int MODE, bool ALIGNED, bool PROBE, bool TS, bool W8>
 int launch_row16(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg, AttnGeom G, hipStream_t st) {
-  G.qgroups = wmz_cdiv(G.H, NW);
+  G.qgroups = wmz_cdiv(G.H, SH::NW);
   const long nwg = (long)G.B * G.heads * G.Sq * G.qgroups;
-  hipLaunchKernelGGL((attn_fwd_row16_kernel<DH, MODE, ALIGNED, PROBE, TS>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, (const bf16_t*)q,
-                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, dbg, G, g_attn_ts);
+  hipLaunchKernelGGL((attn_fwd_row16_kernel<DH, SH, MODE, ALIGNED, PROBE, TS, W8>), dim3((unsigned)nwg), dim3(SH::NW * 64), 0, st,
+                     (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, dbg, G, g_attn_ts);
   WMZ_LAUNCH_CHECK("wmz_local3d_attn_fwd(row16)");
   return WMZ_OK;
 }
 
-template <int SPLIT, bool ALIGNED, bool PROBE, bool TS>
+template <typename SH, int SPLIT, bool ALIGNED, bool PROBE, bool TS, bool W8>
 int by_dh2(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg, const AttnGeom& G, hipStream_t st) {
-  if (G.dh == 128) return launch_row16<128, SPLIT, ALIGNED, PROBE, TS>(q, k, v, out, lse, dbg, G, st);
-  if (G.dh == 64) return launch_row16<64, SPLIT, ALIGNED, PROBE, TS>(q, k, v, out, lse, dbg, G, st);
-  return launch_row16<32, SPLIT, ALIGNED, PROBE, TS>(q, k, v, out, lse, dbg, G, st);
+  if (G.dh == 128) return launch_row16<128, SH, SPLIT, ALIGNED, PROBE, TS, W8>(q, k, v, out, lse, dbg, G, st);
+  if (G.dh == 64) return launch_row16<64, SH, SPLIT, ALIGNED, PROBE, TS, W8>(q, k, v, out, lse, dbg, G, st);
+  return launch_row16<32, SH, SPLIT, ALIGNED, PROBE, TS, W8>(q, k, v, out, lse, dbg, G, st);
 }
-template <int SPLIT, bool PROBE, bool TS>
+template <typename SH, int SPLIT, bool PROBE, bool TS, bool W8>
 int by_dh(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg, const AttnGeom& G, hipStream_t st) {
-  if ((G.H & 15) == 0) return by_dh2<SPLIT, true, PROBE, TS>(q, k, v, out, lse, dbg, G, st);
-  return by_dh2<SPLIT, false, PROBE, TS>(q, k, v, out, lse, dbg, G, st);
+  if ((G.H % SH::CH) == 0) return by_dh2<SH, SPLIT, true, PROBE, TS, W8>(q, k, v, out, lse, dbg, G, st);
+  return by_dh2<SH, SPLIT, false, PROBE, TS, W8>(q, k, v, out, lse, dbg, G, st);
 }
 
 }  // namespace
@@ -537,13 +558,23 @@ extern "C" int wmz_debug_attn_timestamps(void* buf) { g_attn_ts = (long long*)bu
 #define WMZ_ATTN_MODE 9          // kSched[1]: K pieces behind the barrier, V pieces inside the first step; 16-byte output stores
 #endif
 
-// Called by wmz_local3d_attn_fwd when the shape qualifies (bf16, W == 16, dim_head in {32,64,128}).  dbg: optional logits
-// probe [N, heads, window] (natural-log-domain scaled logits of the in-window slots, pre-filled with -1e9 by the caller).
+// Called by wmz_local3d_attn_fwd when the shape qualifies (bf16, dim_head in {32,64,128}; W == 16, or W == 8 with an even number
+// of rows: G.w8 set and G.H = H / 2 tile rows).  dbg: optional logits probe [N, heads, window] (natural-log-domain scaled logits of
+// the in-window slots, pre-filled with -1e9 by the caller).
 int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
                                 const AttnGeom& G, hipStream_t st) {
-  if (dbg != nullptr) return by_dh<WMZ_ATTN_MODE, true, false>(q, k, v, out, lse, dbg, G, st);
-  if (g_attn_ts != nullptr) return by_dh<WMZ_ATTN_MODE, false, true>(q, k, v, out, lse, nullptr, G, st);
+  if (G.w8) {
+    // planes of up to 8 tile rows (the reference's 8x8 latents: 4) on 4-wave workgroups with 2-row slabs, larger ones on the big shape
+    if (G.H <= 8) {
+      if (dbg != nullptr) return by_dh<Small, WMZ_ATTN_MODE, true, false, true>(q, k, v, out, lse, dbg, G, st);
+      return by_dh<Small, WMZ_ATTN_MODE, false, false, true>(q, k, v, out, lse, nullptr, G, st);
+    }
+    if (dbg != nullptr) return by_dh<Big, WMZ_ATTN_MODE, true, false, true>(q, k, v, out, lse, dbg, G, st);
+    return by_dh<Big, WMZ_ATTN_MODE, false, false, true>(q, k, v, out, lse, nullptr, G, st);
+  }
+  if (dbg != nullptr) return by_dh<Big, WMZ_ATTN_MODE, true, false, false>(q, k, v, out, lse, dbg, G, st);
+  if (g_attn_ts != nullptr) return by_dh<Big, WMZ_ATTN_MODE, false, true, false>(q, k, v, out, lse, nullptr, G, st);
   // (the other LDS-DMA schedules / store widths of kSched are timing variants: build them with
   //  tools/build_variant.py <tag> attn_fwd_row16.hip -DWMZ_ATTN_MODE=<0..15> and load the library through WMZ_LIB_PATH)
-  return by_dh<WMZ_ATTN_MODE, false, false>(q, k, v, out, lse, nullptr, G, st);
+  return by_dh<Big, WMZ_ATTN_MODE, false, false, false>(q, k, v, out, lse, nullptr, G, st);
 }
