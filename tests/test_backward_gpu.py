@@ -152,3 +152,30 @@ def test_attention_backward_row16_fast_path(wmz, shape, heads, dh, ext):
     dqkv = torch.empty_like(qkv)
     ops.local3d_attention_bwd(qkv[..., :I], qkv[..., I:2 * I], qkv[..., 2 * I:], out, lse, dod, ext, heads, dqkv=dqkv)
     assert torch.equal(dqkv[..., :I], dq) and torch.equal(dqkv[..., I:], dkv)
+
+
+@pytest.mark.parametrize('shape,heads,dh,ext', [
+    ((1, 8, 8, 8), 1, 128, (3, 3, 3)),         # BASELINE configs[1] grid
+    ((2, 6, 8, 8), 1, 128, (3, 1, 1)),         # the reference's geometry (main.py:394), published window
+    ((1, 3, 8, 8), 2, 64, (1, 2, 2)),          # even row extent
+    ((1, 2, 8, 8), 1, 32, (1, 0, 3)),          # eH = 0
+    ((1, 3, 16, 8), 1, 128, (1, 3, 1)),        # 8 tile rows: two workgroups per plane
+    ((1, 2, 24, 8), 1, 64, (0, 5, 2)),         # 12 tile rows: the 8-wave shapes
+    ((1, 2, 6, 8), 1, 128, (1, 1, 1)),         # ragged chunk
+])
+def test_attention_backward_8_wide_planes(wmz, shape, heads, dh, ext):
+    """bf16, W == 8 (even H): the row kernels of attn_bwd_row16.hip on tile rows of 16 with rim masks, against torch.autograd over
+    the oracle -- dq, dk, dv (2e-2 rel: P and dS are bf16 MFMA operands)."""
+    torch.manual_seed(33)
+    ops = wmz['ops']
+    B, S, H, W = shape
+    I = heads * dh
+    q, k, v, do = (torch.randn(B, S, H, W, I).bfloat16() for _ in range(4))
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    oat.local_attention(kr, vr, qr, ext, heads).backward(do.float())
+    qd, kd, vd, dod = (t.cuda() for t in (q, k, v, do))
+    out, lse, _ = ops.local3d_attention_fwd(qd, kd, vd, ext, heads, need_lse=True)
+    dq, dkv = ops.local3d_attention_bwd(qd, kd, vd, out, lse, dod, ext, heads)
+    e = (rel(dq, qr.grad), rel(dkv[..., :I], kr.grad), rel(dkv[..., I:], vr.grad))
+    print(f'[8-wide bwd {shape} {ext}] dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}')
+    assert max(e) < 2e-2, e

@@ -330,6 +330,11 @@ extern "C" int wmz_local3d_attn_bwd(const void* q, const void* k, const void* v,
   hipStream_t st = (hipStream_t)stream;
   if (dtype == WMZ_BF16 && W == 16 && (dh == 32 || dh == 64 || dh == 128) )
     return wmz_attn_bwd_row16_dispatch(q, k, v, out, lse, dout, dq, dk, dv, delta_ws, G, lddo, lddq, lddk, lddv, st);
+  if (dtype == WMZ_BF16 && W == 8 && (H & 1) == 0 && (dh == 32 || dh == 64 || dh == 128)) {
+    AttnGeom G8 = G;                       // an 8-wide plane as H / 2 tile rows of 16 (attn_fwd_row16.hip)
+    G8.w8 = 1; G8.H = H / 2; G8.W = 16;
+    return wmz_attn_bwd_row16_dispatch(q, k, v, out, lse, dout, dq, dk, dv, delta_ws, G8, lddo, lddq, lddk, lddv, st);
+  }
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {
     if (DHp == 32) return launch_both<bf16_t, 32, 8>(PQ, PK, G, st);

@@ -32,12 +32,12 @@
 
 namespace {
 
-constexpr int KC = 8;
-
-template <int DH> struct BImg {
+// A slab holds KC_ visiting rows (every other row of a chunk of 2 KC_ rows): 8 for whole 16-row planes, 2 for the small planes of
+// the 4-wave workgroup shape (attn_fwd_row16.hip: planes of up to 8 tile rows, i.e. 8-wide planes of up to 16 rows).
+template <int DH, int KC_ = 8> struct BImg {
   static constexpr int ROWP = DH * 2 + 32;             // both read kinds hit this image: +32 B keeps tr reads conflict-free
-  static constexpr int IMG = KC * 16 * ROWP;
-  static constexpr int BUF = 2 * IMG + 2 * KC * 16 * 4; // Y1 | Y2 | visitor lse2 | visitor delta
+  static constexpr int IMG = KC_ * 16 * ROWP;
+  static constexpr int BUF = 2 * IMG + 2 * 128 * 4;    // Y1 | Y2 | visitor lse2 | visitor delta (room for 128 visitors each)
   static constexpr int PIECES = IMG / 1024;
   static_assert(IMG % 1024 == 0, "image must be whole 1 KB DMA pieces");
 };
@@ -49,7 +49,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // is plane row base + 2 t, column w; pad chunks fetch chunk 0; rows past the plane are redirected to row_lim (never read)
 template <int DH>
 __device__ __forceinline__ unsigned bpiece_voff(int piece, int lane, unsigned ld_bytes, int row_lim) {
-  constexpr int ROWP = BImg<DH>::ROWP;
+  constexpr int ROWP = DH * 2 + 32;
   const int off = piece * 1024 + lane * 16;
   const int r = off / ROWP;
   int c = (off - r * ROWP) >> 4;
@@ -92,9 +92,14 @@ struct RBwdPtrs {
   long ldx1, ldx2, ldy1, ldy2, ldo, ldg1, ldg2;
 };
 
-template <int DH, int MODE, int NW, bool ALIGNED>
-__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, AttnGeom G) {
-  using I = BImg<DH>;
+// W8 (8-wide planes handed over as H / 2 tile rows of 16, see attn_fwd_row16.hip): the window is |D| <= eHv = ceil(eH / 2) tile
+// rows, the column mask compares c & 7, and in the two rim rows |D| = eHv a pair is inside only if |2 D + dp| <= eH with
+// dp = sub-row of the lane's visitor columns - sub-row of its owner column: one select per bias there.
+template <int DH, int MODE, int NW, int KC, bool ALIGNED, bool W8>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? (MODE == 0 && !W8 ? 4 : 2) : 1)) void attn_bwd_row16_kernel(RBwdPtrs P, AttnGeom G) {
+  using I = BImg<DH, KC>;
+  constexpr int CH = 2 * KC, LOG_CH = CH == 16 ? 4 : 2;
+  static_assert((1 << LOG_CH) == CH, "chunks of 16 or 4 rows");
   constexpr int KS = DH / 32, MT = DH / 16;
   constexpr int NP = (I::PIECES + NW - 1) / NW;          // DMA pieces per wave and image
   __shared__ __attribute__((aligned(1024))) char smem[2 * I::BUF];
@@ -119,22 +124,40 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
   // window bias of this lane's 4 visitor columns (w = 4g + r) against its owner column (w = li): symmetric in the roles
   float bias[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { const int d = 4 * g + r - li; bias[r] = (d <= G.eW && -d <= G.eW) ? 0.f : -INFINITY; }
+  for (int r = 0; r < 4; ++r) {
+    const int d = W8 ? ((4 * g + r) & 7) - (li & 7) : 4 * g + r - li;
+    bias[r] = (d <= G.eW && -d <= G.eW) ? 0.f : -INFINITY;
+  }
+  const int eHv = W8 ? (G.eH + 1) >> 1 : G.eH;
+  const int dp = (g >> 1) - (li >> 3);
+  const bool ok_lo = (2 * eHv - dp <= G.eH) && (dp - 2 * eHv <= G.eH);    // W8: pair inside the window at D = -eHv / D = +eHv
+  const bool ok_hi = (2 * eHv + dp <= G.eH) && (-2 * eHv - dp <= G.eH);
+  auto rim = [&](int D, auto& o) {                        // a visiting row's four biases / accumulator starts, masked in place
+    if constexpr (W8) {
+      if (D == -eHv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ok_lo ? o[r] : -INFINITY;
+      } else if (D == eHv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ok_hi ? o[r] : -INFINITY;
+      }
+    }
+  };
 
   // ---- slab geometry (as in attn_fwd_row16.hip)
-  const int my_lo = max(h - G.eH, 0), my_hi = min(h + G.eH, H - 1);
-  const int t_lo = max(h0 - G.eH, 0), t_hi = min(min(h0 + NW - 1, H - 1) + G.eH, H - 1);
+  const int my_lo = max(h - eHv, 0), my_hi = min(h + eHv, H - 1);
+  const int t_lo = max(h0 - eHv, 0), t_hi = min(min(h0 + NW - 1, H - 1) + eHv, H - 1);
   const int sk_lo = max(0, s - G.eS), sk_hi = min(G.S - 1, s + G.eS);
-  const int c_first = t_lo >> 4, c_last = t_hi >> 4;
-  const int nch = (c_last - c_first + 1) * 2;               // slabs per visiting plane: (16-row chunk) x (row parity)
+  const int c_first = t_lo >> LOG_CH, c_last = t_hi >> LOG_CH;
+  const int nch = (c_last - c_first + 1) * 2;               // slabs per visiting plane: (chunk) x (row parity)
   const int nslab = (sk_hi - sk_lo + 1) * nch;
   const unsigned ld1_b = (unsigned)P.ldy1 * 2u, ld2_b = (unsigned)P.ldy2 * 2u;
   unsigned vo1[NP], vo2[NP];
   if constexpr (ALIGNED) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      vo1[i] = bpiece_voff<DH>(wave + NW * i, lane, ld1_b, 14);
-      vo2[i] = bpiece_voff<DH>(wave + NW * i, lane, ld2_b, 14);
+      vo1[i] = bpiece_voff<DH>(wave + NW * i, lane, ld1_b, CH - 2);
+      vo2[i] = bpiece_voff<DH>(wave + NW * i, lane, ld2_b, CH - 2);
     }
   }
   const unsigned rs1 = 16u * ld1_b, rs2 = 16u * ld2_b;
@@ -150,10 +173,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
   const char* y1p = nullptr;
   const char* y2p = nullptr;
   char* dbuf = nullptr;
-  int dlim = 14;
+  int dlim = CH - 2;
   long vrow_n = 0;
   auto next_state = [&]() {
-    base_n = ((c_first + (rem_n >> 1)) << 4) + (rem_n & 1);
+    base_n = ((c_first + (rem_n >> 1)) << LOG_CH) + (rem_n & 1);
     y1p = y1pl + (unsigned)base_n * rs1;
     y2p = y2pl + (unsigned)base_n * rs2;
     dbuf = smem + (jn & 1) * I::BUF;
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
         const int prow = min(2 * (idx >> 4), dlim);
         const long row = vrow_n + (long)prow * 16 + (idx & 15);
         const float* src = (wave < 2 ? P.lse : P.delta) + row * G.heads + head;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dbuf + 2 * I::IMG + (wave >> 1) * (KC * 16 * 4) + (wave & 1) * 256), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dbuf + 2 * I::IMG + (wave >> 1) * 512 + (wave & 1) * 256), 4, 0, 0);
       }
     }
   };
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
     const char* Y1s = smem + (j & 1) * I::BUF;
     const char* Y2s = Y1s + I::IMG;
     const float* vlse = reinterpret_cast<const float*>(Y1s + 2 * I::IMG);
-    const float* vdel = vlse + KC * 16;
+    const float* vdel = vlse + 128;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more = j + 1 < nslab;
@@ -267,7 +290,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
         const int ro0 = rbase + t0 * 16 * I::ROWP, ro1 = ro0 + 16 * I::ROWP;
         const int to0 = tbase + t0 * 16 * I::ROWP;
         f32x4 s0 = (f32x4)(0.f), s1 = (f32x4)(0.f), d0 = (f32x4)(0.f), d1 = (f32x4)(0.f);
-        if constexpr (MODE == 0) { s0 = s1 = (f32x4){bl[0], bl[1], bl[2], bl[3]}; d0 = d1 = (f32x4)(nde); }
+        float bA[4] = {bias[0], bias[1], bias[2], bias[3]}, bB[4] = {bias[0], bias[1], bias[2], bias[3]};     // MODE 1: the rows' biases
+        if constexpr (MODE == 0) {
+          s0 = s1 = (f32x4){bl[0], bl[1], bl[2], bl[3]};           // accumulator starts; rim rows of 8-wide planes masked in place
+          d0 = d1 = (f32x4)(nde);
+          rim(base + 2 * t0 - h, s0);
+          rim(base + 2 * t0 + 2 - h, s1);
+        } else {
+          rim(base + 2 * t0 - h, bA);
+          rim(base + 2 * t0 + 2 - h, bB);
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           Frag8<bf16_t> a0, a1, b0, b1;
@@ -321,8 +353,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           const f32x4 e0 = *reinterpret_cast<const f32x4*>(vdel + r0), e1 = *reinterpret_cast<const f32x4*>(vdel + r1);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, fmaf(l0[r], -L2E, bias[r])));     // (lse arrives in natural-log units)
-            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, fmaf(l1[r], -L2E, bias[r])));
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, fmaf(l0[r], -L2E, bA[r])));     // (lse arrives in natural-log units)
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, fmaf(l1[r], -L2E, bB[r])));
             pv[r] = p0;
             pv[4 + r] = p1;
             dsv[r] = p0 * ((d0[r] - e0[r]) * G.scale);
@@ -361,7 +393,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
         const int ro0 = rbase + t0 * 16 * I::ROWP;
         const int to0 = tbase + t0 * 16 * I::ROWP;
         f32x4 s0 = (f32x4)(0.f), d0 = (f32x4)(0.f);
-        if constexpr (MODE == 0) { s0 = (f32x4){bl[0], bl[1], bl[2], bl[3]}; d0 = (f32x4)(nde); }
+        float bA[4] = {bias[0], bias[1], bias[2], bias[3]};
+        if constexpr (MODE == 0) { s0 = (f32x4){bl[0], bl[1], bl[2], bl[3]}; d0 = (f32x4)(nde); rim(base + 2 * t0 - h, s0); }
+        else rim(base + 2 * t0 - h, bA);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           Frag8<bf16_t> a0, b0;
@@ -380,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
           const f32x4 l0 = *reinterpret_cast<const f32x4*>(vlse + r0), e0 = *reinterpret_cast<const f32x4*>(vdel + r0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pv[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, fmaf(l0[r], -L2E, bias[r])));
+            pv[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, fmaf(l0[r], -L2E, bA[r])));
             dsv[r] = pv[r] * ((d0[r] - e0[r]) * G.scale);
           }
         } else {
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_row16_kernel(RBwdPtrs P, 
 template <int DH, bool SAME_LD>
 __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, AttnGeom G, const float* ws, float c2) {   // c2 = scale * log2(e): a kernel argument stays scalar
   using I = BImg<DH>;
-  constexpr int NW = 16, KS = DH / 32, MT = DH / 16;
+  constexpr int NW = 16, KC = 8, KS = DH / 32, MT = DH / 16;
   constexpr int NP = (I::PIECES + NW - 1) / NW;
   constexpr int HDR = 2 * KC * 16 * 4;                   // delta | -lse / scale of the slab's 128 visitors
   constexpr int BUFB = HDR + 2 * I::IMG;
@@ -712,23 +746,30 @@ __global__ __launch_bounds__(1024) void attn_bwd_kvplane_kernel(RBwdPtrs P, Attn
   store_owner_rows<MT>(g2, acc2, 1.f, g);
 }
 
-template <int DH, int MODE, int NW>
+template <int DH, int MODE, int NW, int KC, bool W8>
 int launch_one(const RBwdPtrs& P, AttnGeom G, hipStream_t st) {
   G.qgroups = wmz_cdiv(G.H, NW);
   const long nwg = (long)G.B * G.heads * G.S * G.qgroups;
-  if ((G.H & 15) == 0) hipLaunchKernelGGL((attn_bwd_row16_kernel<DH, MODE, NW, true>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, P, G);
-  else hipLaunchKernelGGL((attn_bwd_row16_kernel<DH, MODE, NW, false>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, P, G);
+  if ((G.H % (2 * KC)) == 0) hipLaunchKernelGGL((attn_bwd_row16_kernel<DH, MODE, NW, KC, true, W8>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, P, G);
+  else hipLaunchKernelGGL((attn_bwd_row16_kernel<DH, MODE, NW, KC, false, W8>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, P, G);
   WMZ_LAUNCH_CHECK("wmz_local3d_attn_bwd(row16)");
   return WMZ_OK;
 }
 
 template <int DH>
 int launch_both(const RBwdPtrs& PQ, const RBwdPtrs& PK, const AttnGeom& G, hipStream_t st) {
-  int rc = launch_one<DH, 0, 16>(PQ, G, st);
+  if (G.w8) {
+    // 8-wide planes (G.H = H / 2 tile rows): up to 8 tile rows on 4-wave workgroups with 2-row slabs, larger planes on the big shapes
+    if (G.H <= 8) {
+      const int rc = launch_one<DH, 0, 4, 2, true>(PQ, G, st);
+      return rc != WMZ_OK ? rc : launch_one<DH, 1, 4, 2, true>(PK, G, st);
+    }
+    // (the dq pass with its rim masks does not fit 128 registers: 8-wave workgroups, two per plane chunk, for it as well)
+    const int rc = launch_one<DH, 0, 8, 8, true>(PQ, G, st);
+    return rc != WMZ_OK ? rc : launch_one<DH, 1, 8, 8, true>(PK, G, st);
+  }
+  int rc = launch_one<DH, 0, 16, 8, false>(PQ, G, st);
   if (rc != WMZ_OK) return rc;
-#ifndef WMZ_ABWD_NWK
-#define WMZ_ABWD_NWK 8      // waves (= owner key rows) per workgroup of the dk | dv pass; 16 (a whole plane, 128 registers per wave)
-#endif                      // is a timing experiment of tools/build_variant.py
 #ifndef WMZ_ABWD_PLANE
 #define WMZ_ABWD_PLANE 1    // 1: the whole-plane 16-wave dk | dv kernel where its preconditions hold; 0: always the 8-wave form
 #endif
@@ -744,7 +785,7 @@ int launch_both(const RBwdPtrs& PQ, const RBwdPtrs& PK, const AttnGeom& G, hipSt
     WMZ_LAUNCH_CHECK("wmz_local3d_attn_bwd(row16, dk|dv plane)");
     return WMZ_OK;
   }
-  return launch_one<DH, 1, WMZ_ABWD_NWK>(PK, G, st);
+  return launch_one<DH, 1, 8, 8, false>(PK, G, st);
 }
 
 }  // namespace
