@@ -653,6 +653,54 @@ def main():
                                      'the module boundary, bf16 inside; B=1, 8x8x8 grid, dim 256, 1 head x 128'})
             log('config 2: ' + ', '.join(f"{c['extents']} {c['us_per_forward']:.1f} us" for c in cfg2))
         out['config2_attention'] = cfg2
+        # ---- secondary figure: the reference's OWN geometry and published model (main.py:394 `data_shape=z.shape # (6,8,8)`,
+        # train_vqae.py:83-86: 3 down-scale steps -> 8x8 latents of 64x64 frames; results/README.md:13-22: run 03, dim 384 / mlp 512 /
+        # 20 layers / one head of 128 / window (7,3,3) = --extent 3,1,1 / batch 64 / 5 context frames + 1): forward denoise step and
+        # full training step, one hipGraph each.  8-wide planes take the row attention kernels as tile rows of 16 (round 4).
+        refgeo = None
+        if not a.eager and not a.no_cone and dtype == torch.bfloat16:
+            from world_modelz_amd.train import DenoiserTrainer as _RT
+            torch.manual_seed(42)
+            mr = VqVideoDiffusionModel(data_shape=(6, 8, 8), dim=384, num_classes=512, extents=(3, 1, 1), depth=20, dim_head=128,
+                                       mlp_dim=512, heads=1).to(dev).eval()
+            zr = torch.randint(0, 513, (64, 6, 8, 8), generator=gen).to(dev)
+            with torch.no_grad():
+                wcfg.set_last_frame_cone(False)
+                rrun = GraphedForward(mr, zr)
+                for _ in range(10):
+                    rrun(rrun.static_in)
+                torch.cuda.synchronize()
+                r0_ = time.perf_counter()
+                for _ in range(10):
+                    rrun(rrun.static_in)
+                torch.cuda.synchronize()
+                rf = (time.perf_counter() - r0_) / 10
+            refgeo = {'forward_ms_per_step': rf * 1e3, 'forward_value': 64 * 6 / rf, 'unit': 'latent-frames/s',
+                      'params': sum(p.numel() for p in mr.parameters()),
+                      'what': 'reference geometry: B = 64 clips of (6, 8, 8) latents, codebook 512, dim 384 / mlp 512 / depth 20 / '
+                              '1 x 128 / extents (3,1,1) (results/README.md run 03); full grid forward and one training step'}
+            del rrun
+            if a.train_steps > 0 and world == 1:
+                mr.train()
+                rt = _RT(mr, 512, lr=1e-4, warmup=500, max_steps=75000, distributed=False)
+                rt.enable_graph(zr.clamp(max=511))
+                rr = torch.full((64,), 0.5)
+                for _ in range(3):
+                    rt.train_step(zr.clamp(max=511), r=rr)
+                torch.cuda.synchronize()
+                r0_ = time.perf_counter()
+                for _ in range(5):
+                    rt.train_step(zr.clamp(max=511), r=rr)
+                torch.cuda.synchronize()
+                rtr = (time.perf_counter() - r0_) / 5
+                refgeo['train_ms_per_step'] = rtr * 1e3
+                refgeo['train_value'] = 64 * 6 / rtr
+                del rt
+            log(f"reference geometry 64 x (6,8,8), dim 384 / depth 20: forward {refgeo['forward_ms_per_step']:.3f} ms, "
+                f"train {refgeo.get('train_ms_per_step', float('nan')):.2f} ms")
+            del mr
+            gc.collect()
+        out['reference_geometry'] = refgeo
         # ---- secondary figure: BASELINE configs[2] -- the training step of vq-video-diffusion/main.py on B = 16 clips of 16x16x16
         # latents (same token count per step as the headline, shorter clips: more border planes), codebook 1024; one hipGraph per step
         cfg3 = None

@@ -279,6 +279,17 @@ int wmz_layer_chain_fwd_planes(const void* o, const void* x, void* x_out, void* 
                                const float* vec, int B, int n_q, int n_in, int HW, int D, int I, int M, int head, int tail,
                                float eps, void* stream);
 
+/* The TRAINING forward of the same launch (whole grids of ntok tokens).  wpack: the RAW weights in the kernel's piece order
+ * (to_out | feed-forward chunks of W1 rows and W2 columns | to_q | to_k | to_v; no LayerNorm folding: the kernel applies the
+ * affines itself), vec: bout[D] b1[M] b2[D] 0[I] bv[I] g_ff[D] be_ff[D] g_attn[D] be_attn[D] (the feed-forward block's norm, then
+ * the NEXT layer's attention norm).  Besides x_out [ntok, D], q_out [ntok, I] and kv_out [ntok, 2 I] (k | v per row) it writes what
+ * the step's backward reads: x1 [ntok, D] the feed-forward block's raw input, xn_ff [ntok, D] its LayerNorm as the first GEMM
+ * consumed it, z / h [ntok, M] the pre-activation and GELU of it, st_ff [2, ntok] mean | rstd (head != 0); xn_attn [ntok, D] and
+ * st_attn [2, ntok] for the next layer's to_k / to_v (tail != 0).  main.py:216-287 (the step), local_3d_attention.py:11-31. */
+int wmz_layer_chain_fwd_train(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                              const float* vec, void* x1, void* xn_ff, void* z, void* h, float* st_ff, void* xn_attn,
+                              float* st_attn, long ntok, int D, int I, int M, int head, int tail, float eps, void* stream);
+
 int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                    const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                    const float* vec, int B, int S, int H, int W, int planes_out, int D, int I, int M,

@@ -654,6 +654,55 @@ def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('dim,mlp', [(96, 256), (384, 512)])
+def test_published_widths_train_on_the_chain_kernel_vs_oracle(wmz, dim, mlp):
+    """The reference's published widths (results/README.md:7-22) TRAIN on csrc/layer_chain.hip's training forward (round 4): loss
+    and every parameter gradient of one step against the fp32 oracle's autograd (bf16 bound as for the default widths) and against
+    the op-by-op path (the two paths' rounding differences); the weight streams are one gather of the flat arena, rebuilt per step."""
+    from oracle import train_step as ots
+    torch.manual_seed(42)
+    C = 64
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(4, 16, 16), dim=dim, num_classes=C, extents=(3, 1, 1), depth=2, dim_head=128,
+                                          mlp_dim=mlp, heads=1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    z = torch.randint(0, C + 1, (2, 4, 16, 16))
+    target = torch.randint(0, C, (2, 16, 16))
+    _, _, loss_ref, grads_ref = ots.step_grads(sd, z, target, (3, 1, 1), 1)
+    m = m.cuda()
+    cfg = wmz['config']
+    with cfg.compute_dtype(torch.bfloat16):
+        tr = wmz['train'].DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
+        assert tr.chain_packs is not None
+        got = {}
+        for fused_on in (True, False):
+            cfg.set_fused_training(fused_on)
+            try:
+                tr.arena.zero_grad()
+                _, mean = tr.forward_backward(z.cuda(), target.cuda())
+            finally:
+                cfg.set_fused_training(True)
+            got[fused_on] = (float(mean), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+        loss_c, g_c = got[True]
+        loss_o, g_o = got[False]
+        assert abs(loss_c - float(loss_ref)) < 2e-2 and abs(loss_c - loss_o) < 2e-2
+        worst = max((float((g_c[n] - grads_ref[n].cuda()).norm() / (grads_ref[n].norm() + 1e-12)), n) for n in g_c)
+        worst_o = max((float((g_c[n] - g_o[n]).norm() / (g_o[n].norm() + 1e-12)), n) for n in g_c)
+        print(f'dim {dim}: chain-kernel training gradients vs oracle {worst[0]:.3e} ({worst[1]}), vs op-by-op {worst_o[0]:.3e} ({worst_o[1]})')
+        assert worst[0] < 6e-2, worst
+        assert worst_o[0] < 6e-2, worst_o
+        # the packed streams follow the weights: one optimizer step, then the same forward must see the new weights
+        tr.optimizer_step()
+        tr.arena.zero_grad()
+        _, mean2 = tr.forward_backward(z.cuda(), target.cuda())
+        cfg.set_fused_training(False)
+        try:
+            tr.arena.zero_grad()
+            _, mean3 = tr.forward_backward(z.cuda(), target.cuda())
+        finally:
+            cfg.set_fused_training(True)
+        assert float(mean2) != loss_c and abs(float(mean2) - float(mean3)) < 2e-2
+
+
 def _two_rank_training(tmp_path, backend, port, dtype='bfloat16', atol=3e-3):
     """Two data-parallel ranks as fresh child processes (nothing has touched the GPU in them before), `backend` 'nccl' (= RCCL,
     one card per rank) or 'gloo' (both ranks on cuda:0: the in-place gradient writes, the `_wmz_ready` notifications, the

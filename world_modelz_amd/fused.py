@@ -68,10 +68,11 @@ def chain_supported(transformer, x_dtype):
     return x_dtype == torch.bfloat16 and hasattr(transformer, 'pos_emb_s') and chain_widths(transformer) is not None
 
 
-def _chain_pieces(w):
+def _chain_pieces(w, pad_value=0):
     """[N, K] fp32 -> the kernel's 1 KB MFMA 16x16x32 A operands in (k-step, 16-feature block) order, lane-linear:
     piece (ks, b), lane l = 16 ga + m, element j = W[(m >> 2) N/4 + 4 b + (m & 3)][ga K/4 + 8 ks + j] -- output feature and k
-    axis both "lane-group-major" (csrc/layer_chain.hip), padded with zero pieces to whole slabs."""
+    axis both "lane-group-major" (csrc/layer_chain.hip), padded with zero pieces to whole slabs (pad_value: the filler -- an
+    INDEX matrix is padded with -1)."""
     N, K = w.shape
     NB, KS = N // 16, K // 32
     dev = w.device
@@ -83,7 +84,7 @@ def _chain_pieces(w):
     t = w[rows.reshape(-1)][:, cols.reshape(-1)].reshape(NB, 16, KS, 4, 8).permute(2, 0, 3, 1, 4).reshape(-1, 512)   # [pieces, 512]
     pad = (-t.shape[0]) % L.lib().wmz_layer_chain_slab_pieces()
     if pad:
-        t = torch.cat([t, t.new_zeros(pad, 512)], 0)
+        t = torch.cat([t, t.new_full((pad, 512), pad_value)], 0)
     return t
 
 
@@ -157,6 +158,173 @@ def transformer_forward_chain(tr, z):
         o, _, _ = ops.local3d_attention_fwd(q, kv[0], kv[1], ext, heads)
         x, q, kv = launch(o, x, (attn, ff), layers[l + 1] if l + 1 < len(layers) else None)
     return x
+
+
+class ChainPackSet:
+    """The training step's weight streams of csrc/layer_chain.hip for EVERY launch of the stack, rebuilt from the flat
+    parameter arena by ONE gather (the packed stream is a fixed permutation of the raw parameters: the training kernel applies
+    the LayerNorm affines itself, nothing is folded).  Index tables are built once from the inference packer's own piece order
+    (`_chain_pieces` on index matrices); refresh() = index_select + mask + cast into buffers whose addresses never change (the
+    captured training graph replays on them)."""
+
+    def __init__(self, tr, arena):
+        self.widths = D, I, M, MC = chain_widths(tr)
+        layers = list(tr.layers)
+        dev = arena.flat_param.device
+        off = {id(p): o for p, o in zip(arena.params, arena.offsets)}
+
+        def idx(p):
+            return off[id(p)] + torch.arange(p.numel(), device=dev, dtype=torch.int64).view(p.shape)
+        sp = L.lib().wmz_layer_chain_slab_pieces()
+        w_parts, v_parts, self.w_slices, self.v_slices = [], [], [], []
+        nvec = 6 * D + M + 2 * I
+        wpos = vpos = 0
+        for l in range(len(layers) + 1):
+            head = layers[l - 1] if l > 0 else None
+            tail = layers[l] if l < len(layers) else None
+            parts = []
+            vec = torch.full((nvec,), -1, dtype=torch.int64, device=dev)
+            if head is not None:
+                attn, ff = head
+                parts.append(_chain_pieces(idx(attn.fn.to_out[0].weight), -1))
+                w1, w2 = idx(ff.fn.net[0].weight), idx(ff.fn.net[3].weight)
+                for c in range(M // MC):
+                    parts.append(_chain_pieces(w1[c * MC:(c + 1) * MC], -1)[:(MC // 16) * (D // 32)])
+                    parts.append(_chain_pieces(w2[:, c * MC:(c + 1) * MC], -1)[:(D // 16) * (MC // 32)])
+                vec[:D] = idx(attn.fn.to_out[0].bias)
+                vec[D:D + M] = idx(ff.fn.net[0].bias)
+                vec[D + M:2 * D + M] = idx(ff.fn.net[3].bias)
+                vec[2 * D + M + 2 * I:3 * D + M + 2 * I] = idx(ff.norm.weight)
+                vec[3 * D + M + 2 * I:4 * D + M + 2 * I] = idx(ff.norm.bias)
+            if tail is not None:
+                an = tail[0]
+                parts += [_chain_pieces(idx(an.fn.to_q.weight), -1), _chain_pieces(idx(an.fn.to_k.weight), -1),
+                          _chain_pieces(idx(an.fn.to_v.weight), -1)]
+                vec[2 * D + M + I:2 * D + M + 2 * I] = idx(an.fn.to_v.bias)
+                vec[4 * D + M + 2 * I:5 * D + M + 2 * I] = idx(an.norm.weight)
+                vec[5 * D + M + 2 * I:] = idx(an.norm.bias)
+            stream = torch.cat(parts, 0).reshape(-1)
+            assert (stream.numel() // 512) % sp == 0
+            w_parts.append(stream)
+            self.w_slices.append((wpos, stream.numel()))
+            wpos += stream.numel()
+            v_parts.append(vec)
+            self.v_slices.append((vpos, nvec))
+            vpos += nvec
+        w_parts.append(torch.full((3 * sp * 512,), -1, dtype=torch.int64, device=dev))     # the prefetch runs past the last slab
+        widx, vidx = torch.cat(w_parts), torch.cat(v_parts)
+        self.flat = arena.flat_param
+        self.widx, self.wmask = widx.clamp(min=0), (widx >= 0).to(torch.float32)
+        self.vidx, self.vmask = vidx.clamp(min=0), (vidx >= 0).to(torch.float32)
+        self.w32 = torch.empty(widx.numel(), dtype=torch.float32, device=dev)
+        self.wpack = torch.empty(widx.numel(), dtype=torch.bfloat16, device=dev)
+        self.vec = torch.empty(vidx.numel(), dtype=torch.float32, device=dev)
+        self.refresh()
+
+    def refresh(self):
+        torch.index_select(self.flat.detach(), 0, self.widx, out=self.w32)
+        self.w32.mul_(self.wmask)
+        self.wpack.copy_(self.w32)
+        torch.index_select(self.flat.detach(), 0, self.vidx, out=self.vec)
+        self.vec.mul_(self.vmask)
+
+    def launch(self, l):
+        """(wpack, vec) views of launch l (0 = the embedding's tail-only launch, l = the launch behind layer l - 1's attention)."""
+        (wo, wn), (vo, vn) = self.w_slices[l], self.v_slices[l]
+        return self.wpack[wo:], self.vec[vo:vo + vn]
+
+
+def _chain_layer_train(packs, l, o, x_in, head, tail):
+    """Launch l of the training forward on the chain kernel -> dict of everything it wrote."""
+    D, I, M, MC = packs.widths
+    ntok = x_in.numel() // D
+    dev, bf = x_in.device, torch.bfloat16
+    wpack, vec = packs.launch(l)
+    r = {}
+    if head:
+        for k, w in (('x', D), ('x1', D), ('xn_ff', D), ('z', M), ('h', M)):
+            r[k] = torch.empty((ntok, w), dtype=bf, device=dev)
+        r['st_ff'] = torch.empty((2, ntok), dtype=torch.float32, device=dev)
+    if tail:
+        r['q'] = torch.empty((ntok, I), dtype=bf, device=dev)
+        r['kv'] = torch.empty((ntok, 2 * I), dtype=bf, device=dev)
+        r['xn_attn'] = torch.empty((ntok, D), dtype=bf, device=dev)
+        r['st_attn'] = torch.empty((2, ntok), dtype=torch.float32, device=dev)
+    g = r.get
+    L.call('wmz_layer_chain_fwd_train', L.ptr(o), L.ptr(x_in), L.ptr(g('x')), L.ptr(g('q')), L.ptr(g('kv')), L.ptr(wpack), L.ptr(vec),
+           L.ptr(g('x1')), L.ptr(g('xn_ff')), L.ptr(g('z')), L.ptr(g('h')), L.ptr(g('st_ff')), L.ptr(g('xn_attn')), L.ptr(g('st_attn')),
+           ntok, D, I, M, 1 if head else 0, 1 if tail else 0, 1e-5, L.stream())
+    return r
+
+
+class _ChainTrainForward(torch.autograd.Function):
+    """The whole stack as one autograd node for the widths of csrc/layer_chain.hip (the reference's published runs): forward =
+    embedding + per layer ONE attention launch + ONE per-token launch that also leaves what the backward reads (normalised rows,
+    pre-activation, GELU of it, LayerNorm statistics); backward layer by layer through the op-by-op block backward functions,
+    which find every operand stored (no recomputation, plain weight-gradient GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, tr, packs, z, last_only, *params):
+        from . import functional as Fw
+        D, I, M, MC = packs.widths
+        layers = list(tr.layers)
+        B, S, H, W = z.shape
+        x0 = Fw.embed_tokens(z, tr.embedding.weight.detach(), tr.pos_emb_s.weight.detach(), tr.pos_emb_h.weight.detach(),
+                             tr.pos_emb_w.weight.detach())
+        cur = _chain_layer_train(packs, 0, None, x0, False, True)
+        x_in = x0.reshape(-1, D)
+        saved = []
+        for l, (attn, ff) in enumerate(layers):
+            q, kv = cur['q'].view(B, S, H, W, I), cur['kv'].view(B, S, H, W, 2 * I)
+            o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], attn.fn.extents, attn.fn.heads, need_lse=True)
+            nxt = _chain_layer_train(packs, l + 1, o, x_in, True, l + 1 < len(layers))
+            saved += [x_in, cur['xn_attn'], cur['st_attn'], q, kv, o, lse, nxt['x1'], nxt['xn_ff'], nxt['st_ff'], nxt['z'], nxt['h']]
+            x_in, cur = nxt['x'], nxt
+        ctx.tr, ctx.widths, ctx.last_only = tr, packs.widths, bool(last_only)
+        ctx.save_for_backward(z, *saved)
+        xo = x_in.view(B, S, H, W, D)
+        return xo[:, -1].contiguous() if last_only else xo
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import backward as Bk
+        tr = ctx.tr
+        D, I, M, MC = ctx.widths
+        layers = list(tr.layers)
+        z, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        B, S, H, W = z.shape
+        grads = [None] * (14 * len(layers))
+        dy = dy.contiguous()
+        if ctx.last_only:
+            full = torch.zeros((B, S, H, W, D), dtype=dy.dtype, device=dy.device)
+            full[:, -1] = dy
+            dy = full
+        NS = 12
+        for l in range(len(layers) - 1, -1, -1):
+            attn, ff = layers[l]
+            x_in, xn_attn, st_attn, q, kv, o, lse, x1, xn_ff, st_ff, zpre, hact = saved[NS * l:NS * l + NS]
+            an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
+            x1v, x_inv = x1.view(B, S, H, W, D), x_in.view(B, S, H, W, D)
+            cf = _Ctx((x1v, fn_g, fn_b, w1, b1, w2, b2, zpre.view(B, S, H, W, M), hact.view(B, S, H, W, M), xn_ff.view(B, S, H, W, D)),
+                      has_res=True, res_is_x=True, ln_stats=(st_ff[0], st_ff[1]))
+            dx1, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2 = Bk.feed_forward_block_backward(cf, dy)[:7]
+            ca = _Ctx((x_inv, x_inv, an_g, an_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse), extents=attn.fn.extents,
+                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, same_src=True, ln_stats=(st_attn[0], st_attn[1]),
+                      xn=xn_attn.view(B, S, H, W, D))
+            r = Bk.attention_block_backward(ca, dx1)
+            dy = r[0]
+            grads[14 * l:14 * l + 14] = [r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]
+        ce = _Ctx((z,), params=(tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight))
+        ge = Bk.embed_backward(ce, dy)
+        return (None, None, None, None, ge[1], ge[2], ge[3], ge[4], *grads)
+
+
+def transformer_forward_chain_train(tr, packs, z, last_only=False):
+    """Training forward of the stack on the chain kernel (ChainPackSet of the trainer's arena)."""
+    params = [tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight]
+    for attn, ff in tr.layers:
+        params += _layer_params(attn, ff)
+    return _ChainTrainForward.apply(tr, packs, z, last_only, *params)
 
 
 def _layer_pack(head, tail):

@@ -336,6 +336,7 @@ class _TrainerBase(_AdamState):
         self.sampler_gen.manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0x7FFFFFFFFFFFFFFF)
         self.sampler = LossAwareSamplerEma(num_histogram_buckets=100, uniform_p=0.01, alpha=0.9, warmup=10)
         self.packs = None                  # fused.PackSet: the fused kernels' weight streams, rebuilt with the operands
+        self.chain_packs = None            # fused.ChainPackSet: the same for the widths of csrc/layer_chain.hip (training forward)
         self.operands = self._register_operands()
         self._refresh_operands()
         self._graph = None                 # captured training step (enable_graph)
@@ -356,6 +357,10 @@ class _TrainerBase(_AdamState):
         if hasattr(tr, 'pos_emb_s') and fused.supported(tr, dt) and config.get_fused_training() and config.fused_backward():
             layers = []
             self.packs = fused.PackSet(tr)
+        elif hasattr(tr, 'pos_emb_s') and fused.chain_supported(tr, dt) and config.get_fused_training():
+            # the reference's published widths: training FORWARD on the chain kernel (one gather rebuilds every launch's weight
+            # stream); the backward runs op by op and keeps reading the per-layer operand copies registered below
+            self.chain_packs = fused.ChainPackSet(tr, self.arena)
         for attn, ff in layers:
             a, f = attn.fn, ff.fn
             if hasattr(a, 'to_qkv'):                     # config 5: lucidrains ViT block with one fused projection
@@ -403,6 +408,8 @@ class _TrainerBase(_AdamState):
         self.operands.refresh()
         if self.packs is not None:
             self.packs.refresh()
+        if self.chain_packs is not None:
+            self.chain_packs.refresh()
 
 
     # ------------------------------------------------------------------------------------------------ hipGraph (every trainer)
@@ -548,6 +555,13 @@ class DenoiserTrainer(_TrainerBase):
             mean, rows = linear_cross_entropy(last.reshape(-1, last.shape[-1]), m.logit_proj.weight, m.logit_proj.bias,
                                               target.reshape(-1), chunk=4096, grad_scale=loss_scale)
             mean.backward()                                # (the accumulation scale is inside the fused gradient)
+            return rows.view(batch_z.shape[0], -1).mean(dim=1), mean.detach()
+        if batch_z.is_cuda and self.chain_packs is not None and config.get_fused_training():
+            tr.check_grid(batch_z)
+            last = fused.transformer_forward_chain_train(tr, self.chain_packs, batch_z, last_only=True)    # [B, H, W, D]
+            mean, rows = linear_cross_entropy(last.reshape(-1, last.shape[-1]), m.logit_proj.weight, m.logit_proj.bias,
+                                              target.reshape(-1), chunk=4096, grad_scale=loss_scale)
+            mean.backward()
             return rows.view(batch_z.shape[0], -1).mean(dim=1), mean.detach()
         y = m(batch_z)
         loss = cross_entropy_rows(y.reshape(-1, self.C), target.reshape(-1))
