@@ -566,17 +566,24 @@ def main():
             ae = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
             frames_in = torch.randn(cfg['B'] * cfg['S'], 3, 64, 64, device=dev)
             with torch.no_grad():
+                if a.eager:
+                    enc = ae.encode
+                else:
+                    from world_modelz_amd.graph import GraphedEncoder
+                    enc = GraphedEncoder(ae, frames_in)
                 for _ in range(2):
-                    tok = ae.encode(frames_in)
+                    tok = enc(frames_in)
                 barrier()
                 f0 = time.perf_counter()
-                for _ in range(5):
-                    tok = ae.encode(frames_in)
+                for _ in range(10):
+                    tok = enc(frames_in)
                 torch.cuda.synchronize()
-                fel = (time.perf_counter() - f0) / 5
+                fel = (time.perf_counter() - f0) / 10
             assert tok.shape == (cfg['B'] * cfg['S'], 16, 16)
             frame_enc = {'value': cfg['B'] * cfg['S'] / fel, 'unit': 'frames/s', 'ms_per_batch': fel * 1e3,
-                         'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens (eager launches)"}
+                         'launch_mode': 'eager' if a.eager else 'hipGraph (GraphedEncoder: one launch per batch of frames)',
+                         'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens "
+                                 '(BatchNorm in training mode as in main.py:236, quirk Q3)'}
             log(f'frame encoder: {fel * 1e3:.2f} ms per {cfg["B"] * cfg["S"]} frames')
         out['frame_encoder'] = frame_enc
         # ---- secondary figure: one VQ-AE training step (train_vqae.py:125-164: encoder -> VectorQuantizerEMA incl. the EMA

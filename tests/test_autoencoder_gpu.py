@@ -432,3 +432,30 @@ def test_conv_operands_bulk_refresh_equals_the_tensor_op_builds(wmz, dtype):
     with torch.no_grad():
         convs[1].weight.mul_(2.0)                                                # a new version: the stale entry must not be served
     assert torch.equal(autoencoder._w_op(convs[1], dtype), (ref[1][0].float() * 2).to(dtype))
+
+
+def test_graphed_frame_encoder_matches_eager_calls():
+    """GraphedEncoder (round 4): VqAutoEncoder.encode as one hipGraph launch.  The encoder runs with BatchNorm in TRAINING mode
+    (main.py:236, quirk Q3), so every call moves the running statistics: three graphed calls on fresh batches must return the
+    tokens of three eager calls from the same starting state and leave the same running statistics behind."""
+    from world_modelz_amd.graph import GraphedEncoder
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    from world_modelz_amd import config
+    torch.manual_seed(9)
+    with config.compute_dtype(torch.float32):
+        a1 = VqAutoEncoder(embedding_dim=16, num_embeddings=64, downscale_steps=2, hidden_planes=24).cuda()
+        a2 = VqAutoEncoder(embedding_dim=16, num_embeddings=64, downscale_steps=2, hidden_planes=24).cuda()
+        a2.load_state_dict(a1.state_dict())
+        frames = [torch.rand(6, 3, 32, 32, device='cuda') for _ in range(3)]
+        with torch.no_grad():
+            enc = GraphedEncoder(a2, frames[0], warmup=1)
+            a1.load_state_dict(a2.state_dict())             # the warm-up call moved a2's statistics: a1 starts from there
+            # (writing a2's buffers instead would change their versions and make the runner capture -- and warm up -- again)
+            for f in frames:
+                t1 = a1.encode(f)
+                t2 = enc(f).clone()
+                assert torch.equal(t1, t2)
+        sd1, sd2 = a1.state_dict(), a2.state_dict()
+        for k in sd1:
+            if 'running' in k or 'num_batches' in k:
+                assert torch.allclose(sd1[k].float(), sd2[k].float(), rtol=1e-6, atol=1e-7), k

@@ -193,6 +193,34 @@ def test_chain_kernel_ragged_grids_vs_oracle(wmz, dim, mlp, shape):
     assert e < 1e-2 and e < 2.0 * e_ops + 2e-3 and rel(y, y_ops) < 2e-2
 
 
+def test_dropout_in_training(wmz):
+    """dropout > 0 (local_3d_attention.py:20-31, :50-53; main.py:182 default 0): in training the feed-forward's two masks and
+    to_out's mask are applied (round 4: used to raise); eval mode and dropout 0 agree; the masks are mean-preserving (the average
+    of many training forwards approaches the eval output); gradients flow to every parameter."""
+    torch.manual_seed(3)
+    kw = dict(data_shape=(3, 8, 8), dim=64, num_classes=64, extents=(1, 1, 1), depth=2, dim_head=32, mlp_dim=96, heads=2)
+    m0 = wmz['main'].VqVideoDiffusionModel(**kw).cuda()
+    md = wmz['main'].VqVideoDiffusionModel(dropout=0.25, **kw).cuda()
+    md.load_state_dict(m0.state_dict())
+    z = torch.randint(0, 65, (2, 3, 8, 8), device='cuda')
+    with wmz['config'].compute_dtype(torch.float32):
+        m0.eval(); md.eval()
+        with torch.no_grad():
+            y0 = m0(z)
+            assert torch.allclose(md(z), y0, rtol=1e-5, atol=1e-6)
+        md.train()
+        with torch.no_grad():
+            ys = torch.stack([md(z) for _ in range(48)])
+        assert not torch.equal(ys[0], ys[1])
+        err = float((ys.mean(0) - y0).norm() / y0.norm())
+        spread = float((ys[0] - y0).norm() / y0.norm())
+        print(f'dropout 0.25: one draw differs from eval by {spread:.2f}, the mean of 48 draws by {err:.2f}')
+        assert spread > 0.05 and err < 0.5 * spread
+        md.zero_grad()
+        md(z).square().mean().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0 for p in md.parameters())
+
+
 def test_cpu_input_is_refused(wmz):
     m = wmz['main'].VqVideoDiffusionModel(data_shape=(2, 4, 4), dim=16, num_classes=8, extents=(1, 1, 1), depth=1,
                                           dim_head=8, mlp_dim=16, heads=2).cuda()

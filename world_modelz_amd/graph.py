@@ -67,3 +67,32 @@ class GraphedForward:
             self.static_in.copy_(tokens, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class _EncodeAdaptor:
+    """VqAutoEncoder.encode behind the interface GraphedForward captures (a callable with parameters() / buffers())."""
+
+    def __init__(self, ae):
+        self.ae = ae
+
+    def parameters(self):
+        return self.ae.parameters()
+
+    def buffers(self):
+        return self.ae.buffers()
+
+    def __call__(self, frames):
+        return self.ae.encode(frames)
+
+
+class GraphedEncoder(GraphedForward):
+    """The frozen VQ auto-encoder's frame encoder (main.py:236 `decoder_model.encode(frames)`: conv encoder with BatchNorm in
+    training mode -- quirk Q3, the running statistics move on every call, inside the graph -- + codebook search) as ONE hipGraph
+    launch per batch of frames:
+
+        enc = GraphedEncoder(ae, example_frames)
+        tokens = enc(frames)                               # [B, h, w] int64 (the runner's static output)
+    """
+
+    def __init__(self, ae, example_frames, warmup=2):
+        super().__init__(_EncodeAdaptor(ae), example_frames, warmup=warmup)

@@ -47,14 +47,25 @@ class FeedForward(nn.Module):
 
     def _run(self, x, ln, residual):
         if self.dropout > 0 and self.training:
-            raise NotImplementedError('dropout > 0 in training is not built into the fused HIP feed-forward '
-                                      '(reference default and every published run use dropout 0)')
+            return self._run_dropout(x, ln, residual)
         res_same = residual is x
         x = Fw._as_compute(x)
         if residual is not None:
             residual = x if res_same else Fw._as_compute(residual)
         l1, l2 = self.net[0], self.net[3]
         return Fw.feed_forward_block(x, ln, l1.weight, l1.bias, l2.weight, l2.bias, residual)
+
+    def _run_dropout(self, x, ln, residual):
+        """Training with dropout > 0 (local_3d_attention.py:20-31: Linear -> GELU -> Dropout -> Linear -> Dropout).  The reference's
+        default and every published run use 0, so this is not a fused path: the two GEMMs are the library's (Fw.linear, weight
+        gradients included), the LayerNorm, GELU, masks and the residual add are torch device ops between them."""
+        F = torch.nn.functional
+        x = Fw._as_compute(x)
+        h = x if ln is None else F.layer_norm(x, (x.shape[-1],), ln[0].to(x.dtype), ln[1].to(x.dtype), 1e-5)
+        l1, l2 = self.net[0], self.net[3]
+        h = F.dropout(F.gelu(Fw.linear(h, l1.weight, l1.bias)), self.dropout, True)
+        y = F.dropout(Fw.linear(h, l2.weight, l2.bias), self.dropout, True)
+        return y if residual is None else y + Fw._as_compute(residual)
 
     def forward(self, x):
         return self._run(x, None, None).to(x.dtype)
@@ -88,8 +99,6 @@ class Local3dAttention(nn.Module):
         self.dropout = dropout
 
     def _run(self, x, q, ln, residual):
-        if self.dropout > 0 and self.training:
-            raise NotImplementedError('dropout > 0 in training is not built into the fused HIP attention block')
         same, res_same = q is x, residual is x            # attn(x, q=x) + x: keep ONE tensor so the backward folds the paths
         x = Fw._as_compute(x)
         q = x if same else Fw._as_compute(q)
@@ -99,6 +108,14 @@ class Local3dAttention(nn.Module):
             wo = bo = None
         else:
             wo, bo = self.to_out[0].weight, self.to_out[0].bias
+        if self.dropout > 0 and self.training and wo is not None:
+            # to_out = Linear -> Dropout (local_3d_attention.py:50-53): the fused block without its residual, the mask and the
+            # residual add as torch device ops behind it (not a fused path: the reference default and every published run use 0)
+            y = Fw.attention_block(x, q, ln, self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_v.bias,
+                                   wo, bo, None, self.extents, self.heads)
+            y = torch.nn.functional.dropout(y, self.dropout, True)
+            y = y if residual is None else y + residual
+            return y.reshape(q.shape[:-1] + (y.shape[-1],))
         y = Fw.attention_block(x, q, ln, self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_v.bias,
                                wo, bo, residual, self.extents, self.heads)
         return y.reshape(q.shape[:-1] + (y.shape[-1],))
