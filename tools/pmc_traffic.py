@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {
     'attn_fwd_row16_kernel': ('attn', 'attn_fwd_row16_kernel', ['attn_fwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
     'layer_fused_kernel<head,tail>': ('fused', 'layer_fused_kernel<256, 128, 256, true, true>', ['layer_fused.hip', 'fused_common.h', 'wmz_common.h']),
+    'attn_bwd_row16_kernel<dq>': ('attn_bwd', 'attn_bwd_row16_kernel<128, 0', ['attn_bwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
+    'attn_bwd_kvplane_kernel<dk|dv>': ('attn_bwd', 'attn_bwd_kvplane_kernel<128', ['attn_bwd_row16.hip', 'attn_common.h', 'wmz_common.h']),
 }
 
 
