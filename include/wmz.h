@@ -279,16 +279,29 @@ int wmz_layer_chain_fwd_planes(const void* o, const void* x, void* x_out, void* 
                                const float* vec, int B, int n_q, int n_in, int HW, int D, int I, int M, int head, int tail,
                                float eps, void* stream);
 
-/* The TRAINING forward of the same launch (whole grids of ntok tokens).  wpack: the RAW weights in the kernel's piece order
- * (to_out | feed-forward chunks of W1 rows and W2 columns | to_q | to_k | to_v; no LayerNorm folding: the kernel applies the
- * affines itself), vec: bout[D] b1[M] b2[D] 0[I] bv[I] g_ff[D] be_ff[D] g_attn[D] be_attn[D] (the feed-forward block's norm, then
- * the NEXT layer's attention norm).  Besides x_out [ntok, D], q_out [ntok, I] and kv_out [ntok, 2 I] (k | v per row) it writes what
- * the step's backward reads: x1 [ntok, D] the feed-forward block's raw input, xn_ff [ntok, D] its LayerNorm as the first GEMM
- * consumed it, z / h [ntok, M] the pre-activation and GELU of it, st_ff [2, ntok] mean | rstd (head != 0); xn_attn [ntok, D] and
- * st_attn [2, ntok] for the next layer's to_k / to_v (tail != 0).  main.py:216-287 (the step), local_3d_attention.py:11-31. */
+/* The TRAINING forward of the same launch (whole grids of ntok tokens); wpack / vec exactly as for wmz_layer_chain_fwd_planes
+ * (LayerNorm affines folded).  Besides x_out [ntok, D], q_out [ntok, I] and kv_out [ntok, 2 I] (k | v per row) it writes what the
+ * step's backward reads: x1 [ntok, D] the feed-forward block's raw input (or NULL), xn_ff [ntok, D] its NORMALISED rows (they are
+ * the packed operand of the GEMM behind the norm), z / h [ntok, M] the pre-activation and GELU of it, st_ff [2, ntok] mean | rstd
+ * (head != 0); xn_attn [ntok, D] normalised rows and st_attn [2, ntok] for the next layer's to_k / to_v (tail != 0).
+ * main.py:216-287 (the step), local_3d_attention.py:11-31. */
 int wmz_layer_chain_fwd_train(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
                               const float* vec, void* x1, void* xn_ff, void* z, void* h, float* st_ff, void* xn_attn,
                               float* st_attn, long ntok, int D, int I, int M, int head, int tail, float eps, void* stream);
+
+/* Backward of the same per-token work (csrc/layer_chain_bwd.hip), two launches per layer around the attention backward
+ * (main.py:278 through local_3d_attention.py:11-31, :46-53, :160-161):
+ *   wmz_chain_ff_bwd:  dy [ntok, D] -> dz = (W2^T dy) gelu'(z) [ntok, M] (operand of dW1), dx1 = dy + LayerNorm'(W1'^T dz; xhat, rstd)
+ *                      [ntok, D], dout = Wout^T dx1 [ntok, I].  z / xhat / rstd: wmz_layer_chain_fwd_train's z, xn_ff, st_ff[1].
+ *                      wpack: per hidden chunk (wmz_layer_chain_supported's mc) the pieces of W2[:, chunk]^T then of W1'[chunk]^T
+ *                      (W1' = W1 diag(gamma_ff)), then Wout^T padded to whole slabs, + 2 slabs of readable padding.
+ *   wmz_chain_qkv_bwd: dx [ntok, D] = dx1 + Wq^T dq + LayerNorm'(Wk'^T dk + Wv'^T dv; xhat, rstd); dq [ntok, I], dkv [ntok, 2 I];
+ *                      wpack: pieces of Wk'^T, Wv'^T (gamma_attn folded; each padded to whole slabs), Wq^T, + 2 slabs.
+ * The weight gradients behind a norm are then plain GEMMs against xhat, converted by wmz_ln_affine_grads. */
+int wmz_chain_ff_bwd(const void* dy, const void* z, const void* xhat, const float* rstd, void* dz, void* dx1, void* dout,
+                     const void* wpack, long ntok, int D, int I, int M, void* stream);
+int wmz_chain_qkv_bwd(const void* dq, const void* dkv, const void* xhat, const float* rstd, const void* dx1, void* dx,
+                      const void* wpack, long ntok, int D, int I, void* stream);
 
 int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                    const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,

@@ -674,22 +674,27 @@ def test_published_widths_train_on_the_chain_kernel_vs_oracle(wmz, dim, mlp):
         tr = wmz['train'].DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
         assert tr.chain_packs is not None
         got = {}
-        for fused_on in (True, False):
+        # 'chain': forward and backward on the chain kernels; 'chain_fwd': chain forward, op-by-op backward; 'ops': op by op
+        for mode, (fused_on, fused_bwd) in (('chain', (True, True)), ('chain_fwd', (True, False)), ('ops', (False, True))):
             cfg.set_fused_training(fused_on)
+            cfg.set_fused_backward(fused_bwd)
             try:
                 tr.arena.zero_grad()
                 _, mean = tr.forward_backward(z.cuda(), target.cuda())
             finally:
                 cfg.set_fused_training(True)
-            got[fused_on] = (float(mean), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
-        loss_c, g_c = got[True]
-        loss_o, g_o = got[False]
+                cfg.set_fused_backward(True)
+            got[mode] = (float(mean), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+        loss_c, g_c = got['chain']
+        loss_o, g_o = got['ops']
         assert abs(loss_c - float(loss_ref)) < 2e-2 and abs(loss_c - loss_o) < 2e-2
-        worst = max((float((g_c[n] - grads_ref[n].cuda()).norm() / (grads_ref[n].norm() + 1e-12)), n) for n in g_c)
-        worst_o = max((float((g_c[n] - g_o[n]).norm() / (g_o[n].norm() + 1e-12)), n) for n in g_c)
-        print(f'dim {dim}: chain-kernel training gradients vs oracle {worst[0]:.3e} ({worst[1]}), vs op-by-op {worst_o[0]:.3e} ({worst_o[1]})')
-        assert worst[0] < 6e-2, worst
-        assert worst_o[0] < 6e-2, worst_o
+        for mode in ('chain', 'chain_fwd'):
+            g_m = got[mode][1]
+            worst = max((float((g_m[n] - grads_ref[n].cuda()).norm() / (grads_ref[n].norm() + 1e-12)), n) for n in g_m)
+            worst_o = max((float((g_m[n] - g_o[n]).norm() / (g_o[n].norm() + 1e-12)), n) for n in g_m)
+            print(f'dim {dim} [{mode}]: gradients vs oracle {worst[0]:.3e} ({worst[1]}), vs op-by-op {worst_o[0]:.3e} ({worst_o[1]})')
+            assert worst[0] < 6e-2, (mode, worst)
+            assert worst_o[0] < 6e-2, (mode, worst_o)
         # the packed streams follow the weights: one optimizer step, then the same forward must see the new weights
         tr.optimizer_step()
         tr.arena.zero_grad()

@@ -71,6 +71,8 @@ SIGNATURES = {
     'wmz_layer_chain_slab_pieces': [],
     'wmz_layer_chain_fwd_planes': [c_void_p] * 7 + [c_int] * 9 + [c_float, c_void_p],
     'wmz_layer_chain_fwd_train': [c_void_p] * 14 + [c_long] + [c_int] * 5 + [c_float, c_void_p],
+    'wmz_chain_ff_bwd': [c_void_p] * 8 + [c_long] + [c_int] * 3 + [c_void_p],
+    'wmz_chain_qkv_bwd': [c_void_p] * 7 + [c_long] + [c_int] * 2 + [c_void_p],
     'wmz_local3d_attn_fwd_planes': [c_void_p] * 5 + [c_int] * 9 + [c_long] * 4 + [c_int, c_int, c_int, c_void_p],
     'wmz_embed_qkv_fused_fwd': [c_void_p] * 10 + [c_int] * 8 + [c_float, c_void_p],
     'wmz_conv2d_nhwc_fwd': [c_void_p] * 9 + [c_int] * 10 + [c_float, c_int, c_void_p],

@@ -48,17 +48,17 @@ struct ChainParams {
   bf16_t* q;            // [B, n_q, HW, I]        (TAIL)
   bf16_t* kv;           // [2, B, n_q, HW, I]     k planes, then v planes (TAIL)
   const char* wpack;    // packed weights (+ CRING-1 slabs of padding: the prefetch runs past the last real slab)
-  const float* vec;     // bout[D] b1'[M] b2[D] bk'[I] bv'[I]     (TRAIN: the raw biases, then g_ff[D] be_ff[D] g_attn[D] be_attn[D])
+  const float* vec;     // bout[D] b1'[M] b2[D] bk'[I] bv'[I]
   int B, n_q, n_in, HW;
   float eps;
   long ldkv, voff;      // kv row stride and offset of the v half in elements (inference: I and ntok I; training: 2 I and I)
   // TRAIN only: what the backward reads (all row-major over the launch's tokens)
-  bf16_t* x1;           // [N, D]  the feed-forward block's input (raw rows)
-  bf16_t* xn_ff;        // [N, D]  LayerNorm(x1) as the first feed-forward GEMM consumed it (affine applied)
+  bf16_t* x1;           // [N, D]  the feed-forward block's input (raw rows), or NULL
+  bf16_t* xn_ff;        // [N, D]  the normalised rows of x1 (no affine: it is folded into the weights)
   bf16_t* z;            // [N, M]  feed-forward pre-activation
   bf16_t* h;            // [N, M]  GELU(z)
   float* st_ff;         // [2, N]  mean | rstd of x1
-  bf16_t* xn_attn;      // [N, D]  LayerNorm(x2) as the next layer's to_k / to_v consume it
+  bf16_t* xn_attn;      // [N, D]  the normalised rows of x2 (what the next layer's folded to_k / to_v consume)
   float* st_attn;       // [2, N]  mean | rstd of x2
 };
 
@@ -73,15 +73,14 @@ struct ChainShape {
   static constexpr int SLABS = ((HEAD ? P_OUT + (M / MC) * P_FFC : 0) + (TAIL ? 3 * P_QKV : 0)) / CSP;
 };
 
-// TRAIN: the training forward (round 4).  The weights are NOT folded (a training step changes them: the host's repack is one
-// gather of the raw parameters), the kernel applies the LayerNorm affines itself -- the rows it normalises are then exactly what the
-// GEMMs behind the norm consume, and it STORES them (the weight gradients and LayerNorm backward of the step read them as plain
-// operands) together with the raw feed-forward input, the pre-activation, GELU of it and both LayerNorm statistics pairs.
+// TRAIN: the training forward (round 4): the same launch that also STORES what the step's backward reads -- the normalised rows
+// (they ARE the packed B operands of the GEMMs behind the norms: no extra arithmetic), the feed-forward pre-activation, GELU of it,
+// both LayerNorm statistics pairs and, on request, the raw feed-forward input.
 template <int D, int I, int M, int MC, bool HEAD, bool TAIL, bool TRAIN>
 __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) {
   using S = ChainShape<D, I, M, MC, HEAD, TAIL>;
   constexpr int NBD = D / 16, NBI = I / 16, KSD = D / 32, KSI = I / 32, NBC = MC / 16, KSC = MC / 32;
-  constexpr int VEC = 2 * D + M + 2 * I + (TRAIN ? 4 * D : 0);
+  constexpr int VEC = 2 * D + M + 2 * I;
   __shared__ __attribute__((aligned(1024))) char ring[CRING * CSLAB];
   __shared__ __attribute__((aligned(16))) float vec[VEC];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -160,15 +159,6 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
 #pragma unroll
       for (int j = 0; j < 8; ++j) opnd[s][j] = (short)f32_to_bf16_bits(fmaf(acc[2 * s + (j >> 2)][j & 3], scale, shift));
   };
-  // TRAIN: acc <- gamma (acc - mean) rstd + beta in place (gamma / beta: this lane's quarter of the two vectors in LDS)
-  auto normalise = [&](f32x4 (&acc)[NBD], float mean, float rstd, const float* gam, const float* bet) {
-#pragma unroll
-    for (int b = 0; b < NBD; ++b) {
-      const f32x4 gq = *reinterpret_cast<const f32x4*>(gam + 4 * b), bq = *reinterpret_cast<const f32x4*>(bet + 4 * b);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[b][r] = fmaf((acc[b][r] - mean) * rstd, gq[r], bq[r]);
-    }
-  };
   // 16-byte global accesses of a lane's contiguous quarter row (NB blocks = 4 NB features)
   auto load_rows = [&](auto nbc, const bf16_t* row, auto& acc, bool add) {
     constexpr int NB = decltype(nbc)::value;
@@ -222,7 +212,6 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
   using CKSD = std::integral_constant<int, KSD>;
   using CKSI = std::integral_constant<int, KSI>;
   using CKSC = std::integral_constant<int, KSC>;
-
   f32x4 xr[NBD];                                            // the residual stream, fp32
   load_rows(CNBD{}, P.x + tok_in * D + g * (D / 4), xr, false);
   __syncthreads();                                          // vec is in LDS
@@ -240,17 +229,15 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
     float mean, rstd;
     ln_stats(xr, mean, rstd);
     s16x8 xb[KSD];
+    pack(CNBD{}, xr, xb, rstd, -mean * rstd);
     if constexpr (TRAIN) {
-      store_rows(CNBD{}, P.x1 + tok * D + g * (D / 4), xr);
+      // what the backward reads: the raw rows (op-by-op fallback only), the statistics, and the NORMALISED rows -- which are
+      // exactly the B operand just packed: 16 bytes per k-step, no extra arithmetic
+      if (P.x1 != nullptr) store_rows(CNBD{}, P.x1 + tok * D + g * (D / 4), xr);
       if (ok && g == 0) { P.st_ff[tok] = mean; P.st_ff[ntok + tok] = rstd; }
-      f32x4 xn[NBD];
 #pragma unroll
-      for (int b = 0; b < NBD; ++b) xn[b] = xr[b];
-      normalise(xn, mean, rstd, vec + 2 * D + M + 2 * I + g * (D / 4), vec + 3 * D + M + 2 * I + g * (D / 4));
-      pack(CNBD{}, xn, xb, 1.f, 0.f);
-      store_rows(CNBD{}, P.xn_ff + tok * D + g * (D / 4), xn);
-    } else {
-      pack(CNBD{}, xr, xb, rstd, -mean * rstd);
+      for (int s2 = 0; s2 < KSD; ++s2)
+        if (ok) *reinterpret_cast<s16x8*>(P.xn_ff + tok * D + g * (D / 4) + 8 * s2) = xb[s2];
     }
     add_vec(CNBD{}, xr, vec + D + M + g * (D / 4));         // + b2 (once)
 #pragma unroll 1
@@ -297,13 +284,12 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
     ln_stats(xr, mean, rstd);
     s16x8 xq[KSD], xn[KSD];
     pack(CNBD{}, xr, xq, 1.f, 0.f);
+    pack(CNBD{}, xr, xn, rstd, -mean * rstd);
     if constexpr (TRAIN) {
       if (ok && g == 0) { P.st_attn[tok] = mean; P.st_attn[ntok + tok] = rstd; }
-      normalise(xr, mean, rstd, vec + 4 * D + M + 2 * I + g * (D / 4), vec + 5 * D + M + 2 * I + g * (D / 4));   // (the stream is stored: xr is free)
-      pack(CNBD{}, xr, xn, 1.f, 0.f);
-      store_rows(CNBD{}, P.xn_attn + tok * D + g * (D / 4), xr);
-    } else {
-      pack(CNBD{}, xr, xn, rstd, -mean * rstd);
+#pragma unroll
+      for (int s2 = 0; s2 < KSD; ++s2)
+        if (ok) *reinterpret_cast<s16x8*>(P.xn_attn + tok * D + g * (D / 4) + 8 * s2) = xn[s2];
     }
     f32x4 a[NBI];
 #pragma unroll
@@ -371,19 +357,18 @@ extern "C" int wmz_layer_chain_fwd_planes(const void* o, const void* x, void* x_
   return WMZ_ERR_UNSUPPORTED;
 }
 
-// The training forward of the same launch (whole grids: ntok tokens, no trailing-planes form).  wpack: the RAW weights in the
-// kernel's piece order (to_out | feed-forward chunks of W1 rows and W2 columns | to_q | to_k | to_v, no LayerNorm folding), vec:
-// bout[D] b1[M] b2[D] 0[I] bv[I] g_ff[D] be_ff[D] g_attn[D] be_attn[D] (g_ff / be_ff: the feed-forward block's norm, g_attn /
-// be_attn: the NEXT layer's attention norm).  Besides x_out / q_out / kv_out ([ntok, 2 I]: k | v per row) it writes what the
-// step's backward reads: x1 [ntok, D] raw feed-forward input, xn_ff [ntok, D] its LayerNorm as consumed, z / h [ntok, M]
-// pre-activation and GELU of it, st_ff [2, ntok] mean | rstd (head != 0); xn_attn [ntok, D], st_attn [2, ntok] (tail != 0).
+// The training forward of the same launch (whole grids: ntok tokens, no trailing-planes form); wpack / vec exactly as for
+// wmz_layer_chain_fwd_planes (LayerNorm affines folded).  Besides x_out / q_out / kv_out ([ntok, 2 I]: k | v per row) it writes what
+// the step's backward reads: x1 [ntok, D] the raw feed-forward input (or NULL), xn_ff [ntok, D] its NORMALISED rows, z / h [ntok, M]
+// pre-activation and GELU of it, st_ff [2, ntok] mean | rstd (head != 0); xn_attn [ntok, D] normalised rows, st_attn [2, ntok]
+// (tail != 0).
 extern "C" int wmz_layer_chain_fwd_train(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                          const float* vec, void* x1, void* xn_ff, void* z, void* h, float* st_ff, void* xn_attn,
                                          float* st_attn, long ntok, int D, int I, int M, int head, int tail, float eps,
                                          void* stream) {
   WMZ_REQUIRE(x && wpack && vec, "wmz_layer_chain_fwd_train: null tensor");
   WMZ_REQUIRE(head || tail, "wmz_layer_chain_fwd_train: nothing to do");
-  WMZ_REQUIRE(!head || (o && x_out && x1 && xn_ff && z && h && st_ff), "wmz_layer_chain_fwd_train: head needs o, x_out and the saved tensors");
+  WMZ_REQUIRE(!head || (o && x_out && xn_ff && z && h && st_ff), "wmz_layer_chain_fwd_train: head needs o, x_out and the saved tensors");
   WMZ_REQUIRE(!tail || (q_out && kv_out && xn_attn && st_attn), "wmz_layer_chain_fwd_train: tail needs q_out, kv_out, xn_attn, st_attn");
   WMZ_REQUIRE(ntok > 0 && ntok < (1L << 31), "wmz_layer_chain_fwd_train: bad token count");
   ChainParams P;

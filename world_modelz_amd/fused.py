@@ -161,107 +161,209 @@ def transformer_forward_chain(tr, z):
 
 
 class ChainPackSet:
-    """The training step's weight streams of csrc/layer_chain.hip for EVERY launch of the stack, rebuilt from the flat
-    parameter arena by ONE gather (the packed stream is a fixed permutation of the raw parameters: the training kernel applies
-    the LayerNorm affines itself, nothing is folded).  Index tables are built once from the inference packer's own piece order
-    (`_chain_pieces` on index matrices); refresh() = index_select + mask + cast into buffers whose addresses never change (the
-    captured training graph replays on them)."""
+    """The training step's weight streams of csrc/layer_chain.hip / layer_chain_bwd.hip for EVERY launch of the stack -- forward
+    launches, feed-forward-side and attention-side backward launches -- rebuilt from the flat parameter arena by a handful of
+    launches: a packed stream is a fixed permutation of the raw parameters times (where a LayerNorm weight is folded in) one
+    gamma element each, so index tables are built ONCE from the inference packer's own piece order (`_chain_pieces` on index
+    matrices) and refresh() = two gathers, a product and a cast; the folded bias terms W beta are one batched matrix-vector
+    product per kind over strided views of the arena.  Buffer addresses never change (the captured training graph replays on
+    them)."""
 
     def __init__(self, tr, arena):
         self.widths = D, I, M, MC = chain_widths(tr)
         layers = list(tr.layers)
+        nl = len(layers)
         dev = arena.flat_param.device
         off = {id(p): o for p, o in zip(arena.params, arena.offsets)}
 
         def idx(p):
             return off[id(p)] + torch.arange(p.numel(), device=dev, dtype=torch.int64).view(p.shape)
+
+        def cols(vec_p, like):                           # index matrix of gamma[k] broadcast over the rows of a [N, K] weight
+            return idx(vec_p)[None, :].expand(like.shape[0], -1)
         sp = L.lib().wmz_layer_chain_slab_pieces()
-        w_parts, v_parts, self.w_slices, self.v_slices = [], [], [], []
-        nvec = 6 * D + M + 2 * I
-        wpos = vpos = 0
-        for l in range(len(layers) + 1):
+        one = torch.full((1, 1), -1, dtype=torch.int64, device=dev)                   # scale index -1 = no scale
+
+        def pieces(w_idx, s_idx=None, n=None):
+            """(source indices, scale indices) of the pieces of an index matrix, optionally only its first n pieces."""
+            a = _chain_pieces(w_idx, -1)
+            b = _chain_pieces(s_idx, -1) if s_idx is not None else torch.full_like(a, -1)
+            return (a, b) if n is None else (a[:n], b[:n])
+        streams, self.slices = [], {}
+        pos = 0
+
+        def add(key, parts):
+            nonlocal pos
+            w = torch.cat([p[0] for p in parts], 0).reshape(-1)
+            sc = torch.cat([p[1] for p in parts], 0).reshape(-1)
+            assert (w.numel() // 512) % sp == 0
+            streams.append((w, sc))
+            self.slices[key] = pos
+            pos += w.numel()
+        nvec = 2 * D + M + 2 * I
+        vidx = torch.full((nl + 1, nvec), -1, dtype=torch.int64, device=dev)
+        for l in range(nl + 1):
             head = layers[l - 1] if l > 0 else None
-            tail = layers[l] if l < len(layers) else None
+            tail = layers[l] if l < nl else None
             parts = []
-            vec = torch.full((nvec,), -1, dtype=torch.int64, device=dev)
             if head is not None:
                 attn, ff = head
-                parts.append(_chain_pieces(idx(attn.fn.to_out[0].weight), -1))
                 w1, w2 = idx(ff.fn.net[0].weight), idx(ff.fn.net[3].weight)
+                g1 = cols(ff.norm.weight, w1)
+                parts.append(pieces(idx(attn.fn.to_out[0].weight)))
                 for c in range(M // MC):
-                    parts.append(_chain_pieces(w1[c * MC:(c + 1) * MC], -1)[:(MC // 16) * (D // 32)])
-                    parts.append(_chain_pieces(w2[:, c * MC:(c + 1) * MC], -1)[:(D // 16) * (MC // 32)])
-                vec[:D] = idx(attn.fn.to_out[0].bias)
-                vec[D:D + M] = idx(ff.fn.net[0].bias)
-                vec[D + M:2 * D + M] = idx(ff.fn.net[3].bias)
-                vec[2 * D + M + 2 * I:3 * D + M + 2 * I] = idx(ff.norm.weight)
-                vec[3 * D + M + 2 * I:4 * D + M + 2 * I] = idx(ff.norm.bias)
+                    parts.append(pieces(w1[c * MC:(c + 1) * MC], g1[c * MC:(c + 1) * MC], (MC // 16) * (D // 32)))
+                    parts.append(pieces(w2[:, c * MC:(c + 1) * MC], None, (D // 16) * (MC // 32)))
+                vidx[l, :D] = idx(attn.fn.to_out[0].bias)
+                vidx[l, D:D + M] = idx(ff.fn.net[0].bias)
+                vidx[l, D + M:2 * D + M] = idx(ff.fn.net[3].bias)
             if tail is not None:
                 an = tail[0]
-                parts += [_chain_pieces(idx(an.fn.to_q.weight), -1), _chain_pieces(idx(an.fn.to_k.weight), -1),
-                          _chain_pieces(idx(an.fn.to_v.weight), -1)]
-                vec[2 * D + M + I:2 * D + M + 2 * I] = idx(an.fn.to_v.bias)
-                vec[4 * D + M + 2 * I:5 * D + M + 2 * I] = idx(an.norm.weight)
-                vec[5 * D + M + 2 * I:] = idx(an.norm.bias)
-            stream = torch.cat(parts, 0).reshape(-1)
-            assert (stream.numel() // 512) % sp == 0
-            w_parts.append(stream)
-            self.w_slices.append((wpos, stream.numel()))
-            wpos += stream.numel()
-            v_parts.append(vec)
-            self.v_slices.append((vpos, nvec))
-            vpos += nvec
-        w_parts.append(torch.full((3 * sp * 512,), -1, dtype=torch.int64, device=dev))     # the prefetch runs past the last slab
-        widx, vidx = torch.cat(w_parts), torch.cat(v_parts)
+                wk, wv = idx(an.fn.to_k.weight), idx(an.fn.to_v.weight)
+                parts += [pieces(idx(an.fn.to_q.weight)), pieces(wk, cols(an.norm.weight, wk)), pieces(wv, cols(an.norm.weight, wv))]
+                vidx[l, 2 * D + M + I:] = idx(an.fn.to_v.bias)
+            add(('fwd', l), parts)
+        for l, (attn, ff) in enumerate(layers):
+            # backward streams: the TRANSPOSED weights, the norms' weights folded in on the side that faces the normalised rows
+            w1, w2 = idx(ff.fn.net[0].weight), idx(ff.fn.net[3].weight)
+            g1 = cols(ff.norm.weight, w1)
+            parts = []
+            for c in range(M // MC):
+                parts.append(pieces(w2[:, c * MC:(c + 1) * MC].t(), None, (MC // 16) * (D // 32)))
+                parts.append(pieces(w1[c * MC:(c + 1) * MC].t(), g1[c * MC:(c + 1) * MC].t(), (D // 16) * (MC // 32)))
+            parts.append(pieces(idx(attn.fn.to_out[0].weight).t()))
+            add(('ff_bwd', l), parts)
+            wk, wv = idx(attn.fn.to_k.weight), idx(attn.fn.to_v.weight)
+            ga = cols(attn.norm.weight, wk)
+            add(('qkv_bwd', l), [pieces(wk.t(), ga.t()), pieces(wv.t(), ga.t()), pieces(idx(attn.fn.to_q.weight).t())])
+        tail_pad = torch.full((3 * sp * 512,), -1, dtype=torch.int64, device=dev)     # the prefetch runs past the last slab
+        widx = torch.cat([w for w, _ in streams] + [tail_pad])
+        sidx = torch.cat([sc for _, sc in streams] + [tail_pad])
         self.flat = arena.flat_param
         self.widx, self.wmask = widx.clamp(min=0), (widx >= 0).to(torch.float32)
-        self.vidx, self.vmask = vidx.clamp(min=0), (vidx >= 0).to(torch.float32)
+        self.sidx, self.smask = sidx.clamp(min=0), (sidx >= 0)
         self.w32 = torch.empty(widx.numel(), dtype=torch.float32, device=dev)
+        self.s32 = torch.empty(widx.numel(), dtype=torch.float32, device=dev)
         self.wpack = torch.empty(widx.numel(), dtype=torch.bfloat16, device=dev)
-        self.vec = torch.empty(vidx.numel(), dtype=torch.float32, device=dev)
+        self.vidx, self.vmask = vidx.reshape(-1).clamp(min=0), (vidx.reshape(-1) >= 0).to(torch.float32)
+        self.vec = torch.empty((nl + 1, nvec), dtype=torch.float32, device=dev)
+        # the folded bias terms: b1' = b1 + W1 beta_ff, bk' = Wk beta_attn, bv' = bv + Wv beta_attn, batched over the layers (a
+        # layer's parameters sit at one stride in the arena: strided [L, N, K] / [L, K, 1] views, one bmm per kind)
+        def strided(ps, shape):
+            o = [off[id(p)] for p in ps]
+            st = o[1] - o[0] if len(o) > 1 else 0
+            if any(o[i + 1] - o[i] != st for i in range(len(o) - 1)):
+                return None
+            n = ps[0].numel()
+            inner = (shape[1], 1) if len(shape) == 2 else (1, 1)
+            return torch.as_strided(self.flat, (len(ps),) + tuple(shape), (st,) + inner, o[0])
+        W1 = strided([ff.fn.net[0].weight for _, ff in layers], (M, D))
+        bff = strided([ff.norm.bias for _, ff in layers], (D, 1))
+        Wk = strided([a.fn.to_k.weight for a, _ in layers], (I, D))
+        Wv = strided([a.fn.to_v.weight for a, _ in layers], (I, D))
+        bat = strided([a.norm.bias for a, _ in layers], (D, 1))
+        assert all(t is not None for t in (W1, bff, Wk, Wv, bat)), 'layers are not laid out at one stride in the arena'
+        self._mv = [(W1, bff, self.vec[1:, D:D + M]), (Wk, bat, self.vec[:nl, 2 * D + M:2 * D + M + I]),
+                    (Wv, bat, self.vec[:nl, 2 * D + M + I:])]
         self.refresh()
 
     def refresh(self):
-        torch.index_select(self.flat.detach(), 0, self.widx, out=self.w32)
-        self.w32.mul_(self.wmask)
+        flat = self.flat.detach()
+        torch.index_select(flat, 0, self.widx, out=self.w32)
+        torch.index_select(flat, 0, self.sidx, out=self.s32)
+        self.s32.masked_fill_(~self.smask, 1.0)
+        self.w32.mul_(self.wmask).mul_(self.s32)
         self.wpack.copy_(self.w32)
-        torch.index_select(self.flat.detach(), 0, self.vidx, out=self.vec)
-        self.vec.mul_(self.vmask)
+        torch.index_select(flat, 0, self.vidx, out=self.vec.view(-1))
+        self.vec.view(-1).mul_(self.vmask)
+        for W, beta, dst in self._mv:
+            dst.add_(torch.bmm(W.detach(), beta.detach()).squeeze(-1))
 
-    def launch(self, l):
-        """(wpack, vec) views of launch l (0 = the embedding's tail-only launch, l = the launch behind layer l - 1's attention)."""
-        (wo, wn), (vo, vn) = self.w_slices[l], self.v_slices[l]
-        return self.wpack[wo:], self.vec[vo:vo + vn]
+    def stream(self, kind, l):
+        """The packed stream of launch (kind, l): 'fwd' l = 0 .. depth (0: the embedding's tail-only launch), 'ff_bwd' / 'qkv_bwd'
+        l = layer.  What lies behind a stream in the buffer is its readable padding."""
+        return self.wpack[self.slices[(kind, l)]:]
 
 
-def _chain_layer_train(packs, l, o, x_in, head, tail):
+def _chain_layer_train(packs, l, o, x_in, head, tail, keep_raw):
     """Launch l of the training forward on the chain kernel -> dict of everything it wrote."""
     D, I, M, MC = packs.widths
     ntok = x_in.numel() // D
     dev, bf = x_in.device, torch.bfloat16
-    wpack, vec = packs.launch(l)
     r = {}
     if head:
-        for k, w in (('x', D), ('x1', D), ('xn_ff', D), ('z', M), ('h', M)):
+        names = (('x', D), ('xh_ff', D), ('z', M), ('h', M)) + ((('x1', D),) if keep_raw else ())
+        for k, w in names:
             r[k] = torch.empty((ntok, w), dtype=bf, device=dev)
         r['st_ff'] = torch.empty((2, ntok), dtype=torch.float32, device=dev)
     if tail:
         r['q'] = torch.empty((ntok, I), dtype=bf, device=dev)
         r['kv'] = torch.empty((ntok, 2 * I), dtype=bf, device=dev)
-        r['xn_attn'] = torch.empty((ntok, D), dtype=bf, device=dev)
+        r['xh_attn'] = torch.empty((ntok, D), dtype=bf, device=dev)
         r['st_attn'] = torch.empty((2, ntok), dtype=torch.float32, device=dev)
     g = r.get
-    L.call('wmz_layer_chain_fwd_train', L.ptr(o), L.ptr(x_in), L.ptr(g('x')), L.ptr(g('q')), L.ptr(g('kv')), L.ptr(wpack), L.ptr(vec),
-           L.ptr(g('x1')), L.ptr(g('xn_ff')), L.ptr(g('z')), L.ptr(g('h')), L.ptr(g('st_ff')), L.ptr(g('xn_attn')), L.ptr(g('st_attn')),
-           ntok, D, I, M, 1 if head else 0, 1 if tail else 0, 1e-5, L.stream())
+    L.call('wmz_layer_chain_fwd_train', L.ptr(o), L.ptr(x_in), L.ptr(g('x')), L.ptr(g('q')), L.ptr(g('kv')),
+           L.ptr(packs.stream('fwd', l)), L.ptr(packs.vec[l]), L.ptr(g('x1')), L.ptr(g('xh_ff')), L.ptr(g('z')), L.ptr(g('h')),
+           L.ptr(g('st_ff')), L.ptr(g('xh_attn')), L.ptr(g('st_attn')), ntok, D, I, M, 1 if head else 0, 1 if tail else 0, 1e-5,
+           L.stream())
     return r
+
+
+def _chain_layer_backward(packs, l, attn, ff, dy, x_in, xh_attn, st_attn, q, kv, o, lse, xh_ff, st_ff, z, h):
+    """One layer of the stack's backward on the chain kernels: wmz_chain_ff_bwd -> attention backward -> wmz_chain_qkv_bwd, the
+    weight gradients as plain GEMMs over the operands the forward and these kernels wrote (normalised rows behind the norms), the
+    LayerNorm affine gradients from the raw weight gradients (wmz_ln_affine_grads) -- the structure of _layer_backward_fused."""
+    D, I, M, MC = packs.widths
+    an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
+    dev, bf = dy.device, torch.bfloat16
+    ntok = dy.numel() // D
+    dy2 = dy.reshape(ntok, D)
+    dz = torch.empty((ntok, M), dtype=bf, device=dev)
+    dx1 = torch.empty((ntok, D), dtype=bf, device=dev)
+    do = torch.empty(o.shape, dtype=bf, device=dev)
+    L.call('wmz_chain_ff_bwd', L.ptr(dy2), L.ptr(z), L.ptr(xh_ff), L.ptr(st_ff[1]), L.ptr(dz), L.ptr(dx1), L.ptr(do),
+           L.ptr(packs.stream('ff_bwd', l)), ntok, D, I, M, L.stream())
+    dq, dkv = ops.local3d_attention_bwd(q, kv[..., :I], kv[..., I:], o, lse, do, attn.fn.extents, attn.fn.heads)
+    dx = torch.empty(dy.shape, dtype=bf, device=dev)
+    L.call('wmz_chain_qkv_bwd', L.ptr(dq), L.ptr(dkv), L.ptr(xh_attn), L.ptr(st_attn[1]), L.ptr(dx1), L.ptr(dx),
+           L.ptr(packs.stream('qkv_bwd', l)), ntok, D, I, L.stream())
+    s_ff2, s_out, s_q = _GradSink(w2, b2), _GradSink(wout, bout), _GradSink(wq)
+    G1 = torch.empty((M, D), dtype=torch.float32, device=dev)
+    c1 = torch.empty((M,), dtype=torch.float32, device=dev)
+    Gkv = torch.empty((2 * I, D), dtype=torch.float32, device=dev)
+    ckv = torch.empty((2 * I,), dtype=torch.float32, device=dev)
+    ops.linear_wgrad_batch([
+        (dy2, h, s_ff2.bufs[0], s_ff2.bufs[1], False),                        # dW2 = dy^T GELU(z), db2 = colsum(dy)
+        (dz, xh_ff, G1, c1, True),                                             # against the NORMALISED rows: raw gradient + column sums
+        (dx1, o.reshape(ntok, I), s_out.bufs[0], s_out.bufs[1], False),
+        (dq.reshape(ntok, I), x_in.reshape(ntok, D), s_q.bufs[0], None, False),
+        (dkv.reshape(ntok, 2 * I), xh_attn, Gkv, ckv, True)])
+    s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
+    s_kv = _GradSink(wk, wv, bv, an_g, an_b)
+    bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
+    adjacent = (wk.is_contiguous() and wv.is_contiguous() and bk_.is_contiguous() and bw_.is_contiguous()
+                and wv.data_ptr() == wk.data_ptr() + 4 * wk.numel() and bw_.data_ptr() == bk_.data_ptr() + 4 * bk_.numel())
+    probs = [(G1, c1, w1, fn_g, fn_b, s_ff1.bufs[0], s_ff1.bufs[1], s_ff1.bufs[2], s_ff1.bufs[3], M, D, 0)]
+    if adjacent:
+        probs.append((Gkv, ckv, wk, an_g, an_b, bk_, s_kv.bufs[2], s_kv.bufs[3], s_kv.bufs[4], 2 * I, D, I))
+    else:
+        probs.append((Gkv[:I], ckv[:I], wk, an_g, an_b, bk_, None, s_kv.bufs[3], s_kv.bufs[4], I, D, I))
+        probs.append((Gkv[I:], ckv[I:], wv, an_g, an_b, bw_, s_kv.bufs[2], s_kv.bufs[3], s_kv.bufs[4], I, D, 0))
+    _ln_affine_grads_batch(probs)
+    g_wk, g_wv, g_bv, g_ag, g_ab = s_kv.done()
+    (g_wq,) = s_q.done()
+    g_wout, g_bout = s_out.done()
+    g_w1, g_b1, g_fg, g_fb = s_ff1.done()
+    g_w2, g_b2 = s_ff2.done()
+    return dx, [g_ag, g_ab, g_wq, g_wk, g_wv, g_bv, g_wout, g_bout, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]
 
 
 class _ChainTrainForward(torch.autograd.Function):
     """The whole stack as one autograd node for the widths of csrc/layer_chain.hip (the reference's published runs): forward =
     embedding + per layer ONE attention launch + ONE per-token launch that also leaves what the backward reads (normalised rows,
-    pre-activation, GELU of it, LayerNorm statistics); backward layer by layer through the op-by-op block backward functions,
-    which find every operand stored (no recomputation, plain weight-gradient GEMMs)."""
+    pre-activation, GELU of it, LayerNorm statistics); backward per layer = wmz_chain_ff_bwd + the attention backward +
+    wmz_chain_qkv_bwd + one batched weight-gradient launch pair (config.fused_backward() off: the op-by-op block backward
+    functions instead, reading the raw rows the forward then keeps as well)."""
 
     @staticmethod
     def forward(ctx, tr, packs, z, last_only, *params):
@@ -269,18 +371,21 @@ class _ChainTrainForward(torch.autograd.Function):
         D, I, M, MC = packs.widths
         layers = list(tr.layers)
         B, S, H, W = z.shape
+        fused_bwd = config.fused_backward()
         x0 = Fw.embed_tokens(z, tr.embedding.weight.detach(), tr.pos_emb_s.weight.detach(), tr.pos_emb_h.weight.detach(),
                              tr.pos_emb_w.weight.detach())
-        cur = _chain_layer_train(packs, 0, None, x0, False, True)
+        cur = _chain_layer_train(packs, 0, None, x0, False, True, False)
         x_in = x0.reshape(-1, D)
         saved = []
+        empty = x0.new_empty(0)
         for l, (attn, ff) in enumerate(layers):
             q, kv = cur['q'].view(B, S, H, W, I), cur['kv'].view(B, S, H, W, 2 * I)
             o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], attn.fn.extents, attn.fn.heads, need_lse=True)
-            nxt = _chain_layer_train(packs, l + 1, o, x_in, True, l + 1 < len(layers))
-            saved += [x_in, cur['xn_attn'], cur['st_attn'], q, kv, o, lse, nxt['x1'], nxt['xn_ff'], nxt['st_ff'], nxt['z'], nxt['h']]
+            nxt = _chain_layer_train(packs, l + 1, o, x_in, True, l + 1 < len(layers), not fused_bwd)
+            saved += [x_in, cur['xh_attn'], cur['st_attn'], q, kv, o, lse, nxt.get('x1', empty), nxt['xh_ff'], nxt['st_ff'],
+                      nxt['z'], nxt['h']]
             x_in, cur = nxt['x'], nxt
-        ctx.tr, ctx.widths, ctx.last_only = tr, packs.widths, bool(last_only)
+        ctx.tr, ctx.packs, ctx.last_only, ctx.fused_bwd = tr, packs, bool(last_only), fused_bwd
         ctx.save_for_backward(z, *saved)
         xo = x_in.view(B, S, H, W, D)
         return xo[:, -1].contiguous() if last_only else xo
@@ -288,8 +393,8 @@ class _ChainTrainForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         from . import backward as Bk
-        tr = ctx.tr
-        D, I, M, MC = ctx.widths
+        tr, packs = ctx.tr, ctx.packs
+        D, I, M, MC = packs.widths
         layers = list(tr.layers)
         z, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         B, S, H, W = z.shape
@@ -302,15 +407,18 @@ class _ChainTrainForward(torch.autograd.Function):
         NS = 12
         for l in range(len(layers) - 1, -1, -1):
             attn, ff = layers[l]
-            x_in, xn_attn, st_attn, q, kv, o, lse, x1, xn_ff, st_ff, zpre, hact = saved[NS * l:NS * l + NS]
+            x_in, xh_attn, st_attn, q, kv, o, lse, x1, xh_ff, st_ff, zpre, hact = saved[NS * l:NS * l + NS]
+            if ctx.fused_bwd:
+                dy, g = _chain_layer_backward(packs, l, attn, ff, dy, x_in, xh_attn, st_attn, q, kv, o, lse, xh_ff, st_ff, zpre, hact)
+                grads[14 * l:14 * l + 14] = g
+                continue
             an_g, an_b, wq, wk, wv, bv, wout, bout, fn_g, fn_b, w1, b1, w2, b2 = _layer_params(attn, ff)
             x1v, x_inv = x1.view(B, S, H, W, D), x_in.view(B, S, H, W, D)
-            cf = _Ctx((x1v, fn_g, fn_b, w1, b1, w2, b2, zpre.view(B, S, H, W, M), hact.view(B, S, H, W, M), xn_ff.view(B, S, H, W, D)),
+            cf = _Ctx((x1v, fn_g, fn_b, w1, b1, w2, b2, zpre.view(B, S, H, W, M), hact.view(B, S, H, W, M)),
                       has_res=True, res_is_x=True, ln_stats=(st_ff[0], st_ff[1]))
             dx1, g_fg, g_fb, g_w1, g_b1, g_w2, g_b2 = Bk.feed_forward_block_backward(cf, dy)[:7]
             ca = _Ctx((x_inv, x_inv, an_g, an_b, wq, wk, wv, bv, wout, bout, q, kv, o, lse), extents=attn.fn.extents,
-                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, same_src=True, ln_stats=(st_attn[0], st_attn[1]),
-                      xn=xn_attn.view(B, S, H, W, D))
+                      heads=attn.fn.heads, has_res=True, res_is_xkv=True, same_src=True, ln_stats=(st_attn[0], st_attn[1]))
             r = Bk.attention_block_backward(ca, dx1)
             dy = r[0]
             grads[14 * l:14 * l + 14] = [r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], g_fg, g_fb, g_w1, g_b1, g_w2, g_b2]
