@@ -608,39 +608,49 @@ def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
                 json.dump({'shape': 'B=2 x 3x16x16, depth 3, default widths, bf16, RCCL world of one, 5 buckets',
                            'eager_ms_per_step': wall['eager'], 'graph_ms_per_step': wall['graph']}, f)
         assert wall['graph'] <= wall['eager'] * 1.05
-        # ---- the op-by-op path (a width without fused per-token kernels): under capture its arena-bound weight gradients leave
-        # as batches on a side branch (ops.linear_wgrad), and the reducer must wait for THAT stream too before it all-reduces a
-        # bucket -- graphed data-parallel step == eager data-parallel step == single-process step
-        def make96():
-            torch.manual_seed(23)
-            return main.VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=96, num_classes=64, extents=(1, 1, 1), depth=3,
-                                              dim_head=128, mlp_dim=256, heads=1).cuda()
-        with config.compute_dtype(torch.bfloat16):
-            me, mg, ms = make96(), make96(), make96()
-            te = train.DenoiserTrainer(me, 64, lr=1e-3, warmup=0, distributed=True)
-            tg = train.DenoiserTrainer(mg, 64, lr=1e-3, warmup=0, distributed=True)
-            ts = train.DenoiserTrainer(ms, 64, lr=1e-3, warmup=0, distributed=False)
-            from world_modelz_amd import ops as _ops
-            issued = []
-            orig_issue = _ops._issue_pending
+        # ---- the other two training paths under the data-parallel capture: dim 160 = the op-by-op path (a width without fused
+        # per-token kernels): its arena-bound weight gradients leave as batches on a side branch (ops.linear_wgrad), and the
+        # reducer must wait for THAT stream too before it all-reduces a bucket; dim 96 = the chain kernels of the published widths
+        # (round 4: forward and backward on csrc/layer_chain*.hip, gradients announced per layer like the default widths').
+        # graphed data-parallel step == eager data-parallel step == single-process step
+        for dim_, batches_expected in ((160, True), (96, False)):
+            def make_w():
+                torch.manual_seed(23)
+                return main.VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=dim_, num_classes=64, extents=(1, 1, 1), depth=3,
+                                                  dim_head=128, mlp_dim=256, heads=1).cuda()
+            with config.compute_dtype(torch.bfloat16):
+                me, mg, ms = make_w(), make_w(), make_w()
+                te = train.DenoiserTrainer(me, 64, lr=1e-3, warmup=0, distributed=True)
+                tg = train.DenoiserTrainer(mg, 64, lr=1e-3, warmup=0, distributed=True)
+                ts = train.DenoiserTrainer(ms, 64, lr=1e-3, warmup=0, distributed=False)
+                assert (tg.chain_packs is not None) == (not batches_expected)
+                from world_modelz_amd import ops as _ops
+                issued = []
+                orig_issue = _ops._issue_pending
 
-            def issue():
-                issued.append(len(_ops._pending))
-                return orig_issue()
-            _ops._issue_pending = issue
-            try:
-                tg.enable_graph(z)
-            finally:
-                _ops._issue_pending = orig_issue
-            assert sum(issued) >= 3 * 4, issued                   # the capture did queue the layers' weight gradients as batches
-            for it in range(3):
-                le, ge = te.train_step(z, r=r)
-                lg, gg = tg.train_step(z, r=r)
-                ls, gs = ts.train_step(z, r=r)
-                assert abs(le - lg) < 2e-2 * max(1.0, abs(le)) and abs(ls - lg) < 2e-2 * max(1.0, abs(ls)), (it, le, lg, ls)
-                assert abs(ge - gg) < 5e-2 * max(1.0, abs(ge)) and abs(gs - gg) < 5e-2 * max(1.0, abs(gs)), (it, ge, gg, gs)
-            for (n, a), b, c in zip(me.named_parameters(), mg.parameters(), ms.parameters()):
-                assert torch.allclose(a, b, rtol=0, atol=3e-3) and torch.allclose(c, b, rtol=0, atol=3e-3), n
+                def issue():
+                    issued.append(len(_ops._pending))
+                    return orig_issue()
+                _ops._issue_pending = issue
+                try:
+                    tg.enable_graph(z)
+                finally:
+                    _ops._issue_pending = orig_issue
+                if batches_expected:
+                    assert sum(issued) >= 3 * 4, issued               # the capture did queue the layers' weight gradients as batches
+                for it in range(3):
+                    le, ge = te.train_step(z, r=r)
+                    lg, gg = tg.train_step(z, r=r)
+                    ls, gs = ts.train_step(z, r=r)
+                    assert abs(le - lg) < 2e-2 * max(1.0, abs(le)) and abs(ls - lg) < 2e-2 * max(1.0, abs(ls)), (dim_, it, le, lg, ls)
+                    assert abs(ge - gg) < 5e-2 * max(1.0, abs(ge)) and abs(gs - gg) < 5e-2 * max(1.0, abs(gs)), (dim_, it, ge, gg, gs)
+                assert sorted(te.reducer.last_order) == list(range(len(te.reducer.buckets))) and te.reducer.last_order[0] == len(te.reducer.buckets) - 1
+                for (n, a), b, c in zip(me.named_parameters(), mg.parameters(), ms.parameters()):
+                    assert torch.allclose(a, b, rtol=0, atol=3e-3) and torch.allclose(c, b, rtol=0, atol=3e-3), (dim_, n)
+                for t_ in (tg, te, ts):
+                    if getattr(t_, '_graph', None) is not None:
+                        t_._graph = None
+                torch.cuda.synchronize()
     finally:
         # (captured graphs hold RCCL kernels: let go of them and drain the device before the communicator is torn down -- a
         #  failing assertion above must surface as that assertion, not as an abort inside destroy_process_group)

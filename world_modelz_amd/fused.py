@@ -332,12 +332,18 @@ def _chain_layer_backward(packs, l, attn, ff, dy, x_in, xh_attn, st_attn, q, kv,
     c1 = torch.empty((M,), dtype=torch.float32, device=dev)
     Gkv = torch.empty((2 * I, D), dtype=torch.float32, device=dev)
     ckv = torch.empty((2 * I,), dtype=torch.float32, device=dev)
-    ops.linear_wgrad_batch([
-        (dy2, h, s_ff2.bufs[0], s_ff2.bufs[1], False),                        # dW2 = dy^T GELU(z), db2 = colsum(dy)
-        (dz, xh_ff, G1, c1, True),                                             # against the NORMALISED rows: raw gradient + column sums
-        (dx1, o.reshape(ntok, I), s_out.bufs[0], s_out.bufs[1], False),
-        (dq.reshape(ntok, I), x_in.reshape(ntok, D), s_q.bufs[0], None, False),
-        (dkv.reshape(ntok, 2 * I), xh_attn, Gkv, ckv, True)])
+    # two launch pairs: the problems that fill the 256-wide tiles of wgrad3_kernel (one ineligible problem would send the whole
+    # batch to the 128-wide kernel: 225 us a layer at dim 384), and the two narrow ones
+    wide = [(dy2, h, s_ff2.bufs[0], s_ff2.bufs[1], False),                     # dW2 = dy^T GELU(z), db2 = colsum(dy)
+            (dz, xh_ff, G1, c1, True),                                          # against the NORMALISED rows: raw gradient + column sums
+            (dkv.reshape(ntok, 2 * I), xh_attn, Gkv, ckv, True)]
+    narrow = [(dx1, o.reshape(ntok, I), s_out.bufs[0], s_out.bufs[1], False),
+              (dq.reshape(ntok, I), x_in.reshape(ntok, D), s_q.bufs[0], None, False)]
+    if D >= 256:
+        ops.linear_wgrad_batch(wide)
+        ops.linear_wgrad_batch(narrow)
+    else:
+        ops.linear_wgrad_batch(wide + narrow)
     s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
     s_kv = _GradSink(wk, wv, bv, an_g, an_b)
     bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
