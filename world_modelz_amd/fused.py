@@ -339,11 +339,6 @@ def _chain_layer_backward(packs, l, attn, ff, dy, x_in, xh_attn, st_attn, q, kv,
             (dkv.reshape(ntok, 2 * I), xh_attn, Gkv, ckv, True)]
     narrow = [(dx1, o.reshape(ntok, I), s_out.bufs[0], s_out.bufs[1], False),
               (dq.reshape(ntok, I), x_in.reshape(ntok, D), s_q.bufs[0], None, False)]
-    if D >= 256:
-        ops.linear_wgrad_batch(wide)
-        ops.linear_wgrad_batch(narrow)
-    else:
-        ops.linear_wgrad_batch(wide + narrow)
     s_ff1 = _GradSink(w1, b1, fn_g, fn_b)
     s_kv = _GradSink(wk, wv, bv, an_g, an_b)
     bk_, bw_ = s_kv.bufs[0], s_kv.bufs[1]
@@ -355,7 +350,21 @@ def _chain_layer_backward(packs, l, attn, ff, dy, x_in, xh_attn, st_attn, q, kv,
     else:
         probs.append((Gkv[:I], ckv[:I], wk, an_g, an_b, bk_, None, s_kv.bufs[3], s_kv.bufs[4], I, D, I))
         probs.append((Gkv[I:], ckv[I:], wv, an_g, an_b, bw_, s_kv.bufs[2], s_kv.bufs[3], s_kv.bufs[4], I, D, 0))
-    _ln_affine_grads_batch(probs)
+
+    def weight_grads(side):
+        if D >= 256:
+            ops.linear_wgrad_batch(wide, side=side)
+            ops.linear_wgrad_batch(narrow, side=side)
+        else:
+            ops.linear_wgrad_batch(wide + narrow, side=side)
+        _ln_affine_grads_batch(probs)
+    # nothing in the backward chain reads these results: under capture they leave on the weight-gradient side branch (gradients that
+    # land in the flat arena only: a gradient handed back to autograd is consumed on the compute stream)
+    direct = all(sk.direct for sk in (s_ff2, s_out, s_q, s_ff1, s_kv))
+    if direct and config.get_wgrad_stream():
+        ops.side_branch(dev, (dy2, h, dz, xh_ff, dkv, xh_attn, dx1, o, dq, x_in, G1, c1, Gkv, ckv), weight_grads)
+    else:
+        weight_grads(None)
     g_wk, g_wv, g_bv, g_ag, g_ab = s_kv.done()
     (g_wq,) = s_q.done()
     g_wout, g_bout = s_out.done()

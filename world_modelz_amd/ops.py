@@ -541,7 +541,26 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
     _defer(launch)
 
 
-def linear_wgrad_batch(problems):
+def side_branch(device, tensors, work):
+    """Run work() -- library launches whose results only the optimizer (and the data-parallel reducer) consume: a layer's batched
+    weight gradients -- on the weight-gradient side stream when a step is being captured (forked where `tensors`, its operands,
+    are complete; issued behind the compute stream's next launch; joined when the autograd pass ends), else right here.
+    work(side): side = the side-stream entry (its workspace) or None."""
+    with arena_fill():
+        side = _wgrad_side_enter(device, tensors)
+    if side is None:
+        work(None)
+        return
+    ent, fork = side
+
+    def launch():
+        ent[0].wait_event(fork)
+        with torch.cuda.stream(ent[0]):
+            work(ent)
+    _defer(launch)
+
+
+def linear_wgrad_batch(problems, side=None):
     """Up to 6 plain weight gradients by one launch pair (wmz_linear_wgrad_batch).  problems: (dc, a, dw, dbias | None,
     overwrite[, a_tiled]) tuples with the meaning of linear_wgrad's arguments; a_tiled: `a` is the fused path's tiled stream
     ([M, 256] bf16 in 32-row tiles) instead of row-major.  (Stays on the compute stream: at config 4 these launches fill the
@@ -568,7 +587,8 @@ def linear_wgrad_batch(problems):
         pc[i], pa[i], pw[i], pb[i] = L.ptr(dc), L.ptr(a), L.ptr(dw), L.ptr(dbias)
         lc[i], la[i], Ms[i], Ns[i], Ks[i], ov[i], tl[i] = ldc, lda, M, N, K, 1 if overwrite else 0, 1 if tiled else 0
         need += L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
-    ws = _workspace(problems[0][0].device, need)
+    dev = problems[0][0].device
+    ws = _workspace(dev, need) if side is None else _side_workspace(side, dev, need)
     L.call('wmz_linear_wgrad_batch', n, pc, lc, pa, la, pw, pb, Ms, Ns, Ks, ov, tl, L.ptr(ws), ws.numel(), dt, L.stream())
 
 
