@@ -422,20 +422,115 @@ __global__ __launch_bounds__(NT, 2) void wgrad2_kernel(WgBatch B, float* __restr
 // is nobody to fill the gaps; with 64 x 128 wave tiles six fragments feed eight MFMAs; (ii) every operand row is re-read from
 // L2 once per 128-wide output tile in the other dimension (536 MB per layer's launch against 300 MB of operands); at the
 // default widths (N, K <= 256) a problem is ONE tile and each operand element enters the CU exactly once.
-// Slabs of 64 rows in a double-buffered LDS image (128 KB), ONE register set in flight (the accumulators take 128 registers);
-// the partial tiles go through the same workspace layout and reduction kernel as version 2's.
-constexpr int W3_NT = 512, W3_T = 256, W3_MS = 64, W3_ROWB = W3_T * 2, W3_IMG = W3_MS * W3_ROWB;   // 32 KB per operand image
+// Slabs of 32 rows travel global -> LDS by DMA (global_load_lds) into a ring of W3_NBUF buffers of 32 KB (dC image | A image),
+// NBUF - 1 of them in flight or in use ahead of the multiply: no staging registers, no ds_write, and the operand stream is
+// two to three slab-times ahead of its use (round 4: with ONE register set in flight a slab had half a multiply phase, ~0.4 us,
+// to cross a ~1.5 us round trip -- the ablations added up, 88 us of streaming + 92 us of multiply = 181 us at dim 384).  LDS reads
+// are inline asm with hand-counted waits (hipcc drains the DMA ring in front of every LDS read it can see); fragments of the
+// next 16-row step are read while the MFMAs of this one run, across slab boundaries too.  The partial tiles go through the same
+// workspace layout and reduction kernel as version 2's.
+constexpr int W3_NT = 512, W3_T = 256, W3_MS = 64, W3_ROWB = W3_T * 2;
+constexpr int W3_SL = 32, W3_SIMG = W3_SL * W3_ROWB, W3_BUF = 2 * W3_SIMG;     // 16 KB per operand image, 32 KB per ring buffer
+#ifndef WMZ_W3_NBUF
+#define WMZ_W3_NBUF 4
+#endif
+constexpr int W3_NBUF = WMZ_W3_NBUF;
+#ifndef WMZ_W3_ABL            // timing ablations (tools/build_variant.py): 1 = no operand loads, 2 = no MFMA loops, 4 = no tile stores, 8 = no slab barriers
+#define WMZ_W3_ABL 0
+#endif
+typedef const __attribute__((address_space(1))) void* w3_gptr_t;
+typedef __attribute__((address_space(3))) void* w3_lptr_t;
+typedef __attribute__((ext_vector_type(2))) unsigned w3_u32x2;
 
-// transposed 32x32x16 operand from a 512-byte-row image: element j = img[m0 + 8*(lane>>5) + j][c0 + (lane&31)]
-__device__ __forceinline__ void w3_col_frag(Frag8<bf16_t>& f, const char* img, int m0, int c0, int lane) {
-  const int gi = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int ra = m0 + 8 * (gi >> 1) + q, rb = ra + 4;
-  const int cb = (c0 + 16 * (gi & 1) + 4 * p) * 2;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + ra * W3_ROWB + (cb ^ ((ra & 3) << 6))));
-  const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rb * W3_ROWB + (cb ^ ((rb & 3) << 6))));
-  f.v = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+struct W3Set { s16x4 h[12]; };      // one 16-row step's operands: halves 2i, 2i+1 of dC fragment i (2), then of A fragment j (4)
+
+// the step's twelve transposed reads (MS: first row of the step within the slab); nothing may touch the set before w3_wait
+template <int MS>
+__device__ __forceinline__ void w3_read_set(W3Set& S, unsigned base, const unsigned (&ca)[2], const unsigned (&aa)[4]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    S.h[2 * i] = ds_read_tr16_asm<MS * W3_ROWB>(base + ca[i]);
+    S.h[2 * i + 1] = ds_read_tr16_asm<(MS + 4) * W3_ROWB>(base + ca[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    S.h[4 + 2 * j] = ds_read_tr16_asm<MS * W3_ROWB>(base + aa[j]);
+    S.h[5 + 2 * j] = ds_read_tr16_asm<(MS + 4) * W3_ROWB>(base + aa[j]);
+  }
 }
+__device__ __forceinline__ void w3_wait(W3Set& S) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(S.h[0]), "+v"(S.h[1]), "+v"(S.h[2]), "+v"(S.h[3]), "+v"(S.h[4]), "+v"(S.h[5]), "+v"(S.h[6]), "+v"(S.h[7]),
+                 "+v"(S.h[8]), "+v"(S.h[9]), "+v"(S.h[10]), "+v"(S.h[11]) :: "memory");
+}
+__device__ __forceinline__ void w3_mma(f32x16 (&acc)[2][4], const W3Set& S) {
+  if (WMZ_W3_ABL & 2) return;
+  Frag8<bf16_t> cf[2], af[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) cf[i].v = __builtin_shufflevector(S.h[2 * i], S.h[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) af[j].v = __builtin_shufflevector(S.h[4 + 2 * j], S.h[5 + 2 * j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mma32(acc[i][j], cf[i], af[j]);
+}
+template <int OFF>
+__device__ __forceinline__ w3_u32x2 w3_read_b64(unsigned addr) {
+  w3_u32x2 r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+// One 16-row step: its eight MFMAs on `cur`, with the twelve reads of the step after it slotted into the first six gaps (fragment
+// g's two halves behind MFMA g; MS: that step's first row within the buffer at nbase) and four of the slab's bias-sum reads
+// into the last two; dma(0), dma(1): the caller's two DMA instructions of this step, behind MFMAs 3 and 7 (a global_load_lds
+// holds its wave's issue for 60-180 cycles: four in a burst behind the barrier, in both waves of a SIMD at once, idle the matrix
+// pipe ~360 cycles per slab).  A wave so keeps the matrix pipe fed by itself: read bursts of the two waves of a SIMD fall in phase behind
+// every barrier and leave the pipe idle for their length (bare loop, bursts: 67 % MFMA-busy).
+template <int MS, int KB, typename DMA>
+__device__ __forceinline__ void w3_mma_read(f32x16 (&acc)[2][4], const W3Set& cur, W3Set& nxt, unsigned nbase,
+                                            const unsigned (&ca)[2], const unsigned (&aa)[4], bool do_bias, w3_u32x2 (&bv)[4],
+                                            unsigned baddr, DMA&& dma) {
+  Frag8<bf16_t> cf[2], af[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) cf[i].v = __builtin_shufflevector(cur.h[2 * i], cur.h[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) af[j].v = __builtin_shufflevector(cur.h[4 + 2 * j], cur.h[5 + 2 * j], 0, 1, 2, 3, 4, 5, 6, 7);
+  static_for<8>([&](auto G) {
+    constexpr int g = G, i = g >> 2, j = g & 3;
+    if (!(WMZ_W3_ABL & 2)) mma32(acc[i][j], cf[i], af[j]);
+    if constexpr (g < 6) {
+      unsigned a = nbase;
+      if constexpr (g < 2) a += ca[g]; else a += aa[g - 2];
+      nxt.h[2 * g] = ds_read_tr16_asm<MS * W3_ROWB>(a);
+      nxt.h[2 * g + 1] = ds_read_tr16_asm<(MS + 4) * W3_ROWB>(a);
+    } else if (do_bias) {
+      constexpr int k = 2 * (g - 6);
+      bv[k] = w3_read_b64<(KB + k) * 4 * W3_ROWB>(baddr);
+      bv[k + 1] = w3_read_b64<(KB + k + 1) * 4 * W3_ROWB>(baddr);
+    }
+    if constexpr ((g & 3) == 3) dma(std::integral_constant<int, (g >> 2)>{});      // behind MFMAs 3 and 7: one DMA instruction each
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+// this wave's own DMA instructions of every slab but the `younger` most recent ones have landed (four instructions per slab)
+__device__ __forceinline__ void w3_wait_dma(int younger) {
+  if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+#ifdef WMZ_W3_STAMPS          // diagnostic build (tools/build_variant.py -DWMZ_W3_STAMPS): s_memtime stamps of wave 0 of every workgroup
+__device__ unsigned long long w3_stamps[1024 * 8];
+#define W3_STAMP(i) do { if (tid == 0) w3_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W3_PARK_BEGIN() unsigned long long park_t0 = __builtin_amdgcn_s_memtime()
+#define W3_PARK_END() do { park_sum += __builtin_amdgcn_s_memtime() - park_t0; } while (0)
+#else
+#define W3_STAMP(i) do {} while (0)
+#define W3_PARK_BEGIN() do {} while (0)
+#define W3_PARK_END() do {} while (0)
+#endif
+static_assert(W3_NBUF >= 3 && W3_NBUF <= 6, "the DMA ring: 3 .. 6 buffers (w3_wait_dma counts up to three younger slabs)");
 
 __global__ __launch_bounds__(W3_NT, 1) void wgrad3_kernel(WgBatch B, float* __restrict__ ws_base) {
   int pi = 0;
@@ -444,9 +539,7 @@ __global__ __launch_bounds__(W3_NT, 1) void wgrad3_kernel(WgBatch B, float* __re
   const WgParams P = B.p[pi];
   float* __restrict__ ws = ws_base + B.wsoff[pi];
   const int wg0 = B.first[pi], nwg = B.first[pi + 1] - B.first[pi];
-  __shared__ __attribute__((aligned(16))) char w3_smem[4 * W3_IMG];     // [buffer][dC image | A image]: 4 x 32 KB
-  constexpr int CPR = W3_ROWB / 16;                                     // 32 chunks of 8 elements per image row
-  constexpr int PER_T = W3_MS * CPR / W3_NT;                            // 4 chunks per thread and image
+  __shared__ __attribute__((aligned(1024))) char w3_smem[W3_NBUF * W3_BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = xcd_remap((int)blockIdx.x - wg0, nwg);
@@ -455,92 +548,144 @@ __global__ __launch_bounds__(W3_NT, 1) void wgrad3_kernel(WgBatch B, float* __re
   const int split = bid;
   const int n0 = bn * W3_T, k0 = bk * W3_T;
   const int m_begin = split * P.rows_per_wg, m_end = min(P.M, m_begin + P.rows_per_wg);
+  const int ns = m_begin < m_end ? (m_end - m_begin + W3_SL - 1) / W3_SL : 0;
+  const int rem = m_end - m_begin - (ns - 1) * W3_SL;                    // rows of the last slab
   const bf16_t* dC = reinterpret_cast<const bf16_t*>(P.dC);
   const bf16_t* A = reinterpret_cast<const bf16_t*>(P.A);
 
-  // a thread always lands on chunk column c = tid % 32 of rows r = tid / 32 + 16 it: column guards are loop invariants
-  const int c = tid & (CPR - 1), rbase = tid / CPR;
-  const bool c_ok = n0 + c * 8 < P.N, a_ok = k0 + c * 8 < P.K;
-  const int cg = (k0 >> 3) + c;                                         // tiled A: 16-byte chunk index of the 256-wide row
-  i32x4 rc[PER_T], ra[PER_T];
-  auto fetch = [&](int m0) {
-#pragma unroll
-    for (int it = 0; it < PER_T; ++it) {
-      const int m = m0 + rbase + 16 * it;
-      rc[it] = (i32x4)(0);
-      ra[it] = (i32x4)(0);
-#ifndef WMZ_W3_ABL            // timing ablations (tools/build_variant.py): 1 = no operand loads, 2 = no MFMA loops
-#define WMZ_W3_ABL 0
-#endif
-      if (m < m_end && !(WMZ_W3_ABL & 1)) {
-        if (c_ok) rc[it] = *reinterpret_cast<const i32x4*>(dC + (long)m * P.ldc + n0 + c * 8);
-        if (a_ok) {
-          const long aoff = P.a_tiled ? (long)(m >> 5) * (32 * 256) + ((((2 * (cg & 15) + (cg >> 4)) << 5) + (m & 31)) << 3)
-                                      : (long)m * P.lda + k0 + c * 8;
-          ra[it] = *reinterpret_cast<const i32x4*>(A + aoff);
-        }
+  // ---- DMA: wave w brings rows 8 (w & 3) .. + 7 of operand w >> 2 (0: dC, 1: A) -- four instructions of two 512-byte image
+  // rows each; lane (half, pc) lands on physical chunk pc of row r and therefore FETCHES logical chunk pc ^ ((r & 3) << 2) (the
+  // image's 64-byte XOR swizzle).  Columns past N / K are fetched from the tile's first chunk instead (finite values in output
+  // columns nobody stores); rows past m_end from row m_end - 1, and the dC rows are zeroed in LDS afterwards.
+  const int op = wave >> 2, r0 = 8 * (wave & 3) + (lane >> 5), pc = lane & 31;
+  auto src_of = [&](int m, int r) -> const char* {
+    int lc = pc ^ ((r & 3) << 2);
+    if (op == 0) {
+      if (n0 + lc * 8 >= P.N) lc = 0;
+      return reinterpret_cast<const char*>(dC + (long)m * P.ldc + n0 + lc * 8);
+    }
+    if (k0 + lc * 8 >= P.K) lc = 0;
+    if (P.a_tiled) {
+      const int cg = (k0 >> 3) + lc;                                      // 16-byte chunk index of the 256-wide row
+      return reinterpret_cast<const char*>(A + (long)(m >> 5) * (32 * 256) + ((((2 * (cg & 15) + (cg >> 4)) << 5) + (m & 31)) << 3));
+    }
+    return reinterpret_cast<const char*>(A + (long)m * P.lda + k0 + lc * 8);
+  };
+  // rows r0, r0 + 2 (their swizzles differ) carry a pointer each; rows r0 + 4, r0 + 6 sit a wave-uniform step behind them
+  const int mlast = max(m_end - 1, 0);
+  const char* sp[2] = {src_of(min(m_begin + r0, mlast), r0), src_of(min(m_begin + r0 + 2, mlast), r0 + 2)};
+  const long slab_stride = op == 0 ? (long)W3_SL * P.ldc * 2 : (P.a_tiled ? (long)32 * 256 * 2 : (long)W3_SL * P.lda * 2);
+  const long step4 = op == 0 ? (long)4 * P.ldc * 2 : (P.a_tiled ? (long)4 * 8 * 2 : (long)4 * P.lda * 2);
+  char* const dst0 = w3_smem + op * W3_SIMG + (wave & 3) * 4096;
+  int ibuf = 0;                                                           // ring buffer of the slab being issued
+  // instruction i (0..3) of slab s; the slab's four go out in order, not necessarily together (see the slab loop)
+  auto issue_part = [&](int s, auto I) {
+    constexpr int i = I;
+    char* dst = dst0 + ibuf * W3_BUF + i * 1024;
+    if (!(WMZ_W3_ABL & 1)) {
+      const int m0 = m_begin + s * W3_SL;
+      if (m0 + W3_SL <= m_end) {
+        __builtin_amdgcn_global_load_lds((w3_gptr_t)(sp[i & 1] + (i >> 1) * step4), (w3_lptr_t)dst, 16, 0, 0);
+      } else {
+        const int r = r0 + 2 * i;
+        __builtin_amdgcn_global_load_lds((w3_gptr_t)src_of(min(m0 + r, m_end - 1), r), (w3_lptr_t)dst, 16, 0, 0);
       }
     }
-  };
-  auto stash = [&](int buf) {
-    char* Cs = w3_smem + buf * 2 * W3_IMG;
-    char* As = Cs + W3_IMG;
-#pragma unroll
-    for (int it = 0; it < PER_T; ++it) {
-      const int r = rbase + 16 * it;
-      const int off = r * W3_ROWB + ((c << 4) ^ ((r & 3) << 6));
-      *reinterpret_cast<i32x4*>(Cs + off) = rc[it];
-      *reinterpret_cast<i32x4*>(As + off) = ra[it];
+    if constexpr (i == 3) {
+      ibuf = ibuf + 1 == W3_NBUF ? 0 : ibuf + 1;
+      sp[0] += slab_stride;
+      sp[1] += slab_stride;
     }
   };
+  auto issue = [&](int s) { static_for<4>([&](auto I) { issue_part(s, I); }); };
+  // rows rem .. 31 of the dC image of the last slab (in buffer `buf`) := 0, between two barriers
+  auto zero_tail = [&](int buf) {
+    char* Cs = w3_smem + buf * W3_BUF;
+    for (int idx = tid; idx < (W3_SL - rem) * 32; idx += W3_NT)
+      *reinterpret_cast<i32x4*>(Cs + (rem + (idx >> 5)) * W3_ROWB + (idx & 31) * 16) = (i32x4)(0);
+    __syncthreads();
+  };
+
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x16)(0.f);
-  float bsum = 0.f;                                    // threads 0..255 of the bk == 0 workgroups: column sums of dC
   const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+  // fragment addresses within a ring buffer (w3_col_frag's addressing: row 8 (gi >> 1) + q (+ 4), the swizzle is q << 6)
+  unsigned ca[2], aa[4];
+  {
+    const int gi = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const unsigned rowp = (8 * (gi >> 1) + q) * W3_ROWB, x = (16 * (gi & 1) + 4 * p) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ca[i] = rowp + ((unsigned)((wn + 32 * i) * 2) ^ (unsigned)(q << 6)) + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aa[j] = W3_SIMG + rowp + ((unsigned)((wk + 32 * j) * 2) ^ (unsigned)(q << 6)) + x;
+  }
+  const unsigned smem0 = lds_addr(w3_smem);
+  // column sums of dC (threads 0..255 of the bk == 0 workgroups): thread (g = tid >> 6, c4 = tid & 63) sums columns 4 c4 .. + 3
+  // over the rows r = g (mod 4) -- one 8-byte read per row; the four row classes meet in LDS at the end
+  const bool do_bias = P.dbias != nullptr && bk == 0 && tid < W3_T;
+  float bsum4[4] = {0.f, 0.f, 0.f, 0.f};
+  const unsigned bias_a = (unsigned)((tid >> 6) & 3) * W3_ROWB + ((unsigned)((tid & 63) * 8) ^ (unsigned)(((tid >> 6) & 3) << 6));
 
-  auto compute = [&](int cur) {
-    const char* Cs = w3_smem + cur * 2 * W3_IMG;
-    const char* As = Cs + W3_IMG;
-    if (P.dbias != nullptr && bk == 0 && tid < W3_T) {
-#pragma unroll 8
-      for (int r = 0; r < W3_MS; ++r) {
-        const char* p = Cs + r * W3_ROWB + ((tid * 2) ^ ((r & 3) << 6));
-        bsum += Elem<bf16_t>::to_f32(*reinterpret_cast<const bf16_t*>(p));
+  unsigned long long park_sum = 0;
+  W3_STAMP(0);
+  const int npro = min(ns, W3_NBUF - 1);
+  for (int s = 0; s < npro; ++s) issue(s);
+  W3Set S0, S1;
+  W3_STAMP(1);
+  if (ns > 0) {
+    w3_wait_dma(npro - 1);
+    __builtin_amdgcn_s_barrier();
+    if (ns == 1 && rem < W3_SL) zero_tail(0);
+    w3_read_set<0>(S0, smem0, ca, aa);
+    w3_wait(S0);
+  }
+  W3_STAMP(2);
+  int cb = 0;                                                             // ring buffer of the slab being multiplied
+  for (int s = 0; s < ns; ++s) {
+    const unsigned base = smem0 + cb * W3_BUF;
+    const int nb = cb + 1 == W3_NBUF ? 0 : cb + 1;
+    w3_u32x2 bv[4];                                                       // bias-sum reads: rows g + 4 k, k < 4 with the first step, the rest with the second
+    auto bias_add = [&]() {
+      asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bsum4[0] += __uint_as_float(bv[k][0] << 16); bsum4[1] += __uint_as_float(bv[k][0] & 0xffff0000u);
+        bsum4[2] += __uint_as_float(bv[k][1] << 16); bsum4[3] += __uint_as_float(bv[k][1] & 0xffff0000u);
       }
+    };
+    // rows 0..15 | reads rows 16..31 | the second half of slab s + NBUF - 2's DMA (its first half went out behind the last barrier)
+    const bool dma_a = s >= 1 && s + W3_NBUF - 2 < ns;
+    w3_mma_read<16, 0>(acc, S0, S1, base, ca, aa, do_bias, bv, base + bias_a, [&](auto K) {
+      if (dma_a) issue_part(s + W3_NBUF - 2, std::integral_constant<int, 2 + decltype(K)::value>{});
+    });
+    w3_wait(S1);
+    if (do_bias) bias_add();
+    if (s + 1 < ns) {
+      // slab s + 1 becomes visible; behind this barrier nobody reads slab s - 1 any more: its buffer takes slab s + NBUF - 1
+      W3_PARK_BEGIN();
+      w3_wait_dma(min(W3_NBUF - 3, ns - s - 2));
+      if (!(WMZ_W3_ABL & 8)) __builtin_amdgcn_s_barrier();
+      W3_PARK_END();
+      if (s + 2 == ns && rem < W3_SL) zero_tail(nb);
     }
-    if (WMZ_W3_ABL & 2) return;
-#pragma unroll
-    for (int ms = 0; ms < W3_MS; ms += 16) {
-      Frag8<bf16_t> cf[2], af[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) w3_col_frag(cf[i], Cs, ms, wn + 32 * i, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w3_col_frag(af[j], As, ms, wk + 32 * j, lane);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mma32(acc[i][j], cf[i], af[j]);
-    }
-  };
-  // slab s lives in LDS buffer s & 1; the register set carries slab s + 1 on its way in while slab s is multiplied
-  if (m_begin < m_end) {
-    fetch(m_begin);
-    stash(0);
-    fetch(m_begin + W3_MS);                            // (rows past m_end come back as zeros)
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int m0 = m_begin; m0 < m_end; m0 += W3_MS) {
-    compute(cur);
-    stash(cur ^ 1);                                    // slab s + 1 (buffer last read before the previous barrier)
-    fetch(m0 + 2 * W3_MS);
-    __syncthreads();
-    cur ^= 1;
+    // rows 16..31 | reads rows 0..15 of slab s + 1 (behind the last slab: of a buffer nobody needs -- the values are dropped) |
+    // the first half of slab s + NBUF - 1's DMA into the buffer the barrier has just freed
+    const bool dma_b = s + W3_NBUF - 1 < ns;
+    w3_mma_read<0, 4>(acc, S1, S0, smem0 + nb * W3_BUF, ca, aa, do_bias, bv, base + bias_a, [&](auto K) {
+      if (dma_b) issue_part(s + W3_NBUF - 1, K);
+    });
+    w3_wait(S0);
+    if (do_bias) bias_add();
+    cb = nb;
   }
 
+  W3_STAMP(3);
+#ifdef WMZ_W3_STAMPS
+  if (tid == 0) w3_stamps[blockIdx.x * 8 + 5] = park_sum;
+#endif
   // D: row (n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (k') = lane&31
   const int l31 = lane & 31, hh = lane >> 5;
   const long nblk256 = ((long)P.N * P.K + 255) >> 8;
@@ -553,15 +698,24 @@ __global__ __launch_bounds__(W3_NT, 1) void wgrad3_kernel(WgBatch B, float* __re
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int n = n0 + wn + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-        if (n < P.N) {
+        if (n < P.N && (!(WMZ_W3_ABL & 4) || P.M < 0)) {
           const long q = (long)n * P.K + kc;
           ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[i][j][reg];
         }
       }
     }
-  if (P.dbias != nullptr && bk == 0 && tid < W3_T && n0 + tid < P.N) {
-    ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = bsum;
+  if (P.dbias != nullptr && bk == 0) {                 // the four row classes of a column meet in LDS (the ring is done with)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(w3_smem);
+    if (tid < W3_T) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[(tid >> 6) * W3_T + 4 * (tid & 63) + e] = bsum4[e];
+    }
+    __syncthreads();
+    if (tid < W3_T && n0 + tid < P.N)
+      ws[nblk256 * P.nsplit * 256 + (long)split * P.N + n0 + tid] = (red[tid] + red[W3_T + tid]) + (red[2 * W3_T + tid] + red[3 * W3_T + tid]);
   }
+  W3_STAMP(4);
 }
 
 // dW[n, k] += sum over the slices; dbias[n] += sum over the slices (fixed order: deterministic).  A workgroup owns 256
@@ -984,6 +1138,12 @@ static int wgrad_batch_plain(int n, const void* const* dC, const long* ldc, cons
                              const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats,
                              int dtype, void* stream, bool single_v3);
 
+#ifdef WMZ_W3_STAMPS
+extern "C" int wmz_debug_w3_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w3_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+
 extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
                                       float* const* dW, float* const* dbias, const int* M, const int* N, const int* K,
                                       const int* overwrite, const int* a_tiled, float* workspace, long workspace_floats,
@@ -991,10 +1151,13 @@ extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* 
   return wgrad_batch_plain(n, dC, ldc, A, lda, dW, dbias, M, N, K, overwrite, a_tiled, workspace, workspace_floats, dtype, stream, false);
 }
 
-// 256-wide tiles (wgrad3_kernel) pay off for a bf16 problem that fills at least half of its tiles and has rows to slice
+// 256-wide tiles (wgrad3_kernel) pay off for a bf16 problem that fills at least WMZ_W3_FILL8 / 8 of its tiles and has rows to slice
+#ifndef WMZ_W3_FILL8
+#define WMZ_W3_FILL8 3          // 128 x 384 (the published width's to_q / to_out) rides along: 12.83 -> 12.65 ms a step
+#endif
 static bool wgrad3_eligible(int M, int N, int K, int dtype) {
   const int tn = wmz_cdiv(N, W3_T), tk = wmz_cdiv(K, W3_T);
-  return dtype == WMZ_BF16 && (long)N * K * 2 >= (long)tn * tk * W3_T * W3_T && M >= 4 * W3_MS;
+  return dtype == WMZ_BF16 && (long)N * K * 8 >= (long)tn * tk * W3_T * W3_T * WMZ_W3_FILL8 && M >= 4 * W3_MS;
 }
 
 static int wgrad_batch_plain(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,

@@ -1,5 +1,6 @@
 """Host side of wmz_layer_fused_fwd: weight / vector packing (cached per parameter version) and the fused
 inference forward of Local3dAttentionTransformer (bf16, default widths)."""
+import os
 import torch
 
 from . import _cast, config, ops
@@ -332,8 +333,8 @@ def _chain_layer_backward(packs, l, attn, ff, dy, x_in, xh_attn, st_attn, q, kv,
     c1 = torch.empty((M,), dtype=torch.float32, device=dev)
     Gkv = torch.empty((2 * I, D), dtype=torch.float32, device=dev)
     ckv = torch.empty((2 * I,), dtype=torch.float32, device=dev)
-    # two launch pairs: the problems that fill the 256-wide tiles of wgrad3_kernel (one ineligible problem would send the whole
-    # batch to the 128-wide kernel: 225 us a layer at dim 384), and the two narrow ones
+    # ONE launch pair: at dim 384 all five fill >= 3/8 of their 256-wide tiles (wgrad3_kernel's bar; one ineligible problem would
+    # send the whole batch to the 128-wide kernel: 225 us a layer)
     wide = [(dy2, h, s_ff2.bufs[0], s_ff2.bufs[1], False),                     # dW2 = dy^T GELU(z), db2 = colsum(dy)
             (dz, xh_ff, G1, c1, True),                                          # against the NORMALISED rows: raw gradient + column sums
             (dkv.reshape(ntok, 2 * I), xh_attn, Gkv, ckv, True)]
@@ -352,11 +353,7 @@ def _chain_layer_backward(packs, l, attn, ff, dy, x_in, xh_attn, st_attn, q, kv,
         probs.append((Gkv[I:], ckv[I:], wv, an_g, an_b, bw_, s_kv.bufs[2], s_kv.bufs[3], s_kv.bufs[4], I, D, 0))
 
     def weight_grads(side):
-        if D >= 256:
-            ops.linear_wgrad_batch(wide, side=side)
-            ops.linear_wgrad_batch(narrow, side=side)
-        else:
-            ops.linear_wgrad_batch(wide + narrow, side=side)
+        ops.linear_wgrad_batch(wide + narrow, side=side)
         _ln_affine_grads_batch(probs)
     # nothing in the backward chain reads these results: under capture they leave on the weight-gradient side branch (gradients that
     # land in the flat arena only: a gradient handed back to autograd is consumed on the compute stream)
