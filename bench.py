@@ -532,7 +532,7 @@ def main():
                         ptr.train_step(z, r=pr)
                     torch.cuda.synchronize()
                     entry['train_ms_per_step'] = (time.perf_counter() - p0) / 5 * 1e3
-                    entry['train_launch_mode'] = 'hipGraph (chain kernels: per layer one attention forward + one per-token launch, attention backward between two per-token backward launches, two weight-gradient launch pairs)'
+                    entry['train_launch_mode'] = 'hipGraph (chain kernels: per layer one attention forward + one per-token launch, attention backward between two per-token backward launches, one weight-gradient launch pair on the side branch)'
                     log(f'published widths dim {dim_} depth {depth_}: training step {entry["train_ms_per_step"]:.2f} ms')
                     del ptr
                 pub.append(entry)

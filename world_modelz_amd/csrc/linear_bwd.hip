@@ -487,6 +487,10 @@ __device__ __forceinline__ w3_u32x2 w3_read_b64(unsigned addr) {
 // holds its wave's issue for 60-180 cycles: four in a burst behind the barrier, in both waves of a SIMD at once, idle the matrix
 // pipe ~360 cycles per slab).  A wave so keeps the matrix pipe fed by itself: read bursts of the two waves of a SIMD fall in phase behind
 // every barrier and leave the pipe idle for their length (bare loop, bursts: 67 % MFMA-busy).
+#ifndef WMZ_W3_RGAPS
+#define WMZ_W3_RGAPS 6
+#endif
+constexpr int W3_RGAPS = WMZ_W3_RGAPS;       // the twelve reads go into the first RGAPS gaps (12 / RGAPS each)
 template <int MS, int KB, typename DMA>
 __device__ __forceinline__ void w3_mma_read(f32x16 (&acc)[2][4], const W3Set& cur, W3Set& nxt, unsigned nbase,
                                             const unsigned (&ca)[2], const unsigned (&aa)[4], bool do_bias, w3_u32x2 (&bv)[4],
@@ -499,15 +503,20 @@ __device__ __forceinline__ void w3_mma_read(f32x16 (&acc)[2][4], const W3Set& cu
   static_for<8>([&](auto G) {
     constexpr int g = G, i = g >> 2, j = g & 3;
     if (!(WMZ_W3_ABL & 2)) mma32(acc[i][j], cf[i], af[j]);
-    if constexpr (g < 6) {
-      unsigned a = nbase;
-      if constexpr (g < 2) a += ca[g]; else a += aa[g - 2];
-      nxt.h[2 * g] = ds_read_tr16_asm<MS * W3_ROWB>(a);
-      nxt.h[2 * g + 1] = ds_read_tr16_asm<(MS + 4) * W3_ROWB>(a);
-    } else if (do_bias) {
-      constexpr int k = 2 * (g - 6);
-      bv[k] = w3_read_b64<(KB + k) * 4 * W3_ROWB>(baddr);
-      bv[k + 1] = w3_read_b64<(KB + k + 1) * 4 * W3_ROWB>(baddr);
+    if constexpr (g < W3_RGAPS) {
+      static_for<12 / W3_RGAPS>([&](auto R) {
+        constexpr int h = g * (12 / W3_RGAPS) + R, f = h >> 1;
+        unsigned a = nbase;
+        if constexpr (f < 2) a += ca[f]; else a += aa[f - 2];
+        nxt.h[h] = ds_read_tr16_asm<(MS + 4 * (h & 1)) * W3_ROWB>(a);
+      });
+    }
+    if constexpr (g >= 6) {
+      if (do_bias) {
+        constexpr int k = 2 * (g - 6);
+        bv[k] = w3_read_b64<(KB + k) * 4 * W3_ROWB>(baddr);
+        bv[k + 1] = w3_read_b64<(KB + k + 1) * 4 * W3_ROWB>(baddr);
+      }
     }
     if constexpr ((g & 3) == 3) dma(std::integral_constant<int, (g >> 2)>{});      // behind MFMAs 3 and 7: one DMA instruction each
     __builtin_amdgcn_sched_barrier(0);
@@ -1151,13 +1160,13 @@ extern "C" int wmz_linear_wgrad_batch(int n, const void* const* dC, const long* 
   return wgrad_batch_plain(n, dC, ldc, A, lda, dW, dbias, M, N, K, overwrite, a_tiled, workspace, workspace_floats, dtype, stream, false);
 }
 
-// 256-wide tiles (wgrad3_kernel) pay off for a bf16 problem that fills at least WMZ_W3_FILL8 / 8 of its tiles and has rows to slice
-#ifndef WMZ_W3_FILL8
-#define WMZ_W3_FILL8 3          // 128 x 384 (the published width's to_q / to_out) rides along: 12.83 -> 12.65 ms a step
+// 256-wide tiles (wgrad3_kernel) pay off for a bf16 problem that fills at least WMZ_W3_FILL16 / 16 of its tiles and has rows to slice
+#ifndef WMZ_W3_FILL16
+#define WMZ_W3_FILL16 6         // 128 x 384 (the published width's to_q / to_out) rides along: 12.83 -> 12.65 ms a step
 #endif
 static bool wgrad3_eligible(int M, int N, int K, int dtype) {
   const int tn = wmz_cdiv(N, W3_T), tk = wmz_cdiv(K, W3_T);
-  return dtype == WMZ_BF16 && (long)N * K * 8 >= (long)tn * tk * W3_T * W3_T * WMZ_W3_FILL8 && M >= 4 * W3_MS;
+  return dtype == WMZ_BF16 && (long)N * K * 16 >= (long)tn * tk * W3_T * W3_T * WMZ_W3_FILL16 && M >= 4 * W3_MS;
 }
 
 static int wgrad_batch_plain(int n, const void* const* dC, const long* ldc, const void* const* A, const long* lda,
