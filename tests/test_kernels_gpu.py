@@ -245,6 +245,28 @@ def test_wgrad_batch_on_256_wide_tiles(ops, M):
             assert rel(db, rb) < 2e-3 and rel(db, sb) < 1e-5
 
 
+@pytest.mark.parametrize('M', [65536, 8231])
+def test_wgrad_batch_on_256_wide_tiles_partial_columns(ops, M):
+    """wgrad3_kernel's operand ring (round 4: LDS-DMA with the swizzle on the source side) where a 256-wide tile is only partly
+    inside the problem: the published width's 128 x 384 / 384 x 128 gradients (3/8 of their tiles: the new eligibility bar), and
+    widths that are multiples of 8 only (N = 200: 25 of a tile's 32 chunks; K = 264: the second tile column holds ONE chunk) --
+    the out-of-range chunks are fetched from the tile's first chunk and must not reach the result; ragged M on top."""
+    torch.manual_seed(53)
+    shapes = [(128, 384, True, False), (384, 128, False, True), (200, 264, True, False), (384, 512, True, True), (264, 200, True, False)]
+    probs, refs = [], []
+    for N, K, bias, over in shapes:
+        dc = (torch.randn(M, N) * 0.3).bfloat16()
+        a = (torch.randn(M, K) * 1.1 + 0.1).bfloat16()
+        init, binit = torch.randn(N, K), torch.randn(N)
+        refs.append(((0 if over else init) + dc.float().t() @ a.float(), (0 if over else binit) + dc.float().sum(0)))
+        probs.append((dev(dc), dev(a), dev(init).clone(), dev(binit).clone() if bias else None, over))
+    ops.linear_wgrad_batch(probs)
+    for (dcd, ad, dw, db, over), (rw, rb) in zip(probs, refs):
+        assert torch.isfinite(dw).all() and rel(dw, rw) < 2e-3
+        if db is not None:
+            assert rel(db, rb) < 2e-3
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,S,HW,D,N', [(8, 5, 256, 256, 1024), (3, 4, 20, 32, 50), (2, 1, 77, 64, 130)])
 def test_linear_on_last_frame_blocks(ops, dtype, B, S, HW, D, N):
