@@ -46,6 +46,38 @@ def test_sparse_model_vs_golden_and_grads(wmz):
         assert rel(p.grad, leaves[n].grad) < 5e-5, n
 
 
+def test_sparse_model_dropout_in_training(wmz):
+    """dropout > 0 in config 5's blocks (minecraft/transformer.py:21-31, :44-62: on the attention PROBABILITIES, behind to_out and
+    inside the feed-forward; sparse_diffusion.py:76 default 0): used to raise in training.  Eval agrees with the dropout-0 model;
+    with every mask drawn as keep (p -> the torch path but dropout 1e-9) the un-fused attention path reproduces the fused one;
+    training draws differ and their mean approaches eval; gradients reach every parameter."""
+    torch.manual_seed(5)
+    kw = dict(shape=(4, 8, 8), dim=64, num_classes=40, depth=2, dim_head=32, mlp_dim=96, heads=2)
+    m0 = wmz['sd'].VqSparseDiffusionModel(**kw).cuda()
+    md = wmz['sd'].VqSparseDiffusionModel(dropout=0.25, **kw).cuda()
+    me = wmz['sd'].VqSparseDiffusionModel(dropout=1e-9, **kw).cuda()
+    md.load_state_dict(m0.state_dict())
+    me.load_state_dict(m0.state_dict())
+    x = torch.randint(0, 41, (3, 48), device='cuda')
+    idx = torch.stack([torch.randperm(256, device='cuda')[:48] for _ in range(3)])
+    with wmz['config'].compute_dtype(torch.float32):
+        m0.eval(); md.eval()
+        with torch.no_grad():
+            y0 = m0(x, idx)
+            assert torch.allclose(md(x, idx), y0, rtol=1e-5, atol=1e-6)
+            me.train()
+            assert rel(me(x, idx), y0) < 1e-5                  # the torch-composed attention == the HIP attention block
+        md.train()
+        with torch.no_grad():
+            ys = torch.stack([md(x, idx) for _ in range(48)])
+        assert not torch.equal(ys[0], ys[1])
+        err, spread = rel(ys.mean(0), y0), rel(ys[0], y0)
+        assert spread > 0.05 and err < 0.5 * spread, (spread, err)
+        md.zero_grad()
+        md(x, idx).square().mean().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0 for p in md.parameters())
+
+
 @pytest.mark.parametrize('n', [512, 100])
 def test_sparse_model_default_width_bf16(wmz, n):
     """dim 512, 4 heads x 128, mlp 1024 (sparse_diffusion.py:233-257), n = 512 tokens (16-wide fast path) and a

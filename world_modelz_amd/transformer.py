@@ -29,13 +29,32 @@ class Attention(nn.Module):
 
     def _run(self, x, ln, residual):
         if self.p_drop > 0 and self.training:
-            raise NotImplementedError('dropout > 0 in training is not built into the fused HIP attention block')
+            return self._run_dropout(x, ln, residual)
         res_same = residual is x
         x = Fw._as_compute(x)
         if residual is not None:
             residual = x if res_same else Fw._as_compute(residual)
         wo, bo = (None, None) if isinstance(self.to_out, nn.Identity) else (self.to_out[0].weight, self.to_out[0].bias)
         return Fw.dense_attention_block(x, ln, self.to_qkv.weight, wo, bo, residual, self.heads)
+
+    def _run_dropout(self, x, ln, residual):
+        """Training with dropout > 0 (transformer.py:44-62: softmax -> Dropout on the attention PROBABILITIES -> . V -> to_out ->
+        Dropout).  The reference default (sparse_diffusion.py:76) is 0, so this is not a fused path: the probabilities have to exist
+        to be masked, which the flash-style HIP attention never lets them -- the two projections are the library's GEMMs
+        (Fw.linear, weight gradients included); LayerNorm, the n x n scores, softmax, both masks, the value product and the
+        residual add are torch device ops (n = 512 context tokens at config 5)."""
+        F = torch.nn.functional
+        x = Fw._as_compute(x)
+        h = x if ln is None else F.layer_norm(x, (x.shape[-1],), ln[0].to(x.dtype), ln[1].to(x.dtype), 1e-5)
+        B, n = h.shape[0], h.shape[1]
+        qkv = Fw.linear(h, self.to_qkv.weight, None).view(B, n, 3, self.heads, -1).permute(2, 0, 3, 1, 4)     # [3, B, heads, n, dh]
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = torch.softmax(torch.matmul(q, k.transpose(-1, -2)).float() * self.scale, dim=-1)
+        attn = F.dropout(attn, self.p_drop, True).to(v.dtype)
+        o = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, n, -1)
+        if not isinstance(self.to_out, nn.Identity):
+            o = F.dropout(Fw.linear(o, self.to_out[0].weight, self.to_out[0].bias), self.p_drop, True)
+        return o if residual is None else o + Fw._as_compute(residual)
 
     def forward(self, x):
         return self._run(x, None, None).to(x.dtype)
