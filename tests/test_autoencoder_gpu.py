@@ -223,12 +223,38 @@ def test_vqae_training_step_grads_vs_golden(wmz):
     assert worst[0] < 5e-4, worst
 
 
-def test_eval_mode_backward_is_refused(wmz):
+def test_eval_mode_backward_vs_oracle_autograd(wmz):
+    """Gradients THROUGH an evaluated encoder / decoder (eval-mode BatchNorm = the affine map of its running statistics; round 4:
+    used to raise): input gradient and every parameter gradient, BatchNorm gamma / beta included, against torch.autograd over the
+    oracle with training=False.  sd1 = the state after a training step, so the running statistics are not the initial 0 / 1."""
+    from oracle import autoencoder as oae
     g = load_golden('ae_roundtrip')
-    m = _model(wmz, sub(g, 'sd0/'))
+    sd = sub(g, 'sd1/')
+    m = _model(wmz, sd)
     m.eval()
-    with pytest.raises(NotImplementedError):
-        m(g['x'].cuda())
+    torch.manual_seed(9)
+    xin = g['x'].clone()
+    zin = torch.randn(xin.shape[0], 16, xin.shape[2] // 4, xin.shape[3] // 4)
+    leaves = {k: (v.clone().float().requires_grad_(True) if v.is_floating_point() and 'running' not in k and not k.startswith('vq.')
+                  else v.clone()) for k, v in sd.items()}
+    with wmz['config'].compute_dtype(torch.float32):
+        for name, mod, fwd, inp in (('encoder', m.encoder, oae.encoder_forward, xin), ('decoder', m.decoder, oae.decoder_forward, zin)):
+            xd = inp.cuda().requires_grad_(True)
+            y = mod(xd)
+            xo = inp.clone().requires_grad_(True)
+            yo = fwd(leaves, xo, False)
+            assert y.shape == yo.shape and rel(y, yo) < 1e-5, name
+            w = torch.randn_like(yo)
+            (y * w.cuda()).sum().backward()
+            (yo * w).sum().backward()
+            assert rel(xd.grad, xo.grad) < 1e-4, name
+            for n, p in mod.named_parameters():
+                ref = leaves[f'{name}.{n}'].grad
+                assert p.grad is not None and rel(p.grad, ref) < 2e-4, (name, n)
+    # the running statistics did not move
+    for n, b in m.named_buffers():
+        if 'running' in n:
+            assert torch.equal(b.cpu(), sd[n]), n
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])

@@ -70,14 +70,7 @@ def _grad_path(x, *mods):
     """True when this forward must be differentiable (training through the HIP autograd Functions): some parameter of the
     block is trainable, or the INPUT carries a gradient (a frozen block inside a trainable encoder must still pass the
     gradient on to the layers in front of it)."""
-    if not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for m in mods for p in m.parameters())):
-        return False
-    for m in mods:
-        for sub in m.modules():
-            if isinstance(sub, nn.BatchNorm2d) and not sub.training:
-                raise NotImplementedError('backward through eval-mode BatchNorm is not built on the HIP path '
-                                          '(train the VQ-AE in .train() mode, run the frozen AE under no_grad)')
-    return True
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
 
 
 def _wT_op(weight, dtype):
@@ -195,7 +188,27 @@ def _conv_g(x, conv):
 
 
 def _bnact_g(x, bn, r=None, leaky=True):
+    if not bn.training:
+        return _bnact_eval_g(x, bn, r, leaky)
     return _BnActFn.apply(x, bn.weight, bn.bias, r, bn, leaky)
+
+
+def _bnact_eval_g(x, bn, r, leaky):
+    """Eval-mode BatchNorm inside a differentiable forward (an evaluated or frozen auto-encoder that still has to pass gradients on:
+    nn.BatchNorm2d in eval mode is the per-channel affine map of its running statistics): y = act(x * scale + shift [+ r]) as torch
+    device ops under autograd -- a rare path (the reference trains the VQ-AE in train mode, train_vqae.py:125, and never evaluates
+    the frozen one, quirk Q3); the convolutions around it stay on the HIP kernels.  x: NHWC, channels padded to a multiple of 8."""
+    c, c8 = bn.num_features, x.shape[-1]
+    scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+    shift = bn.bias.float() - bn.running_mean.float() * scale
+    if c8 != c:
+        scale, shift = F.pad(scale, (0, c8 - c)), F.pad(shift, (0, c8 - c))
+    y = x.float() * scale + shift
+    if r is not None:
+        y = y + r.float()
+    if leaky:
+        y = F.leaky_relu(y, LEAKY)
+    return y.to(x.dtype)
 
 
 def _conv(x, conv, dtype, **kw):
