@@ -259,6 +259,30 @@ def test_vq_module_sequence_vs_golden():
     assert float(m.activation_count.abs().sum()) == 0 and float(m.accumulated_error.abs().sum()) == 0
 
 
+@pytest.mark.parametrize('E,C', [(128, 64), (200, 40), (24, 96)])
+def test_vq_module_wide_and_odd_embedding_dims_vs_oracle(E, C):
+    """embedding_dim off the instantiated widths (8 / 16 / 32 / 64): the run-time-E nearest-code kernel (round 4: rows wider than
+    ~100 floats need more than the default 64 KB of dynamic LDS -- used to fail with `embedding_dim 128 too large`), the gather,
+    the EMA statistics and the codebook update: two training forwards and an eval forward against the oracle's restatement of
+    vq.py:25-75 -- indices equal, outputs and every buffer to 1e-5."""
+    from world_modelz_amd.vq import VectorQuantizerEMA
+    from oracle import vq as ovq
+    torch.manual_seed(E)
+    m = VectorQuantizerEMA(E, C)
+    state = {k: getattr(m, k).clone() for k in ('embedding', 'cluster_size', 'activation_count', 'accumulated_error')}
+    m = m.cuda()
+    for step, training in enumerate((True, True, False)):
+        m.train(training)
+        x = torch.randn(3, 50, 1, E) * 0.7
+        qo, eo, lo, po = ovq.forward(x, state, training)
+        q, e, l, pp = m(x.cuda())
+        assert torch.equal(e.argmax(-1).cpu(), eo.argmax(-1)), step
+        assert torch.allclose(q.detach().cpu(), qo, rtol=0, atol=1e-6)
+        assert torch.allclose(l.detach().cpu(), lo, rtol=1e-5) and torch.allclose(pp.detach().cpu(), po, rtol=1e-5)
+        for b in ('embedding', 'cluster_size', 'activation_count', 'accumulated_error'):
+            assert torch.allclose(getattr(m, b).cpu(), state[b], rtol=1e-5, atol=1e-6), (step, b)
+
+
 def test_vq_module_encode_decode_vs_golden():
     from world_modelz_amd.vq import VectorQuantizerEMA
     g = load_golden('vq_encode_1024')

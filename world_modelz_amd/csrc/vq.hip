@@ -326,10 +326,17 @@ template <int E>
 int launch_argmin(const float* x, long ldx, const float* cb, int64_t* idx, float* dmin, int N, int C, int Ert,
                   hipStream_t st) {
   const int Ed = E > 0 ? E : Ert;
+  // LDS: a tile of CT codes + (run-time E only) the workgroup's 64 rows, transposed + the waves' minima.  Wide rows (E > ~100 on
+  // the run-time path) need more than the default 64 KB of dynamic LDS: the codebook tile shrinks first, then the limit is raised
+  // (160 KB per workgroup on gfx950; E < 512 -- the caller's bound -- fits with CT >= 4)
+  const size_t fixed = (E > 0 ? 0 : (size_t)Ed * VQ_ROWS * 4) + VQ_WAVES * VQ_ROWS * 8;
   int CT = 128;
   while (CT > 4 && (size_t)CT * Ed * 4 > 48 * 1024) CT >>= 1;
-  size_t smem = (size_t)CT * Ed * 4 + (E > 0 ? 0 : (size_t)Ed * VQ_ROWS * 4) + VQ_WAVES * VQ_ROWS * 8;
-  if (smem > 64 * 1024) { wmz_set_error("wmz_vq_argmin: embedding_dim %d too large", Ed); return WMZ_ERR_UNSUPPORTED; }
+  while (CT > 4 && (size_t)CT * Ed * 4 + fixed > 152 * 1024) CT >>= 1;
+  const size_t smem = (size_t)CT * Ed * 4 + fixed;
+  if (smem > 160 * 1024) { wmz_set_error("wmz_vq_argmin: embedding_dim %d too large", Ed); return WMZ_ERR_UNSUPPORTED; }
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(vq_argmin_kernel<E>, dim3(wmz_cdiv(N, VQ_ROWS)), dim3(VQ_NT), smem, st, x, ldx, cb, idx, dmin, N,
                      C, Ert, CT);
   WMZ_LAUNCH_CHECK("wmz_vq_argmin");
