@@ -14,6 +14,17 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # WMZ_GUARD_ALLOC=1 (development sweep, GPU box): every tensor at the end of its own hipMalloc region (tools/guard_alloc.cpp), so a
+    # kernel that runs past the end of an operand faults.  hipMalloc cannot run inside a stream capture: deselect the graph tests
+    # (-k "not graph").  Must happen before the first device allocation of the process.
+    if os.environ.get('WMZ_GUARD_ALLOC') == '1':
+        lib = os.path.join(ROOT, 'tools', 'libguard_alloc.so')
+        alloc = torch.cuda.memory.CUDAPluggableAllocator(lib, 'guard_alloc', 'guard_free')
+        torch.cuda.memory.change_current_allocator(alloc)
+
+        def no_capture(self, *a, **k):          # a test that reaches a capture is skipped before the stream starts capturing
+            pytest.skip('guard allocator: hipMalloc cannot run inside a stream capture')
+        torch.cuda.CUDAGraph.capture_begin = no_capture
 
 
 def load_golden(name):

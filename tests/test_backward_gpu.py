@@ -129,6 +129,8 @@ def test_default_model_backward_bf16_vs_oracle(wmz):
     ((1, 4, 16, 16), 2, 64, (1, 2, 3)),
     ((1, 3, 40, 16), 1, 32, (2, 2, 2)),        # H > 16: several workgroups per plane, both roles
     ((1, 2, 5, 16), 4, 32, (0, 1, 0)),
+    ((2, 2, 1, 16), 4, 128, (0, 1, 16)),       # one row per plane (config 5's dense attention over 16 tokens)
+    ((1, 2, 17, 16), 1, 64, (1, 2, 2)),        # H = 1 (mod 16)
 ])
 def test_attention_backward_row16_fast_path(wmz, shape, heads, dh, ext):
     """bf16, W == 16: attn_bwd_row16.hip against torch.autograd over the oracle (2e-2 rel: P and dS are bf16 MFMA
@@ -162,6 +164,7 @@ def test_attention_backward_row16_fast_path(wmz, shape, heads, dh, ext):
     ((1, 3, 16, 8), 1, 128, (1, 3, 1)),        # 8 tile rows: two workgroups per plane
     ((1, 2, 24, 8), 1, 64, (0, 5, 2)),         # 12 tile rows: the 8-wave shapes
     ((1, 2, 6, 8), 1, 128, (1, 1, 1)),         # ragged chunk
+    ((2, 3, 2, 8), 1, 128, (1, 1, 3)),         # two plane rows = one tile row
 ])
 def test_attention_backward_8_wide_planes(wmz, shape, heads, dh, ext):
     """bf16, W == 8 (even H): the row kernels of attn_bwd_row16.hip on tile rows of 16 with rim masks, against torch.autograd over

@@ -442,6 +442,8 @@ def test_library_refuses_cpu_tensors(ops):
     ((1, 3, 40, 16), 1, 32, (2, 2, 2)),        # H > 16: several workgroups per plane
     ((1, 2, 5, 16), 4, 32, (0, 1, 0)),         # H < 16: idle waves
     ((1, 6, 16, 16), 1, 128, (5, 0, 7)),       # wide column window, single row
+    ((2, 2, 1, 16), 4, 128, (0, 1, 16)),       # ONE row per plane (config 5's dense attention over 16 tokens): no slab of odd rows
+    ((1, 2, 17, 16), 1, 64, (1, 2, 2)),        # H = 1 (mod 16): the last chunk has no odd row either
 ])
 def test_attention_row16_fast_path(ops, shape, heads, dh, ext):
     """bf16, W == 16 takes attn_fwd_row16.hip -- the kernel bench.py times.  Probed directly (its own logits dump, not the
@@ -480,6 +482,7 @@ def test_attention_row16_fast_path(ops, shape, heads, dh, ext):
     ((1, 2, 24, 8), 1, 64, (0, 5, 2)),         # 12 tile rows: the 16-wave shape with 8-wide planes
     ((1, 2, 6, 8), 1, 128, (1, 1, 1)),         # 3 tile rows: a ragged chunk
     ((1, 2, 8, 8), 1, 128, (1, 9, 9)),         # window larger than the plane
+    ((2, 3, 2, 8), 1, 128, (1, 1, 3)),         # two plane rows = ONE tile row
 ])
 def test_attention_8_wide_planes_fast_path(ops, shape, heads, dh, ext):
     """bf16, W == 8 with an even number of rows takes attn_fwd_row16.hip too (round 4): the plane is read as H / 2 tile rows of 16,

@@ -7,6 +7,8 @@ Per case: random (B, S, H, W), heads x dim_head, extents (including windows wide
 library picks its own path (16-wide / 8-wide row kernels, small-plane shape, general kernel).  Checked: out, lse, dq | dk | dv."""
 import sys, random, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _guard  # noqa: F401,E402  (WMZ_GUARD_ALLOC=1: over-read detector)
 from world_modelz_amd import ops
 from oracle import attention as oat
 

@@ -5,6 +5,8 @@ against torch.autograd over the fp32 CPU oracle (test infrastructure: run by han
     python3 tools/fuzz_train.py [cases [seed]]"""
 import sys, random, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _guard  # noqa: F401,E402  (WMZ_GUARD_ALLOC=1: over-read detector)
 from world_modelz_amd import config, fused
 from world_modelz_amd.main import VqVideoDiffusionModel
 from world_modelz_amd.train import DenoiserTrainer

@@ -5,6 +5,8 @@ bit for bit) and the screened search against the exact scan (test infrastructure
     python3 tools/fuzz_vq.py [cases [seed]]"""
 import sys, random, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _guard  # noqa: F401,E402  (WMZ_GUARD_ALLOC=1: over-read detector)
 from world_modelz_amd import ops
 from oracle import vq as ovq
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60

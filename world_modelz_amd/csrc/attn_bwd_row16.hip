@@ -177,11 +177,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (MODE == 0 && !W8 ? 4 : 2) : 1)
   long vrow_n = 0;
   auto next_state = [&]() {
     base_n = ((c_first + (rem_n >> 1)) << LOG_CH) + (rem_n & 1);
-    y1p = y1pl + (unsigned)base_n * rs1;
-    y2p = y2pl + (unsigned)base_n * rs2;
+    const int bsafe = min(base_n, H - 1);                // (a one-row plane has no odd row: fetch that unread slab from inside the plane)
+    y1p = y1pl + (unsigned)bsafe * rs1;
+    y2p = y2pl + (unsigned)bsafe * rs2;
     dbuf = smem + (jn & 1) * I::BUF;
     dlim = max(H - 1 - base_n, 0);
-    vrow_n = vrow_pl + (long)base_n * 16;
+    vrow_n = vrow_pl + (long)bsafe * 16;
   };
   auto advance = [&]() {
     ++jn;

@@ -213,8 +213,11 @@ __global__ __launch_bounds__(SH::NW * 64, 4) void attn_fwd_row16_kernel(const bf
   int dlim = CH - RS;
   auto next_state = [&]() {                                              // descriptors of slab (pl_n, rem_n)
     base_n = ((c_first + (rem_n >> LOG_RS)) << LOG_CH) + (rem_n & (RS - 1));
-    kp = kpl + (unsigned)base_n * rsk;
-    vp = vpl + (unsigned)base_n * rsv;
+    // (a one-row plane has no row of phase 1: that slab -- which no wave reads -- is fetched from the last row instead of from
+    //  behind the plane; found by tools/guard_overread.py: a read past the end of the K / V tensor for H = 1)
+    const int bsafe = min(base_n, H - 1);
+    kp = kpl + (unsigned)bsafe * rsk;
+    vp = vpl + (unsigned)bsafe * rsv;
     dbuf = smem + (jn & (NBUF - 1)) * I::BUF;
     dlim = max(H - 1 - base_n, 0);
   };
