@@ -17,7 +17,7 @@ def pytest_configure(config):
     # WMZ_GUARD_ALLOC=1 (development sweep, GPU box): every tensor at the end of its own hipMalloc region (tools/guard_alloc.cpp), so a
     # kernel that runs past the end of an operand faults.  hipMalloc cannot run inside a stream capture: deselect the graph tests
     # (-k "not graph").  Must happen before the first device allocation of the process.
-    if os.environ.get('WMZ_GUARD_ALLOC') == '1':
+    if os.environ.get('WMZ_GUARD_ALLOC') in ('1', '2'):
         lib = os.path.join(ROOT, 'tools', 'libguard_alloc.so')
         alloc = torch.cuda.memory.CUDAPluggableAllocator(lib, 'guard_alloc', 'guard_free')
         torch.cuda.memory.change_current_allocator(alloc)

@@ -5,6 +5,7 @@
 //   WMZ_GUARD_ALLOC=1 python -m pytest tests -m gpu -k "not graph" ...        (tests/conftest.py switches the allocator)
 #include <hip/hip_runtime.h>
 #include <sys/types.h>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -18,7 +19,10 @@ extern "C" void* guard_alloc(ssize_t size, int device, hipStream_t) {
   void* base = nullptr;
   (void)hipSetDevice(device);
   if (hipMalloc(&base, tot) != hipSuccess) return nullptr;
-  void* p = (char*)base + ((tot - (size_t)size) & ~(size_t)255);
+  // WMZ_GUARD_ALLOC=2: at the START of the region instead (what lies in front of a hipMalloc region is normally unmapped too):
+  // catches reads / writes in FRONT of an operand
+  static const bool at_start = [] { const char* e = getenv("WMZ_GUARD_ALLOC"); return e && e[0] == '2'; }();
+  void* p = at_start ? base : (void*)((char*)base + ((tot - (size_t)size) & ~(size_t)255));
   std::lock_guard<std::mutex> l(g_mu);
   g_base[p] = base;
   return p;
