@@ -2,6 +2,8 @@
 prof_train.py [steps [dim mlp depth eS eH eW]] -- e.g. `8 384 512 20 3 1 1` = the reference's published dim-384 run."""
 import sys, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _guard  # noqa: F401,E402  (WMZ_GUARD_ALLOC=1: over-read detector)
 from world_modelz_amd import config
 from world_modelz_amd.main import VqVideoDiffusionModel
 from world_modelz_amd.train import DenoiserTrainer, corrupt_last_frame

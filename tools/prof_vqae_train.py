@@ -1,6 +1,8 @@
 """Micro-driver: a few VQ-AE training steps (train_vqae.py's step body) on 64 frames of 64x64 for rocprofv3 (not part of the product)."""
 import sys, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
+import _guard  # noqa: F401,E402  (WMZ_GUARD_ALLOC=1: over-read detector)
 from world_modelz_amd import config
 from world_modelz_amd.train_vqae import VqAutoEncoder
 from world_modelz_amd.train import VqaeTrainer
