@@ -1,0 +1,58 @@
+"""Randomised model / grid configurations: the training step as ONE hipGraph (DenoiserTrainer.enable_graph) against the same
+trainer stepping eagerly -- three steps each from the same weights with the same noise levels: losses, gradient norms and the
+final weights (the graph path adds the captured side branches, the device-side step scalars and the in-graph operand re-pack).
+
+    python3 tools/fuzz_graph.py [cases [seed]]"""
+import sys, random, torch
+sys.path.insert(0, '.')
+from world_modelz_amd import config
+from world_modelz_amd.main import VqVideoDiffusionModel
+from world_modelz_amd.train import DenoiserTrainer
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(seed)
+bad = 0
+for c in range(cases):
+    dim, mlp, dh, heads = rng.choice([(256, 256, 128, 1), (96, 256, 128, 1), (384, 512, 128, 1), (64, 96, 32, 2), (160, 256, 128, 1)])
+    H, W = rng.choice([(16, 16), (8, 8), (4, 8), (6, 8), (2, 16), (6, 6), (1, 16)])
+    S, B, depth = rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 4]), rng.choice([1, 2, 3])
+    ext = (rng.choice([1, 2, 3]), rng.choice([0, 1, 3]), rng.choice([0, 1, 3]))
+    dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float32])
+    C = rng.choice([64, 40, 128])
+    def make():
+        torch.manual_seed(seed * 31 + c)
+        m = VqVideoDiffusionModel(data_shape=(S, H, W), dim=dim, num_classes=C, extents=ext, depth=depth, dim_head=dh, mlp_dim=mlp, heads=heads).cuda()
+        return m, DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
+    tag = f'case {c}: B {B} grid {(S, H, W)} dim {dim} mlp {mlp} {heads}x{dh} depth {depth} ext {ext} C {C} {str(dt)[6:]}'
+    try:
+        with config.compute_dtype(dt):
+            me, te = make()
+            mg, tg = make()
+            z = torch.randint(0, C, (B, S, H, W), device='cuda')
+            r = torch.zeros(B)                   # r = 0: the corruption is the identity, so both trainers see the same batch
+
+            class Zero:
+                def sample(self, n, generator=None): return torch.zeros(n)
+                def update_with_losses(self, *a): pass
+            te.sampler, tg.sampler = Zero(), Zero()
+            tg.enable_graph(z)
+            out = []
+            for it in range(3):
+                le, ge = te.train_step(z, r=r)
+                lg, gg = tg.train_step(z, r=r)
+                out.append((le, lg, ge, gg))
+            torch.cuda.synchronize()
+    except Exception as e:                       # noqa: BLE001
+        print(f'{tag}: RAISED {type(e).__name__}: {str(e)[:300]}', flush=True)
+        bad += 1
+        continue
+    f32 = dt == torch.float32
+    dl = max(abs(a - b) / max(1.0, abs(a)) for a, b, _, _ in out)
+    dg = max(abs(a - b) / max(1.0, abs(a)) for _, _, a, b in out)
+    dw = max(float((a - b).abs().max()) for a, b in zip(me.parameters(), mg.parameters()))
+    ok = dl < (2e-5 if f32 else 2e-2) and dg < (1e-3 if f32 else 5e-2) and dw < (1e-5 if f32 else 4e-3)
+    bad += 0 if ok else 1
+    print(f'{tag}: loss {dl:.1e}, grad norm {dg:.1e}, weights {dw:.1e}' + ('' if ok else '   <-- FAIL'), flush=True)
+    del te, tg, me, mg
+print(f'{bad} bad of {cases}')
+sys.exit(1 if bad else 0)
