@@ -162,6 +162,36 @@ def test_sampler_loop_runs_and_unmasks(wmz):
     assert int(torch.isfinite(tk).sum()) == 18
 
 
+def test_sampler_session_is_reused_and_follows_the_weights(wmz):
+    """The fused sampler keeps its captured step (forward + next draw + counter) with the model between calls (round 4: a call
+    used to pay the capture again, ~4 ms against ~11 ms for a frame of 30 iterations): the second call replays the first call's
+    graph, a reseeded generator reproduces a call on it, another generator state gives other tokens, and after the weights moved
+    the SAME session re-captures (GraphedForward's stamp) and samples from the new model."""
+    from world_modelz_amd import sample
+    torch.manual_seed(6)
+    C = 32
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 8, 8), dim=64, num_classes=C, extents=(1, 1, 1), depth=2, dim_head=32,
+                                          mlp_dim=64, heads=2).cuda().eval()
+    z = torch.randint(0, C, (2, 3, 8, 8), device='cuda')
+    def run(seed):
+        return sample.sample_frames(m, z, C, num_frames=2, num_eval_iterations=5, sample_topk=8, generator=torch.Generator().manual_seed(seed))[0]
+    a = run(3)
+    ses = next(iter(sample._sessions[m].values()))
+    g0 = ses.fwd.graph
+    b, c = run(3), run(4)
+    assert len(sample._sessions[m]) == 1 and ses.fwd.graph is g0 and ses.fwd.recaptures == 0
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and any(not torch.equal(x, y) for x, y in zip(a, c))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(-1.0)                                   # (every logit flips sign: the draws change)
+    d = run(3)
+    assert ses.fwd.recaptures == 1 and any(not torch.equal(x, y) for x, y in zip(a, d))
+    # ... and it equals a fresh session on the moved weights
+    sample._sessions[m].clear()
+    e = run(3)
+    assert all(torch.equal(x, y) for x, y in zip(d, e))
+
+
 @pytest.mark.parametrize('name', ['sampler_tiny', 'sampler_tiny_topk'])
 @pytest.mark.parametrize('use_graph', [False, True])
 def test_sampler_loop_token_for_token_vs_reference(wmz, name, use_graph):

@@ -59,10 +59,15 @@ class GraphedForward:
         self._operands = [h[1] for h in _cast._cache.values()]      # strong references (tensors or tuples of tensors)
         self.stamp = self._stamp()
 
-    def __call__(self, tokens):
+    def refresh(self):
+        """Re-capture now if the weights / configuration moved since the capture (a caller whose pre / post work keeps device
+        state -- the sampler's counter and last frame -- calls this BEFORE it sets that state up: a capture runs pre / post)."""
         if self._stamp() != self.stamp:
             self.recaptures += 1
             self._capture()
+
+    def __call__(self, tokens):
+        self.refresh()
         if tokens is not self.static_in:
             self.static_in.copy_(tokens, non_blocking=True)
         self.graph.replay()

@@ -6,6 +6,8 @@ Per generated frame: the last latent frame starts fully masked; 30 denoise itera
 then the frames shift by one.  Everything stays on the GPU: the forward is ONE hipGraph launch per iteration
 (GraphedForward), sampling uses device RNG, and there is no host sync inside a frame.
 """
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -75,54 +77,93 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
             batch_z[:, -1] = frame.view(B, H, W)
             if trace is not None:
                 trace.append(frame.view(B, H, W).clone())
-            logits = (fwd(batch_z) if fwd is not None else model(batch_z)).reshape(B * H * W, num_embeddings).float()
+            if i + 1 < num_eval_iterations:                       # (the reference runs the model behind a frame's last draw too, :111,
+                #                                                    and never reads those logits)
+                logits = (fwd(batch_z) if fwd is not None else model(batch_z)).reshape(B * H * W, num_embeddings).float()
         out.append(denoised.view(B, H, W).clone())
         batch_z[:, :-1] = batch_z[:, 1:].clone()                  # shift frames (:115)
     return out, (batch_z.clone() if fwd is not None else batch_z)   # (never hand out the graph's own buffer)
 
 
+_SEED_KEY = 0x9E3779B97F4A7C15                   # the captured kernels' Philox key (a kernel ARGUMENT, i.e. baked into the graph):
+#                                                   what varies per call is the device-side counter's starting value
+_sessions = weakref.WeakKeyDictionary()          # model -> {configuration: captured sampler step + its device buffers}
+
+
+class _Session:
+    """One captured sampler step (forward + draw of the next iteration + counter) and the device state it works on, kept with the
+    model across sample_frames calls: capturing costs ~4 ms, a frame of 30 iterations ~11 (GraphedForward re-captures by itself
+    when the weights, the compute dtype or the run-time configuration changed)."""
+
+    def __init__(self, model, batch_z, C, n_iter, sample_topk, consistent_masking):
+        from . import ops
+        B, S, H, W = batch_z.shape
+        dev = batch_z.device
+        R = B * H * W
+        self.alphas = torch.zeros(n_iter, dtype=torch.float32, device=dev)
+        self.logits = torch.zeros(R, (C + 3) // 4 * 4, dtype=torch.float32, device=dev)[:, :C]     # rows 16-byte aligned whatever C is
+        self.denoised = torch.zeros(R, dtype=torch.int64, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.last_mask = torch.ones(R, dtype=torch.uint8, device=dev) if consistent_masking else None
+        aligned = C % 4 == 0
+        holder = {}
+
+        def draw(src, z):
+            ops.sample_tokens(src, sample_topk, self.alphas, C, z[:, -1], self.denoised, self.counter, _SEED_KEY, self.last_mask)
+            self.counter.add_(1)
+
+        def pre(z):
+            holder['z'] = z
+
+        def post(y):
+            src = y.reshape(R, C)
+            if not aligned:
+                self.logits.copy_(src)
+                src = self.logits
+            draw(src, holder['z'])
+        self.draw = draw
+        self.fwd = GraphedForward(model, batch_z, pre=pre, post=post)
+
+
 def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_iterations, sample_topk, noise_schedule,
                          consistent_masking, generator):
     """The same loop with NO host work inside a frame but one graph launch per iteration: the draw + re-mask step is one
-    kernel (wmz_sample_tokens_dev: top-k, softmax, inverse-CDF draw and re-mask per row, uniforms from in-kernel Philox keyed by
-    one draw from the caller's generator per call and a device-side iteration counter) captured in FRONT of the forward it feeds, the logits hand-over and
-    the counter increment behind it.  Same distribution as the torch path (which stays for injected uniforms: the parity
-    fixtures), different random stream."""
-    from . import ops
+    kernel (wmz_sample_tokens_dev: top-k, softmax, inverse-CDF draw and re-mask per row, uniforms from in-kernel Philox indexed
+    by a device-side iteration counter that starts, per call, at a draw from the caller's generator) captured BEHIND the forward
+    whose logits it reads, the counter increment behind it.  One graph replay = the forward on the current grid + the draw of the
+    NEXT iteration from its logits (read where the graph leaves them: no hand-over copy when the rows are 16-byte aligned).  A
+    frame's first draw (from the flat start, :71) is one eager launch in front of its replays, and the forward behind a frame's
+    LAST draw -- whose logits the reference computes (:111) and never reads -- is not run: n - 1 forwards per frame instead of n.
+    The captured step stays with the model between calls (_Session).  Same distribution as the torch path (which stays for
+    injected uniforms: the parity fixtures), different random stream."""
     B, S, H, W = batch_z.shape
-    dev = batch_z.device
-    R, C = B * H * W, num_embeddings
-    alphas = torch.tensor([min(max(noise_schedule((i + 1) / num_eval_iterations) if noise_schedule is not None
-                                   else (i + 1) / num_eval_iterations, 0.0), 1.0) for i in range(num_eval_iterations)],
-                          dtype=torch.float32, device=dev)
-    logits = torch.zeros(R, (C + 3) // 4 * 4, dtype=torch.float32, device=dev)[:, :C]     # rows 16-byte aligned whatever C is
-    denoised = torch.zeros(R, dtype=torch.int64, device=dev)
-    counter = torch.zeros(1, dtype=torch.int64, device=dev)
-    last_mask = torch.ones(R, dtype=torch.uint8, device=dev) if consistent_masking else None
-    # The in-kernel Philox is keyed per CALL by one 62-bit draw from the caller's generator (the global CPU generator when none
-    # is passed), which advances that generator like the reference's torch.multinomial / torch.rand do: two calls in a row see
-    # different noise, and reseeding the generator reproduces a call.  (A CUDA generator costs one device sync per call here.)
-    seed = int(torch.randint(0, 1 << 62, (1,), generator=generator,
-                             device=generator.device if generator is not None else 'cpu').item())
-
-    def pre(z):                                                   # draw from the previous logits into the last frame, in place
-        ops.sample_tokens(logits, sample_topk, alphas, num_embeddings, z[:, -1], denoised, counter, seed, last_mask)
-
-    def post(y):
-        logits.copy_(y.reshape(R, C))
-        counter.add_(1)
-
-    fwd = GraphedForward(model, batch_z, pre=pre, post=post)
+    n = num_eval_iterations
+    key = (B, S, H, W, num_embeddings, n, int(sample_topk), bool(consistent_masking), batch_z.device)
+    per_model = _sessions.setdefault(model, {})
+    ses = per_model.get(key)
+    if ses is None:
+        ses = per_model[key] = _Session(model, batch_z, num_embeddings, n, sample_topk, consistent_masking)
+    ses.alphas.copy_(torch.tensor([min(max(noise_schedule((i + 1) / n) if noise_schedule is not None else (i + 1) / n, 0.0), 1.0)
+                                   for i in range(n)], dtype=torch.float32))
+    # The Philox stream is indexed by the counter; a call starts it at a 62-bit draw from the caller's generator (the global CPU
+    # generator when none is passed) rounded to a multiple of n (the kernel takes alpha = alphas[counter % n]), which advances
+    # that generator like the reference's torch.multinomial / torch.rand do: two calls in a row see different noise, reseeding
+    # the generator reproduces a call.  (A CUDA generator costs one device sync per call here.)
+    base = int(torch.randint(0, 1 << 62, (1,), generator=generator,
+                             device=generator.device if generator is not None else 'cpu').item()) // n * n
+    fwd = ses.fwd
+    fwd.refresh()                                                 # (a re-capture draws: before the call's state is set up, not inside it)
     z = fwd.static_in
-    z.copy_(batch_z)                                              # (capture and warm-up drew into the last frame: start over)
-    counter.zero_()
+    z.copy_(batch_z)                                              # (the capture / the previous call drew into the last frame)
+    ses.counter.fill_(base)
     out = []
     for f in range(num_frames):
-        logits.zero_()                                            # flat start (:71)
-        if last_mask is not None:
-            last_mask.fill_(1)
-        for i in range(num_eval_iterations):
-            fwd(z)
-        out.append(denoised.view(B, H, W).clone())
+        ses.logits.zero_()                                        # flat start (:71)
+        if ses.last_mask is not None:
+            ses.last_mask.fill_(1)
+        ses.draw(ses.logits, z)                                   # iteration 0
+        for i in range(1, n):
+            fwd(z)                                                # forward of iteration i - 1, draw of iteration i
+        out.append(ses.denoised.view(B, H, W).clone())
         z[:, :-1] = z[:, 1:].clone()                              # shift frames (:115)
     return out, z.clone()
