@@ -256,7 +256,8 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from world_modelz_amd.graph import capture_mode
+        with torch.cuda.graph(g, capture_error_mode=capture_mode()):
             for _ in range(reps):
                 fn()
         for _ in range(3):                 # clocks / caches settled before the timed replays

@@ -27,6 +27,16 @@ def pytest_configure(config):
         torch.cuda.CUDAGraph.capture_begin = no_capture
 
 
+@pytest.fixture(autouse=True)
+def _collect_after_each_test():
+    """Captured hipGraphs (and the device memory of their private pools) held in reference cycles -- a model and the sampler
+    session it carries, a trainer and its graph -- are let go when the test that made them is over, not at some later collection
+    in the middle of another test's stream capture."""
+    yield
+    import gc
+    gc.collect()
+
+
 def load_golden(name):
     """tests/golden/<name>.npz -> dict of torch tensors (made by tests/golden/make_golden.py)."""
     with np.load(os.path.join(GOLDEN, name + '.npz')) as f:

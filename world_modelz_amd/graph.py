@@ -11,6 +11,15 @@ import torch
 from . import _cast, config
 
 
+def capture_mode():
+    """capture_error_mode for torch.cuda.graph: with a process group alive its watchdog thread issues HIP calls (event queries) of
+    its own while this thread captures; under the default 'global' mode those interact with the capture (an intermittent crash
+    inside capture_end() with an RCCL world of one, twice in ~10 full test-suite runs).  'thread_local' confines the capture's
+    legality checks to the capturing thread -- the recipe for captures next to NCCL / RCCL."""
+    import torch.distributed as dist
+    return 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
+
+
 class GraphedForward:
     """The captured graph bakes in the device addresses of the operand copies of the weights (bf16 casts, packed weight
     streams: _cast).  It therefore (i) holds strong references to every operand tensor that existed at capture time, so
@@ -50,7 +59,7 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
             if self.pre is not None:
                 self.pre(self.static_in)
             self.static_out = self.model(self.static_in)

@@ -6,8 +6,6 @@ Per generated frame: the last latent frame starts fully masked; 30 denoise itera
 then the frames shift by one.  Everything stays on the GPU: the forward is ONE hipGraph launch per iteration
 (GraphedForward), sampling uses device RNG, and there is no host sync inside a frame.
 """
-import weakref
-
 import torch
 import torch.nn.functional as F
 
@@ -87,7 +85,9 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
 
 _SEED_KEY = 0x9E3779B97F4A7C15                   # the captured kernels' Philox key (a kernel ARGUMENT, i.e. baked into the graph):
 #                                                   what varies per call is the device-side counter's starting value
-_sessions = weakref.WeakKeyDictionary()          # model -> {configuration: captured sampler step + its device buffers}
+# (the sessions live ON the model -- `model._wmz_sampler_sessions`, {configuration: captured sampler step + its device buffers} --
+#  and die with it: a session references its model through the graph runner, so a module-level map keyed by the model, weak or
+#  not, would keep both alive for the life of the process)
 
 
 class _Session:
@@ -139,7 +139,7 @@ def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_it
     B, S, H, W = batch_z.shape
     n = num_eval_iterations
     key = (B, S, H, W, num_embeddings, n, int(sample_topk), bool(consistent_masking), batch_z.device)
-    per_model = _sessions.setdefault(model, {})
+    per_model = model.__dict__.setdefault('_wmz_sampler_sessions', {})
     ses = per_model.get(key)
     if ses is None:
         ses = per_model[key] = _Session(model, batch_z, num_embeddings, n, sample_topk, consistent_masking)

@@ -457,7 +457,9 @@ class _TrainerBase(_AdamState):
             torch.cuda.synchronize()
             self._set_step_inputs(None)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            from .graph import capture_mode
+            mode = capture_mode()              # ('thread_local' next to a live process group: see there)
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 self._g_out = self._graph_body()
         except BaseException:
             ops.wgrad_reset()
@@ -744,7 +746,8 @@ class VqaeTrainer(_AdamState):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from .graph import capture_mode
+        with torch.cuda.graph(g, capture_error_mode=capture_mode()):
             self._g_out = self._graph_body()
         self._graph = g
         self._g_ws = ops.workspace_snapshot(dev)
