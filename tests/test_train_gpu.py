@@ -186,6 +186,12 @@ def test_sampler_session_is_reused_and_follows_the_weights(wmz):
             p.mul_(-1.0)                                   # (every logit flips sign: the draws change)
     d = run(3)
     assert ses.fwd.recaptures == 1 and any(not torch.equal(x, y) for x, y in zip(a, d))
+    # a copy of the model starts without the sessions (they hold a hipGraph: not copyable), the original keeps its own
+    import copy
+    import pickle
+    m2 = copy.deepcopy(m)
+    assert len(m2._wmz_sampler_sessions) == 0 and len(m._wmz_sampler_sessions) == 1
+    assert len(pickle.loads(pickle.dumps(m._wmz_sampler_sessions))) == 0
     # ... and it equals a fresh session on the moved weights
     m._wmz_sampler_sessions.clear()
     e = run(3)

@@ -83,6 +83,17 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
     return out, (batch_z.clone() if fwd is not None else batch_z)   # (never hand out the graph's own buffer)
 
 
+class _Sessions(dict):
+    """The model's captured sampler steps.  They belong to THIS module object on THIS device: a copy of the model
+    (copy.deepcopy, pickling the module) starts without them instead of failing on the hipGraph inside."""
+
+    def __deepcopy__(self, memo):
+        return _Sessions()
+
+    def __reduce__(self):
+        return (_Sessions, ())
+
+
 _SEED_KEY = 0x9E3779B97F4A7C15                   # the captured kernels' Philox key (a kernel ARGUMENT, i.e. baked into the graph):
 #                                                   what varies per call is the device-side counter's starting value
 # (the sessions live ON the model -- `model._wmz_sampler_sessions`, {configuration: captured sampler step + its device buffers} --
@@ -139,7 +150,7 @@ def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_it
     B, S, H, W = batch_z.shape
     n = num_eval_iterations
     key = (B, S, H, W, num_embeddings, n, int(sample_topk), bool(consistent_masking), batch_z.device)
-    per_model = model.__dict__.setdefault('_wmz_sampler_sessions', {})
+    per_model = model.__dict__.setdefault('_wmz_sampler_sessions', _Sessions())
     ses = per_model.get(key)
     if ses is None:
         ses = per_model[key] = _Session(model, batch_z, num_embeddings, n, sample_topk, consistent_masking)
