@@ -427,10 +427,14 @@ def main():
             trainer._graph = None
         return err
 
+    # The single-GPU secondary figures (cone, other window, published widths, sampler, frame encoder, VQ-AE step, VQ search, config 2,
+    # reference geometry, config 3) are the N = 1 line's: at N > 1 the ranks go straight from the headline to the data-parallel
+    # training steps (every rank used to run all of them).
+    single_figs = not a.no_cone and world == 1
     try:
         # ---- secondary figure: the same forward with the dead planes elided (bit-identical logits; NOT the headline)
         cone = None
-        if use_fused and not a.eager and not a.no_cone:
+        if use_fused and not a.eager and single_figs:
             wcfg.set_last_frame_cone(True)
             with torch.no_grad():
                 crun = GraphedForward(model, z)
@@ -463,7 +467,7 @@ def main():
         # ---- secondary figure: the same step with the reference's other published attention window, 7 x 3 x 3 (extents 3, 1, 1:
         # BASELINE.md run-03), full grid, same model otherwise
         win = None
-        if use_fused and not a.eager and not a.no_cone:
+        if use_fused and not a.eager and single_figs:
             torch.manual_seed(42)
             m2 = VqVideoDiffusionModel(data_shape=(cfg['S'], cfg['H'], cfg['W']), dim=cfg['dim'], num_classes=cfg['C'],
                                        extents=(3, 1, 1), depth=cfg['depth'], dim_head=cfg['dim_head'], mlp_dim=cfg['mlp_dim'],
@@ -495,7 +499,7 @@ def main():
         # kernel (register-chained 32-token waves: DESIGN.md 4.2) and run on csrc/layer_chain.hip (16-token waves, same fusion: one
         # attention launch + one per-token launch per layer); one hipGraph per step.
         pub = None
-        if not a.eager and not a.no_cone and dtype == torch.bfloat16:
+        if not a.eager and single_figs and dtype == torch.bfloat16:
             pub = []
             for dim_, mlp_, depth_ in ((96, 256, 12), (384, 512, 20)):
                 torch.manual_seed(42)
@@ -543,7 +547,7 @@ def main():
         # ---- secondary figure: the sampler loop (main.py:50-117): one denoise iteration = draw + re-mask + forward
         # on the last frame's dependence cone, ONE hipGraph launch (sample.py); B clips, top-k 100
         smp = None
-        if use_fused and not a.eager and not a.no_cone:
+        if use_fused and not a.eager and single_figs:
             from world_modelz_amd.sample import sample_frames
             wcfg.set_last_frame_cone(True)
             # the first call of a configuration captures the sampler step (kept with the model: sample._Session); timed: the steady state
@@ -563,7 +567,7 @@ def main():
         # latent tokens -- conv encoder (NHWC implicit GEMM, BatchNorm in train mode: quirk Q3) + codebook argmin.  B*S frames
         # of 64x64 RGB -> 16x16 tokens each (2 down-scale steps), codebook 1024 x 64.
         frame_enc = None
-        if not a.no_cone:
+        if single_figs:
             from world_modelz_amd.train_vqae import VqAutoEncoder
             torch.manual_seed(7)
             ae = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
@@ -592,7 +596,7 @@ def main():
         # ---- secondary figure: one VQ-AE training step (train_vqae.py:125-164: encoder -> VectorQuantizerEMA incl. the EMA
         # codebook update -> decoder, SmoothL1 + commitment loss, backward, AdamW) on 64 frames of 64x64, eager launches
         vqae = None
-        if not a.no_cone and world == 1:
+        if single_figs and world == 1:
             from world_modelz_amd.train import VqaeTrainer
             torch.manual_seed(7)
             ae2 = VqAutoEncoder(embedding_dim=64, num_embeddings=cfg['C'], downscale_steps=2, hidden_planes=128).to(dev)
@@ -622,7 +626,7 @@ def main():
         # (csrc/vq.hip) -- three UN-fused fp32 lane operations per (n, c, e), bound: the vector ALU's lane-op rate (half the
         # 157.3 TFLOP/s FMA peak).  HBM traffic (N*E*4 in, N*8 out, codebook resident) is two orders below its roof.
         vq = None
-        if not a.no_cone:
+        if single_figs:
             vq = []
             gvq = torch.Generator(device='cpu').manual_seed(0)
             Nq, Eq = 65536, 64
@@ -648,7 +652,7 @@ def main():
         # two workgroups' worth of attention and four small GEMMs, so the figure is launch latency, not throughput; one hipGraph
         # of 20 forwards, HIP events around the replay.
         cfg2 = None
-        if not a.no_cone and dtype == torch.bfloat16:
+        if single_figs and dtype == torch.bfloat16:
             from world_modelz_amd.local_3d_attention import Local3dAttention
             cfg2 = []
             for ext2 in ((3, 3, 3), (3, 1, 1)):
@@ -668,7 +672,7 @@ def main():
         # 20 layers / one head of 128 / window (7,3,3) = --extent 3,1,1 / batch 64 / 5 context frames + 1): forward denoise step and
         # full training step, one hipGraph each.  8-wide planes take the row attention kernels as tile rows of 16 (round 4).
         refgeo = None
-        if not a.eager and not a.no_cone and dtype == torch.bfloat16:
+        if not a.eager and single_figs and dtype == torch.bfloat16:
             from world_modelz_amd.train import DenoiserTrainer as _RT
             torch.manual_seed(42)
             mr = VqVideoDiffusionModel(data_shape=(6, 8, 8), dim=384, num_classes=512, extents=(3, 1, 1), depth=20, dim_head=128,
@@ -714,7 +718,7 @@ def main():
         # ---- secondary figure: BASELINE configs[2] -- the training step of vq-video-diffusion/main.py on B = 16 clips of 16x16x16
         # latents (same token count per step as the headline, shorter clips: more border planes), codebook 1024; one hipGraph per step
         cfg3 = None
-        if a.train_steps > 0 and not a.no_cone and world == 1 and not a.eager:
+        if a.train_steps > 0 and single_figs and world == 1 and not a.eager:
             from world_modelz_amd.train import DenoiserTrainer as _DT
             torch.manual_seed(42)
             m3 = VqVideoDiffusionModel(data_shape=(16, 16, 16), dim=cfg['dim'], num_classes=cfg['C'], extents=cfg['extents'],
