@@ -248,7 +248,7 @@ def main():
     def time_kernel(fn, reps):
         """Average duration of `reps` back-to-back launches: the launches are captured into one hipGraph (so no host
         gap can sit between them) and the replay is bracketed by one HIP-event pair on the launch stream."""
-        side = torch.cuda.Stream()
+        side = config.shared_stream('warmup')
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):

@@ -557,11 +557,9 @@ def test_optimizer_state_and_ema_round_trip_through_the_reference_layout(wmz, tm
 
 
 def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
-    """The RCCL world-of-one checks below, in a FRESH child process.  Late in a long pytest process the RCCL-capturing
-    enable_graph() died inside torch's capture_end() (a host-side segfault / abort in the HIP runtime: every run of the full suite
-    once it had grown to ~247 tests with the sampler tests among them, never alone, never with any subset tried, never after 400
-    captures or with 20 other graphs alive in a process of its own) -- a crash that takes every test behind it down with it.  The
-    child gives the capture the clean process it has in production and turns a crash into one failing test."""
+    """The RCCL world-of-one checks below, in a FRESH child process: a host-side crash inside an RCCL-capturing capture_end()
+    (round 4: streams re-used from torch's pool of 32 after ~250 tests' worth of new streams -- fixed by config.shared_stream)
+    takes every test behind it down with it; here it would cost one test.  WMZ_RCCL_CHILD=1 runs the body in this process."""
     import os
     import subprocess
     import sys

@@ -135,3 +135,25 @@ def get_clip_streams():
 def set_clip_streams(n):
     global _clip_streams
     _clip_streams = max(1, int(n))
+
+
+_shared_streams = {}
+
+
+def shared_stream(kind, device=None):
+    """ONE side stream per (purpose, device) for the life of the process.  torch hands out streams from a pool of 32 per device,
+    round robin: a process that makes a new torch.cuda.Stream() for every capture warm-up / reducer / trainer (a test suite: ~250
+    of them) sooner or later gets one that IS an older, still used stream -- the weight-gradient side stream, a clip chain, another
+    trainer's reducer -- and two roles that the capture logic orders against each other become one queue (round 4: the full GPU
+    suite died inside capture_end() of an RCCL-capturing step exactly when the number of capturing tests in front of it crossed
+    such a wrap; any one group of them less and it passed)."""
+    import torch
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = (kind, dev.index)
+    s = _shared_streams.get(key)
+    if s is None:
+        s = _shared_streams[key] = torch.cuda.Stream(device=dev)
+    return s
+

@@ -47,7 +47,7 @@ class GraphedForward:
 
     def _capture(self):
         self._tensors = list(self.model.parameters()) + list(self.model.buffers())
-        s = torch.cuda.Stream()
+        s = config.shared_stream('warmup')
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():
             for _ in range(self.warmup):

@@ -74,7 +74,8 @@ class BucketedAllReduce:
         self.active = self.world > 1 or (always and dist.is_initialized())
         self.rounds = int(rounds)
         self.cuda = arena.flat_grad.is_cuda
-        self.stream = torch.cuda.Stream() if self.cuda else None
+        from . import config
+        self.stream = config.shared_stream('allreduce', arena.flat_grad.device) if self.cuda else None     # (one per device: see there)
         self.buckets = []                      # (start_elem, end_elem, [param indices])
         self.order = []                        # bucket ids in the order their collectives are enqueued this step
         self.last_order = []                   # ... and were in the step finish() closed last

@@ -446,7 +446,8 @@ class _TrainerBase(_AdamState):
                                                  self.sampler_gen.get_state(),
                                                  None if getattr(self, 'ema_flat', None) is None else self.ema_flat.clone())
         ops.wgrad_reset()                  # nothing queued by an earlier (failed) pass may flush into this capture
-        side = torch.cuda.Stream()
+        from . import config as _cfg
+        side = _cfg.shared_stream('warmup')
         side.wait_stream(torch.cuda.current_stream())
         try:
             with torch.cuda.stream(side):
@@ -736,7 +737,8 @@ class VqaeTrainer(_AdamState):
         self._g_x = example_batch.contiguous().clone()
         self._g_hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self._g_sq = torch.zeros(1, dtype=torch.float32, device=dev)
-        side = torch.cuda.Stream()
+        from . import config as _cfg
+        side = _cfg.shared_stream('warmup')
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
