@@ -221,6 +221,41 @@ def test_dropout_in_training(wmz):
         assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0 for p in md.parameters())
 
 
+def test_side_streams_are_made_once_per_purpose(wmz, monkeypatch):
+    """torch hands out streams from a pool of 32 per device, round robin: a library that makes a new stream per capture / re-capture
+    / trainer sooner or later holds two roles on one queue (round 4: the cause of a crash inside an RCCL-capturing capture_end() once
+    ~250 tests had made their streams).  Graph runners, re-captures and trainers draw their side streams from
+    config.shared_stream: however many are built, the library itself asks torch for no further stream."""
+    from world_modelz_amd import config, graph, train
+    made = []
+    real = torch.cuda.Stream
+
+    class Counted(real):
+        def __new__(cls, *a, **k):
+            if 'stream_id' not in k and 'stream_ptr' not in k:        # (a wrapper around an existing stream -- current_stream() -- is not a new one)
+                made.append(1)
+            return super().__new__(cls, *a, **k)
+    torch.manual_seed(0)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(2, 4, 4), dim=64, num_classes=16, extents=(1, 1, 1), depth=1, dim_head=32,
+                                          mlp_dim=64, heads=2).cuda()
+    z = torch.randint(0, 16, (2, 2, 4, 4), device='cuda')
+    g0 = graph.GraphedForward(m, z)                     # (whatever is made lazily -- torch.cuda.graph's own capture stream, the shared
+    t0 = train.DenoiserTrainer(m, 16, distributed=False)  #  warm-up stream, the weight-gradient side stream -- exists after these)
+    t0.enable_graph(z)
+    monkeypatch.setattr(torch.cuda, 'Stream', Counted)
+    for _ in range(3):
+        g = graph.GraphedForward(m, z)
+        with torch.no_grad():
+            m.logit_proj.bias.add_(0.01)
+        g(z)                                            # stale stamp: re-captures
+        assert g.recaptures == 1
+        t = train.DenoiserTrainer(m, 16, distributed=False)
+        t.enable_graph(z)
+        t.train_step(z, r=torch.zeros(2))
+    assert not made, f'{len(made)} new streams'
+    assert config.shared_stream('warmup') is config.shared_stream('warmup')
+
+
 def test_cpu_input_is_refused(wmz):
     m = wmz['main'].VqVideoDiffusionModel(data_shape=(2, 4, 4), dim=16, num_classes=8, extents=(1, 1, 1), depth=1,
                                           dim_head=8, mlp_dim=16, heads=2).cuda()
