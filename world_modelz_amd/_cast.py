@@ -28,11 +28,23 @@ def operand(params, dtype, tag='w', build=None):
     with torch.no_grad():
         src = build(*params) if build is not None else params[0]
         val = src.detach().to(dtype).contiguous()
-    if len(_cache) > 2048:
-        for k in [k for k, h in _cache.items() if any(r() is None for r in h[2])]:
-            del _cache[k]
+    _sweep()
     _cache[key] = (ver, val, tuple(weakref.ref(p) for p in params))
     return val
+
+
+_sweep_at = 256
+
+
+def _sweep():
+    """Drop the entries of parameters that no longer exist (a model that was deleted leaves ~10 MB of operand copies per 3 M
+    parameters behind).  Runs when the cache has doubled since the last sweep (at least 256 entries): amortised O(1) per insert."""
+    global _sweep_at
+    if len(_cache) < _sweep_at:
+        return
+    for k in [k for k, h in _cache.items() if any(r() is None for r in h[2])]:
+        del _cache[k]
+    _sweep_at = max(256, 2 * len(_cache))
 
 
 def cached(params, tag, build):
@@ -45,6 +57,7 @@ def cached(params, tag, build):
         return hit[1]
     with torch.no_grad():
         val = build(*params)
+    _sweep()
     _cache[key] = (ver, val, tuple(weakref.ref(p) for p in params))
     return val
 
