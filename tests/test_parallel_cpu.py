@@ -365,3 +365,28 @@ def _check_vq_against_single_process(sd0, act0, err0, err1, perp0, perp1):
     for x in _vq_inputs():
         qa(x[0:1]); qb(x[1:2])
     assert not torch.equal(qa.embedding, qb.embedding)
+
+
+def test_operand_cache_drops_the_entries_of_deleted_parameters():
+    """_cast caches operand copies per parameter object; a deleted model's entries (~10 MB per 3 M parameters on the GPU) go when the
+    cache has doubled since the last sweep (at least 256 entries) -- not only past 2048 entries as before round 4."""
+    import gc
+    from world_modelz_amd import _cast
+    _cast.clear()
+    _cast._sweep_at = 256
+    keep = [torch.nn.Parameter(torch.randn(4, 4)) for _ in range(10)]
+    for p in keep:
+        _cast.operand(p, torch.bfloat16)
+    for _ in range(6):
+        dead = [torch.nn.Parameter(torch.randn(4, 4)) for _ in range(100)]
+        for p in dead:
+            _cast.operand(p, torch.bfloat16)
+        del dead, p
+        gc.collect()
+    live = sum(1 for h in _cast._cache.values() if all(r() is not None for r in h[2]))
+    assert live >= 10 and len(_cast._cache) < 400, (live, len(_cast._cache))          # 610 were inserted
+    for p in keep:                                                                # the living ones still hit
+        v = _cast.operand(p, torch.bfloat16)
+        assert v is _cast.operand(p, torch.bfloat16)
+    _cast.clear()
+
