@@ -20,7 +20,7 @@ LN_EPS = 1e-5
 class _AttentionBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_kv, x_q, ln_g, ln_b, wq, wk, wv, bv, wout, bout, residual, extents, heads, grad_on, same_src,
-                res_is_xkv):
+                res_is_xkv, out_f32=False):
         dt = x_kv.dtype
         I = wq.shape[0]
         ln = None if ln_g is None else (ln_g.detach(), ln_b.detach())
@@ -39,7 +39,9 @@ class _AttentionBlock(torch.autograd.Function):
             kv = ops.linear_fwd(x_kv, wkv_c, bias=bkv, ln=ln, ln_eps=LN_EPS, ln_stats=stats)   # to_k | to_v on LN(x)
         o, lse, _ = ops.local3d_attention_fwd(q, kv[..., :I], kv[..., I:], extents, heads, need_lse=need_bwd)
         if wout is not None:
-            y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual)
+            # (inference at a module boundary that wants fp32 back -- Local3dAttention.forward on fp32 inputs: the to_out GEMM's
+            #  epilogue writes it, instead of a cast launch behind the block)
+            y = ops.linear_fwd(o, _cast.operand(wout, dt), bias=bout.detach(), residual=residual, out_f32=bool(out_f32) and not need_bwd)
         else:
             y = o if residual is None else o + residual
         if need_bwd:
@@ -55,7 +57,7 @@ class _AttentionBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         from . import backward as B
-        return B.attention_block_backward(ctx, dy)
+        return B.attention_block_backward(ctx, dy) + (None,)
 
 
 class _FeedForwardBlock(torch.autograd.Function):
@@ -133,10 +135,10 @@ def _as_compute(x):
     return x if x.dtype == dt else x.to(dt)
 
 
-def attention_block(x_kv, x_q, ln, wq, wk, wv, bv, wout, bout, residual, extents, heads):
+def attention_block(x_kv, x_q, ln, wq, wk, wv, bv, wout, bout, residual, extents, heads, out_f32=False):
     g, b = (None, None) if ln is None else ln
     return _AttentionBlock.apply(x_kv, x_q, g, b, wq, wk, wv, bv, wout, bout, residual, tuple(int(e) for e in extents),
-                                 int(heads), torch.is_grad_enabled(), x_q is x_kv, residual is x_kv)
+                                 int(heads), torch.is_grad_enabled(), x_q is x_kv, residual is x_kv, bool(out_f32))
 
 
 def feed_forward_block(x, ln, w1, b1, w2, b2, residual):

@@ -98,7 +98,7 @@ class Local3dAttention(nn.Module):
         self.use_checkpointing = use_checkpointing
         self.dropout = dropout
 
-    def _run(self, x, q, ln, residual):
+    def _run(self, x, q, ln, residual, out_f32=False):
         same, res_same = q is x, residual is x            # attn(x, q=x) + x: keep ONE tensor so the backward folds the paths
         x = Fw._as_compute(x)
         q = x if same else Fw._as_compute(q)
@@ -117,11 +117,11 @@ class Local3dAttention(nn.Module):
             y = y if residual is None else y + residual
             return y.reshape(q.shape[:-1] + (y.shape[-1],))
         y = Fw.attention_block(x, q, ln, self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_v.bias,
-                               wo, bo, residual, self.extents, self.heads)
+                               wo, bo, residual, self.extents, self.heads, out_f32=out_f32)
         return y.reshape(q.shape[:-1] + (y.shape[-1],))
 
     def forward(self, x, q):
-        return self._run(x, q, None, None).to(q.dtype)
+        return self._run(x, q, None, None, out_f32=q.dtype == torch.float32).to(q.dtype)
 
     def forward_prenorm(self, x, norm, q, residual=None):
         return self._run(x, q, (norm.weight, norm.bias), residual)
