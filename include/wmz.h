@@ -424,6 +424,18 @@ int wmz_conv2d_nhwc_fwd_pre(const void* x, const void* w, void* out, const float
                             const float* shift, const void* residual, float* stat_sum, float* stat_sq,
                             const float* in_scale, const float* in_shift, float in_slope, int B, int Hi, int Wi, int Cin,
                             int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, int dtype, void* stream);
+/* Direct 3x3 / stride 1 / pad 1 convolution in bf16 (csrc/conv_direct.hip; autoencoder.py:8-10 conv3x3 inside Residual :18-42,
+ * UpscaleResidual :89-131 and the decoder's first / last convolutions :134-152): the same result as wmz_conv2d_nhwc_fwd on
+ * these shapes (same k order, same epilogue arithmetic) with the haloed input patch and the weight stream staged by LDS-DMA.
+ * wpack: the GEMM operand [Cout, 9 * Cin] re-ordered by wmz_conv3x3_direct_pack (wmz_conv3x3_direct_pack_elems(Cin, Cout) bf16
+ * elements).  Shapes: wmz_conv3x3_direct_supported(H, W, Cin, Cout) != 0 -- Cin % 64 == 0, Cout % 8 == 0 and <= 128, W a
+ * multiple of 32 with H % 8 == 0, or W = 16 with H % 16 == 0. */
+int wmz_conv3x3_direct_supported(int H, int W, int Cin, int Cout);
+long wmz_conv3x3_direct_pack_elems(int Cin, int Cout);
+int wmz_conv3x3_direct_pack(const void* w_op, void* wpack, int Cin, int Cout, void* stream);
+int wmz_conv3x3_direct_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale,
+                           const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int H, int W,
+                           int Cin, int Cout, int leaky, float slope, void* stream);
 /* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [WMZ_STAT_REPLICAS][C]). */
 int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream);
 /* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq: [WMZ_STAT_REPLICAS][C], summed here; count), running stats updated with

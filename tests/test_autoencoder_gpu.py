@@ -370,29 +370,44 @@ def test_vqae_graphed_training_step_matches_eager(wmz, dtype):
         assert len(out) == 4 and all(v == v for v in out)
 
 
-def test_direct_3x3_conv_equals_the_implicit_gemm_kernel(wmz):
-    """conv3x3s1_kernel (3x3, stride 1, pad 1, 64 -> 128 channels, bf16, planes of 8k x 32m pixels: the encoder's big layers)
-    against conv2d_kernel on the same data: same K order, same epilogue arithmetic -> the same bits, statistics included
-    (to fp32 summation order); and against torch."""
+@pytest.mark.parametrize('geom', [(3, 16, 64, 64, 128), (2, 32, 32, 64, 64), (2, 16, 16, 64, 128), (1, 8, 32, 128, 128),
+                                  (2, 16, 16, 128, 64), (1, 16, 32, 128, 8), (2, 48, 16, 64, 24)])
+def test_direct_3x3_conv_equals_the_implicit_gemm_kernel(wmz, geom):
+    """csrc/conv_direct.hip (3x3, stride 1, pad 1, bf16; patch + weight stream by LDS-DMA) against conv2d_kernel on the same
+    data: same K order and epilogue arithmetic -> the same bits for Cin = 64 (Cin = 128 accumulates in two channel passes: fp32
+    summation order), statistics to fp32 summation order; every epilogue combination (bias, folded BatchNorm, LeakyReLU,
+    residual, statistics); and against torch."""
     from world_modelz_amd import ops
+    B, H, W, Ci, Co = geom
+    assert ops.L.lib().wmz_conv3x3_direct_supported(H, W, Ci, Co)
     torch.manual_seed(12)
-    B, H, W = 3, 16, 64
-    x = torch.randn(B, H, W, 64, device='cuda').bfloat16()
-    w = (torch.randn(128, 9 * 64, device='cuda') * 0.05).bfloat16()
-    bias = torch.randn(128, device='cuda')
-    res = torch.randn(B, H, W, 128, device='cuda').bfloat16()
-    y_d, s_d, q_d = ops.conv2d_nhwc(x, w, 3, 3, 1, 1, bias=bias, residual=res, leaky=True, stats=True)       # direct kernel
-    # the implicit-GEMM kernel takes any plane whose height is not a multiple of 8: rows 0..7 of a 12-row plane see the
-    # same inputs (rows 0..8) as rows 0..7 of the 16-row one
-    x12, r12 = x[:, :12].contiguous(), res[:, :12].contiguous()
-    y_g = ops.conv2d_nhwc(x12, w, 3, 3, 1, 1, bias=bias, residual=r12, leaky=True)
-    assert torch.equal(y_d[:, :8], y_g[:, :8])
-    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(128, 3, 3, 64).permute(0, 3, 1, 2),
+    x = torch.randn(B, H, W, Ci, device='cuda').bfloat16()
+    w = (torch.randn(Co, 9 * Ci, device='cuda') * 0.05).bfloat16()
+    bias = torch.randn(Co, device='cuda')
+    sc, sh = torch.rand(Co, device='cuda') + 0.5, torch.randn(Co, device='cuda')
+    res = torch.randn(B, H, W, Co, device='cuda').bfloat16()
+    for kw in (dict(bias=bias, residual=res, leaky=True, stats=True), dict(bias=bias, leaky=True, stats=True), dict(stats=True),
+               dict(scale=sc, shift=sh, leaky=True), dict(bias=bias, scale=sc, shift=sh, residual=res), dict()):
+        ops.DIRECT_CONV = True
+        try:
+            out_d = ops.conv2d_nhwc(x, w, 3, 3, 1, 1, **kw)
+            ops.DIRECT_CONV = False
+            out_g = ops.conv2d_nhwc(x, w, 3, 3, 1, 1, **kw)
+        finally:
+            ops.DIRECT_CONV = True
+        y_d, y_g = (out_d[0], out_g[0]) if kw.get('stats') else (out_d, out_g)
+        if Ci == 64:
+            assert torch.equal(y_d, y_g), kw.keys()
+        else:
+            assert float((y_d.float() - y_g.float()).norm() / y_g.float().norm()) < 2e-3
+        if kw.get('stats'):
+            assert torch.allclose(out_d[1].sum(0), y_d.float().sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
+            assert torch.allclose(out_d[2].sum(0), (y_d.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2),
                                      bias=bias, padding=1).permute(0, 2, 3, 1) + res.float()
     ref = torch.nn.functional.leaky_relu(ref, 0.01)
-    assert float((y_d.float() - ref).norm() / ref.norm()) < 4e-3
-    assert torch.allclose(s_d.sum(0), y_d.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
-    assert torch.allclose(q_d.sum(0), (y_d.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    y = ops.conv2d_nhwc(x, w, 3, 3, 1, 1, bias=bias, residual=res, leaky=True)
+    assert float((y.float() - ref).norm() / ref.norm()) < 4e-3
 
 
 @pytest.mark.parametrize('C,dtype', [(128, torch.bfloat16), (128, torch.float32), (16, torch.bfloat16), (24, torch.bfloat16),

@@ -53,6 +53,7 @@ SIGNATURES = {
     'wmz_debug_fused_timestamps': [c_void_p],
     'wmz_debug_attn_timestamps': [c_void_p],
     'wmz_debug_fused_knobs': [c_int],
+    'wmz_debug_conv_knobs': [c_int, c_int],
     'wmz_layer_fused_fwd': [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p],
     'wmz_operands_refresh': [c_void_p] * 7 + [c_int, c_void_p],
     'wmz_conv_operands_refresh': [c_void_p] * 6 + [c_int, c_int, c_void_p],
@@ -77,6 +78,10 @@ SIGNATURES = {
     'wmz_embed_qkv_fused_fwd': [c_void_p] * 10 + [c_int] * 8 + [c_float, c_void_p],
     'wmz_conv2d_nhwc_fwd': [c_void_p] * 9 + [c_int] * 10 + [c_float, c_int, c_void_p],
     'wmz_conv2d_nhwc_fwd_pre': [c_void_p] * 11 + [c_float] + [c_int] * 10 + [c_float, c_int, c_void_p],
+    'wmz_conv3x3_direct_supported': [c_int] * 4,
+    'wmz_conv3x3_direct_pack_elems': [c_int, c_int],                       # returns long
+    'wmz_conv3x3_direct_pack': [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'wmz_conv3x3_direct_fwd': [c_void_p] * 9 + [c_int] * 6 + [c_float, c_void_p],
     'wmz_channel_stats_nhwc': [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p],
     'wmz_bn_finalize': [c_void_p, c_void_p, c_double] + [c_void_p] * 4 + [c_double, c_double, c_int] + [c_void_p] * 4
                        + [c_int, c_void_p, c_void_p],
@@ -134,7 +139,7 @@ def lib():
             if fn is None:
                 continue  # declared but not built yet: calling it raises below
             fn.argtypes = argtypes
-            fn.restype = c_long if name.endswith(('_workspace_floats', '_workspace_ints', '_workspace_bytes')) else c_int
+            fn.restype = c_long if name.endswith(('_workspace_floats', '_workspace_ints', '_workspace_bytes', '_pack_elems')) else c_int
         _lib = L
     return _lib
 

@@ -19,6 +19,10 @@ int wmz_debug_attn_timestamps(void* buf);
  * shape class; other schedules are separate builds, tools/build_variant.py); (0, 0) is the product behaviour. */
 int wmz_debug_attn_knobs(int dbg, int variant);
 
+/* development knobs of the direct convolution (csrc/conv_direct.hip): skew = start delay (units of s_sleep 127) of the second
+ * workgroup per CU; dbg = ablation switches (1 skip the epilogue, 2 one weight slab only: timing experiments, results are garbage). */
+int wmz_debug_conv_knobs(int skew, int dbg);
+
 #ifdef __cplusplus
 }
 #endif

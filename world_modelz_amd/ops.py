@@ -646,6 +646,22 @@ def embed_pos3d_bwd(z, dx, tabs):
 STAT_REPLICAS = 8          # include/wmz.h: WMZ_STAT_REPLICAS
 
 
+DIRECT_CONV = True         # tools / tests: False keeps every convolution on the implicit-GEMM kernel (A/B comparisons)
+
+
+def _direct_pack(w_op, Cin, Cout):
+    """The fragment-order weight stream of csrc/conv_direct.hip for a GEMM operand [Cout, 9 * Cin], kept while the operand lives
+    and the parameters have not been rewritten (the operand copies themselves are cached per parameter version: _cast)."""
+    from . import _cast
+
+    def build(w):
+        n = L.lib().wmz_conv3x3_direct_pack_elems(Cin, Cout)
+        dst = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        L.call('wmz_conv3x3_direct_pack', L.ptr(w), L.ptr(dst), Cin, Cout, L.stream())
+        return dst
+    return _cast.cached((w_op,), 'convq', build)
+
+
 def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None, residual=None, leaky=False,
                 slope=0.01, stats=False, pre=None):
     """x: [B,H,W,Cin] contiguous (Cin % 8 == 0), w_op: [Cout, KH*KW*Cin] in x's dtype -> [B,Ho,Wo,Cout] (+ sum, sq: fp32
@@ -661,6 +677,12 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
         s, q = torch.zeros((2, STAT_REPLICAS, Cout), dtype=torch.float32, device=x.device).unbind(0)      # one fill for both
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
+    if (DIRECT_CONV and x.dtype == torch.bfloat16 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pre is None
+            and L.lib().wmz_conv3x3_direct_supported(Hi, Wi, Cin, Cout)):
+        # csrc/conv_direct.hip: the haloed patch and the weight stream by LDS-DMA (same arithmetic as the implicit-GEMM kernel)
+        L.call('wmz_conv3x3_direct_fwd', L.ptr(x), L.ptr(_direct_pack(w_op, Cin, Cout)), L.ptr(out), L.ptr(bias), L.ptr(scale),
+               L.ptr(shift), L.ptr(residual), L.ptr(s), L.ptr(q), B, Hi, Wi, Cin, Cout, 1 if leaky else 0, float(slope), L.stream())
+        return (out, s, q) if stats else out
     psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
     L.call('wmz_conv2d_nhwc_fwd_pre', L.ptr(x), L.ptr(w_op), L.ptr(out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
            L.ptr(residual), L.ptr(s), L.ptr(q), L.ptr(psc), L.ptr(psh), float(psl), B, Hi, Wi, Cin, Cout, KH, KW, stride,
