@@ -436,6 +436,18 @@ int wmz_conv3x3_direct_pack(const void* w_op, void* wpack, int Cin, int Cout, vo
 int wmz_conv3x3_direct_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale,
                            const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int H, int W,
                            int Cin, int Cout, int leaky, float slope, void* stream);
+/* Small-K convolutions in bf16 (csrc/conv_point.hip; K = KH KW Cin <= 256: the 1x1 convolutions of Residual :18-42 and
+ * UpscaleResidual :89-131, the 2x2 / stride 2 down-sampling convolution :29-33, the 3-channel conv_1 :60-86): the same result as
+ * wmz_conv2d_nhwc_fwd_pre without a residual (same k order and epilogue arithmetic), as a persistent streaming kernel -- weights
+ * resident in LDS, every wave on its own runs of 64 output pixels.  wpack: the GEMM operand [Cout, K] re-ordered by
+ * wmz_conv_point_pack (wmz_conv_point_pack_elems(K, Cout) bf16 elements).  Shapes: wmz_conv_point_supported(...) != 0 -- Cin % 8
+ * == 0, Cout % 8 == 0 and <= 128, pad <= 1, B Ho Wo a multiple of 64. */
+int wmz_conv_point_supported(int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad);
+long wmz_conv_point_pack_elems(int K, int Cout);
+int wmz_conv_point_pack(const void* w_op, void* wpack, int K, int Cout, void* stream);
+int wmz_conv_point_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale, const float* shift,
+                       float* stat_sum, float* stat_sq, const float* in_scale, const float* in_shift, float in_slope, int B, int Hi,
+                       int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, void* stream);
 /* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [WMZ_STAT_REPLICAS][C]). */
 int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream);
 /* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq: [WMZ_STAT_REPLICAS][C], summed here; count), running stats updated with

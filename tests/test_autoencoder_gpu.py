@@ -410,6 +410,38 @@ def test_direct_3x3_conv_equals_the_implicit_gemm_kernel(wmz, geom):
     assert float((y.float() - ref).norm() / ref.norm()) < 4e-3
 
 
+@pytest.mark.parametrize('geom', [(4, 16, 16, 128, 64, 1, 1, 0, True), (2, 32, 32, 64, 64, 2, 2, 0, False), (4, 16, 16, 8, 64, 3, 1, 1, False),
+                                  (1, 8, 8, 64, 128, 1, 1, 0, False), (2, 16, 16, 128, 128, 1, 1, 0, False), (4, 16, 16, 8, 128, 3, 1, 1, False),
+                                  (2, 8, 16, 64, 24, 1, 1, 0, True), (3, 16, 16, 64, 64, 2, 2, 0, False), (4, 24, 24, 16, 40, 3, 2, 1, False)])
+def test_small_k_conv_equals_the_implicit_gemm_kernel(wmz, geom):
+    """csrc/conv_point.hip (K = KH KW Cin <= 256: 1x1 with and without the BatchNorm + LeakyReLU prologue, 2x2 / stride 2, the
+    3-channel 3x3 layers; bf16, persistent waves) against conv2d_kernel on the same data: same k order and epilogue arithmetic ->
+    the same bits, statistics to fp32 summation order; every epilogue combination without a residual."""
+    from world_modelz_amd import ops
+    B, H, W, Ci, Co, k, st, pad, pre = geom
+    assert ops.L.lib().wmz_conv_point_supported(B, H, W, Ci, Co, k, k, st, pad)
+    torch.manual_seed(5)
+    x = torch.randn(B, H, W, Ci, device='cuda').bfloat16()
+    w = (torch.randn(Co, k * k * Ci, device='cuda') * 0.1).bfloat16()
+    bias = torch.randn(Co, device='cuda')
+    sc, sh = torch.rand(Co, device='cuda') + 0.5, torch.randn(Co, device='cuda')
+    prol = (torch.rand(Ci, device='cuda') + 0.5, torch.randn(Ci, device='cuda'), 0.01) if pre else None
+    for kw in (dict(bias=bias, leaky=True, stats=True), dict(stats=True), dict(scale=sc, shift=sh, leaky=True),
+               dict(bias=bias, scale=sc, shift=sh, stats=True), dict()):
+        ops.DIRECT_CONV = True
+        try:
+            out_p = ops.conv2d_nhwc(x, w, k, k, st, pad, pre=prol, **kw)
+            ops.DIRECT_CONV = False
+            out_g = ops.conv2d_nhwc(x, w, k, k, st, pad, pre=prol, **kw)
+        finally:
+            ops.DIRECT_CONV = True
+        y_p, y_g = (out_p[0], out_g[0]) if kw.get('stats') else (out_p, out_g)
+        assert torch.equal(y_p, y_g), (geom, list(kw))
+        if kw.get('stats'):
+            assert torch.allclose(out_p[1].sum(0), y_p.float().sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
+            assert torch.allclose(out_p[2].sum(0), (y_p.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
+
+
 @pytest.mark.parametrize('C,dtype', [(128, torch.bfloat16), (128, torch.float32), (16, torch.bfloat16), (24, torch.bfloat16),
                                      (512, torch.float32), (2048, torch.bfloat16)])
 def test_training_elementwise_kernels_vector_and_scalar_forms(wmz, C, dtype):

@@ -22,7 +22,7 @@ def timed(fn, n=20):
 for (H, W, Ci, Co, st) in ((64, 64, 64, 128, True), (64, 64, 128, 128, True), (32, 32, 64, 128, True)):
     x = torch.randn(B, H, W, Ci, device='cuda').bfloat16()
     w = (torch.randn(Co, 9 * Ci, device='cuda') * 0.05).bfloat16()
-    for skew, dbg in ((0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 12), (0, 13), (1, 0), (2, 0), (1, 1)):
+    for skew, dbg in ((1, 0), (1, 128), (1, 1)):
         L.call('wmz_debug_conv_knobs', skew, dbg)
         t = timed(lambda: ops.conv2d_nhwc(x, w, 3, 3, 1, 1, stats=st))
         print(f'{H}x{W} {Ci}->{Co} skew {skew} dbg {dbg}: {t:7.1f} us')

@@ -35,6 +35,7 @@ struct DirectParams {
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
   float slope; int leaky;
   int skew, dbg;        // development knobs (wmz_debug_conv_knobs)
+  int ncb_pack;         // channel blocks of the packed weight stream (wmz_conv3x3_direct_pack)
 };
 
 constexpr int CQ_PITCH = 144;          // bytes per patch pixel: 64 channels + one dead 16-byte slot
@@ -358,6 +359,304 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(DirectParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// convr_kernel: the same convolution with DECOUPLED waves.  convq_kernel's four waves share every weight slab (one s_barrier per
+// slab, a DMA wait in front of it) -- measured on the 64 -> 128 layer of 256 frames: 37 of 220 us in those waits, and the chip's
+// workgroups march through load / multiply / store in step.  Here a wave owns ONE block of 32 output channels for 2 NCB blocks
+// of 32 pixels (Cout = 128: all 256 pixels of the tile), so its weight fragments are private: they come straight from global
+// memory (L2-resident, one contiguous KB per fragment) into a register ring two slabs deep -- no LDS ring, no barrier and no
+// shared wait inside the loop; the patch is the only LDS operand (one ds_read_b128 per MFMA, a window of four in flight across
+// slab boundaries).  Same k order per accumulator as convq_kernel / conv2d.hip: the same bits.
+template <int NCB, int TW>
+struct CrShape {
+  static constexpr int TH = 256 / TW, PH = TH + 2, PW = TW + 2, NPX = PH * PW;
+  static constexpr int PATCH = (NPX * CQ_PITCH + 1023) / 1024 * 1024;
+  static constexpr int NPB = 2 * NCB;                              // 32-pixel blocks per wave
+  static constexpr int BPR = 2;                                    // blocks per epilogue round (bf16 staging, double-buffered)
+  static constexpr int OPITCH = 80, FPITCH = 144;                  // staging rows: 32 channels bf16 / fp32 + 16 bytes
+  static constexpr int STAGE_A = 2 * BPR * 32 * OPITCH, STAGE_B = 64 * FPITCH;
+  static constexpr int STAGE = STAGE_A > STAGE_B ? STAGE_A : STAGE_B;
+  static constexpr int LDS = PATCH > 4 * STAGE ? PATCH : 4 * STAGE;
+};
+
+template <int NCB, int TW, int NPASS>
+__global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
+  using S = CrShape<NCB, TW>;
+  constexpr int NPB = S::NPB, NSEQ = 4 * NPB, WIN = 4;
+  __shared__ __attribute__((aligned(1024))) char lds[S::LDS];
+  char* patch = lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int cb = wave % NCB, i0 = (wave / NCB) * NPB;              // channel block; first pixel block
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = lid % P.tiles_x; lid /= P.tiles_x;
+  const int ty = lid % P.tiles_y;
+  const int b = lid / P.tiles_y;
+  const int oy0 = ty * S::TH, ox0 = tx * TW;
+  constexpr int nslab = NPASS * 9;
+
+  auto issue_patch = [&](int pass) {
+    const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + pass * 64;
+    for (int pc = wave; pc < S::PATCH / 1024; pc += 4) {
+      const int q = pc * 64 + lane;
+      const int pix = q / CQ_SPP, c = q - pix * CQ_SPP;
+      const int py = pix / S::PW, px = pix - py * S::PW;
+      const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+      const bool ok = c < 8 && pix < S::NPX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      const void* src = ok ? (const void*)(xb + ((long)iy * P.W + ix) * P.Cin + c * 8) : (const void*)cq_zero_chunk;
+      __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
+    }
+  };
+  if (P.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < P.skew; ++i) __builtin_amdgcn_s_sleep(127);
+  issue_patch(0);
+
+  // this wave's weight fragments: (slab s, k-step kk) at fragment row (4 s + kk) of the packed stream, block cb of ncb_pack
+  const s16x8* const wp = reinterpret_cast<const s16x8*>(P.wpack) + cb * 64 + lane;
+  const long wstep = (long)P.ncb_pack * 64;                        // fragments are ncb_pack KB apart per (s, kk)
+  // Loads hipcc does not track (inline asm): its own wait in front of a fragment's first use comes out as vmcnt(0) -- a drain of
+  // the whole ring every other slab -- where the issue order says exactly SEVEN younger loads may still be in flight: fragment
+  // (s, kk) is requested behind k-step kk of slab s - 2, followed by 3 - kk more of that slab, 4 of slab s - 1 and kk of slab s.
+  // Nothing may touch a destination register between its load and the counted wait (straight-line code, no copies: checked on
+  // the ISA by tools/check_untracked_conv.py).
+  auto wload = [&](long frag) {
+    s16x8 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(wp + frag * wstep) : "memory");
+    return v;
+  };
+  s16x8 bq[2][4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) bq[0][kk] = wload(kk);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) bq[1][kk] = wload(4 + kk);
+
+  float cbias, cscale, cshift;
+  {
+    const int col = 32 * cb + l31;
+    const bool cok = col < P.Cout;
+    cbias = (cok && P.bias) ? P.bias[col] : 0.f;
+    cscale = (cok && P.scale) ? P.scale[col] : 1.f;
+    cshift = (cok && P.shift) ? P.shift[col] : 0.f;
+  }
+
+  unsigned abase[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int t = 32 * (i0 + i) + l31;
+    const int py = t / TW, px = t - py * TW;
+    abase[i] = lds_addr(patch) + (unsigned)((py * S::PW + px) * CQ_PITCH + hh * 16);
+  }
+  f32x16 acc[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) acc[i] = (f32x16)(0.f);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // patch pieces (and the first weight fragments) landed
+  __builtin_amdgcn_s_barrier();
+
+  // A-fragment sequence of a slab (= tap t of the pass): n = kk * NPB + i -> ds_read_b128 at abase[i] + tap offset + 32 kk, the
+  // offsets instruction immediates (all slabs are unrolled: straight-line code); WIN reads in flight, carried across slabs (the
+  // first WIN reads of tap t + 1 are issued under the last MFMAs of tap t).
+  s16x8 fr[WIN];
+  auto read_n = [&](auto tc, auto nc) {
+    constexpr int t = decltype(tc)::value % 9, n = decltype(nc)::value, kk = n / NPB, i = n % NPB;
+    constexpr int off = ((t / 3) * S::PW + (t % 3)) * CQ_PITCH + kk * 32;
+    fr[n % WIN] = ds_read_b128_asm<off>(abase[i]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  static_for<WIN>([&](auto nc) { read_n(I0{}, nc); });
+
+  static_for<nslab>([&](auto sc) {
+    constexpr int s = decltype(sc)::value, t = s % 9;
+    constexpr long fnext = 4 * (s + 2 < nslab ? s + 2 : nslab - 1);            // (the tail re-loads the last slab: uniform counts)
+    static_for<NSEQ>([&](auto nc) {
+      constexpr int n = decltype(nc)::value, kk = n / NPB, i = n % NPB;
+      if constexpr (i == 0) asm volatile("s_waitcnt vmcnt(7)" : "+v"(bq[s & 1][kk]) :: "memory");
+      lgkm_wait_for<WIN - 1>(fr[n % WIN]);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n % WIN], bq[s & 1][kk], acc[i], 0, 0, 0);
+      if constexpr (n + WIN < NSEQ) read_n(sc, std::integral_constant<int, n + WIN>{});
+      else read_n(std::integral_constant<int, s + 1>{}, std::integral_constant<int, n + WIN - NSEQ>{});    // next tap
+      if constexpr (i == NPB - 1) bq[s & 1][kk] = wload(fnext + kk);            // k-step kk done: its register takes slab s + 2
+    });
+    if constexpr (t == 8 && s + 1 < nslab) {                       // Cin = 128: the patch of the next 64 channels
+      // (the window's run-ahead reads -- of the OLD patch: dead values -- retire here; their registers stay named until then:
+      //  hipcc hands the register of a dead asm result to the next instruction while the LDS return is still in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
+      __builtin_amdgcn_s_barrier();                                // every wave is done with the patch
+      issue_patch((s + 1) / 9);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      static_for<WIN>([&](auto nc) { read_n(I0{}, nc); });         // (the window was read from the old patch)
+    }
+  });
+  // the window's run-ahead reads and the ring's (redundant) tail loads retire here: their registers stay named until then
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+               : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]),
+                 "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
+
+  // ------------------------------------------------------------------------------------------------ epilogue
+  if (P.dbg & 1) { if (acc[0][0] == 12345.f) P.out[0] = __float2bfloat16(acc[1][3]); return; }
+  __syncthreads();                                                 // every wave is done with the patch: its LDS is the staging space
+  char* const stage = lds + wave * S::STAGE;
+  const int col = 32 * cb + l31;
+  const bool want_stats = P.stat_sum != nullptr;
+  const int ch = lane & 3, lpx = lane >> 2;                        // store phase: 16-byte chunk of the 32 channels, pixel of 16
+  const int ccol = 32 * cb + ch * 8;
+  const bool chunk_ok = ccol < P.Cout;
+  // pixel address of the 16-pixel group that starts at tile pixel t0 (t0 % 16 == 0: one row of pixels)
+  auto group_ptr = [&](const bf16_t* base, int t0) {
+    const int py = t0 / TW, px = t0 - py * TW + lpx;
+    return base + (((long)b * P.H + oy0 + py) * P.W + ox0 + px) * P.Cout + ccol;
+  };
+  const bool nt = (P.dbg & 128) != 0;
+  auto st_out = [&](const bf16_t* p, const i32x4& v) {
+    if (nt) __builtin_nontemporal_store(v, reinterpret_cast<i32x4*>(const_cast<bf16_t*>(p)));
+    else *reinterpret_cast<i32x4*>(const_cast<bf16_t*>(p)) = v;
+  };
+  if (P.res == nullptr) {
+    f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+    auto finish = [&](auto affc, auto leakyc, auto statsc) {
+      constexpr bool AFF = decltype(affc)::value, LEAKY = decltype(leakyc)::value, STATS = decltype(statsc)::value;
+      // rounds of 64 pixels through a double-buffered staging image: the rows of round r are read back right behind their
+      // writes and STORED one round later, under the arithmetic of round r + 1 (no wait for the LDS round trip)
+      constexpr int NR = NPB / S::BPR, HALF = S::BPR * 32 * S::OPITCH, NIT = S::BPR * 2;
+      i32x4 prev[NIT];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        char* const buf = stage + (r & 1) * HALF;
+        char* const wpos = buf + (4 * hh) * S::OPITCH + l31 * 2;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ib = 0; ib < S::BPR; ++ib) {
+#pragma unroll
+          for (int rp = 0; rp < 8; ++rp) {
+            const int reg = 2 * rp, rl = 32 * ib + (reg & 3) + 8 * (reg >> 2);
+            float v0 = acc[r * S::BPR + ib][reg] + cbias, v1 = acc[r * S::BPR + ib][reg + 1] + cbias;
+            if constexpr (AFF) { v0 = v0 * cscale + cshift; v1 = v1 * cscale + cshift; }
+            if constexpr (LEAKY) { v0 = fmaxf(v0, v0 * P.slope); v1 = fmaxf(v1, v1 * P.slope); }
+            const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, bf16x2_t));
+            *reinterpret_cast<unsigned short*>(wpos + rl * S::OPITCH) = (unsigned short)pk;
+            *reinterpret_cast<unsigned short*>(wpos + (rl + 1) * S::OPITCH) = (unsigned short)(pk >> 16);
+            if constexpr (STATS) {                                  // statistics of what the next stage will read
+              const f32x2 q = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xFFFF0000u)};
+              s1 += q;
+              s2 = q * q + s2;
+            }
+          }
+          if (ib == 0 && r > 0 && chunk_ok && !(P.dbg & 32)) {      // the previous round's rows leave under this round's arithmetic
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+              st_out(group_ptr(P.out, 32 * (i0 + (r - 1) * S::BPR) + 16 * it), prev[it]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) prev[it] = *reinterpret_cast<const i32x4*>(buf + (it * 16 + lpx) * S::OPITCH + ch * 16);
+      }
+      if (chunk_ok && !(P.dbg & 32)) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          st_out(group_ptr(P.out, 32 * (i0 + (NR - 1) * S::BPR) + 16 * it), prev[it]);
+      }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    const int sel = (P.scale ? 4 : 0) | (P.leaky ? 2 : 0) | (want_stats ? 1 : 0);
+    if (P.dbg & 64) {
+      if (chunk_ok) {
+#pragma unroll
+        for (int it = 0; it < NPB * 2; ++it) {
+          const i32x4 v = *reinterpret_cast<const i32x4*>(stage + ((it & 7) * 16 + lpx) * S::OPITCH + ch * 16);
+          *reinterpret_cast<i32x4*>(const_cast<bf16_t*>(group_ptr(P.out, 32 * i0 + 16 * it))) = v;
+        }
+      }
+    } else
+    switch (sel) {
+      case 0: finish(F_{}, F_{}, F_{}); break;
+      case 1: finish(F_{}, F_{}, T_{}); break;
+      case 2: finish(F_{}, T_{}, F_{}); break;
+      case 3: finish(F_{}, T_{}, T_{}); break;
+      case 4: finish(T_{}, F_{}, F_{}); break;
+      case 5: finish(T_{}, F_{}, T_{}); break;
+      case 6: finish(T_{}, T_{}, F_{}); break;
+      default: finish(T_{}, T_{}, T_{}); break;
+    }
+    if (want_stats) {
+      const float t1 = wave_halves_sum(s1[0] + s1[1]), t2 = wave_halves_sum(s2[0] + s2[1]);
+      if (hh == 0 && col < P.Cout) {
+        const long rep = (long)(blockIdx.x % WMZ_STAT_REPLICAS) * P.Cout;
+        atomicAdd(P.stat_sum + rep + col, t1);
+        atomicAdd(P.stat_sq + rep + col, t2);
+      }
+    }
+  } else {
+    // residual: fp32 rows of 64 pixels x 32 channels staged per round, finished on 16-byte chunks (conv2d.hip's arithmetic)
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    char* const wpos = stage + (4 * hh) * S::FPITCH + l31 * 4;
+#pragma unroll
+    for (int r = 0; r < NPB / 2; ++r) {
+      i32x4 rv[4];
+      if (chunk_ok) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) rv[it] = *reinterpret_cast<const i32x4*>(group_ptr(P.res, 32 * (i0 + 2 * r) + 16 * it));
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int rl = 32 * ib + (reg & 3) + 8 * (reg >> 2);
+          *reinterpret_cast<float*>(wpos + rl * S::FPITCH) = (acc[2 * r + ib][reg] + cbias) * cscale + cshift;
+        }
+      __builtin_amdgcn_wave_barrier();
+      if (chunk_ok) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const char* const rp_ = stage + (it * 16 + lpx) * S::FPITCH + ch * 32;
+          const f32x4 va = *reinterpret_cast<const f32x4*>(rp_);
+          const f32x4 vb = *reinterpret_cast<const f32x4*>(rp_ + 16);
+          float f[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[2 * e] += __uint_as_float(((unsigned)rv[it][e]) << 16);
+            f[2 * e + 1] += __uint_as_float(((unsigned)rv[it][e]) & 0xFFFF0000u);
+          }
+          if (P.leaky) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], f[e] * P.slope);
+          }
+          i32x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            pk[e] = (int)__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){f[2 * e], f[2 * e + 1]}, bf16x2_t));
+          *reinterpret_cast<i32x4*>(const_cast<bf16_t*>(group_ptr(P.out, 32 * (i0 + 2 * r) + 16 * it))) = pk;
+          if (want_stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float q0 = __uint_as_float(((unsigned)pk[e]) << 16), q1 = __uint_as_float(((unsigned)pk[e]) & 0xFFFF0000u);
+              s1[2 * e] += q0; s2[2 * e] = fmaf(q0, q0, s2[2 * e]);
+              s1[2 * e + 1] += q1; s2[2 * e + 1] = fmaf(q1, q1, s2[2 * e + 1]);
+            }
+          }
+        }
+      }
+    }
+    if (want_stats) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o); s2[e] += __shfl_xor(s2[e], o); }
+      }
+      if (lane < 4 && chunk_ok) {
+        const long rep = (long)(blockIdx.x % WMZ_STAT_REPLICAS) * P.Cout;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(P.stat_sum + rep + ccol + e, s1[e]); atomicAdd(P.stat_sq + rep + ccol + e, s2[e]); }
+      }
+    }
+  }
+}
+
 // GEMM operand [Cout, 9 * Cin] (tap-major, channels inside: autoencoder.py:_w_op) -> the fragment-order stream convq_kernel's
 // DMA reads: [pass = Cin / 64][tap 9][k-step 4][Cout block of 32][lane 64][8]: lane (l31, hh) of fragment (pass, tap, kk, j) holds
 // W[32 j + l31][tap * Cin + 64 pass + 16 kk + 8 hh + 0..7]; rows past Cout are zero.
@@ -385,7 +684,7 @@ static int g_conv_skew = 1, g_conv_dbg = 0;
 extern "C" int wmz_debug_conv_knobs(int skew, int dbg) { g_conv_skew = skew; g_conv_dbg = dbg; return WMZ_OK; }
 
 extern "C" int wmz_conv3x3_direct_supported(int H, int W, int Cin, int Cout) {
-  if (Cin <= 0 || (Cin & 63) != 0 || Cout <= 0 || Cout > 128 || (Cout & 7) != 0) return 0;
+  if ((Cin != 64 && Cin != 128) || Cout <= 0 || Cout > 128 || (Cout & 7) != 0) return 0;
   if (W >= 32 && (W & 31) == 0 && (H & 7) == 0) return 1;
   if (W == 16 && (H & 15) == 0) return 1;
   return 0;
@@ -429,12 +728,24 @@ extern "C" int wmz_conv3x3_direct_fwd(const void* x, const void* wpack, void* ou
   WMZ_REQUIRE(tiles < (1L << 31), "wmz_conv3x3_direct_fwd: too many tiles");
   dim3 grid((unsigned)tiles), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (Cout <= 64) {
-    if (wide) hipLaunchKernelGGL((convq_kernel<2, 32>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((convq_kernel<2, 16>), grid, block, 0, st, P);
+  P.ncb_pack = Cout <= 64 ? 2 : 4;
+  if (g_conv_dbg & 16) {                                           // development: the shared-slab kernel (A/B timing)
+    if (Cout <= 64) {
+      if (wide) hipLaunchKernelGGL((convq_kernel<2, 32>), grid, block, 0, st, P);
+      else hipLaunchKernelGGL((convq_kernel<2, 16>), grid, block, 0, st, P);
+    } else {
+      if (wide) hipLaunchKernelGGL((convq_kernel<4, 32>), grid, block, 0, st, P);
+      else hipLaunchKernelGGL((convq_kernel<4, 16>), grid, block, 0, st, P);
+    }
+  } else if (Cout <= 32) {
+    if (wide) { if (Cin == 64) hipLaunchKernelGGL((convr_kernel<1, 32, 1>), grid, block, 0, st, P); else hipLaunchKernelGGL((convr_kernel<1, 32, 2>), grid, block, 0, st, P); }
+    else { if (Cin == 64) hipLaunchKernelGGL((convr_kernel<1, 16, 1>), grid, block, 0, st, P); else hipLaunchKernelGGL((convr_kernel<1, 16, 2>), grid, block, 0, st, P); }
+  } else if (Cout <= 64) {
+    if (wide) { if (Cin == 64) hipLaunchKernelGGL((convr_kernel<2, 32, 1>), grid, block, 0, st, P); else hipLaunchKernelGGL((convr_kernel<2, 32, 2>), grid, block, 0, st, P); }
+    else { if (Cin == 64) hipLaunchKernelGGL((convr_kernel<2, 16, 1>), grid, block, 0, st, P); else hipLaunchKernelGGL((convr_kernel<2, 16, 2>), grid, block, 0, st, P); }
   } else {
-    if (wide) hipLaunchKernelGGL((convq_kernel<4, 32>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((convq_kernel<4, 16>), grid, block, 0, st, P);
+    if (wide) { if (Cin == 64) hipLaunchKernelGGL((convr_kernel<4, 32, 1>), grid, block, 0, st, P); else hipLaunchKernelGGL((convr_kernel<4, 32, 2>), grid, block, 0, st, P); }
+    else { if (Cin == 64) hipLaunchKernelGGL((convr_kernel<4, 16, 1>), grid, block, 0, st, P); else hipLaunchKernelGGL((convr_kernel<4, 16, 2>), grid, block, 0, st, P); }
   }
   WMZ_LAUNCH_CHECK("wmz_conv3x3_direct_fwd");
   return WMZ_OK;

@@ -662,6 +662,18 @@ def _direct_pack(w_op, Cin, Cout):
     return _cast.cached((w_op,), 'convq', build)
 
 
+def _point_pack(w_op, K, Cout):
+    """The fragment-order weights of csrc/conv_point.hip for a GEMM operand [Cout, K] (kept like _direct_pack's)."""
+    from . import _cast
+
+    def build(w):
+        n = L.lib().wmz_conv_point_pack_elems(K, Cout)
+        dst = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        L.call('wmz_conv_point_pack', L.ptr(w), L.ptr(dst), K, Cout, L.stream())
+        return dst
+    return _cast.cached((w_op,), 'convp', build)
+
+
 def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None, residual=None, leaky=False,
                 slope=0.01, stats=False, pre=None):
     """x: [B,H,W,Cin] contiguous (Cin % 8 == 0), w_op: [Cout, KH*KW*Cin] in x's dtype -> [B,Ho,Wo,Cout] (+ sum, sq: fp32
@@ -684,6 +696,13 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
                L.ptr(shift), L.ptr(residual), L.ptr(s), L.ptr(q), B, Hi, Wi, Cin, Cout, 1 if leaky else 0, float(slope), L.stream())
         return (out, s, q) if stats else out
     psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
+    if (DIRECT_CONV and x.dtype == torch.bfloat16 and residual is None and 0.0 <= slope <= 1.0
+            and L.lib().wmz_conv_point_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad)):
+        # csrc/conv_point.hip: small-K layers (1x1, 2x2 / stride 2, the 3-channel conv_1) as a persistent streaming kernel
+        L.call('wmz_conv_point_fwd', L.ptr(x), L.ptr(_point_pack(w_op, KH * KW * Cin, Cout)), L.ptr(out), L.ptr(bias), L.ptr(scale),
+               L.ptr(shift), L.ptr(s), L.ptr(q), L.ptr(psc), L.ptr(psh), float(psl), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad,
+               1 if leaky else 0, float(slope), L.stream())
+        return (out, s, q) if stats else out
     L.call('wmz_conv2d_nhwc_fwd_pre', L.ptr(x), L.ptr(w_op), L.ptr(out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
            L.ptr(residual), L.ptr(s), L.ptr(q), L.ptr(psc), L.ptr(psh), float(psl), B, Hi, Wi, Cin, Cout, KH, KW, stride,
            pad, 1 if leaky else 0, float(slope), L.dtype_code(x.dtype), L.stream())
