@@ -448,6 +448,9 @@ int wmz_conv_point_pack(const void* w_op, void* wpack, int K, int Cout, void* st
 int wmz_conv_point_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale, const float* shift,
                        float* stat_sum, float* stat_sq, const float* in_scale, const float* in_shift, float in_slope, int B, int Hi,
                        int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, void* stream);
+/* logical NCHW frames (contiguous; in_dtype) -> NHWC with the channels zero-padded to a multiple of 8 (out_dtype): the layout
+ * flip in front of the encoder's first convolution (autoencoder.py:83; the reference's modules take NCHW) as one pass. */
+int wmz_nchw_to_nhwc8(const void* x, void* y, int B, int C, int H, int W, int in_dtype, int out_dtype, void* stream);
 /* per-channel sum / sum of squares of an NHWC tensor viewed as [M, C] (accumulated into fp32 [WMZ_STAT_REPLICAS][C]). */
 int wmz_channel_stats_nhwc(const void* x, long M, int C, float* sum, float* sq, int dtype, void* stream);
 /* nn.BatchNorm2d bookkeeping: training != 0: batch mean / biased var from (sum, sq: [WMZ_STAT_REPLICAS][C], summed here; count), running stats updated with

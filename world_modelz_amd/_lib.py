@@ -86,6 +86,7 @@ SIGNATURES = {
     'wmz_conv_point_pack_elems': [c_int, c_int],                           # returns long
     'wmz_conv_point_pack': [c_void_p, c_void_p, c_int, c_int, c_void_p],
     'wmz_conv_point_fwd': [c_void_p] * 10 + [c_float] + [c_int] * 10 + [c_float, c_void_p],
+    'wmz_nchw_to_nhwc8': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_channel_stats_nhwc': [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p],
     'wmz_bn_finalize': [c_void_p, c_void_p, c_double] + [c_void_p] * 4 + [c_double, c_double, c_int] + [c_void_p] * 4
                        + [c_int, c_void_p, c_void_p],

@@ -54,6 +54,8 @@ def _to_nhwc(x, dtype):
     """logical NCHW (any memory format) -> contiguous [B,H,W,C8] in the compute dtype."""
     if not x.is_cuda:
         raise WmzError('the conv encoder/decoder runs on the GPU only (no CPU fallback)')
+    if (x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16) and not (torch.is_grad_enabled() and x.requires_grad)):
+        return ops.nchw_to_nhwc8(x, dtype)                         # flip + channel pad + cast in one launch
     x = x.permute(0, 2, 3, 1)
     c = x.shape[-1]
     if _pad8(c) != c:
@@ -302,11 +304,12 @@ class SimpleResidualEncoder(nn.Module):
     def forward_nhwc(self, x):
         """NCHW frames -> [B,h,w,E] latents (what VectorQuantizerEMA wants: no NCHW<->NHWC flips)."""
         dt = get_compute_dtype()
-        if _grad_path(x, self):
-            h = F.leaky_relu(_conv_g(_to_nhwc(x, dt), self._conv_1), LEAKY)
-        else:
-            h = _conv(_to_nhwc(x, dt), self._conv_1, dt, leaky=True, slope=LEAKY)
-        return self._residual_stack.forward_nhwc(h, dt)
+        with ops.stat_arena():                                     # (one zero fill for every BatchNorm statistic of the pass)
+            if _grad_path(x, self):
+                h = F.leaky_relu(_conv_g(_to_nhwc(x, dt), self._conv_1), LEAKY)
+            else:
+                h = _conv(_to_nhwc(x, dt), self._conv_1, dt, leaky=True, slope=LEAKY)
+            return self._residual_stack.forward_nhwc(h, dt)
 
     def forward(self, x):
         return _to_nchw_view(self.forward_nhwc(x)).to(x.dtype)
@@ -382,10 +385,11 @@ class SimpleResidualDecoder(nn.Module):
         dt = get_compute_dtype()
         mods = list(self.decoder_stack)
         grad = _grad_path(h, self)
-        h = _conv_g(h, mods[0]) if grad else _conv(h, mods[0], dt)
-        for m in mods[1:-1]:
-            h = m.forward_nhwc(h, dt)
-        return _to_nchw_view(_conv_g(h, mods[-1]) if grad else _conv(h, mods[-1], dt))
+        with ops.stat_arena():
+            h = _conv_g(h, mods[0]) if grad else _conv(h, mods[0], dt)
+            for m in mods[1:-1]:
+                h = m.forward_nhwc(h, dt)
+            return _to_nchw_view(_conv_g(h, mods[-1]) if grad else _conv(h, mods[-1], dt))
 
     def forward(self, x):
         return self.forward_nhwc(_to_nhwc(x, get_compute_dtype())).to(x.dtype)

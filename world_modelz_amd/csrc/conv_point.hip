@@ -258,6 +258,36 @@ __global__ __launch_bounds__(256) void convp_pack_kernel(const bf16_t* __restric
   *reinterpret_cast<i32x4*>(dst + i * 8) = v;
 }
 
+// logical NCHW frames (contiguous, fp32 or bf16) -> NHWC with the channels zero-padded to a multiple of 8, in the compute dtype:
+// the layout flip + pad + cast in front of conv_1 (autoencoder.py:83) as ONE pass (F.pad + copy + cast were three launches,
+// 34 us for 256 frames of 64 x 64).  A thread owns one pixel and one group of 8 channels: plane reads coalesce along W, the
+// write is one 16-byte (bf16) / two 16-byte (fp32) chunks.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const TI* __restrict__ x, TO* __restrict__ y, int C, int C8, long HW, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;              // pixel-major: consecutive threads = consecutive pixels
+  if (i >= total) return;
+  const int ngrp = C8 >> 3;
+  const long pix = i % (total / ngrp);                               // (channel groups outermost: a warp stays in one plane set)
+  const int grp = (int)(i / (total / ngrp));
+  const long b = pix / HW, p = pix - b * HW;
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = grp * 8 + e;
+    f[e] = c < C ? Elem<TI>::to_f32(x[(b * C + c) * HW + p]) : 0.f;
+  }
+  TO* const dst = y + pix * C8 + grp * 8;
+  if constexpr (sizeof(TO) == 2) {
+    i32x4 pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = (int)((unsigned)f32_to_bf16_bits(f[2 * e]) | ((unsigned)f32_to_bf16_bits(f[2 * e + 1]) << 16));
+    *reinterpret_cast<i32x4*>(dst) = pk;
+  } else {
+    *reinterpret_cast<f32x4*>(dst) = (f32x4){f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+  }
+}
+
 int point_ncb(int Cout) { return Cout <= 64 ? 2 : 4; }
 
 }  // namespace
@@ -333,5 +363,20 @@ extern "C" int wmz_conv_point_fwd(const void* x, const void* wpack, void* out, c
     else hipLaunchKernelGGL((convp_kernel<4, 1, false>), dim3(grid), dim3(256), lds_bytes, st, P);
   }
   WMZ_LAUNCH_CHECK("wmz_conv_point_fwd");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_nchw_to_nhwc8(const void* x, void* y, int B, int C, int H, int W, int in_dtype, int out_dtype, void* stream) {
+  WMZ_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "wmz_nchw_to_nhwc8: bad arguments");
+  WMZ_REQUIRE((in_dtype == WMZ_F32 || in_dtype == WMZ_BF16) && (out_dtype == WMZ_F32 || out_dtype == WMZ_BF16), "wmz_nchw_to_nhwc8: bad dtype");
+  const int C8 = (C + 7) & ~7;
+  const long HW = (long)H * W, total = (long)B * HW * (C8 >> 3);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == WMZ_F32 && out_dtype == WMZ_BF16) hipLaunchKernelGGL((nchw_to_nhwc8_kernel<float, bf16_t>), grid, block, 0, st, (const float*)x, (bf16_t*)y, C, C8, HW, total);
+  else if (in_dtype == WMZ_F32) hipLaunchKernelGGL((nchw_to_nhwc8_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)y, C, C8, HW, total);
+  else if (out_dtype == WMZ_BF16) hipLaunchKernelGGL((nchw_to_nhwc8_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, C, C8, HW, total);
+  else hipLaunchKernelGGL((nchw_to_nhwc8_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, (float*)y, C, C8, HW, total);
+  WMZ_LAUNCH_CHECK("wmz_nchw_to_nhwc8");
   return WMZ_OK;
 }

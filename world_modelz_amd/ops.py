@@ -686,7 +686,7 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
     out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     s = q = None
     if stats:
-        s, q = torch.zeros((2, STAT_REPLICAS, Cout), dtype=torch.float32, device=x.device).unbind(0)      # one fill for both
+        s, q = _stat_pair(Cout, x.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
     if (DIRECT_CONV and x.dtype == torch.bfloat16 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pre is None
@@ -709,10 +709,49 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
     return (out, s, q) if stats else out
 
 
+_stat_arena = None         # [zero tensor [slots, 2 * STAT_REPLICAS * 128], next slot] while a stat_arena() is open
+
+
+@contextlib.contextmanager
+def stat_arena(slots=32):
+    """One zero fill for the BatchNorm statistics of a whole encoder / decoder pass: inside the context the (sum, sumsq) pairs
+    of conv2d_nhwc(stats=True) / channel_stats_nhwc are slices of ONE zeroed tensor (allocated at the first request) instead of a
+    torch.zeros each -- ten ~5 us fills per frame-encoder call.  Re-entrant: an inner context shares the outer arena."""
+    global _stat_arena
+    if _stat_arena is not None:
+        yield
+        return
+    _stat_arena = [None, 0, slots]
+    try:
+        yield
+    finally:
+        _stat_arena = None
+
+
+def _stat_pair(C, device):
+    a = _stat_arena
+    if a is not None and C <= 128:
+        if a[0] is None:
+            a[0] = torch.zeros((a[2], 2 * STAT_REPLICAS * 128), dtype=torch.float32, device=device)
+        if a[1] < a[2] and a[0].device == device:
+            row = a[0][a[1]]
+            a[1] += 1
+            return row[:2 * STAT_REPLICAS * C].view(2, STAT_REPLICAS, C).unbind(0)
+    return torch.zeros((2, STAT_REPLICAS, C), dtype=torch.float32, device=device).unbind(0)      # one fill for both
+
+
+def nchw_to_nhwc8(x, dtype):
+    """logical NCHW (contiguous) -> [B, H, W, C8] in `dtype`, channels zero-padded to a multiple of 8: one launch."""
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, (C + 7) // 8 * 8), dtype=dtype, device=x.device)
+    L.call('wmz_nchw_to_nhwc8', L.ptr(x), L.ptr(y), B, C, H, W, L.dtype_code(x.dtype), L.dtype_code(dtype), L.stream())
+    return y
+
+
 def channel_stats_nhwc(x):
     C = x.shape[-1]
     M = x.numel() // C
-    s, q = torch.zeros((2, STAT_REPLICAS, C), dtype=torch.float32, device=x.device).unbind(0)
+    s, q = _stat_pair(C, x.device)
     L.call('wmz_channel_stats_nhwc', L.ptr(x), M, C, L.ptr(s), L.ptr(q), L.dtype_code(x.dtype), L.stream())
     return s, q
 
