@@ -35,6 +35,51 @@ def algorithmic_bytes(cfg, elt=2):
     return step, attn
 
 
+def ae_layer_model(downscale=2, E=64, P=128, res=64, in_ch=3, elt=2):
+    """Per-FRAME flops and tensor traffic of the conv encoder / decoder of the frozen VQ auto-encoder (autoencoder.py:60-152;
+    `downscale` Residual pairs, E latent / P hidden planes, res x res frames), layer by layer.  Flops: 2 M K N per convolution
+    with the real channel counts.  Bytes: training-mode BatchNorm (quirk Q3) needs a layer's whole-batch statistics before its
+    consumer may run, so every normalised tensor makes one round trip per consumer -- the traffic of the launch plan as it
+    stands (conv -> [stats] -> conv with prologue -> [stats] -> skip add), bf16 tensors, NOT a lower bound of the problem
+    (whose only compulsory traffic is 48 KB of frame in and 2 KB of tokens out).  Returns dicts for encoder and decoder."""
+    enc_f = enc_b = 0.0
+    px = res * res
+    enc_f += 2.0 * px * 9 * in_ch * E
+    enc_b += px * in_ch * 4 + px * 8 * elt * 2 + px * E * elt                       # frame in, NHWC8 copy out + in, conv_1 out
+    r = res
+    for _ in range(downscale):
+        for stride in (1, 2):
+            pi, po = r * r, (r // stride) ** 2
+            enc_f += 2.0 * po * 9 * E * P + 2.0 * po * P * E                        # conv3x3, conv1x1
+            enc_b += pi * E * elt + po * P * elt                                    # conv3x3: in, hidden out
+            enc_b += po * P * elt + po * E * elt                                    # conv1x1 (BatchNorm + LeakyReLU prologue): in, out
+            if stride == 2:
+                enc_f += 2.0 * po * 4 * E * E
+                enc_b += pi * E * elt + po * E * elt                                # 2x2 / stride 2 skip: in, out
+                enc_b += 3 * po * E * elt                                           # BN + BN + add + LeakyReLU: two in, one out
+            else:
+                enc_b += 3 * po * E * elt                                           # BN + skip + LeakyReLU: two in, one out
+            r //= stride
+    lat = r * r
+    enc_b += lat * E * elt + lat * E * 4 + lat * E * 4 + lat * 8                    # latents -> fp32 -> codebook search -> tokens
+    dec_f = dec_b = 0.0
+    dec_f += 2.0 * lat * 9 * E * E
+    dec_b += 2 * lat * E * elt
+    cin = E
+    for _ in range(downscale):
+        pi, po = r * r, 4 * r * r
+        dec_f += 2.0 * po * 9 * cin * P + 2.0 * po * 9 * P * P + 2.0 * po * cin * P
+        dec_b += (2 * pi * cin + 2 * po * cin) * elt                                # BN + act; two bilinear x2
+        dec_b += (po * cin + po * P) * elt + 2 * po * P * elt                       # conv1; BN + act
+        dec_b += (po * cin + po * P) * elt                                          # conv_residual
+        dec_b += 3 * po * P * elt                                                   # conv2 + skip
+        cin, r = P, 2 * r
+    dec_f += 2.0 * r * r * 9 * P * in_ch
+    dec_b += r * r * P * elt + r * r * 8 * elt
+    return {'enc_flops': enc_f, 'enc_bytes': enc_b, 'dec_flops': dec_f, 'dec_bytes': dec_b,
+            'conv1_flops': 2.0 * px * 9 * in_ch * E}
+
+
 def usable_cores():
     """CPU share of this process: affinity mask capped by the cgroup quota (the GPU box gives 16 of the
     host's cores to one GPU; os.cpu_count() reports the whole host)."""
@@ -464,6 +509,44 @@ def main():
             log(f'last-frame cone: {cone["ms_per_step"]:.3f} ms/step, identical={same}')
         out['last_frame_cone'] = cone
         gc.collect()
+        # ---- secondary figure: the headline step in the REFERENCE's own precision (all reference arithmetic is fp32: SURVEY 8;
+        # main.py:33-36) -- the same model and clips on the library's fp32 mode (op-by-op kernels, exact-f32 MFMA), the step
+        # roofline on elt = 4 bytes, and the logits of one clip against the CPU oracle measured in the same run
+        fp32m = None
+        if single_figs and dtype == torch.bfloat16 and not a.eager:
+            with torch.no_grad():
+                y16_1 = runner(runner.static_in)[:1].float().cpu()          # (before the dtype moves: the runner re-captures on that)
+            config.set_compute_dtype(torch.float32)
+            try:
+                with torch.no_grad():
+                    frun = GraphedForward(model, z)
+                    fz = frun.static_in
+                    for _ in range(5):
+                        y32 = frun(fz)
+                    torch.cuda.synchronize()
+                    f0_ = time.perf_counter()
+                    nf = 10
+                    for _ in range(nf):
+                        y32 = frun(fz)
+                    torch.cuda.synchronize()
+                    fel32 = (time.perf_counter() - f0_) / nf
+                    from oracle import denoiser as _oden
+                    torch.set_num_threads(usable_cores())
+                    ref1 = _oden.denoiser_forward(sd_cpu, z[:1].cpu(), cfg['extents'], cfg['heads'])
+                    rel32 = float((y32[:1].float().cpu() - ref1).norm() / ref1.norm())
+                    rel16 = float((y16_1 - ref1).norm() / ref1.norm())
+                b32, _ = algorithmic_bytes(cfg, elt=4)
+                fp32m = {'ms_per_step': fel32 * 1e3, 'value': cfg['B'] * cfg['S'] / fel32, 'unit': 'latent-frames/s', 'dtype': 'f32',
+                         'roofline': {'bound': 'hbm', 'achieved': b32 / fel32 / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                      'frac': b32 / fel32 / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_step': b32},
+                         'logits_rel_err_vs_cpu_oracle_one_clip': rel32, 'bf16_logits_rel_err_same_clip': rel16,
+                         'what': 'the headline forward step with fp32 activations and fp32 MFMA arithmetic (the reference\'s precision), full grid, one hipGraph'}
+                log(f'fp32 mode: {fel32 * 1e3:.3f} ms/step, logits rel err vs oracle {rel32:.2e} (bf16: {rel16:.2e})')
+                del frun
+            finally:
+                config.set_compute_dtype(dtype)
+        out['fp32_mode'] = fp32m
+        gc.collect()
         # ---- secondary figure: the same step with the reference's other published attention window, 7 x 3 x 3 (extents 3, 1, 1:
         # BASELINE.md run-03), full grid, same model otherwise
         win = None
@@ -587,7 +670,18 @@ def main():
                 torch.cuda.synchronize()
                 fel = (time.perf_counter() - f0) / 10
             assert tok.shape == (cfg['B'] * cfg['S'], 16, 16)
+            aem = ae_layer_model()
+            nfr = cfg['B'] * cfg['S']
+            vq_flops = 3.0 * 256 * cfg['C'] * 64                   # per frame: 256 latents x C codes x E (sub, mul, add)
             frame_enc = {'value': cfg['B'] * cfg['S'] / fel, 'unit': 'frames/s', 'ms_per_batch': fel * 1e3,
+                         # HBM: the launch plan's tensor traffic (training-mode BatchNorm forces a round trip per normalised
+                         # tensor: ae_layer_model); MFMA: the convolutions' 2 M K N at the dense bf16 peak
+                         'roofline': {'bound': 'hbm', 'achieved': aem['enc_bytes'] * nfr / fel / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                      'frac': aem['enc_bytes'] * nfr / fel / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                      'bytes_per_frame': aem['enc_bytes'], 'what': 'tensor traffic of the launch plan (one round trip per BatchNorm-ed tensor and consumer), bf16'},
+                         'roofline_mfma': {'bound': 'mfma', 'achieved': (aem['enc_flops'] + vq_flops) * nfr / fel / 1e12, 'peak': 2500.0,
+                                           'unit': 'TFLOP/s', 'frac': (aem['enc_flops'] + vq_flops) * nfr / fel / 1e12 / 2500.0,
+                                           'flops_per_frame': aem['enc_flops'] + vq_flops},
                          'launch_mode': 'eager' if a.eager else 'hipGraph (GraphedEncoder: one launch per batch of frames)',
                          'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens "
                                  '(BatchNorm in training mode as in main.py:236, quirk Q3)'}
@@ -612,7 +706,13 @@ def main():
                 vt.train_step(fr)
             torch.cuda.synchronize()
             vel = (time.perf_counter() - v0) / 5
+            aem = ae_layer_model()
+            # forward + data gradient + weight gradient of every convolution (the first layer has no data gradient)
+            vq_tr_flops = 64 * (3.0 * (aem['enc_flops'] + aem['dec_flops']) - aem['conv1_flops'])
             vqae = {'value': 64 / vel, 'unit': 'frames/s', 'ms_per_step': vel * 1e3,
+                    'roofline': {'bound': 'mfma', 'achieved': vq_tr_flops / vel / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                 'frac': vq_tr_flops / vel / 1e12 / 2500.0, 'flops_per_step': vq_tr_flops,
+                                 'what': '3 x the convolutions 2 M K N (forward, data gradient, weight gradient) of encoder + decoder on 64 frames'},
                     'launch_mode': 'eager' if a.eager else 'hipGraph',
                     'what': 'VqaeTrainer.train_step on 64 RGB frames of 64x64 (codebook 1024 x 64, 2 down-scale steps, 128 planes): one hipGraph replay + one host read-back per step'}
             log(f'VQ-AE training step: {vel * 1e3:.2f} ms per 64 frames')
@@ -748,6 +848,30 @@ def main():
                     f3run(f3run.static_in)
                 torch.cuda.synchronize()
                 f3 = (time.perf_counter() - c0_) / a.steps
+            # ... and the reference's step END TO END (main.py:229-237: every training step first encodes its B x (n_past + 1)
+            # frames with the frozen auto-encoder -- BatchNorm in training mode, quirk Q3 -- then corrupts and trains): 256 fp32
+            # frames of 64x64 in -> encode (one hipGraph) -> tokens [16, 16, 16, 16] -> the graphed training step.  One number.
+            e2e = None
+            if frame_enc is not None and not a.eager:
+                fr3 = torch.randn(16 * 16, 3, 64, 64, device=dev)
+
+                def e2e_step():
+                    tok3 = enc(fr3)
+                    return t3.train_step(tok3.view(16, 16, 16, 16), r=r3)
+                for _ in range(3):
+                    e2e_step()
+                torch.cuda.synchronize()
+                c0_ = time.perf_counter()
+                for _ in range(n3):
+                    e2e_step()
+                torch.cuda.synchronize()
+                ce = (time.perf_counter() - c0_) / n3
+                e2e = {'ms_per_step': ce * 1e3, 'value': 16 * 16 / ce, 'unit': 'latent-frames/s',
+                       'encode_ms': frame_enc['ms_per_batch'], 'train_ms': c3 * 1e3,
+                       'what': 'main.py:229-287 end to end: 256 fp32 RGB frames of 64x64 -> VqAutoEncoder.encode (BatchNorm in training '
+                               'mode, one hipGraph) -> token corruption + forward + CE + backward + AdamW (one hipGraph) on 16 clips of 16x16x16'}
+                log(f'config 3 end to end (frames -> tokens -> training step): {ce * 1e3:.2f} ms/step')
+            out['config3_end_to_end'] = e2e
             cfg3 = {'train_ms_per_step': c3 * 1e3, 'train_value': 16 * 16 / c3, 'forward_ms_per_step': f3 * 1e3,
                     'forward_value': 16 * 16 / f3, 'unit': 'latent-frames/s',
                     'what': 'B=16 clips of 16x16x16 latents, codebook 1024, default model: full training step (one hipGraph) and the '
@@ -756,6 +880,7 @@ def main():
             del t3, m3, f3run
             gc.collect()
         out['config3_train_step'] = cfg3
+        out.setdefault('config3_end_to_end', None)
         # ---- secondary figure: the full training step (corrupt -> forward -> CE -> backward -> grad-norm -> AdamW -> operand
         # re-pack), same shapes, same rules (barrier + sync both sides, max over ranks).  One GPU: the whole step is ONE hipGraph
         # replay (DenoiserTrainer.enable_graph) plus the loss-aware sampler's one host read-back per step.  n_gpus > 1: the same

@@ -534,3 +534,33 @@ def test_graphed_frame_encoder_matches_eager_calls():
         for k in sd1:
             if 'running' in k or 'num_batches' in k:
                 assert torch.allclose(sd1[k].float(), sd2[k].float(), rtol=1e-6, atol=1e-7), k
+
+
+def test_frozen_encoder_graph_survives_the_denoiser_optimizer_steps():
+    """main.py:229-287 runs the FROZEN auto-encoder's encode and a denoiser training step in every iteration.  The trainer's
+    optimizer launch rewrites its arena behind torch's version counters and says so (_cast.invalidate): that must name the
+    trainer's own parameters -- the encoder's captured graph (GraphedEncoder) re-captured on every step before (5 ms per step on
+    the reference's configuration 3), while a graph over the TRAINED model still has to re-capture."""
+    from world_modelz_amd import config
+    from world_modelz_amd.graph import GraphedEncoder, GraphedForward
+    from world_modelz_amd.main import VqVideoDiffusionModel
+    from world_modelz_amd.train import DenoiserTrainer
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    torch.manual_seed(3)
+    with config.compute_dtype(torch.bfloat16):
+        ae = VqAutoEncoder(embedding_dim=16, num_embeddings=32, downscale_steps=2, hidden_planes=24).cuda()
+        frames = torch.rand(8, 3, 32, 32, device='cuda')
+        model = VqVideoDiffusionModel(data_shape=(2, 8, 8), dim=64, num_classes=32, extents=(1, 1, 1), depth=1, dim_head=32,
+                                      mlp_dim=64, heads=2).cuda()
+        with torch.no_grad():
+            enc = GraphedEncoder(ae, frames, warmup=1)
+            fwd = GraphedForward(model, torch.randint(0, 33, (4, 2, 8, 8), device='cuda'))
+        tr = DenoiserTrainer(model, 32, lr=1e-3, warmup=1, max_steps=100, distributed=False)
+        for _ in range(3):
+            with torch.no_grad():
+                tok = enc(frames)
+            tr.train_step(tok.view(4, 2, 8, 8).clone(), r=torch.full((4,), 0.5))
+        assert enc.recaptures == 0
+        with torch.no_grad():
+            fwd(fwd.static_in)
+        assert fwd.recaptures == 1                      # the trained model's weights did move

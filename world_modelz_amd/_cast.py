@@ -62,10 +62,27 @@ def cached(params, tag, build):
     return val
 
 
-def invalidate():
-    """Parameters changed in place without torch noticing (wmz_adamw_step on the flat arena)."""
-    global _epoch
+_scoped = {}       # id(parameter) -> how often invalidate(params) named it
+_unscoped = 0      # invalidate() calls that named nothing
+
+
+def invalidate(params=None):
+    """Parameters changed in place without torch noticing (wmz_adamw_step on the flat arena).  Every operand copy is rebuilt at its
+    next use either way (the global epoch moves); `params` says WHOSE weights moved, for holders of captured graphs: a graph
+    re-captures only when its own model's tensors were named (graph.GraphedForward: the frozen auto-encoder's encoder graph must
+    survive the denoiser's optimizer steps -- main.py:229-287 runs both in every training step)."""
+    global _epoch, _unscoped
     _epoch += 1
+    if params is None:
+        _unscoped += 1
+    else:
+        for p in params:
+            _scoped[id(p)] = _scoped.get(id(p), 0) + 1
+
+
+def epoch_of(tensors):
+    """What a graph holder stamps: moves when invalidate() named one of `tensors` (or named nothing)."""
+    return _unscoped, sum(_scoped.get(id(t), 0) for t in tensors)
 
 
 def clear():

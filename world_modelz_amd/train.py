@@ -397,7 +397,7 @@ class _TrainerBase(_AdamState):
         L.call('wmz_adamw_step', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
                float(lr), self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(scale), st)
         self._ema_update()
-        _cast.invalidate()            # the kernel rewrote the arena behind torch's version counters
+        _cast.invalidate(self.arena.params)            # the kernel rewrote the arena behind torch's version counters
         self._refresh_operands()      # ... and every operand copy of the weights is rebuilt by one launch
         return self.sq
 
@@ -474,7 +474,7 @@ class _TrainerBase(_AdamState):
             self.v.copy_(snap[2])
             self.step_count = snap[3]
             self.sampler_gen.set_state(snap[4])
-            _cast.invalidate()
+            _cast.invalidate(self.arena.params)
             self._refresh_operands()
         self._graph = g
         # the graph bakes in the addresses of the library workspaces it was captured with (split-K partial tiles, counting-sort
@@ -511,7 +511,7 @@ class _TrainerBase(_AdamState):
         a.flat_grad.zero_()
         # whatever is derived from the weights is rebuilt INSIDE the graph, every replay: the bulk operand copies by one
         # launch here, the fused kernels' weight streams by the forward (their cache entries are stale by construction)
-        _cast.invalidate()
+        _cast.invalidate(self.arena.params)
         self._refresh_operands()
         per_sample, mean = self._graph_step(self._g_z, self._g_r)      # subclass: corruption (device counter) -> forward / backward
         self._g_ctr += 1
@@ -533,7 +533,7 @@ class _TrainerBase(_AdamState):
         self._g_z.copy_(batch_z, non_blocking=True)
         self._set_step_inputs(r)
         self._graph.replay()
-        _cast.invalidate()             # the replay rewrote the weights: eager consumers rebuild their operand copies
+        _cast.invalidate(self.arena.params)             # the replay rewrote the weights: eager consumers rebuild their operand copies
         out = self._g_out.cpu()                                                  # the step's one host sync
         self.sampler.update_with_losses(self._g_r_host, out[2:])
         return float(out[0]), math.sqrt(float(out[1]))
@@ -765,7 +765,7 @@ class VqaeTrainer(_AdamState):
     def _graph_body(self):
         a = self.arena
         a.flat_grad.zero_()
-        _cast.invalidate()                 # (the conv / codebook operand copies are rebuilt from the weights inside the graph)
+        _cast.invalidate(self.arena.params)                 # (the conv / codebook operand copies are rebuilt from the weights inside the graph)
         self._refresh_conv_operands()
         out = self._forward_backward(self._g_x)
         ops.wgrad_join()                   # (the conv weight gradients' side branch; already joined when the autograd pass ended)
@@ -776,7 +776,7 @@ class VqaeTrainer(_AdamState):
         return out
 
     def _after_step(self):
-        _cast.invalidate()
+        _cast.invalidate(self.arena.params)
         if self.vq_reuse_interval and self.step_count % self.vq_reuse_interval == 0:
             self.reused = self.model.vq.reuse_inactive()
             self.model.vq.reset_stats()
