@@ -564,3 +564,37 @@ def test_frozen_encoder_graph_survives_the_denoiser_optimizer_steps():
         with torch.no_grad():
             fwd(fwd.static_in)
         assert fwd.recaptures == 1                      # the trained model's weights did move
+
+
+@pytest.mark.parametrize('geom', [(2, 16, 32, 64, True), (1, 8, 16, 128, True), (3, 24, 48, 128, False), (5, 16, 16, 64, False),
+                                  (70, 16, 32, 128, True)])
+def test_direct_3x3_weight_gradient_vs_torch(wmz, geom):
+    """csrc/conv_wgrad.hip (3x3 / stride 1 / pad 1, Cout = 128, Cin 64 or 128, bf16: the pixel axis tiled, all nine taps from one
+    staged patch, persistent workgroups + the deterministic two-stage reduction) against torch.autograd on the same bf16 operands:
+    weight and bias gradients, plain [N, K] result and nn.Conv2d's layout accumulated in place; more tiles than workgroups, fewer
+    tiles than workgroups, image borders."""
+    from world_modelz_amd import ops
+    B, H, W, Ci, bias = geom
+    Co = 128
+    torch.manual_seed(21)
+    x = torch.randn(B, H, W, Ci, device='cuda').bfloat16()
+    dy = (torch.randn(B, H, W, Co, device='cuda') * 0.5).bfloat16()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    w = torch.zeros(Co, Ci, 3, 3, device='cuda', requires_grad=True)
+    b = torch.zeros(Co, device='cuda', requires_grad=True)
+    y = torch.nn.functional.conv2d(xr, w, b, padding=1)
+    (y * dy.float().permute(0, 3, 1, 2)).sum().backward()
+    dw, db = ops.conv2d_nhwc_wgrad(x, dy, 3, 3, 1, 1, bias)                   # [Co, 9 * Ci] (tap-major), [Co]
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci)
+    assert rel(dw, ref) < 2e-5, geom
+    if bias:
+        assert rel(db, b.grad) < 2e-5
+    # nn.Conv2d's own gradient tensors, accumulated (twice: the second call adds)
+    gw = torch.zeros(Co, Ci, 3, 3, device='cuda')
+    gb = torch.zeros(Co, device='cuda') if bias else None
+    for _ in range(2):
+        ops.conv2d_nhwc_wgrad(x, dy, 3, 3, 1, 1, bias, into=(gw, gb))
+    ops.wgrad_join()
+    assert rel(gw, 2 * w.grad) < 2e-5
+    if bias:
+        assert rel(gb, 2 * b.grad) < 2e-5

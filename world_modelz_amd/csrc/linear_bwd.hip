@@ -4,6 +4,7 @@
 //   wmz_layernorm_bwd   dx = LN'(x)^T dyhat (+ skip gradient),  dgamma, dbeta
 // (the data gradient dA' = dC . W is wmz_linear_fwd on the transposed weight, optionally x gelu'(z).)
 #include "wmz_common.h"
+#include "wmz_internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -1120,6 +1121,18 @@ int wg_batch_launch(const WgBatch& B, const RedBatch& R, int pro, float* workspa
 }
 }  // namespace
 
+int wmz_wgrad_reduce_launch(const float* workspace, float* dW, float* dbias, long NK, int nsplit, int N, int overwrite, int taps,
+                            int cin_p, int co, int ci, hipStream_t stream) {
+  RedBatch R;
+  R.n = 1;
+  RedProb& Q = R.p[0];
+  Q.dW = dW; Q.dbias = dbias; Q.wsoff = 0; Q.NK = NK; Q.nsplit = nsplit; Q.N = N; Q.nblk_w = wmz_cdiv(NK, 256); Q.overwrite = overwrite;
+  Q.taps = taps; Q.cin_p = cin_p; Q.co = co; Q.ci = ci; Q.first = 0;
+  const int nred = Q.nblk_w + (dbias != nullptr ? wmz_cdiv(N, 64) : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nred), dim3(1024), 0, stream, workspace, R);
+  return WMZ_OK;
+}
+
 extern "C" int wmz_linear_wgrad_ws(const void* dC, long ldc, const void* A, long lda, float* dW, float* dbias, int M, int N,
                                    int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
                                    const float* ln_rstd, int gelu_in, int overwrite, float* workspace,
@@ -1373,7 +1386,12 @@ extern "C" long wmz_conv2d_nhwc_wgrad_workspace_floats(int B, int Hi, int Wi, in
                                                        int pad, int dtype) {
   const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
-  return wmz_linear_wgrad_workspace_floats(B * Ho * Wo, Cout, KH * KW * Cin, dtype);
+  const long base = wmz_linear_wgrad_workspace_floats(B * Ho * Wo, Cout, KH * KW * Cin, dtype);
+  if (wmz_convw_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dtype)) {
+    const long direct = wmz_convw_workspace_floats(B, Hi, Wi, Cin, Cout);
+    return direct > base ? direct : base;
+  }
+  return base;
 }
 extern "C" int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin,
                                         int Cout, int KH, int KW, int stride, int pad, int overwrite, int conv_layout_co,
@@ -1387,6 +1405,9 @@ extern "C" int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW
   WMZ_REQUIRE((long)B * Ho * Wo < (1L << 31), "wmz_conv2d_nhwc_wgrad_ws: too many output pixels");
   const int M = B * Ho * Wo, K = KH * KW * Cin;
   WMZ_REQUIRE(workspace_floats >= wmz_linear_wgrad_workspace_floats(M, Cout, K, dtype), "wmz_conv2d_nhwc_wgrad_ws: workspace too small");
+  if (wmz_convw_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dtype) && workspace_floats >= wmz_convw_workspace_floats(B, Hi, Wi, Cin, Cout))
+    return wmz_convw_launch(x, dy, dW, dbias, B, Hi, Wi, Cin, Cout, overwrite, conv_layout_co, conv_layout_ci, workspace, workspace_floats,
+                            (hipStream_t)stream);
   WgBatch Bt;
   RedBatch R;
   Bt.n = R.n = 1;
