@@ -322,6 +322,11 @@ int wmz_operands_refresh(const void* const* src0, const void* const* src1, const
  * (autoencoder.py:_w_op / _wT_op); dst in `dtype`. */
 int wmz_conv_operands_refresh(const void* const* weight, void* const* dst, const int* co, const int* ci, const int* kk,
                               const int* mode, int n, int dtype, void* stream);
+/* The same with, per entry, an optional fragment-order destination instead of the row-major one (bf16): pack[i] = 1: the weight
+ * stream of wmz_conv3x3_direct_fwd for that operand (what wmz_conv3x3_direct_pack makes of it), 2: wmz_conv_point_fwd's
+ * (wmz_conv_point_pack), 0: row-major as above; pack == NULL: all row-major. */
+int wmz_conv_operands_refresh_packed(const void* const* weight, void* const* dst, const int* co, const int* ci, const int* kk,
+                                     const int* mode, const int* pack, int n, int dtype, void* stream);
 
 /* Builds the packed weight stream and the vector block of wmz_layer_fused_fwd* from the layer's fp32 parameters in one
  * launch (the LayerNorm affines g2/be2 -- the feed-forward's norm -- and g1/be1 -- the NEXT layer's attention norm -- are

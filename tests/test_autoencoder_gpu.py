@@ -502,11 +502,36 @@ def test_conv_operands_bulk_refresh_equals_the_tensor_op_builds(wmz, dtype):
     bulk.refresh()
     for c, (rw, rt) in zip(convs, ref):
         w, t = autoencoder._w_op(c, dtype), autoencoder._wT_op(c.weight, dtype)
-        assert any(w.data_ptr() == e[3].data_ptr() for e in bulk.entries)          # served from the bulk buffers (a cache hit)
+        assert any(w.data_ptr() == e[4].data_ptr() for e in bulk.entries)          # served from the bulk buffers (a cache hit)
         assert w.shape == rw.shape and t.shape == rt.shape and torch.equal(w, rw) and torch.equal(t, rt)
     with torch.no_grad():
         convs[1].weight.mul_(2.0)                                                # a new version: the stale entry must not be served
     assert torch.equal(autoencoder._w_op(convs[1], dtype), (ref[1][0].float() * 2).to(dtype))
+    if dtype == torch.bfloat16:
+        # ... and the fragment-order weight streams of the direct kernels (conv_direct.hip / conv_point.hip), written by the same
+        # launch: identical to what the stand-alone pack kernels make of the refreshed operands, and served from the cache
+        from world_modelz_amd import ops
+        convs = [torch.nn.Conv2d(64, 128, 3, 1, 1), torch.nn.Conv2d(128, 64, 1), torch.nn.Conv2d(64, 64, 2, 2), torch.nn.Conv2d(3, 64, 3, 1, 1),
+                 torch.nn.Conv2d(128, 128, 3, 1, 1), torch.nn.Conv2d(128, 3, 3, 1, 1)]
+        convs = [c.cuda() for c in convs]
+        _cast.clear()
+        bulk = _cast.ConvOperands(convs, dtype)
+        bulk.refresh()
+        packs = [e for e in bulk.entries if e[3] != 0]
+        assert len(packs) >= 9
+        for w, tag, mode, kind, dst, op in packs:
+            rows, K = op.shape
+            if kind == 1:
+                got = ops._direct_pack(op, K // 9, rows)
+                assert got.data_ptr() == dst.data_ptr()
+                _cast.clear()
+                assert torch.equal(ops._direct_pack(op, K // 9, rows), dst)
+            else:
+                got = ops._point_pack(op, K, rows)
+                assert got.data_ptr() == dst.data_ptr()
+                _cast.clear()
+                assert torch.equal(ops._point_pack(op, K, rows), dst)
+            bulk.refresh()
 
 
 def test_graphed_frame_encoder_matches_eager_calls():

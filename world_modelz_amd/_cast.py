@@ -136,18 +136,29 @@ class BulkOperands:
 
 class ConvOperands:
     """The conv encoder / decoder's GEMM operands (autoencoder.py: tags 'conv' and 'convT'), rebuilt together by ONE launch of
-    wmz_conv_operands_refresh after every optimizer step; refresh() stamps the cache entries valid for the current weights, so
-    the forward / backward's operand() calls hit (built with tensor ops: permute, pad, flip, cast -- ~6 launches per layer)."""
+    wmz_conv_operands_refresh_packed after every optimizer step; refresh() stamps the cache entries valid for the current weights,
+    so the forward / backward's operand() calls hit (built with tensor ops: permute, pad, flip, cast -- ~6 launches per layer).
+    bf16: the same launch also writes the fragment-order weight streams of the direct kernels (csrc/conv_direct.hip,
+    csrc/conv_point.hip: ops._direct_pack / ops._point_pack, cached per operand tensor) -- 34 pack launches per step otherwise."""
 
     def __init__(self, convs, dtype):
         self.dtype = dtype
-        self.entries = []          # (weight, tag, mode, dst)
+        self.entries = []          # (weight, tag, mode, pack kind, dst, operand dst the pack belongs to | None)
         for conv in convs:
             w = conv.weight
             co, ci, kh, kw = w.shape
             ci8, co8 = (ci + 7) // 8 * 8, (co + 7) // 8 * 8
-            self.entries.append((w, 'conv', 0, torch.empty((co, kh * kw * ci8), dtype=dtype, device=w.device)))
-            self.entries.append((w, 'convT', 1, torch.empty((ci8, kh * kw * co8), dtype=dtype, device=w.device)))
+            for tag, mode, rows, kin in (('conv', 0, co8, ci8), ('convT', 1, ci8, co8)):
+                op = torch.empty((rows, kh * kw * kin), dtype=dtype, device=w.device)
+                self.entries.append((w, tag, mode, 0, op, None))
+                if dtype != torch.bfloat16 or rows > 128 or rows % 8 != 0:
+                    continue
+                ncb = 2 if rows <= 64 else 4
+                if kh == 3 and kw == 3 and kin in (64, 128):
+                    self.entries.append((w, 'convq', mode, 1, torch.empty(9 * kin * ncb * 32, dtype=dtype, device=w.device), op))
+                elif kh * kw * kin <= 256:
+                    n = (kh * kw * kin + 63) // 64 * 64 * ncb * 32
+                    self.entries.append((w, 'convp', mode, 2, torch.empty(n, dtype=dtype, device=w.device), op))
 
     def refresh(self):
         import ctypes
@@ -156,13 +167,17 @@ class ConvOperands:
             ent = self.entries[i0:i0 + 48]
             n = len(ent)
             vp, ci_ = ctypes.c_void_p * n, ctypes.c_int * n
-            ws, ds, cos, cis, kks, ms = vp(), vp(), ci_(), ci_(), ci_(), ci_()
-            for i, (w, tag, mode, dst) in enumerate(ent):
+            ws, ds, cos, cis, kks, ms, pk = vp(), vp(), ci_(), ci_(), ci_(), ci_(), ci_()
+            for i, (w, tag, mode, pack, dst, _op) in enumerate(ent):
                 wd = w.detach()
                 assert wd.dtype == torch.float32 and wd.is_contiguous()
                 ws[i], ds[i] = wd.data_ptr(), dst.data_ptr()
-                cos[i], cis[i], kks[i], ms[i] = w.shape[0], w.shape[1], w.shape[2] * w.shape[3], mode
-            L.call('wmz_conv_operands_refresh', ws, ds, cos, cis, kks, ms, n, L.dtype_code(self.dtype), L.stream())
-        for w, tag, mode, dst in self.entries:
-            ver = (_epoch, (w._version, w.data_ptr()))
-            _cache[_key((w,), self.dtype, tag)] = (ver, dst, (weakref.ref(w),))
+                cos[i], cis[i], kks[i], ms[i], pk[i] = w.shape[0], w.shape[1], w.shape[2] * w.shape[3], mode, pack
+            L.call('wmz_conv_operands_refresh_packed', ws, ds, cos, cis, kks, ms, pk, n, L.dtype_code(self.dtype), L.stream())
+        for w, tag, mode, pack, dst, op in self.entries:
+            if pack == 0:
+                ver = (_epoch, (w._version, w.data_ptr()))
+                _cache[_key((w,), self.dtype, tag)] = (ver, dst, (weakref.ref(w),))
+            else:               # keyed by the operand tensor it re-orders (ops._direct_pack / _point_pack -> cached((op,), tag, ..))
+                ver = (_epoch, (op._version, op.data_ptr()))
+                _cache[_key((op,), None, tag)] = (ver, dst, (weakref.ref(op),))

@@ -57,6 +57,7 @@ SIGNATURES = {
     'wmz_layer_fused_fwd': [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p],
     'wmz_operands_refresh': [c_void_p] * 7 + [c_int, c_void_p],
     'wmz_conv_operands_refresh': [c_void_p] * 6 + [c_int, c_int, c_void_p],
+    'wmz_conv_operands_refresh_packed': [c_void_p] * 7 + [c_int, c_int, c_void_p],
     'wmz_layer_fused_pack': [c_void_p] * 16 + [c_int] * 3 + [c_void_p],
     'wmz_layer_fused_fwd_train': [c_void_p] * 12 + [c_int] * 7 + [c_float, c_void_p],
     'wmz_fused_pack_table': [c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

@@ -39,15 +39,19 @@ def _pad8(c):
     return (c + 7) // 8 * 8
 
 
+def _w_build(w):
+    co, ci, kh, kw = w.shape
+    w = w.permute(0, 2, 3, 1)
+    if _pad8(ci) != ci or _pad8(co) != co:
+        w = F.pad(w, (0, _pad8(ci) - ci, 0, 0, 0, 0, 0, _pad8(co) - co))
+    return w.reshape(_pad8(co), -1)
+
+
 def _w_op(conv, dtype):
-    """nn.Conv2d weight [Cout,Cin,KH,KW] -> GEMM operand [Cout, KH*KW*Cin8] (tap-major, channel fastest, zero-padded)."""
-    def build(w):
-        co, ci, kh, kw = w.shape
-        w = w.permute(0, 2, 3, 1)
-        if _pad8(ci) != ci:
-            w = F.pad(w, (0, _pad8(ci) - ci))
-        return w.reshape(co, -1)
-    return _cast.operand((conv.weight,), dtype, 'conv', build)
+    """nn.Conv2d weight [Cout,Cin,KH,KW] -> GEMM operand [Cout8, KH*KW*Cin8] (tap-major, channel fastest; input AND output channels
+    zero-padded to multiples of 8: the decoder's 3-channel last layer runs on the direct kernels like every other one, its five
+    padding channels are zeros that the caller slices off)."""
+    return _cast.operand((conv.weight,), dtype, 'conv', _w_build)
 
 
 def _to_nhwc(x, dtype):
@@ -86,33 +90,39 @@ def _wT_op(weight, dtype):
 
 
 class _Conv2dFn(torch.autograd.Function):
+    """y = conv(x) [+ bias] [+ residual] on the HIP kernels; want_stats: also the per-channel (sum, sum of squares) of the stored
+    y -- the batch statistics of the BatchNorm behind the conv -- from the conv's own epilogue instead of a pass over y
+    (non-differentiable outputs).  Returns (y, s, q); y has the output channels padded to a multiple of 8."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad):
+    def forward(ctx, x, weight, bias, stride, pad, residual, want_stats):
         k = weight.shape[2]
         dt = x.dtype
-
-        def build(w):
-            co, ci, kh, kw = w.shape
-            w = w.permute(0, 2, 3, 1)
-            if _pad8(ci) != ci:
-                w = F.pad(w, (0, _pad8(ci) - ci))
-            return w.reshape(co, -1)
-        y = ops.conv2d_nhwc(x, _cast.operand((weight,), dt, 'conv', build), k, k, stride, pad,
-                            bias=None if bias is None else bias.detach())
+        bop = None
+        if bias is not None:
+            bop = bias.detach()
+            if _pad8(bop.numel()) != bop.numel():
+                bop = F.pad(bop, (0, _pad8(bop.numel()) - bop.numel()))
+        out = ops.conv2d_nhwc(x, _cast.operand((weight,), dt, 'conv', _w_build), k, k, stride, pad, bias=bop,
+                              residual=None if residual is None else residual.detach(), stats=want_stats)
         ctx.save_for_backward(x, weight)
         ctx.bias = bias
-        ctx.geom = (k, stride, pad, bias is not None)
-        return y
+        ctx.geom = (k, stride, pad, bias is not None, residual is not None)
+        if want_stats:
+            y, s, q = out
+            ctx.mark_non_differentiable(s, q)
+            return y, s, q
+        return out, None, None
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _ds, _dq):
         x, weight = ctx.saved_tensors
-        k, stride, pad, has_bias = ctx.geom
+        k, stride, pad, has_bias, has_res = ctx.geom
         co, ci = weight.shape[:2]
         cop, cip = _pad8(co), x.shape[-1]
         dy = dy.contiguous()
-        if cop != co:
-            dy = F.pad(dy, (0, cop - co))
+        if dy.shape[-1] != cop:
+            dy = F.pad(dy, (0, cop - dy.shape[-1]))
         gw = getattr(weight, '_wmz_grad', None)
         gb = getattr(ctx.bias, '_wmz_grad', None) if has_bias else None
         if gw is not None and (not has_bias or gb is not None):
@@ -141,15 +151,16 @@ class _Conv2dFn(torch.autograd.Function):
                                  device=dy.device)
                 dz[:, 0:(Ho - 1) * stride + 1:stride, 0:(Wo - 1) * stride + 1:stride] = dy
             dx = ops.conv2d_nhwc(dz, _wT_op(weight, dy.dtype), k, k, 1, k - 1 - pad)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, (dy if has_res else None), None
 
 
 class _BnActFn(torch.autograd.Function):
     """y = act(BatchNorm_train(x) [+ r]); updates the module's running statistics like nn.BatchNorm2d."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, r, bn, leaky):
-        s, q = ops.channel_stats_nhwc(x)
+    def forward(ctx, x, gamma, beta, r, bn, leaky, s=None, q=None):
+        if s is None:
+            s, q = ops.channel_stats_nhwc(x)
         scale, shift, mean, rstd = ops.bn_finalize(bn, s, q, _count(x), want_stats=True)
         y = ops.affine_act_nhwc(x, scale, shift, b=r, leaky=leaky, slope=LEAKY)
         ctx.save_for_backward(x, y, mean, rstd, gamma)
@@ -170,9 +181,9 @@ class _BnActFn(torch.autograd.Function):
                 ready = getattr(prm, '_wmz_ready', None)
                 if ready is not None:
                     ready()
-            return dx, None, None, (g if ctx.has_r else None), None, None
+            return dx, None, None, (g if ctx.has_r else None), None, None, None, None
         dx, dgamma, dbeta, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY)
-        return dx, dgamma, dbeta, (g if ctx.has_r else None), None, None
+        return dx, dgamma, dbeta, (g if ctx.has_r else None), None, None, None, None
 
 
 class _Bilinear2xFn(torch.autograd.Function):
@@ -185,8 +196,17 @@ class _Bilinear2xFn(torch.autograd.Function):
         return ops.bilinear2x_nhwc_bwd(dy)
 
 
-def _conv_g(x, conv):
-    return _Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+def _conv_g(x, conv, residual=None):
+    y = _Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], residual, False)[0]
+    return y if y.shape[-1] == conv.out_channels else y[..., :conv.out_channels]      # (output channels padded to 8 by the operand)
+
+
+def _conv_bnact_g(x, conv, bn, r=None, leaky=True):
+    """conv -> training-mode BatchNorm (-> + r) -> LeakyReLU under autograd, the batch statistics from the conv's epilogue."""
+    if not bn.training or _pad8(conv.out_channels) != conv.out_channels:
+        return _bnact_g(_conv_g(x, conv), bn, r=r, leaky=leaky)
+    y, s, q = _Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], None, True)
+    return _BnActFn.apply(y, bn.weight, bn.bias, r, bn, leaky, s, q)
 
 
 def _bnact_g(x, bn, r=None, leaky=True):
@@ -216,6 +236,8 @@ def _bnact_eval_g(x, bn, r, leaky):
 def _conv(x, conv, dtype, **kw):
     k = conv.kernel_size[0]
     bias = conv.bias.detach() if conv.bias is not None else None
+    if bias is not None and _pad8(bias.numel()) != bias.numel():
+        bias = F.pad(bias, (0, _pad8(bias.numel()) - bias.numel()))
     return ops.conv2d_nhwc(x, _w_op(conv, dtype), k, k, conv.stride[0], conv.padding[0], bias=bias, **kw)
 
 
@@ -237,13 +259,12 @@ class Residual(nn.Module):
     def forward_nhwc(self, x, dtype):
         c1, bn1, c2, bn2 = self._block[0], self._block[1], self._block[3], self._block[4]
         if _grad_path(x, self):
-            h = _bnact_g(_conv_g(x, c1), bn1)
-            h = _conv_g(h, c2)
+            h = _conv_bnact_g(x, c1, bn1)
             if self.downsample is not None:
-                r = _bnact_g(_conv_g(x, self.downsample[0]), self.downsample[1], leaky=False)
+                r = _conv_bnact_g(x, self.downsample[0], self.downsample[1], leaky=False)
             else:
                 r = x
-            return _bnact_g(h, bn2, r=r)
+            return _conv_bnact_g(h, c2, bn2, r=r)
         if bn1.training:
             h, s, q = _conv(x, c1, dtype, stats=True)
             sc, sh = ops.bn_finalize(bn1, s, q, _count(h))
@@ -339,11 +360,10 @@ class UpscaleResidual(nn.Module):
             if self.upsample:
                 h = _Bilinear2xFn.apply(h)
                 x = _Bilinear2xFn.apply(x)
-            h = _bnact_g(_conv_g(h, self.conv1), self.bn2)
-            h = _conv_g(h, self.conv2)
+            h = _conv_bnact_g(h, self.conv1, self.bn2)
             if self.learn_conv_residual:
                 x = _conv_g(x, self.conv_residual)
-            return h + x
+            return _conv_g(h, self.conv2, residual=x)              # (the skip add rides in conv2's epilogue)
         if self.bn1.training:
             s, q = ops.channel_stats_nhwc(x)
             sc, sh = ops.bn_finalize(self.bn1, s, q, _count(x))
@@ -389,7 +409,8 @@ class SimpleResidualDecoder(nn.Module):
             h = _conv_g(h, mods[0]) if grad else _conv(h, mods[0], dt)
             for m in mods[1:-1]:
                 h = m.forward_nhwc(h, dt)
-            return _to_nchw_view(_conv_g(h, mods[-1]) if grad else _conv(h, mods[-1], dt))
+            y = _conv_g(h, mods[-1]) if grad else _conv(h, mods[-1], dt)
+            return _to_nchw_view(y)[:, :mods[-1].out_channels]      # (the operand's output channels are padded to 8)
 
     def forward(self, x):
         return self.forward_nhwc(_to_nhwc(x, get_compute_dtype())).to(x.dtype)
