@@ -591,16 +591,16 @@ def test_frozen_encoder_graph_survives_the_denoiser_optimizer_steps():
         assert fwd.recaptures == 1                      # the trained model's weights did move
 
 
-@pytest.mark.parametrize('geom', [(2, 16, 32, 64, True), (1, 8, 16, 128, True), (3, 24, 48, 128, False), (5, 16, 16, 64, False),
-                                  (70, 16, 32, 128, True)])
+@pytest.mark.parametrize('geom', [(2, 16, 32, 64, True, 128), (1, 8, 16, 128, True, 128), (3, 24, 48, 128, False, 128),
+                                  (5, 16, 16, 64, False, 128), (70, 16, 32, 128, True, 128), (3, 16, 32, 128, False, 8),
+                                  (2, 8, 16, 64, True, 24), (40, 16, 16, 128, True, 8)])
 def test_direct_3x3_weight_gradient_vs_torch(wmz, geom):
-    """csrc/conv_wgrad.hip (3x3 / stride 1 / pad 1, Cout = 128, Cin 64 or 128, bf16: the pixel axis tiled, all nine taps from one
+    """csrc/conv_wgrad.hip (3x3 / stride 1 / pad 1, Cout = 128 or <= 32, Cin 64 or 128, bf16: the pixel axis tiled, all nine taps from one
     staged patch, persistent workgroups + the deterministic two-stage reduction) against torch.autograd on the same bf16 operands:
     weight and bias gradients, plain [N, K] result and nn.Conv2d's layout accumulated in place; more tiles than workgroups, fewer
     tiles than workgroups, image borders."""
     from world_modelz_amd import ops
-    B, H, W, Ci, bias = geom
-    Co = 128
+    B, H, W, Ci, bias, Co = geom
     torch.manual_seed(21)
     x = torch.randn(B, H, W, Ci, device='cuda').bfloat16()
     dy = (torch.randn(B, H, W, Co, device='cuda') * 0.5).bfloat16()

@@ -108,6 +108,7 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.bias = bias
         ctx.geom = (k, stride, pad, bias is not None, residual is not None)
+        ctx.set_materialize_grads(False)          # (the statistics get no gradient: without this autograd zero-fills two tensors per call)
         if want_stats:
             y, s, q = out
             ctx.mark_non_differentiable(s, q)
@@ -118,6 +119,8 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _ds, _dq):
         x, weight = ctx.saved_tensors
         k, stride, pad, has_bias, has_res = ctx.geom
+        if dy is None:
+            return (None,) * 7
         co, ci = weight.shape[:2]
         cop, cip = _pad8(co), x.shape[-1]
         dy = dy.contiguous()

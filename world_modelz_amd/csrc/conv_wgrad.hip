@@ -14,6 +14,9 @@
 //     reads of the pixel-major image) is read once and multiplied against the 18 shifted x fragments -- the taps are address
 //     offsets into the same patch (19 fragment reads per 18 MFMAs; all offsets instruction immediates, the code is unrolled);
 //   * Cin = 128: two groups of workgroups, one per half of the input channels;
+//   * Cout <= 32 (the decoder's 3-channel last layer, autoencoder.py:134-152 -- 524 us on wgrad2_kernel, whose 128-wide tile holds 8
+//     useful columns): the NCOB = 1 form -- two waves per workgroup, a wave owns one block of 32 input channels x 9 taps against the
+//     one (zero-padded) block of output channels;
 //   * each workgroup stores its partial result once, in the [block][split][256] layout linear_bwd.hip's wgrad_reduce_kernel sums
 //     (deterministic two-stage reduction, nn.Conv2d gradient layout and bias gradient included).
 #include "wmz_common.h"
@@ -28,17 +31,23 @@ __device__ __attribute__((aligned(16))) unsigned cw_zero_chunk[4] = {0u, 0u, 0u,
 
 struct CwParams {
   const bf16_t* x; const bf16_t* dy; float* ws;
-  int H, W, Cin, nsplit, ncig, tiles_x, tiles_y, ntiles;
+  int H, W, Cin, Cout, nsplit, ncig, tiles_x, tiles_y, ntiles;
 };
 
 constexpr int CW_PW = 18, CW_NPX = 180;           // haloed patch of an 8 x 16 tile
 constexpr int CW_XIMG = 23 * 1024;                // 180 pixels x 128 bytes (64 channels) = 23040 -> 23 DMA pieces
-constexpr int CW_DIMG = 32 * 1024;                // 128 pixels x 256 bytes (128 channels)
-constexpr int CW_BUF = CW_XIMG + CW_DIMG;
-constexpr int CW_NITEM = 8 * 19;                  // fragment sequence of a tile: per tile row one dy fragment + 18 x fragments
 constexpr int CW_WIN = 4;                         // fragments in flight
 
-__global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
+// NCOB: blocks of 32 output channels (4: Cout = 128, four waves, one block each x two blocks of input channels; 1: Cout <= 32, two
+// waves, one block of input channels each)
+template <int NCOB>
+__global__ __launch_bounds__(NCOB == 4 ? 256 : 128, NCOB == 4 ? 1 : 2) void convw_kernel(CwParams P) {
+  constexpr int NW = NCOB == 4 ? 4 : 2;                             // waves
+  constexpr int NB = NCOB == 4 ? 18 : 9;                            // accumulator blocks of a wave: taps x its input-channel blocks
+  constexpr int DROW = NCOB == 4 ? 256 : 64;                        // bytes per pixel of the dy image (128 | 32 channels)
+  constexpr int CW_DIMG = 128 * DROW;
+  constexpr int CW_BUF = CW_XIMG + CW_DIMG;
+  constexpr int CW_NITEM = 8 * (NB + 1);                            // fragment sequence of a tile: per tile row one dy fragment + NB x fragments
   __shared__ __attribute__((aligned(1024))) char lds[2 * CW_BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,7 +61,7 @@ __global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
     char* const xi = lds + buf * CW_BUF;
     char* const di = xi + CW_XIMG;
     const bf16_t* const xb = P.x + (long)img * P.H * P.W * P.Cin + cig * 64;
-    for (int pc = wave; pc < CW_XIMG / 1024; pc += 4) {
+    for (int pc = wave; pc < CW_XIMG / 1024; pc += NW) {
       const int q = pc * 64 + lane;
       const int r = q >> 3, s = q & 7;                              // patch pixel, 16-byte slot of its 128 bytes
       const int py = r / CW_PW, px = r - py * CW_PW;
@@ -62,13 +71,20 @@ __global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
       const void* src = ok ? (const void*)(xb + ((long)iy * P.W + ix) * P.Cin + c * 8) : (const void*)cw_zero_chunk;
       __builtin_amdgcn_global_load_lds((cw_gptr_t)src, (cw_lptr_t)(xi + pc * 1024), 16, 0, 0);
     }
-    const bf16_t* const db = P.dy + (long)img * P.H * P.W * 128;
-    for (int pc = wave; pc < CW_DIMG / 1024; pc += 4) {
+    const bf16_t* const db = P.dy + (long)img * P.H * P.W * P.Cout;
+    for (int pc = wave; pc < CW_DIMG / 1024; pc += NW) {
       const int q = pc * 64 + lane;
-      const int r = q >> 4, s = q & 15;                             // tile pixel (row-major 8 x 16), slot of its 256 bytes
-      const int c = s ^ ((r & 3) << 2);
-      const void* src = db + ((long)(oy0 + (r >> 4)) * P.W + ox0 + (r & 15)) * 128 + c * 8;
-      __builtin_amdgcn_global_load_lds((cw_gptr_t)src, (cw_lptr_t)(di + pc * 1024), 16, 0, 0);
+      if constexpr (NCOB == 4) {
+        const int r = q >> 4, s = q & 15;                           // tile pixel (row-major 8 x 16), slot of its 256 bytes
+        const int c = s ^ ((r & 3) << 2);
+        const void* src = db + ((long)(oy0 + (r >> 4)) * P.W + ox0 + (r & 15)) * 128 + c * 8;
+        __builtin_amdgcn_global_load_lds((cw_gptr_t)src, (cw_lptr_t)(di + pc * 1024), 16, 0, 0);
+      } else {
+        const int r = q >> 2, s = q & 3;                            // 64 bytes = 32 channels per pixel: the real ones, then zeros
+        const void* src = s * 8 < P.Cout ? (const void*)(db + ((long)(oy0 + (r >> 4)) * P.W + ox0 + (r & 15)) * P.Cout + s * 8)
+                                         : (const void*)cw_zero_chunk;
+        __builtin_amdgcn_global_load_lds((cw_gptr_t)src, (cw_lptr_t)(di + pc * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -77,7 +93,9 @@ __global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
   const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
   const int r0 = 8 * (gi >> 1) + q4;
   // dy image: rows of 256 bytes, 64-byte granule XOR (row & 3) -- the tile rows start at multiples of 16: (row & 3) = q4
-  const unsigned offA = (unsigned)(r0 * 256 + (((32 * wave + 16 * (gi & 1) + 4 * p4) * 2) ^ (q4 << 6)));
+  // (NCOB = 1: rows of 64 bytes = one granule: four consecutive rows already cover the 64 banks)
+  const unsigned offA = NCOB == 4 ? (unsigned)(r0 * 256 + (((32 * wave + 16 * (gi & 1) + 4 * p4) * 2) ^ (q4 << 6)))
+                                  : (unsigned)(r0 * 64 + (16 * (gi & 1) + 4 * p4) * 2);
   // x image: rows of 128 bytes, 64-byte granule XOR ((row >> 1) & 1): a fragment starting at patch pixel m0 reads rows m0 + r0 (+ 4);
   // with v = m0 & 3 the lane's offset is offB[v][channel block] + 128 (m0 - v) -- the second term an immediate
   unsigned offB[4][2];
@@ -89,9 +107,9 @@ __global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
       offB[v][c2] = (unsigned)(r * 128 + (((32 * c2 + 16 * (gi & 1) + 4 * p4) * 2) ^ (((r >> 1) & 1) << 6)));
     }
 
-  f32x16 acc[18];
+  f32x16 acc[NB];
 #pragma unroll
-  for (int b = 0; b < 18; ++b) acc[b] = (f32x16)(0.f);
+  for (int b = 0; b < NB; ++b) acc[b] = (f32x16)(0.f);
   float bias_acc = 0.f;
 
   int t = split;
@@ -113,20 +131,21 @@ __global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
     // block c2) for that row.  CW_WIN items (two reads each) in flight; every wait names the registers it releases.
     s16x4 ar[2][2], br[CW_WIN][2];
     auto issue = [&](auto nc) {
-      constexpr int n = decltype(nc)::value, ty = n / 19, j = n % 19;
+      constexpr int n = decltype(nc)::value, ty = n / (NB + 1), j = n % (NB + 1);
       if constexpr (j == 0) {
-        ar[ty & 1][0] = ds_read_tr16_asm<ty * 4096>(aA);
-        ar[ty & 1][1] = ds_read_tr16_asm<ty * 4096 + 1024>(aA);
+        ar[ty & 1][0] = ds_read_tr16_asm<ty * 16 * DROW>(aA);
+        ar[ty & 1][1] = ds_read_tr16_asm<ty * 16 * DROW + 4 * DROW>(aA);
       } else {
-        constexpr int b = j - 1, tap = b >> 1, c2 = b & 1, kh = tap / 3, kw = tap % 3;
-        constexpr int m0 = (ty + kh) * CW_PW + kw, v = m0 & 3, imm = (m0 - v) * 128, slot = (ty * 18 + b) % CW_WIN;
-        br[slot][0] = ds_read_tr16_asm<imm>(aB[v][c2]);
-        br[slot][1] = ds_read_tr16_asm<imm + 512>(aB[v][c2]);
+        constexpr int b = j - 1, tap = NCOB == 4 ? (b >> 1) : b, kh = tap / 3, kw = tap % 3;
+        constexpr int m0 = (ty + kh) * CW_PW + kw, v = m0 & 3, imm = (m0 - v) * 128, slot = (ty * NB + b) % CW_WIN;
+        const unsigned a = NCOB == 4 ? aB[v][b & 1] : aB[v][wave];
+        br[slot][0] = ds_read_tr16_asm<imm>(a);
+        br[slot][1] = ds_read_tr16_asm<imm + 512>(a);
       }
     };
     static_for<CW_WIN>([&](auto nc) { issue(nc); });
     static_for<CW_NITEM>([&](auto nc) {
-      constexpr int n = decltype(nc)::value, ty = n / 19, j = n % 19;
+      constexpr int n = decltype(nc)::value, ty = n / (NB + 1), j = n % (NB + 1);
       constexpr int younger = (CW_NITEM - 1 - n) < (CW_WIN - 1) ? (CW_NITEM - 1 - n) : (CW_WIN - 1);
       if constexpr (j == 0) {
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ar[ty & 1][0]), "+v"(ar[ty & 1][1]) : "n"(2 * younger) : "memory");
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias_acc += bf16_bits_to_f32((unsigned short)af[e]);
       } else {
-        constexpr int b = j - 1, slot = (ty * 18 + b) % CW_WIN;
+        constexpr int b = j - 1, slot = (ty * NB + b) % CW_WIN;
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(br[slot][0]), "+v"(br[slot][1]) : "n"(2 * younger) : "memory");
         const s16x8 af = __builtin_shufflevector(ar[ty & 1][0], ar[ty & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
         const s16x8 bf = __builtin_shufflevector(br[slot][0], br[slot][1], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -149,21 +168,22 @@ __global__ __launch_bounds__(256, 1) void convw_kernel(CwParams P) {
 
   // ---- this workgroup's partial result -> workspace[block of 256][split][256] (the layout wgrad_reduce_kernel sums)
   const int K = 9 * P.Cin;
-  const long NK = (long)128 * K;
+  const long NK = (long)P.Cout * K;
 #pragma unroll
-  for (int b = 0; b < 18; ++b) {
-    const int tap = b >> 1, c2 = b & 1;
+  for (int b = 0; b < NB; ++b) {
+    const int tap = NCOB == 4 ? (b >> 1) : b, c2 = NCOB == 4 ? (b & 1) : wave;
     const int k = tap * P.Cin + 64 * cig + 32 * c2 + l31;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int co = 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+      const int co = (NCOB == 4 ? 32 * wave : 0) + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
       const long q = (long)co * K + k;
-      P.ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[b][reg];
+      if (co < P.Cout) P.ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[b][reg];
     }
   }
-  if (cig == 0) {
+  if (cig == 0 && (NCOB == 4 || wave == 0)) {
     const float tb = wave_halves_sum(bias_acc);
-    if (hh == 0) P.ws[(((NK + 255) >> 8) * P.nsplit << 8) + (long)split * 128 + 32 * wave + l31] = tb;
+    const int co = (NCOB == 4 ? 32 * wave : 0) + l31;
+    if (hh == 0 && co < P.Cout) P.ws[(((NK + 255) >> 8) * P.nsplit << 8) + (long)split * P.Cout + co] = tb;
   }
 }
 
@@ -178,7 +198,8 @@ int convw_nsplit(int B, int H, int W, int Cin) {
 }  // namespace
 
 int wmz_convw_supported(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype) {
-  return dtype == WMZ_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cout == 128 && (Cin == 64 || Cin == 128) && B > 0 &&
+  return dtype == WMZ_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (Cout == 128 || (Cout <= 32 && (Cout & 7) == 0)) &&
+         (Cin == 64 || Cin == 128) && B > 0 &&
          H > 0 && W > 0 && (H & 7) == 0 && (W & 15) == 0 && (long)B * H * W * 128 < (1L << 31);
 }
 
@@ -194,10 +215,11 @@ int wmz_convw_launch(const void* x, const void* dy, float* dW, float* dbias, int
     WMZ_REQUIRE(conv_layout_co <= Cout && conv_layout_ci > 0 && conv_layout_ci <= Cin, "wmz_conv2d_nhwc_wgrad_ws: bad nn.Conv2d layout sizes");
   CwParams P;
   P.x = (const bf16_t*)x; P.dy = (const bf16_t*)dy; P.ws = workspace;
-  P.H = H; P.W = W; P.Cin = Cin; P.ncig = Cin / 64;
+  P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.ncig = Cin / 64;
   P.tiles_x = W / 16; P.tiles_y = H / 8; P.ntiles = B * P.tiles_x * P.tiles_y;
   P.nsplit = convw_nsplit(B, H, W, Cin);
-  hipLaunchKernelGGL(convw_kernel, dim3((unsigned)(P.nsplit * P.ncig)), dim3(256), 0, stream, P);
+  if (Cout == 128) hipLaunchKernelGGL(convw_kernel<4>, dim3((unsigned)(P.nsplit * P.ncig)), dim3(256), 0, stream, P);
+  else hipLaunchKernelGGL(convw_kernel<1>, dim3((unsigned)(P.nsplit * P.ncig)), dim3(128), 0, stream, P);
   WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_wgrad_ws");
   const long NK = (long)Cout * 9 * Cin;
   wmz_wgrad_reduce_launch(workspace, dW, dbias, NK, P.nsplit, Cout, overwrite, conv_layout_co > 0 ? 9 : 0, Cin, conv_layout_co, conv_layout_ci, stream);
