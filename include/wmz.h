@@ -441,6 +441,13 @@ int wmz_conv3x3_direct_pack(const void* w_op, void* wpack, int Cin, int Cout, vo
 int wmz_conv3x3_direct_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale,
                            const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int H, int W,
                            int Cin, int Cout, int leaky, float slope, void* stream);
+/* The same at stride 2 (pad 1; autoencoder.py:27-33, the first convolution of the down-sampling Residual): H, W the (even) INPUT
+ * plane, the output H / 2 x W / 2; Cout = 128, output planes of 8 k x 16 m pixels; same packed weight stream.  stride == 1 is
+ * wmz_conv3x3_direct_fwd. */
+int wmz_conv3x3_direct_supported_strided(int H, int W, int Cin, int Cout, int stride);
+int wmz_conv3x3_direct_fwd_strided(const void* x, const void* wpack, void* out, const float* bias, const float* scale,
+                                   const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int H, int W,
+                                   int Cin, int Cout, int stride, int leaky, float slope, void* stream);
 /* Small-K convolutions in bf16 (csrc/conv_point.hip; K = KH KW Cin <= 256: the 1x1 convolutions of Residual :18-42 and
  * UpscaleResidual :89-131, the 2x2 / stride 2 down-sampling convolution :29-33, the 3-channel conv_1 :60-86): the same result as
  * wmz_conv2d_nhwc_fwd_pre without a residual (same k order and epilogue arithmetic), as a persistent streaming kernel -- weights
@@ -485,6 +492,15 @@ long wmz_conv2d_nhwc_wgrad_workspace_floats(int B, int Hi, int Wi, int Cin, int 
 int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW, float* dbias, int B, int Hi, int Wi, int Cin, int Cout,
                              int KH, int KW, int stride, int pad, int overwrite, int conv_layout_co, int conv_layout_ci,
                              float* workspace, long workspace_floats, int dtype, void* stream);
+/* n <= 6 such weight gradients by ONE launch pair (HOST tables of n entries; dbias[i] may be NULL; workspace: the sum of the
+ * problems' wmz_conv2d_nhwc_wgrad_workspace_floats suffices): the small layers of a VQ-AE training step, whose launches sit on a
+ * side branch of the step's hipGraph.  wmz_conv2d_nhwc_wgrad_is_direct(...) != 0: the layer has a kernel of its own (3x3 / stride 1
+ * on the direct weight-gradient kernel) and is better launched alone through wmz_conv2d_nhwc_wgrad_ws. */
+int wmz_conv2d_nhwc_wgrad_batch(int n, const void* const* x, const void* const* dy, float* const* dW, float* const* dbias,
+                                const int* B, const int* Hi, const int* Wi, const int* Cin, const int* Cout, const int* KH,
+                                const int* KW, const int* stride, const int* pad, const int* overwrite, const int* conv_layout_co,
+                                const int* conv_layout_ci, float* workspace, long workspace_floats, int dtype, void* stream);
+int wmz_conv2d_nhwc_wgrad_is_direct(int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype);
 /* training-mode BatchNorm + LeakyReLU backward, pass 1: g = dy * act'(y) (optional g_out), sum_g[C] += g,
  * sum_gx[C] += g * (x - mean) * rstd;  pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)  (dgamma = sum_gx, dbeta = sum_g). */
 int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, void* g_out,

@@ -623,3 +623,35 @@ def test_direct_3x3_weight_gradient_vs_torch(wmz, geom):
     assert rel(gw, 2 * w.grad) < 2e-5
     if bias:
         assert rel(gb, 2 * b.grad) < 2e-5
+
+
+@pytest.mark.parametrize('geom', [(3, 32, 64, 64), (2, 16, 32, 128), (5, 64, 64, 64)])
+def test_direct_3x3_stride2_conv_vs_the_implicit_gemm_kernel_and_torch(wmz, geom):
+    """convr_kernel<.., STRIDE = 2> (3x3 / stride 2 / pad 1, Cout = 128: autoencoder.py:27-33; the four parity planes of the input
+    staged 32 channels at a time) against conv2d_kernel (other k order: fp32 summation order) and torch, statistics included."""
+    from world_modelz_amd import ops
+    B, H, W, Ci = geom
+    Co = 128
+    assert ops.L.lib().wmz_conv3x3_direct_supported_strided(H, W, Ci, Co, 2)
+    torch.manual_seed(31)
+    x = torch.randn(B, H, W, Ci, device='cuda').bfloat16()
+    w = (torch.randn(Co, 9 * Ci, device='cuda') * 0.05).bfloat16()
+    bias = torch.randn(Co, device='cuda')
+    for kw in (dict(stats=True), dict(bias=bias, leaky=True, stats=True), dict()):
+        ops.DIRECT_CONV = True
+        try:
+            out_d = ops.conv2d_nhwc(x, w, 3, 3, 2, 1, **kw)
+            ops.DIRECT_CONV = False
+            out_g = ops.conv2d_nhwc(x, w, 3, 3, 2, 1, **kw)
+        finally:
+            ops.DIRECT_CONV = True
+        y_d, y_g = (out_d[0], out_g[0]) if kw.get('stats') else (out_d, out_g)
+        assert y_d.shape == (B, H // 2, W // 2, Co)
+        assert float((y_d.float() - y_g.float()).norm() / y_g.float().norm()) < 2e-3
+        if kw.get('stats'):
+            assert torch.allclose(out_d[1].sum(0), y_d.float().sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
+            assert torch.allclose(out_d[2].sum(0), (y_d.float() ** 2).sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2), bias=bias,
+                                     stride=2, padding=1).permute(0, 2, 3, 1)
+    y = ops.conv2d_nhwc(x, w, 3, 3, 2, 1, bias=bias)
+    assert float((y.float() - ref).norm() / ref.norm()) < 4e-3

@@ -83,11 +83,15 @@ SIGNATURES = {
     'wmz_conv3x3_direct_pack_elems': [c_int, c_int],                       # returns long
     'wmz_conv3x3_direct_pack': [c_void_p, c_void_p, c_int, c_int, c_void_p],
     'wmz_conv3x3_direct_fwd': [c_void_p] * 9 + [c_int] * 6 + [c_float, c_void_p],
+    'wmz_conv3x3_direct_supported_strided': [c_int] * 5,
+    'wmz_conv3x3_direct_fwd_strided': [c_void_p] * 9 + [c_int] * 7 + [c_float, c_void_p],
     'wmz_conv_point_supported': [c_int] * 9,
     'wmz_conv_point_pack_elems': [c_int, c_int],                           # returns long
     'wmz_conv_point_pack': [c_void_p, c_void_p, c_int, c_int, c_void_p],
     'wmz_conv_point_fwd': [c_void_p] * 10 + [c_float] + [c_int] * 10 + [c_float, c_void_p],
     'wmz_nchw_to_nhwc8': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'wmz_conv2d_nhwc_wgrad_batch': [c_int] + [c_void_p] * 17 + [c_long, c_int, c_void_p],
+    'wmz_conv2d_nhwc_wgrad_is_direct': [c_int] * 10,
     'wmz_channel_stats_nhwc': [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_void_p],
     'wmz_bn_finalize': [c_void_p, c_void_p, c_double] + [c_void_p] * 4 + [c_double, c_double, c_int] + [c_void_p] * 4
                        + [c_int, c_void_p, c_void_p],

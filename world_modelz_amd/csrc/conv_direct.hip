@@ -33,6 +33,7 @@ struct DirectParams {
   const float* bias; const float* scale; const float* shift; const bf16_t* res;
   float* stat_sum; float* stat_sq;
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
+  int Ho, Wo;           // output plane (= H, W at stride 1)
   float slope; int leaky;
   int skew, dbg;        // development knobs (wmz_debug_conv_knobs)
   int ncb_pack;         // channel blocks of the packed weight stream (wmz_conv3x3_direct_pack)
@@ -367,22 +368,37 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(DirectParams P) {
 // memory (L2-resident, one contiguous KB per fragment) into a register ring two slabs deep -- no LDS ring, no barrier and no
 // shared wait inside the loop; the patch is the only LDS operand (one ds_read_b128 per MFMA, a window of four in flight across
 // slab boundaries).  Same k order per accumulator as convq_kernel / conv2d.hip: the same bits.
-template <int NCB, int TW>
+// STRIDE = 2 (3x3 / stride 2 / pad 1, Cout = 128: the first convolution of the down-sampling Residual, autoencoder.py:27-33): the
+// same machine on the four PARITY planes of the input -- x[2 i + p, 2 j + q] for (p, q) in {0, 1}^2: tap (kh, kw) reads plane
+// (kh != 1, kw != 1) at the output pixel's own (i, j) or one row / column before it, so inside a plane the lanes of a fragment
+// again walk consecutive pixels (the DMA de-interleaves on the source side).  An output tile of 8 x 16 pixels needs 4 x 9 x 17
+// plane pixels: staged 32 channels at a time (pixel pitch 80 bytes: the image stays under 48 KB), i.e. Cin / 32 passes of 9 taps x
+// 2 k-steps; the packed weight stream is the stride-1 one, its fragments visited in this order.
+template <int NCB, int TW, int STRIDE>
 struct CrShape {
-  static constexpr int TH = 256 / TW, PH = TH + 2, PW = TW + 2, NPX = PH * PW;
-  static constexpr int PATCH = (NPX * CQ_PITCH + 1023) / 1024 * 1024;
-  static constexpr int NPB = 2 * NCB;                              // 32-pixel blocks per wave
+  static constexpr int TILE_PX = STRIDE == 1 ? 256 : 128;
+  static constexpr int TH = TILE_PX / TW, PH = TH + 2, PW = TW + 2;
+  static constexpr int PLANE = (TH + 1) * (TW + 1);                // STRIDE 2: pixels of one parity plane of the patch
+  static constexpr int NPX = STRIDE == 1 ? PH * PW : 4 * PLANE;
+  static constexpr int PITCH = STRIDE == 1 ? CQ_PITCH : 80;        // bytes per patch pixel: 64 | 32 channels + one dead 16-byte slot
+  static constexpr int SPP = PITCH / 16;                           // 16-byte slots per patch pixel
+  static constexpr int KS = STRIDE == 1 ? 4 : 2;                   // k-steps per (pass, tap)
+  static constexpr int PATCH = (NPX * PITCH + 1023) / 1024 * 1024;
+  static constexpr int NPB = TILE_PX * NCB / 128;                  // 32-pixel blocks per wave
   static constexpr int BPR = 2;                                    // blocks per epilogue round (bf16 staging, double-buffered)
   static constexpr int OPITCH = 80, FPITCH = 144;                  // staging rows: 32 channels bf16 / fp32 + 16 bytes
   static constexpr int STAGE_A = 2 * BPR * 32 * OPITCH, STAGE_B = 64 * FPITCH;
   static constexpr int STAGE = STAGE_A > STAGE_B ? STAGE_A : STAGE_B;
   static constexpr int LDS = PATCH > 4 * STAGE ? PATCH : 4 * STAGE;
+  static_assert(STRIDE == 1 || (TW == 16 && NCB == 4), "the stride-2 form is built for Cout = 128 on 8 x 16 tiles");
+  static_assert(LDS <= 81920, "two workgroups per CU");
 };
 
-template <int NCB, int TW, int NPASS>
+// NPASS = Cin / 64
+template <int NCB, int TW, int NPASS, int STRIDE = 1>
 __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
-  using S = CrShape<NCB, TW>;
-  constexpr int NPB = S::NPB, NSEQ = 4 * NPB, WIN = 4;
+  using S = CrShape<NCB, TW, STRIDE>;
+  constexpr int NPB = S::NPB, KS = S::KS, NSEQ = KS * NPB, WIN = 4;
   __shared__ __attribute__((aligned(1024))) char lds[S::LDS];
   char* patch = lds;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -394,16 +410,23 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   const int ty = lid % P.tiles_y;
   const int b = lid / P.tiles_y;
   const int oy0 = ty * S::TH, ox0 = tx * TW;
-  constexpr int nslab = NPASS * 9;
+  constexpr int nslab = NPASS * 9 * (STRIDE == 1 ? 1 : 2);         // (channel pass, tap) slabs: passes of 64 | 32 channels
 
   auto issue_patch = [&](int pass) {
-    const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + pass * 64;
+    const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + pass * (STRIDE == 1 ? 64 : 32);
     for (int pc = wave; pc < S::PATCH / 1024; pc += 4) {
       const int q = pc * 64 + lane;
-      const int pix = q / CQ_SPP, c = q - pix * CQ_SPP;
-      const int py = pix / S::PW, px = pix - py * S::PW;
-      const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-      const bool ok = c < 8 && pix < S::NPX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      const int pix = q / S::SPP, c = q - pix * S::SPP;
+      int iy, ix;
+      if constexpr (STRIDE == 1) {
+        const int py = pix / S::PW, px = pix - py * S::PW;
+        iy = oy0 - 1 + py; ix = ox0 - 1 + px;
+      } else {
+        const int plane = pix / S::PLANE, rr = pix - plane * S::PLANE;
+        const int pi = rr / (TW + 1), pj = rr - pi * (TW + 1);
+        iy = 2 * (oy0 - 1 + pi) + (plane >> 1); ix = 2 * (ox0 - 1 + pj) + (plane & 1);
+      }
+      const bool ok = c < S::SPP - 1 && pix < S::NPX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
       const void* src = ok ? (const void*)(xb + ((long)iy * P.W + ix) * P.Cin + c * 8) : (const void*)cq_zero_chunk;
       __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
     }
@@ -412,12 +435,19 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
     for (int i = 0; i < P.skew; ++i) __builtin_amdgcn_s_sleep(127);
   issue_patch(0);
 
-  // this wave's weight fragments: (slab s, k-step kk) at fragment row (4 s + kk) of the packed stream, block cb of ncb_pack
+  // this wave's weight fragments: fragment row f of the packed stream ([64-channel pass][tap][k-step 0..3]), block cb of ncb_pack
   const s16x8* const wp = reinterpret_cast<const s16x8*>(P.wpack) + cb * 64 + lane;
-  const long wstep = (long)P.ncb_pack * 64;                        // fragments are ncb_pack KB apart per (s, kk)
+  const long wstep = (long)P.ncb_pack * 64;                        // fragment rows are ncb_pack KB apart
+  // fragment row of (slab s, k-step kk): stride 1: 4 s + kk; stride 2: slab s = (32-channel pass p, tap t) -> the half (p & 1) of
+  // the k-steps of (64-channel pass p >> 1, tap t)
+  auto frag_row = [](int s, int kk) {
+    if (STRIDE == 1) return 4 * s + kk;
+    const int p = s / 9, t = s - 9 * p;
+    return ((p >> 1) * 9 + t) * 4 + (p & 1) * 2 + kk;
+  };
   // Loads hipcc does not track (inline asm): its own wait in front of a fragment's first use comes out as vmcnt(0) -- a drain of
-  // the whole ring every other slab -- where the issue order says exactly SEVEN younger loads may still be in flight: fragment
-  // (s, kk) is requested behind k-step kk of slab s - 2, followed by 3 - kk more of that slab, 4 of slab s - 1 and kk of slab s.
+  // the whole ring every other slab -- where the issue order says exactly 2 KS - 1 younger loads may still be in flight: fragment
+  // (s, kk) is requested behind k-step kk of slab s - 2, followed by KS - 1 - kk more of that slab, KS of slab s - 1 and kk of slab s.
   // Nothing may touch a destination register between its load and the counted wait (straight-line code, no copies: checked on
   // the ISA by tools/check_untracked_conv.py).
   auto wload = [&](long frag) {
@@ -425,11 +455,11 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(wp + frag * wstep) : "memory");
     return v;
   };
-  s16x8 bq[2][4];
+  s16x8 bq[2][KS];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) bq[0][kk] = wload(kk);
+  for (int kk = 0; kk < KS; ++kk) bq[0][kk] = wload(frag_row(0, kk));
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) bq[1][kk] = wload(4 + kk);
+  for (int kk = 0; kk < KS; ++kk) bq[1][kk] = wload(frag_row(1, kk));
 
   float cbias, cscale, cshift;
   {
@@ -445,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   for (int i = 0; i < NPB; ++i) {
     const int t = 32 * (i0 + i) + l31;
     const int py = t / TW, px = t - py * TW;
-    abase[i] = lds_addr(patch) + (unsigned)((py * S::PW + px) * CQ_PITCH + hh * 16);
+    abase[i] = lds_addr(patch) + (unsigned)((py * (STRIDE == 1 ? S::PW : TW + 1) + px) * S::PITCH + hh * 16);
   }
   f32x16 acc[NPB];
 #pragma unroll
@@ -460,7 +490,10 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   s16x8 fr[WIN];
   auto read_n = [&](auto tc, auto nc) {
     constexpr int t = decltype(tc)::value % 9, n = decltype(nc)::value, kk = n / NPB, i = n % NPB;
-    constexpr int off = ((t / 3) * S::PW + (t % 3)) * CQ_PITCH + kk * 32;
+    constexpr int kh = t / 3, kw = t % 3;
+    constexpr int tpix = STRIDE == 1 ? kh * S::PW + kw
+                                     : (((kh != 1) * 2 + (kw != 1)) * S::PLANE + (kh != 0) * (TW + 1) + (kw != 0));
+    constexpr int off = tpix * S::PITCH + kk * 32;
     fr[n % WIN] = ds_read_b128_asm<off>(abase[i]);
   };
   using I0 = std::integral_constant<int, 0>;
@@ -468,17 +501,17 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
 
   static_for<nslab>([&](auto sc) {
     constexpr int s = decltype(sc)::value, t = s % 9;
-    constexpr long fnext = 4 * (s + 2 < nslab ? s + 2 : nslab - 1);            // (the tail re-loads the last slab: uniform counts)
+    constexpr int snext = s + 2 < nslab ? s + 2 : nslab - 1;       // (the tail re-loads the last slab: uniform counts)
     static_for<NSEQ>([&](auto nc) {
       constexpr int n = decltype(nc)::value, kk = n / NPB, i = n % NPB;
-      if constexpr (i == 0) asm volatile("s_waitcnt vmcnt(7)" : "+v"(bq[s & 1][kk]) :: "memory");
+      if constexpr (i == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bq[s & 1][kk]) : "n"(2 * KS - 1) : "memory");
       lgkm_wait_for<WIN - 1>(fr[n % WIN]);
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n % WIN], bq[s & 1][kk], acc[i], 0, 0, 0);
       if constexpr (n + WIN < NSEQ) read_n(sc, std::integral_constant<int, n + WIN>{});
       else read_n(std::integral_constant<int, s + 1>{}, std::integral_constant<int, n + WIN - NSEQ>{});    // next tap
-      if constexpr (i == NPB - 1) bq[s & 1][kk] = wload(fnext + kk);            // k-step kk done: its register takes slab s + 2
+      if constexpr (i == NPB - 1) bq[s & 1][kk] = wload(frag_row(snext, kk));   // k-step kk done: its register takes slab s + 2
     });
-    if constexpr (t == 8 && s + 1 < nslab) {                       // Cin = 128: the patch of the next 64 channels
+    if constexpr (t == 8 && s + 1 < nslab) {                       // the patch of the next 64 (32) channels
       // (the window's run-ahead reads -- of the OLD patch: dead values -- retire here; their registers stay named until then:
       //  hipcc hands the register of a dead asm result to the next instruction while the LDS return is still in flight)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
@@ -490,9 +523,13 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
     }
   });
   // the window's run-ahead reads and the ring's (redundant) tail loads retire here: their registers stay named until then
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-               : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]),
-                 "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
+  if constexpr (KS == 4)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]),
+                   "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
 
   // ------------------------------------------------------------------------------------------------ epilogue
   if (P.dbg & 1) { if (acc[0][0] == 12345.f) P.out[0] = __float2bfloat16(acc[1][3]); return; }
@@ -506,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   // pixel address of the 16-pixel group that starts at tile pixel t0 (t0 % 16 == 0: one row of pixels)
   auto group_ptr = [&](const bf16_t* base, int t0) {
     const int py = t0 / TW, px = t0 - py * TW + lpx;
-    return base + (((long)b * P.H + oy0 + py) * P.W + ox0 + px) * P.Cout + ccol;
+    return base + (((long)b * P.Ho + oy0 + py) * P.Wo + ox0 + px) * P.Cout + ccol;
   };
   const bool nt = (P.dbg & 128) != 0;
   auto st_out = [&](const bf16_t* p, const i32x4& v) {
@@ -706,6 +743,43 @@ extern "C" int wmz_conv3x3_direct_pack(const void* w_op, void* wpack, int Cin, i
   return WMZ_OK;
 }
 
+// stride 2 (pad 1): H, W the INPUT plane (even); the output is H / 2 x W / 2.  Cout = 128, output planes of 8 k x 16 m pixels.
+extern "C" int wmz_conv3x3_direct_supported_strided(int H, int W, int Cin, int Cout, int stride) {
+  if (stride == 1) return wmz_conv3x3_direct_supported(H, W, Cin, Cout);
+  if (stride != 2 || (Cin != 64 && Cin != 128) || Cout != 128 || (H & 1) || (W & 1)) return 0;
+  return ((H / 2) & 7) == 0 && ((W / 2) & 15) == 0;
+}
+
+extern "C" int wmz_conv3x3_direct_fwd_strided(const void* x, const void* wpack, void* out, const float* bias, const float* scale,
+                                              const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B,
+                                              int H, int W, int Cin, int Cout, int stride, int leaky, float slope, void* stream) {
+  if (stride == 1)
+    return wmz_conv3x3_direct_fwd(x, wpack, out, bias, scale, shift, residual, stat_sum, stat_sq, B, H, W, Cin, Cout, leaky, slope, stream);
+  WMZ_REQUIRE(x && wpack && out, "wmz_conv3x3_direct_fwd_strided: null tensor");
+  WMZ_REQUIRE(B > 0 && wmz_conv3x3_direct_supported_strided(H, W, Cin, Cout, stride),
+              "wmz_conv3x3_direct_fwd_strided: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d stride=%d", B, H, W, Cin, Cout, stride);
+  WMZ_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "wmz_conv3x3_direct_fwd_strided: stat_sum and stat_sq go together");
+  WMZ_REQUIRE((scale == nullptr) == (shift == nullptr), "wmz_conv3x3_direct_fwd_strided: scale and shift go together");
+  WMZ_REQUIRE(slope >= 0.f && slope <= 1.f, "wmz_conv3x3_direct_fwd_strided: LeakyReLU slope in [0, 1] expected");
+  DirectParams P;
+  P.x = (const bf16_t*)x; P.wpack = (const bf16_t*)wpack; P.out = (bf16_t*)out;
+  P.bias = bias; P.scale = scale; P.shift = shift; P.res = (const bf16_t*)residual;
+  P.stat_sum = stat_sum; P.stat_sq = stat_sq;
+  P.B = B; P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.Ho = H / 2; P.Wo = W / 2;
+  P.slope = slope; P.leaky = leaky;
+  P.skew = g_conv_skew; P.dbg = g_conv_dbg & 1;
+  P.ncb_pack = 4;
+  P.tiles_x = P.Wo / 16; P.tiles_y = P.Ho / 8;
+  const long tiles = (long)B * P.tiles_x * P.tiles_y;
+  WMZ_REQUIRE(tiles < (1L << 31), "wmz_conv3x3_direct_fwd_strided: too many tiles");
+  dim3 grid((unsigned)tiles), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 64) hipLaunchKernelGGL((convr_kernel<4, 16, 1, 2>), grid, block, 0, st, P);
+  else hipLaunchKernelGGL((convr_kernel<4, 16, 2, 2>), grid, block, 0, st, P);
+  WMZ_LAUNCH_CHECK("wmz_conv3x3_direct_fwd_strided");
+  return WMZ_OK;
+}
+
 extern "C" int wmz_conv3x3_direct_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale,
                                       const float* shift, const void* residual, float* stat_sum, float* stat_sq, int B, int H,
                                       int W, int Cin, int Cout, int leaky, float slope, void* stream) {
@@ -718,7 +792,7 @@ extern "C" int wmz_conv3x3_direct_fwd(const void* x, const void* wpack, void* ou
   P.x = (const bf16_t*)x; P.wpack = (const bf16_t*)wpack; P.out = (bf16_t*)out;
   P.bias = bias; P.scale = scale; P.shift = shift; P.res = (const bf16_t*)residual;
   P.stat_sum = stat_sum; P.stat_sq = stat_sq;
-  P.B = B; P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout;
+  P.B = B; P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.Ho = H; P.Wo = W;
   P.slope = slope; P.leaky = leaky;
   P.skew = g_conv_skew; P.dbg = g_conv_dbg;
   const bool wide = W >= 32;

@@ -1424,6 +1424,53 @@ extern "C" int wmz_conv2d_nhwc_wgrad_ws(const void* x, const void* dy, float* dW
   return WMZ_OK;
 }
 
+// n <= 6 conv weight gradients (any kernel size / stride / padding) by ONE launch pair of the implicit-im2col kernel: the small
+// layers of a VQ-AE training step (1x1, 2x2 / stride 2, 3x3 / stride 2, the 3-channel conv_1) are 13 launch pairs otherwise, on a
+// side branch of the step's hipGraph whose nodes the host enqueues LAST (~10 us a node).  Workspace: the sum of the problems'
+// wmz_conv2d_nhwc_wgrad_workspace_floats is enough.  HOST tables of n entries; dbias[i] may be NULL.
+extern "C" int wmz_conv2d_nhwc_wgrad_batch(int n, const void* const* x, const void* const* dy, float* const* dW, float* const* dbias,
+                                           const int* B, const int* Hi, const int* Wi, const int* Cin, const int* Cout, const int* KH,
+                                           const int* KW, const int* stride, const int* pad, const int* overwrite,
+                                           const int* conv_layout_co, const int* conv_layout_ci, float* workspace,
+                                           long workspace_floats, int dtype, void* stream) {
+  WMZ_REQUIRE(n >= 1 && n <= WG_MAXB, "wmz_conv2d_nhwc_wgrad_batch: 1..%d problems per call (got %d)", WG_MAXB, n);
+  WMZ_REQUIRE(x && dy && dW && dbias && B && Hi && Wi && Cin && Cout && KH && KW && stride && pad && overwrite && conv_layout_co &&
+              conv_layout_ci && workspace, "wmz_conv2d_nhwc_wgrad_batch: null table");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_conv2d_nhwc_wgrad_batch: bad dtype %d", dtype);
+  WgBatch Bt;
+  RedBatch R;
+  Bt.n = R.n = n;
+  Bt.first[0] = 0;
+  long off = 0;
+  struct TargetGuard { int saved; ~TargetGuard() { g_wgrad_target = saved; } } guard{g_wgrad_target};
+  g_wgrad_target = n >= 3 ? 96 : (n == 2 ? 128 : 256);
+  for (int i = 0; i < n; ++i) {
+    WMZ_REQUIRE(x[i] && dy[i] && dW[i] && B[i] > 0 && Hi[i] > 0 && Wi[i] > 0 && Cin[i] > 0 && Cout[i] > 0 && KH[i] > 0 && KW[i] > 0 &&
+                stride[i] > 0 && pad[i] >= 0, "wmz_conv2d_nhwc_wgrad_batch: bad problem %d", i);
+    WMZ_REQUIRE(Cin[i] % 8 == 0 && Cout[i] % 8 == 0, "wmz_conv2d_nhwc_wgrad_batch: problem %d: Cin and Cout must be multiples of 8", i);
+    const int Ho = (Hi[i] + 2 * pad[i] - KH[i]) / stride[i] + 1, Wo = (Wi[i] + 2 * pad[i] - KW[i]) / stride[i] + 1;
+    WMZ_REQUIRE(Ho > 0 && Wo > 0 && (long)B[i] * Ho * Wo < (1L << 31), "wmz_conv2d_nhwc_wgrad_batch: problem %d: bad output size", i);
+    const int M = B[i] * Ho * Wo, K = KH[i] * KW[i] * Cin[i];
+    off += wg_batch_add(Bt, R, i, dy[i], Cout[i], x[i], 0, dW[i], dbias[i], M, Cout[i], K, nullptr, nullptr, nullptr, nullptr, 0,
+                        overwrite[i], dtype, off, 0);
+    WgParams& P = Bt.p[i];
+    P.Hi = Hi[i]; P.Wi = Wi[i]; P.Cin = Cin[i]; P.KW = KW[i]; P.cstride = stride[i]; P.cpad = pad[i]; P.Ho = Ho; P.Wo = Wo;
+    if (conv_layout_co[i] > 0) {
+      WMZ_REQUIRE(conv_layout_co[i] <= Cout[i] && conv_layout_ci[i] > 0 && conv_layout_ci[i] <= Cin[i], "wmz_conv2d_nhwc_wgrad_batch: problem %d: bad nn.Conv2d layout sizes", i);
+      R.p[i].taps = KH[i] * KW[i]; R.p[i].cin_p = Cin[i]; R.p[i].co = conv_layout_co[i]; R.p[i].ci = conv_layout_ci[i];
+    }
+  }
+  WMZ_REQUIRE(workspace_floats >= off, "wmz_conv2d_nhwc_wgrad_batch: workspace too small (%ld floats needed)", off);
+  wg_batch_launch(Bt, R, 3, workspace, dtype, (hipStream_t)stream);
+  WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_wgrad_batch");
+  return WMZ_OK;
+}
+
+/* != 0: wmz_conv2d_nhwc_wgrad_ws takes the direct 3x3 kernel (csrc/conv_wgrad.hip) for this layer -- a launch of its own */
+extern "C" int wmz_conv2d_nhwc_wgrad_is_direct(int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int dtype) {
+  return wmz_convw_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dtype);
+}
+
 extern "C" int wmz_layernorm_stats(const void* x, long ldx, float* mean, float* rstd, int M, int K, float eps, int dtype,
                                    void* stream) {
   WMZ_REQUIRE(x && mean && rstd, "wmz_layernorm_stats: null tensor");

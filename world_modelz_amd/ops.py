@@ -354,6 +354,7 @@ def side_blocked(block=True):
 # cross-queue hand-over each, and the chain's next node queued behind the weight gradient: measured on config 5).
 _deferred = []            # launches to issue behind the compute stream's next library call
 _pending = []             # plain / LayerNorm-prologue weight gradients waiting to leave as ONE batched launch pair
+_pending_conv = []        # the same for the conv layers' weight gradients (wmz_conv2d_nhwc_wgrad_batch)
 _flushing = False
 WGRAD_BATCH = 6           # problems per wmz_linear_wgrad_batch_ln call (the library's limit)
 
@@ -381,6 +382,32 @@ def linear_wgrad_batch_ln(problems, side=None):
            L.stream())
 
 
+def _issue_pending_conv():
+    """The queued conv weight gradients as one launch pair on the side stream, behind the LAST one's fork point."""
+    global _pending_conv
+    if not _pending_conv:
+        return
+    import ctypes
+    batch, _pending_conv = _pending_conv[:WGRAD_BATCH], _pending_conv[WGRAD_BATCH:]
+    n = len(batch)
+    vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+    px, pdy, pw, pb = vp(), vp(), vp(), vp()
+    cols = [ci() for _ in range(12)]
+    need = 0
+    for i, q in enumerate(batch):
+        px[i], pdy[i], pw[i], pb[i] = L.ptr(q['x']), L.ptr(q['dy']), L.ptr(q['gw']), L.ptr(q['gb'])
+        for c, v in zip(cols, q['geom']):
+            c[i] = v
+        need += q['need']
+    ent = batch[0]['ent']
+    ent[0].wait_event(batch[-1]['fork'])
+    with torch.cuda.stream(ent[0]):
+        ws = _side_workspace(ent, batch[0]['x'].device, need)
+        L.call('wmz_conv2d_nhwc_wgrad_batch', n, px, pdy, pw, pb, *cols, L.ptr(ws), ws.numel(), batch[0]['dt'], L.stream())
+    if _pending_conv:
+        _issue_pending_conv()
+
+
 def _issue_pending():
     """The queued weight gradients as one launch pair on the side stream (behind the LAST one's fork point: the compute stream
     is in order, so the earlier operands are complete there too).  At few tokens the captured step is a chain of launches each
@@ -401,7 +428,7 @@ def _issue_pending():
 
 def _flush_deferred(force=True):
     global _flushing
-    if _flushing or not (_deferred or _pending):
+    if _flushing or not (_deferred or _pending or _pending_conv):
         return
     _flushing = True
     try:
@@ -409,9 +436,11 @@ def _flush_deferred(force=True):
             _deferred.pop(0)()
         if force or len(_pending) >= WGRAD_BATCH:
             _issue_pending()
+        if force or len(_pending_conv) >= WGRAD_BATCH:
+            _issue_pending_conv()
     finally:
         _flushing = False
-        if not (_deferred or _pending):
+        if not (_deferred or _pending or _pending_conv):
             L.after_call = None
 
 
@@ -419,8 +448,11 @@ def _after_call():
     _flush_deferred(force=False)
 
 
+DEFER_SIDE = int(__import__('os').environ.get('WMZ_WGRAD_DEFER', '1'))      # development: 0 = record side launches at their fork
+
+
 def _defer(launch):
-    if _flushing:                      # (a deferred launch's own L.call)
+    if _flushing or not DEFER_SIDE:    # (a deferred launch's own L.call)
         launch()
         return
     _deferred.append(launch)
@@ -442,8 +474,9 @@ def wgrad_join():
 def wgrad_reset():
     """Forget every queued / deferred side-stream launch and the bookkeeping around them: called before a step is captured and
     after a capture or a backward pass failed, so that nothing stale is flushed into the next step."""
-    global _pending, _arena_depth, _side_blocked, _flushing
+    global _pending, _pending_conv, _arena_depth, _side_blocked, _flushing
     _pending = []
+    _pending_conv = []
     del _deferred[:]
     _arena_depth = _side_blocked = 0
     _flushing = False
@@ -689,11 +722,12 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
         s, q = _stat_pair(Cout, x.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
-    if (DIRECT_CONV and x.dtype == torch.bfloat16 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pre is None
-            and L.lib().wmz_conv3x3_direct_supported(Hi, Wi, Cin, Cout)):
-        # csrc/conv_direct.hip: the haloed patch and the weight stream by LDS-DMA (same arithmetic as the implicit-GEMM kernel)
-        L.call('wmz_conv3x3_direct_fwd', L.ptr(x), L.ptr(_direct_pack(w_op, Cin, Cout)), L.ptr(out), L.ptr(bias), L.ptr(scale),
-               L.ptr(shift), L.ptr(residual), L.ptr(s), L.ptr(q), B, Hi, Wi, Cin, Cout, 1 if leaky else 0, float(slope), L.stream())
+    if (DIRECT_CONV and x.dtype == torch.bfloat16 and KH == 3 and KW == 3 and pad == 1 and pre is None and 0.0 <= slope <= 1.0
+            and L.lib().wmz_conv3x3_direct_supported_strided(Hi, Wi, Cin, Cout, stride)):
+        # csrc/conv_direct.hip: the haloed patch by LDS-DMA, decoupled waves (same arithmetic as the implicit-GEMM kernel)
+        L.call('wmz_conv3x3_direct_fwd_strided', L.ptr(x), L.ptr(_direct_pack(w_op, Cin, Cout)), L.ptr(out), L.ptr(bias), L.ptr(scale),
+               L.ptr(shift), L.ptr(residual), L.ptr(s), L.ptr(q), B, Hi, Wi, Cin, Cout, stride, 1 if leaky else 0, float(slope),
+               L.stream())
         return (out, s, q) if stats else out
     psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
     if (DIRECT_CONV and x.dtype == torch.bfloat16 and residual is None and 0.0 <= slope <= 1.0
@@ -835,6 +869,13 @@ def conv2d_nhwc_wgrad(x, dy, KH, KW, stride, pad, want_bias, into=None):
             side = _wgrad_side_enter(x.device, (x, dy))
         if side is not None:
             ent, fork = side
+            if not L.lib().wmz_conv2d_nhwc_wgrad_is_direct(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, dt):
+                # a small layer: leaves with up to five others as ONE launch pair (graph nodes on the side branch cost host time)
+                def queue():
+                    _pending_conv.append(dict(x=x, dy=dy, gw=gw, gb=gb, need=need, ent=ent, fork=fork, dt=dt,
+                                              geom=(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 0, co, ci)))
+                _defer(queue)
+                return None, None
 
             def launch():
                 ent[0].wait_event(fork)
