@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 102
+#define WMZ_VERSION 103
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };

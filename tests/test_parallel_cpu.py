@@ -43,7 +43,8 @@ def _worker(rank, world, port, ret):
     y = torch.randint(0, 5, (8,))
     for it in range(2):                                 # two steps: state resets between them
         arena.zero_grad()
-        xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        n = 8 // world
+        xs, ys = x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
         torch.nn.functional.cross_entropy(model(xs), ys).backward()
         scale = red.finish()
         g = (arena.flat_grad * scale).clone()
@@ -72,6 +73,27 @@ def test_bucketed_allreduce_world2():
     loss.backward()
     assert torch.allclose(g0, arena.flat_grad, rtol=1e-5, atol=1e-7)
     assert buckets[0][0] == 0 and buckets[-1][1] == arena.numel
+
+
+def test_bucketed_allreduce_world4():
+    """The same over FOUR ranks (rank counts above two had never run any of this code: VERDICT r04): identical replicas after the
+    broadcast, the same reduced gradient on every rank, equal to the single-process gradient of the mean loss over the union."""
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(4, _free_port(), ret), nprocs=4, join=True)
+        res = [ret[r] for r in range(4)]
+    for g, p_, _ in res[1:]:
+        assert torch.equal(p_, res[0][1]) and torch.equal(g, res[0][0])
+    from world_modelz_amd.parallel import FlatArena
+    model = _model()
+    arena = FlatArena(model)
+    torch.manual_seed(100)
+    x = torch.randn(8, 12)
+    y = torch.randint(0, 5, (8,))
+    loss = sum(torch.nn.functional.cross_entropy(model(x[2 * r:2 * r + 2]), y[2 * r:2 * r + 2]) for r in range(4)) / 4
+    loss.backward()
+    assert torch.allclose(res[0][0], arena.flat_grad, rtol=1e-5, atol=1e-7)
 
 
 class _DirectLinear(torch.autograd.Function):
@@ -232,6 +254,35 @@ def test_untracked_loads_stay_untouched_until_their_wait():
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count('touches in between: 0') >= 2, r.stdout
+
+
+def test_direct_conv_kernels_never_touch_loads_in_flight():
+    """conv_direct.hip (convr_kernel) fetches its weight fragments with inline-asm global loads retired by counted vmcnt waits and
+    its patch fragments with inline-asm LDS reads retired by counted lgkmcnt waits: nothing may read or write a destination
+    register before the wait that retires it (hipcc hands the register of a DEAD asm result to the next instruction -- the round-5
+    memory fault).  tools/check_untracked_conv.py compiles the file to ISA and scans every instantiation."""
+    import os, shutil, subprocess, sys
+    if not os.path.exists('/opt/rocm/bin/hipcc') and shutil.which('hipcc') is None:
+        import pytest
+        pytest.skip('hipcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_untracked_conv.py')], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('touches before their waits: 0') == 14, r.stdout
+
+
+def test_scoped_invalidate_names_whose_weights_moved():
+    """_cast.invalidate(params) moves every operand copy's epoch (rebuilt at next use) but only the graph stamps of holders of
+    those parameters (graph.GraphedForward stamps _cast.epoch_of(its tensors)): the frozen auto-encoder's captured encoder
+    must survive the denoiser's optimizer steps (main.py:229-287)."""
+    from world_modelz_amd import _cast
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
+    ea, eb, glob = _cast.epoch_of([a]), _cast.epoch_of([b]), _cast._epoch
+    _cast.invalidate([a])
+    assert _cast.epoch_of([a]) != ea and _cast.epoch_of([b]) == eb and _cast._epoch == glob + 1
+    _cast.invalidate()
+    assert _cast.epoch_of([b]) != eb
 
 
 def test_fused_backward_kernels_are_straight_line_and_never_touch_loads_in_flight():

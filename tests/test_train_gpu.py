@@ -705,11 +705,44 @@ def _rccl_world_of_one_body():
                     if getattr(t_, '_graph', None) is not None:
                         t_._graph = None
                 torch.cuda.synchronize()
+        # ---- the VQ-AE trainer under the data-parallel capture (round 5: VqaeTrainer.enable_graph accepts a reducer): the gradient
+        # buckets' all-reduces AND the VQ EMA statistics' (counts, dw inside VectorQuantizerEMA.forward: SURVEY 8e) are graph nodes;
+        # graphed data-parallel step == eager data-parallel step == single-process step
+        from world_modelz_amd.train_vqae import VqAutoEncoder
+
+        def make_ae():
+            torch.manual_seed(29)
+            return VqAutoEncoder(embedding_dim=16, num_embeddings=64, downscale_steps=2, hidden_planes=24).cuda()
+        frames = torch.rand(8, 3, 32, 32, device='cuda')
+        with config.compute_dtype(torch.bfloat16):
+            ae_e, ae_g, ae_s = make_ae(), make_ae(), make_ae()
+            ve = train.VqaeTrainer(ae_e, distributed=True)
+            vg = train.VqaeTrainer(ae_g, distributed=True)
+            vs = train.VqaeTrainer(ae_s, distributed=False)
+            assert vg.reducer is not None and vg.reducer.active and ae_g.vq.sync_stats
+            vg.enable_graph(frames, warmup=0)
+            assert vg._graph is not None
+            for it in range(3):
+                oe, og, os_ = ve.train_step(frames), vg.train_step(frames), vs.train_step(frames)
+                for j, (a, b, c) in enumerate(zip(oe, og, os_)):          # loss, reconstruction loss, latent loss, perplexity
+                    tol = 5e-2 if j == 3 else 2e-2                       # (the perplexity counts nearest-code flips of bf16 latents)
+                    assert abs(a - b) < tol * max(1.0, abs(a)) and abs(c - b) < tol * max(1.0, abs(c)), (it, oe, og, os_)
+            assert sorted(vg.reducer.last_order) == list(range(len(vg.reducer.buckets)))
+            for (n, a), b, c in zip(ae_e.named_parameters(), ae_g.parameters(), ae_s.parameters()):
+                assert torch.allclose(a, b, rtol=0, atol=3e-3) and torch.allclose(c, b, rtol=0, atol=3e-3), n
+            # (the EMA codebook follows the encoder's bf16 latents: a handful of nearest-code flips between launch orders move rows by ~1e-3)
+            #  -- and a rarely used code's row by much more: (batch sum) / (EMA count): compared on average, not row by row)
+            assert float((ae_e.vq.embedding - ae_g.vq.embedding).abs().median()) < 1e-3 and float((ae_s.vq.embedding - ae_g.vq.embedding).abs().median()) < 1e-3
+            print('[ddp world-of-one] graphed data-parallel VQ-AE step == eager == single-process')
+            for t_ in (vg, ve, vs):
+                if getattr(t_, '_graph', None) is not None:
+                    t_._graph = None
+            torch.cuda.synchronize()
     finally:
         # (captured graphs hold RCCL kernels: let go of them and drain the device before the communicator is torn down -- a
         #  failing assertion above must surface as that assertion, not as an abort inside destroy_process_group)
         import gc
-        for name in ('tg', 'te', 'td', 'ts'):
+        for name in ('tg', 'te', 'td', 'ts', 'vg', 've', 'vs'):
             t = locals().get(name)
             if t is not None and getattr(t, '_graph', None) is not None:
                 t._graph = None

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16 = 0, 1
+EXPECTED_VERSION = 103      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -143,6 +144,9 @@ def lib():
                            '(there is no CPU fallback for the HIP path)')
         L = ctypes.CDLL(LIB_PATH)
         L.wmz_version.restype = c_int
+        if L.wmz_version() != EXPECTED_VERSION:
+            raise WmzError(f'{LIB_PATH} is version {L.wmz_version()}, this Python package expects {EXPECTED_VERSION} (include/wmz.h '
+                           'WMZ_VERSION): a stale build -- run `python -m world_modelz_amd.build`')
         L.wmz_last_error.restype = ctypes.c_char_p
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name, None)

@@ -20,6 +20,25 @@ def capture_mode():
     return 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
 
 
+def gc_quiet(fn):
+    """Decorator for functions that warm up and capture a hipGraph: one collection up front, the cyclic collector off until the
+    function returns -- a collection inside would destroy dead graph holders (and free their pools) in the middle of the capture."""
+    import functools
+    import gc
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return fn(*a, **k)
+        finally:
+            if was_enabled:
+                gc.enable()
+    return wrapped
+
+
 class GraphedForward:
     """The captured graph bakes in the device addresses of the operand copies of the weights (bf16 casts, packed weight
     streams: _cast).  It therefore (i) holds strong references to every operand tensor that existed at capture time, so
@@ -45,6 +64,7 @@ class GraphedForward:
         return (_cast.epoch_of(self._tensors), config.get_compute_dtype(), config.get_last_frame_cone(), config.get_clip_streams(),
                 tuple((t._version, t.data_ptr()) for t in self._tensors))
 
+    @gc_quiet
     def _capture(self):
         self._tensors = list(self.model.parameters()) + list(self.model.buffers())
         s = config.shared_stream('warmup')

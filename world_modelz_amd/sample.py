@@ -83,9 +83,13 @@ def sample_frames(model, batch_z, num_embeddings, num_frames, num_eval_iteration
     return out, (batch_z.clone() if fwd is not None else batch_z)   # (never hand out the graph's own buffer)
 
 
+MAX_SESSIONS = 2          # captured sampler steps kept per model (least recently used beyond that are dropped: a graph, its
+#                           buffers and its references to the operand copies are ~tens of MB each)
+
+
 class _Sessions(dict):
-    """The model's captured sampler steps.  They belong to THIS module object on THIS device: a copy of the model
-    (copy.deepcopy, pickling the module) starts without them instead of failing on the hipGraph inside."""
+    """The model's captured sampler steps, most recently used last.  They belong to THIS module object on THIS device: a copy of the
+    model (copy.deepcopy, pickling the module) starts without them instead of failing on the hipGraph inside."""
 
     def __deepcopy__(self, memo):
         return _Sessions()
@@ -93,12 +97,52 @@ class _Sessions(dict):
     def __reduce__(self):
         return (_Sessions, ())
 
+    def touch(self, key, make):
+        ses = self.pop(key, None)
+        if ses is None:
+            ses = make()
+        self[key] = ses                                   # (re-inserted: dicts keep insertion order)
+        while len(self) > MAX_SESSIONS:
+            del self[next(iter(self))]
+        return ses
+
+
+class _WeakModel:
+    """What a session's graph runner holds instead of the model: a weak reference.  model -> sessions -> session -> runner -> model
+    was a reference cycle -- a dropped model, its hipGraphs and their private pools were freed only by the cyclic collector,
+    whenever that ran (possibly in the middle of another stream capture); now dropping the model frees them at once."""
+
+    def __init__(self, model):
+        import weakref
+        self._ref = weakref.ref(model)
+
+    def _model(self):
+        m = self._ref()
+        if m is None:
+            raise RuntimeError('the model of this sampler session no longer exists')
+        return m
+
+    def parameters(self):
+        return self._model().parameters()
+
+    def buffers(self):
+        return self._model().buffers()
+
+    def __call__(self, z):
+        return self._model()(z)
+
+
+def release_sampler_sessions(model):
+    """Drop the captured sampler steps kept with `model` (their graphs, device buffers and operand references) now."""
+    ses = model.__dict__.pop('_wmz_sampler_sessions', None)
+    if ses is not None:
+        ses.clear()
+
 
 _SEED_KEY = 0x9E3779B97F4A7C15                   # the captured kernels' Philox key (a kernel ARGUMENT, i.e. baked into the graph):
 #                                                   what varies per call is the device-side counter's starting value
-# (the sessions live ON the model -- `model._wmz_sampler_sessions`, {configuration: captured sampler step + its device buffers} --
-#  and die with it: a session references its model through the graph runner, so a module-level map keyed by the model, weak or
-#  not, would keep both alive for the life of the process)
+# (the sessions live ON the model -- `model._wmz_sampler_sessions`, {configuration: captured sampler step + its device buffers},
+#  at most MAX_SESSIONS of them -- and die with it: the graph runner of a session holds the model weakly (_WeakModel))
 
 
 class _Session:
@@ -133,7 +177,7 @@ class _Session:
                 src = self.logits
             draw(src, holder['z'])
         self.draw = draw
-        self.fwd = GraphedForward(model, batch_z, pre=pre, post=post)
+        self.fwd = GraphedForward(_WeakModel(model), batch_z, pre=pre, post=post)
 
 
 def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_iterations, sample_topk, noise_schedule,
@@ -151,9 +195,7 @@ def _sample_frames_fused(model, batch_z, num_embeddings, num_frames, num_eval_it
     n = num_eval_iterations
     key = (B, S, H, W, num_embeddings, n, int(sample_topk), bool(consistent_masking), batch_z.device)
     per_model = model.__dict__.setdefault('_wmz_sampler_sessions', _Sessions())
-    ses = per_model.get(key)
-    if ses is None:
-        ses = per_model[key] = _Session(model, batch_z, num_embeddings, n, sample_topk, consistent_masking)
+    ses = per_model.touch(key, lambda: _Session(model, batch_z, num_embeddings, n, sample_topk, consistent_masking))
     ses.alphas.copy_(torch.tensor([min(max(noise_schedule((i + 1) / n) if noise_schedule is not None else (i + 1) / n, 0.0), 1.0)
                                    for i in range(n)], dtype=torch.float32))
     # The Philox stream is indexed by the counter; a call starts it at a 62-bit draw from the caller's generator (the global CPU

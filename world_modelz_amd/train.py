@@ -83,6 +83,8 @@ def corrupt_tokens(tokens, r, num_embeddings, generator=None, seed=None, rank=No
     return out, target
 
 
+from .graph import gc_quiet as _gc_quiet
+
 class _LinearCrossEntropy(torch.autograd.Function):
     """mean CrossEntropy(x W^T + b, target) WITHOUT the [R, C] logits in memory (config 5: R = 3072 rows per GPU x C = 8192
     classes x fp32 = 100 MB, 800 MB for the global batch on one device): the rows are walked in chunks whose logits stay
@@ -413,6 +415,7 @@ class _TrainerBase(_AdamState):
 
 
     # ------------------------------------------------------------------------------------------------ hipGraph (every trainer)
+    @_gc_quiet
     def enable_graph(self, example_batch, warmup=3, keep_warmup_updates=False):
         """Capture corrupt -> forward -> CE -> backward -> [gradient all-reduce] -> grad-norm -> AdamW -> operand re-pack as ONE
         hipGraph and replay it from train_step() (single micro-batch).  With a data-parallel reducer the per-layer RCCL
@@ -725,13 +728,21 @@ class VqaeTrainer(_AdamState):
         loss.backward()
         return torch.stack([loss.detach(), r_loss.detach(), latent_loss.detach().reshape(()), perplexity.detach().reshape(())])
 
+    @_gc_quiet
     def enable_graph(self, example_batch, warmup=2):
         """Capture zero-grad -> encoder -> VectorQuantizerEMA (incl. the in-place EMA codebook update, vq.py:42-65) -> decoder ->
         losses -> backward -> AdamW as ONE hipGraph, replayed by train_step() for batches of this shape: ~460 launches with the
         autograd bookkeeping between them become one launch, the step's four scalars come back in one read.  The learning rate
         and AdamW's bias corrections live in device memory (wmz_adamw_step_dev); the dead-code revival (train_vqae.py:160-164,
         host-driven, every vq_reuse_interval steps) runs between replays.  The warm-up steps are real training steps."""
-        assert self.reducer is None, 'the graphed VQ-AE step is single-process (gloo / RCCL statistics sync stays eager)'
+        # data parallel (SURVEY 8e): the gradient buckets' all-reduces and the VQ EMA statistics' (counts [C], dw [C, E]: vq.sync_stats)
+        # are captured with the step -- RCCL collectives are capturable, gloo's are not
+        if self.reducer is not None:
+            import torch.distributed as _dist
+            if _dist.get_backend() != 'nccl':
+                raise RuntimeError('the graphed data-parallel VQ-AE step needs the RCCL (`nccl`) backend: gloo collectives cannot '
+                                   'be captured into a hipGraph (train eagerly, or drop enable_graph)')
+        ops.wgrad_reset()
         dev = self.arena.flat_param.device
         self.model.train()
         self._g_x = example_batch.contiguous().clone()
@@ -769,9 +780,12 @@ class VqaeTrainer(_AdamState):
         self._refresh_conv_operands()
         out = self._forward_backward(self._g_x)
         ops.wgrad_join()                   # (the conv weight gradients' side branch; already joined when the autograd pass ended)
+        # data parallel: buckets the backward did not launch itself, then the compute stream joins the reducer's side stream;
+        # the 1 / world of the gradient mean is folded into AdamW's gradient scale
+        scale = self.reducer.finish() if self.reducer is not None else 1.0
         self._g_sq.zero_()
         L.call('wmz_adamw_step_dev', L.ptr(a.flat_param), L.ptr(a.flat_grad), L.ptr(self.m), L.ptr(self.v), a.numel,
-               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, 1.0, L.ptr(self._g_sq), L.stream())
+               L.ptr(self._g_hyper), self.betas[0], self.betas[1], self.eps, self.wd, float(scale), L.ptr(self._g_sq), L.stream())
         self._ema_update()
         return out
 
