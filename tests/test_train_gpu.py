@@ -571,7 +571,12 @@ def test_overlapped_allreduce_path_runs_on_rccl_world_of_one():
     for line in r.stdout.splitlines():
         if line.startswith('[ddp'):
             print(line)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    if r.returncode != 0:                                          # (keep the whole story: the head of stderr names what aborted)
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        if os.path.isdir(out):
+            with open(os.path.join(out, 'rccl_child_failure.log'), 'w') as f:
+                f.write(r.stdout + '\n=== stderr ===\n' + r.stderr)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[:3000] + '\n...\n' + r.stderr[-1500:]
 
 
 def _rccl_world_of_one_body():
