@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 103
+#define WMZ_VERSION 104
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
@@ -507,6 +507,15 @@ int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* dy, const fl
                           float* sum_g, float* sum_gx, long M, int C, int leaky, float slope, int dtype, void* stream);
 int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean, const float* rstd, const float* gamma,
                      const float* sum_g, const float* sum_gx, void* dx, long M, int C, int dtype, void* stream);
+/* Both of the above for y = LeakyReLU(BatchNorm_train(x)) WITHOUT a skip input (autoencoder.py:21-25 Residual's first
+ * normalisation, :100-118 UpscaleResidual's two): the LeakyReLU mask is recomputed from x and the forward's (scale, shift) -- the
+ * sign of fmaf(x, scale, shift), what wmz_affine_act_nhwc evaluated -- so the stored output is not read and g = dy * act'(y) is not
+ * written: 5 tensor passes instead of 7.  dy: the gradient behind the activation; sum_g / sum_gx: fp32 [C], ZERO on entry,
+ * receive dbeta / dgamma; dx = dL/dx.  Shapes: wmz_bn_leaky_bwd_supported(C, dtype) != 0 (the 16-byte kernels). */
+int wmz_bn_leaky_bwd_supported(int C, int dtype);
+int wmz_bn_leaky_bwd(const void* x, const void* dy, const float* scale, const float* shift, const float* mean,
+                     const float* rstd, const float* gamma, float* sum_g, float* sum_gx, void* dx, long M, int C, float slope,
+                     int dtype, void* stream);
 /* adjoint of wmz_bilinear2x_nhwc (gather form, deterministic): dy [B,2H,2W,C] -> dx [B,H,W,C]. */
 int wmz_bilinear2x_nhwc_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 

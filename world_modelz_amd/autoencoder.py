@@ -166,26 +166,36 @@ class _BnActFn(torch.autograd.Function):
             s, q = ops.channel_stats_nhwc(x)
         scale, shift, mean, rstd = ops.bn_finalize(bn, s, q, _count(x), want_stats=True)
         y = ops.affine_act_nhwc(x, scale, shift, b=r, leaky=leaky, slope=LEAKY)
-        ctx.save_for_backward(x, y, mean, rstd, gamma)
-        ctx.beta = beta
         ctx.leaky, ctx.has_r = leaky, r is not None
+        # without a skip input the backward recomputes the LeakyReLU mask from x and (scale, shift): y is not kept for it
+        ctx.remask = leaky and r is None and ops.bn_leaky_bwd_supported(x)
+        if ctx.remask:
+            ctx.save_for_backward(x, scale, shift, mean, rstd, gamma)
+        else:
+            ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.beta = beta
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, rstd, gamma = ctx.saved_tensors
+        if ctx.remask:
+            x, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+            y, remask = None, (scale, shift)
+        else:
+            x, y, mean, rstd, gamma = ctx.saved_tensors
+            remask = None
         beta = ctx.beta
         gg, gb = getattr(gamma, '_wmz_grad', None), getattr(beta, '_wmz_grad', None)
         if gg is not None and gb is not None and getattr(gamma, '_wmz_single_use', False):
             # VqaeTrainer's arena: zeroed at the start of the step, this layer its slots' only writer -- the reduction's
             # atomics land there (28 zero fills and 28 `grad += g` launches fewer per step)
-            dx, _, _, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, into=(gg, gb))
+            dx, _, _, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, into=(gg, gb), remask=remask)
             for prm in (gamma, beta):
                 ready = getattr(prm, '_wmz_ready', None)
                 if ready is not None:
                     ready()
             return dx, None, None, (g if ctx.has_r else None), None, None, None, None
-        dx, dgamma, dbeta, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY)
+        dx, dgamma, dbeta, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, remask=remask)
         return dx, dgamma, dbeta, (g if ctx.has_r else None), None, None, None, None
 
 

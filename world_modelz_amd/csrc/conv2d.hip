@@ -558,12 +558,17 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ a
 // tensors): a thread keeps its channel group for the whole launch when the grid stride is a multiple of C / VW vectors --
 // the host picks the grid that way -- so its scale / shift values are loaded once; 32-bit index arithmetic.
 // (The scalar form above moved 2 bytes per access and paid a 64-bit modulo per 4 elements: 6-10x off the HBM rate.)
+// The streaming loops below keep EW_UNROLL independent 16-byte loads per operand in flight per thread, on a grid that is resident
+// at once (EW_GRID workgroups = 8 per CU): with one load per iteration and 8192 short-lived workgroups the 100-MB launches of the
+// frame encoder ran at 1.6-2.6 TB/s (latency chains: per-channel constants -> load -> store, four rounds of workgroups).
+constexpr int EW_UNROLL = 4, EW_GRID = 2048;
+
 template <typename T>
 __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict__ a, const float* __restrict__ sa,
                                                              const float* __restrict__ ta, const T* __restrict__ b,
                                                              const float* __restrict__ sb, const float* __restrict__ tb,
                                                              T* __restrict__ y, long nvec, int C, int leaky, float slope) {
-  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int VW = 16 / (int)sizeof(T), U = EW_UNROLL;
   const int cv = C / VW;                                        // vectors per pixel
   const long stride = (long)gridDim.x * blockDim.x;             // a multiple of cv (host)
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,14 +579,12 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
     s1[e] = sa ? sa[c0 + e] : 1.f; t1[e] = sa ? ta[c0 + e] : 0.f;
     s2[e] = sb ? sb[c0 + e] : 1.f; t2[e] = sb ? tb[c0 + e] : 0.f;
   }
-  for (; i < nvec; i += stride) {
-    const i32x4 va = *reinterpret_cast<const i32x4*>(a + i * VW);
+  auto finish = [&](const i32x4& va, const i32x4& vb, long at) {
     float f[VW];
     chunk_to_f32<T>(va, f);
 #pragma unroll
     for (int e = 0; e < VW; ++e) f[e] = fmaf(f[e], s1[e], t1[e]);
     if (b) {
-      const i32x4 vb = *reinterpret_cast<const i32x4*>(b + i * VW);
       float u[VW];
       chunk_to_f32<T>(vb, u);
 #pragma unroll
@@ -591,7 +594,23 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < VW; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * slope;
     }
-    *reinterpret_cast<i32x4*>(y + i * VW) = f32_to_chunk<T>(f);
+    *reinterpret_cast<i32x4*>(y + at * VW) = f32_to_chunk<T>(f);
+  };
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {
+    i32x4 va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      va[u] = *reinterpret_cast<const i32x4*>(a + (i + u * stride) * VW);
+      if (b) vb[u] = *reinterpret_cast<const i32x4*>(b + (i + u * stride) * VW);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) finish(va[u], vb[u], i + u * stride);
+  }
+  for (; i < nvec; i += stride) {
+    const i32x4 va = *reinterpret_cast<const i32x4*>(a + i * VW);
+    i32x4 vb = va;
+    if (b) vb = *reinterpret_cast<const i32x4*>(b + i * VW);
+    finish(va, vb, i);
   }
 }
 
@@ -712,15 +731,42 @@ __global__ __launch_bounds__(RED_NT) void bn_act_bwd_reduce_vec_kernel(const T* 
                                                                     const T* __restrict__ dy, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, T* __restrict__ g_out,
                                                                     float* __restrict__ sum_g, float* __restrict__ sum_gx,
-                                                                    long nvec, int C, int leaky, float slope) {
+                                                                    long nvec, int C, int leaky, float slope,
+                                                                    const float* __restrict__ msc, const float* __restrict__ msh) {
+  // msc / msh (optional): the forward's scale / shift -- the LeakyReLU mask is recomputed from x (sign of fmaf(x, scale, shift), the
+  // expression affine_act_vec_kernel evaluated) instead of read from the stored output: one tensor less to read
   constexpr int VW = 16 / (int)sizeof(T);
   const int cv = C / VW;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c0 = (int)(i % cv) * VW;
-  float mu[VW], rs[VW], s1[VW], s2[VW];
+  float mu[VW], rs[VW], s1[VW], s2[VW], ms[VW], mt[VW];
 #pragma unroll
-  for (int e = 0; e < VW; ++e) { mu[e] = mean ? mean[c0 + e] : 0.f; rs[e] = rstd ? rstd[c0 + e] : 1.f; s1[e] = 0.f; s2[e] = 0.f; }
+  for (int e = 0; e < VW; ++e) {
+    mu[e] = mean ? mean[c0 + e] : 0.f; rs[e] = rstd ? rstd[c0 + e] : 1.f; s1[e] = 0.f; s2[e] = 0.f;
+    ms[e] = msc ? msc[c0 + e] : 0.f; mt[e] = msc ? msh[c0 + e] : 0.f;
+  }
+  if (msc != nullptr) {                                       // recomputed mask, no g_out: two streams, two iterations in flight
+    for (; i < nvec; i += 2 * stride) {
+      const bool two = i + stride < nvec;
+      const i32x4 vg0 = *reinterpret_cast<const i32x4*>(dy + i * VW), vx0 = *reinterpret_cast<const i32x4*>(x + i * VW);
+      i32x4 vg1 = vg0, vx1 = vx0;
+      if (two) { vg1 = *reinterpret_cast<const i32x4*>(dy + (i + stride) * VW); vx1 = *reinterpret_cast<const i32x4*>(x + (i + stride) * VW); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !two) break;
+        float g[VW], xv[VW];
+        chunk_to_f32<T>(h ? vg1 : vg0, g);
+        chunk_to_f32<T>(h ? vx1 : vx0, xv);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          if (fmaf(xv[e], ms[e], mt[e]) <= 0.f) g[e] *= slope;
+          s1[e] += g[e];
+          s2[e] += g[e] * (xv[e] - mu[e]) * rs[e];
+        }
+      }
+    }
+  } else
   for (; i < nvec; i += stride) {
     float g[VW];
     chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(dy + i * VW), g);
@@ -763,26 +809,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                                const float* __restrict__ sum_gx, T* __restrict__ dx, long nvec,
-                                                               int C, float invM) {
+                                                               int C, float invM, const float* __restrict__ msc,
+                                                               const float* __restrict__ msh, float slope) {
+  // msc / msh (optional): g holds the gradient BEHIND the LeakyReLU and the mask is recomputed from x (see the reducing kernel)
   constexpr int VW = 16 / (int)sizeof(T);
   const int cv = C / VW;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c0 = (int)(i % cv) * VW;
-  float mu[VW], rs[VW], gr[VW], sg[VW], sgx[VW];
+  float mu[VW], rs[VW], gr[VW], sg[VW], sgx[VW], ms[VW], mt[VW];
 #pragma unroll
   for (int e = 0; e < VW; ++e) {
     mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; gr[e] = gamma[c0 + e] * rs[e];
     sg[e] = sum_g[c0 + e] * invM; sgx[e] = sum_gx[c0 + e] * invM;
+    ms[e] = msc ? msc[c0 + e] : 0.f; mt[e] = msc ? msh[c0 + e] : 1.f;          // (no mask: 0 * x + 1 > 0)
   }
-  for (; i < nvec; i += stride) {
+  auto finish = [&](const i32x4& vx, const i32x4& vg, long at) {
     float xv[VW], gv[VW];
-    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(x + i * VW), xv);
-    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(g + i * VW), gv);
+    chunk_to_f32<T>(vx, xv);
+    chunk_to_f32<T>(vg, gv);
+    if (msc != nullptr) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) if (fmaf(xv[e], ms[e], mt[e]) <= 0.f) gv[e] *= slope;
+    }
 #pragma unroll
     for (int e = 0; e < VW; ++e) gv[e] = gr[e] * (gv[e] - sg[e] - (xv[e] - mu[e]) * rs[e] * sgx[e]);
-    *reinterpret_cast<i32x4*>(dx + i * VW) = f32_to_chunk<T>(gv);
+    *reinterpret_cast<i32x4*>(dx + at * VW) = f32_to_chunk<T>(gv);
+  };
+  constexpr int U = EW_UNROLL;
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {
+    i32x4 vx[U], vg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      vx[u] = *reinterpret_cast<const i32x4*>(x + (i + u * stride) * VW);
+      vg[u] = *reinterpret_cast<const i32x4*>(g + (i + u * stride) * VW);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) finish(vx[u], vg[u], i + u * stride);
   }
+  for (; i < nvec; i += stride)
+    finish(*reinterpret_cast<const i32x4*>(x + i * VW), *reinterpret_cast<const i32x4*>(g + i * VW), i);
 }
 
 template <typename T>
@@ -999,7 +1065,7 @@ extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* 
   if (C % VW == 0 && aligned && 256 % (C / VW) == 0) {
     // every thread keeps its channel group: the grid stride (grid * 256 vectors) is a multiple of C / VW since 256 is
     const long nvec = total / VW;
-    const int gridv = (int)(wmz_cdiv(nvec, 256) < 8192 ? wmz_cdiv(nvec, 256) : 8192);
+    const int gridv = grid_for(nvec, 256, EW_GRID);
     if (dtype == WMZ_BF16)
       hipLaunchKernelGGL(affine_act_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, st, (const bf16_t*)a, sa, ta, (const bf16_t*)b, sb, tb, (bf16_t*)y, nvec, C, leaky, slope);
     else
@@ -1049,9 +1115,9 @@ extern "C" int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* d
     const long nvec = M * C / VW;
     const int gridv = grid_for(nvec, RED_NT * 4, 256);                 // (a multiple of C / VW vectors per sweep: 256 is)
     if (dtype == WMZ_BF16)
-      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridv), dim3(RED_NT), 0, st, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, (bf16_t*)g_out, sum_g, sum_gx, nvec, C, leaky, slope);
+      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridv), dim3(RED_NT), 0, st, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, (bf16_t*)g_out, sum_g, sum_gx, nvec, C, leaky, slope, nullptr, nullptr);
     else
-      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridv), dim3(RED_NT), 0, st, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, (float*)g_out, sum_g, sum_gx, nvec, C, leaky, slope);
+      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridv), dim3(RED_NT), 0, st, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, (float*)g_out, sum_g, sum_gx, nvec, C, leaky, slope, nullptr, nullptr);
     WMZ_LAUNCH_CHECK("wmz_bn_act_bwd_reduce");
     return WMZ_OK;
   }
@@ -1072,11 +1138,11 @@ extern "C" int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean,
   if (vec_ok(C, dtype, {x, g, dx})) {
     const int VW = dtype == WMZ_BF16 ? 8 : 4;
     const long nvec = M * C / VW;
-    const int gridv = grid_for(nvec, 256, 8192);
+    const int gridv = grid_for(nvec, 256, EW_GRID);
     if (dtype == WMZ_BF16)
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M);
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
     else
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(gridv), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M);
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(gridv), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
     WMZ_LAUNCH_CHECK("wmz_bn_bwd_apply");
     return WMZ_OK;
   }
@@ -1086,6 +1152,33 @@ extern "C" int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean,
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, M, C);
   WMZ_LAUNCH_CHECK("wmz_bn_bwd_apply");
+  return WMZ_OK;
+}
+
+extern "C" int wmz_bn_leaky_bwd_supported(int C, int dtype) {
+  const int VW = dtype == WMZ_BF16 ? 8 : 4;
+  return (dtype == WMZ_F32 || dtype == WMZ_BF16) && C > 0 && C % VW == 0 && 256 % (C / VW) == 0 ? 1 : 0;
+}
+
+extern "C" int wmz_bn_leaky_bwd(const void* x, const void* dy, const float* scale, const float* shift, const float* mean,
+                                const float* rstd, const float* gamma, float* sum_g, float* sum_gx, void* dx, long M, int C,
+                                float slope, int dtype, void* stream) {
+  WMZ_REQUIRE(x && dy && scale && shift && mean && rstd && gamma && sum_g && sum_gx && dx && M > 0, "wmz_bn_leaky_bwd: bad arguments");
+  WMZ_REQUIRE(wmz_bn_leaky_bwd_supported(C, dtype) && vec_ok(C, dtype, {x, dy, dx}),
+              "wmz_bn_leaky_bwd: C = %d / dtype %d / alignment not built (wmz_bn_leaky_bwd_supported; 16-byte aligned tensors)", C, dtype);
+  WMZ_REQUIRE(slope >= 0.f && slope <= 1.f, "wmz_bn_leaky_bwd: LeakyReLU slope in [0, 1] expected");
+  hipStream_t st = (hipStream_t)stream;
+  const int VW = dtype == WMZ_BF16 ? 8 : 4;
+  const long nvec = M * C / VW;
+  const int gridr = grid_for(nvec, RED_NT * 4, 256), grida = grid_for(nvec, 256, EW_GRID);
+  if (dtype == WMZ_BF16) {
+    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridr), dim3(RED_NT), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)dy, mean, rstd, (bf16_t*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(grida), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
+  } else {
+    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridr), dim3(RED_NT), 0, st, (const float*)x, (const float*)nullptr, (const float*)dy, mean, rstd, (float*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(grida), dim3(256), 0, st, (const float*)x, (const float*)dy, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
+  }
+  WMZ_LAUNCH_CHECK("wmz_bn_leaky_bwd");
   return WMZ_OK;
 }
 
