@@ -30,3 +30,6 @@ for (H, C, two) in ((64, 64, False), (32, 64, True), (32, 64, False), (16, 64, T
     mean, rstd = torch.randn(C, device='cuda'), torch.rand(C, device='cuda') + 0.5
     t = timed(lambda: ops.bn_act_bwd(x, r, x, mean, rstd, sc, True))
     print(f'bn_act_bwd  B={B} {H}x{H}x{C} (reduce 3R+1W, apply 2R+1W): {t:7.1f} us  {7 * mb / t:6.2f} TB/s ({7 * mb:.0f} MB)')
+    sg = torch.zeros(2, C, device='cuda')
+    t = timed(lambda: ops.bn_act_bwd(x, None, r, mean, rstd, sc, True, into=(sg[0], sg[1]), remask=(sc, sh)))
+    print(f'bn_leaky_bwd B={B} {H}x{H}x{C} (mask recomputed: reduce 2R, apply 2R+1W): {t:7.1f} us  {5 * mb / t:6.2f} TB/s ({5 * mb:.0f} MB)')

@@ -558,27 +558,55 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ a
 // tensors): a thread keeps its channel group for the whole launch when the grid stride is a multiple of C / VW vectors --
 // the host picks the grid that way -- so its scale / shift values are loaded once; 32-bit index arithmetic.
 // (The scalar form above moved 2 bytes per access and paid a 64-bit modulo per 4 elements: 6-10x off the HBM rate.)
-// The streaming loops below keep EW_UNROLL independent 16-byte loads per operand in flight per thread, on a grid that is resident
-// at once (EW_GRID workgroups = 8 per CU): with one load per iteration and 8192 short-lived workgroups the 100-MB launches of the
-// frame encoder ran at 1.6-2.6 TB/s (latency chains: per-channel constants -> load -> store, four rounds of workgroups).
-constexpr int EW_UNROLL = 4, EW_GRID = 2048;
+// Shape of the streaming kernels below (affine_act, BatchNorm backward, channel statistics), measured on the frame encoder's and the
+// VQ-AE step's tensors (tools/time_affine.py): (i) a grid that is resident at once (<= EW_GRID workgroups of 256 threads, 8 per CU)
+// instead of 8192 short-lived ones; (ii) the per-channel constants come from an LDS table the workgroup fills once (one channel per
+// thread, coalesced) -- the first version had every thread fetch its 8 channels of 4-7 arrays by 32-56 global_load_dword, most of
+// a 100-MB launch; (iii) U vectors per operand in flight per thread, pinned by issued(): hipcc otherwise sinks the second
+// operand's load behind the first one's use (load, wait, convert, load, wait).  affine_act on 100 MB: 40 -> 20 us.
+constexpr int EW_GRID = 2048;
+
+__device__ __forceinline__ void issued(i32x4& a, i32x4& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void issued(i32x4& a, i32x4& b, i32x4& c, i32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void issued(i32x4& a, i32x4& b, i32x4& c, i32x4& d, i32x4& e, i32x4& f) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+__device__ __forceinline__ void issued(i32x4& a, i32x4& b, i32x4& c, i32x4& d, i32x4& e, i32x4& f, i32x4& g, i32x4& h) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+
+// row k of the workgroup's LDS table [rows][C]: this thread's VW channels
+template <int VW>
+__device__ __forceinline__ void tab_row(const float* tab, int C, int k, int c0, float* out) {
+#pragma unroll
+  for (int e = 0; e < VW; e += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(tab + k * C + c0 + e);
+    out[e] = v[0]; out[e + 1] = v[1]; out[e + 2] = v[2]; out[e + 3] = v[3];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ i32x4 ld16(const T* p, long i) { return *reinterpret_cast<const i32x4*>(p + i * (16 / (int)sizeof(T))); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict__ a, const float* __restrict__ sa,
                                                              const float* __restrict__ ta, const T* __restrict__ b,
                                                              const float* __restrict__ sb, const float* __restrict__ tb,
                                                              T* __restrict__ y, long nvec, int C, int leaky, float slope) {
-  constexpr int VW = 16 / (int)sizeof(T), U = EW_UNROLL;
+  constexpr int VW = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float ew_tab[];       // [4][C]: sa, ta, sb, tb
+  for (int c = threadIdx.x; c < C; c += 256) {
+    ew_tab[c] = sa ? sa[c] : 1.f; ew_tab[C + c] = sa ? ta[c] : 0.f;
+    ew_tab[2 * C + c] = sb ? sb[c] : 1.f; ew_tab[3 * C + c] = sb ? tb[c] : 0.f;
+  }
+  __syncthreads();
   const int cv = C / VW;                                        // vectors per pixel
   const long stride = (long)gridDim.x * blockDim.x;             // a multiple of cv (host)
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c0 = (int)(i % cv) * VW;
   float s1[VW], t1[VW], s2[VW], t2[VW];
-#pragma unroll
-  for (int e = 0; e < VW; ++e) {
-    s1[e] = sa ? sa[c0 + e] : 1.f; t1[e] = sa ? ta[c0 + e] : 0.f;
-    s2[e] = sb ? sb[c0 + e] : 1.f; t2[e] = sb ? tb[c0 + e] : 0.f;
-  }
+  tab_row<VW>(ew_tab, C, 0, c0, s1); tab_row<VW>(ew_tab, C, 1, c0, t1);
+  tab_row<VW>(ew_tab, C, 2, c0, s2); tab_row<VW>(ew_tab, C, 3, c0, t2);
   auto finish = [&](const i32x4& va, const i32x4& vb, long at) {
     float f[VW];
     chunk_to_f32<T>(va, f);
@@ -596,21 +624,23 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
     }
     *reinterpret_cast<i32x4*>(y + at * VW) = f32_to_chunk<T>(f);
   };
-  for (; i + (U - 1) * stride < nvec; i += U * stride) {
-    i32x4 va[U], vb[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      va[u] = *reinterpret_cast<const i32x4*>(a + (i + u * stride) * VW);
-      if (b) vb[u] = *reinterpret_cast<const i32x4*>(b + (i + u * stride) * VW);
+  if (b) {
+    for (; i + stride < nvec; i += 2 * stride) {
+      i32x4 a0 = ld16(a, i), a1 = ld16(a, i + stride), b0 = ld16(b, i), b1 = ld16(b, i + stride);
+      issued(a0, a1, b0, b1);
+      finish(a0, b0, i); finish(a1, b1, i + stride);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) finish(va[u], vb[u], i + u * stride);
+  } else {
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+      i32x4 a0 = ld16(a, i), a1 = ld16(a, i + stride), a2 = ld16(a, i + 2 * stride), a3 = ld16(a, i + 3 * stride);
+      issued(a0, a1, a2, a3);
+      finish(a0, a0, i); finish(a1, a1, i + stride); finish(a2, a2, i + 2 * stride); finish(a3, a3, i + 3 * stride);
+    }
   }
   for (; i < nvec; i += stride) {
-    const i32x4 va = *reinterpret_cast<const i32x4*>(a + i * VW);
-    i32x4 vb = va;
-    if (b) vb = *reinterpret_cast<const i32x4*>(b + i * VW);
-    finish(va, vb, i);
+    i32x4 a0 = ld16(a, i), b0 = b ? ld16(b, i) : a0;
+    issued(a0, b0);
+    finish(a0, b0, i);
   }
 }
 
@@ -734,64 +764,88 @@ __global__ __launch_bounds__(RED_NT) void bn_act_bwd_reduce_vec_kernel(const T* 
                                                                     long nvec, int C, int leaky, float slope,
                                                                     const float* __restrict__ msc, const float* __restrict__ msh) {
   // msc / msh (optional): the forward's scale / shift -- the LeakyReLU mask is recomputed from x (sign of fmaf(x, scale, shift), the
-  // expression affine_act_vec_kernel evaluated) instead of read from the stored output: one tensor less to read
+  // expression affine_act_vec_kernel evaluated) instead of read from the stored output: one tensor less to read, none to write
   constexpr int VW = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float ew_tab[];       // [4][C]: mean, rstd, msc, msh; behind the loop: red[2][RED_NT][VW + 1]
+  for (int c = threadIdx.x; c < C; c += RED_NT) {
+    ew_tab[c] = mean ? mean[c] : 0.f; ew_tab[C + c] = rstd ? rstd[c] : 1.f;
+    ew_tab[2 * C + c] = msc ? msc[c] : 0.f; ew_tab[3 * C + c] = msc ? msh[c] : 0.f;
+  }
+  __syncthreads();
   const int cv = C / VW;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c0 = (int)(i % cv) * VW;
-  float mu[VW], rs[VW], s1[VW], s2[VW], ms[VW], mt[VW];
+  float mu[VW], rs[VW], s1[VW], s2[VW];
+  tab_row<VW>(ew_tab, C, 0, c0, mu); tab_row<VW>(ew_tab, C, 1, c0, rs);
 #pragma unroll
-  for (int e = 0; e < VW; ++e) {
-    mu[e] = mean ? mean[c0 + e] : 0.f; rs[e] = rstd ? rstd[c0 + e] : 1.f; s1[e] = 0.f; s2[e] = 0.f;
-    ms[e] = msc ? msc[c0 + e] : 0.f; mt[e] = msc ? msh[c0 + e] : 0.f;
-  }
-  if (msc != nullptr) {                                       // recomputed mask, no g_out: two streams, two iterations in flight
-    for (; i < nvec; i += 2 * stride) {
-      const bool two = i + stride < nvec;
-      const i32x4 vg0 = *reinterpret_cast<const i32x4*>(dy + i * VW), vx0 = *reinterpret_cast<const i32x4*>(x + i * VW);
-      i32x4 vg1 = vg0, vx1 = vx0;
-      if (two) { vg1 = *reinterpret_cast<const i32x4*>(dy + (i + stride) * VW); vx1 = *reinterpret_cast<const i32x4*>(x + (i + stride) * VW); }
+  for (int e = 0; e < VW; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (msc != nullptr) {
+    float ms[VW], mt[VW];
+    tab_row<VW>(ew_tab, C, 2, c0, ms); tab_row<VW>(ew_tab, C, 3, c0, mt);
+    auto take = [&](const i32x4& vg, const i32x4& vx) {
+      float g[VW], xv[VW];
+      chunk_to_f32<T>(vg, g);
+      chunk_to_f32<T>(vx, xv);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (h == 1 && !two) break;
-        float g[VW], xv[VW];
-        chunk_to_f32<T>(h ? vg1 : vg0, g);
-        chunk_to_f32<T>(h ? vx1 : vx0, xv);
-#pragma unroll
-        for (int e = 0; e < VW; ++e) {
-          if (fmaf(xv[e], ms[e], mt[e]) <= 0.f) g[e] *= slope;
-          s1[e] += g[e];
-          s2[e] += g[e] * (xv[e] - mu[e]) * rs[e];
-        }
+      for (int e = 0; e < VW; ++e) {
+        if (fmaf(xv[e], ms[e], mt[e]) <= 0.f) g[e] *= slope;
+        s1[e] += g[e];
+        s2[e] += g[e] * (xv[e] - mu[e]) * rs[e];
       }
+    };
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+      i32x4 g0 = ld16(dy, i), g1 = ld16(dy, i + stride), g2 = ld16(dy, i + 2 * stride), g3 = ld16(dy, i + 3 * stride);
+      i32x4 x0 = ld16(x, i), x1 = ld16(x, i + stride), x2 = ld16(x, i + 2 * stride), x3 = ld16(x, i + 3 * stride);
+      issued(g0, g1, g2, g3, x0, x1, x2, x3);
+      take(g0, x0); take(g1, x1); take(g2, x2); take(g3, x3);
     }
-  } else
-  for (; i < nvec; i += stride) {
-    float g[VW];
-    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(dy + i * VW), g);
-    if (leaky) {
-      float yv[VW];
-      chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(y + i * VW), yv);
-#pragma unroll
-      for (int e = 0; e < VW; ++e) g[e] = yv[e] <= 0.f ? g[e] * slope : g[e];
+    for (; i < nvec; i += stride) {
+      i32x4 g0 = ld16(dy, i), x0 = ld16(x, i);
+      issued(g0, x0);
+      take(g0, x0);
     }
-    if (g_out) {
-      const i32x4 gv = f32_to_chunk<T>(g);
-      *reinterpret_cast<i32x4*>(g_out + i * VW) = gv;
-      chunk_to_f32<T>(gv, g);                           // the sums see what was stored (as the scalar kernel's do)
+  } else {
+    auto take = [&](const i32x4& vg, const i32x4& vy, const i32x4& vx, long at) {
+      float g[VW];
+      chunk_to_f32<T>(vg, g);
+      if (leaky) {
+        float yv[VW];
+        chunk_to_f32<T>(vy, yv);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) g[e] = yv[e] <= 0.f ? g[e] * slope : g[e];
+      }
+      if (g_out) {
+        const i32x4 gv = f32_to_chunk<T>(g);
+        *reinterpret_cast<i32x4*>(g_out + at * VW) = gv;
+        chunk_to_f32<T>(gv, g);                           // the sums see what was stored (as the scalar kernel's do)
+      }
+#pragma unroll
+      for (int e = 0; e < VW; ++e) s1[e] += g[e];
+      if (x) {
+        float xv[VW];
+        chunk_to_f32<T>(vx, xv);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s2[e] += g[e] * (xv[e] - mu[e]) * rs[e];
+      }
+    };
+    for (; i + stride < nvec; i += 2 * stride) {
+      i32x4 g0 = ld16(dy, i), g1 = ld16(dy, i + stride);
+      i32x4 y0 = leaky ? ld16(y, i) : g0, y1 = leaky ? ld16(y, i + stride) : g1;
+      i32x4 x0 = x ? ld16(x, i) : g0, x1 = x ? ld16(x, i + stride) : g1;
+      issued(g0, g1, y0, y1, x0, x1);
+      take(g0, y0, x0, i); take(g1, y1, x1, i + stride);
     }
-#pragma unroll
-    for (int e = 0; e < VW; ++e) s1[e] += g[e];
-    if (x) {
-      float xv[VW];
-      chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(x + i * VW), xv);
-#pragma unroll
-      for (int e = 0; e < VW; ++e) s2[e] += g[e] * (xv[e] - mu[e]) * rs[e];
+    for (; i < nvec; i += stride) {
+      i32x4 g0 = ld16(dy, i);
+      i32x4 y0 = leaky ? ld16(y, i) : g0, x0 = x ? ld16(x, i) : g0;
+      issued(g0, y0); issued(g0, x0);
+      take(g0, y0, x0, i);
     }
   }
   if (sum_g == nullptr) return;
-  __shared__ float red[2][RED_NT][VW + 1];
+  __syncthreads();                                              // every thread is through with the table: the space is red[][][] now
+  float (*red)[RED_NT][VW + 1] = reinterpret_cast<float (*)[RED_NT][VW + 1]>(ew_tab);
 #pragma unroll
   for (int e = 0; e < VW; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
   __syncthreads();
@@ -811,44 +865,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
                                                                const float* __restrict__ sum_gx, T* __restrict__ dx, long nvec,
                                                                int C, float invM, const float* __restrict__ msc,
                                                                const float* __restrict__ msh, float slope) {
-  // msc / msh (optional): g holds the gradient BEHIND the LeakyReLU and the mask is recomputed from x (see the reducing kernel)
+  // dx = gamma rstd (g - mean(g) - xhat mean(g xhat));  msc / msh (optional): g holds the gradient BEHIND the LeakyReLU and the
+  // mask is recomputed from x (see the reducing kernel)
   constexpr int VW = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float ew_tab[];       // [6][C]: gamma rstd, mean(g), mean, rstd mean(g xhat), msc, msh
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float rs = rstd[c];
+    ew_tab[c] = gamma[c] * rs; ew_tab[C + c] = sum_g[c] * invM; ew_tab[2 * C + c] = mean[c]; ew_tab[3 * C + c] = rs * (sum_gx[c] * invM);
+    ew_tab[4 * C + c] = msc ? msc[c] : 0.f; ew_tab[5 * C + c] = msc ? msh[c] : 1.f;          // (no mask: 0 x + 1 > 0)
+  }
+  __syncthreads();
   const int cv = C / VW;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c0 = (int)(i % cv) * VW;
-  float mu[VW], rs[VW], gr[VW], sg[VW], sgx[VW], ms[VW], mt[VW];
-#pragma unroll
-  for (int e = 0; e < VW; ++e) {
-    mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; gr[e] = gamma[c0 + e] * rs[e];
-    sg[e] = sum_g[c0 + e] * invM; sgx[e] = sum_gx[c0 + e] * invM;
-    ms[e] = msc ? msc[c0 + e] : 0.f; mt[e] = msc ? msh[c0 + e] : 1.f;          // (no mask: 0 * x + 1 > 0)
-  }
+  float gr[VW], sg[VW], mu[VW], q[VW], ms[VW], mt[VW];
+  tab_row<VW>(ew_tab, C, 0, c0, gr); tab_row<VW>(ew_tab, C, 1, c0, sg); tab_row<VW>(ew_tab, C, 2, c0, mu);
+  tab_row<VW>(ew_tab, C, 3, c0, q); tab_row<VW>(ew_tab, C, 4, c0, ms); tab_row<VW>(ew_tab, C, 5, c0, mt);
   auto finish = [&](const i32x4& vx, const i32x4& vg, long at) {
     float xv[VW], gv[VW];
     chunk_to_f32<T>(vx, xv);
     chunk_to_f32<T>(vg, gv);
-    if (msc != nullptr) {
 #pragma unroll
-      for (int e = 0; e < VW; ++e) if (fmaf(xv[e], ms[e], mt[e]) <= 0.f) gv[e] *= slope;
+    for (int e = 0; e < VW; ++e) {
+      if (fmaf(xv[e], ms[e], mt[e]) <= 0.f) gv[e] *= slope;
+      gv[e] = gr[e] * (gv[e] - sg[e] - (xv[e] - mu[e]) * q[e]);
     }
-#pragma unroll
-    for (int e = 0; e < VW; ++e) gv[e] = gr[e] * (gv[e] - sg[e] - (xv[e] - mu[e]) * rs[e] * sgx[e]);
     *reinterpret_cast<i32x4*>(dx + at * VW) = f32_to_chunk<T>(gv);
   };
-  constexpr int U = EW_UNROLL;
-  for (; i + (U - 1) * stride < nvec; i += U * stride) {
-    i32x4 vx[U], vg[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      vx[u] = *reinterpret_cast<const i32x4*>(x + (i + u * stride) * VW);
-      vg[u] = *reinterpret_cast<const i32x4*>(g + (i + u * stride) * VW);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) finish(vx[u], vg[u], i + u * stride);
+  for (; i + stride < nvec; i += 2 * stride) {
+    i32x4 x0 = ld16(x, i), x1 = ld16(x, i + stride), g0 = ld16(g, i), g1 = ld16(g, i + stride);
+    issued(x0, x1, g0, g1);
+    finish(x0, g0, i); finish(x1, g1, i + stride);
   }
-  for (; i < nvec; i += stride)
-    finish(*reinterpret_cast<const i32x4*>(x + i * VW), *reinterpret_cast<const i32x4*>(g + i * VW), i);
+  for (; i < nvec; i += stride) {
+    i32x4 x0 = ld16(x, i), g0 = ld16(g, i);
+    issued(x0, g0);
+    finish(x0, g0, i);
+  }
 }
 
 template <typename T>
@@ -861,12 +915,18 @@ __global__ __launch_bounds__(RED_NT) void channel_stats_vec_kernel(const T* __re
   float s1[VW], s2[VW];
 #pragma unroll
   for (int e = 0; e < VW; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  for (; i < nvec; i += stride) {
+  auto take = [&](const i32x4& vx) {
     float v[VW];
-    chunk_to_f32<T>(*reinterpret_cast<const i32x4*>(x + i * VW), v);
+    chunk_to_f32<T>(vx, v);
 #pragma unroll
     for (int e = 0; e < VW; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+  };
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    i32x4 x0 = ld16(x, i), x1 = ld16(x, i + stride), x2 = ld16(x, i + 2 * stride), x3 = ld16(x, i + 3 * stride);
+    issued(x0, x1, x2, x3);
+    take(x0); take(x1); take(x2); take(x3);
   }
+  for (; i < nvec; i += stride) take(ld16(x, i));
   __shared__ float red[2][RED_NT][VW + 1];
 #pragma unroll
   for (int e = 0; e < VW; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
@@ -957,6 +1017,12 @@ static bool vec_ok(int C, int dtype, std::initializer_list<const void*> ptrs) {
   if (C % VW != 0 || 256 % (C / VW) != 0) return false;
   for (const void* q : ptrs) if (q != nullptr && (((uintptr_t)q) & 15) != 0) return false;
   return true;
+}
+
+// dynamic LDS of the reducing BatchNorm-backward kernel: its constant table [4][C], re-used as red[2][RED_NT][VW + 1]
+size_t red_lds(int C, int VW) {
+  const size_t tab = (size_t)4 * C * sizeof(float), red = (size_t)2 * RED_NT * (VW + 1) * sizeof(float);
+  return tab > red ? tab : red;
 }
 
 int grid_for(long total, int per_block, int cap) {
@@ -1067,9 +1133,9 @@ extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* 
     const long nvec = total / VW;
     const int gridv = grid_for(nvec, 256, EW_GRID);
     if (dtype == WMZ_BF16)
-      hipLaunchKernelGGL(affine_act_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, st, (const bf16_t*)a, sa, ta, (const bf16_t*)b, sb, tb, (bf16_t*)y, nvec, C, leaky, slope);
+      hipLaunchKernelGGL(affine_act_vec_kernel<bf16_t>, dim3(gridv), dim3(256), (size_t)4 * C * sizeof(float), st, (const bf16_t*)a, sa, ta, (const bf16_t*)b, sb, tb, (bf16_t*)y, nvec, C, leaky, slope);
     else
-      hipLaunchKernelGGL(affine_act_vec_kernel<float>, dim3(gridv), dim3(256), 0, st, (const float*)a, sa, ta, (const float*)b, sb, tb, (float*)y, nvec, C, leaky, slope);
+      hipLaunchKernelGGL(affine_act_vec_kernel<float>, dim3(gridv), dim3(256), (size_t)4 * C * sizeof(float), st, (const float*)a, sa, ta, (const float*)b, sb, tb, (float*)y, nvec, C, leaky, slope);
     WMZ_LAUNCH_CHECK("wmz_affine_act_nhwc");
     return WMZ_OK;
   }
@@ -1115,9 +1181,9 @@ extern "C" int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* d
     const long nvec = M * C / VW;
     const int gridv = grid_for(nvec, RED_NT * 4, 256);                 // (a multiple of C / VW vectors per sweep: 256 is)
     if (dtype == WMZ_BF16)
-      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridv), dim3(RED_NT), 0, st, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, (bf16_t*)g_out, sum_g, sum_gx, nvec, C, leaky, slope, nullptr, nullptr);
+      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridv), dim3(RED_NT), red_lds(C, 8), st, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, (bf16_t*)g_out, sum_g, sum_gx, nvec, C, leaky, slope, nullptr, nullptr);
     else
-      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridv), dim3(RED_NT), 0, st, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, (float*)g_out, sum_g, sum_gx, nvec, C, leaky, slope, nullptr, nullptr);
+      hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridv), dim3(RED_NT), red_lds(C, 4), st, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, (float*)g_out, sum_g, sum_gx, nvec, C, leaky, slope, nullptr, nullptr);
     WMZ_LAUNCH_CHECK("wmz_bn_act_bwd_reduce");
     return WMZ_OK;
   }
@@ -1140,9 +1206,9 @@ extern "C" int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean,
     const long nvec = M * C / VW;
     const int gridv = grid_for(nvec, 256, EW_GRID);
     if (dtype == WMZ_BF16)
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(gridv), dim3(256), (size_t)6 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
     else
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(gridv), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(gridv), dim3(256), (size_t)6 * C * sizeof(float), st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
     WMZ_LAUNCH_CHECK("wmz_bn_bwd_apply");
     return WMZ_OK;
   }
@@ -1172,11 +1238,11 @@ extern "C" int wmz_bn_leaky_bwd(const void* x, const void* dy, const float* scal
   const long nvec = M * C / VW;
   const int gridr = grid_for(nvec, RED_NT * 4, 256), grida = grid_for(nvec, 256, EW_GRID);
   if (dtype == WMZ_BF16) {
-    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridr), dim3(RED_NT), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)dy, mean, rstd, (bf16_t*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
-    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(grida), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridr), dim3(RED_NT), red_lds(C, 8), st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)dy, mean, rstd, (bf16_t*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(grida), dim3(256), (size_t)6 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
   } else {
-    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridr), dim3(RED_NT), 0, st, (const float*)x, (const float*)nullptr, (const float*)dy, mean, rstd, (float*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
-    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(grida), dim3(256), 0, st, (const float*)x, (const float*)dy, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridr), dim3(RED_NT), red_lds(C, 4), st, (const float*)x, (const float*)nullptr, (const float*)dy, mean, rstd, (float*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(grida), dim3(256), (size_t)6 * C * sizeof(float), st, (const float*)x, (const float*)dy, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
   }
   WMZ_LAUNCH_CHECK("wmz_bn_leaky_bwd");
   return WMZ_OK;
