@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 104
+#define WMZ_VERSION 105
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
@@ -514,8 +514,14 @@ int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean, const floa
  * receive dbeta / dgamma; dx = dL/dx.  Shapes: wmz_bn_leaky_bwd_supported(C, dtype) != 0 (the 16-byte kernels). */
 int wmz_bn_leaky_bwd_supported(int C, int dtype);
 int wmz_bn_leaky_bwd(const void* x, const void* dy, const float* scale, const float* shift, const float* mean,
-                     const float* rstd, const float* gamma, float* sum_g, float* sum_gx, void* dx, long M, int C, float slope,
-                     int dtype, void* stream);
+                     const float* rstd, const float* gamma, float* sum_g, float* sum_gx, const void* add, void* dx, long M, int C,
+                     float slope, int dtype, void* stream);
+/* wmz_bn_bwd_apply with dx += add (optional, [M, C] in the activations' dtype): the gradient x receives from its other consumer --
+ * a residual block's skip path (autoencoder.py:35-42, :119-131) -- summed by this pass instead of one of its own (the reference's
+ * autograd runs an add kernel there); wmz_bn_leaky_bwd's `add` is the same. */
+int wmz_bn_bwd_apply_add(const void* x, const void* g, const float* mean, const float* rstd, const float* gamma,
+                         const float* sum_g, const float* sum_gx, const void* add, void* dx, long M, int C, int dtype,
+                         void* stream);
 /* adjoint of wmz_bilinear2x_nhwc (gather form, deterministic): dy [B,2H,2W,C] -> dx [B,H,W,C]. */
 int wmz_bilinear2x_nhwc_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 

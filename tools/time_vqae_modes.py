@@ -1,12 +1,14 @@
-"""VQ-AE graphed training step with / without the weight-gradient side branch (development timing)."""
+"""VQ-AE graphed training step with / without the weight-gradient side branch, with / without the skip gradients summed inside
+the backward kernels (development timing, one process)."""
 import sys, time, torch
 sys.path.insert(0, '.')
-from world_modelz_amd import config
+from world_modelz_amd import config, autoencoder
 from world_modelz_amd.train_vqae import VqAutoEncoder
 from world_modelz_amd.train import VqaeTrainer
 config.set_compute_dtype(torch.bfloat16)
-for side in (True, False):
+for side, fuse in ((True, True), (True, False), (True, True), (True, False), (False, True)):
     config.set_wgrad_stream(side)
+    autoencoder.FUSE_SKIP_GRAD = fuse
     torch.manual_seed(7)
     ae = VqAutoEncoder(embedding_dim=64, num_embeddings=1024, downscale_steps=2, hidden_planes=128).cuda()
     tr = VqaeTrainer(ae, distributed=False)
@@ -19,5 +21,5 @@ for side in (True, False):
     for _ in range(20):
         tr.train_step(fr)
     torch.cuda.synchronize()
-    print(f'side branch {side}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per step')
+    print(f'side branch {side}, skip gradients fused {fuse}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per step')
     del tr, ae

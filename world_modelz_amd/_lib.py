@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16 = 0, 1
-EXPECTED_VERSION = 104      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
+EXPECTED_VERSION = 105      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -102,7 +102,8 @@ SIGNATURES = {
     'wmz_bn_act_bwd_reduce': [c_void_p] * 8 + [c_long, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_bn_bwd_apply': [c_void_p] * 8 + [c_long, c_int, c_int, c_void_p],
     'wmz_bn_leaky_bwd_supported': [c_int, c_int],
-    'wmz_bn_leaky_bwd': [c_void_p] * 10 + [c_long, c_int, c_float, c_int, c_void_p],
+    'wmz_bn_leaky_bwd': [c_void_p] * 11 + [c_long, c_int, c_float, c_int, c_void_p],
+    'wmz_bn_bwd_apply_add': [c_void_p] * 9 + [c_long, c_int, c_int, c_void_p],
     'wmz_bilinear2x_nhwc_bwd': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_affine_act_nhwc': [c_void_p] * 7 + [c_long, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_bilinear2x_nhwc': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],

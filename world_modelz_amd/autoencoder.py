@@ -89,13 +89,19 @@ def _wT_op(weight, dtype):
     return _cast.operand((weight,), dtype, 'convT', build)
 
 
+FUSE_SKIP_GRAD = True      # A/B (tools/time_vqae_modes.py): False = autograd sums the two gradients of a block's input by an add pass
+
+
 class _Conv2dFn(torch.autograd.Function):
     """y = conv(x) [+ bias] [+ residual] on the HIP kernels; want_stats: also the per-channel (sum, sum of squares) of the stored
     y -- the batch statistics of the BatchNorm behind the conv -- from the conv's own epilogue instead of a pass over y
-    (non-differentiable outputs).  Returns (y, s, q); y has the output channels padded to a multiple of 8."""
+    (non-differentiable outputs).  Returns (y, s, q, x'); y has the output channels padded to a multiple of 8.
+    passthrough: x' is x handed on for its OTHER consumer (the skip path of a residual block) -- the gradient that consumer sends
+    back arrives HERE, as a second output's gradient, and rides in the data-gradient convolution's epilogue (its residual
+    operand) instead of an add pass of autograd's behind it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, residual, want_stats):
+    def forward(ctx, x, weight, bias, stride, pad, residual, want_stats, passthrough=False):
         k = weight.shape[2]
         dt = x.dtype
         bop = None
@@ -109,18 +115,19 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.bias = bias
         ctx.geom = (k, stride, pad, bias is not None, residual is not None)
         ctx.set_materialize_grads(False)          # (the statistics get no gradient: without this autograd zero-fills two tensors per call)
+        xp = x if passthrough else None
         if want_stats:
             y, s, q = out
             ctx.mark_non_differentiable(s, q)
-            return y, s, q
-        return out, None, None
+            return y, s, q, xp
+        return out, None, None, xp
 
     @staticmethod
-    def backward(ctx, dy, _ds, _dq):
+    def backward(ctx, dy, _ds, _dq, dskip):
         x, weight = ctx.saved_tensors
         k, stride, pad, has_bias, has_res = ctx.geom
         if dy is None:
-            return (None,) * 7
+            return (dskip,) + (None,) * 7
         co, ci = weight.shape[:2]
         cop, cip = _pad8(co), x.shape[-1]
         dy = dy.contiguous()
@@ -153,15 +160,18 @@ class _Conv2dFn(torch.autograd.Function):
                 dz = torch.zeros((B, (Ho - 1) * stride + 1 + op_h, (Wo - 1) * stride + 1 + op_w, cop), dtype=dy.dtype,
                                  device=dy.device)
                 dz[:, 0:(Ho - 1) * stride + 1:stride, 0:(Wo - 1) * stride + 1:stride] = dy
-            dx = ops.conv2d_nhwc(dz, _wT_op(weight, dy.dtype), k, k, 1, k - 1 - pad)
-        return dx, dw, db, None, None, (dy if has_res else None), None
+            dx = ops.conv2d_nhwc(dz, _wT_op(weight, dy.dtype), k, k, 1, k - 1 - pad,
+                                 residual=None if dskip is None else dskip.contiguous())
+        elif dskip is not None:
+            dx = dskip
+        return dx, dw, db, None, None, (dy if has_res else None), None, None
 
 
 class _BnActFn(torch.autograd.Function):
     """y = act(BatchNorm_train(x) [+ r]); updates the module's running statistics like nn.BatchNorm2d."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, r, bn, leaky, s=None, q=None):
+    def forward(ctx, x, gamma, beta, r, bn, leaky, s=None, q=None, passthrough=False):
         if s is None:
             s, q = ops.channel_stats_nhwc(x)
         scale, shift, mean, rstd = ops.bn_finalize(bn, s, q, _count(x), want_stats=True)
@@ -174,10 +184,13 @@ class _BnActFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, y, mean, rstd, gamma)
         ctx.beta = beta
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x) if passthrough else y                  # (x handed on for its other consumer: see _Conv2dFn)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
+        if dy is None:
+            return (dskip,) + (None,) * 8
         if ctx.remask:
             x, scale, shift, mean, rstd, gamma = ctx.saved_tensors
             y, remask = None, (scale, shift)
@@ -189,14 +202,14 @@ class _BnActFn(torch.autograd.Function):
         if gg is not None and gb is not None and getattr(gamma, '_wmz_single_use', False):
             # VqaeTrainer's arena: zeroed at the start of the step, this layer its slots' only writer -- the reduction's
             # atomics land there (28 zero fills and 28 `grad += g` launches fewer per step)
-            dx, _, _, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, into=(gg, gb), remask=remask)
+            dx, _, _, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, into=(gg, gb), remask=remask, add=dskip)
             for prm in (gamma, beta):
                 ready = getattr(prm, '_wmz_ready', None)
                 if ready is not None:
                     ready()
-            return dx, None, None, (g if ctx.has_r else None), None, None, None, None
-        dx, dgamma, dbeta, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, remask=remask)
-        return dx, dgamma, dbeta, (g if ctx.has_r else None), None, None, None, None
+            return dx, None, None, (g if ctx.has_r else None), None, None, None, None, None
+        dx, dgamma, dbeta, g = ops.bn_act_bwd(x, y, dy, mean, rstd, gamma.detach(), ctx.leaky, LEAKY, remask=remask, add=dskip)
+        return dx, dgamma, dbeta, (g if ctx.has_r else None), None, None, None, None, None
 
 
 class _Bilinear2xFn(torch.autograd.Function):
@@ -214,18 +227,22 @@ def _conv_g(x, conv, residual=None):
     return y if y.shape[-1] == conv.out_channels else y[..., :conv.out_channels]      # (output channels padded to 8 by the operand)
 
 
-def _conv_bnact_g(x, conv, bn, r=None, leaky=True):
-    """conv -> training-mode BatchNorm (-> + r) -> LeakyReLU under autograd, the batch statistics from the conv's epilogue."""
+def _conv_bnact_g(x, conv, bn, r=None, leaky=True, passthrough=False):
+    """conv -> training-mode BatchNorm (-> + r) -> LeakyReLU under autograd, the batch statistics from the conv's epilogue.
+    passthrough: -> (y, x') with x' = x for its other consumer (_Conv2dFn)."""
     if not bn.training or _pad8(conv.out_channels) != conv.out_channels:
-        return _bnact_g(_conv_g(x, conv), bn, r=r, leaky=leaky)
-    y, s, q = _Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], None, True)
-    return _BnActFn.apply(y, bn.weight, bn.bias, r, bn, leaky, s, q)
+        y = _bnact_g(_conv_g(x, conv), bn, r=r, leaky=leaky)
+        return (y, x) if passthrough else y
+    y, s, q, xp = _Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], None, True, passthrough)
+    y = _BnActFn.apply(y, bn.weight, bn.bias, r, bn, leaky, s, q)
+    return (y, xp) if passthrough else y
 
 
-def _bnact_g(x, bn, r=None, leaky=True):
+def _bnact_g(x, bn, r=None, leaky=True, passthrough=False):
     if not bn.training:
-        return _bnact_eval_g(x, bn, r, leaky)
-    return _BnActFn.apply(x, bn.weight, bn.bias, r, bn, leaky)
+        y = _bnact_eval_g(x, bn, r, leaky)
+        return (y, x) if passthrough else y
+    return _BnActFn.apply(x, bn.weight, bn.bias, r, bn, leaky, None, None, passthrough)
 
 
 def _bnact_eval_g(x, bn, r, leaky):
@@ -272,11 +289,13 @@ class Residual(nn.Module):
     def forward_nhwc(self, x, dtype):
         c1, bn1, c2, bn2 = self._block[0], self._block[1], self._block[3], self._block[4]
         if _grad_path(x, self):
-            h = _conv_bnact_g(x, c1, bn1)
+            # (x has two consumers -- c1 and the skip path; the skip path's gradient comes back through c1's Function and is
+            #  summed in its data-gradient convolution's epilogue)
+            h, xs = _conv_bnact_g(x, c1, bn1, passthrough=True) if FUSE_SKIP_GRAD else (_conv_bnact_g(x, c1, bn1), x)
             if self.downsample is not None:
-                r = _conv_bnact_g(x, self.downsample[0], self.downsample[1], leaky=False)
+                r = _conv_bnact_g(xs, self.downsample[0], self.downsample[1], leaky=False)
             else:
-                r = x
+                r = xs
             return _conv_bnact_g(h, c2, bn2, r=r)
         if bn1.training:
             h, s, q = _conv(x, c1, dtype, stats=True)
@@ -369,7 +388,8 @@ class UpscaleResidual(nn.Module):
 
     def forward_nhwc(self, x, dtype):
         if _grad_path(x, self):
-            h = _bnact_g(x, self.bn1)
+            # (the skip path's gradient is summed by bn1's backward pass)
+            h, x = _bnact_g(x, self.bn1, passthrough=True) if FUSE_SKIP_GRAD else (_bnact_g(x, self.bn1), x)
             if self.upsample:
                 h = _Bilinear2xFn.apply(h)
                 x = _Bilinear2xFn.apply(x)

@@ -706,14 +706,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                            const float* __restrict__ sum_gx, T* __restrict__ dx, long M,
-                                                           int C) {
+                                                           int C, const T* __restrict__ add) {
   const long total = M * C;
   const float invM = 1.f / (float)M;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const float rs = rstd[c];
     const float xh = (Elem<T>::to_f32(x[i]) - mean[c]) * rs;
-    const float v = gamma[c] * rs * (Elem<T>::to_f32(g[i]) - sum_g[c] * invM - xh * sum_gx[c] * invM);
+    float v = gamma[c] * rs * (Elem<T>::to_f32(g[i]) - sum_g[c] * invM - xh * sum_gx[c] * invM);
+    if (add) v += Elem<T>::to_f32(add[i]);
     dx[i] = Elem<T>::from_f32(v);
   }
 }
@@ -864,9 +865,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
                                                                const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                                const float* __restrict__ sum_gx, T* __restrict__ dx, long nvec,
                                                                int C, float invM, const float* __restrict__ msc,
-                                                               const float* __restrict__ msh, float slope) {
-  // dx = gamma rstd (g - mean(g) - xhat mean(g xhat));  msc / msh (optional): g holds the gradient BEHIND the LeakyReLU and the
-  // mask is recomputed from x (see the reducing kernel)
+                                                               const float* __restrict__ msh, float slope,
+                                                               const T* __restrict__ add) {
+  // dx = gamma rstd (g - mean(g) - xhat mean(g xhat)) [+ add];  msc / msh (optional): g holds the gradient BEHIND the LeakyReLU and
+  // the mask is recomputed from x (see the reducing kernel);  add (optional): the gradient x receives from its OTHER consumer (the
+  // skip path of a residual block) -- summed here instead of by a pass of its own behind this kernel
   constexpr int VW = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float ew_tab[];       // [6][C]: gamma rstd, mean(g), mean, rstd mean(g xhat), msc, msh
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
   float gr[VW], sg[VW], mu[VW], q[VW], ms[VW], mt[VW];
   tab_row<VW>(ew_tab, C, 0, c0, gr); tab_row<VW>(ew_tab, C, 1, c0, sg); tab_row<VW>(ew_tab, C, 2, c0, mu);
   tab_row<VW>(ew_tab, C, 3, c0, q); tab_row<VW>(ew_tab, C, 4, c0, ms); tab_row<VW>(ew_tab, C, 5, c0, mt);
-  auto finish = [&](const i32x4& vx, const i32x4& vg, long at) {
+  auto finish = [&](const i32x4& vx, const i32x4& vg, const i32x4& va, long at) {
     float xv[VW], gv[VW];
     chunk_to_f32<T>(vx, xv);
     chunk_to_f32<T>(vg, gv);
@@ -891,17 +894,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
       if (fmaf(xv[e], ms[e], mt[e]) <= 0.f) gv[e] *= slope;
       gv[e] = gr[e] * (gv[e] - sg[e] - (xv[e] - mu[e]) * q[e]);
     }
+    if (add) {
+      float av[VW];
+      chunk_to_f32<T>(va, av);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) gv[e] += av[e];
+    }
     *reinterpret_cast<i32x4*>(dx + at * VW) = f32_to_chunk<T>(gv);
   };
   for (; i + stride < nvec; i += 2 * stride) {
     i32x4 x0 = ld16(x, i), x1 = ld16(x, i + stride), g0 = ld16(g, i), g1 = ld16(g, i + stride);
-    issued(x0, x1, g0, g1);
-    finish(x0, g0, i); finish(x1, g1, i + stride);
+    i32x4 a0 = add ? ld16(add, i) : g0, a1 = add ? ld16(add, i + stride) : g1;
+    issued(x0, x1, g0, g1, a0, a1);
+    finish(x0, g0, a0, i); finish(x1, g1, a1, i + stride);
   }
   for (; i < nvec; i += stride) {
     i32x4 x0 = ld16(x, i), g0 = ld16(g, i);
-    issued(x0, g0);
-    finish(x0, g0, i);
+    i32x4 a0 = add ? ld16(add, i) : g0;
+    issued(x0, g0); issued(x0, a0);
+    finish(x0, g0, a0, i);
   }
 }
 
@@ -1196,29 +1207,35 @@ extern "C" int wmz_bn_act_bwd_reduce(const void* x, const void* y, const void* d
   return WMZ_OK;
 }
 
-extern "C" int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean, const float* rstd, const float* gamma,
-                                const float* sum_g, const float* sum_gx, void* dx, long M, int C, int dtype, void* stream) {
+extern "C" int wmz_bn_bwd_apply_add(const void* x, const void* g, const float* mean, const float* rstd, const float* gamma,
+                                    const float* sum_g, const float* sum_gx, const void* add, void* dx, long M, int C, int dtype,
+                                    void* stream) {
   WMZ_REQUIRE(x && g && mean && rstd && gamma && sum_g && sum_gx && dx && M > 0 && C > 0, "wmz_bn_bwd_apply: bad arguments");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_bn_bwd_apply: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(C, dtype, {x, g, dx})) {
+  if (vec_ok(C, dtype, {x, g, dx, add})) {
     const int VW = dtype == WMZ_BF16 ? 8 : 4;
     const long nvec = M * C / VW;
     const int gridv = grid_for(nvec, 256, EW_GRID);
     if (dtype == WMZ_BF16)
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(gridv), dim3(256), (size_t)6 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(gridv), dim3(256), (size_t)6 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f, (const bf16_t*)add);
     else
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(gridv), dim3(256), (size_t)6 * C * sizeof(float), st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f);
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(gridv), dim3(256), (size_t)6 * C * sizeof(float), st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, nullptr, nullptr, 1.f, (const float*)add);
     WMZ_LAUNCH_CHECK("wmz_bn_bwd_apply");
     return WMZ_OK;
   }
   const int grid = grid_for(M * C, 256, 4096);
   if (dtype == WMZ_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, M, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, M, C, (const bf16_t*)add);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, M, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)g, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, M, C, (const float*)add);
   WMZ_LAUNCH_CHECK("wmz_bn_bwd_apply");
   return WMZ_OK;
+}
+
+extern "C" int wmz_bn_bwd_apply(const void* x, const void* g, const float* mean, const float* rstd, const float* gamma,
+                                const float* sum_g, const float* sum_gx, void* dx, long M, int C, int dtype, void* stream) {
+  return wmz_bn_bwd_apply_add(x, g, mean, rstd, gamma, sum_g, sum_gx, nullptr, dx, M, C, dtype, stream);
 }
 
 extern "C" int wmz_bn_leaky_bwd_supported(int C, int dtype) {
@@ -1227,10 +1244,10 @@ extern "C" int wmz_bn_leaky_bwd_supported(int C, int dtype) {
 }
 
 extern "C" int wmz_bn_leaky_bwd(const void* x, const void* dy, const float* scale, const float* shift, const float* mean,
-                                const float* rstd, const float* gamma, float* sum_g, float* sum_gx, void* dx, long M, int C,
-                                float slope, int dtype, void* stream) {
+                                const float* rstd, const float* gamma, float* sum_g, float* sum_gx, const void* add, void* dx,
+                                long M, int C, float slope, int dtype, void* stream) {
   WMZ_REQUIRE(x && dy && scale && shift && mean && rstd && gamma && sum_g && sum_gx && dx && M > 0, "wmz_bn_leaky_bwd: bad arguments");
-  WMZ_REQUIRE(wmz_bn_leaky_bwd_supported(C, dtype) && vec_ok(C, dtype, {x, dy, dx}),
+  WMZ_REQUIRE(wmz_bn_leaky_bwd_supported(C, dtype) && vec_ok(C, dtype, {x, dy, dx, add}),
               "wmz_bn_leaky_bwd: C = %d / dtype %d / alignment not built (wmz_bn_leaky_bwd_supported; 16-byte aligned tensors)", C, dtype);
   WMZ_REQUIRE(slope >= 0.f && slope <= 1.f, "wmz_bn_leaky_bwd: LeakyReLU slope in [0, 1] expected");
   hipStream_t st = (hipStream_t)stream;
@@ -1239,10 +1256,10 @@ extern "C" int wmz_bn_leaky_bwd(const void* x, const void* dy, const float* scal
   const int gridr = grid_for(nvec, RED_NT * 4, 256), grida = grid_for(nvec, 256, EW_GRID);
   if (dtype == WMZ_BF16) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<bf16_t>, dim3(gridr), dim3(RED_NT), red_lds(C, 8), st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)dy, mean, rstd, (bf16_t*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
-    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(grida), dim3(256), (size_t)6 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16_t>, dim3(grida), dim3(256), (size_t)6 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma, sum_g, sum_gx, (bf16_t*)dx, nvec, C, 1.f / (float)M, scale, shift, slope, (const bf16_t*)add);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel<float>, dim3(gridr), dim3(RED_NT), red_lds(C, 4), st, (const float*)x, (const float*)nullptr, (const float*)dy, mean, rstd, (float*)nullptr, sum_g, sum_gx, nvec, C, 1, slope, scale, shift);
-    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(grida), dim3(256), (size_t)6 * C * sizeof(float), st, (const float*)x, (const float*)dy, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, scale, shift, slope);
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(grida), dim3(256), (size_t)6 * C * sizeof(float), st, (const float*)x, (const float*)dy, mean, rstd, gamma, sum_g, sum_gx, (float*)dx, nvec, C, 1.f / (float)M, scale, shift, slope, (const float*)add);
   }
   WMZ_LAUNCH_CHECK("wmz_bn_leaky_bwd");
   return WMZ_OK;

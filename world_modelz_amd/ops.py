@@ -902,12 +902,13 @@ def bn_leaky_bwd_supported(x):
     return bool(L.lib().wmz_bn_leaky_bwd_supported(x.shape[-1], L.dtype_code(x.dtype))) and x.is_contiguous() and x.data_ptr() % 16 == 0
 
 
-def bn_act_bwd(x, y, dy, mean, rstd, gamma, leaky, slope=0.01, into=None, remask=None):
+def bn_act_bwd(x, y, dy, mean, rstd, gamma, leaky, slope=0.01, into=None, remask=None, add=None):
     """Training-mode BatchNorm (+ LeakyReLU) backward -> (dx, dgamma, dbeta, g) ; g = dy * act'(y).
     into = (dgamma, dbeta): fp32 [C] buffers that are ZERO on entry and receive the two column sums in place (the parameters'
     slots of a freshly zeroed gradient arena, each written once per step: no zero fills here, no `grad += g` afterwards).
     remask = (scale, shift) of the forward, for a LeakyReLU layer WITHOUT a skip input: the mask is recomputed from x, y is not
-    read and g not produced (returned as None) -- wmz_bn_leaky_bwd, 5 tensor passes instead of 7."""
+    read and g not produced (returned as None) -- wmz_bn_leaky_bwd, 5 tensor passes instead of 7.
+    add (optional, like x): dx += add inside the apply pass -- the gradient x receives from its other consumer (a skip path)."""
     C = dy.shape[-1]
     M = dy.numel() // C
     dy = dy.contiguous()
@@ -918,16 +919,19 @@ def bn_act_bwd(x, y, dy, mean, rstd, gamma, leaky, slope=0.01, into=None, remask
         sg, sgx = torch.zeros((2, C), dtype=torch.float32, device=dy.device).unbind(0)      # one fill for both
     dt = L.dtype_code(dy.dtype)
     dx = torch.empty_like(dy)
+    if add is not None:
+        add = add.contiguous()
+        assert add.shape == dy.shape and add.dtype == dy.dtype
     if remask is not None:
         assert leaky and bn_leaky_bwd_supported(x) and dy.data_ptr() % 16 == 0
         L.call('wmz_bn_leaky_bwd', L.ptr(x), L.ptr(dy), L.ptr(remask[0]), L.ptr(remask[1]), L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
-               L.ptr(sg), L.ptr(sgx), L.ptr(dx), M, C, float(slope), dt, L.stream())
+               L.ptr(sg), L.ptr(sgx), L.ptr(add), L.ptr(dx), M, C, float(slope), dt, L.stream())
         return dx, sgx, sg, None
     g = torch.empty_like(dy)
     L.call('wmz_bn_act_bwd_reduce', L.ptr(x), L.ptr(y), L.ptr(dy), L.ptr(mean), L.ptr(rstd), L.ptr(g), L.ptr(sg),
            L.ptr(sgx), M, C, 1 if leaky else 0, float(slope), dt, L.stream())
-    L.call('wmz_bn_bwd_apply', L.ptr(x), L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(sg), L.ptr(sgx), L.ptr(dx),
-           M, C, dt, L.stream())
+    L.call('wmz_bn_bwd_apply_add', L.ptr(x), L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(sg), L.ptr(sgx), L.ptr(add),
+           L.ptr(dx), M, C, dt, L.stream())
     return dx, sgx, sg, g
 
 
