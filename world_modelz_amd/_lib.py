@@ -26,6 +26,7 @@ SIGNATURES = {
     'wmz_local3d_attn_fwd': [c_void_p] * 6 + [c_int] * 9 + [c_long] * 4 + [c_int, c_void_p],
     'wmz_local3d_attn_fwd_general': [c_void_p] * 6 + [c_int] * 9 + [c_long] * 4 + [c_int, c_void_p],
     'wmz_debug_attn_knobs': [c_int, c_int],
+    'wmz_debug_linear_knobs': [c_int],
     'wmz_local3d_attn_bwd': [c_void_p] * 10 + [c_int] * 9 + [c_long] * 8 + [c_int, c_void_p],
     'wmz_linear_wgrad': [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                         + [c_int, c_int, c_void_p],

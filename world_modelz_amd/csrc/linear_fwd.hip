@@ -28,7 +28,16 @@ struct LinParams {
   int flags, out_f32;
   int nbn;
   int rpb; long bstride;                     // A rows in blocks: row m lives at A + (m / rpb) * bstride + (m % rpb) * lda (rpb 0: plain)
+  int dma;                                   // BM = 64, bf16, no prologue: the K loop as an LDS-DMA ring (linear_launch decides)
 };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait_for3(s16x8& a, s16x8& b, s16x8& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
 
 // address of A row m (blocked rows: the last frame of every clip, x[:, -1], read in place)
 template <typename T> __device__ __forceinline__ const T* a_row(const LinParams& P, int m) {
@@ -80,7 +89,9 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = CPR * EPC;              // 64 (bf16) / 32 (f32)
   constexpr int KSTEPS = BK / 16;
-  __shared__ __attribute__((aligned(16))) char tiles[(BM + BN) * ROWB];   // A slab | B slab; reused by the epilogue
+  constexpr bool DMA_FORM = PRO == 0 && BM == 64 && sizeof(T) == 2;       // (a ring of three slab pairs instead of one)
+  constexpr int SLAB = (BM + BN) * ROWB;
+  __shared__ __attribute__((aligned(1024))) char tiles[(DMA_FORM ? 3 : 1) * SLAB];   // A slab | B slab; reused by the epilogue
   char* As = tiles;
   char* Bs = tiles + BM * ROWB;
   __shared__ float mean_s[BM], rstd_s[BM];
@@ -248,6 +259,85 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  bool k_done = false;
+  if constexpr (DMA_FORM) {
+    if (P.dma) {
+      // ---- small-M GEMMs (config 5: 3 072 rows per GPU; the last-frame logits): with one workgroup per CU the register-staged loop
+      // below is a chain of memory round trips (~2 us per 64-wide slab, 16 us for K = 512).  Here the slabs travel by LDS-DMA into a
+      // ring of three (two in flight while one is multiplied), the XOR swizzle applied on the SOURCE side (lane p of a 1 KB piece
+      // fetches the chunk that belongs at LDS position p), one raw barrier per slab; the fragment reads are inline asm with counted
+      // waits -- a compiler-visible LDS read behind a pending LDS-DMA gets a vmcnt(0) in front, i.e. drains the prefetch.
+      using S2 = std::integral_constant<int, 2>;
+      const int lr = lane >> 3, lc = lane & 7;
+      const char* asrc[2];
+      const char* bsrc[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = 8 * (wave + 4 * q) + lr;
+        asrc[q] = reinterpret_cast<const char*>(a_row<T>(P, min(m0 + r, P.M - 1))) + ((lc ^ (swz128(r) >> 4)) << 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 8 * (wave + 4 * q) + lr;
+        bsrc[q] = reinterpret_cast<const char*>(Wt + (long)min(n0 + r, P.N - 1) * K) + ((lc ^ (swz128(r) >> 4)) << 4);
+      }
+      auto issue = [&](auto bufc, int sl) {
+        constexpr int B = decltype(bufc)::value;
+        char* dst = tiles + B * SLAB;
+        const long ko = (long)sl * ROWB;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + ko), (lptr_t)(dst + (wave + 4 * q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[q] + ko), (lptr_t)(dst + BM * ROWB + (wave + 4 * q) * 1024), 16, 0, 0);
+      };
+      // fragment addresses: row l31 (+ 32 for the second A block; + 32 wave for this wave's weight rows: the swizzle of row r + 32 is
+      // that of r), byte (32 kk + 16 hh) ^ swizzle -- the XOR is not an immediate, so one address per k-step
+      unsigned aA[KSTEPS], aB[KSTEPS];
+      {
+        const unsigned base = lds_addr(tiles) + (unsigned)l31 * ROWB;
+        const int t = (hh * 16) ^ swz128(l31);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+          aA[kk] = base + (unsigned)((kk * 32) ^ t);
+          aB[kk] = aA[kk] + (unsigned)(BM * ROWB + wave * 32 * ROWB);
+        }
+      }
+      auto step = [&](auto bufc, int sl, int nsl) {
+        constexpr int B = decltype(bufc)::value;
+        if (sl + 1 < nsl) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // (six requests per wave and slab)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (sl + 2 < nsl) issue(std::integral_constant<int, (B + 2) % 3>{}, sl + 2);
+        s16x8 fa[KSTEPS], fb[KSTEPS], fw[KSTEPS];
+        static_for<KSTEPS>([&](auto kc) {
+          constexpr int kk = decltype(kc)::value;
+          fa[kk] = ds_read_b128_asm<B * SLAB>(aA[kk]);
+          fb[kk] = ds_read_b128_asm<B * SLAB + 32 * ROWB>(aA[kk]);
+          fw[kk] = ds_read_b128_asm<B * SLAB>(aB[kk]);
+        });
+        static_for<KSTEPS>([&](auto kc) {
+          constexpr int kk = decltype(kc)::value;
+          lgkm_wait_for3<3 * (KSTEPS - 1 - kk)>(fa[kk], fb[kk], fw[kk]);
+          Frag8<T> a0, a1, w;
+          a0.v = fa[kk]; a1.v = fb[kk]; w.v = fw[kk];
+          mma32(acc[0][0], a0, w);
+          mma32(acc[1][0], a1, w);
+        });
+      };
+      const int nsl = K / BK;
+      issue(S0{}, 0);
+      if (nsl > 1) issue(S1{}, 1);
+      for (int sl = 0; sl < nsl; sl += 3) {
+        step(S0{}, sl, nsl);
+        if (sl + 1 < nsl) step(S1{}, sl + 1, nsl);
+        if (sl + 2 < nsl) step(S2{}, sl + 2, nsl);
+      }
+      k_done = true;
+    }
+  }
+  if (!k_done) {
   fetch(S0{}, 0);
   fetch(S1{}, BK);                                       // (a slab past K re-reads the last chunk column; it is never stashed)
   for (int k0 = 0; k0 < K; k0 += 2 * BK) {
@@ -263,6 +353,7 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
     __syncthreads();
     fetch(S1{}, k0 + 3 * BK);
     compute();
+  }
   }
 
   // epilogue: D col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -392,6 +483,9 @@ extern "C" int wmz_linear_fwd(const void* A, long lda, const void* Wt, const flo
                               flags, out_f32, dtype, stream);
 }
 
+static int g_linear_dma = 1;
+extern "C" int wmz_debug_linear_knobs(int dma) { g_linear_dma = dma; return WMZ_OK; }      // (development A/B: 0 = the register-staged loop)
+
 static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtype, hipStream_t st) {
   const bool ln = ln_gamma != nullptr;
   const bool gin = (flags & WMZ_LIN_GELU_IN) != 0;
@@ -401,6 +495,8 @@ static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtyp
   // the chip (a 16-bit output then leaves by per-lane stores: fine at these sizes)
   const bool small = (long)wmz_cdiv(P.M, 128) * P.nbn < (P.out_f32 ? 192 : 320) && (dtype == WMZ_BF16 || (!ln && !gin));
   const int bm = small ? 64 : 128;
+  const uintptr_t al = (uintptr_t)P.A | (uintptr_t)P.Wt | (uintptr_t)(P.lda * 2) | (uintptr_t)(P.bstride * 2);
+  P.dma = (small && dtype == WMZ_BF16 && !ln && !gin && P.K % 64 == 0 && (al & 15) == 0 && g_linear_dma) ? 1 : 0;
   dim3 grid((unsigned)(wmz_cdiv(P.M, bm) * P.nbn)), block(NT);
   if (dtype == WMZ_BF16) {
     if (small && ln) hipLaunchKernelGGL((linear_kernel<bf16_t, 1, 64>), grid, block, 0, st, P);

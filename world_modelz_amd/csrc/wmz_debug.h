@@ -23,6 +23,10 @@ int wmz_debug_attn_knobs(int dbg, int variant);
  * workgroup per CU; dbg = ablation switches (1 skip the epilogue, 2 one weight slab only: timing experiments, results are garbage). */
 int wmz_debug_conv_knobs(int skew, int dbg);
 
+/* development knob of the nn.Linear kernel (csrc/linear_fwd.hip): dma = 0 runs the small-M GEMMs on the register-staged K loop
+ * instead of the LDS-DMA ring (A/B timing; same results). */
+int wmz_debug_linear_knobs(int dma);
+
 #ifdef __cplusplus
 }
 #endif
