@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 105
+#define WMZ_VERSION 106
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
@@ -460,6 +460,25 @@ int wmz_conv_point_pack(const void* w_op, void* wpack, int K, int Cout, void* st
 int wmz_conv_point_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale, const float* shift,
                        float* stat_sum, float* stat_sq, const float* in_scale, const float* in_shift, float in_slope, int B, int Hi,
                        int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope, void* stream);
+/* A training-mode nn.BatchNorm2d (autoencoder.py:21-25) handed to the kernel that APPLIES it as its raw batch statistics: that kernel
+ * does what wmz_bn_finalize does -- same arithmetic -- while it sets up its per-channel constants, and one of its workgroups moves the
+ * running statistics (momentum, unbiased variance), increments *num_batches_tracked and writes the optional outputs (scale / shift /
+ * mean / rstd of this batch, for the backward pass): no wmz_bn_finalize launch between a convolution and its consumer.  A HOST
+ * struct of DEVICE pointers, read at call time.  sum / sq: [WMZ_STAT_REPLICAS][C] as the producer left them; count = B Ho Wo. */
+typedef struct wmz_bn_stats {
+  const float* sum; const float* sq;
+  const float* gamma; const float* beta;            /* NULL: 1 / 0 */
+  float* running_mean; float* running_var;          /* both or neither */
+  int64_t* num_batches_tracked;                     /* or NULL */
+  float* scale; float* shift;                       /* out [C], both or neither */
+  float* mean; float* rstd;                         /* out [C], both or neither */
+  double count, momentum, eps;
+} wmz_bn_stats;
+/* wmz_conv_point_fwd with the input prologue's BatchNorm given as raw statistics (in_bn; then in_scale = in_shift = NULL). */
+int wmz_conv_point_fwd_bn(const void* x, const void* wpack, void* out, const float* bias, const float* scale, const float* shift,
+                          float* stat_sum, float* stat_sq, const float* in_scale, const float* in_shift, const wmz_bn_stats* in_bn,
+                          float in_slope, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky,
+                          float slope, void* stream);
 /* logical NCHW frames (contiguous; in_dtype) -> NHWC with the channels zero-padded to a multiple of 8 (out_dtype): the layout
  * flip in front of the encoder's first convolution (autoencoder.py:83; the reference's modules take NCHW) as one pass. */
 int wmz_nchw_to_nhwc8(const void* x, void* y, int B, int C, int H, int W, int in_dtype, int out_dtype, void* stream);
@@ -474,6 +493,13 @@ int wmz_bn_finalize(const float* sum, const float* sq, double count, const float
 /* y = act(a*sa + ta (+ b*sb + tb)) per channel on NHWC [M, C] (BatchNorm apply, skip add, LeakyReLU). */
 int wmz_affine_act_nhwc(const void* a, const float* sa, const float* ta, const void* b, const float* sb, const float* tb,
                         void* y, long M, int C, int leaky, float slope, int dtype, void* stream);
+/* The same with either operand's affine given as a training-mode BatchNorm's raw statistics (wmz_bn_stats; bna replaces sa / ta,
+ * bnb replaces sb / tb; NULL: the plain call).  Needs the 16-byte kernel: wmz_affine_act_bn_supported(C, dtype) != 0 and 16-byte
+ * aligned tensors. */
+int wmz_affine_act_bn_supported(int C, int dtype);
+int wmz_affine_act_nhwc_bn(const void* a, const float* sa, const float* ta, const wmz_bn_stats* bna, const void* b, const float* sb,
+                           const float* tb, const wmz_bn_stats* bnb, void* y, long M, int C, int leaky, float slope, int dtype,
+                           void* stream);
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (autoencoder.py:138) on NHWC. */
 int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 

@@ -682,3 +682,88 @@ def test_direct_3x3_stride2_conv_vs_the_implicit_gemm_kernel_and_torch(wmz, geom
     y = ops.conv2d_nhwc(x, w, 3, 3, 2, 1, bias=bias)
     assert float((y.float() - ref).norm() / ref.norm()) < 4e-3
 
+
+
+@pytest.mark.gpu
+def test_batchnorm_finalised_by_the_kernel_that_applies_it(wmz):
+    """include/wmz.h wmz_bn_stats (ops.BnLazy): a training-mode BatchNorm handed to its consumer -- the streaming 1x1 conv's input
+    prologue, wmz_affine_act_nhwc_bn -- as raw statistics is the same arithmetic as a wmz_bn_finalize launch in between (one device
+    function computes both).  The statistics themselves are summed by atomics in either mode, so two runs agree to fp32 summation
+    order, not bit for bit: tokens (a few near-ties may flip), running statistics, step counters, loss and gradients are compared
+    at that level; the kernel-level check below is exact."""
+    import copy
+    from world_modelz_amd import ops
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    torch.manual_seed(3)
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        ae_l = VqAutoEncoder(embedding_dim=64, num_embeddings=256, downscale_steps=2, hidden_planes=128).cuda()
+        ae_f = copy.deepcopy(ae_l)
+        frames = torch.rand(16, 3, 64, 64, device='cuda')
+        outs = {}
+        for lazy, ae in ((True, ae_l), (False, ae_f)):
+            ops.BN_LAZY = lazy
+            try:
+                with torch.no_grad():
+                    tok = ae.encode(frames)
+                recon, latent_loss, _ = ae(frames)
+                loss = torch.nn.functional.mse_loss(recon, frames) + 0.25 * latent_loss
+                loss.backward()
+            finally:
+                ops.BN_LAZY = True
+            outs[lazy] = (tok, float(loss))
+        assert float((outs[True][0] != outs[False][0]).float().mean()) < 0.02
+        assert abs(outs[True][1] - outs[False][1]) < 2e-3 * abs(outs[False][1])
+        n_bn = 0
+        for (n, ml), mf in zip(ae_l.named_modules(), ae_f.modules()):
+            if isinstance(ml, torch.nn.BatchNorm2d):
+                n_bn += 1
+                at = 3e-3 if n.startswith('decoder') else 1e-4          # (behind the codebook a flipped near-tie changes the input)
+                assert torch.allclose(ml.running_mean, mf.running_mean, rtol=1e-3, atol=at), n
+                assert torch.allclose(ml.running_var, mf.running_var, rtol=1e-2 if n.startswith('decoder') else 1e-3, atol=at / 10), n
+                assert int(ml.num_batches_tracked) == int(mf.num_batches_tracked) >= 1, n
+        assert n_bn >= 10
+    # gradients: through one residual block (no codebook in between, whose flipped near-ties move the whole encoder's gradient)
+    from world_modelz_amd.autoencoder import Residual
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        torch.manual_seed(4)
+        blk_l = Residual(64, 128, 2).cuda()
+        blk_f = copy.deepcopy(blk_l)
+        xin = torch.randn(8, 64, 32, 32, device='cuda')
+        dy = torch.randn(8, 64, 16, 16, device='cuda')
+        gin = {}
+        for lazy, blk in ((True, blk_l), (False, blk_f)):
+            ops.BN_LAZY = lazy
+            try:
+                xi = xin.clone().requires_grad_(True)
+                (blk(xi) * dy).sum().backward()
+            finally:
+                ops.BN_LAZY = True
+            gin[lazy] = xi.grad
+        assert rel(gin[True], gin[False]) < 2e-2
+        for (n, pl), pf in zip(blk_l.named_parameters(), blk_f.parameters()):
+            assert pl.grad is not None and pf.grad is not None and rel(pl.grad, pf.grad) < 2e-2, n
+    # kernel level, exact: the same statistics through both routes
+    C, M = 128, 4096
+    x = torch.randn(4, 32, 32, C, device='cuda').bfloat16()
+    r = torch.randn(4, 32, 32, C, device='cuda').bfloat16()
+    bn_a = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5)
+        bn_a.bias.normal_()
+    bn_b = copy.deepcopy(bn_a)
+    s, q = ops.channel_stats_nhwc(x)
+    lz = ops.BnLazy(bn_a, s, q, M, want_stats=True)
+    y_l = ops.affine_act_nhwc(x, lz, None, r, leaky=True)
+    sc, sh, mean, rstd = ops.bn_finalize(bn_b, s, q, M, want_stats=True)
+    y_f = ops.affine_act_nhwc(x, sc, sh, r, leaky=True)
+    assert torch.equal(y_l, y_f)
+    for a_, b_ in ((lz.scale, sc), (lz.shift, sh), (lz.mean, mean), (lz.rstd, rstd), (bn_a.running_mean, bn_b.running_mean),
+                   (bn_a.running_var, bn_b.running_var), (bn_a.num_batches_tracked, bn_b.num_batches_tracked)):
+        assert torch.equal(a_, b_)
+    # ... and as the streaming 1x1 conv's input prologue
+    w = (torch.randn(64, C, device='cuda') * 0.1).bfloat16()
+    bn_c, bn_d = copy.deepcopy(bn_a), copy.deepcopy(bn_a)
+    y_l = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, pre=(ops.BnLazy(bn_c, s, q, M), None, 0.01))
+    sc, sh = ops.bn_finalize(bn_d, s, q, M)
+    y_f = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, pre=(sc, sh, 0.01))
+    assert torch.equal(y_l, y_f) and torch.equal(bn_c.running_var, bn_d.running_var) and torch.equal(bn_c.running_mean, bn_d.running_mean)

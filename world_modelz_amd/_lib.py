@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16 = 0, 1
-EXPECTED_VERSION = 105      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
+EXPECTED_VERSION = 106      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -91,6 +91,9 @@ SIGNATURES = {
     'wmz_conv_point_pack_elems': [c_int, c_int],                           # returns long
     'wmz_conv_point_pack': [c_void_p, c_void_p, c_int, c_int, c_void_p],
     'wmz_conv_point_fwd': [c_void_p] * 10 + [c_float] + [c_int] * 10 + [c_float, c_void_p],
+    'wmz_conv_point_fwd_bn': [c_void_p] * 11 + [c_float] + [c_int] * 10 + [c_float, c_void_p],      # (.., in_shift, const wmz_bn_stats*, in_slope, ..)
+    'wmz_affine_act_bn_supported': [c_int, c_int],
+    'wmz_affine_act_nhwc_bn': [c_void_p] * 9 + [c_long, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_nchw_to_nhwc8': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_conv2d_nhwc_wgrad_batch': [c_int] + [c_void_p] * 17 + [c_long, c_int, c_void_p],
     'wmz_conv2d_nhwc_wgrad_is_direct': [c_int] * 10,
@@ -137,6 +140,13 @@ SIGNATURES = {
 
 class WmzError(RuntimeError):
     pass
+
+
+class BnStats(ctypes.Structure):
+    """include/wmz.h wmz_bn_stats: a host struct of device pointers, read by the call."""
+    _fields_ = [('sum', c_void_p), ('sq', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p),
+                ('running_var', c_void_p), ('num_batches_tracked', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
+                ('mean', c_void_p), ('rstd', c_void_p), ('count', c_double), ('momentum', c_double), ('eps', c_double)]
 
 
 def lib():

@@ -174,8 +174,9 @@ class _BnActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, r, bn, leaky, s=None, q=None, passthrough=False):
         if s is None:
             s, q = ops.channel_stats_nhwc(x)
-        scale, shift, mean, rstd = ops.bn_finalize(bn, s, q, _count(x), want_stats=True)
-        y = ops.affine_act_nhwc(x, scale, shift, b=r, leaky=leaky, slope=LEAKY)
+        lz = ops.bn_lazy(bn, s, q, _count(x), want_stats=True)      # (finalised by the launch that applies it)
+        y = ops.affine_act_nhwc(x, lz, None, b=r, leaky=leaky, slope=LEAKY)
+        scale, shift, mean, rstd = lz.scale, lz.shift, lz.mean, lz.rstd
         ctx.leaky, ctx.has_r = leaky, r is not None
         # without a skip input the backward recomputes the LeakyReLU mask from x and (scale, shift): y is not kept for it
         ctx.remask = leaky and r is None and ops.bn_leaky_bwd_supported(x)
@@ -298,16 +299,17 @@ class Residual(nn.Module):
                 r = xs
             return _conv_bnact_g(h, c2, bn2, r=r)
         if bn1.training:
+            # (every BatchNorm is finalised by the launch that applies it -- ops.bn_lazy: no launch between a conv and its consumer)
             h, s, q = _conv(x, c1, dtype, stats=True)
-            sc, sh = ops.bn_finalize(bn1, s, q, _count(h))
+            lz1 = ops.bn_lazy(bn1, s, q, _count(h))
             # BatchNorm apply + LeakyReLU ride in the 1x1 conv's operand staging (no pass over the hidden tensor)
-            h, s, q = _conv(h, c2, dtype, stats=True, pre=(sc, sh, LEAKY))
-            sc2, sh2 = ops.bn_finalize(bn2, s, q, _count(h))
+            h, s, q = _conv(h, c2, dtype, stats=True, pre=(lz1, None, LEAKY))
+            lz2 = ops.bn_lazy(bn2, s, q, _count(h))
             if self.downsample is not None:
                 r, s, q = _conv(x, self.downsample[0], dtype, stats=True)
-                sc3, sh3 = ops.bn_finalize(self.downsample[1], s, q, _count(r))
-                return ops.affine_act_nhwc(h, sc2, sh2, r, sc3, sh3, leaky=True, slope=LEAKY)
-            return ops.affine_act_nhwc(h, sc2, sh2, x, leaky=True, slope=LEAKY)
+                lz3 = ops.bn_lazy(self.downsample[1], s, q, _count(r))
+                return ops.affine_act_nhwc(h, lz2, None, r, lz3, None, leaky=True, slope=LEAKY)
+            return ops.affine_act_nhwc(h, lz2, None, x, leaky=True, slope=LEAKY)
         # eval: BatchNorm folds into the conv epilogues, the skip add + LeakyReLU into the 1x1 conv's
         sc, sh = ops.bn_finalize(bn1, None, None, 0)
         h = _conv(x, c1, dtype, scale=sc, shift=sh, leaky=True, slope=LEAKY)
@@ -399,7 +401,7 @@ class UpscaleResidual(nn.Module):
             return _conv_g(h, self.conv2, residual=x)              # (the skip add rides in conv2's epilogue)
         if self.bn1.training:
             s, q = ops.channel_stats_nhwc(x)
-            sc, sh = ops.bn_finalize(self.bn1, s, q, _count(x))
+            sc, sh = ops.bn_lazy(self.bn1, s, q, _count(x)), None
         else:
             sc, sh = ops.bn_finalize(self.bn1, None, None, 0)
         h = ops.affine_act_nhwc(x, sc, sh, leaky=True, slope=LEAKY)
@@ -408,8 +410,7 @@ class UpscaleResidual(nn.Module):
             x = ops.bilinear2x_nhwc(x)
         if self.bn2.training:
             h, s, q = _conv(h, self.conv1, dtype, stats=True)
-            sc, sh = ops.bn_finalize(self.bn2, s, q, _count(h))
-            h = ops.affine_act_nhwc(h, sc, sh, leaky=True, slope=LEAKY)
+            h = ops.affine_act_nhwc(h, ops.bn_lazy(self.bn2, s, q, _count(h)), None, leaky=True, slope=LEAKY)
         else:
             sc, sh = ops.bn_finalize(self.bn2, None, None, 0)
             h = _conv(h, self.conv1, dtype, scale=sc, shift=sh, leaky=True, slope=LEAKY)

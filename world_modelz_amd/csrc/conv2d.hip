@@ -8,6 +8,7 @@
 //          per-channel sum / sum-of-squares of the stored output (training-mode BatchNorm statistics).
 //   channel_stats / bn_finalize / affine_act / bilinear2x: the memory-bound companions.
 #include "wmz_common.h"
+#include "bn_lazy.h"
 #ifndef WMZ_ABL_NOSTAT
 #define WMZ_ABL_NOSTAT 0      // timing ablation (tools/build_variant.py): drop the global statistics atomics
 #endif
@@ -510,20 +511,17 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && training && num_batches_tracked != nullptr) *num_batches_tracked += 1;     // nn.BatchNorm2d's step counter
   if (c >= C) return;
-  float mean, var;
-  if (training) {
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < WMZ_STAT_REPLICAS; ++r) { s1 += sum[r * C + c]; s2 += sq[r * C + c]; }
-    mean = s1 / count;
-    var = fmaxf(s2 / count - mean * mean, 0.f);
-    const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-  } else {
-    mean = running_mean[c];
-    var = running_var[c];
+  if (training) {                                             // (bn_lazy.h: the arithmetic shared with the consumers that finalise themselves)
+    BnStats b{};
+    b.sum = sum; b.sq = sq; b.gamma = gamma; b.beta = beta; b.running_mean = running_mean; b.running_var = running_var;
+    b.nbt = nullptr;                                          // (counted above)
+    b.scale = scale; b.shift = shift; b.mean = mean_out; b.rstd = rstd_out;
+    b.count = count; b.momentum = momentum; b.eps = eps;
+    float sc, sh;
+    bn_channel(b, C, c, true, sc, sh);
+    return;
   }
+  const float mean = running_mean[c], var = running_var[c];
   const float rs = rsqrtf(var + eps);
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   scale[c] = g * rs;
@@ -592,12 +590,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict__ a, const float* __restrict__ sa,
                                                              const float* __restrict__ ta, const T* __restrict__ b,
                                                              const float* __restrict__ sb, const float* __restrict__ tb,
-                                                             T* __restrict__ y, long nvec, int C, int leaky, float slope) {
+                                                             T* __restrict__ y, long nvec, int C, int leaky, float slope,
+                                                             BnStats bna, BnStats bnb) {
+  // bna / bnb (sum != nullptr): the affine of that operand is a training-mode BatchNorm whose statistics arrive raw -- finalised here
+  // while the table is filled, published by workgroup 0 (bn_lazy.h)
   constexpr int VW = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float ew_tab[];       // [4][C]: sa, ta, sb, tb
   for (int c = threadIdx.x; c < C; c += 256) {
-    ew_tab[c] = sa ? sa[c] : 1.f; ew_tab[C + c] = sa ? ta[c] : 0.f;
-    ew_tab[2 * C + c] = sb ? sb[c] : 1.f; ew_tab[3 * C + c] = sb ? tb[c] : 0.f;
+    float s1v = sa ? sa[c] : 1.f, t1v = sa ? ta[c] : 0.f, s2v = sb ? sb[c] : 1.f, t2v = sb ? tb[c] : 0.f;
+    if (bna.sum != nullptr) bn_channel(bna, C, c, blockIdx.x == 0, s1v, t1v);
+    if (bnb.sum != nullptr) bn_channel(bnb, C, c, blockIdx.x == 0, s2v, t2v);
+    ew_tab[c] = s1v; ew_tab[C + c] = t1v; ew_tab[2 * C + c] = s2v; ew_tab[3 * C + c] = t2v;
   }
   __syncthreads();
   const int cv = C / VW;                                        // vectors per pixel
@@ -1129,12 +1132,18 @@ extern "C" int wmz_bn_finalize(const float* sum, const float* sq, double count, 
   return WMZ_OK;
 }
 
-extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* ta, const void* b, const float* sb,
-                                   const float* tb, void* y, long M, int C, int leaky, float slope, int dtype,
-                                   void* stream) {
+extern "C" int wmz_affine_act_bn_supported(int C, int dtype) {
+  const int VW = dtype == WMZ_BF16 ? 8 : 4;
+  return (dtype == WMZ_F32 || dtype == WMZ_BF16) && C > 0 && C % VW == 0 && 256 % (C / VW) == 0 ? 1 : 0;
+}
+
+extern "C" int wmz_affine_act_nhwc_bn(const void* a, const float* sa, const float* ta, const wmz_bn_stats* bna, const void* b,
+                                      const float* sb, const float* tb, const wmz_bn_stats* bnb, void* y, long M, int C, int leaky,
+                                      float slope, int dtype, void* stream) {
   WMZ_REQUIRE(a && y && M > 0 && C > 0 && C % 4 == 0, "wmz_affine_act_nhwc: bad arguments (C %% 4 == 0 required)");
   WMZ_REQUIRE((sa == nullptr) == (ta == nullptr) && (sb == nullptr) == (tb == nullptr), "wmz_affine_act_nhwc: scale/shift pairs");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_affine_act_nhwc: bad dtype %d", dtype);
+  WMZ_REQUIRE(bn_stats_ok(bna) && bn_stats_ok(bnb) && (bnb == nullptr || b != nullptr), "wmz_affine_act_nhwc_bn: incomplete wmz_bn_stats");
   const long total = M * C;
   hipStream_t st = (hipStream_t)stream;
   const int VW = dtype == WMZ_BF16 ? 8 : 4;
@@ -1144,12 +1153,13 @@ extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* 
     const long nvec = total / VW;
     const int gridv = grid_for(nvec, 256, EW_GRID);
     if (dtype == WMZ_BF16)
-      hipLaunchKernelGGL(affine_act_vec_kernel<bf16_t>, dim3(gridv), dim3(256), (size_t)4 * C * sizeof(float), st, (const bf16_t*)a, sa, ta, (const bf16_t*)b, sb, tb, (bf16_t*)y, nvec, C, leaky, slope);
+      hipLaunchKernelGGL(affine_act_vec_kernel<bf16_t>, dim3(gridv), dim3(256), (size_t)4 * C * sizeof(float), st, (const bf16_t*)a, sa, ta, (const bf16_t*)b, sb, tb, (bf16_t*)y, nvec, C, leaky, slope, bn_stats_from(bna), bn_stats_from(bnb));
     else
-      hipLaunchKernelGGL(affine_act_vec_kernel<float>, dim3(gridv), dim3(256), (size_t)4 * C * sizeof(float), st, (const float*)a, sa, ta, (const float*)b, sb, tb, (float*)y, nvec, C, leaky, slope);
+      hipLaunchKernelGGL(affine_act_vec_kernel<float>, dim3(gridv), dim3(256), (size_t)4 * C * sizeof(float), st, (const float*)a, sa, ta, (const float*)b, sb, tb, (float*)y, nvec, C, leaky, slope, bn_stats_from(bna), bn_stats_from(bnb));
     WMZ_LAUNCH_CHECK("wmz_affine_act_nhwc");
     return WMZ_OK;
   }
+  WMZ_REQUIRE(bna == nullptr && bnb == nullptr, "wmz_affine_act_nhwc_bn: raw BatchNorm statistics need the 16-byte kernel (wmz_affine_act_bn_supported, 16-byte aligned tensors)");
   const int grid = grid_for(total, 1024, 4096);
   if (dtype == WMZ_BF16)
     hipLaunchKernelGGL(affine_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)a, sa, ta, (const bf16_t*)b, sb, tb, (bf16_t*)y, total, C, leaky, slope);
@@ -1157,6 +1167,12 @@ extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* 
     hipLaunchKernelGGL(affine_act_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a, sa, ta, (const float*)b, sb, tb, (float*)y, total, C, leaky, slope);
   WMZ_LAUNCH_CHECK("wmz_affine_act_nhwc");
   return WMZ_OK;
+}
+
+extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* ta, const void* b, const float* sb,
+                                   const float* tb, void* y, long M, int C, int leaky, float slope, int dtype,
+                                   void* stream) {
+  return wmz_affine_act_nhwc_bn(a, sa, ta, nullptr, b, sb, tb, nullptr, y, M, C, leaky, slope, dtype, stream);
 }
 
 extern "C" int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {

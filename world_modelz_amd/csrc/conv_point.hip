@@ -15,6 +15,7 @@
 //     the bf16 tile transposed through the same LDS image into 16-byte stores of whole contiguous rows.
 // Same arithmetic as conv2d.hip's kernel (k order, epilogue): the same bits; statistics to fp32 summation order.
 #include "wmz_common.h"
+#include "bn_lazy.h"
 
 namespace {
 
@@ -28,6 +29,7 @@ struct PointParams {
   int gpt;           // 16-byte granules per tap = Cin / 8
   int nruns;         // M / 64
   float slope; int leaky;
+  BnStats in_bn;     // the input prologue's BatchNorm from raw statistics (sum != nullptr; bn_lazy.h) instead of in_scale / in_shift
 };
 
 constexpr int CP_PITCH = 144;                    // bytes per pixel of a wave's LDS image: 64 channels + 16
@@ -48,12 +50,17 @@ __global__ __launch_bounds__(256, 2) void convp_kernel(PointParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* const img = lds + wbytes + 1024 + wave * CP_IMG;
   const int l31 = lane & 31, hh = lane >> 5;
-  const bool pre = P.in_scale != nullptr;
+  const bool pre = P.in_scale != nullptr || P.in_bn.sum != nullptr;
 
   // ---- once per workgroup: weights (fragment order, contiguous) and the prologue's per-channel constants into LDS
   for (int i = tid; i < wbytes / 16; i += 256)
     *reinterpret_cast<i32x4*>(wlds + i * 16) = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(P.wpack) + (long)i * 16);
-  if (pre && tid < P.Cin) { ptab[tid] = P.in_scale[tid]; ptab[128 + tid] = P.in_shift[tid]; }
+  if (pre && tid < P.Cin) {
+    float sc, sh;
+    if (P.in_bn.sum != nullptr) bn_channel(P.in_bn, P.Cin, tid, blockIdx.x == 0, sc, sh);      // (workgroup 0 publishes)
+    else { sc = P.in_scale[tid]; sh = P.in_shift[tid]; }
+    ptab[tid] = sc; ptab[128 + tid] = sh;
+  }
   // the epilogue's per-channel constants (a lane owns channel 32 j + l31 of every block j)
   float cbias[NCB], cscale[NCB], cshift[NCB];
 #pragma unroll
@@ -317,21 +324,24 @@ extern "C" int wmz_conv_point_pack(const void* w_op, void* wpack, int K, int Cou
   return WMZ_OK;
 }
 
-extern "C" int wmz_conv_point_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale, const float* shift,
-                                  float* stat_sum, float* stat_sq, const float* in_scale, const float* in_shift, float in_slope, int B,
-                                  int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope,
-                                  void* stream) {
+// in_bn (optional, HOST pointer to a wmz_bn_stats): the prologue's BatchNorm from its raw batch statistics (replaces in_scale / in_shift)
+extern "C" int wmz_conv_point_fwd_bn(const void* x, const void* wpack, void* out, const float* bias, const float* scale, const float* shift,
+                                     float* stat_sum, float* stat_sq, const float* in_scale, const float* in_shift,
+                                     const wmz_bn_stats* in_bn, float in_slope, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
+                                     int stride, int pad, int leaky, float slope, void* stream) {
   WMZ_REQUIRE(x && wpack && out, "wmz_conv_point_fwd: null tensor");
   WMZ_REQUIRE(wmz_conv_point_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad), "wmz_conv_point_fwd: unsupported shape (wmz_conv_point_supported)");
   WMZ_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "wmz_conv_point_fwd: stat_sum and stat_sq go together");
   WMZ_REQUIRE((scale == nullptr) == (shift == nullptr), "wmz_conv_point_fwd: scale and shift go together");
   WMZ_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wmz_conv_point_fwd: in_scale and in_shift go together");
-  WMZ_REQUIRE(in_scale == nullptr || (KH == 1 && KW == 1 && pad == 0 && Cin <= 128), "wmz_conv_point_fwd: the input prologue is built for 1x1 convolutions of <= 128 channels");
+  WMZ_REQUIRE(bn_stats_ok(in_bn) && (in_bn == nullptr || in_scale == nullptr), "wmz_conv_point_fwd_bn: incomplete wmz_bn_stats (or both prologue forms given)");
+  WMZ_REQUIRE((in_scale == nullptr && in_bn == nullptr) || (KH == 1 && KW == 1 && pad == 0 && Cin <= 128), "wmz_conv_point_fwd: the input prologue is built for 1x1 convolutions of <= 128 channels");
   WMZ_REQUIRE(slope >= 0.f && slope <= 1.f, "wmz_conv_point_fwd: LeakyReLU slope in [0, 1] expected");
   PointParams P;
   P.x = (const bf16_t*)x; P.wpack = (const bf16_t*)wpack; P.out = (bf16_t*)out;
   P.bias = bias; P.scale = scale; P.shift = shift; P.stat_sum = stat_sum; P.stat_sq = stat_sq;
   P.in_scale = in_scale; P.in_shift = in_shift; P.in_slope = in_slope;
+  P.in_bn = bn_stats_from(in_bn);
   P.Hi = Hi; P.Wi = Wi; P.Cin = Cin; P.Cout = Cout; P.KH = KH; P.KW = KW; P.stride = stride; P.pad = pad;
   P.Ho = (Hi + 2 * pad - KH) / stride + 1;
   P.Wo = (Wi + 2 * pad - KW) / stride + 1;
@@ -364,6 +374,14 @@ extern "C" int wmz_conv_point_fwd(const void* x, const void* wpack, void* out, c
   }
   WMZ_LAUNCH_CHECK("wmz_conv_point_fwd");
   return WMZ_OK;
+}
+
+extern "C" int wmz_conv_point_fwd(const void* x, const void* wpack, void* out, const float* bias, const float* scale, const float* shift,
+                                  float* stat_sum, float* stat_sq, const float* in_scale, const float* in_shift, float in_slope, int B,
+                                  int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int leaky, float slope,
+                                  void* stream) {
+  return wmz_conv_point_fwd_bn(x, wpack, out, bias, scale, shift, stat_sum, stat_sq, in_scale, in_shift, nullptr, in_slope, B, Hi, Wi, Cin,
+                               Cout, KH, KW, stride, pad, leaky, slope, stream);
 }
 
 extern "C" int wmz_nchw_to_nhwc8(const void* x, void* y, int B, int C, int H, int W, int in_dtype, int out_dtype, void* stream) {

@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI (shape/stride checks, output allocation).  No autograd here."""
 import contextlib
+import ctypes
+import os
 
 import torch
 
@@ -730,12 +732,19 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
                L.stream())
         return (out, s, q) if stats else out
     psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
-    if (DIRECT_CONV and x.dtype == torch.bfloat16 and residual is None and 0.0 <= slope <= 1.0
-            and L.lib().wmz_conv_point_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad)):
+    point = (DIRECT_CONV and x.dtype == torch.bfloat16 and residual is None and 0.0 <= slope <= 1.0
+             and L.lib().wmz_conv_point_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad))
+    pst = None
+    if isinstance(psc, BnLazy):                   # the prologue's BatchNorm as raw statistics: the streaming kernel finalises it
+        if point and not psc.done:
+            pst, psc, psh = psc.struct(), None, None
+        else:
+            psc, psh = psc.materialize()
+    if point:
         # csrc/conv_point.hip: small-K layers (1x1, 2x2 / stride 2, the 3-channel conv_1) as a persistent streaming kernel
-        L.call('wmz_conv_point_fwd', L.ptr(x), L.ptr(_point_pack(w_op, KH * KW * Cin, Cout)), L.ptr(out), L.ptr(bias), L.ptr(scale),
-               L.ptr(shift), L.ptr(s), L.ptr(q), L.ptr(psc), L.ptr(psh), float(psl), B, Hi, Wi, Cin, Cout, KH, KW, stride, pad,
-               1 if leaky else 0, float(slope), L.stream())
+        L.call('wmz_conv_point_fwd_bn', L.ptr(x), L.ptr(_point_pack(w_op, KH * KW * Cin, Cout)), L.ptr(out), L.ptr(bias), L.ptr(scale),
+               L.ptr(shift), L.ptr(s), L.ptr(q), L.ptr(psc), L.ptr(psh), ctypes.addressof(pst) if pst is not None else None, float(psl),
+               B, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 1 if leaky else 0, float(slope), L.stream())
         return (out, s, q) if stats else out
     L.call('wmz_conv2d_nhwc_fwd_pre', L.ptr(x), L.ptr(w_op), L.ptr(out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
            L.ptr(residual), L.ptr(s), L.ptr(q), L.ptr(psc), L.ptr(psh), float(psl), B, Hi, Wi, Cin, Cout, KH, KW, stride,
@@ -790,6 +799,58 @@ def channel_stats_nhwc(x):
     return s, q
 
 
+BN_LAZY = os.environ.get('WMZ_BN_LAZY', '1') != '0'      # A/B: 0 = a wmz_bn_finalize launch between every convolution and its consumer
+
+
+class BnLazy:
+    """A training-mode nn.BatchNorm2d as the raw batch statistics its producer left (include/wmz.h wmz_bn_stats): the kernel that
+    applies the normalisation finalises it (scale / shift from the sums, running statistics moved by one of its workgroups).
+    .scale / .shift (/ .mean / .rstd with want_stats) are filled by that launch; materialize() runs wmz_bn_finalize instead (for a
+    consumer that takes plain per-channel arrays)."""
+
+    def __init__(self, bn, s, q, count, want_stats=False):
+        C = bn.num_features
+        dev = s.device
+        self.bn, self.s, self.q, self.count, self.C = bn, s, q, float(count), C
+        buf = torch.empty((4 if want_stats else 2, C), dtype=torch.float32, device=dev)
+        self.scale, self.shift = buf[0], buf[1]
+        self.mean, self.rstd = (buf[2], buf[3]) if want_stats else (None, None)
+        self.done = False
+
+    def struct(self):
+        """The ctypes struct for ONE consuming launch (keep it alive until the call returns)."""
+        assert not self.done, 'a BnLazy is consumed once (the running statistics move once)'
+        self.done = True
+        bn = self.bn
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        track = bn.running_mean is not None
+        return L.BnStats(L.ptr(self.s), L.ptr(self.q), L.ptr(bn.weight.detach()) if bn.weight is not None else None,
+                         L.ptr(bn.bias.detach()) if bn.bias is not None else None, L.ptr(bn.running_mean) if track else None,
+                         L.ptr(bn.running_var) if track else None,
+                         L.ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
+                         L.ptr(self.scale), L.ptr(self.shift), L.ptr(self.mean), L.ptr(self.rstd), self.count, float(mom), float(bn.eps))
+
+    def materialize(self):
+        if not self.done:
+            self.done = True
+            bn = self.bn
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            nbt = bn.num_batches_tracked if bn.num_batches_tracked is not None else None
+            L.call('wmz_bn_finalize', L.ptr(self.s), L.ptr(self.q), self.count, L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()),
+                   L.ptr(bn.running_mean), L.ptr(bn.running_var), float(mom), float(bn.eps), 1, L.ptr(self.scale), L.ptr(self.shift),
+                   L.ptr(self.mean), L.ptr(self.rstd), self.C, L.ptr(nbt), L.stream())
+        return self.scale, self.shift
+
+
+def bn_lazy(bn, s, q, count, want_stats=False):
+    """bn_finalize deferred into the consumer (BnLazy) when the module is in training mode with tracked statistics; otherwise -- or
+    with WMZ_BN_LAZY=0 -- finalised now: the returned object has .scale / .shift (/ .mean / .rstd) either way."""
+    lz = BnLazy(bn, s, q, count, want_stats)
+    if not (BN_LAZY and bn.training and bn.running_mean is not None and bn.weight is not None):
+        lz.materialize()
+    return lz
+
+
 def bn_finalize(bn, s, q, count, want_stats=False):
     """(scale, shift[, mean, rstd]) of an nn.BatchNorm2d; in training mode also updates its running statistics."""
     C = bn.num_features
@@ -808,11 +869,33 @@ def bn_finalize(bn, s, q, count, want_stats=False):
 
 
 def affine_act_nhwc(a, sa=None, ta=None, b=None, sb=None, tb=None, leaky=False, slope=0.01):
+    """y = act(a * sa + ta (+ b * sb + tb)).  sa / sb may be a BnLazy (ta / tb then None): its BatchNorm is finalised by this launch."""
     C = a.shape[-1]
     M = a.numel() // C
     y = torch.empty_like(a)
-    L.call('wmz_affine_act_nhwc', L.ptr(a), L.ptr(sa), L.ptr(ta), L.ptr(b), L.ptr(sb), L.ptr(tb), L.ptr(y), M, C,
-           1 if leaky else 0, float(slope), L.dtype_code(a.dtype), L.stream())
+    dt = L.dtype_code(a.dtype)
+    lazy = [t for t in (sa, sb) if isinstance(t, BnLazy) and not t.done]
+    if lazy and not (L.lib().wmz_affine_act_bn_supported(C, dt) and (a.data_ptr() | (b.data_ptr() if b is not None else 0)) % 16 == 0):
+        for t in lazy:
+            t.materialize()
+    sta = stb = None
+    if isinstance(sa, BnLazy):
+        if sa.done:
+            sa, ta = sa.scale, sa.shift
+        else:
+            sta, sa, ta = sa.struct(), None, None
+    if isinstance(sb, BnLazy):
+        if sb.done:
+            sb, tb = sb.scale, sb.shift
+        else:
+            stb, sb, tb = sb.struct(), None, None
+    if sta is None and stb is None:
+        L.call('wmz_affine_act_nhwc', L.ptr(a), L.ptr(sa), L.ptr(ta), L.ptr(b), L.ptr(sb), L.ptr(tb), L.ptr(y), M, C,
+               1 if leaky else 0, float(slope), dt, L.stream())
+    else:
+        L.call('wmz_affine_act_nhwc_bn', L.ptr(a), L.ptr(sa), L.ptr(ta), ctypes.addressof(sta) if sta is not None else None, L.ptr(b),
+               L.ptr(sb), L.ptr(tb), ctypes.addressof(stb) if stb is not None else None, L.ptr(y), M, C, 1 if leaky else 0, float(slope),
+               dt, L.stream())
     return y
 
 
