@@ -154,6 +154,57 @@ def _worker_direct(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _worker_echo(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from world_modelz_amd.parallel import BucketedAllReduce, FlatArena
+    torch.set_num_threads(1)
+    model = _TwoNodeBlock()
+    arena = FlatArena(model)
+    red = BucketedAllReduce(arena, group_of=lambda name: 'all', always=True)
+    log = []
+    orig = red._launch
+    red._launch = lambda b: (log.append('launch'), orig(b))[1]
+    hooks = [red._make_hooks(i) for i in range(len(arena.params))]
+    # step 1: every gradient announced by its kernel, and NO echo from autograd (the other torch behaviour)
+    for _, from_kernel in hooks:
+        from_kernel()
+    assert log == ['launch']                                    # the bucket left when its last gradient was announced
+    red.finish()
+    log.append('finish')
+    # step 2: the same parameters arrive through autograd -- none may be mistaken for an echo of step 1
+    for from_autograd, _ in hooks:
+        from_autograd(None)
+    ok2 = log == ['launch', 'finish', 'launch']
+    red.finish()
+    # step 3: kernel announcements WITH their echoes, in between and behind
+    n0 = len(log)
+    for j, (from_autograd, from_kernel) in enumerate(hooks):
+        from_kernel()
+        if j % 2 == 0:
+            from_autograd(None)
+    launched_early = len(log) == n0 + 1
+    for j, (from_autograd, _) in enumerate(hooks):
+        if j % 2 == 1:
+            from_autograd(None)
+    ret[rank] = (ok2, launched_early, len(log) == n0 + 1)
+    red.finish()
+    dist.destroy_process_group()
+
+
+def test_reducer_counts_a_gradient_once_whether_or_not_autograd_echoes_a_kernel_announcement():
+    """parallel.BucketedAllReduce: a gradient a backward kernel wrote in place is announced by the kernel; torch 2.10 then still runs the
+    parameter's post-accumulate hook for the None the node returned (an echo that must not count), other versions may not.  The
+    dedup mark is scoped to the reducing step: without an echo nothing stale survives into the next step (a genuine autograd gradient
+    there is counted, the bucket leaves before finish()), with echoes -- early or late -- the bucket leaves exactly once."""
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_echo, args=(1, _free_port(), ret), nprocs=1, join=True)
+        assert ret[0] == (True, True, True), ret[0]
+
+
 def test_bucket_waits_for_every_autograd_node_that_writes_in_place():
     """A bucket whose gradients are written in place by SEVERAL autograd nodes (the op-by-op HIP backward: feed-forward node, then
     attention node of one layer) is reduced once ALL of them have written: torch runs a parameter's post-accumulate hooks even

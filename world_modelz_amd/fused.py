@@ -161,6 +161,10 @@ def transformer_forward_chain(tr, z):
     return x
 
 
+class ChainLayoutError(RuntimeError):
+    """ChainPackSet cannot describe this model's parameter layout (the trainer then takes the op-by-op path)."""
+
+
 class ChainPackSet:
     """The training step's weight streams of csrc/layer_chain.hip / layer_chain_bwd.hip for EVERY launch of the stack -- forward
     launches, feed-forward-side and attention-side backward launches -- rebuilt from the flat parameter arena by a handful of
@@ -241,12 +245,18 @@ class ChainPackSet:
         widx = torch.cat([w for w, _ in streams] + [tail_pad])
         sidx = torch.cat([sc for _, sc in streams] + [tail_pad])
         self.flat = arena.flat_param
-        self.widx, self.wmask = widx.clamp(min=0), (widx >= 0).to(torch.float32)
-        self.sidx, self.smask = sidx.clamp(min=0), (sidx >= 0)
+        assert arena.flat_param.numel() < 2 ** 31 and widx.numel() < 2 ** 31
+        # tables (round 5): 32-bit indices, a byte mask for the padding, and the LayerNorm-weight factors only for the
+        # elements that HAVE one (the w1 / k / v pieces: about half) as a compact (position, source) pair -- 31 -> ~15 bytes per
+        # packed element (0.7 -> 0.34 GB at dim 384 / depth 20) and half the bytes a refresh moves
+        self.widx, self.wpad = widx.clamp(min=0).to(torch.int32), (widx < 0)
+        self.spos = torch.nonzero(sidx >= 0).reshape(-1)                     # (int64: index_copy_ takes nothing narrower)
+        self.ssrc = sidx[sidx >= 0].to(torch.int32)
         self.w32 = torch.empty(widx.numel(), dtype=torch.float32, device=dev)
-        self.s32 = torch.empty(widx.numel(), dtype=torch.float32, device=dev)
+        self.sw = torch.empty(self.spos.numel(), dtype=torch.float32, device=dev)
+        self.sg = torch.empty(self.spos.numel(), dtype=torch.float32, device=dev)
         self.wpack = torch.empty(widx.numel(), dtype=torch.bfloat16, device=dev)
-        self.vidx, self.vmask = vidx.reshape(-1).clamp(min=0), (vidx.reshape(-1) >= 0).to(torch.float32)
+        self.vidx, self.vpad = vidx.reshape(-1).clamp(min=0).to(torch.int32), (vidx.reshape(-1) < 0)
         self.vec = torch.empty((nl + 1, nvec), dtype=torch.float32, device=dev)
         # the folded bias terms: b1' = b1 + W1 beta_ff, bk' = Wk beta_attn, bv' = bv + Wv beta_attn, batched over the layers (a
         # layer's parameters sit at one stride in the arena: strided [L, N, K] / [L, K, 1] views, one bmm per kind)
@@ -263,7 +273,9 @@ class ChainPackSet:
         Wk = strided([a.fn.to_k.weight for a, _ in layers], (I, D))
         Wv = strided([a.fn.to_v.weight for a, _ in layers], (I, D))
         bat = strided([a.norm.bias for a, _ in layers], (D, 1))
-        assert all(t is not None for t in (W1, bff, Wk, Wv, bat)), 'layers are not laid out at one stride in the arena'
+        if any(t is None for t in (W1, bff, Wk, Wv, bat)):
+            # (frozen or re-ordered layers: no strided view of the arena holds them -- the caller trains op by op instead)
+            raise ChainLayoutError('the transformer layers are not laid out at one stride in the parameter arena')
         self._mv = [(W1, bff, self.vec[1:, D:D + M]), (Wk, bat, self.vec[:nl, 2 * D + M:2 * D + M + I]),
                     (Wv, bat, self.vec[:nl, 2 * D + M + I:])]
         self.refresh()
@@ -271,12 +283,13 @@ class ChainPackSet:
     def refresh(self):
         flat = self.flat.detach()
         torch.index_select(flat, 0, self.widx, out=self.w32)
-        torch.index_select(flat, 0, self.sidx, out=self.s32)
-        self.s32.masked_fill_(~self.smask, 1.0)
-        self.w32.mul_(self.wmask).mul_(self.s32)
+        self.w32.masked_fill_(self.wpad, 0.0)
+        torch.index_select(self.w32, 0, self.spos, out=self.sw)          # the elements a LayerNorm weight is folded into
+        torch.index_select(flat, 0, self.ssrc, out=self.sg)
+        self.w32.index_copy_(0, self.spos, self.sw.mul_(self.sg))
         self.wpack.copy_(self.w32)
         torch.index_select(flat, 0, self.vidx, out=self.vec.view(-1))
-        self.vec.view(-1).mul_(self.vmask)
+        self.vec.view(-1).masked_fill_(self.vpad, 0.0)
         for W, beta, dst in self._mv:
             dst.add_(torch.bmm(W.detach(), beta.detach()).squeeze(-1))
 

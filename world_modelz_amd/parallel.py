@@ -98,7 +98,8 @@ class BucketedAllReduce:
         self.launched = []
         self._hooks = []
         self._timing = None                    # enable_timing(): [(start, end) events of every collective], [(w0, w1) of finish()]
-        self._direct = [False] * len(arena.params)
+        self._epoch = 0                        # one per reducing step (reset()): scopes the kernel-announced marks below
+        self._direct = [-1] * len(arena.params)
         if self.active:
             for i, p in enumerate(arena.params):
                 from_autograd, from_kernel = self._make_hooks(i)
@@ -110,7 +111,7 @@ class BucketedAllReduce:
         self.pending = [len(idxs) * self.rounds for (_, _, idxs) in self.buckets]
         self.handles = []
         self.launched = [False] * len(self.buckets)
-        self._direct = [False] * len(self._direct)
+        self._epoch += 1                       # (marks of the step just closed no longer match: nothing carries over)
 
     def _make_hooks(self, i):
         """A parameter's gradient is counted ONCE per backward pass, whichever way it arrives.  A backward kernel that wrote it
@@ -119,7 +120,8 @@ class BucketedAllReduce:
         returns: that echo must not count a second time (with several autograd nodes per bucket -- the op-by-op path: a
         layer's feed-forward node, then its attention node -- the doubled counts of the first node's parameters launched the
         bucket's all-reduce before the second node had written its gradients: replicas diverged; found by the fp32 two-rank
-        test of round 4)."""
+        test of round 4).  The mark is the step's epoch, not a flag the echo clears: whether torch sends the echo is version
+        dependent, and a flag left standing by a missing echo would swallow a genuine autograd gradient of a later step."""
         def count():
             b = self.bucket_of[i]
             self.pending[b] -= 1
@@ -127,13 +129,12 @@ class BucketedAllReduce:
                 self._launch(b)
 
         def from_autograd(_param):
-            if self._direct[i]:                # the echo of a gradient the kernel already announced
-                self._direct[i] = False
+            if self._direct[i] == self._epoch:     # the echo of a gradient the kernel announced in THIS step
                 return
             count()
 
         def from_kernel():
-            self._direct[i] = True
+            self._direct[i] = self._epoch
             count()
         return from_autograd, from_kernel
 

@@ -362,7 +362,10 @@ class _TrainerBase(_AdamState):
         elif hasattr(tr, 'pos_emb_s') and fused.chain_supported(tr, dt) and config.get_fused_training():
             # the reference's published widths: training FORWARD on the chain kernel (one gather rebuilds every launch's weight
             # stream); the backward runs op by op and keeps reading the per-layer operand copies registered below
-            self.chain_packs = fused.ChainPackSet(tr, self.arena)
+            try:
+                self.chain_packs = fused.ChainPackSet(tr, self.arena)
+            except fused.ChainLayoutError:
+                self.chain_packs = None                  # (op by op: the per-layer operand copies below serve both directions)
         for attn, ff in layers:
             a, f = attn.fn, ff.fn
             if hasattr(a, 'to_qkv'):                     # config 5: lucidrains ViT block with one fused projection
