@@ -293,6 +293,25 @@ def test_graphed_training_step_matches_eager(wmz, dtype):
             l3, _ = tg.train_step(z, r=r0)
             assert tg._graph is g_before and l3 == l3 and int(tg._g_ctr) == c3 + 1
             assert any(w is old for w in tg._g_ws)
+        # ... and with EVERY library workspace replaced (the counting-sort scratch of the embedding backward and of the VQ statistics
+        # zero their counters once and re-zero them per call -- state a replay must find where it left it): the graph replays on
+        # the allocations it holds, eager calls move to the new ones, and both produce the step the other does
+        for wsd, dtype_ in ((ops._wgrad_ws, torch.float32), (ops._embed_ws, torch.int32), (ops._vq_ws, torch.int32)):
+            cur = wsd.get(dev)
+            if cur is not None:
+                wsd[dev] = (torch.empty if dtype_ == torch.float32 else torch.zeros)(2 * cur.numel() + 4096, dtype=dtype_, device=dev)
+        me.load_state_dict(mg.state_dict())
+        te.m.copy_(tg.m); te.v.copy_(tg.v); te.step_count = tg.step_count
+        from world_modelz_amd import _cast
+        _cast.invalidate()
+        for it in range(2):
+            le, ge = te.train_step(z, r=r0)                 # eager: the new workspaces
+            lg, gg = tg.train_step(z, r=r0)                 # replay: the captured ones
+            assert tg._graph is g_before
+            assert abs(le - lg) < (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, abs(le)), (it, le, lg)
+            assert abs(ge - gg) < (1e-3 if dtype == torch.float32 else 5e-2) * max(1.0, abs(ge)), (it, ge, gg)
+        for (n, a), b in zip(me.named_parameters(), mg.parameters()):
+            assert torch.allclose(a, b, **tol), n
         # capturing again (a caller's second enable_graph) does not restart the counter either
         c4 = int(tg._g_ctr)
         tg.enable_graph(z, warmup=1)
