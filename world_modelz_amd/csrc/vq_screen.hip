@@ -218,38 +218,55 @@ __global__ __launch_bounds__(ROWS_WG * 2) void vq_screen_kernel(const float* __r
 }
 
 // rows the screening could not decide: the whole codebook in the pinned arithmetic -- exactly what vq_argmin_kernel computes for
-// the row.  A block takes 4 flagged rows (one per wave); tiles of 64 codes go through LDS (coalesced 16-byte loads, rows pitched
-// 65 floats: lane = code reads its row conflict-free) and are shared by the 4 waves; lexicographic (distance, index) minimum
-// over the wave at the end.
+// the row.  A block takes ONE flagged row, its four waves a quarter of the codebook each: tiles of 64 codes go through a
+// WAVE-PRIVATE LDS image (coalesced 16-byte loads, the next tile's in flight while this one is evaluated; rows pitched 65 floats:
+// lane = code reads its row conflict-free; no block barrier per tile); lexicographic (distance, index) minimum over the wave, then
+// over the four waves.  (Round 5: one wave per row walked all C / 64 tiles behind two block barriers each -- a ~30-us critical
+// path for ~260 rows of work; now C / 256 tile steps per wave, on a grid that gives every flagged row its own workgroup.)
+constexpr int RC_TILE = 64 * 65;                 // floats of one wave's tile image
+constexpr int RC_LDS = 4 * RC_TILE * 4 + 64;     // bytes: four images + the waves' minima
+
 __global__ __launch_bounds__(256) void vq_recheck_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ CB,
                                                          int64_t* __restrict__ IDX, float* __restrict__ DMIN,
                                                          const int* __restrict__ nflag, const int* __restrict__ flagged, int C) {
-  __shared__ float tile[64 * 65];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) float rc_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const tile = rc_lds + wave * RC_TILE;
+  float* const sd = rc_lds + 4 * RC_TILE;
+  int* const sc = reinterpret_cast<int*>(sd + 4);
   const int n = *nflag;
-  for (int i0 = blockIdx.x * 4; i0 < n; i0 += gridDim.x * 4) {          // block-uniform trip count: barriers inside are safe
-    const int i = i0 + wave;
-    const bool have = i < n;
-    const int row = __builtin_amdgcn_readfirstlane(flagged[have ? i : i0]);
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {                       // block-uniform trip count: barriers inside are safe
+    const int row = __builtin_amdgcn_readfirstlane(flagged[i]);
     const float* xrow = X + (long)row * ldx;                              // wave-uniform: scalar loads
     float xr[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) xr[e] = xrow[e];
     float bd = INFINITY;
     int bc = INT_MAX;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-      __syncthreads();
+    // a tile = 64 codes x 16 chunks of 16 bytes: chunk q = lane + 64 k belongs to code q >> 4, columns 4 (q & 15) ..
+    f32x4 nxt[16];
+    auto fetch = [&](int c0) {
+      const float* src = CB + (long)min(c0, C - 64) * E + lane * 4;       // (past the codebook: a valid tile, never evaluated)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {                                       // 64 codes x 16 chunks of 16 bytes, 4 per thread
-        const int q = tid + 256 * k, code = q >> 4, ch = q & 15;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(CB + (long)(c0 + code) * E + ch * 4);
-        float* d = tile + code * 65 + ch * 4;
-        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      for (int k = 0; k < 16; ++k) nxt[k] = *reinterpret_cast<const f32x4*>(src + 256 * k);
+    };
+    fetch(64 * wave);
+    for (int c0 = 64 * wave; c0 < C; c0 += 256) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int q = lane + 64 * k;
+        float* d = tile + (q >> 4) * 65 + (q & 15) * 4;
+        d[0] = nxt[k][0]; d[1] = nxt[k][1]; d[2] = nxt[k][2]; d[3] = nxt[k][3];
       }
-      __syncthreads();
+      fetch(c0 + 256);
+      __builtin_amdgcn_sched_barrier(0);                                  // (the requests stay above the evaluation: hipcc would sink them to their use)
+      __builtin_amdgcn_wave_barrier();
       const float* cr = tile + lane * 65;
       const float d = dist_pinned64([&](int e) { return xr[e]; }, [&](int e) { return cr[e]; });
       if (d < bd) { bd = d; bc = c0 + lane; }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -257,10 +274,19 @@ __global__ __launch_bounds__(256) void vq_recheck_kernel(const float* __restrict
       const int oc = __shfl_xor(bc, m);
       if (od < bd || (od == bd && oc < bc)) { bd = od; bc = oc; }
     }
-    if (lane == 0 && have) {
+    if (lane == 0) { sd[wave] = bd; sc[wave] = bc; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float od = sd[w];
+        const int oc = sc[w];
+        if (od < bd || (od == bd && oc < bc)) { bd = od; bc = oc; }
+      }
       IDX[row] = bc == INT_MAX ? 0 : bc;
       if (DMIN != nullptr) DMIN[row] = bd;
     }
+    __syncthreads();
   }
 }
 
@@ -293,7 +319,14 @@ extern "C" int wmz_vq_argmin_screened(const float* x, long ldx, const float* cod
   hipLaunchKernelGGL(vq_prep_kernel, dim3(C / 64), dim3(256), 0, st, codebook, EH, EL, NH, emax2_blk, nflag, C);
   hipLaunchKernelGGL(vq_screen_kernel, dim3(wmz_cdiv(N, ROWS_WG)), dim3(ROWS_WG * 2), 0, st, x, ldx, codebook, EH, EL, NH, emax2_blk,
                      idx, dist_min, nflag, flagged, N, C);
-  hipLaunchKernelGGL(vq_recheck_kernel, dim3(256), dim3(256), 0, st, x, ldx, codebook, idx, dist_min, nflag, flagged, C);
+  static bool attr_set = false;                                         // (> 64 KB of dynamic LDS has to be asked for once)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_recheck_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+    attr_set = true;
+  }
+  // (the flagged-row count lives on the device: a grid that gives ~0.4 % of the rows a workgroup each, the rest leave at once)
+  const int rgrid = N / 128 < 256 ? 256 : (N / 128 > 2048 ? 2048 : N / 128);
+  hipLaunchKernelGGL(vq_recheck_kernel, dim3(rgrid), dim3(256), RC_LDS, st, x, ldx, codebook, idx, dist_min, nflag, flagged, C);
   WMZ_LAUNCH_CHECK("wmz_vq_argmin_screened");
   return WMZ_OK;
 }
