@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 106
+#define WMZ_VERSION 107
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1 };
 enum { WMZ_OK = 0, WMZ_ERR_ARG = 1, WMZ_ERR_HIP = 2, WMZ_ERR_UNSUPPORTED = 3 };
@@ -500,6 +500,10 @@ int wmz_affine_act_bn_supported(int C, int dtype);
 int wmz_affine_act_nhwc_bn(const void* a, const float* sa, const float* ta, const wmz_bn_stats* bna, const void* b, const float* sb,
                            const float* tb, const wmz_bn_stats* bnb, void* y, long M, int C, int leaky, float slope, int dtype,
                            void* stream);
+/* dz [B, Hz, Wz, C] = dy [B, Ho, Wo, C] placed at every `stride`-th pixel (dz[b, s y, s x] = dy[b, y, x]), zero elsewhere: the
+ * zero-inserted plane on which the data gradient of a strided nn.Conv2d (autoencoder.py:27-33) runs as a stride-1 convolution.
+ * C a multiple of 8 (bf16) / 4 (fp32), 16-byte aligned tensors. */
+int wmz_dilate_nhwc(const void* dy, void* dz, int B, int Ho, int Wo, int C, int Hz, int Wz, int stride, int dtype, void* stream);
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (autoencoder.py:138) on NHWC. */
 int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 

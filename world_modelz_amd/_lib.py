@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16 = 0, 1
-EXPECTED_VERSION = 106      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
+EXPECTED_VERSION = 107      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -93,6 +93,7 @@ SIGNATURES = {
     'wmz_conv_point_fwd': [c_void_p] * 10 + [c_float] + [c_int] * 10 + [c_float, c_void_p],
     'wmz_conv_point_fwd_bn': [c_void_p] * 11 + [c_float] + [c_int] * 10 + [c_float, c_void_p],      # (.., in_shift, const wmz_bn_stats*, in_slope, ..)
     'wmz_affine_act_bn_supported': [c_int, c_int],
+    'wmz_dilate_nhwc': [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p],
     'wmz_affine_act_nhwc_bn': [c_void_p] * 9 + [c_long, c_int, c_int, c_float, c_int, c_void_p],
     'wmz_nchw_to_nhwc8': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_conv2d_nhwc_wgrad_batch': [c_int] + [c_void_p] * 17 + [c_long, c_int, c_void_p],

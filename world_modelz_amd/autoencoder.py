@@ -157,9 +157,7 @@ class _Conv2dFn(torch.autograd.Function):
             else:
                 op_h = Hi - ((Ho - 1) * stride - 2 * pad + k)
                 op_w = Wi - ((Wo - 1) * stride - 2 * pad + k)
-                dz = torch.zeros((B, (Ho - 1) * stride + 1 + op_h, (Wo - 1) * stride + 1 + op_w, cop), dtype=dy.dtype,
-                                 device=dy.device)
-                dz[:, 0:(Ho - 1) * stride + 1:stride, 0:(Wo - 1) * stride + 1:stride] = dy
+                dz = ops.dilate_nhwc(dy, (Ho - 1) * stride + 1 + op_h, (Wo - 1) * stride + 1 + op_w, stride)     # zero-inserted dy
             dx = ops.conv2d_nhwc(dz, _wT_op(weight, dy.dtype), k, k, 1, k - 1 - pad,
                                  residual=None if dskip is None else dskip.contiguous())
         elif dskip is not None:

@@ -647,6 +647,25 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
   }
 }
 
+// dz[b, s y, s x, :] = dy[b, y, x, :], zero elsewhere: the zero-inserted plane on which a strided convolution's data gradient runs as a
+// stride-1 convolution (autoencoder._Conv2dFn.backward).  One pass of 16-byte stores (the torch form: a fill + a strided copy that
+// ran at a few hundred GB/s).  One thread per output vector, rows of the output plane on blockIdx.y.
+template <typename T>
+__global__ __launch_bounds__(256) void dilate_vec_kernel(const T* __restrict__ dy, T* __restrict__ dz, int Ho, int Wo, int cv, int Hz,
+                                                         int Wz, int stride) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int rowv = Wz * cv;                                       // vectors per output row
+  const int b = blockIdx.z, y = blockIdx.y;
+  const bool yin = (y % stride) == 0 && y / stride < Ho;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rowv; i += gridDim.x * 256) {
+    const int x = i / cv, c = i - x * cv;
+    i32x4 v = (i32x4)(0);
+    if (yin && (x % stride) == 0 && x / stride < Wo)
+      v = *reinterpret_cast<const i32x4*>(dy + (((long)b * Ho + y / stride) * Wo + x / stride) * cv * VW + c * VW);
+    *reinterpret_cast<i32x4*>(dz + (((long)b * Hz + y) * Wz) * cv * VW + (long)i * VW) = v;
+  }
+}
+
 // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on NHWC
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
@@ -1173,6 +1192,23 @@ extern "C" int wmz_affine_act_nhwc(const void* a, const float* sa, const float* 
                                    const float* tb, void* y, long M, int C, int leaky, float slope, int dtype,
                                    void* stream) {
   return wmz_affine_act_nhwc_bn(a, sa, ta, nullptr, b, sb, tb, nullptr, y, M, C, leaky, slope, dtype, stream);
+}
+
+extern "C" int wmz_dilate_nhwc(const void* dy, void* dz, int B, int Ho, int Wo, int C, int Hz, int Wz, int stride, int dtype,
+                               void* stream) {
+  WMZ_REQUIRE(dy && dz && B > 0 && Ho > 0 && Wo > 0 && C > 0 && stride >= 1, "wmz_dilate_nhwc: bad arguments");
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_dilate_nhwc: bad dtype %d", dtype);
+  WMZ_REQUIRE(Hz >= (Ho - 1) * stride + 1 && Wz >= (Wo - 1) * stride + 1, "wmz_dilate_nhwc: the output plane %d x %d does not hold %d x %d at stride %d", Hz, Wz, Ho, Wo, stride);
+  const int VW = dtype == WMZ_BF16 ? 8 : 4;
+  WMZ_REQUIRE(C % VW == 0 && (((uintptr_t)dy | (uintptr_t)dz) & 15) == 0, "wmz_dilate_nhwc: C must be a multiple of %d and the tensors 16-byte aligned", VW);
+  WMZ_REQUIRE(Hz <= 65535 && B <= 65535, "wmz_dilate_nhwc: plane height / batch beyond the launch grid");
+  const int cv = C / VW;
+  dim3 grid((unsigned)wmz_cdiv(Wz * cv, 256), (unsigned)Hz, (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == WMZ_BF16) hipLaunchKernelGGL(dilate_vec_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dz, Ho, Wo, cv, Hz, Wz, stride);
+  else hipLaunchKernelGGL(dilate_vec_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (float*)dz, Ho, Wo, cv, Hz, Wz, stride);
+  WMZ_LAUNCH_CHECK("wmz_dilate_nhwc");
+  return WMZ_OK;
 }
 
 extern "C" int wmz_bilinear2x_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {

@@ -899,6 +899,22 @@ def affine_act_nhwc(a, sa=None, ta=None, b=None, sb=None, tb=None, leaky=False, 
     return y
 
 
+DILATE_KERNEL = True
+
+
+def dilate_nhwc(dy, Hz, Wz, stride):
+    """dz [B, Hz, Wz, C] with dz[:, ::stride, ::stride] = dy and zeros elsewhere (one pass: wmz_dilate_nhwc)."""
+    B, Ho, Wo, C = dy.shape
+    dy = dy.contiguous()
+    if not DILATE_KERNEL:                         # A/B (tools/time_vqae_modes.py): the fill + strided copy of torch
+        dz = torch.zeros((B, Hz, Wz, C), dtype=dy.dtype, device=dy.device)
+        dz[:, 0:(Ho - 1) * stride + 1:stride, 0:(Wo - 1) * stride + 1:stride] = dy
+        return dz
+    dz = torch.empty((B, Hz, Wz, C), dtype=dy.dtype, device=dy.device)
+    L.call('wmz_dilate_nhwc', L.ptr(dy), L.ptr(dz), B, Ho, Wo, C, Hz, Wz, stride, L.dtype_code(dy.dtype), L.stream())
+    return dz
+
+
 def bilinear2x_nhwc(x):
     B, H, W, C = x.shape
     y = torch.empty((B, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
