@@ -790,3 +790,39 @@ def test_zero_inserted_plane_of_a_strided_data_gradient(wmz, dtype):
         gx = x.grad.clone()
         ref_blk = wmz['oracle_ae'].Residual(64, 128, 2).cuda() if 'oracle_ae' in wmz else None
     assert torch.isfinite(gx).all() and float(gx.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_frame_encoder_at_full_size_on_the_direct_kernels_vs_the_implicit_gemm_path(wmz):
+    """BASELINE config 3's frame batch (256 frames of 64 x 64, the VQ auto-encoder of main.py:229-237, BatchNorm in training mode):
+    the round-5 kernels (direct 3x3 / streaming small-K / consumer-finalised BatchNorm) against the implicit-GEMM kernels with a
+    wmz_bn_finalize launch each, on the same weights -- the same latents to bf16 rounding (the stride-2 form sums in another
+    order), tokens up to near-ties, running statistics to the same level (two forward passes each); and the encoder's output is invariant under a
+    permutation of the frames (BatchNorm statistics are sums over the batch: a size-independent property at full size)."""
+    import copy
+    from world_modelz_amd import ops
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    torch.manual_seed(11)
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        ae_a = VqAutoEncoder(embedding_dim=64, num_embeddings=1024, downscale_steps=2, hidden_planes=128).cuda()
+        ae_b, ae_c = copy.deepcopy(ae_a), copy.deepcopy(ae_a)
+        frames = torch.rand(256, 3, 64, 64, device='cuda')
+        with torch.no_grad():
+            lat_a = ae_a._latents(frames).float()
+            tok_a = ae_a.vq.encode(ae_a._latents(frames)).view(256, 16, 16)
+            ops.DIRECT_CONV, ops.BN_LAZY = False, False
+            try:
+                lat_b = ae_b._latents(frames).float()
+                tok_b = ae_b.vq.encode(ae_b._latents(frames)).view(256, 16, 16)
+            finally:
+                ops.DIRECT_CONV, ops.BN_LAZY = True, True
+            perm = torch.randperm(256, device='cuda')
+            lat_c = ae_c._latents(frames[perm]).float()
+        # (bf16 activations: the two routes round differently in the stride-2 layers; a random-init codebook has many near-ties)
+        assert rel(lat_a, lat_b) < 2e-2, rel(lat_a, lat_b)
+        assert float((tok_a != tok_b).float().mean()) < 0.04
+        assert rel(lat_a[perm], lat_c) < 1.5e-2, rel(lat_a[perm], lat_c)     # (statistics summed in another order: bf16 rounding, six normalisations deep)
+        for (n, ma), mb in zip(ae_a.named_modules(), ae_b.modules()):
+            if isinstance(ma, torch.nn.BatchNorm2d) and n.startswith('encoder'):
+                assert torch.allclose(ma.running_mean, mb.running_mean, rtol=2e-3, atol=2e-4), n
+                assert torch.allclose(ma.running_var, mb.running_var, rtol=5e-3, atol=1e-5), n
