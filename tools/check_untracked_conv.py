@@ -2,13 +2,13 @@
 track; load k is retired by the first inline-asm `s_waitcnt vmcnt(7)` behind load k + 7 (or any vmcnt(0)).  Nothing may read or
 write a load's destination registers between the load and that wait.  Compiles the file to ISA and scans every instantiation.
 
-    python tools/check_untracked_conv.py"""
+    python tools/check_untracked_conv.py [-D... of a variant build]"""
 import os
 import re
 import subprocess
 import sys
 src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'world_modelz_amd', 'csrc', 'conv_direct.hip')
-asm = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', src, '-o', '-'],
+asm = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only'] + [a for a in sys.argv[1:] if a.startswith('-D')] + [src, '-o', '-'],
                      capture_output=True, text=True).stdout
 bad_total = 0
 for name, body in re.findall(r'^(_ZN\S*convr_kernel\S*):\s*;.*?\n(.*?)\.end_amdhsa_kernel', asm, flags=re.S | re.M):

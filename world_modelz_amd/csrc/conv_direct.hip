@@ -20,6 +20,16 @@
 // Two workgroups per CU (<= 80 KB of LDS each): one computes while the other loads its patch or stores its tile.
 #include "wmz_common.h"
 #include "wmz_debug.h"
+#ifdef WMZ_CONV_STAMPS         // diagnostic build (tools/build_variant.py -DWMZ_CONV_STAMPS): s_memtime stamps of wave 0 of every workgroup of
+                               // convr_kernel + the CU it ran on (tools/conv_stamps.py)
+__device__ unsigned long long conv_stamps[8192 * 8];
+#define CONV_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) conv_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CONV_STAMP(i) do {} while (0)
+#endif
+#ifndef WMZ_CONV_ABL
+#define WMZ_CONV_ABL 0      // timing ablations of convr_kernel (tools/build_variant.py; results are garbage): 1 = a quarter of the A-fragment LDS reads, 2 = every weight fragment from the first two slabs (cache-resident)
+#endif
 
 namespace {
 
@@ -431,9 +441,19 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
       __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
     }
   };
+  CONV_STAMP(0);
+#ifdef WMZ_CONV_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    conv_stamps[blockIdx.x * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   if (P.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
     for (int i = 0; i < P.skew; ++i) __builtin_amdgcn_s_sleep(127);
   issue_patch(0);
+  CONV_STAMP(1);
 
   // this wave's weight fragments: fragment row f of the packed stream ([64-channel pass][tap][k-step 0..3]), block cb of ncb_pack
   const s16x8* const wp = reinterpret_cast<const s16x8*>(P.wpack) + cb * 64 + lane;
@@ -483,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // patch pieces (and the first weight fragments) landed
   __builtin_amdgcn_s_barrier();
+  CONV_STAMP(2);
 
   // A-fragment sequence of a slab (= tap t of the pass): n = kk * NPB + i -> ds_read_b128 at abase[i] + tap offset + 32 kk, the
   // offsets instruction immediates (all slabs are unrolled: straight-line code); WIN reads in flight, carried across slabs (the
@@ -494,6 +515,15 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
     constexpr int tpix = STRIDE == 1 ? kh * S::PW + kw
                                      : (((kh != 1) * 2 + (kw != 1)) * S::PLANE + (kh != 0) * (TW + 1) + (kw != 0));
     constexpr int off = tpix * S::PITCH + kk * 32;
+#if WMZ_CONV_ABL & 1
+    // timing ablation (garbage results): three of four A-fragment reads become register copies -- every destination is still WRITTEN
+    // (a skipped asm read leaves its register unassigned: hipcc re-uses it and the counted waits protect nothing -- that variant faulted)
+    if constexpr (i % 4 != 0) {
+      fr[n % WIN] = (s16x8)((short)abase[i]);
+      asm volatile("" : "+v"(fr[n % WIN]));
+      return;
+    }
+#endif
     fr[n % WIN] = ds_read_b128_asm<off>(abase[i]);
   };
   using I0 = std::integral_constant<int, 0>;
@@ -509,7 +539,11 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n % WIN], bq[s & 1][kk], acc[i], 0, 0, 0);
       if constexpr (n + WIN < NSEQ) read_n(sc, std::integral_constant<int, n + WIN>{});
       else read_n(std::integral_constant<int, s + 1>{}, std::integral_constant<int, n + WIN - NSEQ>{});    // next tap
+#if WMZ_CONV_ABL & 2
+      if constexpr (i == NPB - 1) bq[s & 1][kk] = wload(frag_row(snext & 1, kk));   // timing ablation: the same two slabs over and over (cache-resident)
+#else
       if constexpr (i == NPB - 1) bq[s & 1][kk] = wload(frag_row(snext, kk));   // k-step kk done: its register takes slab s + 2
+#endif
     });
     if constexpr (t == 8 && s + 1 < nslab) {                       // the patch of the next 64 (32) channels
       // (the window's run-ahead reads -- of the OLD patch: dead values -- retire here; their registers stay named until then:
@@ -532,8 +566,10 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
                  : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
 
   // ------------------------------------------------------------------------------------------------ epilogue
+  CONV_STAMP(3);
   if (P.dbg & 1) { if (acc[0][0] == 12345.f) P.out[0] = __float2bfloat16(acc[1][3]); return; }
   __syncthreads();                                                 // every wave is done with the patch: its LDS is the staging space
+  CONV_STAMP(4);
   char* const stage = lds + wave * S::STAGE;
   const int col = 32 * cb + l31;
   const bool want_stats = P.stat_sum != nullptr;
@@ -692,6 +728,7 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
       }
     }
   }
+  CONV_STAMP(5);
 }
 
 // GEMM operand [Cout, 9 * Cin] (tap-major, channels inside: autoencoder.py:_w_op) -> the fragment-order stream convq_kernel's
@@ -717,6 +754,12 @@ __global__ __launch_bounds__(256) void convq_pack_kernel(const bf16_t* __restric
 static int g_conv_skew = 1, g_conv_dbg = 0;
 
 }  // namespace
+
+#ifdef WMZ_CONV_STAMPS
+extern "C" int wmz_debug_conv_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int wmz_debug_conv_knobs(int skew, int dbg) { g_conv_skew = skew; g_conv_dbg = dbg; return WMZ_OK; }
 
