@@ -107,6 +107,43 @@ def log(msg):
     sys.stderr.flush()
 
 
+def encoder_token_agreement(dev, n_frames=16, C=1024):
+    """VqAutoEncoder.encode of `n_frames` 64x64 frames on the benched route (compute dtype of the run, BatchNorm in training mode:
+    main.py:229-237) against oracle.autoencoder.vqae_encode(training=True) on the same weights: the share of equal tokens, the
+    latents' relative error, and whether every differing token is explained by its latent's measured error (the arg-min itself is
+    bit-exact on equal inputs; for a differing token the triangle inequality demands
+    |x - c_picked| - |x - c_best| <= 2 |x' - x| with x the oracle's latent, x' the route's: tests/test_conv_bf16_oracle_gpu.py)."""
+    import torch
+    from oracle import autoencoder as oae
+    from oracle import vq as ovq
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    torch.manual_seed(11)
+    ae = VqAutoEncoder(embedding_dim=64, num_embeddings=C, downscale_steps=2, hidden_planes=128).to(dev)
+    ae.train()
+    sd = {k: v.detach().cpu().clone() for k, v in ae.state_dict().items()}
+    frames = torch.rand(n_frames, 3, 64, 64)
+    lat_ref = oae.encoder_forward(sd, frames, training=True).permute(0, 2, 3, 1).reshape(-1, 64)
+    cb = sd['vq.embedding']
+    tok_ref = ovq.encode(lat_ref, cb).reshape(-1)
+    with torch.no_grad():
+        lat = ae._latents(frames.to(dev))
+        tok = ae.vq.encode(lat).reshape(-1).cpu()
+    lat = lat.float().cpu().reshape(-1, 64)
+    exact_on_own_inputs = bool(torch.equal(tok, ovq.encode(lat, cb).reshape(-1)))
+    bad = (tok != tok_ref).nonzero().reshape(-1)
+    explained = True
+    if bad.numel():
+        x, xp = lat_ref[bad].double(), lat[bad].double()
+        slack = ((x - cb[0][tok[bad]].double()).norm(dim=-1) - (x - cb[0][tok_ref[bad]].double()).norm(dim=-1)
+                 - 2 * (xp - x).norm(dim=-1))
+        explained = bool(float(slack.max()) <= 1e-6)
+    return {'agreement': 1.0 - bad.numel() / tok.numel(), 'tokens': int(tok.numel()), 'differing': int(bad.numel()),
+            'latent_rel_err': float((lat - lat_ref).norm() / lat_ref.norm()),
+            'argmin_bit_exact_on_the_routes_own_latents': exact_on_own_inputs,
+            'every_difference_within_2x_latent_error': explained,
+            'sample': f'{n_frames} frames of 64x64, codebook {C}, random-init weights: a random codebook has many near-ties'}
+
+
 def cpu_baseline(cfg, sd, budget_s=20.0):
     """The oracle (CPU restatement, kind 'port') on a bounded sample: single clips of the same shape."""
     from oracle import denoiser as oden
@@ -685,6 +722,27 @@ def main():
                          'launch_mode': 'eager' if a.eager else 'hipGraph (GraphedEncoder: one launch per batch of frames)',
                          'what': f"VqAutoEncoder.encode of {cfg['B'] * cfg['S']} 64x64 RGB frames -> 16x16 tokens "
                                  '(BatchNorm in training mode as in main.py:236, quirk Q3)'}
+            # fabric-side bytes of one call, every launch summed (tools/pmc_encode_total.py, committed under profiles/): reported
+            # only while the conv / VQ sources still hash to what was measured
+            try:
+                ppath, pme = newest('pmc_frame_encoder.json')
+                if pme:
+                    if src_hash(pme['sources']) == pme['source_sha16'] and pme['frames_per_call'] == nfr:
+                        frame_enc['roofline']['traffic'] = pme['traffic_bytes_per_call']
+                        frame_enc['roofline']['traffic_per_frame'] = pme['traffic_bytes_per_call'] / nfr
+                        frame_enc['roofline']['traffic_source'] = f'{ppath} (rocprofv3 PMC passes over tools/prof_encode.py, all launches of one call)'
+                    else:
+                        frame_enc['roofline']['traffic_stale'] = f'kernel sources (or the batch) changed since {ppath} was measured'
+            except (OSError, KeyError, ValueError, NameError):
+                pass
+            # how far the benched route's tokens are from the reference's: 16 frames through THIS route (bf16 direct kernels,
+            # training-mode BatchNorm) against the fp32 CPU oracle on the same weights -- outside the timed loop, oracle as checker
+            if rank == 0 and not a.no_cpu_baseline:
+                try:
+                    frame_enc['token_agreement_vs_fp32_oracle'] = encoder_token_agreement(dev)
+                    log(f"frame encoder tokens vs fp32 oracle: {frame_enc['token_agreement_vs_fp32_oracle']}")
+                except Exception as e:                                   # noqa: BLE001  (a diagnostic must not cost the bench line)
+                    frame_enc['token_agreement_vs_fp32_oracle'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             log(f'frame encoder: {fel * 1e3:.2f} ms per {cfg["B"] * cfg["S"]} frames')
         out['frame_encoder'] = frame_enc
         # ---- secondary figure: one VQ-AE training step (train_vqae.py:125-164: encoder -> VectorQuantizerEMA incl. the EMA

@@ -107,9 +107,9 @@ def vqae_decode(params, z, training):
     return decoder_forward(params, h, training)
 
 
-def vqae_forward(params, x, training):
-    """VqAutoEncoder.forward (train_vqae.py:33-43): (recon, latent_loss, perplexity)."""
+def vqae_forward(params, x, training, assign=None):
+    """VqAutoEncoder.forward (train_vqae.py:33-43): (recon, latent_loss, perplexity).  assign: oracle.vq.forward's test knob."""
     h = encoder_forward(params, x, training).permute(0, 2, 3, 1)
-    q, _, loss, ppl = ovq.forward(h, _vq_state(params), training)
+    q, _, loss, ppl = ovq.forward(h, _vq_state(params), training, assign=assign)
     q = q.permute(0, 3, 1, 2).contiguous()
     return decoder_forward(params, q, training), loss, ppl

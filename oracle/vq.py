@@ -91,32 +91,36 @@ def decode(indices, embedding):
     return rows.reshape(*indices.shape, E)
 
 
-def forward(x, state, training, decay=0.99, eps=1e-5):
+def forward(x, state, training, decay=0.99, eps=1e-5, assign=None):
     """VectorQuantizerEMA.forward (vq.py:25-75).  Mutates `state` in place exactly where the
     reference mutates its buffers (quirk Q4).  Returns (quantized, encodings, loss, perplexity);
     `quantized` carries the straight-through value (== gathered codebook rows numerically:
-    x + (q - x), vq.py:70), computed with the same two fp32 roundings."""
+    x + (q - x), vq.py:70), computed with the same two fp32 roundings.
+    `assign` (int64 [N, L], test knob, default None = the reference's own argmin): evaluate everything
+    behind line :33 on GIVEN code assignments -- so that the gradients of a reduced-precision encoder,
+    whose latents flip a few near-ties, can be compared on the same assignment."""
     emb = state['embedding']
     L, C, E = emb.shape
     flat = x.reshape(-1, L, E)
     dist = distances(flat, emb)
-    idx = dist.argmin(dim=-1)                                            # :33
+    idx = dist.argmin(dim=-1) if assign is None else assign.reshape(-1, L)   # :33
     quant = decode(idx, emb)                                             # :34
-    err = ((quant - flat) ** 2).sum(dim=2)                               # :35
+    err = ((quant - flat) ** 2).sum(dim=2).detach()                      # :35
     state['accumulated_error'].scatter_add_(-1, idx.t(), err.t())        # :36
     quant = quant.view_as(x)
     enc = torch.zeros_like(dist).scatter(-1, idx.unsqueeze(-1), 1)       # :39
     if training:
-        counts = enc.sum(dim=0)                                          # :43
-        state['activation_count'].add_(counts)                           # :44
-        dw = enc.permute(1, 2, 0) @ flat.transpose(0, 1)                 # :46  [L,C,E]
-        state['cluster_size'].mul_(decay).add_(counts, alpha=1 - decay)  # :53
-        n = state['cluster_size'].sum(dim=-1, keepdim=True)              # :57
-        cs = (state['cluster_size'] + eps) / (n + C * eps) * n           # :58
-        dw = dw / cs.unsqueeze(-1)                                       # :64
-        state['embedding'].mul_(decay).add_(dw, alpha=1 - decay)         # :65
-    loss = torch.nn.functional.mse_loss(quant, x)                        # :67
-    st = x + (quant - x)                                                 # :70
+        with torch.no_grad():                                            # (the reference updates .data / buffers: no autograd history)
+            counts = enc.sum(dim=0)                                          # :43
+            state['activation_count'].add_(counts)                           # :44
+            dw = enc.permute(1, 2, 0) @ flat.transpose(0, 1)                 # :46  [L,C,E]
+            state['cluster_size'].mul_(decay).add_(counts, alpha=1 - decay)  # :53
+            n = state['cluster_size'].sum(dim=-1, keepdim=True)              # :57
+            cs = (state['cluster_size'] + eps) / (n + C * eps) * n           # :58
+            dw = dw / cs.unsqueeze(-1)                                       # :64
+            state['embedding'].mul_(decay).add_(dw, alpha=1 - decay)         # :65
+    loss = torch.nn.functional.mse_loss(quant.detach(), x)               # :67  (gradient -> encoder only)
+    st = x + (quant - x).detach()                                        # :70  straight-through estimator
     avg = enc.mean(dim=0)
     perplexity = torch.exp(-torch.sum(avg * torch.log(avg + 1e-10) / L))  # :73
     return st, enc, loss, perplexity

@@ -1,3 +1,4 @@
+import contextlib
 import os
 import sys
 
@@ -77,3 +78,20 @@ def near_tie_mismatches(idx, idx_ref, latents_ref, codebook, rel_gap=1e-5):
     assert torch.equal(top.indices[:, 1], idx[bad]), 'a differing index is not the runner-up code'
     assert float(gap.max()) < rel_gap, f'index differs away from a near-tie (gap {float(gap.max()):.3e})'
     return int(bad.numel())
+
+
+@contextlib.contextmanager
+def recorded_calls():
+    """The C-ABI entry points a block of code reaches (their names, in order): tests assert WHICH kernels produced a result."""
+    from world_modelz_amd import _lib
+    seen = []
+    orig = _lib.call
+
+    def call(name, *a):
+        seen.append(name)
+        return orig(name, *a)
+    _lib.call = call
+    try:
+        yield seen
+    finally:
+        _lib.call = orig

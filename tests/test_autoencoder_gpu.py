@@ -3,7 +3,7 @@
 import pytest
 import torch
 
-from conftest import load_golden, near_tie_mismatches, sub
+from conftest import load_golden, near_tie_mismatches, recorded_calls, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -207,19 +207,33 @@ def test_vqae_training_step_grads_vs_golden(wmz):
         out, ll, ppl = m(x)
         loss = torch.nn.functional.smooth_l1_loss(out, g['x'].cuda()) + 0.25 * ll
         loss.backward()
+    ref = {'recon': g['train/recon'], 'loss': g['train/loss'], 'dx': g['train/dx'],
+           'grad': {n: g['train/grad/' + n] for n, _ in m.named_parameters()}}
     if not torch.equal(idx.cpu(), g['train/idx']):
-        pytest.skip('a code index flipped on last-bit latent differences; gradient comparison not meaningful')
-    assert rel(out, g['train/recon']) < 1e-4
-    assert abs(float(loss) - float(g['train/loss'])) < 1e-5
-    assert rel(x.grad, g['train/dx']) < 2e-4
+        # a code index flipped on last-bit latent differences: it has to be a genuine near-tie of the oracle's distances (this
+        # FAILS otherwise), and the comparison then runs against the oracle's autograd on the SAME assignment (oracle.vq.forward's
+        # test knob) instead of the capture -- never a skip
+        sd1 = sub(g, 'sd1/')
+        lat_ref = oae.encoder_forward({k: v.clone() for k, v in sd1.items()}, g['x'], training=True)
+        near_tie_mismatches(idx, g['train/idx'], lat_ref.permute(0, 2, 3, 1), sd1['vq.embedding'][0])
+        leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k and not k.startswith('vq.')
+                      else v.clone()) for k, v in sd1.items()}
+        xo = g['x'].clone().requires_grad_(True)
+        rec_o, ll_o, _ = oae.vqae_forward(oae.with_vq_stats(leaves), xo, training=True, assign=idx.cpu().reshape(-1, 1))
+        lo = torch.nn.functional.smooth_l1_loss(rec_o, g['x']) + 0.25 * ll_o
+        lo.backward()
+        ref = {'recon': rec_o.detach(), 'loss': lo.detach(), 'dx': xo.grad, 'grad': {n: leaves[n].grad for n, _ in m.named_parameters()}}
+    assert rel(out, ref['recon']) < 1e-4
+    assert abs(float(loss) - float(ref['loss'])) < 1e-5
+    assert rel(x.grad, ref['dx']) < 2e-4
     # a bias in front of a training-mode BatchNorm has an exactly-zero true gradient (the reference holds 1e-9 noise
     # there): measure errors against the typical gradient magnitude, not against that noise
-    floor = 1e-3 * max(float(g['train/grad/' + n].norm()) for n, _ in m.named_parameters())
+    floor = 1e-3 * max(float(ref['grad'][n].norm()) for n, _ in m.named_parameters())
 
     def err(a, b):
         a, b = a.detach().float().cpu(), b.float()
         return float((a - b).norm() / max(float(b.norm()), floor))
-    worst = max((err(p.grad, g['train/grad/' + n]), n) for n, p in m.named_parameters())
+    worst = max((err(p.grad, ref['grad'][n]), n) for n, p in m.named_parameters())
     assert worst[0] < 5e-4, worst
 
 
@@ -781,15 +795,49 @@ def test_zero_inserted_plane_of_a_strided_data_gradient(wmz, dtype):
         ref = torch.zeros(B, Hz, Wz, C, device='cuda', dtype=dtype)
         ref[:, 0:(Ho - 1) * st + 1:st, 0:(Wo - 1) * st + 1:st] = dy
         assert torch.equal(ops.dilate_nhwc(dy, Hz, Wz, st), ref)
+    # the whole data gradient of a stride-2 block (autoencoder.py:18-42: conv3x3 / s2 and the 2x2 / s2 skip conv, both strided data
+    # gradients landing in one input) and every parameter gradient against torch autograd over the oracle's block on the same
+    # weights, training-mode BatchNorm
     from world_modelz_amd.autoencoder import Residual
+    torch.manual_seed(4)
     with wmz['config'].compute_dtype(dtype):
         blk = Residual(64, 128, 2).cuda()
-        x = torch.randn(4, 64, 32, 32, device='cuda', requires_grad=True)
-        dyo = torch.randn(4, 64, 16, 16, device='cuda')
-        (blk(x) * dyo).sum().backward()
-        gx = x.grad.clone()
-        ref_blk = wmz['oracle_ae'].Residual(64, 128, 2).cuda() if 'oracle_ae' in wmz else None
-    assert torch.isfinite(gx).all() and float(gx.abs().sum()) > 0
+        with torch.no_grad():
+            for mod in blk.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.weight.uniform_(0.5, 1.5)
+                    mod.bias.normal_(0, 0.3)
+        x0 = torch.randn(4, 64, 32, 32)
+        dyo = torch.randn(4, 64, 16, 16)
+        x = x0.cuda().requires_grad_(True)
+        with recorded_calls() as seen:
+            y = blk(x)
+            (y * dyo.cuda()).sum().backward()
+        assert 'wmz_dilate_nhwc' in seen
+    leaves = {'b.' + k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+                          else v.detach().cpu().clone()) for k, v in blk.state_dict().items()}
+    for k in leaves:                                   # (the HIP pass already moved the running statistics; the oracle gets its own)
+        if k.endswith('running_mean'):
+            leaves[k] = torch.zeros_like(leaves[k])
+        elif k.endswith('running_var'):
+            leaves[k] = torch.ones_like(leaves[k])
+    xo = x0.clone().requires_grad_(True)
+    yo = oae.residual_block(leaves, 'b.', xo, 2, True)
+    (yo * dyo).sum().backward()
+    # bf16: the gradient of a LeakyReLU network against a RANDOM output direction is not smooth in the activations -- an element whose
+    # pre-activation lies within the bf16 error of zero (~0.4 % of them here) changes its mask, i.e. its whole contribution: expected
+    # error ~ sqrt(0.004) = 6 % in every gradient, from the last BatchNorm's bias on (tools/diag_resblock_grad.py; any bf16 framework
+    # shows it).  The fp32 branch is the exact check of the kernels; the bf16 one bounds the route and pins the explanation below.
+    t_out, t_g = (1e-5, 2e-4) if dtype == torch.float32 else (1e-2, 1e-1)
+    assert y.shape == yo.shape and rel(y, yo) < t_out, rel(y, yo)
+    if dtype == torch.bfloat16:
+        # ... the last BatchNorm's bias gradient is sum(dy * mask): with the mask of the HIP path's OWN output it is reproduced to
+        # bf16 rounding of dy -- the 6 % is the mask, not the arithmetic
+        emul = (dyo.bfloat16().float() * torch.where(y.detach().float().cpu() > 0, 1.0, 0.01)).sum((0, 2, 3))
+        assert rel(blk._block[4].bias.grad, emul) < 5e-3, rel(blk._block[4].bias.grad, emul)
+    assert rel(x.grad, xo.grad) < t_g, rel(x.grad, xo.grad)
+    for n, prm in blk.named_parameters():
+        assert prm.grad is not None and rel(prm.grad, leaves['b.' + n].grad) < t_g, (n, rel(prm.grad, leaves['b.' + n].grad))
 
 
 @pytest.mark.gpu

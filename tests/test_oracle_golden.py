@@ -145,6 +145,34 @@ def test_autoencoder_roundtrip():
             assert torch.allclose(p[k], v, rtol=1e-5, atol=1e-6), k
 
 
+def test_autoencoder_autograd_vs_reference_capture():
+    """The oracle's VqAutoEncoder.forward under torch autograd (straight-through estimator and commitment loss of vq.py:67-70,
+    EMA update outside the graph) reproduces the reference's captured gradients: the GPU tests compare the bf16 conv route's
+    gradients with THIS autograd, so it is pinned here first."""
+    g = load_golden('ae_roundtrip')
+    sd1 = sub(g, 'sd1/')
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k and not k.startswith('vq.')
+                  else v.clone()) for k, v in sd1.items()}
+    x = g['x'].clone().requires_grad_(True)
+    rec, ll, _ = oae.vqae_forward(oae.with_vq_stats(leaves), x, training=True)
+    loss = torch.nn.functional.smooth_l1_loss(rec, g['x']) + 0.25 * ll
+    loss.backward()
+    assert torch.allclose(loss.detach(), g['train/loss'], rtol=1e-5)
+    assert rel(x.grad, g['train/dx']) < 2e-5
+    names = [k[len('train/grad/'):] for k in g if k.startswith('train/grad/')]
+    assert len(names) > 40
+    floor = 1e-3 * max(float(g['train/grad/' + n].norm()) for n in names)      # (biases in front of a training-mode BatchNorm: true gradient 0)
+    for n in names:
+        ref = g['train/grad/' + n]
+        assert leaves[n].grad is not None, n
+        assert float((leaves[n].grad - ref).norm()) / max(float(ref.norm()), floor) < 5e-5, n
+    # the same forward with the assignment handed in (the test knob the GPU gradient tests use) is the same computation
+    leaves2 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k and not k.startswith('vq.')
+                   else v.clone()) for k, v in sd1.items()}
+    rec2, ll2, _ = oae.vqae_forward(oae.with_vq_stats(leaves2), g['x'], training=True, assign=g['train/idx'].reshape(-1, 1))
+    assert torch.equal(rec2, rec) and torch.equal(ll2, ll)
+
+
 def test_training_step():
     g = load_golden('step_tiny')
     sd0 = sub(g, 'sd0/')

@@ -62,8 +62,9 @@ def cached(params, tag, build):
     return val
 
 
-_scoped = {}       # id(parameter) -> how often invalidate(params) named it
+_scoped = {}       # id(parameter) -> [weakref to it, how often invalidate(params) named it]
 _unscoped = 0      # invalidate() calls that named nothing
+_scoped_sweep_at = 1024
 
 
 def invalidate(params=None):
@@ -71,18 +72,33 @@ def invalidate(params=None):
     next use either way (the global epoch moves); `params` says WHOSE weights moved, for holders of captured graphs: a graph
     re-captures only when its own model's tensors were named (graph.GraphedForward: the frozen auto-encoder's encoder graph must
     survive the denoiser's optimizer steps -- main.py:229-287 runs both in every training step)."""
-    global _epoch, _unscoped
+    global _epoch, _unscoped, _scoped_sweep_at
     _epoch += 1
     if params is None:
         _unscoped += 1
-    else:
-        for p in params:
-            _scoped[id(p)] = _scoped.get(id(p), 0) + 1
+        return
+    for p in params:
+        e = _scoped.get(id(p))
+        # (the key is an id(): a freed parameter's id can come back with another model's tensor -- an entry counts only while its
+        #  weak reference still points at this very object, like _cache's)
+        if e is None or e[0]() is not p:
+            _scoped[id(p)] = [weakref.ref(p), 1]
+        else:
+            e[1] += 1
+    if len(_scoped) >= _scoped_sweep_at:
+        for k in [k for k, e in _scoped.items() if e[0]() is None]:
+            del _scoped[k]
+        _scoped_sweep_at = max(1024, 2 * len(_scoped))
 
 
 def epoch_of(tensors):
     """What a graph holder stamps: moves when invalidate() named one of `tensors` (or named nothing)."""
-    return _unscoped, sum(_scoped.get(id(t), 0) for t in tensors)
+    n = 0
+    for t in tensors:
+        e = _scoped.get(id(t))
+        if e is not None and e[0]() is t:
+            n += e[1]
+    return _unscoped, n
 
 
 def clear():

@@ -223,7 +223,8 @@ class _Bilinear2xFn(torch.autograd.Function):
 
 def _conv_g(x, conv, residual=None):
     y = _Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], residual, False)[0]
-    return y if y.shape[-1] == conv.out_channels else y[..., :conv.out_channels]      # (output channels padded to 8 by the operand)
+    # (output channels padded to 8 by the operand; the kernels behind read raw pointers: hand on a contiguous tensor)
+    return y if y.shape[-1] == conv.out_channels else y[..., :conv.out_channels].contiguous()
 
 
 def _conv_bnact_g(x, conv, bn, r=None, leaky=True, passthrough=False):
@@ -274,9 +275,20 @@ def _count(t):
     return t.numel() // t.shape[-1]
 
 
+def _check_widths(**widths):
+    """The NHWC kernels move channels in groups of 8 (16-byte granules) and the BatchNorm / statistics kernels take the conv's
+    padded output as it is: a width behind a BatchNorm that is not a multiple of 8 would be normalised over padding channels.
+    The reference's defaults and every published run use 64 / 128 (train_vqae.py:205-206); anything else raises here instead of
+    computing something silently different."""
+    for name, c in widths.items():
+        if c % 8 != 0:
+            raise WmzError(f'{name} = {c}: the HIP conv encoder / decoder needs channel widths that are multiples of 8')
+
+
 class Residual(nn.Module):
     def __init__(self, in_planes, hidden_planes, stride=1, normalize=nn.BatchNorm2d, nonlinearity=nn.LeakyReLU):
         super().__init__()
+        _check_widths(in_planes=in_planes, hidden_planes=hidden_planes)
         self._block = nn.Sequential(conv3x3(in_planes, hidden_planes, stride=stride), normalize(hidden_planes),
                                     nonlinearity(inplace=True), conv1x1(hidden_planes, in_planes), normalize(in_planes))
         if stride != 1:
@@ -371,6 +383,7 @@ class SimpleResidualEncoder(nn.Module):
 class UpscaleResidual(nn.Module):
     def __init__(self, in_planes, out_planes, upsample):
         super().__init__()
+        _check_widths(in_planes=in_planes, out_planes=out_planes)
         self.conv1 = nn.Conv2d(in_planes, out_planes, kernel_size=3, padding=1, bias=True)
         self.conv2 = nn.Conv2d(out_planes, out_planes, kernel_size=3, padding=1, bias=True)
         self.bn1 = nn.BatchNorm2d(in_planes)

@@ -356,13 +356,12 @@ extern "C" int wmz_conv_point_fwd_bn(const void* x, const void* wpack, void* out
   const int need = (P.nruns + 3) / 4;
   if (grid > need) grid = need;
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;                                    // (> 64 KB of dynamic LDS has to be asked for once)
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_devs{0};                       // (> 64 KB of dynamic LDS has to be asked for once per device)
+  if (wmz_first_use_on_device(attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convp_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convp_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convp_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convp_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const bool padded = pad > 0;
   if (ncb == 2) {

@@ -319,10 +319,9 @@ extern "C" int wmz_vq_argmin_screened(const float* x, long ldx, const float* cod
   hipLaunchKernelGGL(vq_prep_kernel, dim3(C / 64), dim3(256), 0, st, codebook, EH, EL, NH, emax2_blk, nflag, C);
   hipLaunchKernelGGL(vq_screen_kernel, dim3(wmz_cdiv(N, ROWS_WG)), dim3(ROWS_WG * 2), 0, st, x, ldx, codebook, EH, EL, NH, emax2_blk,
                      idx, dist_min, nflag, flagged, N, C);
-  static bool attr_set = false;                                         // (> 64 KB of dynamic LDS has to be asked for once)
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_devs{0};                       // (> 64 KB of dynamic LDS has to be asked for once per device)
+  if (wmz_first_use_on_device(attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_recheck_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-    attr_set = true;
   }
   // (the flagged-row count lives on the device: a grid that gives ~0.4 % of the rows a workgroup each, the rest leave at once)
   const int rgrid = N / 128 < 256 ? 256 : (N / 128 > 2048 ? 2048 : N / 128);

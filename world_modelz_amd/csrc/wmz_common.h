@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <utility>
+#include <atomic>
 
 #include "../../include/wmz.h"
 
@@ -19,6 +20,15 @@ void wmz_set_error(const char* fmt, ...);
       return WMZ_ERR_ARG;                            \
     }                                                \
   } while (0)
+
+// Function attributes (the > 64 KB dynamic-LDS opt-in) are per DEVICE: a process that drives several GPUs has to set them on each.
+// True the first time the calling thread's current device is seen through `mask` (thread-safe; setting an attribute twice is harmless).
+static inline bool wmz_first_use_on_device(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (mask.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+}
 
 #define WMZ_LAUNCH_CHECK(name)                                               \
   do {                                                                       \

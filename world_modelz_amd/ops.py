@@ -733,7 +733,10 @@ def conv2d_nhwc(x, w_op, KH, KW, stride, pad, bias=None, scale=None, shift=None,
         return (out, s, q) if stats else out
     psc, psh, psl = pre if pre is not None else (None, None, 0.0)     # 1x1 only: LeakyReLU(x * psc + psh) on load
     point = (DIRECT_CONV and x.dtype == torch.bfloat16 and residual is None and 0.0 <= slope <= 1.0
-             and L.lib().wmz_conv_point_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad))
+             and L.lib().wmz_conv_point_supported(B, Hi, Wi, Cin, Cout, KH, KW, stride, pad)
+             # (the streaming kernel's input prologue is built for 1x1 layers of <= 128 channels: wider hidden planes keep
+             #  the implicit-GEMM kernel's prologue)
+             and (pre is None or (KH == 1 and KW == 1 and pad == 0 and Cin <= 128)))
     pst = None
     if isinstance(psc, BnLazy):                   # the prologue's BatchNorm as raw statistics: the streaming kernel finalises it
         if point and not psc.done:
@@ -906,7 +909,7 @@ def dilate_nhwc(dy, Hz, Wz, stride):
     """dz [B, Hz, Wz, C] with dz[:, ::stride, ::stride] = dy and zeros elsewhere (one pass: wmz_dilate_nhwc)."""
     B, Ho, Wo, C = dy.shape
     dy = dy.contiguous()
-    if not DILATE_KERNEL:                         # A/B (tools/time_vqae_modes.py): the fill + strided copy of torch
+    if not DILATE_KERNEL or B > 65535 or Hz > 65535:     # (the kernel's grid.y / grid.z limits; A/B: tools/time_vqae_modes.py) the fill + strided copy of torch
         dz = torch.zeros((B, Hz, Wz, C), dtype=dy.dtype, device=dy.device)
         dz[:, 0:(Ho - 1) * stride + 1:stride, 0:(Wo - 1) * stride + 1:stride] = dy
         return dz
