@@ -10,8 +10,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
-WMZ_F32, WMZ_BF16 = 0, 1
-EXPECTED_VERSION = 107      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
+WMZ_F32, WMZ_BF16, WMZ_F16 = 0, 1, 2
+EXPECTED_VERSION = 108      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -139,6 +139,11 @@ SIGNATURES = {
 }
 
 
+for _n in ('wmz_layer_fused_fwd', 'wmz_embed_qkv_fused_fwd', 'wmz_layer_fused_fwd_planes', 'wmz_embed_qkv_fused_fwd_planes',
+           'wmz_layer_fused_pack', 'wmz_fused_pack_table'):
+    SIGNATURES[_n + '_f16'] = SIGNATURES[_n]          # the precise (IEEE half) instantiations: include/wmz.h
+
+
 class WmzError(RuntimeError):
     pass
 
@@ -193,6 +198,8 @@ def dtype_code(dt):
         return WMZ_F32
     if dt == torch.bfloat16:
         return WMZ_BF16
+    if dt == torch.float16:
+        return WMZ_F16          # (the precise fused inference mode: the few entry points that take it say so in include/wmz.h)
     raise WmzError(f'unsupported activation dtype {dt}: the HIP path computes in float32 or bfloat16')
 
 

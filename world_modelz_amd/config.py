@@ -4,30 +4,51 @@ import os
 
 import torch
 
-_DTYPES = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'fp32': torch.float32, 'float32': torch.float32}
+_DTYPES = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'fp32': torch.float32, 'float32': torch.float32,
+           'f16': torch.float16, 'fp16': torch.float16, 'float16': torch.float16, 'precise': torch.float16}
 
 # Activation / MFMA-operand dtype of the denoiser kernels.  Parameters stay fp32 (state_dict compatible with
-# the reference); bf16 operand copies are cached per parameter version.  fp32 is the parity mode
-# (exact-f32 MFMA), bf16 the speed mode named by BASELINE.json.
-_compute_dtype = _DTYPES[os.environ.get('WMZ_COMPUTE_DTYPE', 'bf16').lower()]
+# the reference); operand copies are cached per parameter version.  Three modes:
+#   bf16    the speed mode named by BASELINE.json (end-to-end logits ~4e-3 from the fp32 reference on the default model);
+#   fp32    the parity mode (exact-f32 MFMA at 1/16 of the matrix rate, op by op: ~4e-7, 11x slower);
+#   float16 the PRECISE fused mode: inference at the default widths runs the fused kernels with IEEE-half MFMA operands and a half
+#           residual stream between the layers (~5e-4 at the bf16 speed: inside the 1e-3 BASELINE.json asks for); everything the
+#           half kernels are not built for (training, other widths, the conv encoder / decoder) runs the fp32 route -- never bf16.
+_precise = False
+_compute_dtype = None
 
 
 def get_compute_dtype():
+    """The dtype of everything that is NOT on the fused inference kernels (fp32 in the precise mode)."""
     return _compute_dtype
 
 
+def get_fused_dtype():
+    """The operand / stream dtype of the fused inference kernels: torch.float16 in the precise mode, else the compute dtype."""
+    return torch.float16 if _precise else _compute_dtype
+
+
+def get_mode_dtype():
+    """What set_compute_dtype was given (the context manager restores this)."""
+    return torch.float16 if _precise else _compute_dtype
+
+
 def set_compute_dtype(dt):
-    global _compute_dtype
+    global _compute_dtype, _precise
     if isinstance(dt, str):
         dt = _DTYPES[dt.lower()]
-    if dt not in (torch.float32, torch.bfloat16):
-        raise ValueError(f'compute dtype must be float32 or bfloat16, got {dt}')
-    _compute_dtype = dt
+    if dt not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError(f'compute dtype must be float32, bfloat16 or float16 (the precise fused mode), got {dt}')
+    _precise = dt == torch.float16
+    _compute_dtype = torch.float32 if _precise else dt
+
+
+set_compute_dtype(os.environ.get('WMZ_COMPUTE_DTYPE', 'bf16'))
 
 
 @contextlib.contextmanager
 def compute_dtype(dt):
-    prev = get_compute_dtype()
+    prev = get_mode_dtype()
     set_compute_dtype(dt)
     try:
         yield

@@ -251,6 +251,9 @@ int launch(const void* q, const void* k, const void* v, void* out, float* lse, f
 // fast path for 16-wide planes: one query row per wave (attn_fwd_row16.hip)
 int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
                                 const AttnGeom& G, hipStream_t st);
+// ... and its IEEE-half instantiation (attn_fwd_row16_f16.hip: the precise fused mode, dtype WMZ_F16)
+int wmz_attn_fwd_row16_dispatch_f16(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
+                                    const AttnGeom& G, hipStream_t st);
 
 // development knobs (wmz_debug_attn_knobs): ablation switches and kernel-variant selector, 0 / 0 in production
 static int g_attn_dbg = 0, g_attn_variant = 0;
@@ -291,7 +294,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
   WMZ_REQUIRE(H <= 16384 && W <= 16384, "wmz_local3d_attn_fwd: H, W must be <= 16384");
   WMZ_REQUIRE(dh % 8 == 0, "wmz_local3d_attn_fwd: dim_head must be a multiple of 8 (got %d)", dh);
   WMZ_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "wmz_local3d_attn_fwd: row strides must be multiples of 8");
-  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_local3d_attn_fwd: bad dtype %d", dtype);
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16 || dtype == WMZ_F16, "wmz_local3d_attn_fwd: bad dtype %d", dtype);
   if (dh > 128) { wmz_set_error("wmz_local3d_attn_fwd: dim_head %d > 128 not built", dh); return WMZ_ERR_UNSUPPORTED; }
   AttnGeom G;
   G.B = B; G.S = S; G.H = H; G.W = W; G.heads = heads; G.dh = dh; G.eS = eS; G.eH = eH; G.eW = eW;
@@ -303,15 +306,20 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* out,
   G.variant = g_attn_variant;
   G.w8 = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == WMZ_BF16 && (dh == 32 || dh == 64 || dh == 128) && !general) {
-    if (W == 16) return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G, st);
+  if (dtype != WMZ_F32 && (dh == 32 || dh == 64 || dh == 128) && !general) {
+    const auto row16 = dtype == WMZ_F16 ? wmz_attn_fwd_row16_dispatch_f16 : wmz_attn_fwd_row16_dispatch;
+    if (W == 16) return row16(q, k, v, out, lse, logits_dbg, G, st);
     if (W == 8 && (H & 1) == 0) {
       // an 8-wide plane with an even number of rows is a 16-wide plane of H / 2 tile rows in memory (the reference's own 8x8
       // latents, main.py:394): the row kernel with its window test in tile coordinates
       AttnGeom G8 = G;
       G8.w8 = 1; G8.H = H / 2; G8.W = 16;
-      return wmz_attn_fwd_row16_dispatch(q, k, v, out, lse, logits_dbg, G8, st);
+      return row16(q, k, v, out, lse, logits_dbg, G8, st);
     }
+  }
+  if (dtype == WMZ_F16) {
+    wmz_set_error("wmz_local3d_attn_fwd: half operands are built for the row kernel's shapes (dim_head 32 / 64 / 128, planes 16 wide or 8 wide with an even number of rows)");
+    return WMZ_ERR_UNSUPPORTED;
   }
   const int DHp = dh <= 32 ? 32 : (dh <= 64 ? 64 : 128);
   if (dtype == WMZ_BF16) {

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(SH::NW * 64, 4) void attn_fwd_row16_kernel(const bf
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           asm volatile("" : "+v"(x0[mt]));
-          o[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x0[mt], pf, o[mt], 0, 0, 0);
+          o[mt] = op16_mfma_16x16x16(x0[mt], pf, o[mt]);
         }
       }
     }
@@ -555,7 +555,9 @@ int by_dh(const void* q, const void* k, const void* v, void* out, float* lse, fl
 
 // Development probe: per-wave s_memtime stamps of workgroup 0 (tools/ts_attn.py); nullptr switches back to the product
 // instantiation, which carries no stamp code at all.
+#ifndef WMZ_OP16_F16
 extern "C" int wmz_debug_attn_timestamps(void* buf) { g_attn_ts = (long long*)buf; return WMZ_OK; }
+#endif
 
 #ifndef WMZ_ATTN_MODE
 #define WMZ_ATTN_MODE 9          // kSched[1]: K pieces behind the barrier, V pieces inside the first step; 16-byte output stores
@@ -564,7 +566,7 @@ extern "C" int wmz_debug_attn_timestamps(void* buf) { g_attn_ts = (long long*)bu
 // Called by wmz_local3d_attn_fwd when the shape qualifies (bf16, dim_head in {32,64,128}; W == 16, or W == 8 with an even number
 // of rows: G.w8 set and G.H = H / 2 tile rows).  dbg: optional logits probe [N, heads, window] (natural-log-domain scaled logits of
 // the in-window slots, pre-filled with -1e9 by the caller).
-int wmz_attn_fwd_row16_dispatch(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
+int WMZ_FN(wmz_attn_fwd_row16_dispatch)(const void* q, const void* k, const void* v, void* out, float* lse, float* dbg,
                                 const AttnGeom& G, hipStream_t st) {
   if (G.w8) {
     // planes of up to 8 tile rows (the reference's 8x8 latents: 4) on 4-wave workgroups with 2-row slabs, larger ones on the big shape

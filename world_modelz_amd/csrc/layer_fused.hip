@@ -390,14 +390,16 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
 static int fused_launch(FusedParams& P, int ntok, int D, int I, int M, int has_head, int has_tail, void* stream);
 static long long* g_fused_ts = nullptr;
 static int g_fused_dbg = 0;       // ablation switches (wmz_debug_fused_knobs): 1 = skip the MFMA loops, 2 = skip the weight DMA + waits
+#ifndef WMZ_OP16_F16
 extern "C" int wmz_debug_fused_knobs(int dbg) { g_fused_dbg = dbg; return WMZ_OK; }
 // Timing probe for kernel development (tools/ts_fused.py): a device buffer of 8 * 64 int64; NULL switches it off.
 extern "C" int wmz_debug_fused_timestamps(void* buf) { g_fused_ts = (long long*)buf; return WMZ_OK; }
+#endif
 
-extern "C" int wmz_layer_fused_fwd(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
+extern "C" int WMZ_FN(wmz_layer_fused_fwd)(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
                                    const void* wpack, const float* vec, int ntok, int D, int I, int M, int has_head,
                                    int has_tail, float eps, void* stream) {
-  return wmz_layer_fused_fwd_planes(o, x, x_out, q_out, kv_out, wpack, vec, 1, 1, 1, ntok, D, I, M, has_head, has_tail, 0,
+  return WMZ_FN(wmz_layer_fused_fwd_planes)(o, x, x_out, q_out, kv_out, wpack, vec, 1, 1, 1, ntok, D, I, M, has_head, has_tail, 0,
                                     eps, stream);
 }
 
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256) void fused_pack_vec_kernel(PackParams P) {
 }
 }  // namespace
 
-extern "C" int wmz_layer_fused_pack(const float* wout, const float* bout, const float* g2, const float* be2, const float* w1,
+extern "C" int WMZ_FN(wmz_layer_fused_pack)(const float* wout, const float* bout, const float* g2, const float* be2, const float* w1,
                                     const float* b1, const float* w2, const float* b2, const float* g1, const float* be1,
                                     const float* wq, const float* wk, const float* wv, const float* bv, void* wpack,
                                     float* vec, int D, int I, int M, void* stream) {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void fused_pack_vec_table_kernel(const VecJobG
 }
 }  // namespace
 
-extern "C" int wmz_fused_pack_table(const void* block_rows, int nblk, long total8, const void* vec_jobs, int nvec, int D, int I,
+extern "C" int WMZ_FN(wmz_fused_pack_table)(const void* block_rows, int nblk, long total8, const void* vec_jobs, int nvec, int D, int I,
                                     int M, void* stream) {
   WMZ_REQUIRE(nblk >= 0 && nvec >= 0 && (nblk == 0 || (block_rows && total8 > 0)) && (nvec == 0 || vec_jobs),
               "wmz_fused_pack_table: bad arguments");
@@ -583,6 +585,7 @@ extern "C" int wmz_fused_pack_table(const void* block_rows, int nblk, long total
   return WMZ_OK;
 }
 
+#ifndef WMZ_OP16_F16      // (training forward + backward streams: the bf16 unit only)
 // Weight streams of the fused BACKWARD kernels (layer_fused_bwd.hip), TRANSPOSED blocks in consumption order:
 //   wpack_qkv:  Wk'^T | Wv'^T | Wq^T          ([D x I] each; ' = the attention LayerNorm's gamma folded in: rows scaled)
 //   wpack_ff:   W2^T[c] (c = 0 .. M/32-1: [32 x D]) | W1'^T [D x M] | Wout^T [I x D]
@@ -670,7 +673,9 @@ extern "C" int wmz_embed_qkv_fused_fwd_train(const int64_t* z, const float* emb,
   return fused_launch(P, P.ntok, D, I, M, 0, 1, stream);
 }
 
-extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
+#endif  // WMZ_OP16_F16
+
+extern "C" int WMZ_FN(wmz_layer_fused_fwd_planes)(const void* o, const void* x, void* x_out, void* q_out, void* kv_out,
                                           const void* wpack, const float* vec, int B, int planes_out, int planes_in, int HW,
                                           int D, int I, int M, int has_head, int has_tail, int xflags, float eps,
                                           void* stream) {
@@ -696,15 +701,15 @@ extern "C" int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_
   return fused_launch(P, ntok, D, I, M, has_head, has_tail, stream);
 }
 
-extern "C" int wmz_embed_qkv_fused_fwd(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+extern "C" int WMZ_FN(wmz_embed_qkv_fused_fwd)(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                        const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                        const float* vec, int B, int S, int H, int W, int D, int I, int M, int num_classes,
                                        float eps, void* stream) {
-  return wmz_embed_qkv_fused_fwd_planes(z, emb, pos_s, pos_h, pos_w, x_out, q_out, kv_out, wpack, vec, B, S, H, W, S, D, I, M,
+  return WMZ_FN(wmz_embed_qkv_fused_fwd_planes)(z, emb, pos_s, pos_h, pos_w, x_out, q_out, kv_out, wpack, vec, B, S, H, W, S, D, I, M,
                                         num_classes, 0, eps, stream);
 }
 
-extern "C" int wmz_embed_qkv_fused_fwd_planes(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
+extern "C" int WMZ_FN(wmz_embed_qkv_fused_fwd_planes)(const int64_t* z, const float* emb, const float* pos_s, const float* pos_h,
                                               const float* pos_w, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                               const float* vec, int B, int S, int H, int W, int planes_out, int D, int I,
                                               int M, int num_classes, int xflags, float eps, void* stream) {

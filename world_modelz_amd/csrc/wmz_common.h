@@ -50,6 +50,41 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;   // 8 bf16 = one 16x16
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
+// ---- the 16-bit MFMA operand format of a translation unit.  The kernels move 16-bit elements as raw bits (s16x8 fragments, the
+// `bf16_t` storage tag) and touch their VALUE only through the few primitives below, so the number format is decided here, once
+// per translation unit: bfloat16 (the speed mode BASELINE.json names) by default; IEEE half when the unit is compiled with
+// WMZ_OP16_F16 -- the "precise" fused mode (same MFMA rate, 11 significand bits instead of 8: end-to-end logits 8x closer to the
+// reference's fp32, range +-65504).  A precise unit is a second compilation of the same source (csrc/*_f16.hip) whose entry
+// points carry the suffix _f16 (WMZ_FN below).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#ifdef WMZ_OP16_F16
+#define WMZ_FN(name) name##_f16
+constexpr int kOp16Dtype = WMZ_F16;
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+// round-to-nearest-even (v_cvt_f16_f32); beyond +-65504 the result is an infinity, like the hardware conversion
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ s16x4 cvt_pk4_bf16(float a, float b, float c, float d) {
+  const f16x2_t lo = __builtin_convertvector((f32x2){a, b}, f16x2_t), hi = __builtin_convertvector((f32x2){c, d}, f16x2_t);
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const u32x2 w = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, w);
+}
+__device__ __forceinline__ f32x4 op16_mfma_16x16x32(const s16x8& a, const s16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 op16_mfma_32x32x16(const s16x8& a, const s16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 op16_mfma_16x16x16(const s16x4& a, const s16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
+}
+#else
+#define WMZ_FN(name) name
+constexpr int kOp16Dtype = WMZ_BF16;
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
   return __uint_as_float(((unsigned)b) << 16);
 }
@@ -60,14 +95,22 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
 }
 
 // four floats -> four bf16 (round-to-nearest-even) in two registers: two v_cvt_pk_bf16_f32, nothing else
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ s16x4 cvt_pk4_bf16(float a, float b, float c, float d) {
   const bf16x2_t lo = __builtin_convertvector((f32x2){a, b}, bf16x2_t), hi = __builtin_convertvector((f32x2){c, d}, bf16x2_t);
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
   const u32x2 w = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
   return __builtin_bit_cast(s16x4, w);
 }
+__device__ __forceinline__ f32x4 op16_mfma_16x16x32(const s16x8& a, const s16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 op16_mfma_32x32x16(const s16x8& a, const s16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 op16_mfma_16x16x16(const s16x4& a, const s16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+#endif
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -79,8 +122,8 @@ template <> struct Elem<float> {
 template <> struct Elem<bf16_t> {
   static constexpr int kDtype = WMZ_BF16;
   static constexpr int kPerChunk = 8;
-  __device__ static __forceinline__ float to_f32(bf16_t v) { return __bfloat162float(v); }
-  __device__ static __forceinline__ bf16_t from_f32(float v) { return __float2bfloat16(v); }
+  __device__ static __forceinline__ float to_f32(bf16_t v) { return bf16_bits_to_f32(__builtin_bit_cast(unsigned short, v)); }
+  __device__ static __forceinline__ bf16_t from_f32(float v) { return __builtin_bit_cast(bf16_t, f32_to_bf16_bits(v)); }
 };
 
 // An MFMA operand fragment of 8 consecutive k-elements (lane-local).
@@ -108,7 +151,7 @@ __device__ __forceinline__ void frag_load(Frag8<float>& f, const float* p) {
 // D(16x16) += A(16x32) * B(32x16).  Lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15],
 // j = 0..7; D: col = l&15, row = 4*(l>>4)+reg.   f32: eight exact-f32 16x16x4 MFMAs (k = 8g+j summed over g).
 __device__ __forceinline__ void mma16(f32x4& acc, const Frag8<bf16_t>& a, const Frag8<bf16_t>& b) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+  acc = op16_mfma_16x16x32(a.v, b.v, acc);
 }
 __device__ __forceinline__ void mma16(f32x4& acc, const Frag8<float>& a, const Frag8<float>& b) {
 #pragma unroll
@@ -118,7 +161,7 @@ __device__ __forceinline__ void mma16(f32x4& acc, const Frag8<float>& a, const F
 // D(32x32) += A(32x16) * B(16x32).  Lane l holds A[row l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col l&31];
 // D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 __device__ __forceinline__ void mma32(f32x16& acc, const Frag8<bf16_t>& a, const Frag8<bf16_t>& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+  acc = op16_mfma_32x32x16(a.v, b.v, acc);
 }
 __device__ __forceinline__ void mma32(f32x16& acc, const Frag8<float>& a, const Frag8<float>& b) {
 #pragma unroll

@@ -27,7 +27,9 @@ def _pack_w(w):
 
 
 def supported(transformer, x_dtype):
-    if x_dtype != torch.bfloat16 or len(transformer.layers) == 0:
+    """The fused per-token + row-attention kernels hold this stack: bf16 (speed mode) or float16 (the precise mode: inference
+    only -- the callers that train pass the compute dtype, which is fp32 there), default widths, no dropout."""
+    if x_dtype not in (torch.bfloat16, torch.float16) or len(transformer.layers) == 0:
         return False
     for attn, ff in transformer.layers:
         a, f = attn.fn, ff.fn
@@ -460,7 +462,11 @@ def transformer_forward_chain_train(tr, packs, z, last_only=False):
     return _ChainTrainForward.apply(tr, packs, z, last_only, *params)
 
 
-def _layer_pack(head, tail):
+def _sfx(dt):
+    return '_f16' if dt == torch.float16 else ''
+
+
+def _layer_pack(head, tail, dt=torch.bfloat16):
     """head / tail: (attn PreNorm, ff PreNorm) of the layer whose to_out+FF run, and of the layer whose q|k|v run.
     Returns (wpack bf16, vec fp32) built by ONE launch of wmz_layer_fused_pack from the fp32 parameters: the weights in
     the kernel's streaming order (see _pack_w for the element order; W1 rows one chunk ahead of the W2 columns:
@@ -482,12 +488,12 @@ def _layer_pack(head, tail):
         tp = ps[-6:] if tail is not None else [None] * 6
         nw = (D_ * I_ + 2 * M_ * D_ if head is not None else 0) + (3 * I_ * D_ if tail is not None else 0)
         dev = ps[0].device
-        wpack = torch.empty(nw + _PAD // 2, dtype=torch.bfloat16, device=dev)
+        wpack = torch.empty(nw + _PAD // 2, dtype=dt, device=dev)
         vec = torch.empty(2048, dtype=torch.float32, device=dev)
-        L.call('wmz_layer_fused_pack', *[L.ptr(t) for t in hp], *[L.ptr(t) for t in tp], L.ptr(wpack), L.ptr(vec),
+        L.call('wmz_layer_fused_pack' + _sfx(dt), *[L.ptr(t) for t in hp], *[L.ptr(t) for t in tp], L.ptr(wpack), L.ptr(vec),
                D_, I_, M_, L.stream())
         return wpack, vec
-    return _cast.cached(params, 'fusedpack', build)
+    return _cast.cached(params, 'fusedpack' + _sfx(dt), build)
 
 
 def _layer_pack_bwd(attn, ff):
@@ -616,12 +622,12 @@ def layer_fused(o, x, head, tail, eps=1e-5, xflags=0):
     """One launch of the fused per-token kernel on row-major (or, with xflags, tiled-stream) x.
     Returns (x_out | None, q | None, kv | None)."""
     ntok = x.numel() // D_
-    wpack, vec = _layer_pack(head, tail)
+    wpack, vec = _layer_pack(head, tail, x.dtype)
     lead = x.shape[:-1]
     xo = torch.empty_like(x) if head is not None else None
     q = torch.empty(lead + (I_,), dtype=x.dtype, device=x.device) if tail is not None else None
     kv = torch.empty((2,) + lead + (I_,), dtype=x.dtype, device=x.device) if tail is not None else None
-    L.call('wmz_layer_fused_fwd_planes', L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
+    L.call('wmz_layer_fused_fwd_planes' + _sfx(x.dtype), L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
            1, 1, 1, ntok, D_, I_, M_, 1 if head is not None else 0, 1 if tail is not None else 0, int(xflags), float(eps),
            L.stream())
     return xo, q, kv
@@ -660,7 +666,8 @@ def _run(tr, z, cone):
     if groups <= 1:
         return _run_chain(tr, z, cone, None)
     n_out = (cone_planes(z.shape[1], eS, len(layers))[0][-1]) if use_cone else z.shape[1]
-    out = torch.empty((B, n_out) + tuple(z.shape[2:]) + (D_,), dtype=torch.bfloat16, device=z.device)
+    dt = config.get_fused_dtype()
+    out = torch.empty((B, n_out) + tuple(z.shape[2:]) + (D_,), dtype=dt, device=z.device)
     cur = torch.cuda.current_stream()
     pool = _side_streams.setdefault(z.device, [])
     while len(pool) < groups - 1:
@@ -669,8 +676,8 @@ def _run(tr, z, cone):
     bounds = [(g * B) // groups for g in range(groups + 1)]
     # the weight streams are packed (cached per parameter version) on the caller's stream BEFORE the fork: every chain reads them
     for l in range(len(layers)):
-        _layer_pack(None if l == 0 else layers[l - 1], layers[l])
-    _layer_pack(layers[-1], None)
+        _layer_pack(None if l == 0 else layers[l - 1], layers[l], dt)
+    _layer_pack(layers[-1], None, dt)
     for g in range(1, groups):
         st = pool[g - 1]
         st.wait_stream(cur)
@@ -694,13 +701,15 @@ def _run_chain(tr, z, cone, out):
         cone = False
     need, src = cone_planes(S, eS, depth) if cone else ([S] * depth, [S] * depth)
     tiled = HW % 32 == 0                      # whole 32-token tiles per plane: the stream between layers stays tiled
-    dev, bf = z.device, torch.bfloat16
+    from . import config
+    dev, bf = z.device, config.get_fused_dtype()          # (bf: bfloat16, or float16 in the precise mode)
+    sfx = _sfx(bf)
     n0 = src[0]
-    wpack, vec = _layer_pack(None, layers[0])
+    wpack, vec = _layer_pack(None, layers[0], bf)
     x = torch.empty((B, n0, H, W, D_), dtype=bf, device=dev)
     q = torch.empty((B, n0, H, W, I_), dtype=bf, device=dev)
     kv = torch.empty((2, B, n0, H, W, I_), dtype=bf, device=dev)          # k planes, then v planes
-    L.call('wmz_embed_qkv_fused_fwd_planes', L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
+    L.call('wmz_embed_qkv_fused_fwd_planes' + sfx, L.ptr(z.contiguous()), L.ptr(tr.embedding.weight.detach()),
            L.ptr(tr.pos_emb_s.weight.detach()), L.ptr(tr.pos_emb_h.weight.detach()), L.ptr(tr.pos_emb_w.weight.detach()),
            L.ptr(x), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec), B, S, H, W, n0, D_, I_, M_,
            tr.embedding.num_embeddings, X_OUT_TILED if tiled else 0, 1e-5, L.stream())
@@ -716,12 +725,12 @@ def _run_chain(tr, z, cone, out):
         if ops._profile_hook is not None:
             ops._profile_hook('wmz_local3d_attn_fwd', False)
         tail = layers[l + 1] if l + 1 < depth else None
-        wpack, vec = _layer_pack((attn, ff), tail)
+        wpack, vec = _layer_pack((attn, ff), tail, bf)
         xo = out if (tail is None and out is not None) else torch.empty((B, n_q, H, W, D_), dtype=bf, device=dev)
         q = torch.empty((B, n_q, H, W, I_), dtype=bf, device=dev) if tail is not None else None
         kv = torch.empty((2, B, n_q, H, W, I_), dtype=bf, device=dev) if tail is not None else None
         xflags = (X_IN_TILED if tiled else 0) | (X_OUT_TILED if tiled and tail is not None else 0)
-        L.call('wmz_layer_fused_fwd_planes', L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
+        L.call('wmz_layer_fused_fwd_planes' + sfx, L.ptr(o), L.ptr(x), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
                B, n_q, n_in, HW, D_, I_, M_, 1, 1 if tail is not None else 0, xflags, 1e-5, L.stream())
         x = xo
     return x

@@ -61,7 +61,7 @@ class GraphedForward:
         # version / address reads of ~90 tensors ~20; parameters replaced by NEW objects are caught by _capture's list
         # being rebuilt whenever anything else in the stamp changes -- and by load_state_dict / .to() / optimizers, which
         # all write the existing objects)
-        return (_cast.epoch_of(self._tensors), config.get_compute_dtype(), config.get_last_frame_cone(), config.get_clip_streams(),
+        return (_cast.epoch_of(self._tensors), config.get_mode_dtype(), config.get_last_frame_cone(), config.get_clip_streams(),
                 tuple((t._version, t.data_ptr()) for t in self._tensors))
 
     @gc_quiet

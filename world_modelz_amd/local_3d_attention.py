@@ -182,10 +182,10 @@ class Local3dAttentionTransformer(nn.Module):
         self.check_grid(img_z)
         if not torch.is_grad_enabled():
             from . import fused
-            from .config import get_compute_dtype
-            if fused.supported(self, get_compute_dtype()):
-                # inference, bf16, default widths: one attention launch + one per-token launch per layer, the
-                # embedding fused into the first one
+            from .config import get_compute_dtype, get_fused_dtype
+            if fused.supported(self, get_fused_dtype()):
+                # inference, bf16 (or half: the precise mode), default widths: one attention launch + one per-token launch per
+                # layer, the embedding fused into the first one
                 return fused.transformer_forward(self, z=img_z)
             if fused.chain_supported(self, get_compute_dtype()):
                 # the reference's published widths: the same fusion on csrc/layer_chain.hip

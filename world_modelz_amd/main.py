@@ -20,13 +20,17 @@ class VqVideoDiffusionModel(nn.Module):
     def forward(self, x):
         if not torch.is_grad_enabled() and x.is_cuda:
             from . import config, fused
-            if config.get_last_frame_cone() and fused.supported(self.transformer, config.get_compute_dtype()):
+            if config.get_last_frame_cone() and fused.supported(self.transformer, config.get_fused_dtype()):
                 tr = self.transformer
                 _, S, H, W = x.shape
                 if S > tr.pos_emb_s.num_embeddings or H > tr.pos_emb_h.num_embeddings or W > tr.pos_emb_w.num_embeddings:
                     raise IndexError('token grid larger than the position-embedding tables')
                 last = fused.transformer_forward_last(tr, x)      # only the planes the last frame depends on
-                return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)
+                return self._logits(last)
         h = self.transformer.forward_compute(x)
-        last = h[:, -1]                       # [B,H,W,D] view: uniform row stride, no copy
+        return self._logits(h[:, -1])         # [B,H,W,D] view: uniform row stride, no copy
+
+    def _logits(self, last):
+        if last.dtype == torch.float16:       # the precise mode's half stream: the last frame's projection runs in fp32
+            last = last.float()
         return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)
