@@ -46,8 +46,13 @@ def _deps_mtime():
 def _compile(src, force, hdr_mtime):
     obj = os.path.join(OBJ, src[:-4] + '.o')
     path = os.path.join(CSRC, src)
+    src_mtime = os.path.getmtime(path)
+    if src.endswith('_f16.hip'):                # a precise-mode unit is a second compilation of its base source (wmz_common.h)
+        base = os.path.join(CSRC, src[:-8] + '.hip')
+        if os.path.exists(base):
+            src_mtime = max(src_mtime, os.path.getmtime(base))
     if (not force and os.path.exists(obj)
-            and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_mtime)):
+            and os.path.getmtime(obj) >= max(src_mtime, hdr_mtime)):
         return obj, False
     extra = os.environ.get('WMZ_EXTRA_HIPCC_FLAGS', '').split()     # kernel-tuning experiments (-DWMZ_FUSED_HPS=1 ...)
     cmd = [_hipcc()] + COMMON + PER_FILE.get(src, []) + extra + ['-c', path, '-o', obj]

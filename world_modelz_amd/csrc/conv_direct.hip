@@ -381,19 +381,26 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(DirectParams P) {
 // STRIDE = 2 (3x3 / stride 2 / pad 1, Cout = 128: the first convolution of the down-sampling Residual, autoencoder.py:27-33): the
 // same machine on the four PARITY planes of the input -- x[2 i + p, 2 j + q] for (p, q) in {0, 1}^2: tap (kh, kw) reads plane
 // (kh != 1, kw != 1) at the output pixel's own (i, j) or one row / column before it, so inside a plane the lanes of a fragment
-// again walk consecutive pixels (the DMA de-interleaves on the source side).  An output tile of 8 x 16 pixels needs 4 x 9 x 17
-// plane pixels: staged 32 channels at a time (pixel pitch 80 bytes: the image stays under 48 KB), i.e. Cin / 32 passes of 9 taps x
-// 2 k-steps; the packed weight stream is the stride-1 one, its fragments visited in this order.
+// again walk consecutive pixels (the DMA de-interleaves on the source side).  Round 6: every input pixel belongs to ONE plane, so
+// the taps are grouped by the planes they read and a pixel's 64 channels (one 128-byte line) are fetched ONCE: group A = the four
+// corner taps (plane (1, 1)), group B = the centre tap and the four edge taps (planes (0, 0), (0, 1), (1, 0)); a 64-channel pass is
+// [stage A's plane, 4 taps][stage B's three planes, 5 taps] (round 5 staged all four planes 32 channels at a time: every line
+// fetched as two halves in two passes -- fabric traffic 1.86 x the input, pmc_conv.json).  An 8 x 16 output tile needs 9 x 17
+// pixels of a plane at the stride-1 pixel pitch of 144 bytes; a plane ROW is padded to 160 sixteen-byte slots (= 0 mod 16): the 16
+// lanes of a ds_read_b128 group are 8 pixels of one tile row and 8 of the next, and with 17-pixel rows two of them met in a bank
+// (round 5: 0.47 of the LDS cycles were conflicts) -- with rows a multiple of 16 slots apart the 16 slot residues are distinct.
+// The packed weight stream is the stride-1 one, its fragments visited in this order.
 template <int NCB, int TW, int STRIDE>
 struct CrShape {
   static constexpr int TILE_PX = STRIDE == 1 ? 256 : 128;
   static constexpr int TH = TILE_PX / TW, PH = TH + 2, PW = TW + 2;
-  static constexpr int PLANE = (TH + 1) * (TW + 1);                // STRIDE 2: pixels of one parity plane of the patch
-  static constexpr int NPX = STRIDE == 1 ? PH * PW : 4 * PLANE;
-  static constexpr int PITCH = STRIDE == 1 ? CQ_PITCH : 80;        // bytes per patch pixel: 64 | 32 channels + one dead 16-byte slot
+  static constexpr int PITCH = CQ_PITCH;                           // bytes per patch pixel: 64 channels + one dead 16-byte slot
   static constexpr int SPP = PITCH / 16;                           // 16-byte slots per patch pixel
-  static constexpr int KS = STRIDE == 1 ? 4 : 2;                   // k-steps per (pass, tap)
-  static constexpr int PATCH = (NPX * PITCH + 1023) / 1024 * 1024;
+  static constexpr int ROW_SLOTS = STRIDE == 1 ? PW * SPP : 160;   // 16-byte slots per patch row (STRIDE 2: 17 pixels padded, see above)
+  static constexpr int ROW_BYTES = ROW_SLOTS * 16;
+  static constexpr int PLANE_BYTES = (TH + 1) * ROW_BYTES;         // STRIDE 2: one parity plane of the patch (TH + 1 rows)
+  static constexpr int KS = 4;                                     // k-steps per (pass, tap)
+  static constexpr int PATCH = ((STRIDE == 1 ? PH * PW * PITCH : 3 * PLANE_BYTES) + 1023) / 1024 * 1024;
   static constexpr int NPB = TILE_PX * NCB / 128;                  // 32-pixel blocks per wave
   static constexpr int BPR = 2;                                    // blocks per epilogue round (bf16 staging, double-buffered)
   static constexpr int OPITCH = 80, FPITCH = 144;                  // staging rows: 32 channels bf16 / fp32 + 16 bytes
@@ -401,8 +408,12 @@ struct CrShape {
   static constexpr int STAGE = STAGE_A > STAGE_B ? STAGE_A : STAGE_B;
   static constexpr int LDS = PATCH > 4 * STAGE ? PATCH : 4 * STAGE;
   static_assert(STRIDE == 1 || (TW == 16 && NCB == 4), "the stride-2 form is built for Cout = 128 on 8 x 16 tiles");
+  static_assert(STRIDE == 1 || (ROW_SLOTS >= (TW + 1) * SPP && ROW_SLOTS % 16 == 0), "conflict-free plane rows");
   static_assert(LDS <= 81920, "two workgroups per CU");
 };
+// STRIDE 2: tap order of a 64-channel pass (group A: 4 corner taps, then group B: centre + edges) and where a tap's plane is staged
+__host__ __device__ constexpr int cr2_tap(int idx) { constexpr int o[9] = {0, 2, 6, 8, 4, 3, 5, 1, 7}; return o[idx]; }
+__host__ __device__ constexpr int cr2_slot(int kh, int kw) { return (kh != 1 && kw != 1) ? 0 : ((kh == 1 && kw == 1) ? 0 : (kh == 1 ? 1 : 2)); }
 
 // NPASS = Cin / 64
 template <int NCB, int TW, int NPASS, int STRIDE = 1>
@@ -420,25 +431,37 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   const int ty = lid % P.tiles_y;
   const int b = lid / P.tiles_y;
   const int oy0 = ty * S::TH, ox0 = tx * TW;
-  constexpr int nslab = NPASS * 9 * (STRIDE == 1 ? 1 : 2);         // (channel pass, tap) slabs: passes of 64 | 32 channels
+  constexpr int nslab = NPASS * 9;                                 // (64-channel pass, tap) slabs
 
+  // stride 1: pass = 64-channel pass.  stride 2: pass = 2 * (64-channel pass) + group (0: A = plane (1, 1); 1: B = planes (0, 0), (0, 1), (1, 0))
   auto issue_patch = [&](int pass) {
-    const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + pass * (STRIDE == 1 ? 64 : 32);
-    for (int pc = wave; pc < S::PATCH / 1024; pc += 4) {
-      const int q = pc * 64 + lane;
-      const int pix = q / S::SPP, c = q - pix * S::SPP;
-      int iy, ix;
-      if constexpr (STRIDE == 1) {
+    if constexpr (STRIDE == 1) {
+      const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + pass * 64;
+      for (int pc = wave; pc < S::PATCH / 1024; pc += 4) {
+        const int q = pc * 64 + lane;
+        const int pix = q / S::SPP, c = q - pix * S::SPP;
         const int py = pix / S::PW, px = pix - py * S::PW;
-        iy = oy0 - 1 + py; ix = ox0 - 1 + px;
-      } else {
-        const int plane = pix / S::PLANE, rr = pix - plane * S::PLANE;
-        const int pi = rr / (TW + 1), pj = rr - pi * (TW + 1);
-        iy = 2 * (oy0 - 1 + pi) + (plane >> 1); ix = 2 * (ox0 - 1 + pj) + (plane & 1);
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = c < S::SPP - 1 && pix < S::PH * S::PW && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        const void* src = ok ? (const void*)(xb + ((long)iy * P.W + ix) * P.Cin + c * 8) : (const void*)cq_zero_chunk;
+        __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
       }
-      const bool ok = c < S::SPP - 1 && pix < S::NPX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-      const void* src = ok ? (const void*)(xb + ((long)iy * P.W + ix) * P.Cin + c * 8) : (const void*)cq_zero_chunk;
-      __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
+    } else {
+      const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + (pass >> 1) * 64;
+      const int grp = pass & 1;
+      const int npc = ((grp ? 3 : 1) * S::PLANE_BYTES + 1023) / 1024;
+      for (int pc = wave; pc < npc; pc += 4) {
+        const int q = pc * 64 + lane;
+        const int slot = q / ((S::TH + 1) * S::ROW_SLOTS), r = q - slot * ((S::TH + 1) * S::ROW_SLOTS);
+        const int pi = r / S::ROW_SLOTS, sl = r - pi * S::ROW_SLOTS;
+        const int pj = sl / S::SPP, c = sl - pj * S::SPP;
+        // plane of the slot: A: (1, 1); B: slot 0 -> (0, 0), 1 -> (0, 1), 2 -> (1, 0)
+        const int pr = grp ? (slot == 2) : 1, pq = grp ? (slot == 1) : 1;
+        const int iy = 2 * (oy0 - 1 + pi) + pr, ix = 2 * (ox0 - 1 + pj) + pq;
+        const bool ok = c < S::SPP - 1 && pj <= TW && slot < (grp ? 3 : 1) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        const void* src = ok ? (const void*)(xb + ((long)iy * P.W + ix) * P.Cin + c * 8) : (const void*)cq_zero_chunk;
+        __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
+      }
     }
   };
   CONV_STAMP(0);
@@ -458,12 +481,10 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   // this wave's weight fragments: fragment row f of the packed stream ([64-channel pass][tap][k-step 0..3]), block cb of ncb_pack
   const s16x8* const wp = reinterpret_cast<const s16x8*>(P.wpack) + cb * 64 + lane;
   const long wstep = (long)P.ncb_pack * 64;                        // fragment rows are ncb_pack KB apart
-  // fragment row of (slab s, k-step kk): stride 1: 4 s + kk; stride 2: slab s = (32-channel pass p, tap t) -> the half (p & 1) of
-  // the k-steps of (64-channel pass p >> 1, tap t)
+  // fragment row of (slab s, k-step kk): stride 1: 4 s + kk; stride 2: slab s = (64-channel pass s / 9, the (s % 9)-th tap of cr2_tap's order)
   auto frag_row = [](int s, int kk) {
     if (STRIDE == 1) return 4 * s + kk;
-    const int p = s / 9, t = s - 9 * p;
-    return ((p >> 1) * 9 + t) * 4 + (p & 1) * 2 + kk;
+    return ((s / 9) * 9 + cr2_tap(s % 9)) * 4 + kk;
   };
   // Loads hipcc does not track (inline asm): its own wait in front of a fragment's first use comes out as vmcnt(0) -- a drain of
   // the whole ring every other slab -- where the issue order says exactly 2 KS - 1 younger loads may still be in flight: fragment
@@ -495,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   for (int i = 0; i < NPB; ++i) {
     const int t = 32 * (i0 + i) + l31;
     const int py = t / TW, px = t - py * TW;
-    abase[i] = lds_addr(patch) + (unsigned)((py * (STRIDE == 1 ? S::PW : TW + 1) + px) * S::PITCH + hh * 16);
+    abase[i] = lds_addr(patch) + (unsigned)(py * S::ROW_BYTES + px * S::PITCH + hh * 16);
   }
   f32x16 acc[NPB];
 #pragma unroll
@@ -510,11 +531,11 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   // first WIN reads of tap t + 1 are issued under the last MFMAs of tap t).
   s16x8 fr[WIN];
   auto read_n = [&](auto tc, auto nc) {
-    constexpr int t = decltype(tc)::value % 9, n = decltype(nc)::value, kk = n / NPB, i = n % NPB;
+    constexpr int t = STRIDE == 1 ? decltype(tc)::value % 9 : cr2_tap(decltype(tc)::value % 9);
+    constexpr int n = decltype(nc)::value, kk = n / NPB, i = n % NPB;
     constexpr int kh = t / 3, kw = t % 3;
-    constexpr int tpix = STRIDE == 1 ? kh * S::PW + kw
-                                     : (((kh != 1) * 2 + (kw != 1)) * S::PLANE + (kh != 0) * (TW + 1) + (kw != 0));
-    constexpr int off = tpix * S::PITCH + kk * 32;
+    constexpr int off = (STRIDE == 1 ? kh * S::ROW_BYTES + kw * S::PITCH
+                                     : cr2_slot(kh, kw) * S::PLANE_BYTES + (kh != 0) * S::ROW_BYTES + (kw != 0) * S::PITCH) + kk * 32;
 #if WMZ_CONV_ABL & 1
     // timing ablation (garbage results): three of four A-fragment reads become register copies -- every destination is still WRITTEN
     // (a skipped asm read leaves its register unassigned: hipcc re-uses it and the counted waits protect nothing -- that variant faulted)
@@ -545,15 +566,15 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
       if constexpr (i == NPB - 1) bq[s & 1][kk] = wload(frag_row(snext, kk));   // k-step kk done: its register takes slab s + 2
 #endif
     });
-    if constexpr (t == 8 && s + 1 < nslab) {                       // the patch of the next 64 (32) channels
+    if constexpr ((t == 8 || (STRIDE == 2 && t == 3)) && s + 1 < nslab) {   // the patch of the next 64 channels (stride 2: of the next tap group)
       // (the window's run-ahead reads -- of the OLD patch: dead values -- retire here; their registers stay named until then:
       //  hipcc hands the register of a dead asm result to the next instruction while the LDS return is still in flight)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
       __builtin_amdgcn_s_barrier();                                // every wave is done with the patch
-      issue_patch((s + 1) / 9);
+      issue_patch(STRIDE == 1 ? (s + 1) / 9 : 2 * ((s + 1) / 9) + ((s + 1) % 9 >= 4));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      static_for<WIN>([&](auto nc) { read_n(I0{}, nc); });         // (the window was read from the old patch)
+      static_for<WIN>([&](auto nc) { read_n(std::integral_constant<int, s + 1>{}, nc); });   // (the window was read from the old patch)
     }
   });
   // the window's run-ahead reads and the ring's (redundant) tail loads retire here: their registers stay named until then
@@ -817,7 +838,7 @@ extern "C" int wmz_conv3x3_direct_fwd_strided(const void* x, const void* wpack, 
   WMZ_REQUIRE(tiles < (1L << 31), "wmz_conv3x3_direct_fwd_strided: too many tiles");
   dim3 grid((unsigned)tiles), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 64) hipLaunchKernelGGL((convr_kernel<4, 16, 1, 2>), grid, block, 0, st, P);
+  if (Cin == 64) hipLaunchKernelGGL((convr_kernel<4, 16, 1, 2>), grid, block, 0, st, P);      // <.., NPASS = Cin / 64, STRIDE>
   else hipLaunchKernelGGL((convr_kernel<4, 16, 2, 2>), grid, block, 0, st, P);
   WMZ_LAUNCH_CHECK("wmz_conv3x3_direct_fwd_strided");
   return WMZ_OK;

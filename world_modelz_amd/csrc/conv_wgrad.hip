@@ -5,14 +5,17 @@
 // re-gathers x through L2 -- 18 passes over the two tensors per layer, 0.3 PFLOP/s (258 us for the 128 -> 128 layers of 64 frames
 // of 64 x 64, a third of the VQ-AE training step).  Here the REDUCTION dimension (pixels) is tiled instead and all nine taps are
 // computed from one staged copy:
-//   * a persistent workgroup (one per CU, 4 waves, one wave per SIMD with the 512-register budget) walks tiles of 8 x 16 pixels of
-//     one image; per tile the haloed 10 x 18 patch of x (64 input channels) and the 128 pixels x 128 channels of dy go to LDS ONCE
-//     by global_load_lds, double-buffered -- the next tile lands while this one multiplies (one barrier per tile = per 144 MFMAs of
-//     a wave);
-//   * a wave owns 32 output channels x 64 input channels x 9 taps = 18 accumulator blocks of 32 x 32 (288 registers) for the WHOLE
-//     launch; a tile row of 16 pixels is one k-step: the dy fragment (pixels on the reduction axis: transposing ds_read_b64_tr_b16
-//     reads of the pixel-major image) is read once and multiplied against the 18 shifted x fragments -- the taps are address
-//     offsets into the same patch (19 fragment reads per 18 MFMAs; all offsets instruction immediates, the code is unrolled);
+//   * a persistent workgroup (one per CU, 8 waves) walks tiles of 8 x 16 pixels of one image; per tile the haloed 10 x 18 patch of
+//     x (64 input channels) and the 128 pixels x 128 channels of dy go to LDS ONCE by global_load_lds, double-buffered -- the next
+//     tile lands while this one multiplies (one barrier per tile = per 72 MFMAs of a wave);
+//   * a wave owns 32 output channels x 32 input channels x 9 taps = 9 accumulator blocks of 32 x 32 (144 registers, all in the AGPR
+//     half) for the WHOLE launch; a tile row of 16 pixels is one k-step: the dy fragment (pixels on the reduction axis: transposing
+//     ds_read_b64_tr_b16 reads of the pixel-major image) is read once and multiplied against the 9 shifted x fragments -- the taps
+//     are address offsets into the same patch (10 fragment reads per 9 MFMAs; all offsets instruction immediates, unrolled).
+//     (Round 5 gave a wave 64 input channels = 18 blocks = 288 registers at one wave per SIMD: more than the 256 AGPRs, and hipcc
+//     kept every MFMA in its AGPR form and ROTATED accumulator blocks between the two register halves -- 2 753 v_accvgpr moves
+//     for 144 MFMAs per tile, 19 per MFMA: the kernel issued moves 61 % of the time at MFMA-busy 0.15.  Two waves per SIMD with half
+//     the blocks each need none.)
 //   * Cin = 128: two groups of workgroups, one per half of the input channels;
 //   * Cout <= 32 (the decoder's 3-channel last layer, autoencoder.py:134-152 -- 524 us on wgrad2_kernel, whose 128-wide tile holds 8
 //     useful columns): the NCOB = 1 form -- two waves per workgroup, a wave owns one block of 32 input channels x 9 taps against the
@@ -36,14 +39,14 @@ struct CwParams {
 
 constexpr int CW_PW = 18, CW_NPX = 180;           // haloed patch of an 8 x 16 tile
 constexpr int CW_XIMG = 23 * 1024;                // 180 pixels x 128 bytes (64 channels) = 23040 -> 23 DMA pieces
-constexpr int CW_WIN = 4;                         // fragments in flight
+constexpr int CW_WIN = 8;                         // fragments in flight
 
-// NCOB: blocks of 32 output channels (4: Cout = 128, four waves, one block each x two blocks of input channels; 1: Cout <= 32, two
-// waves, one block of input channels each)
+// NCOB: blocks of 32 output channels (4: Cout = 128, eight waves = four output blocks x two blocks of 32 input channels; 1: Cout <= 32,
+// two waves, one block of input channels each)
 template <int NCOB>
-__global__ __launch_bounds__(NCOB == 4 ? 256 : 128, NCOB == 4 ? 1 : 2) void convw_kernel(CwParams P) {
-  constexpr int NW = NCOB == 4 ? 4 : 2;                             // waves
-  constexpr int NB = NCOB == 4 ? 18 : 9;                            // accumulator blocks of a wave: taps x its input-channel blocks
+__global__ __launch_bounds__(NCOB == 4 ? 512 : 128, NCOB == 4 ? 1 : 2) void convw_kernel(CwParams P) {
+  constexpr int NW = NCOB == 4 ? 8 : 2;                             // waves
+  constexpr int NB = 9;                                             // accumulator blocks of a wave: the taps of its (output, input) channel block pair
   constexpr int DROW = NCOB == 4 ? 256 : 64;                        // bytes per pixel of the dy image (128 | 32 channels)
   constexpr int CW_DIMG = 128 * DROW;
   constexpr int CW_BUF = CW_XIMG + CW_DIMG;
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(NCOB == 4 ? 256 : 128, NCOB == 4 ? 1 : 2) void conv
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cig = blockIdx.x % P.ncig, split = blockIdx.x / P.ncig;
   const int l31 = lane & 31, hh = lane >> 5;
+  const int cob = NCOB == 4 ? (wave & 3) : 0, cib = NCOB == 4 ? (wave >> 2) : wave;   // this wave's output / input channel block
 
   auto issue_tile = [&](int t, int buf) {
     const int tx = t % P.tiles_x, r1 = t / P.tiles_x;
@@ -94,18 +98,16 @@ __global__ __launch_bounds__(NCOB == 4 ? 256 : 128, NCOB == 4 ? 1 : 2) void conv
   const int r0 = 8 * (gi >> 1) + q4;
   // dy image: rows of 256 bytes, 64-byte granule XOR (row & 3) -- the tile rows start at multiples of 16: (row & 3) = q4
   // (NCOB = 1: rows of 64 bytes = one granule: four consecutive rows already cover the 64 banks)
-  const unsigned offA = NCOB == 4 ? (unsigned)(r0 * 256 + (((32 * wave + 16 * (gi & 1) + 4 * p4) * 2) ^ (q4 << 6)))
+  const unsigned offA = NCOB == 4 ? (unsigned)(r0 * 256 + (((32 * cob + 16 * (gi & 1) + 4 * p4) * 2) ^ (q4 << 6)))
                                   : (unsigned)(r0 * 64 + (16 * (gi & 1) + 4 * p4) * 2);
   // x image: rows of 128 bytes, 64-byte granule XOR ((row >> 1) & 1): a fragment starting at patch pixel m0 reads rows m0 + r0 (+ 4);
   // with v = m0 & 3 the lane's offset is offB[v][channel block] + 128 (m0 - v) -- the second term an immediate
-  unsigned offB[4][2];
+  unsigned offB[4];
 #pragma unroll
-  for (int v = 0; v < 4; ++v)
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-      const int r = r0 + v;
-      offB[v][c2] = (unsigned)(r * 128 + (((32 * c2 + 16 * (gi & 1) + 4 * p4) * 2) ^ (((r >> 1) & 1) << 6)));
-    }
+  for (int v = 0; v < 4; ++v) {
+    const int r = r0 + v;
+    offB[v] = (unsigned)(r * 128 + (((32 * cib + 16 * (gi & 1) + 4 * p4) * 2) ^ (((r >> 1) & 1) << 6)));
+  }
 
   f32x16 acc[NB];
 #pragma unroll
@@ -121,14 +123,12 @@ __global__ __launch_bounds__(NCOB == 4 ? 256 : 128, NCOB == 4 ? 1 : 2) void conv
     if (t + P.nsplit < P.ntiles) issue_tile(t + P.nsplit, (it + 1) & 1);    // (that buffer: every wave left it at the last barrier)
     const unsigned xbase = lds_addr(lds + (it & 1) * CW_BUF);
     const unsigned aA = xbase + CW_XIMG + offA;
-    unsigned aB[4][2];
+    unsigned aB[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) aB[v][c2] = xbase + offB[v][c2];
+    for (int v = 0; v < 4; ++v) aB[v] = xbase + offB[v];
 
-    // fragment queue: item n = 19 ty + j; j = 0: the dy fragment of tile row ty, j = 1 + 2 tap + c2: the x fragment of (tap, channel
-    // block c2) for that row.  CW_WIN items (two reads each) in flight; every wait names the registers it releases.
+    // fragment queue: item n = 10 ty + j; j = 0: the dy fragment of tile row ty, j = 1 + tap: the x fragment of that tap for the row.
+    // CW_WIN items (two reads each) in flight; every wait names the registers it releases.
     s16x4 ar[2][2], br[CW_WIN][2];
     auto issue = [&](auto nc) {
       constexpr int n = decltype(nc)::value, ty = n / (NB + 1), j = n % (NB + 1);
@@ -136,11 +136,10 @@ __global__ __launch_bounds__(NCOB == 4 ? 256 : 128, NCOB == 4 ? 1 : 2) void conv
         ar[ty & 1][0] = ds_read_tr16_asm<ty * 16 * DROW>(aA);
         ar[ty & 1][1] = ds_read_tr16_asm<ty * 16 * DROW + 4 * DROW>(aA);
       } else {
-        constexpr int b = j - 1, tap = NCOB == 4 ? (b >> 1) : b, kh = tap / 3, kw = tap % 3;
+        constexpr int b = j - 1, tap = b, kh = tap / 3, kw = tap % 3;
         constexpr int m0 = (ty + kh) * CW_PW + kw, v = m0 & 3, imm = (m0 - v) * 128, slot = (ty * NB + b) % CW_WIN;
-        const unsigned a = NCOB == 4 ? aB[v][b & 1] : aB[v][wave];
-        br[slot][0] = ds_read_tr16_asm<imm>(a);
-        br[slot][1] = ds_read_tr16_asm<imm + 512>(a);
+        br[slot][0] = ds_read_tr16_asm<imm>(aB[v]);
+        br[slot][1] = ds_read_tr16_asm<imm + 512>(aB[v]);
       }
     };
     static_for<CW_WIN>([&](auto nc) { issue(nc); });
@@ -171,18 +170,18 @@ __global__ __launch_bounds__(NCOB == 4 ? 256 : 128, NCOB == 4 ? 1 : 2) void conv
   const long NK = (long)P.Cout * K;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int tap = NCOB == 4 ? (b >> 1) : b, c2 = NCOB == 4 ? (b & 1) : wave;
-    const int k = tap * P.Cin + 64 * cig + 32 * c2 + l31;
+    const int tap = b;
+    const int k = tap * P.Cin + 64 * cig + 32 * cib + l31;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int co = (NCOB == 4 ? 32 * wave : 0) + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+      const int co = 32 * cob + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
       const long q = (long)co * K + k;
       if (co < P.Cout) P.ws[(((q >> 8) * P.nsplit + split) << 8) + (q & 255)] = acc[b][reg];
     }
   }
-  if (cig == 0 && (NCOB == 4 || wave == 0)) {
+  if (cig == 0 && cib == 0) {
     const float tb = wave_halves_sum(bias_acc);
-    const int co = (NCOB == 4 ? 32 * wave : 0) + l31;
+    const int co = 32 * cob + l31;
     if (hh == 0 && co < P.Cout) P.ws[(((NK + 255) >> 8) * P.nsplit << 8) + (long)split * P.Cout + co] = tb;
   }
 }
@@ -218,7 +217,7 @@ int wmz_convw_launch(const void* x, const void* dy, float* dW, float* dbias, int
   P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.ncig = Cin / 64;
   P.tiles_x = W / 16; P.tiles_y = H / 8; P.ntiles = B * P.tiles_x * P.tiles_y;
   P.nsplit = convw_nsplit(B, H, W, Cin);
-  if (Cout == 128) hipLaunchKernelGGL(convw_kernel<4>, dim3((unsigned)(P.nsplit * P.ncig)), dim3(256), 0, stream, P);
+  if (Cout == 128) hipLaunchKernelGGL(convw_kernel<4>, dim3((unsigned)(P.nsplit * P.ncig)), dim3(512), 0, stream, P);
   else hipLaunchKernelGGL(convw_kernel<1>, dim3((unsigned)(P.nsplit * P.ncig)), dim3(128), 0, stream, P);
   WMZ_LAUNCH_CHECK("wmz_conv2d_nhwc_wgrad_ws");
   const long NK = (long)Cout * 9 * Cin;
