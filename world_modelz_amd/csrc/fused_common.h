@@ -212,9 +212,16 @@ __device__ __forceinline__ void init_vec(f32x16 (&acc)[NB], const float* vec) {
 // The empty asm pins the packed operand HERE: without it the compiler sinks the conversion arithmetic down to the MFMA
 // that consumes it and keeps the fp32 sources (and every gamma / beta / bias fetched for them) alive until then.
 __device__ __forceinline__ void pack8(Frag8<bf16_t>& f, const float (&y)[8]) {
+#ifdef WMZ_OP16_F16
+  // (half operands: written as four explicit two-wide conversions -- element by element hipcc pairs most but not all of them
+  //  into v_cvt_pk_f16_f32 and assembles the rest with v_cvt_f16_f32 + v_alignbit + moves)
+  const s16x4 lo = cvt_pk4_bf16(y[0], y[1], y[2], y[3]), hi = cvt_pk4_bf16(y[4], y[5], y[6], y[7]);
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#else
   s16x8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = (short)f32_to_bf16_bits(y[j]);
+#endif
   asm volatile("" : "+v"(v));
   f.v = v;
 }
@@ -257,7 +264,7 @@ __device__ __forceinline__ void add_bop(f32x16 (&acc)[NB], const Frag8<bf16_t> (
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[b][i] += bf16_bits_to_f32((unsigned short)bop[2 * b + (i >> 3)].v[i & 7]);
+    for (int i = 0; i < 16; ++i) acc[b][i] = op16_add_to(acc[b][i], (unsigned short)bop[2 * b + (i >> 3)].v[i & 7]);
 }
 
 template <int KS>
@@ -351,6 +358,12 @@ __device__ __forceinline__ void acc_from_bop(f32x16 (&acc)[NB], const Frag8<bf16
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[b][i] = bf16_bits_to_f32((unsigned short)bop[2 * b + (i >> 3)].v[i & 7]);
+#ifdef WMZ_OP16_F16
+  // (half operands: without this pin hipcc folds the conversion into the LayerNorm's multiply-add as v_fma_mix_f32 reading the
+  //  PACKED source -- and keeps the packed row alive beside its fp32 copy: +30 registers, a spill in the head kernels)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(acc[b]));
+#endif
 }
 template <int NB>
 __device__ __forceinline__ void bop_from_acc(Frag8<bf16_t> (&bop)[2 * NB], const f32x16 (&acc)[NB]) {

@@ -73,6 +73,9 @@ __device__ __forceinline__ s16x4 cvt_pk4_bf16(float a, float b, float c, float d
   const u32x2 w = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
   return __builtin_bit_cast(s16x4, w);
 }
+// acc + value(bits): as ONE v_fma_mix_f32 (the half operand converted inside the instruction, hi / lo half selected by op_sel) --
+// no conversion temporaries where a whole operand row is added to the fp32 stream (fused_common.h add_bop)
+__device__ __forceinline__ float op16_add_to(float acc, unsigned short b) { return __builtin_fmaf((float)__builtin_bit_cast(_Float16, b), 1.0f, acc); }
 __device__ __forceinline__ f32x4 op16_mfma_16x16x32(const s16x8& a, const s16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
@@ -101,6 +104,7 @@ __device__ __forceinline__ s16x4 cvt_pk4_bf16(float a, float b, float c, float d
   const u32x2 w = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
   return __builtin_bit_cast(s16x4, w);
 }
+__device__ __forceinline__ float op16_add_to(float acc, unsigned short b) { return acc + bf16_bits_to_f32(b); }
 __device__ __forceinline__ f32x4 op16_mfma_16x16x32(const s16x8& a, const s16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
