@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 108
+#define WMZ_VERSION 109
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1,
        WMZ_F16 = 2 /* IEEE half activations / MFMA operands: the PRECISE fused inference mode (wmz_local3d_attn_fwd* on the
@@ -338,6 +338,17 @@ int wmz_layer_fused_pack_f16(const float* wout, const float* bout, const float* 
                              int D, int I, int M, void* stream);
 int wmz_fused_pack_table_f16(const void* block_rows, int nblk, long total8, const void* vec_jobs, int nvec, int D, int I, int M,
                              void* stream);
+/* ... and the linear behind it (VqVideoDiffusionModel.logit_proj on the last frame, main.py:33-36): wmz_linear_fwd /
+ * wmz_linear_fwd_stats / wmz_linear_fwd_blocked with dtype = WMZ_F16 (A and Wt half, bias / LayerNorm parameters fp32, C half or,
+ * with out_f32, fp32). */
+int wmz_linear_fwd_f16(const void* A, long lda, const void* Wt, const float* bias, const void* residual, long ldr, void* C,
+                       long ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta, float ln_eps, int flags,
+                       int out_f32, int dtype, void* stream);
+int wmz_linear_fwd_stats_f16(const void* A, long lda, const void* Wt, const float* bias, const void* residual, long ldr, void* C,
+                             long ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta, const float* ln_mean,
+                             const float* ln_rstd, float ln_eps, int flags, int out_f32, int dtype, void* stream);
+int wmz_linear_fwd_blocked_f16(const void* A, long lda, int rows_per_block, long block_stride, const void* Wt, const float* bias,
+                               void* C, long ldc, int M, int N, int K, int out_f32, int dtype, void* stream);
 /* All MFMA-operand copies of the fp32 parameters in one launch (after wmz_adamw_step has rewritten the weights): entry i
  * turns the logical matrix [rows0 + rows1, cols] = (src0 ; src1) -- src1 optional (row concatenation, e.g. to_k over
  * to_v), src0 NULL = zero rows -- into dst[i], row-major or transposed (WMZ_OPERAND_TRANSPOSE: what the dgrad GEMMs

@@ -59,8 +59,8 @@ template <> __device__ __forceinline__ void chunk_to_f32<float>(const i32x4& c, 
 template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const i32x4& c, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __uint_as_float(((unsigned)c[i]) << 16);
-    f[2 * i + 1] = __uint_as_float(((unsigned)c[i]) & 0xFFFF0000u);
+    f[2 * i] = bf16_bits_to_f32((unsigned short)((unsigned)c[i] & 0xFFFFu));          // (the unit's 16-bit format: wmz_common.h)
+    f[2 * i + 1] = bf16_bits_to_f32((unsigned short)((unsigned)c[i] >> 16));
   }
 }
 template <typename T> __device__ __forceinline__ i32x4 f32_to_chunk(const float* f);
@@ -476,15 +476,17 @@ __global__ __launch_bounds__(NT, 2) void linear_kernel(LinParams P) {
 
 }  // namespace
 
-extern "C" int wmz_linear_fwd(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
+extern "C" int WMZ_FN(wmz_linear_fwd)(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
                               long ldr, void* C, long ldc, int M, int N, int K, const float* ln_gamma,
                               const float* ln_beta, float ln_eps, int flags, int out_f32, int dtype, void* stream) {
-  return wmz_linear_fwd_stats(A, lda, Wt, bias, residual, ldr, C, ldc, M, N, K, ln_gamma, ln_beta, nullptr, nullptr, ln_eps,
+  return WMZ_FN(wmz_linear_fwd_stats)(A, lda, Wt, bias, residual, ldr, C, ldc, M, N, K, ln_gamma, ln_beta, nullptr, nullptr, ln_eps,
                               flags, out_f32, dtype, stream);
 }
 
 static int g_linear_dma = 1;
+#ifndef WMZ_OP16_F16
 extern "C" int wmz_debug_linear_knobs(int dma) { g_linear_dma = dma; return WMZ_OK; }      // (development A/B: 0 = the register-staged loop)
+#endif
 
 static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtype, hipStream_t st) {
   const bool ln = ln_gamma != nullptr;
@@ -493,12 +495,12 @@ static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtyp
   P.nbn = wmz_cdiv(P.N, BN);
   // small-M GEMMs (the last-frame logits: M = B*H*W; config 5's 3 072 tokens per GPU): 64-row tiles, so that the grid covers
   // the chip (a 16-bit output then leaves by per-lane stores: fine at these sizes)
-  const bool small = (long)wmz_cdiv(P.M, 128) * P.nbn < (P.out_f32 ? 192 : 320) && (dtype == WMZ_BF16 || (!ln && !gin));
+  const bool small = (long)wmz_cdiv(P.M, 128) * P.nbn < (P.out_f32 ? 192 : 320) && (dtype == kOp16Dtype || (!ln && !gin));
   const int bm = small ? 64 : 128;
   const uintptr_t al = (uintptr_t)P.A | (uintptr_t)P.Wt | (uintptr_t)(P.lda * 2) | (uintptr_t)(P.bstride * 2);
-  P.dma = (small && dtype == WMZ_BF16 && !ln && !gin && P.K % 64 == 0 && (al & 15) == 0 && g_linear_dma) ? 1 : 0;
+  P.dma = (small && dtype == kOp16Dtype && !ln && !gin && P.K % 64 == 0 && (al & 15) == 0 && g_linear_dma) ? 1 : 0;
   dim3 grid((unsigned)(wmz_cdiv(P.M, bm) * P.nbn)), block(NT);
-  if (dtype == WMZ_BF16) {
+  if (dtype == kOp16Dtype) {
     if (small && ln) hipLaunchKernelGGL((linear_kernel<bf16_t, 1, 64>), grid, block, 0, st, P);
     else if (small && gin) hipLaunchKernelGGL((linear_kernel<bf16_t, 2, 64>), grid, block, 0, st, P);
     else if (small) hipLaunchKernelGGL((linear_kernel<bf16_t, 0, 64>), grid, block, 0, st, P);
@@ -515,7 +517,7 @@ static int linear_launch(LinParams P, const float* ln_gamma, int flags, int dtyp
   return WMZ_OK;
 }
 
-extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
+extern "C" int WMZ_FN(wmz_linear_fwd_stats)(const void* A, long lda, const void* Wt, const float* bias, const void* residual,
                                     long ldr, void* C, long ldc, int M, int N, int K, const float* ln_gamma,
                                     const float* ln_beta, const float* ln_mean, const float* ln_rstd, float ln_eps,
                                     int flags, int out_f32, int dtype, void* stream) {
@@ -524,7 +526,7 @@ extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, con
   WMZ_REQUIRE(ln_mean == nullptr || ln_gamma != nullptr, "wmz_linear_fwd: statistics without a LayerNorm prologue");
   WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
   WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0, "wmz_linear_fwd: K and lda must be multiples of 8 (K=%d lda=%ld)", K, lda);
-  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd: bad dtype %d", dtype);
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == kOp16Dtype, "wmz_linear_fwd: bad dtype %d", dtype);
   WMZ_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "wmz_linear_fwd: ln_gamma and ln_beta go together");
   LinParams P;
   P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = residual; P.ldr = ldr; P.C = C; P.ldc = ldc;
@@ -537,6 +539,7 @@ extern "C" int wmz_linear_fwd_stats(const void* A, long lda, const void* Wt, con
   return linear_launch(P, ln_gamma, flags, dtype, (hipStream_t)stream);
 }
 
+#ifndef WMZ_OP16_F16      // (the training forward's GEMMs: the bfloat16 / fp32 unit only)
 // FeedForward's first GEMM in training (local_3d_attention.py:24-25: Linear -> GELU): Z = LN?(A) Wt^T + bias AND H = GELU(Z),
 // both in the activation dtype, from one accumulator (H rounds GELU of the fp32 sum, as the inference epilogue does).  The
 // second GEMM and its weight gradient then read H as it is -- with the activation recomputed in their loaders every column
@@ -549,7 +552,7 @@ extern "C" int wmz_linear_fwd_gelu_pair(const void* A, long lda, const void* Wt,
   WMZ_REQUIRE(ln_mean == nullptr || ln_gamma != nullptr, "wmz_linear_fwd_gelu_pair: statistics without a LayerNorm prologue");
   WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_fwd_gelu_pair: bad shape M=%d N=%d K=%d", M, N, K);
   WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0, "wmz_linear_fwd_gelu_pair: K and lda must be multiples of 8 (K=%d lda=%ld)", K, lda);
-  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd_gelu_pair: bad dtype %d", dtype);
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == kOp16Dtype, "wmz_linear_fwd_gelu_pair: bad dtype %d", dtype);
   WMZ_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "wmz_linear_fwd_gelu_pair: ln_gamma and ln_beta go together");
   LinParams P;
   P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = nullptr; P.ldr = 0; P.C = Z; P.ldc = ldz;
@@ -573,7 +576,7 @@ extern "C" int wmz_linear_fwd_train(const void* A, long lda, const void* Wt, con
   WMZ_REQUIRE((ln_mean == nullptr) == (ln_rstd == nullptr), "wmz_linear_fwd_train: ln_mean and ln_rstd go together");
   WMZ_REQUIRE(M > 0 && N > 0 && K > 0, "wmz_linear_fwd_train: bad shape M=%d N=%d K=%d", M, N, K);
   WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0 && (An == nullptr || ldan % 8 == 0), "wmz_linear_fwd_train: K, lda, ldan must be multiples of 8");
-  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd_train: bad dtype %d", dtype);
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == kOp16Dtype, "wmz_linear_fwd_train: bad dtype %d", dtype);
   LinParams P;
   P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = nullptr; P.ldr = 0; P.C = C; P.ldc = ldc;
   P.M = M; P.N = N; P.K = K; P.gamma = ln_gamma; P.beta = ln_beta; P.eps = ln_eps; P.flags = 0;
@@ -585,15 +588,17 @@ extern "C" int wmz_linear_fwd_train(const void* A, long lda, const void* Wt, con
   return linear_launch(P, ln_gamma, 0, dtype, (hipStream_t)stream);
 }
 
+#endif  // WMZ_OP16_F16
+
 // logit_proj on the LAST FRAME of every clip (main.py:35-36: x[:, -1] -> nn.Linear), read in place: A's rows come in blocks of
 // rows_per_block (= H*W) rows lda apart, the blocks block_stride apart (= S*H*W*D for the last plane of each clip).
-extern "C" int wmz_linear_fwd_blocked(const void* A, long lda, int rows_per_block, long block_stride, const void* Wt,
+extern "C" int WMZ_FN(wmz_linear_fwd_blocked)(const void* A, long lda, int rows_per_block, long block_stride, const void* Wt,
                                       const float* bias, void* C, long ldc, int M, int N, int K, int out_f32, int dtype,
                                       void* stream) {
   WMZ_REQUIRE(A && Wt && C, "wmz_linear_fwd_blocked: null tensor");
   WMZ_REQUIRE(M > 0 && N > 0 && K > 0 && rows_per_block > 0, "wmz_linear_fwd_blocked: bad shape M=%d N=%d K=%d rows_per_block=%d", M, N, K, rows_per_block);
   WMZ_REQUIRE(K % 8 == 0 && lda % 8 == 0 && block_stride % 8 == 0, "wmz_linear_fwd_blocked: K, lda, block_stride must be multiples of 8");
-  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_linear_fwd_blocked: bad dtype %d", dtype);
+  WMZ_REQUIRE(dtype == WMZ_F32 || dtype == kOp16Dtype, "wmz_linear_fwd_blocked: bad dtype %d", dtype);
   LinParams P;
   P.A = A; P.lda = lda; P.Wt = Wt; P.bias = bias; P.res = nullptr; P.ldr = 0; P.C = C; P.ldc = ldc;
   P.M = M; P.N = N; P.K = K; P.gamma = nullptr; P.beta = nullptr; P.eps = 0.f; P.flags = 0;

@@ -31,6 +31,5 @@ class VqVideoDiffusionModel(nn.Module):
         return self._logits(h[:, -1])         # [B,H,W,D] view: uniform row stride, no copy
 
     def _logits(self, last):
-        if last.dtype == torch.float16:       # the precise mode's half stream: the last frame's projection runs in fp32
-            last = last.float()
+        # (a half stream -- the precise mode -- takes the half unit of the same GEMM: fp32 accumulation, fp32 logits)
         return Fw.linear(last, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)

@@ -86,7 +86,8 @@ def linear_fwd(a, weight, bias=None, residual=None, ln=None, ln_eps=1e-5, gelu=F
     if ln_stats is not None:
         mean, rstd = ln_stats
         assert ln is not None and mean.numel() == M and rstd.numel() == M
-    L.call('wmz_linear_fwd_stats', L.ptr(a), lda, L.ptr(weight), L.ptr(bias), L.ptr(residual), ldr, L.ptr(out), ldc,
+    # (half operands: the precise fused mode's unit of the same kernel, include/wmz.h)
+    L.call('wmz_linear_fwd_stats' + ('_f16' if a.dtype == torch.float16 else ''), L.ptr(a), lda, L.ptr(weight), L.ptr(bias), L.ptr(residual), ldr, L.ptr(out), ldc,
            M, N, K, L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(rstd), float(ln_eps),
            (L.WMZ_LIN_GELU if gelu else 0) | (L.WMZ_LIN_GELU_IN if gelu_in else 0), 1 if out_f32 else 0, dt,
            L.stream())
@@ -150,7 +151,7 @@ def linear_fwd_blocks(a, weight, bias=None, out_f32=False):
     N = weight.shape[0]
     assert a.stride(2) == 1 and weight.dtype == a.dtype and weight.is_contiguous() and weight.shape[1] == K
     out = torch.empty((Bk, R, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
-    L.call('wmz_linear_fwd_blocked', L.ptr(a), a.stride(1), R, a.stride(0), L.ptr(weight), L.ptr(bias), L.ptr(out), N,
+    L.call('wmz_linear_fwd_blocked' + ('_f16' if a.dtype == torch.float16 else ''), L.ptr(a), a.stride(1), R, a.stride(0), L.ptr(weight), L.ptr(bias), L.ptr(out), N,
            Bk * R, N, K, 1 if out_f32 else 0, L.dtype_code(a.dtype), L.stream())
     return out
 
