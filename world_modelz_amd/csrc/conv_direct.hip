@@ -383,8 +383,9 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(DirectParams P) {
 // (kh != 1, kw != 1) at the output pixel's own (i, j) or one row / column before it, so inside a plane the lanes of a fragment
 // again walk consecutive pixels (the DMA de-interleaves on the source side).  Round 6: every input pixel belongs to ONE plane, so
 // the taps are grouped by the planes they read and a pixel's 64 channels (one 128-byte line) are fetched ONCE: group A = the four
-// corner taps (plane (1, 1)), group B = the centre tap and the four edge taps (planes (0, 0), (0, 1), (1, 0)); a 64-channel pass is
-// [stage A's plane, 4 taps][stage B's three planes, 5 taps] (round 5 staged all four planes 32 channels at a time: every line
+// corner taps (plane (1, 1)), group B = the four edge taps (planes (0, 1), (1, 0)), group C = the centre tap (plane (0, 0)); a
+// 64-channel pass is [stage A's plane, 4 taps][stage B's two planes, 4 taps][stage C's plane, 1 tap] -- at most two planes = 46 KB
+// resident, THREE workgroups per CU at 161 VGPRs (round 5 staged all four planes 32 channels at a time: every line
 // fetched as two halves in two passes -- fabric traffic 1.86 x the input, pmc_conv.json).  An 8 x 16 output tile needs 9 x 17
 // pixels of a plane at the stride-1 pixel pitch of 144 bytes; a plane ROW is padded to 160 sixteen-byte slots (= 0 mod 16): the 16
 // lanes of a ds_read_b128 group are 8 pixels of one tile row and 8 of the next, and with 17-pixel rows two of them met in a bank
@@ -400,7 +401,7 @@ struct CrShape {
   static constexpr int ROW_BYTES = ROW_SLOTS * 16;
   static constexpr int PLANE_BYTES = (TH + 1) * ROW_BYTES;         // STRIDE 2: one parity plane of the patch (TH + 1 rows)
   static constexpr int KS = 4;                                     // k-steps per (pass, tap)
-  static constexpr int PATCH = ((STRIDE == 1 ? PH * PW * PITCH : 3 * PLANE_BYTES) + 1023) / 1024 * 1024;
+  static constexpr int PATCH = ((STRIDE == 1 ? PH * PW * PITCH : 2 * PLANE_BYTES) + 1023) / 1024 * 1024;
   static constexpr int NPB = TILE_PX * NCB / 128;                  // 32-pixel blocks per wave
   static constexpr int BPR = 2;                                    // blocks per epilogue round (bf16 staging, double-buffered)
   static constexpr int OPITCH = 80, FPITCH = 144;                  // staging rows: 32 channels bf16 / fp32 + 16 bytes
@@ -410,14 +411,17 @@ struct CrShape {
   static_assert(STRIDE == 1 || (TW == 16 && NCB == 4), "the stride-2 form is built for Cout = 128 on 8 x 16 tiles");
   static_assert(STRIDE == 1 || (ROW_SLOTS >= (TW + 1) * SPP && ROW_SLOTS % 16 == 0), "conflict-free plane rows");
   static_assert(LDS <= 81920, "two workgroups per CU");
+  static_assert(STRIDE == 1 || LDS <= 53248, "stride 2: three workgroups per CU");
 };
-// STRIDE 2: tap order of a 64-channel pass (group A: 4 corner taps, then group B: centre + edges) and where a tap's plane is staged
-__host__ __device__ constexpr int cr2_tap(int idx) { constexpr int o[9] = {0, 2, 6, 8, 4, 3, 5, 1, 7}; return o[idx]; }
-__host__ __device__ constexpr int cr2_slot(int kh, int kw) { return (kh != 1 && kw != 1) ? 0 : ((kh == 1 && kw == 1) ? 0 : (kh == 1 ? 1 : 2)); }
+// STRIDE 2: tap order of a 64-channel pass (group A: the 4 corner taps, group B: the 4 edge taps, group C: the centre tap), the
+// group of the idx-th tap and the slot its plane is staged in
+__host__ __device__ constexpr int cr2_tap(int idx) { constexpr int o[9] = {0, 2, 6, 8, 3, 5, 1, 7, 4}; return o[idx]; }
+__host__ __device__ constexpr int cr2_group(int idx) { return idx < 4 ? 0 : (idx < 8 ? 1 : 2); }
+__host__ __device__ constexpr int cr2_slot(int kh, int kw) { return (kh != 1 && kw == 1) ? 1 : 0; }   // B: (0, 1) -> slot 0, (1, 0) -> slot 1
 
 // NPASS = Cin / 64
 template <int NCB, int TW, int NPASS, int STRIDE = 1>
-__global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
+__global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 3) void convr_kernel(DirectParams P) {
   using S = CrShape<NCB, TW, STRIDE>;
   constexpr int NPB = S::NPB, KS = S::KS, NSEQ = KS * NPB, WIN = 4;
   __shared__ __attribute__((aligned(1024))) char lds[S::LDS];
@@ -433,7 +437,8 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
   const int oy0 = ty * S::TH, ox0 = tx * TW;
   constexpr int nslab = NPASS * 9;                                 // (64-channel pass, tap) slabs
 
-  // stride 1: pass = 64-channel pass.  stride 2: pass = 2 * (64-channel pass) + group (0: A = plane (1, 1); 1: B = planes (0, 0), (0, 1), (1, 0))
+  // stride 1: pass = 64-channel pass.  stride 2: pass = 3 * (64-channel pass) + group (0: A = plane (1, 1); 1: B = planes (0, 1), (1, 0);
+  // 2: C = plane (0, 0))
   auto issue_patch = [&](int pass) {
     if constexpr (STRIDE == 1) {
       const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + pass * 64;
@@ -447,18 +452,19 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
         __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
       }
     } else {
-      const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + (pass >> 1) * 64;
-      const int grp = pass & 1;
-      const int npc = ((grp ? 3 : 1) * S::PLANE_BYTES + 1023) / 1024;
+      const int c64 = pass / 3, grp = pass - 3 * c64;
+      const bf16_t* xb = P.x + (long)b * P.H * P.W * P.Cin + c64 * 64;
+      const int nplanes = grp == 1 ? 2 : 1;
+      const int npc = (nplanes * S::PLANE_BYTES + 1023) / 1024;
       for (int pc = wave; pc < npc; pc += 4) {
         const int q = pc * 64 + lane;
         const int slot = q / ((S::TH + 1) * S::ROW_SLOTS), r = q - slot * ((S::TH + 1) * S::ROW_SLOTS);
         const int pi = r / S::ROW_SLOTS, sl = r - pi * S::ROW_SLOTS;
         const int pj = sl / S::SPP, c = sl - pj * S::SPP;
-        // plane of the slot: A: (1, 1); B: slot 0 -> (0, 0), 1 -> (0, 1), 2 -> (1, 0)
-        const int pr = grp ? (slot == 2) : 1, pq = grp ? (slot == 1) : 1;
+        // plane of the slot: A: (1, 1); B: slot 0 -> (0, 1), slot 1 -> (1, 0); C: (0, 0)
+        const int pr = grp == 0 ? 1 : (grp == 1 ? slot : 0), pq = grp == 0 ? 1 : (grp == 1 ? 1 - slot : 0);
         const int iy = 2 * (oy0 - 1 + pi) + pr, ix = 2 * (ox0 - 1 + pj) + pq;
-        const bool ok = c < S::SPP - 1 && pj <= TW && slot < (grp ? 3 : 1) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        const bool ok = c < S::SPP - 1 && pj <= TW && slot < nplanes && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
         const void* src = ok ? (const void*)(xb + ((long)iy * P.W + ix) * P.Cin + c * 8) : (const void*)cq_zero_chunk;
         __builtin_amdgcn_global_load_lds((cq_gptr_t)src, (cq_lptr_t)(patch + pc * 1024), 16, 0, 0);
       }
@@ -566,12 +572,12 @@ __global__ __launch_bounds__(256, 2) void convr_kernel(DirectParams P) {
       if constexpr (i == NPB - 1) bq[s & 1][kk] = wload(frag_row(snext, kk));   // k-step kk done: its register takes slab s + 2
 #endif
     });
-    if constexpr ((t == 8 || (STRIDE == 2 && t == 3)) && s + 1 < nslab) {   // the patch of the next 64 channels (stride 2: of the next tap group)
+    if constexpr ((t == 8 || (STRIDE == 2 && (t == 3 || t == 7))) && s + 1 < nslab) {   // the patch of the next 64 channels (stride 2: of the next tap group)
       // (the window's run-ahead reads -- of the OLD patch: dead values -- retire here; their registers stay named until then:
       //  hipcc hands the register of a dead asm result to the next instruction while the LDS return is still in flight)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) :: "memory");
       __builtin_amdgcn_s_barrier();                                // every wave is done with the patch
-      issue_patch(STRIDE == 1 ? (s + 1) / 9 : 2 * ((s + 1) / 9) + ((s + 1) % 9 >= 4));
+      issue_patch(STRIDE == 1 ? (s + 1) / 9 : 3 * ((s + 1) / 9) + cr2_group((s + 1) % 9));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       static_for<WIN>([&](auto nc) { read_n(std::integral_constant<int, s + 1>{}, nc); });   // (the window was read from the old patch)
