@@ -604,3 +604,46 @@ def test_vq_ema_statistics_sorted_gather_vs_scatter_and_torch(N, C, E, dominant)
     torch.cuda.synchronize()
     # (its thousands of sequential fp32 atomic adds into one dominant code's sums are the LESS accurate of the two)
     assert float((dw2 - dw).abs().max() / rd.abs().max()) < 1e-5 and float((sq2 - sq).abs().max() / rs.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('n_lat', [2, 3])
+def test_vector_quantizer_with_several_latents_vs_oracle(n_lat):
+    """VectorQuantizerEMA(num_latents > 1) (vq.py:7, :27: every latent has its own codebook; the reference's callers in scope use 1 --
+    train_vqae.py:31 -- but the constructor accepts it): encode / decode / three training forwards + one evaluation forward against
+    the oracle's restatement of vq.py:25-94 -- indices bit-identical, every buffer, the quantised tensor, loss, perplexity, the
+    dense one-hot on request, and the straight-through gradient."""
+    from oracle import vq as ovq
+    from world_modelz_amd.vq import VectorQuantizerEMA
+    torch.manual_seed(17)
+    E, C = 8, 32
+    m = VectorQuantizerEMA(E, C, num_latents=n_lat).cuda()
+    st = {'embedding': m.embedding.detach().cpu().clone(), 'cluster_size': m.cluster_size.detach().cpu().clone(),
+          'activation_count': torch.zeros(n_lat, C), 'accumulated_error': torch.zeros(n_lat, C)}
+    x0 = torch.randn(6, 10, n_lat * E)
+    assert torch.equal(m.encode(x0.cuda()).cpu(), ovq.encode(x0, st['embedding']))
+    idx = ovq.encode(x0, st['embedding']).view(6, 10, n_lat)
+    assert torch.equal(m.decode(idx.cuda()).cpu(), ovq.decode(idx, st['embedding']))
+    for step in range(4):
+        training = step < 3
+        m.train(training)
+        x = torch.randn(6, 10, n_lat * E)
+        xg = x.cuda().requires_grad_(True)
+        q, enc, loss, ppl = m(xg)
+        q_ref, enc_ref, loss_ref, ppl_ref = ovq.forward(x, st, training)
+        assert q.shape == x.shape and torch.allclose(q.detach().cpu(), q_ref, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(loss.detach().cpu(), loss_ref, rtol=1e-5) and torch.allclose(ppl.cpu(), ppl_ref, rtol=1e-5)
+        assert enc.shape == enc_ref.shape and torch.equal(enc.indices.cpu(), enc_ref.argmax(-1))
+        if step == 0:
+            assert torch.equal(enc.materialize().cpu(), enc_ref)
+        for name in ('embedding', 'cluster_size', 'activation_count', 'accumulated_error'):
+            assert torch.allclose(getattr(m, name).cpu(), st[name], rtol=1e-5, atol=1e-6), (step, name)
+        (q * 2.0).sum().backward()
+        assert torch.equal(xg.grad.cpu(), torch.full_like(x, 2.0))             # straight-through: d quantized / d input = 1
+    m.activation_count[1, :5] = 0
+    st['activation_count'][1, :5] = 0
+    before = m.embedding.cpu().clone()
+    dead = (m.activation_count == 0).cpu()
+    n = m.reuse_inactive()
+    assert n == ovq.reuse_inactive(st) == int(dead.sum()) >= 5             # (which of several equally active codes topk names is
+    moved = (m.embedding.cpu() - before).abs().amax(-1) > 0                 #  the device's choice: only the count and the rows compared)
+    assert torch.equal(moved, dead)

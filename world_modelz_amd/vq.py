@@ -14,19 +14,21 @@ from ._lib import WmzError
 
 
 class LazyOneHot:
-    """The `encodings` return value of VectorQuantizerEMA.forward (reference vq.py:39: a dense fp32 one-hot [N, 1, C]):
+    """The `encodings` return value of VectorQuantizerEMA.forward (reference vq.py:39: a dense fp32 one-hot [N, L, C]):
     268 MB at N = 65 536, C = 1024, and no caller in scope reads it (train_vqae.py:38 drops it).  This stands in for the
     tensor and builds it only when something actually looks at it: any torch function or tensor method applied to it
-    materialises the dense one-hot first (`.indices` gives the int64 codes without materialising anything)."""
+    materialises the dense one-hot first (`.indices` gives the int64 codes -- [N] for one latent, [N, L] otherwise -- without
+    materialising anything)."""
 
     def __init__(self, indices, num_embeddings):
-        self.indices = indices                      # int64 [N]
+        self.indices = indices                      # int64 [N] or [N, L]
         self._C = num_embeddings
         self._dense = None
 
     @property
     def shape(self):
-        return torch.Size((self.indices.shape[0], 1, self._C))
+        n_lat = 1 if self.indices.dim() == 1 else self.indices.shape[1]
+        return torch.Size((self.indices.shape[0], n_lat, self._C))
 
     dtype = torch.float32
 
@@ -36,8 +38,8 @@ class LazyOneHot:
 
     def materialize(self):
         if self._dense is None:
-            N = self.indices.shape[0]
-            self._dense = torch.zeros(N, 1, self._C, device=self.indices.device).scatter_(-1, self.indices.view(N, 1, 1), 1.0)
+            N, n_lat, C = self.shape
+            self._dense = torch.zeros(N, n_lat, C, device=self.indices.device).scatter_(-1, self.indices.view(N, n_lat, 1), 1.0)
         return self._dense
 
     @classmethod
@@ -92,40 +94,47 @@ class VectorQuantizerEMA(nn.Module):
 
     # ---- helpers
     def _flat(self, x):
-        if self.num_latents != 1:
-            raise WmzError('the HIP VectorQuantizerEMA is built for num_latents == 1 (every caller in scope, '
-                           'train_vqae.py:31)')
+        """input -> fp32 [N, L, E] (reference :27: `input.reshape(-1, num_latents, embedding_dim)`)."""
         if not x.is_cuda:
             raise WmzError('VectorQuantizerEMA runs on the GPU only (no CPU fallback)')
-        return x.reshape(-1, self.embedding_dim).float()
+        return x.reshape(-1, self.num_latents, self.embedding_dim).float()
 
     def codebook_distance(self, input, normalize=True):
-        """[N, 1, C] distances (reference :77-82).  Diagnostic API: materialises N*C floats, chunked over N."""
+        """[N, L, C] distances (reference :77-82).  Diagnostic API: materialises N*L*C floats, chunked over N."""
         flat = self._flat(input)
-        cb = self.embedding[0]
-        outs = [(flat[i:i + 8192, None, :] - cb[None]).pow(2).sum(-1) for i in range(0, flat.shape[0], 8192)]
-        d = torch.cat(outs, 0).unsqueeze(1)
+        outs = [(flat[i:i + 8192, :, None, :] - self.embedding[None]).pow(2).sum(-1) for i in range(0, flat.shape[0], 8192)]
+        d = torch.cat(outs, 0)
         return d / self.embedding_dim if normalize else d
 
     def encode(self, input):
-        """int64 [N, 1] nearest-code indices (reference :84-87)."""
-        return ops.vq_argmin(self._flat(input), self.embedding[0]).unsqueeze(1)
+        """int64 [N, L] nearest-code indices (reference :84-87); every latent searches its own codebook."""
+        flat = self._flat(input)
+        return torch.stack([ops.vq_argmin(flat[:, l], self.embedding[l]) for l in range(self.num_latents)], dim=1)
 
     def decode(self, indices):
-        """codebook rows, [*indices.shape, E] (reference :89-94)."""
-        idx = indices.reshape(-1)
-        return ops.vq_gather(idx, self.embedding[0]).reshape(*indices.shape, self.embedding_dim)
+        """codebook rows, [*indices.shape, E] (reference :89-94: with several latents the last axis of `indices` walks them)."""
+        if self.num_latents == 1:
+            idx = indices.reshape(-1)
+            return ops.vq_gather(idx, self.embedding[0]).reshape(*indices.shape, self.embedding_dim)
+        if indices.shape[-1] != self.num_latents:
+            raise WmzError(f'decode: the last axis of the indices ({indices.shape[-1]}) must be num_latents = {self.num_latents}')
+        idx = indices.reshape(-1, self.num_latents)
+        rows = torch.stack([ops.vq_gather(idx[:, l].contiguous(), self.embedding[l]) for l in range(self.num_latents)], dim=1)
+        return rows.reshape(*indices.shape, self.embedding_dim)
 
     def forward(self, input):
-        flat = self._flat(input)
-        N, C = flat.shape[0], self.num_embeddings
-        cb = self.embedding[0]
-        idx = ops.vq_argmin(flat.detach(), cb)
-        quantized = ops.vq_gather(idx, cb)                                    # before the EMA update, like :34
-        counts = torch.zeros(C, device=flat.device)
-        dw = torch.zeros(C, self.embedding_dim, device=flat.device) if self.training else None
-        ops.vq_ema_stats(flat.detach(), idx, cb, counts, dw, self.accumulated_error[0])   # :35-36 always, :43-46
-        encodings = LazyOneHot(idx, C)                                        # returned (:39), dense only if it is read
+        flat = self._flat(input)                                              # [N, L, E]
+        N, C, n_lat = flat.shape[0], self.num_embeddings, self.num_latents
+        fd = flat.detach()
+        idx_l, q_l, counts = [], [], torch.zeros(n_lat, C, device=flat.device)
+        dw = torch.zeros(n_lat, C, self.embedding_dim, device=flat.device) if self.training else None
+        for l in range(n_lat):                                                # (one latent everywhere in scope: train_vqae.py:31)
+            cb = self.embedding[l]
+            idx = ops.vq_argmin(fd[:, l], cb)
+            idx_l.append(idx)
+            q_l.append(ops.vq_gather(idx, cb))                                # before the EMA update, like :34
+            ops.vq_ema_stats(fd[:, l], idx, cb, counts[l], dw[l] if dw is not None else None, self.accumulated_error[l])   # :35-36 always, :43-46
+        encodings = LazyOneHot(idx_l[0] if n_lat == 1 else torch.stack(idx_l, 1), C)   # returned (:39), dense only if it is read
         local_counts = counts
         if self.training:
             if self.sync_stats is not None and torch.distributed.is_initialized():
@@ -133,8 +142,9 @@ class VectorQuantizerEMA(nn.Module):
                 local_counts = counts.clone()
                 torch.distributed.all_reduce(counts, group=group)
                 torch.distributed.all_reduce(dw, group=group)
-            ops.vq_ema_update(self.embedding, self.cluster_size, self.activation_count, counts, dw, self.decay, self.eps)
-        quantized = quantized.view_as(input).to(input.dtype)
+            for l in range(n_lat):
+                ops.vq_ema_update(self.embedding[l], self.cluster_size[l], self.activation_count[l], counts[l], dw[l], self.decay, self.eps)
+        quantized = (q_l[0] if n_lat == 1 else torch.stack(q_l, 1)).view_as(input).to(input.dtype)
         commitment_loss = F.mse_loss(quantized.detach(), input)               # :67
         quantized = input + (quantized - input).detach()                      # straight-through (:70)
         avg_probs = local_counts / N                                          # == encodings.mean(0) (:72), this rank's batch
