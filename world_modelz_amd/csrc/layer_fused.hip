@@ -183,9 +183,6 @@ __global__ __launch_bounds__(NTHR, 8 / FW) void layer_fused_kernel(FusedParams P
   ws.probe = 0;
   ws.ts = (P.ts != nullptr && blockIdx.x == 0 && lane == 0) ? P.ts + wave * 64 : nullptr;
   WMZ_TS(0);
-#ifdef WMZ_FUSED_PRIO
-  if (wave >= FW / 2) __builtin_amdgcn_s_setprio(1);                  // (experiment: static priority for the younger half of the workgroup)
-#endif
   const long tok0 = (long)blockIdx.x * (TW * FW) + wave * TW;        // first token of this wave
   const long tok = tok0 + (lane & 31);
   const long tokc = tok < P.ntok ? tok : P.ntok - 1;                  // clamped: loads are unconditional
