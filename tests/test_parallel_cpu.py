@@ -401,7 +401,7 @@ class _TorchVqOps:
 def _vq_on_cpu():
     from world_modelz_amd import vq as vq_mod
     vq_mod.ops = _TorchVqOps
-    vq_mod.VectorQuantizerEMA._flat = lambda self, x: x.reshape(-1, self.embedding_dim).float()
+    vq_mod.VectorQuantizerEMA._flat = lambda self, x: x.reshape(-1, self.num_latents, self.embedding_dim).float()      # (the module's reshape without its GPU-only check)
     return vq_mod
 
 
