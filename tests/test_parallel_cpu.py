@@ -390,12 +390,12 @@ class _TorchVqOps:
 
     @staticmethod
     def vq_ema_update(embedding, cluster_size, activation_count, counts, dw, decay, eps):
-        C = embedding.shape[-2]                                     # vq.py:44, :53-65 (laplace smoothing, batch sum / EMA count)
-        activation_count[0] += counts
-        cluster_size[0].mul_(decay).add_(counts, alpha=1 - decay)
-        n = cluster_size[0].sum()
-        cs = (cluster_size[0] + eps) / (n + C * eps) * n
-        embedding[0].mul_(decay).add_(dw / cs.unsqueeze(-1), alpha=1 - decay)
+        C = embedding.shape[-2]                                     # vq.py:44, :53-65 (laplace smoothing, batch sum / EMA count);
+        activation_count += counts                                  # one latent's slices of the buffers, as the module hands them over
+        cluster_size.mul_(decay).add_(counts, alpha=1 - decay)
+        n = cluster_size.sum()
+        cs = (cluster_size + eps) / (n + C * eps) * n
+        embedding.mul_(decay).add_(dw / cs.unsqueeze(-1), alpha=1 - decay)
 
 
 def _vq_on_cpu():
