@@ -32,6 +32,8 @@ struct PointParams {
   BnStats in_bn;     // the input prologue's BatchNorm from raw statistics (sum != nullptr; bn_lazy.h) instead of in_scale / in_shift
 };
 
+__device__ __attribute__((aligned(16))) unsigned cp_zero_chunk[4] = {0u, 0u, 0u, 0u};      // what a padding / empty granule loads
+
 constexpr int CP_PITCH = 144;                    // bytes per pixel of a wave's LDS image: 64 channels + 16
 constexpr int CP_IMG = 64 * CP_PITCH;            // one wave's image: 64 pixels
 
@@ -112,8 +114,16 @@ __global__ __launch_bounds__(256, 2) void convp_kernel(PointParams P) {
         const unsigned iy = (pyx[i] >> 16) + kh - 1, ix = (pyx[i] & 0xFFFFu) + kw - 1;       // (wraps to a huge value when negative)
         ok = ok && iy < (unsigned)P.Hi && ix < (unsigned)P.Wi;
       }
-      ld[i] = (i32x4)(0);
-      if (ok) ld[i] = *reinterpret_cast<const i32x4*>(P.x + (long)(poff[i] + toff));
+      if constexpr (PAD) {
+        ld[i] = (i32x4)(0);
+        if (ok) ld[i] = *reinterpret_cast<const i32x4*>(P.x + (long)(poff[i] + toff));
+      } else {
+        // (round 6: an unconditional load from a SELECTED address -- the granules behind the last tap read a zero chunk: the
+        //  predicated form made hipcc branch around the loads; 1x1 128 -> 64 at 256 x 64^2: 103.9 -> 93.5 us.  The padded layers
+        //  keep the predicate: there a third of the granules would hammer the one zero line, measured 9-15 % slower)
+        const i32x4* const src = ok ? reinterpret_cast<const i32x4*>(P.x + (long)(poff[i] + toff)) : reinterpret_cast<const i32x4*>(cp_zero_chunk);
+        ld[i] = *src;
+      }
     }
   };
   i32x4 ld[NLD];
