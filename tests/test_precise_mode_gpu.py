@@ -111,3 +111,22 @@ def test_half_mode_refuses_shapes_the_row_kernel_is_not_built_for(wmz):
     q = torch.randn(1, 2, 5, 7, 64, device='cuda').half()               # 7-wide planes: the general kernel has no half form
     with pytest.raises(WmzError):
         wmz['ops'].local3d_attention_fwd(q, q, q, (1, 1, 1), 1)
+
+
+def test_precise_mode_runs_other_widths_on_the_fp32_route(wmz):
+    """Documented behaviour (config.py): what the half kernels are not built for -- here the published dim-96 width, which has bf16
+    chain kernels but no half ones -- runs the fp32 route in the precise mode, never bf16: the logits are the fp32 mode's, bit for
+    bit, and no half or chain entry point is reached."""
+    from conftest import recorded_calls
+    cfg = wmz['config']
+    torch.manual_seed(5)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(4, 16, 16), dim=96, num_classes=128, extents=(1, 1, 1), depth=2, dim_head=128,
+                                          mlp_dim=256, heads=1).cuda()
+    z = torch.randint(0, 129, (2, 4, 16, 16), device='cuda')
+    with torch.no_grad():
+        with cfg.compute_dtype(torch.float32):
+            y32 = m(z)
+        with cfg.compute_dtype(torch.float16), recorded_calls() as seen:
+            yp = m(z)
+    assert torch.equal(yp, y32)
+    assert not any(n.endswith('_f16') or 'chain' in n for n in seen), set(seen)
