@@ -894,6 +894,22 @@ def main():
                       'what': 'reference geometry: B = 64 clips of (6, 8, 8) latents, codebook 512, dim 384 / mlp 512 / depth 20 / '
                               '1 x 128 / extents (3,1,1) (results/README.md run 03); full grid forward and one training step'}
             del rrun
+            # ... the same forward in the precise mode (half unit of the chain kernel + half attention, round 6)
+            config.set_compute_dtype(torch.float16)
+            try:
+                with torch.no_grad():
+                    rrun = GraphedForward(mr, zr)
+                    for _ in range(10):
+                        rrun(rrun.static_in)
+                    torch.cuda.synchronize()
+                    r0_ = time.perf_counter()
+                    for _ in range(10):
+                        rrun(rrun.static_in)
+                    torch.cuda.synchronize()
+                    refgeo['precise_forward_ms_per_step'] = (time.perf_counter() - r0_) / 10 * 1e3
+                del rrun
+            finally:
+                config.set_compute_dtype(dtype)
             if a.train_steps > 0 and world == 1:
                 mr.train()
                 rt = _RT(mr, 512, lr=1e-4, warmup=500, max_steps=75000, distributed=False)
@@ -910,7 +926,8 @@ def main():
                 refgeo['train_ms_per_step'] = rtr * 1e3
                 refgeo['train_value'] = 64 * 6 / rtr
                 del rt
-            log(f"reference geometry 64 x (6,8,8), dim 384 / depth 20: forward {refgeo['forward_ms_per_step']:.3f} ms, "
+            log(f"reference geometry 64 x (6,8,8), dim 384 / depth 20: forward {refgeo['forward_ms_per_step']:.3f} ms "
+                f"(precise mode {refgeo['precise_forward_ms_per_step']:.3f}), "
                 f"train {refgeo.get('train_ms_per_step', float('nan')):.2f} ms")
             del mr
             gc.collect()

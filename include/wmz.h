@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 109
+#define WMZ_VERSION 110
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1,
        WMZ_F16 = 2 /* IEEE half activations / MFMA operands: the PRECISE fused inference mode (wmz_local3d_attn_fwd* on the
@@ -338,6 +338,11 @@ int wmz_layer_fused_pack_f16(const float* wout, const float* bout, const float* 
                              int D, int I, int M, void* stream);
 int wmz_fused_pack_table_f16(const void* block_rows, int nblk, long total8, const void* vec_jobs, int nvec, int D, int I, int M,
                              void* stream);
+/* ... the same for the published widths (wmz_layer_chain_supported: dim 96 / mlp 256, dim 384 / mlp 512): wmz_layer_chain_fwd_planes
+ * with half tensors and a half weight stream (world_modelz_amd/fused.py::_chain_pack packs either format). */
+int wmz_layer_chain_fwd_planes_f16(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
+                                   const float* vec, int B, int n_q, int n_in, int HW, int D, int I, int M, int head, int tail,
+                                   float eps, void* stream);
 /* ... and the linear behind it (VqVideoDiffusionModel.logit_proj on the last frame, main.py:33-36): wmz_linear_fwd /
  * wmz_linear_fwd_stats / wmz_linear_fwd_blocked with dtype = WMZ_F16 (A and Wt half, bias / LayerNorm parameters fp32, C half or,
  * with out_f32, fp32). */

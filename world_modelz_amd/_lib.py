@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16, WMZ_F16 = 0, 1, 2
-EXPECTED_VERSION = 109      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
+EXPECTED_VERSION = 110      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -140,7 +140,8 @@ SIGNATURES = {
 
 
 for _n in ('wmz_layer_fused_fwd', 'wmz_embed_qkv_fused_fwd', 'wmz_layer_fused_fwd_planes', 'wmz_embed_qkv_fused_fwd_planes',
-           'wmz_layer_fused_pack', 'wmz_fused_pack_table', 'wmz_linear_fwd', 'wmz_linear_fwd_stats', 'wmz_linear_fwd_blocked'):
+           'wmz_layer_fused_pack', 'wmz_fused_pack_table', 'wmz_linear_fwd', 'wmz_linear_fwd_stats', 'wmz_linear_fwd_blocked',
+           'wmz_layer_chain_fwd_planes'):
     SIGNATURES[_n + '_f16'] = SIGNATURES[_n]          # the precise (IEEE half) instantiations: include/wmz.h
 
 

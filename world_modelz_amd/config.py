@@ -13,7 +13,8 @@ _DTYPES = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'fp32': torch.flo
 #   fp32    the parity mode (exact-f32 MFMA at 1/16 of the matrix rate, op by op: ~4e-7, 11x slower);
 #   float16 the PRECISE fused mode: inference at the default widths runs the fused kernels with IEEE-half MFMA operands and a half
 #           residual stream between the layers (~5e-4 at the bf16 speed: inside the 1e-3 BASELINE.json asks for); everything the
-#           half kernels are not built for (training, other widths, the conv encoder / decoder) runs the fp32 route -- never bf16.
+#           half kernels are not built for (training, widths other than the default and the published ones, planes outside the row
+#           attention kernel's shapes, the conv encoder / decoder) runs the fp32 route -- never bf16.
 _precise = False
 _compute_dtype = None
 

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
     constexpr int NB = decltype(nbc)::value, KS = decltype(ksc)::value;
     run(std::integral_constant<int, NB * KS>{}, [&](auto pc, const s16x8& a) {
       constexpr int p = decltype(pc)::value, ks = p / NB, b = p % NB;
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, opnd[ks], acc[b], 0, 0, 0);
+      acc[b] = op16_mfma_16x16x32(a, opnd[ks], acc[b]);
     });
   };
   // fp32 accumulator blocks (lane-group-major) -> bf16 B operands of the next GEMM: k-step s = blocks 2 s, 2 s + 1
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
       const i32x4 c = *reinterpret_cast<const i32x4*>(row + 8 * s);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float lo = __uint_as_float(((unsigned)c[j]) << 16), hi = __uint_as_float(((unsigned)c[j]) & 0xFFFF0000u);
+        const float lo = bf16_bits_to_f32((unsigned short)((unsigned)c[j] & 0xFFFFu)), hi = bf16_bits_to_f32((unsigned short)((unsigned)c[j] >> 16));   // (the unit's 16-bit format: wmz_common.h)
         const int e = 2 * j;
         if (add) { acc[2 * s + (e >> 2)][e & 3] += lo; acc[2 * s + ((e + 1) >> 2)][(e + 1) & 3] += hi; }
         else { acc[2 * s + (e >> 2)][e & 3] = lo; acc[2 * s + ((e + 1) >> 2)][(e + 1) & 3] = hi; }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
         constexpr int p = decltype(pc)::value;
         if constexpr (p < NBC * KSD) {
           constexpr int ks = p / NBC, b = p % NBC;
-          h[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[ks], h[b], 0, 0, 0);
+          h[b] = op16_mfma_16x16x32(a, xb[ks], h[b]);
         } else {
           if constexpr (p == NBC * KSD) {
             if constexpr (TRAIN) store_rows(CNBC{}, P.z + tok * M + c * MC + g * (MC / 4), h);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(CW * 64, 2) void layer_chain_kernel(ChainParams P) 
             }
           }
           constexpr int q2 = p - NBC * KSD, ks = q2 / NBD, b = q2 % NBD;
-          xr[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hb[ks], xr[b], 0, 0, 0);
+          xr[b] = op16_mfma_16x16x32(a, hb[ks], xr[b]);
         }
       });
     }
@@ -321,6 +321,7 @@ int launch_chain(const ChainParams& P, int head, int tail, hipStream_t st) {
 }  // namespace
 
 // pieces (KB) per weight slab: every GEMM stage of the packed stream is padded to a multiple of it
+#ifndef WMZ_OP16_F16
 extern "C" int wmz_layer_chain_slab_pieces(void) { return CSP; }
 
 // 1 when (D, I, M) has an instantiation; the hidden-chunk size MC of that instantiation through *mc (the host packer needs it)
@@ -332,12 +333,14 @@ extern "C" int wmz_layer_chain_supported(int D, int I, int M, int* mc) {
   return c != 0;
 }
 
+#endif  // WMZ_OP16_F16 (slab size and supported widths are the bfloat16 unit's exports; they hold for both)
+
 // One launch for everything per-token between two attention launches, widths (D, I, M) of wmz_layer_chain_supported.
 //   o [B, n_q, HW, I] attention output (head != 0), x [B, n_in, HW, D] the stream (trailing n_q planes of every clip are read),
 //   x_out [B, n_q, HW, D] (head), q_out [B, n_q, HW, I] and kv_out [2, B, n_q, HW, I] (tail != 0): all bf16, row-major.
 //   wpack / vec: the weight stream and fp32 vectors in the kernel's order (world_modelz_amd/fused.py::_chain_pack), wpack with
 //   CRING - 1 slabs (wmz_layer_chain_slab_pieces() KB each) of readable padding behind the last piece.
-extern "C" int wmz_layer_chain_fwd_planes(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
+extern "C" int WMZ_FN(wmz_layer_chain_fwd_planes)(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                           const float* vec, int B, int n_q, int n_in, int HW, int D, int I, int M, int head,
                                           int tail, float eps, void* stream) {
   WMZ_REQUIRE(x && wpack && vec, "wmz_layer_chain_fwd_planes: null tensor");
@@ -357,6 +360,7 @@ extern "C" int wmz_layer_chain_fwd_planes(const void* o, const void* x, void* x_
   return WMZ_ERR_UNSUPPORTED;
 }
 
+#ifndef WMZ_OP16_F16      // (the training forward: the bfloat16 unit only)
 // The training forward of the same launch (whole grids: ntok tokens, no trailing-planes form); wpack / vec exactly as for
 // wmz_layer_chain_fwd_planes (LayerNorm affines folded).  Besides x_out / q_out / kv_out ([ntok, 2 I]: k | v per row) it writes what
 // the step's backward reads: x1 [ntok, D] the raw feed-forward input (or NULL), xn_ff [ntok, D] its NORMALISED rows, z / h [ntok, M]
@@ -383,3 +387,4 @@ extern "C" int wmz_layer_chain_fwd_train(const void* o, const void* x, void* x_o
   wmz_set_error("wmz_layer_chain_fwd_train: widths (%d, %d, %d) not built", D, I, M);
   return WMZ_ERR_UNSUPPORTED;
 }
+#endif  // WMZ_OP16_F16

@@ -67,8 +67,16 @@ def chain_widths(transformer):
     return D, I, M, mc.value
 
 
-def chain_supported(transformer, x_dtype):
-    return x_dtype == torch.bfloat16 and hasattr(transformer, 'pos_emb_s') and chain_widths(transformer) is not None
+def chain_supported(transformer, x_dtype, inference=False):
+    # (training: bfloat16 only; the inference launch also has a half unit -- layer_chain_f16.hip, the precise mode)
+    ok = (torch.bfloat16, torch.float16) if inference else (torch.bfloat16,)
+    return x_dtype in ok and hasattr(transformer, 'pos_emb_s') and chain_widths(transformer) is not None
+
+
+def half_attention_ok(transformer, H, W):
+    """The half attention unit (csrc/attn_fwd_row16_f16.hip) is built for these planes and heads (csrc/attn_fwd.hip)."""
+    dh = {a.fn.to_q.weight.shape[0] // a.fn.heads for a, _ in transformer.layers}
+    return dh <= {32, 64, 128} and (W == 16 or (W == 8 and H % 2 == 0))
 
 
 def _chain_pieces(w, pad_value=0):
@@ -91,8 +99,8 @@ def _chain_pieces(w, pad_value=0):
     return t
 
 
-def _chain_pack(head, tail, D, I, M, MC):
-    """(wpack bf16, vec fp32) for one launch of wmz_layer_chain_fwd_planes: stages to_out | MC-wide feed-forward chunks (W1'
+def _chain_pack(head, tail, D, I, M, MC, dt=torch.bfloat16):
+    """(wpack in dt -- bf16, or half for the _f16 unit --, vec fp32) for one launch of wmz_layer_chain_fwd_planes: stages to_out | MC-wide feed-forward chunks (W1'
     rows, then W2 columns) | q | k | v, LayerNorm affines folded in (W1' = W1 diag(g2), b1' = b1 + W1 be2; to_k / to_v likewise
     with the next layer's norm); vec = bout | b1' | b2 | bk' | bv'.  Cached per parameter version."""
     params = []
@@ -130,9 +138,9 @@ def _chain_pack(head, tail, D, I, M, MC):
         stream = torch.cat(parts, 0)
         sp = L.lib().wmz_layer_chain_slab_pieces()
         assert stream.shape[0] % sp == 0
-        wpack = torch.cat([stream.reshape(-1), stream.new_zeros(3 * sp * 512)]).to(torch.bfloat16).contiguous()
+        wpack = torch.cat([stream.reshape(-1), stream.new_zeros(3 * sp * 512)]).to(dt).contiguous()
         return wpack, vec
-    return _cast.cached(params, f'chainpack{D}_{I}_{M}', build)
+    return _cast.cached(params, f'chainpack{D}_{I}_{M}{_sfx(dt)}', build)
 
 
 def transformer_forward_chain(tr, z):
@@ -143,16 +151,18 @@ def transformer_forward_chain(tr, z):
     layers = list(tr.layers)
     B, S, H, W = z.shape
     HW = H * W
-    dev, bf = z.device, torch.bfloat16
+    dev, bf = z.device, config.get_fused_dtype()       # (bf: the stream's 16-bit format -- bfloat16, or half in the precise mode)
     x = Fw.embed_tokens(z, tr.embedding.weight, tr.pos_emb_s.weight, tr.pos_emb_h.weight, tr.pos_emb_w.weight)
-    assert x.dtype == bf and x.is_contiguous()
+    if x.dtype != bf:
+        x = x.to(bf)                                   # (precise mode: the embedding sum in fp32, rounded once to half)
+    assert x.is_contiguous()
 
     def launch(o, x_in, head, tail):
-        wpack, vec = _chain_pack(head, tail, D, I, M, MC)
+        wpack, vec = _chain_pack(head, tail, D, I, M, MC, bf)
         xo = torch.empty((B, S, H, W, D), dtype=bf, device=dev) if head is not None else None
         q = torch.empty((B, S, H, W, I), dtype=bf, device=dev) if tail is not None else None
         kv = torch.empty((2, B, S, H, W, I), dtype=bf, device=dev) if tail is not None else None
-        L.call('wmz_layer_chain_fwd_planes', L.ptr(o), L.ptr(x_in), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
+        L.call('wmz_layer_chain_fwd_planes' + _sfx(bf), L.ptr(o), L.ptr(x_in), L.ptr(xo), L.ptr(q), L.ptr(kv), L.ptr(wpack), L.ptr(vec),
                B, S, S, HW, D, I, M, 1 if head is not None else 0, 1 if tail is not None else 0, 1e-5, L.stream())
         return xo, q, kv
     _, q, kv = launch(None, x, None, layers[0])

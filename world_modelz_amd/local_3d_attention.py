@@ -187,8 +187,10 @@ class Local3dAttentionTransformer(nn.Module):
                 # inference, bf16 (or half: the precise mode), default widths: one attention launch + one per-token launch per
                 # layer, the embedding fused into the first one
                 return fused.transformer_forward(self, z=img_z)
-            if fused.chain_supported(self, get_compute_dtype()):
-                # the reference's published widths: the same fusion on csrc/layer_chain.hip
+            if fused.chain_supported(self, get_fused_dtype(), True) and (
+                    get_fused_dtype() != torch.float16 or fused.half_attention_ok(self, img_z.shape[2], img_z.shape[3])):
+                # the reference's published widths: the same fusion on csrc/layer_chain.hip (its half unit in the precise mode,
+                # where the planes are the row attention kernel's; other planes stay on the fp32 route below)
                 return fused.transformer_forward_chain(self, img_z)
         else:
             from . import config, fused
