@@ -270,8 +270,9 @@ int wmz_layer_fused_fwd_planes(const void* o, const void* x, void* x_out, void* 
                                int has_head, int has_tail, int xflags, float eps, void* stream);
 /*
  * The same fusion for widths the default-width kernel cannot hold in registers (csrc/layer_chain.hip: 16-token waves, MFMA
- * 16x16x32, fp32 residual stream in registers, activations chained lane-locally, weights by an LDS-DMA ring): the reference's
- * published runs (dim 96 / mlp 256, dim 384 / mlp 512; results/README.md).
+ * 16x16x32, fp32 residual stream in registers, activations chained lane-locally, weights by an LDS-DMA ring): the width triples of
+ * csrc/chain_widths.h -- the reference's published runs (dim 96 / mlp 256, dim 384 / mlp 512; results/README.md), its own test()
+ * geometry (local_3d_attention.py:166-174: dim 128, 3 heads of 64, mlp 256) and the neighbours of the argparse defaults.
  * wmz_layer_chain_supported: 1 when (D, I, M) is instantiated, *mc = the hidden-chunk size the weight packer must use.
  * Tensors as wmz_layer_fused_fwd_planes (row-major only); wpack / vec in the order of world_modelz_amd/fused.py::_chain_pack,
  * wpack followed by two slabs of readable padding.  Replaces: local_3d_attention.py:11-31, :46-53, :106-108, :159-161.
@@ -338,7 +339,7 @@ int wmz_layer_fused_pack_f16(const float* wout, const float* bout, const float* 
                              int D, int I, int M, void* stream);
 int wmz_fused_pack_table_f16(const void* block_rows, int nblk, long total8, const void* vec_jobs, int nvec, int D, int I, int M,
                              void* stream);
-/* ... the same for the published widths (wmz_layer_chain_supported: dim 96 / mlp 256, dim 384 / mlp 512): wmz_layer_chain_fwd_planes
+/* ... the same for the chain kernels' widths (wmz_layer_chain_supported, csrc/chain_widths.h): wmz_layer_chain_fwd_planes
  * with half tensors and a half weight stream (world_modelz_amd/fused.py::_chain_pack packs either format). */
 int wmz_layer_chain_fwd_planes_f16(const void* o, const void* x, void* x_out, void* q_out, void* kv_out, const void* wpack,
                                    const float* vec, int B, int n_q, int n_in, int HW, int D, int I, int M, int head, int tail,

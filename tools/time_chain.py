@@ -1,19 +1,28 @@
-"""Forward step of the reference's published widths (dim 96 / mlp 256 / depth 12, dim 384 / mlp 512 / depth 20, window 7x3x3) at
-config-4 clips: the chain kernel (csrc/layer_chain.hip) against the per-op path."""
+"""Forward step and training step of the chain kernels' width triples (csrc/chain_widths.h) at config-4 clips (8 x 32 x 16 x 16):
+the chain kernels (csrc/layer_chain.hip, layer_chain_bwd.hip) against the per-op path.
+    python3 tools/time_chain.py [all]          (default: the published widths and the reference's test() geometry)"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from world_modelz_amd import config, fused
 from world_modelz_amd.main import VqVideoDiffusionModel
 from world_modelz_amd.graph import GraphedForward
+from world_modelz_amd.train import DenoiserTrainer
 config.set_compute_dtype(torch.bfloat16)
 config.set_last_frame_cone(False)
-z = torch.randint(0, 1025, (8, 32, 16, 16), device='cuda')
+z = torch.randint(0, 1024, (8, 32, 16, 16), device='cuda')
 orig = fused.chain_supported
-for dim, mlp, depth in ((96, 256, 12), (384, 512, 20)):
+# (dim, heads, dim_head, mlp, depth, extents)
+CASES = [(96, 1, 128, 256, 12, (3, 1, 1)), (384, 1, 128, 512, 20, (3, 1, 1)), (128, 3, 64, 256, 4, (2, 2, 2))]
+if 'all' in sys.argv[1:]:
+    CASES += [(128, 2, 64, 512, 4, (3, 3, 3)), (192, 1, 128, 512, 4, (3, 3, 3)), (256, 1, 128, 512, 4, (3, 3, 3)),
+              (256, 1, 128, 1024, 4, (3, 3, 3)), (256, 2, 128, 256, 4, (3, 3, 3)), (256, 2, 128, 1024, 4, (3, 3, 3)),
+              (512, 1, 128, 1024, 4, (3, 3, 3))]
+for dim, heads, dh, mlp, depth, ext in CASES:
     torch.manual_seed(42)
-    m = VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=dim, num_classes=1024, extents=(3, 1, 1), depth=depth, dim_head=128,
-                              mlp_dim=mlp, heads=1).cuda().eval()
-    outs = {}
+    m = VqVideoDiffusionModel(data_shape=(32, 16, 16), dim=dim, num_classes=1024, extents=ext, depth=depth, dim_head=dh,
+                              mlp_dim=mlp, heads=heads).cuda().eval()
+    assert fused.chain_widths(m.transformer) is not None
+    outs, line = {}, []
     for mode in ('chain', 'per-op'):
         fused.chain_supported = orig if mode == 'chain' else (lambda *a: False)
         with torch.no_grad():
@@ -25,7 +34,24 @@ for dim, mlp, depth in ((96, 256, 12), (384, 512, 20)):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 20
         outs[mode] = y.clone()
-        print(f'dim {dim} depth {depth} {mode}: {dt * 1e3:.3f} ms/step ({dt / depth * 1e6:.1f} us per layer)', flush=True)
+        line.append(f'forward {mode} {dt * 1e3:.3f} ms')
+        del r
+    fused.chain_supported = orig
     d = (outs['chain'].float() - outs['per-op'].float()).norm() / outs['per-op'].float().norm()
-    print(f'   chain vs per-op logits: rel {float(d):.2e}')
-fused.chain_supported = orig
+    m.train()
+    for mode in ('chain', 'per-op'):
+        config.set_fused_training(mode == 'chain')
+        try:
+            t = DenoiserTrainer(m, 1024, lr=1e-4, warmup=500, max_steps=100000, distributed=False)
+            rr = torch.full((8,), 0.5)
+            t.enable_graph(z)
+            for _ in range(3): t.train_step(z, r=rr)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5): t.train_step(z, r=rr)
+            torch.cuda.synchronize()
+            line.append(f'train {mode} {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms')
+            del t
+        finally:
+            config.set_fused_training(True)
+    print(f'dim {dim} {heads}x{dh} mlp {mlp} depth {depth}: ' + ', '.join(line) + f'   (chain vs per-op logits rel {float(d):.2e})', flush=True)

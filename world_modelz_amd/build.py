@@ -18,7 +18,8 @@ LIB = os.path.join(HERE, 'libwmz_hip.so')
 ROOT = os.path.dirname(HERE)
 
 COMMON = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
-          '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-Wno-unused-result']
+          '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-Wno-unused-result', '-Wno-unused-lambda-capture',
+          '-Wno-unused-local-typedef']
 PER_FILE = {
     # distance arithmetic must round like the reference's separate sub/mul/add tensor ops
     'vq.hip': ['-ffp-contract=off'],
@@ -43,14 +44,25 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def _hip_mtime(path, seen=None):
+    """Newest mtime of a .hip source and of the .hip sources it #includes (transitively)."""
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return 0.0
+    seen.add(path)
+    m = os.path.getmtime(path)
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith('#include "') and line.endswith('.hip"'):
+                m = max(m, _hip_mtime(os.path.join(CSRC, line[len('#include "'):-1]), seen))
+    return m
+
+
 def _compile(src, force, hdr_mtime):
     obj = os.path.join(OBJ, src[:-4] + '.o')
     path = os.path.join(CSRC, src)
-    src_mtime = os.path.getmtime(path)
-    if src.endswith('_f16.hip'):                # a precise-mode unit is a second compilation of its base source (wmz_common.h)
-        base = os.path.join(CSRC, src[:-8] + '.hip')
-        if os.path.exists(base):
-            src_mtime = max(src_mtime, os.path.getmtime(base))
+    src_mtime = _hip_mtime(path)                # (a wrapper unit -- *_f16.hip, *_g<n>.hip -- is a second compilation of the source it includes)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(src_mtime, hdr_mtime)):
         return obj, False

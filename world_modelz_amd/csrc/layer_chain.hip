@@ -22,6 +22,20 @@
 // LDS ring of 3 slabs is filled by LDS-DMA (4 pieces per wave and slab), one counted vmcnt + one raw s_barrier per slab
 // (= 32 MFMAs per wave).  The feed-forward is walked MC hidden units at a time (W1' rows -> GELU -> W2 columns).
 #include "wmz_common.h"
+#include "chain_widths.h"
+
+#ifndef WMZ_CHAIN_GROUP
+#define WMZ_CHAIN_GROUP 0         // this unit's group of width triples (chain_widths.h); group 0 also holds the entry points
+#endif
+// a group's launcher: WMZ_OK / an error code, or -1 when the widths are not this group's
+#ifdef WMZ_OP16_F16
+#define CHAIN_GROUP_FN(g) WMZ_CHAIN_CAT(WMZ_CHAIN_CAT(wmz_chain_fwd_group, g), _f16)
+#else
+#define CHAIN_GROUP_FN(g) WMZ_CHAIN_CAT(wmz_chain_fwd_group, g)
+#endif
+#define CHAIN_DECLARE_GROUP(g) \
+  int CHAIN_GROUP_FN(g)(const void* params, int D, int I, int M, int head, int tail, int train, hipStream_t st);
+WMZ_CHAIN_ALL_GROUPS(CHAIN_DECLARE_GROUP)
 
 namespace {
 
@@ -320,6 +334,36 @@ int launch_chain(const ChainParams& P, int head, int tail, hipStream_t st) {
 
 }  // namespace
 
+int CHAIN_GROUP_FN(WMZ_CHAIN_GROUP)(const void* params, int D, int I, int M, int head, int tail, int train, hipStream_t st) {
+  const ChainParams& P = *static_cast<const ChainParams*>(params);
+#ifdef WMZ_OP16_F16
+#define CHAIN_TRY(d, i, m, mc) \
+  if (D == d && I == i && M == m) return train ? WMZ_ERR_UNSUPPORTED : launch_chain<d, i, m, mc, false>(P, head, tail, st);
+#else
+#define CHAIN_TRY(d, i, m, mc)    \
+  if (D == d && I == i && M == m) \
+    return train ? launch_chain<d, i, m, mc, true>(P, head, tail, st) : launch_chain<d, i, m, mc, false>(P, head, tail, st);
+#endif
+  WMZ_CHAIN_WIDTHS_OF(WMZ_CHAIN_GROUP)(CHAIN_TRY)
+#undef CHAIN_TRY
+  return -1;
+}
+
+#if WMZ_CHAIN_GROUP == 0          // ---- the entry points (this group's bfloat16 / half unit)
+namespace {
+int chain_dispatch(const ChainParams& P, int D, int I, int M, int head, int tail, int train, hipStream_t st, const char* who) {
+  int r = -1;
+#define CHAIN_ASK(g) if (r == -1) r = CHAIN_GROUP_FN(g)(&P, D, I, M, head, tail, train, st);
+  WMZ_CHAIN_ALL_GROUPS(CHAIN_ASK)
+#undef CHAIN_ASK
+  if (r == -1) {
+    wmz_set_error("%s: widths (%d, %d, %d) not built (csrc/chain_widths.h)", who, D, I, M);
+    return WMZ_ERR_UNSUPPORTED;
+  }
+  return r;
+}
+}  // namespace
+
 // pieces (KB) per weight slab: every GEMM stage of the packed stream is padded to a multiple of it
 #ifndef WMZ_OP16_F16
 extern "C" int wmz_layer_chain_slab_pieces(void) { return CSP; }
@@ -327,8 +371,9 @@ extern "C" int wmz_layer_chain_slab_pieces(void) { return CSP; }
 // 1 when (D, I, M) has an instantiation; the hidden-chunk size MC of that instantiation through *mc (the host packer needs it)
 extern "C" int wmz_layer_chain_supported(int D, int I, int M, int* mc) {
   int c = 0;
-  if (D == 96 && I == 128 && M == 256) c = 256;
-  else if (D == 384 && I == 128 && M == 512) c = 64;
+#define CHAIN_HAS(d, i, m, mcv) if (D == d && I == i && M == m) c = mcv;
+  WMZ_CHAIN_ALL_WIDTHS(CHAIN_HAS)
+#undef CHAIN_HAS
   if (mc) *mc = c;
   return c != 0;
 }
@@ -354,10 +399,7 @@ extern "C" int WMZ_FN(wmz_layer_chain_fwd_planes)(const void* o, const void* x, 
   P.ldkv = I; P.voff = (long)B * n_q * HW * I;
   P.x1 = P.xn_ff = P.z = P.h = P.xn_attn = nullptr; P.st_ff = P.st_attn = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 96 && I == 128 && M == 256) return launch_chain<96, 128, 256, 256, false>(P, head, tail, st);
-  if (D == 384 && I == 128 && M == 512) return launch_chain<384, 128, 512, 64, false>(P, head, tail, st);
-  wmz_set_error("wmz_layer_chain_fwd_planes: widths (%d, %d, %d) not built", D, I, M);
-  return WMZ_ERR_UNSUPPORTED;
+  return chain_dispatch(P, D, I, M, head, tail, 0, st, "wmz_layer_chain_fwd_planes");
 }
 
 #ifndef WMZ_OP16_F16      // (the training forward: the bfloat16 unit only)
@@ -382,9 +424,7 @@ extern "C" int wmz_layer_chain_fwd_train(const void* o, const void* x, void* x_o
   P.x1 = (bf16_t*)x1; P.xn_ff = (bf16_t*)xn_ff; P.z = (bf16_t*)z; P.h = (bf16_t*)h; P.st_ff = st_ff;
   P.xn_attn = (bf16_t*)xn_attn; P.st_attn = st_attn;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 96 && I == 128 && M == 256) return launch_chain<96, 128, 256, 256, true>(P, head, tail, st);
-  if (D == 384 && I == 128 && M == 512) return launch_chain<384, 128, 512, 64, true>(P, head, tail, st);
-  wmz_set_error("wmz_layer_chain_fwd_train: widths (%d, %d, %d) not built", D, I, M);
-  return WMZ_ERR_UNSUPPORTED;
+  return chain_dispatch(P, D, I, M, head, tail, 1, st, "wmz_layer_chain_fwd_train");
 }
 #endif  // WMZ_OP16_F16
+#endif  // WMZ_CHAIN_GROUP == 0

@@ -16,6 +16,16 @@
 // GELU' is the derivative of the forward's fitted GELU (wmz_gelu_fast_both).  z is fetched by loads the compiler does not track
 // (asm + a counted wait: a tracked load in front of the weight ring makes hipcc drain the ring at its first use).
 #include "wmz_common.h"
+#include "chain_widths.h"
+
+#ifndef WMZ_CHAIN_GROUP
+#define WMZ_CHAIN_GROUP 0         // this unit's group of width triples (chain_widths.h); group 0 also holds the entry points
+#endif
+// a group's launchers: WMZ_OK / an error code, or -1 when the widths are not this group's
+#define CHAIN_BWD_DECLARE_GROUP(g)                                                                                     \
+  int WMZ_CHAIN_CAT(wmz_chain_ff_bwd_group, g)(const void* params, int D, int I, int M, hipStream_t st); \
+  int WMZ_CHAIN_CAT(wmz_chain_qkv_bwd_group, g)(const void* params, int D, int I, hipStream_t st);
+WMZ_CHAIN_ALL_GROUPS(CHAIN_BWD_DECLARE_GROUP)
 
 namespace {
 
@@ -331,6 +341,23 @@ int launch_qkv(const ChainBwdParams& P, hipStream_t st) {
 
 }  // namespace
 
+int WMZ_CHAIN_CAT(wmz_chain_ff_bwd_group, WMZ_CHAIN_GROUP)(const void* params, int D, int I, int M, hipStream_t st) {
+  const ChainBwdParams& P = *static_cast<const ChainBwdParams*>(params);
+#define CHAIN_TRY(d, i, m, mc) if (D == d && I == i && M == m) return launch_ff<d, i, m, mc>(P, st);
+  WMZ_CHAIN_WIDTHS_OF(WMZ_CHAIN_GROUP)(CHAIN_TRY)
+#undef CHAIN_TRY
+  return -1;
+}
+int WMZ_CHAIN_CAT(wmz_chain_qkv_bwd_group, WMZ_CHAIN_GROUP)(const void* params, int D, int I, hipStream_t st) {
+  const ChainBwdParams& P = *static_cast<const ChainBwdParams*>(params);
+  // (triples that share (D, I) name the same instantiation: the first match launches it)
+#define CHAIN_TRY(d, i, m, mc) if (D == d && I == i) return launch_qkv<d, i>(P, st);
+  WMZ_CHAIN_WIDTHS_OF(WMZ_CHAIN_GROUP)(CHAIN_TRY)
+#undef CHAIN_TRY
+  return -1;
+}
+
+#if WMZ_CHAIN_GROUP == 0          // ---- the entry points
 // dy [ntok, D] -> dz [ntok, M], dx1 [ntok, D], dout [ntok, I] (all bf16, row-major).  z / xhat / rstd: what wmz_layer_chain_fwd_train
 // left (xhat: its xn_ff output).  wpack: per hidden chunk of MC (wmz_layer_chain_supported) the pieces of W2[:, chunk]^T then of
 // W1'[chunk, :]^T (W1' = W1 diag(g_ff)), then Wout^T padded to whole slabs, + 2 slabs of readable padding.
@@ -342,9 +369,12 @@ extern "C" int wmz_chain_ff_bwd(const void* dy, const void* z, const void* xhat,
   P.dy = (const bf16_t*)dy; P.z = (const bf16_t*)z; P.xhat = (const bf16_t*)xhat; P.rstd = rstd; P.dz = (bf16_t*)dz;
   P.dx1 = (bf16_t*)dx1; P.dout = (bf16_t*)dout; P.wpack = (const char*)wpack; P.ntok = ntok;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 96 && I == 128 && M == 256) return launch_ff<96, 128, 256, 256>(P, st);
-  if (D == 384 && I == 128 && M == 512) return launch_ff<384, 128, 512, 64>(P, st);
-  wmz_set_error("wmz_chain_ff_bwd: widths (%d, %d, %d) not built", D, I, M);
+  int r = -1;
+#define CHAIN_ASK(g) if (r == -1) r = WMZ_CHAIN_CAT(wmz_chain_ff_bwd_group, g)(&P, D, I, M, st);
+  WMZ_CHAIN_ALL_GROUPS(CHAIN_ASK)
+#undef CHAIN_ASK
+  if (r != -1) return r;
+  wmz_set_error("wmz_chain_ff_bwd: widths (%d, %d, %d) not built (csrc/chain_widths.h)", D, I, M);
   return WMZ_ERR_UNSUPPORTED;
 }
 
@@ -359,8 +389,12 @@ extern "C" int wmz_chain_qkv_bwd(const void* dq, const void* dkv, const void* xh
   P.dq = (const bf16_t*)dq; P.dkv = (const bf16_t*)dkv; P.xhat = (const bf16_t*)xhat; P.rstd = rstd;
   P.dx1 = (bf16_t*)const_cast<void*>(dx1); P.dx = (bf16_t*)dx; P.wpack = (const char*)wpack; P.ntok = ntok;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 96 && I == 128) return launch_qkv<96, 128>(P, st);
-  if (D == 384 && I == 128) return launch_qkv<384, 128>(P, st);
-  wmz_set_error("wmz_chain_qkv_bwd: widths (%d, %d) not built", D, I);
+  int r = -1;
+#define CHAIN_ASK(g) if (r == -1) r = WMZ_CHAIN_CAT(wmz_chain_qkv_bwd_group, g)(&P, D, I, st);
+  WMZ_CHAIN_ALL_GROUPS(CHAIN_ASK)
+#undef CHAIN_ASK
+  if (r != -1) return r;
+  wmz_set_error("wmz_chain_qkv_bwd: widths (%d, %d) not built (csrc/chain_widths.h)", D, I);
   return WMZ_ERR_UNSUPPORTED;
 }
+#endif  // WMZ_CHAIN_GROUP == 0

@@ -1,0 +1,3 @@
+// Group 2 of the chain kernels' width triples (chain_widths.h): the backward launches.
+#define WMZ_CHAIN_GROUP 2
+#include "layer_chain_bwd.hip"

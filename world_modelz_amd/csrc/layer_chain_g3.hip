@@ -1,0 +1,3 @@
+// Group 3 of the chain kernels' width triples (chain_widths.h): the forward launches, bfloat16 unit (inference + training).
+#define WMZ_CHAIN_GROUP 3
+#include "layer_chain.hip"
