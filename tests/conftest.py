@@ -95,3 +95,15 @@ def recorded_calls():
         yield seen
     finally:
         _lib.call = orig
+
+
+@contextlib.contextmanager
+def chain_policy(policy):
+    """config.chain_policy for the block ('always': the chain kernels whatever the token count -- parity tests run small grids,
+    where 'auto' would take the op-by-op path; 'never': the op-by-op path)."""
+    from world_modelz_amd import config
+    prev = config.set_chain_policy(policy)
+    try:
+        yield
+    finally:
+        config.set_chain_policy(prev)

@@ -61,7 +61,7 @@ def test_table_matches_the_library(wmz):
 def test_inference_vs_oracle(wmz, D, I, M, MC):
     """Logits of a 3-layer model on the chain kernel: bfloat16 within the bf16 error of the other fused paths, the precise mode within
     north_star's 1e-3, the last-frame cone bit-identical to the full grid, and the entry points reached are the chain kernel's."""
-    from conftest import recorded_calls
+    from conftest import chain_policy, recorded_calls
     cfg = wmz['config']
     heads, dh = heads_of(D, I)
     torch.manual_seed(D + I + M)
@@ -73,7 +73,7 @@ def test_inference_vs_oracle(wmz, D, I, M, MC):
     ref = oden.denoiser_forward(sd, z, (2, 2, 2), heads)
     m = m.cuda().eval()
     assert wmz['fused'].chain_widths(m.transformer) == (D, I, M, MC)
-    with torch.no_grad():
+    with torch.no_grad(), chain_policy('always'):
         with cfg.compute_dtype(torch.bfloat16), recorded_calls() as seen_b:
             y_b = m(z.cuda())
             cfg.set_last_frame_cone(False)
@@ -94,7 +94,7 @@ def test_inference_vs_oracle(wmz, D, I, M, MC):
 def test_training_step_vs_oracle_autograd(wmz, D, I, M, MC):
     """Loss and every parameter gradient of one training step on the chain kernels (training forward, wmz_chain_ff_bwd,
     wmz_chain_qkv_bwd, batched weight gradients) against the fp32 oracle's autograd and against the op-by-op path."""
-    from conftest import recorded_calls
+    from conftest import chain_policy, recorded_calls
     from oracle import train_step as ots
     cfg = wmz['config']
     heads, dh = heads_of(D, I)
@@ -107,7 +107,7 @@ def test_training_step_vs_oracle_autograd(wmz, D, I, M, MC):
     target = torch.randint(0, C, (2, 16, 16))
     _, _, loss_ref, grads_ref = ots.step_grads(sd, z, target, (1, 2, 2), heads)
     m = m.cuda()
-    with cfg.compute_dtype(torch.bfloat16):
+    with cfg.compute_dtype(torch.bfloat16), chain_policy('always'):
         tr = wmz['train'].DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
         assert tr.chain_packs is not None
         got = {}
@@ -129,6 +129,35 @@ def test_training_step_vs_oracle_autograd(wmz, D, I, M, MC):
     worst_o = max((float((g_c[n] - g_o[n]).norm() / (g_o[n].norm() + 1e-12)), n) for n in g_c)
     print(f'widths ({D}, {I}, {M}): gradients vs oracle {worst[0]:.3e} ({worst[1]}), vs op-by-op {worst_o[0]:.3e} ({worst_o[1]})')
     assert worst[0] < 6e-2 and worst_o[0] < 6e-2, (worst, worst_o)
+
+
+def test_auto_policy_takes_the_chain_kernels_where_they_pay(wmz):
+    """config.chain_policy 'auto' (the default; fused.chain_pays, profiles/r06/time_chain_tokens.txt): a model of 2.6 MB of weights
+    per layer (dim 512 / mlp 1024) runs op by op on 1 536 tokens -- 12 chain workgroups would each stream all of it -- and on the
+    chain kernel on 8 192; a 0.2 MB model (dim 96) takes the chain kernel on both; the precise mode takes the half chain kernel
+    whatever the count (its alternative is the fp32 route).  Same logits either way within the two paths' rounding."""
+    from conftest import chain_policy, recorded_calls
+    cfg, fused = wmz['config'], wmz['fused']
+    assert cfg.get_chain_policy() == 'auto'
+    assert not fused.chain_pays((512, 128, 1024, 32), 1536, False) and fused.chain_pays((512, 128, 1024, 32), 8192, False)
+    assert not fused.chain_pays((384, 128, 512, 64), 8192, True) and fused.chain_pays((384, 128, 512, 64), 16384, True)
+    assert fused.chain_pays((96, 128, 256, 256), 512, True) and fused.chain_pays((96, 128, 256, 256), 512, False)
+    torch.manual_seed(9)
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(8, 16, 16), dim=512, num_classes=100, extents=(1, 1, 1), depth=2, dim_head=128,
+                                          mlp_dim=1024, heads=1).cuda().eval()
+    small, large = torch.randint(0, 101, (2, 3, 16, 16), device='cuda'), torch.randint(0, 101, (4, 8, 16, 16), device='cuda')
+    with torch.no_grad(), cfg.compute_dtype(torch.bfloat16):
+        with recorded_calls() as seen_small:
+            y_small = m(small)
+        with recorded_calls() as seen_large:
+            m(large)
+        with chain_policy('always'):
+            y_small_chain = m(small)
+    assert 'wmz_layer_chain_fwd_planes' not in seen_small and 'wmz_layer_chain_fwd_planes' in seen_large
+    assert rel(y_small_chain, y_small) < 2e-2
+    with torch.no_grad(), cfg.compute_dtype(torch.float16), recorded_calls() as seen_p:
+        m(small)
+    assert 'wmz_layer_chain_fwd_planes_f16' in seen_p
 
 
 def test_reference_test_geometry_forward_backward(wmz):

@@ -122,7 +122,8 @@ def test_default_config_vs_oracle_bf16(wmz):
     z = torch.randint(0, 1025, (2, 6, 16, 16))
     ref = oden.denoiser_forward(sd, z, (3, 3, 3), 1)
     m = m.cuda()
-    with torch.no_grad():
+    from conftest import chain_policy
+    with torch.no_grad(), chain_policy('always'):
         with wmz['config'].compute_dtype(torch.float32):
             y32 = m(z.cuda())
         with wmz['config'].compute_dtype(torch.bfloat16):
@@ -178,15 +179,14 @@ def test_chain_kernel_ragged_grids_vs_oracle(wmz, dim, mlp, shape):
     ref = oden.denoiser_forward(sd, z, (1, 1, 1), 1)
     m = m.cuda().eval()
     assert fused.chain_supported(m.transformer, torch.bfloat16)
+    from conftest import chain_policy, recorded_calls
     with torch.no_grad(), wmz['config'].compute_dtype(torch.bfloat16):
-        y = m(z.cuda())
-        yg = GraphedForward(m, z.cuda())(z.cuda()).clone()
-        orig = fused.chain_supported
-        fused.chain_supported = lambda *a: False
-        try:
+        with chain_policy('always'), recorded_calls() as seen:
+            y = m(z.cuda())
+            yg = GraphedForward(m, z.cuda())(z.cuda()).clone()
+        with chain_policy('never'), recorded_calls() as seen_ops:
             y_ops = m(z.cuda())
-        finally:
-            fused.chain_supported = orig
+    assert 'wmz_layer_chain_fwd_planes' in seen and 'wmz_layer_chain_fwd_planes' not in seen_ops
     assert torch.equal(y, yg)
     e, e_ops = rel(y, ref), rel(y_ops, ref)
     print(f'dim {dim} grid {shape}: chain kernel {e:.3e}, per-op path {e_ops:.3e} vs fp32 oracle')

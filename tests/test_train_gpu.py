@@ -791,7 +791,8 @@ def test_published_widths_train_on_the_chain_kernel_vs_oracle(wmz, dim, mlp):
     _, _, loss_ref, grads_ref = ots.step_grads(sd, z, target, (3, 1, 1), 1)
     m = m.cuda()
     cfg = wmz['config']
-    with cfg.compute_dtype(torch.bfloat16):
+    from conftest import chain_policy
+    with cfg.compute_dtype(torch.bfloat16), chain_policy('always'):
         tr = wmz['train'].DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
         assert tr.chain_packs is not None
         got = {}

@@ -37,6 +37,7 @@ for c in range(cases):
     m = m.cuda()
     tag = f'case {c}: B {B} grid {(S, H, W)} dim {dim} mlp {mlp} {heads}x{dh} depth {depth} ext {ext} C {C} {str(dt)[6:]}'
     try:
+        config.set_chain_policy('always')        # (small grids: 'auto' would send every chain-width case to the op-by-op path)
         with config.compute_dtype(dt):
             tr = DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
             path = 'chain' if tr.chain_packs is not None else ('fused' if fused.supported(m.transformer, dt) and z.numel() % 32 == 0 else 'ops')

@@ -100,6 +100,25 @@ def set_fused_training(on):
 # ... and its backward on the fused per-token backward kernels (csrc/layer_fused_bwd.hip: wmz_ff_fused_bwd /
 # wmz_qkv_fused_bwd; the forward then also saves the feed-forward pre-activation).  Off: the op-by-op backward
 # (backward.py) behind the fused forward.
+# Which per-token path the chain kernels' widths (csrc/chain_widths.h) take in bfloat16: 'auto' = the chain kernels where they pay
+# (fused.chain_pays: their workgroups hold 128 tokens and stream the layer's whole weight set each, so below a token count that
+# grows with the weight bytes the op-by-op GEMMs -- tiled over tokens AND features -- are faster; profiles/r06/time_chain_tokens.txt),
+# 'always' / 'never' for tests and timing tools.  The precise mode always takes the half chain kernels (its alternative is fp32).
+_chain_policy = os.environ.get('WMZ_CHAIN_POLICY', 'auto')
+
+
+def get_chain_policy():
+    return _chain_policy
+
+
+def set_chain_policy(policy):
+    global _chain_policy
+    if policy not in ('auto', 'always', 'never'):
+        raise ValueError("chain policy: 'auto', 'always' or 'never'")
+    prev, _chain_policy = _chain_policy, policy
+    return prev
+
+
 _fused_backward = True
 
 

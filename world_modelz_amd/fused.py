@@ -73,6 +73,22 @@ def chain_supported(transformer, x_dtype, inference=False):
     return x_dtype in ok and hasattr(transformer, 'pos_emb_s') and chain_widths(transformer) is not None
 
 
+def chain_pays(widths, ntok, training):
+    """Whether the chain kernels beat the op-by-op path at ntok tokens (bfloat16; config.chain_policy 'auto').  A chain workgroup
+    holds 128 tokens and streams the layer's whole weight set through its LDS: 3 072 tokens are 24 workgroups on 256 CUs, each
+    moving every weight byte, while the op-by-op GEMMs tile tokens AND features.  Measured crossovers
+    (profiles/r06/time_chain_tokens.txt; weights per layer 0.2 / 0.33 / 1.2 / 2.6 MB at dim 96 / 128 / 384 / 512): forward ~2 000
+    tokens per MB of weights; training step ~10 000 tokens (none below 0.25 MB)."""
+    policy = config.get_chain_policy()
+    if policy != 'auto':
+        return policy == 'always'
+    D, I, M = widths[:3]
+    wbytes = 2 * (4 * D * I + 2 * D * M)
+    if training:
+        return wbytes < (1 << 18) or ntok >= 10240
+    return ntok * 512 >= wbytes
+
+
 def half_attention_ok(transformer, H, W):
     """The half attention unit (csrc/attn_fwd_row16_f16.hip) is built for these planes and heads (csrc/attn_fwd.hip)."""
     dh = {a.fn.to_q.weight.shape[0] // a.fn.heads for a, _ in transformer.layers}

@@ -188,9 +188,11 @@ class Local3dAttentionTransformer(nn.Module):
                 # layer, the embedding fused into the first one
                 return fused.transformer_forward(self, z=img_z)
             if fused.chain_supported(self, get_fused_dtype(), True) and (
-                    get_fused_dtype() != torch.float16 or fused.half_attention_ok(self, img_z.shape[2], img_z.shape[3])):
-                # the reference's published widths: the same fusion on csrc/layer_chain.hip (its half unit in the precise mode,
-                # where the planes are the row attention kernel's; other planes stay on the fp32 route below)
+                    fused.half_attention_ok(self, img_z.shape[2], img_z.shape[3]) if get_fused_dtype() == torch.float16
+                    else fused.chain_pays(fused.chain_widths(self), img_z.numel(), False)):
+                # the width table of csrc/chain_widths.h: the same fusion on csrc/layer_chain.hip -- its half unit in the precise
+                # mode, where the planes are the row attention kernel's (other planes stay on the fp32 route below); in bfloat16
+                # where the token count fills enough 128-token workgroups to beat the op-by-op GEMMs (fused.chain_pays)
                 return fused.transformer_forward_chain(self, img_z)
         else:
             from . import config, fused

@@ -565,7 +565,8 @@ class DenoiserTrainer(_TrainerBase):
                                               target.reshape(-1), chunk=4096, grad_scale=loss_scale)
             mean.backward()                                # (the accumulation scale is inside the fused gradient)
             return rows.view(batch_z.shape[0], -1).mean(dim=1), mean.detach()
-        if batch_z.is_cuda and self.chain_packs is not None and config.get_fused_training():
+        if (batch_z.is_cuda and self.chain_packs is not None and config.get_fused_training()
+                and fused.chain_pays(self.chain_packs.widths, batch_z.numel(), True)):
             tr.check_grid(batch_z)
             last = fused.transformer_forward_chain_train(tr, self.chain_packs, batch_z, last_only=True)    # [B, H, W, D]
             mean, rows = linear_cross_entropy(last.reshape(-1, last.shape[-1]), m.logit_proj.weight, m.logit_proj.bias,
