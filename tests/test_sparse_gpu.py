@@ -113,6 +113,85 @@ def test_position_samplers(wmz):
     assert int(q.max()) < 8 * 16
 
 
+def test_fused_context_draw_vs_reference_law(wmz):
+    """wmz_sparse_draw_context (one launch for sparse_diffusion.py:44-72 sample_time_dependent + :437 gather + :440-449 corruption):
+    the window is the reference's (first frame, frame count: its fp32 formula, restated here on the CPU), the positions are distinct
+    and inside it, targets are the clip's tokens there, the corruption obeys the law at r = 0 / r = 1 / in between, the draw is a
+    function of (seed, rank, counter) and changes with each of them, and over many draws every position of the window is equally
+    likely in every output slot (uniform without replacement, random order)."""
+    import math
+    from world_modelz_amd import train
+    torch.manual_seed(3)
+    S, H, W, n, C = 8, 4, 4, 32, 50
+    HW = H * W
+    B = 5
+    z = torch.randint(0, C, (B, S, H, W), device='cuda')
+    r = torch.tensor([0.0, 0.3, 0.6, 1.0, 0.45])
+    o = torch.tensor([0.0, 0.5, 0.99, 0.2, 0.7])
+    ctr = torch.full((1,), 7, dtype=torch.int64, device='cuda')
+    idx, tok, tgt = train.draw_sparse_context(z, r, n, (S, H, W), C, seed=11, rank=0, counter=ctr, o=o)
+    need = math.ceil(n / HW)
+    frames = torch.floor(need + r.clamp(0, 1) * (S - need + 1)).clamp(max=S - need)
+    first = torch.floor(o.clamp(0, 1 - 1e-5) * (S - frames + 1))
+    for b in range(B):
+        lo, hi = int(first[b]) * HW, (int(first[b]) + int(frames[b])) * HW
+        v = idx[b].tolist()
+        assert len(set(v)) == n and min(v) >= lo and max(v) < hi, (b, lo, hi, min(v), max(v))
+    assert torch.equal(tgt, torch.gather(z.reshape(B, -1), 1, idx))
+    assert torch.equal(tok[0], tgt[0]) and bool((tok[3] == C).all())                      # r = 0: untouched; r = 1: all masked
+    masked = float((tok[2] == C).float().mean())
+    assert 0.3 < masked < 0.9, masked                                                       # r = 0.6 of 32 tokens
+    again = train.draw_sparse_context(z, r, n, (S, H, W), C, seed=11, rank=0, counter=ctr, o=o)
+    assert all(torch.equal(a, b_) for a, b_ in zip((idx, tok, tgt), again))               # a function of (seed, rank, counter)
+    for kw in (dict(seed=12, rank=0), dict(seed=11, rank=1)):
+        other = train.draw_sparse_context(z, r, n, (S, H, W), C, counter=ctr, o=o, **kw)
+        assert not torch.equal(other[0], idx)
+    ctr += 1
+    other = train.draw_sparse_context(z, r, n, (S, H, W), C, seed=11, rank=0, counter=ctr, o=o)
+    assert not torch.equal(other[0], idx)
+    # uniformity: one clip, fixed window (r = 1 -> frames = S - need = 6 of 8, o = 0 -> first = 0): 96 positions, 32 drawn per call
+    reps = 1500
+    zz = z[:1].expand(reps, S, H, W).contiguous()
+    draws = train.draw_sparse_context(zz, torch.ones(reps), n, (S, H, W), C, seed=5, rank=0, o=torch.zeros(reps))[0]   # [reps, n]
+    Wn = 6 * HW
+    assert int(draws.max()) < Wn
+    counts = torch.bincount(draws.reshape(-1), minlength=Wn).float()                      # each position: reps * n / Wn = 500 expected
+    exp = reps * n / Wn
+    assert float((counts - exp).abs().max()) < 6 * math.sqrt(exp), (counts.min(), counts.max(), exp)
+    slot0 = torch.bincount(draws[:, 0], minlength=Wn).float()                             # the first slot alone: reps / Wn = 15.6 expected
+    assert float(slot0.max()) < 45 and float((slot0 == 0).float().mean()) < 0.01         # (random order: no position favoured up front)
+    assert abs(float(draws[:, 0].float().mean()) - (Wn - 1) / 2) < 4 * (Wn / math.sqrt(12 * reps))
+    # the window placement drawn in the kernel (o = None) covers every admissible first frame
+    firsts = train.draw_sparse_context(zz, torch.zeros(reps), n, (S, H, W), C, seed=6, rank=0)[0].min(dim=1).values // HW
+    assert set(firsts.tolist()) == set(range(S - need + 1)), set(firsts.tolist())
+
+
+def test_fused_context_config5_shape_and_unsupported_grids(wmz):
+    """Config 5's own shape (64 x 16 x 16 = 16 384 positions, 512 context tokens: 128 KB of LDS keys), and the shapes the kernel
+    declines (more than 65 536 positions; a grid too short for the narrowest window): there the trainer draws with the torch ops."""
+    from world_modelz_amd import train
+    from world_modelz_amd import _lib as L
+    S, H, W, n, C, B = 64, 16, 16, 512, 8192, 6
+    z = torch.randint(0, C, (B, S, H, W), device='cuda')
+    r = torch.tensor([0.0, 0.2, 0.4, 0.6, 0.8, 1.0])
+    idx, tok, tgt = train.draw_sparse_context(z, r, n, (S, H, W), C, seed=1, rank=0)
+    for b in range(B):
+        assert idx[b].unique().numel() == n
+    assert int(idx.min()) >= 0 and int(idx.max()) < S * H * W
+    assert torch.equal(tgt, torch.gather(z.reshape(B, -1), 1, idx))
+    span = (idx.max(dim=1).values - idx.min(dim=1).values).tolist()
+    assert span[0] < 2 * 256 + 256 and span[-1] > 40 * 256                                 # narrow window at r = 0, wide at r = 1
+    assert L.lib().wmz_sparse_draw_context_supported(64, 256, 512) == 1
+    assert L.lib().wmz_sparse_draw_context_supported(257, 256, 512) == 0                   # > 65 536 positions
+    assert L.lib().wmz_sparse_draw_context_supported(3, 16, 32) == 0                       # 2 * ceil(n / HW) > S
+    with pytest.raises(L.WmzError):
+        train.draw_sparse_context(torch.zeros((1, 257, 16, 16), dtype=torch.int64, device='cuda'), torch.ones(1), 512, (257, 16, 16), C)
+    # a grid four times config 5's (65 536 positions: 32 keys a histogram bin)
+    zb = torch.randint(0, C, (2, 256, 16, 16), device='cuda')
+    ib, _, tb = train.draw_sparse_context(zb, torch.tensor([1.0, 0.5]), n, (256, 16, 16), C, seed=2, rank=0)
+    assert ib[0].unique().numel() == n and ib[1].unique().numel() == n and torch.equal(tb, torch.gather(zb.reshape(2, -1), 1, ib))
+
+
 def test_sparse_training_step_vs_oracle_autograd(wmz):
     """SparseDenoiserTrainer (minecraft/sparse_diffusion.py:398-467): one fp32 step on the reference capture's model -- the
     chunked linear + cross-entropy (no [R, C] logits in memory) and the dense-attention backward against torch.autograd over
@@ -241,3 +320,13 @@ def test_sparse_graphed_training_step(wmz):
         idx = tg.sample_positions(B, r, z.device)
         out = tg.train_step(z, r=r, indices=idx)                 # injected positions: eager path
         assert out[0] == out[0] and tg.step_count == 13
+        # the captured step draws its context by ONE launch (wmz_sparse_draw_context); with the knob off the torch ops of
+        # sparse_diffusion.py do (the same law from torch's device generator): same training behaviour
+        assert tg.fused_context(z)
+        mt = make()
+        tt = train.SparseDenoiserTrainer(mt, C, num_context=n, lr=3e-4, warmup=0, distributed=False)
+        tt.use_fused_context = False
+        tt.enable_graph(z)
+        lt = [tt.train_step(z, r=r)[0] for _ in range(12)]
+        print('[config-5 graphed] torch-op prologue loss', [f'{v:.3f}' for v in lt])
+        assert lt[-1] < lt[0] and abs(lg[-1] - lt[-1]) < 0.15 * lt[0]

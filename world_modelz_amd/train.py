@@ -83,6 +83,36 @@ def corrupt_tokens(tokens, r, num_embeddings, generator=None, seed=None, rank=No
     return out, target
 
 
+def draw_sparse_context(z, r, num_context, shape, num_embeddings, generator=None, seed=None, rank=None, counter=None, o=None):
+    """Config 5's step prologue by ONE launch (wmz_sparse_draw_context: minecraft/sparse_diffusion.py:44-72 sample_time_dependent,
+    :437 gather, :440-449 perturbation & masking): z [B, S, H, W] token clips, r [B] noise levels -> (indices, corrupted tokens,
+    target), each [B, num_context].  o [B]: the window placements (else drawn in the kernel).  Random stream as corrupt_tokens:
+    (seed, rank, per-call counter -- on the device when `counter` is given: hipGraph replays)."""
+    global _corrupt_calls
+    assert z.is_cuda and z.dtype == torch.int64
+    B = z.shape[0]
+    S, H, W = (int(v) for v in shape)
+    zf = z.reshape(B, -1)
+    assert zf.shape[1] == S * H * W and zf.stride(1) == 1
+    n = int(num_context)
+    dev = z.device
+    indices = torch.empty((B, n), dtype=torch.int64, device=dev)
+    tokens, target = torch.empty_like(indices), torch.empty_like(indices)
+    r = r.reshape(-1).to(dev, torch.float32).contiguous()
+    o = None if o is None else o.reshape(-1).to(dev, torch.float32).contiguous()
+    if seed is None:
+        seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+    rank = _dp_rank() if rank is None else int(rank)
+    if counter is None:
+        _corrupt_calls += 1
+        stream_id = (rank << 40) | (_corrupt_calls & ((1 << 40) - 1))
+    else:
+        stream_id = rank << 40
+    L.call('wmz_sparse_draw_context', L.ptr(zf), zf.stride(0), L.ptr(r), L.ptr(o), L.ptr(indices), L.ptr(tokens), L.ptr(target),
+           B, S, H * W, n, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_id, L.ptr(counter), L.stream())
+    return indices, tokens, target
+
+
 from .graph import gc_quiet as _gc_quiet
 
 class _LinearCrossEntropy(torch.autograd.Function):
@@ -620,6 +650,7 @@ class SparseDenoiserTrainer(_TrainerBase):
         if sampling_type not in ('uniform', 'neighbors'):
             raise ValueError('Specified sampling_type not supported')          # sparse_diffusion.py:408
         self.sampling_type = sampling_type
+        self.use_fused_context = True      # (False: positions / gather / corruption by the torch ops of sparse_diffusion.py)
 
     def sample_positions(self, B, r, device):
         from .sparse_diffusion import sample_flat_positions, sample_time_dependent
@@ -646,10 +677,22 @@ class SparseDenoiserTrainer(_TrainerBase):
         """The device side of one step on static inputs (captured by enable_graph): position sampling (torch's capture-aware
         device RNG), gather, corruption from the in-kernel Philox stream counted on the device, forward / backward."""
         B = z.shape[0]
+        if self.fused_context(z):
+            # one launch instead of ~45 graph nodes (window arithmetic on B-element tensors, top-k, sort, gather, corruption)
+            indices, tokens, target = draw_sparse_context(z, r, self.num_context, self.model.shape, self.C, seed=self._g_seed,
+                                                          rank=self.rank, counter=self._g_ctr)
+            return self.forward_backward(tokens, indices, target)
         indices = self.sample_positions(B, r, z.device)
         gathered = torch.gather(z.reshape(B, -1), 1, indices)
         tokens, target = corrupt_tokens(gathered, r, self.C, seed=self._g_seed, rank=self.rank, counter=self._g_ctr)
         return self.forward_backward(tokens, indices, target)
+
+    def fused_context(self, z):
+        """The step prologue runs as wmz_sparse_draw_context: the reference's default sampler ('neighbors'), a grid the kernel
+        holds (<= 65 536 positions, <= 512 drawn), `self.use_fused_context` left on."""
+        S, H, W = self.model.shape
+        return (self.use_fused_context and self.sampling_type == 'neighbors' and z.is_cuda
+                and bool(L.lib().wmz_sparse_draw_context_supported(int(S), int(H) * int(W), self.num_context)))
 
     def train_step(self, batch_z, r=None, indices=None, generator=None):
         """batch_z: [B,S,H,W] token clips (the frozen VQ-AE's output).  Returns (mean loss, grad norm)."""
@@ -658,11 +701,15 @@ class SparseDenoiserTrainer(_TrainerBase):
         B = batch_z.shape[0]
         if r is None:
             r = self.sampler.sample(B, generator=self.sampler_gen)
-        if indices is None:
-            indices = self.sample_positions(B, r, batch_z.device)
         self.arena.zero_grad()
-        gathered = torch.gather(batch_z.reshape(B, -1), 1, indices)                  # :437
-        tokens, target = corrupt_tokens(gathered, r, self.C, generator, rank=self.rank)
+        if indices is None and self.fused_context(batch_z):
+            indices, tokens, target = draw_sparse_context(batch_z, r, self.num_context, self.model.shape, self.C, generator,
+                                                          rank=self.rank)
+        else:
+            if indices is None:
+                indices = self.sample_positions(B, r, batch_z.device)
+            gathered = torch.gather(batch_z.reshape(B, -1), 1, indices)              # :437
+            tokens, target = corrupt_tokens(gathered, r, self.C, generator, rank=self.rank)
         per_sample, mean = self.forward_backward(tokens, indices, target)
         sq = self.optimizer_step()
         self.sampler.update_with_losses(r, per_sample)
