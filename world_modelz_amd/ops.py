@@ -474,6 +474,11 @@ def wgrad_join():
         del ent[3][:]
 
 
+def wgrad_join_at_end():
+    """Called inside an autograd pass: the pass ends with wgrad_join() (for side-stream launches forked BEFORE the pass began)."""
+    torch.autograd.Variable._execution_engine.queue_callback(wgrad_join)
+
+
 def wgrad_reset():
     """Forget every queued / deferred side-stream launch and the bookkeeping around them: called before a step is captured and
     after a capture or a backward pass failed, so that nothing stale is flushed into the next step."""
@@ -497,20 +502,22 @@ def wgrad_side_wait(stream):
             stream.wait_stream(ent[0])
 
 
-def _wgrad_side_enter(device, tensors):
+def _wgrad_side_enter(device, tensors, join_later=False):
     """None (launch on the current stream), or the side-stream entry: forked from the current stream, `tensors` (allocated on
-    the compute stream) marked as in use there."""
+    the compute stream) marked as in use there.  join_later: the caller is NOT inside an autograd pass (a gradient produced by a
+    forward: train._LinearCrossEntropy) and promises that one follows, whose first node calls wgrad_join_at_end()."""
     from . import config
     # (hipGraph capture only: in eager launches the step is host-bound and the extra stream / event calls cost more than the
     #  overlap returns -- config 5: 4.8 -> 5.9 ms per step eager, 4.06 -> 3.38 as a graph)
     if (_arena_depth == 0 or _side_blocked > 0 or not config.get_wgrad_stream()
             or not torch.cuda.is_current_stream_capturing()):
         return None
-    try:
-        # (one callback per launch, each a no-op once the first has joined: no state that a failed pass could leave behind)
-        torch.autograd.Variable._execution_engine.queue_callback(wgrad_join)
-    except RuntimeError:                # not inside an autograd pass (a block backward called by hand): stay on the stream
-        return None
+    if not join_later:
+        try:
+            # (one callback per launch, each a no-op once the first has joined: no state that a failed pass could leave behind)
+            torch.autograd.Variable._execution_engine.queue_callback(wgrad_join)
+        except RuntimeError:            # not inside an autograd pass (a block backward called by hand): stay on the stream
+            return None
     device = torch.device(device)
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
@@ -534,7 +541,7 @@ def _side_workspace(ent, device, floats):
     return w
 
 
-def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, overwrite=False, then=None):
+def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, overwrite=False, then=None, join_later=False):
     """dw[N,K] += dc^T @ a' ; dbias[N] += colsum(dc) (overwrite: = instead of +=).  dw / dbias fp32 (two-stage reduction
     through a per-device workspace: deterministic, no float atomics).  then(): follow-up work on the result, issued behind the
     launch on whichever stream it went to."""
@@ -548,7 +555,7 @@ def linear_wgrad(dc, a, dw, dbias=None, ln=None, ln_stats=None, gelu_in=False, o
         g, b = ln
         mean, rstd = ln_stats
     need = L.lib().wmz_linear_wgrad_workspace_floats(M, N, K, dt)
-    side = _wgrad_side_enter(dc.device, (dc, a, g, b, mean, rstd, dbias))
+    side = _wgrad_side_enter(dc.device, (dc, a, g, b, mean, rstd, dbias), join_later)
     if side is None:
         ws = _workspace(dc.device, need)
         L.call('wmz_linear_wgrad_ws', L.ptr(dc), ldc, L.ptr(a), lda, L.ptr(dw), L.ptr(dbias), M, N, K, L.ptr(g), L.ptr(b),

@@ -115,6 +115,10 @@ def draw_sparse_context(z, r, num_context, shape, num_embeddings, generator=None
 
 from .graph import gc_quiet as _gc_quiet
 
+CE_DIRECT = True      # development knobs of _LinearCrossEntropy (tools/time_train_step.py): parameter gradients straight into the arena;
+CE_SIDE = None        # ... and, in a captured step, on the weight-gradient side branch (None: as the caller asks)
+
+
 class _LinearCrossEntropy(torch.autograd.Function):
     """mean CrossEntropy(x W^T + b, target) WITHOUT the [R, C] logits in memory (config 5: R = 3072 rows per GPU x C = 8192
     classes x fp32 = 100 MB, 800 MB for the global batch on one device): the rows are walked in chunks whose logits stay
@@ -122,7 +126,7 @@ class _LinearCrossEntropy(torch.autograd.Function):
     dgrad and wgrad -- so the gradient w.r.t. x, W and b is complete when the forward returns; backward() only scales it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, target, chunk, grad_scale):
+    def forward(ctx, x, w, b, target, chunk, grad_scale, grad_on, side_branch):
         from . import backward as Bk
         R, K = x.shape
         C = w.shape[0]
@@ -132,9 +136,11 @@ class _LinearCrossEntropy(torch.autograd.Function):
         dx = torch.empty_like(x) if R > chunk else None
         wbuf, bbuf = getattr(w, '_wmz_grad', None), getattr(b, '_wmz_grad', None) if b is not None else None
         # (the arena shortcut is only taken when a backward will follow: under no_grad, or for callers that do not ask for the
-        #  parameter gradients, nothing may be accumulated into the arena behind autograd's back)
-        direct = (wbuf is not None and (b is None or bbuf is not None) and torch.is_grad_enabled()
-                  and ctx.needs_input_grad[1])
+        #  parameter gradients, nothing may be accumulated into the arena behind autograd's back.  grad_on is the CALLER's grad mode:
+        #  inside Function.forward autograd has switched it off -- round 6: read here, it was always False and the shortcut never
+        #  taken: zero fills of [C, K] and [C], three scalings and two accumulations per step, 12 graph nodes at config 5)
+        direct = (CE_DIRECT and wbuf is not None and (b is None or bbuf is not None) and bool(grad_on) and ctx.needs_input_grad[1]
+                  and (b is None or ctx.needs_input_grad[2]))
         dw = wbuf if direct else torch.zeros(w.shape, dtype=torch.float32, device=x.device)
         db = (bbuf if direct else torch.zeros(C, dtype=torch.float32, device=x.device)) if b is not None else None
         # d(grad_scale * mean loss) / d(row loss): the scale of gradient accumulation (main.py:274-278) is applied HERE, the
@@ -153,7 +159,15 @@ class _LinearCrossEntropy(torch.autograd.Function):
                 dx = ops.linear_dgrad(d, wT)               # one chunk (the denoiser's last frame): no staging copy
             else:
                 dx[r0:r1] = ops.linear_dgrad(d, wT)
-            ops.linear_wgrad(d, xs, dw, db)
+            if direct and (side_branch if CE_SIDE is None else CE_SIDE):
+                # straight into the arena, and -- in a captured step -- on the weight-gradient side branch: nothing of the forward
+                # or of the backward's chain reads it (joined when the backward pass ends: backward() below asks for that).  The
+                # caller's choice: it pays where the step is a chain of small launches with a side branch of its own (config 5:
+                # 2.94 -> 2.79 ms); beside chip-filling launches the fork and join cost more than they hide (config 4: 1.79 -> 1.91)
+                with ops.arena_fill():
+                    ops.linear_wgrad(d, xs, dw, db, join_later=True)
+            else:
+                ops.linear_wgrad(d, xs, dw, db)
         ctx.direct = direct
         ctx.params = (w, b)
         ctx.save_for_backward(dx, None if direct else dw, None if (direct or db is None) else db)
@@ -165,20 +179,22 @@ class _LinearCrossEntropy(torch.autograd.Function):
         dx, dw, db = ctx.saved_tensors
         w, b = ctx.params
         if ctx.direct:
+            ops.wgrad_join_at_end()
             # the arena already holds grad_scale * d(mean loss)/dW, and dx is scaled the same way: `mean.backward()` is called
             # as it is on this path (g == 1 by contract: a scale belongs in grad_scale, where it reaches every gradient)
             for p in (w, b):
                 ready = getattr(p, '_wmz_ready', None) if p is not None else None
                 if ready is not None:
                     ready()
-            return dx, None, None, None, None, None
-        return dx * g.to(dx.dtype), dw * g, (db * g if db is not None else None), None, None, None
+            return dx, None, None, None, None, None, None, None
+        return dx * g.to(dx.dtype), dw * g, (db * g if db is not None else None), None, None, None, None, None
 
 
-def linear_cross_entropy(x, w, b, target, chunk=1024, grad_scale=1.0):
+def linear_cross_entropy(x, w, b, target, chunk=1024, grad_scale=1.0, side_branch=False):
     """(mean loss, per-row loss [R], detached) of CrossEntropy(x W^T + b, target) over rows x: [R, K].  The gradients it
-    produces are those of grad_scale * mean loss (gradient accumulation): call `.backward()` on the returned mean as it is."""
-    return _LinearCrossEntropy.apply(x, w, b, target, chunk, grad_scale)
+    produces are those of grad_scale * mean loss (gradient accumulation): call `.backward()` on the returned mean as it is.
+    side_branch: in a captured step the parameter gradients leave on the weight-gradient side stream (ops.side_branch)."""
+    return _LinearCrossEntropy.apply(x, w, b, target, chunk, grad_scale, torch.is_grad_enabled(), bool(side_branch))
 
 
 class _CrossEntropyRows(torch.autograd.Function):
@@ -669,7 +685,7 @@ class SparseDenoiserTrainer(_TrainerBase):
         # (config 5: 3 072 rows per GPU = ONE chunk -- 100 MB of fp32 logits is nothing on a 288 GB card, and a 1 024-row chunk
         #  leaves the 8 192-deep dgrad on 64 workgroups)
         mean, rows = linear_cross_entropy(h.reshape(-1, h.shape[-1]), m.logit_proj.weight, m.logit_proj.bias, target.reshape(-1),
-                                          chunk=4096, grad_scale=loss_scale)
+                                          chunk=4096, grad_scale=loss_scale, side_branch=True)
         mean.backward()                                    # (the accumulation scale is inside the fused gradient)
         return rows.view(tokens.shape[0], -1).mean(dim=1), mean.detach()
 
