@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 111
+#define WMZ_VERSION 112
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1,
        WMZ_F16 = 2 /* IEEE half activations / MFMA operands: the PRECISE fused inference mode (wmz_local3d_attn_fwd* on the
@@ -201,6 +201,25 @@ int wmz_vq_argmin_screened(const float* x, long ldx, const float* codebook, int6
 /* decode (vq.py:89-94): out[n,:] = codebook[idx[n],:]; out in `dtype` (row stride ldo). */
 int wmz_vq_gather(const int64_t* idx, const float* codebook, void* out, long ldo, int N, int C, int E,
                   int dtype, void* stream);
+/* The tail of VectorQuantizerEMA.forward (vq.py:67 commitment loss, :70 straight-through estimator, :72-73 perplexity) as two
+ * launches: st [N, Ep] = x + (q - x) in out_dtype (columns E..Ep zero: the decoder's first conv wants channels % 8 == 0),
+ * loss[0] = mean (q - x)^2, perplexity[0] = exp(-sum p log(p + 1e-10)), p = counts / N.  x, q fp32 [N, E] contiguous, counts fp32
+ * [C]; partial: wmz_loss_partials_workspace_floats() floats of workspace (per-workgroup sums, added in a fixed order: deterministic).
+ * wmz_vq_tail_bwd: d_x [N, E] (in_dtype) = d_st[:, :E] (st_dtype, row stride Ep; NULL: 0) + g_loss[0] * 2 / (N E) * (x - q)
+ * (g_loss: device scalar, NULL: 0). */
+long wmz_loss_partials_workspace_floats(void);
+int wmz_vq_tail_fwd(const float* x, const float* q, const float* counts, void* st, float* partial, float* loss,
+                    float* perplexity, long N, int E, int Ep, int C, int out_dtype, void* stream);
+int wmz_vq_tail_bwd(const void* d_st, const float* x, const float* q, const float* g_loss, void* d_x, long N, int E, int Ep,
+                    int in_dtype, int st_dtype, void* stream);
+/* The reconstruction loss of train_vqae.py:139-150 / :264-271 (kind 0 SmoothL1 with beta 1, 1 MSE, 2 L1; reduction 'mean') read
+ * from the decoder's NHWC output in place: y [B, HW, Cp] in `dtype` (channels C..Cp are padding), target [B, C, HW] fp32 (NCHW
+ * frames); loss[0] fp32.  wmz_recon_loss_bwd: d_y [B, HW, Cp] = g_loss[0] (device scalar, NULL: 1) / (B HW C) * loss'(y - target),
+ * zero in the padding channels -- the operand of the last conv's gradients, no NCHW copy either way. */
+int wmz_recon_loss_fwd(const void* y, const float* target, float* partial, float* loss, long B, long HW, int C, int Cp,
+                       int kind, int dtype, void* stream);
+int wmz_recon_loss_bwd(const void* y, const float* target, const float* g_loss, void* d_y, long B, long HW, int C, int Cp,
+                       int kind, int dtype, void* stream);
 /* statistics of forward (vq.py:35-36, :43-46): counts[c] += #{n: idx[n]==c}, dw[c,:] += sum x[n,:],
  * sqerr[c] += sum |codebook[c]-x[n]|^2.  Caller zeroes counts/dw (sqerr accumulates into accumulated_error). */
 int wmz_vq_ema_stats(const float* x, long ldx, const int64_t* idx, const float* codebook, float* counts,

@@ -389,6 +389,18 @@ class _TorchVqOps:
             sqerr.index_add_(0, idx, (cb[idx] - x).pow(2).sum(-1))
 
     @staticmethod
+    def vq_tail(inp, flat, q, counts, out_dtype, Ep):
+        """vq.py:67-73 (commitment loss, straight-through estimator, perplexity): what ops.vq_tail launches on the GPU."""
+        qv = q.view_as(inp).to(inp.dtype)
+        loss = torch.nn.functional.mse_loss(qv.detach(), inp)
+        st = inp + (qv - inp).detach()
+        p = counts / flat.shape[0]
+        ppl = torch.exp(-torch.sum(p * torch.log(p + 1e-10)))
+        if Ep != st.shape[-1]:
+            st = torch.nn.functional.pad(st, (0, Ep - st.shape[-1]))
+        return st.to(out_dtype), loss, ppl
+
+    @staticmethod
     def vq_ema_update(embedding, cluster_size, activation_count, counts, dw, decay, eps):
         C = embedding.shape[-2]                                     # vq.py:44, :53-65 (laplace smoothing, batch sum / EMA count);
         activation_count += counts                                  # one latent's slices of the buffers, as the module hands them over

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16, WMZ_F16 = 0, 1, 2
-EXPECTED_VERSION = 111      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
+EXPECTED_VERSION = 112      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -56,6 +56,7 @@ SIGNATURES = {
     'wmz_debug_attn_timestamps': [c_void_p],
     'wmz_debug_fused_knobs': [c_int],
     'wmz_debug_conv_knobs': [c_int, c_int],
+    'wmz_debug_stamp': [c_void_p, c_int, c_void_p],
     'wmz_layer_fused_fwd': [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p],
     'wmz_operands_refresh': [c_void_p] * 7 + [c_int, c_void_p],
     'wmz_conv_operands_refresh': [c_void_p] * 6 + [c_int, c_int, c_void_p],
@@ -116,6 +117,11 @@ SIGNATURES = {
     'wmz_embed_indexed_bwd': [c_void_p] * 7 + [c_long] + [c_int] * 6 + [c_void_p],
     'wmz_corrupt_tokens': [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
                            ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p],
+    'wmz_loss_partials_workspace_floats': [],
+    'wmz_vq_tail_fwd': [c_void_p] * 7 + [c_long, c_int, c_int, c_int, c_int, c_void_p],
+    'wmz_vq_tail_bwd': [c_void_p] * 5 + [c_long, c_int, c_int, c_int, c_int, c_void_p],
+    'wmz_recon_loss_fwd': [c_void_p] * 4 + [c_long, c_long, c_int, c_int, c_int, c_int, c_void_p],
+    'wmz_recon_loss_bwd': [c_void_p] * 4 + [c_long, c_long, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_sparse_draw_context_supported': [c_int, c_int, c_int],
     'wmz_sparse_draw_context': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p],

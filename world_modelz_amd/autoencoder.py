@@ -445,8 +445,9 @@ class SimpleResidualDecoder(nn.Module):
         layers += [conv3x3(in_channels, out_channels)]
         self.decoder_stack = nn.Sequential(*layers)
 
-    def forward_nhwc(self, h):
-        """[B,h,w,E] latents (NHWC, C % 8 == 0) -> logical NCHW image."""
+    def forward_nhwc(self, h, raw=False):
+        """[B,h,w,E] latents (NHWC, C % 8 == 0) -> logical NCHW image (raw: the last conv's NHWC output as it is, its channels
+        padded to a multiple of 8 -- what ops.recon_loss reads)."""
         dt = get_compute_dtype()
         mods = list(self.decoder_stack)
         grad = _grad_path(h, self)
@@ -454,6 +455,12 @@ class SimpleResidualDecoder(nn.Module):
             h = _conv_g(h, mods[0]) if grad else _conv(h, mods[0], dt)
             for m in mods[1:-1]:
                 h = m.forward_nhwc(h, dt)
+            if raw:
+                # (the padded output as the kernel wrote it: no slice copy here, no zero-padding launch in its backward)
+                last = mods[-1]
+                if grad:
+                    return _Conv2dFn.apply(h, last.weight, last.bias, last.stride[0], last.padding[0], None, False)[0]
+                return _conv(h, last, dt)
             y = _conv_g(h, mods[-1]) if grad else _conv(h, mods[-1], dt)
             return _to_nchw_view(y)[:, :mods[-1].out_channels]      # (the operand's output channels are padded to 8)
 

@@ -279,3 +279,14 @@ extern "C" int wmz_embed_pos3d_fwd(const int64_t* z, const float* emb, const flo
   WMZ_LAUNCH_CHECK("wmz_embed_pos3d_fwd");
   return WMZ_OK;
 }
+
+// ---- development probe (csrc/wmz_debug.h): a wall-clock marker between the phases of a captured step
+namespace {
+__global__ void stamp_kernel(long long* buf, int slot) { buf[slot] = (long long)wall_clock64(); }
+}  // namespace
+extern "C" int wmz_debug_stamp(void* buf, int slot, void* stream) {
+  WMZ_REQUIRE(buf != nullptr && slot >= 0, "wmz_debug_stamp: bad arguments");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)buf, slot);
+  WMZ_LAUNCH_CHECK("wmz_debug_stamp");
+  return WMZ_OK;
+}

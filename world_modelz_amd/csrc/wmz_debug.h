@@ -27,6 +27,11 @@ int wmz_debug_conv_knobs(int skew, int dbg);
  * instead of the LDS-DMA ring (A/B timing; same results). */
 int wmz_debug_linear_knobs(int dma);
 
+/* Timeline probe for captured steps: one thread writes the device's constant-rate wall clock (wall_clock64: 100 MHz) into
+ * buf[slot] (device int64) when the launch executes on `stream` -- a marker between the phases of a hipGraph replay, where a
+ * profiler's own per-node cost (rocprofv3 --kernel-trace: ~9 us a node) would distort the very overlap under study. */
+int wmz_debug_stamp(void* buf, int slot, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

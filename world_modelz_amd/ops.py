@@ -201,6 +201,90 @@ def vq_gather(idx, codebook, dtype=torch.float32):
     return out.reshape(*idx.shape, E)
 
 
+_loss_partials = {}
+
+
+def _partials(device):
+    """fp32 workspace of the loss kernels' per-workgroup sums (one per device; the launches of a step run in stream order)."""
+    w = _loss_partials.get(device)
+    if w is None:
+        w = _loss_partials[device] = torch.empty(int(L.lib().wmz_loss_partials_workspace_floats()), dtype=torch.float32, device=device)
+    return w
+
+
+class _VqTail(torch.autograd.Function):
+    """vq.py:67-73 behind the nearest-code search: commitment loss, straight-through estimator, perplexity (wmz_vq_tail_fwd /
+    _bwd).  inp: the quantiser's input as the caller holds it (any float dtype, [..., E]); flat / q: fp32 [N, E] (the input's fp32
+    rows the search ran on, the gathered codebook rows); counts fp32 [C].  -> (straight-through tensor [..., Ep] in out_dtype,
+    loss, perplexity)."""
+
+    @staticmethod
+    def forward(ctx, inp, flat, q, counts, out_dtype, Ep):
+        N, E = flat.shape
+        dev = flat.device
+        st = torch.empty(inp.shape[:-1] + (Ep,), dtype=out_dtype, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ppl = torch.empty((), dtype=torch.float32, device=dev)
+        L.call('wmz_vq_tail_fwd', L.ptr(flat), L.ptr(q), L.ptr(counts), L.ptr(st), L.ptr(_partials(dev)), L.ptr(loss), L.ptr(ppl),
+               N, E, Ep, counts.numel(), L.dtype_code(out_dtype), L.stream())
+        ctx.save_for_backward(flat, q)
+        ctx.meta = (inp.shape, inp.dtype, Ep, out_dtype)
+        ctx.mark_non_differentiable(ppl)
+        return st, loss, ppl
+
+    @staticmethod
+    def backward(ctx, d_st, d_loss, _d_ppl):
+        flat, q = ctx.saved_tensors
+        shape, in_dtype, Ep, out_dtype = ctx.meta
+        N, E = flat.shape
+        if d_st is not None:
+            d_st = d_st.contiguous()
+            assert d_st.dtype == out_dtype
+        if d_loss is not None:
+            d_loss = d_loss.reshape(1).float()
+        dx = torch.empty(shape, dtype=in_dtype, device=flat.device)
+        L.call('wmz_vq_tail_bwd', L.ptr(d_st), L.ptr(flat), L.ptr(q), L.ptr(d_loss), L.ptr(dx), N, E, Ep, L.dtype_code(in_dtype),
+               L.dtype_code(out_dtype), L.stream())
+        return dx, None, None, None, None, None
+
+
+def vq_tail(inp, flat, q, counts, out_dtype, Ep):
+    return _VqTail.apply(inp, flat, q, counts, out_dtype, int(Ep))
+
+
+RECON_LOSS_KINDS = {'SmoothL1': 0, 'MSE': 1, 'MAE': 2, 'L1': 2}
+
+
+class _ReconLoss(torch.autograd.Function):
+    """mean loss(y[..., :C] - target) with y the decoder's NHWC output [B, H, W, Cp] (padding channels ignored) and target the
+    NCHW fp32 frames [B, C, H, W] (wmz_recon_loss_fwd / _bwd: train_vqae.py:139-150)."""
+
+    @staticmethod
+    def forward(ctx, y, target, kind):
+        B, H, W, Cp = y.shape
+        C = target.shape[1]
+        assert y.is_contiguous() and target.is_contiguous() and target.dtype == torch.float32 and target.shape == (B, C, H, W)
+        loss = torch.empty((), dtype=torch.float32, device=y.device)
+        L.call('wmz_recon_loss_fwd', L.ptr(y), L.ptr(target), L.ptr(_partials(y.device)), L.ptr(loss), B, H * W, C, Cp, kind,
+               L.dtype_code(y.dtype), L.stream())
+        ctx.save_for_backward(y, target)
+        ctx.kind = kind
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        y, target = ctx.saved_tensors
+        B, H, W, Cp = y.shape
+        dy = torch.empty_like(y)
+        L.call('wmz_recon_loss_bwd', L.ptr(y), L.ptr(target), L.ptr(g.reshape(1).float()), L.ptr(dy), B, H * W, target.shape[1], Cp,
+               ctx.kind, L.dtype_code(y.dtype), L.stream())
+        return dy, None, None
+
+
+def recon_loss(y_nhwc, target_nchw, kind):
+    return _ReconLoss.apply(y_nhwc, target_nchw, RECON_LOSS_KINDS[kind])
+
+
 def sample_tokens(logits, top_k, alphas, mask_token, last_frame, denoised, counter, seed, last_mask=None):
     """wmz_sample_tokens_dev: logits fp32 [R, C]; last_frame: the [B, H, W] int64 view batch_z[:, -1] the tokens are written
     into in place; denoised int64 [R]; alphas fp32 [n]; counter int64 [1] (device); last_mask uint8 [R] or None."""

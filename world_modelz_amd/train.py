@@ -746,7 +746,7 @@ class VqaeTrainer(_AdamState):
                  latent_loss_weight=0.01, vq_reuse_interval=500, steps_per_epoch=None, distributed=None):
         if loss_fn not in self.LOSSES:
             raise RuntimeError('Unsupported loss function type specified.')     # train_vqae.py:271
-        self.model, self.loss_fn = model, self.LOSSES[loss_fn]
+        self.model, self.loss_fn, self.loss_name = model, self.LOSSES[loss_fn], loss_fn
         self.latent_loss_weight, self.vq_reuse_interval = latent_loss_weight, vq_reuse_interval
         self.arena = FlatArena(model)
         self.m = torch.zeros_like(self.arena.flat_param)
@@ -766,6 +766,7 @@ class VqaeTrainer(_AdamState):
         for mod in model.modules():
             if isinstance(mod, torch.nn.BatchNorm2d) and mod.weight is not None:
                 mod.weight._wmz_single_use = True
+        self.fused_losses = True       # (False: the reconstruction as an NCHW fp32 tensor and torch's loss on it)
         self._conv_ops = {}            # compute dtype -> _cast.ConvOperands (every conv layer's GEMM operands, one launch a step)
 
     def _refresh_conv_operands(self):
@@ -789,8 +790,13 @@ class VqaeTrainer(_AdamState):
     def _forward_backward(self, batch):
         """model -> reconstruction + commitment loss -> backward (gradients land in the arena).  Returns the four scalars of the
         step as ONE device tensor [loss, reconstruction loss, latent loss, perplexity]."""
-        recon, latent_loss, perplexity = self.model(batch)
-        r_loss = self.loss_fn(recon, batch)
+        if (self.fused_losses and batch.is_cuda and batch.dtype == torch.float32 and hasattr(self.model, 'training_losses')
+                and self.loss_name in ops.RECON_LOSS_KINDS):
+            # the reconstruction loss on the decoder's NHWC output in place (one launch pair forward, one backward)
+            r_loss, latent_loss, perplexity = self.model.training_losses(batch, self.loss_name)
+        else:
+            recon, latent_loss, perplexity = self.model(batch)
+            r_loss = self.loss_fn(recon, batch)
         loss = r_loss + self.latent_loss_weight * latent_loss
         loss.backward()
         return torch.stack([loss.detach(), r_loss.detach(), latent_loss.detach().reshape(()), perplexity.detach().reshape(())])

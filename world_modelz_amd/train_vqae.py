@@ -28,10 +28,25 @@ class VqAutoEncoder(nn.Module):
             q = torch.nn.functional.pad(q, (0, _pad8(E) - E))
         return self.decoder.forward_nhwc(q.to(get_compute_dtype()).contiguous()).float()
 
+    def _quantized_nhwc(self, x):
+        """frames -> (straight-through latents in the decoder's operand dtype, channel-padded for its first conv; commitment loss;
+        perplexity): the encoder's NHWC output goes to the quantiser as it is, whose tail kernel writes the decoder's operand."""
+        h = self.encoder.forward_nhwc(x)
+        st, _, latent_loss, perplexity = self.vq.forward_fused(h, get_compute_dtype(), True)
+        return st, latent_loss, perplexity
+
     def forward(self, x):
-        h = self._latents(x)
-        quantized, _, latent_loss, perplexity = self.vq.forward(h)
-        return self._decode_latents(quantized), latent_loss, perplexity
+        st, latent_loss, perplexity = self._quantized_nhwc(x)
+        return self.decoder.forward_nhwc(st).float(), latent_loss, perplexity
+
+    def training_losses(self, x, loss_kind):
+        """(reconstruction loss, commitment loss, perplexity) of train_vqae.py:139-150 without the reconstruction as an NCHW fp32
+        tensor: the loss (ops.recon_loss: 'SmoothL1' | 'MSE' | 'MAE' | 'L1', reduction mean) reads the decoder's NHWC output in
+        place and its backward writes that layout.  x: NCHW fp32 frames on the GPU."""
+        from . import ops
+        st, latent_loss, perplexity = self._quantized_nhwc(x)
+        y = self.decoder.forward_nhwc(st, raw=True)
+        return ops.recon_loss(y, x.contiguous(), loss_kind), latent_loss, perplexity
 
     def encode(self, x):
         h = self._latents(x)

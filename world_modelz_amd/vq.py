@@ -123,6 +123,12 @@ class VectorQuantizerEMA(nn.Module):
         return rows.reshape(*indices.shape, self.embedding_dim)
 
     def forward(self, input):
+        return self.forward_fused(input, input.dtype, False)
+
+    def forward_fused(self, input, out_dtype, pad8):
+        """forward() with the straight-through tensor written in `out_dtype` and, with pad8, its channels zero-padded to a multiple
+        of 8 -- what the decoder's first conv consumes (VqAutoEncoder: no cast / pad launches between the two); `input` may be the
+        encoder's activation dtype (the search runs on its fp32 rows either way)."""
         flat = self._flat(input)                                              # [N, L, E]
         N, C, n_lat = flat.shape[0], self.num_embeddings, self.num_latents
         fd = flat.detach()
@@ -144,12 +150,20 @@ class VectorQuantizerEMA(nn.Module):
                 torch.distributed.all_reduce(dw, group=group)
             for l in range(n_lat):
                 ops.vq_ema_update(self.embedding[l], self.cluster_size[l], self.activation_count[l], counts[l], dw[l], self.decay, self.eps)
+        E = self.embedding_dim
+        Ep = -(-E // 8) * 8 if pad8 else E
+        if n_lat == 1 and out_dtype in (torch.float32, torch.bfloat16) and input.dtype in (torch.float32, torch.bfloat16):
+            # :67 commitment loss, :70 straight-through estimator, :72-73 perplexity: two launches (ops.vq_tail), one in the backward
+            quantized, commitment_loss, perplexity = ops.vq_tail(input, fd[:, 0], q_l[0], local_counts[0], out_dtype, Ep)
+            return quantized, encodings, commitment_loss, perplexity
         quantized = (q_l[0] if n_lat == 1 else torch.stack(q_l, 1)).view_as(input).to(input.dtype)
         commitment_loss = F.mse_loss(quantized.detach(), input)               # :67
         quantized = input + (quantized - input).detach()                      # straight-through (:70)
         avg_probs = local_counts / N                                          # == encodings.mean(0) (:72), this rank's batch
         perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10) / self.num_latents))
-        return quantized, encodings, commitment_loss, perplexity
+        if Ep != E:
+            quantized = F.pad(quantized, (0, Ep - E))
+        return quantized.to(out_dtype), encodings, commitment_loss, perplexity
 
     def reuse_inactive(self):
         """Host-driven, rare (every 500 steps, train_vqae.py:160-164): kept in torch (reference :96-107)."""
