@@ -930,3 +930,40 @@ def test_two_rank_training_on_one_card_equals_the_union_batch_in_fp32(tmp_path):
     steps must equal those of ONE process stepping on the union batch to 1e-5 (gradient of the mean loss = mean of the shards'
     gradients: the exactness of the sharding + all-reduce + 1/world in the AdamW pass, not just replica-vs-replica identity)."""
     _two_rank_training(tmp_path, 'gloo', 29545, dtype='float32', atol=1e-5)
+
+
+@pytest.mark.parametrize('C,dim,mlp,dtype', [(37, 256, 256, torch.bfloat16), (1001, 256, 256, torch.bfloat16), (37, 64, 96, torch.float32),
+                                             (1003, 64, 96, torch.bfloat16), (45, 96, 256, torch.bfloat16)])
+def test_vocabulary_that_is_no_multiple_of_8(wmz, C, dim, mlp, dtype):
+    """The reference takes any --num_embeddings (main.py:404); the GEMM kernels' granule is 8 elements.  The fused linear +
+    cross-entropy (default / chain widths) and the op-by-op logits backward run a class count that is no multiple of 8 on
+    zero-padded operands (padding classes at probability exactly 0): logits, loss and every gradient of one training step against
+    the fp32 oracle's autograd."""
+    from conftest import chain_policy
+    from oracle import denoiser as oden
+    from oracle import train_step as ots
+    torch.manual_seed(C + dim)
+    heads = 1 if dim != 64 else 2
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 16, 16), dim=dim, num_classes=C, extents=(1, 1, 1), depth=2,
+                                          dim_head=128 if dim != 64 else 32, mlp_dim=mlp, heads=heads)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    z = torch.randint(0, C + 1, (2, 3, 16, 16))
+    target = torch.randint(0, C, (2, 16, 16))
+    ref_logits = oden.denoiser_forward(sd, z, (1, 1, 1), heads)
+    _, _, loss_ref, grads_ref = ots.step_grads(sd, z, target, (1, 1, 1), heads)
+    m = m.cuda()
+    cfg = wmz['config']
+    with cfg.compute_dtype(dtype), chain_policy('always'):
+        with torch.no_grad():
+            y = m(z.cuda())
+        assert y.shape == (2, 16, 16, C)
+        tr = wmz['train'].DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
+        tr.arena.zero_grad()
+        _, mean = tr.forward_backward(z.cuda(), target.cuda())
+    e_y = rel(y, ref_logits)
+    worst = max((float((p.grad.detach().cpu() - grads_ref[n]).norm() / (grads_ref[n].norm() + 1e-12)), n) for n, p in m.named_parameters())
+    print(f'C = {C}, dim {dim} {str(dtype)[6:]}: logits {e_y:.2e}, loss diff {abs(float(mean) - float(loss_ref)):.1e}, worst gradient {worst[0]:.2e} ({worst[1]})')
+    f32 = dtype == torch.float32
+    assert e_y < (1e-5 if f32 else 1e-2)
+    assert abs(float(mean) - float(loss_ref)) < (1e-5 if f32 else 2e-2)
+    assert worst[0] < (2e-4 if f32 else 6e-2), worst

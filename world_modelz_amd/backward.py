@@ -220,6 +220,19 @@ def embed_backward(ctx, dx):
 def linear_backward(ctx, dy):
     x, w, b = ctx.saved_tensors
     dt = x.dtype
+    N = w.shape[0]
+    if N % 8:
+        # an output width that is no multiple of 8 (a vocabulary the reference accepts, main.py:404 --num_embeddings): the
+        # gradient GEMMs run on zero-padded columns / weight rows, the padding's gradient rows are dropped
+        import torch.nn.functional as F
+        pad = -N % 8
+        dyc = F.pad(dy.to(dt), (0, pad)).contiguous()
+        xc = x.contiguous()
+        gw = torch.zeros((N + pad, w.shape[1]), dtype=torch.float32, device=x.device)
+        gb = torch.zeros(N + pad, dtype=torch.float32, device=x.device) if b is not None else None
+        ops.linear_wgrad(dyc, xc, gw, gb)
+        dx = ops.linear_dgrad(dyc, _cast.operand((w,), dt, 'wTpad8', lambda a: F.pad(a, (0, 0, 0, pad)).t()))
+        return dx.reshape(x.shape), gw[:N], (gb[:N] if gb is not None else None), None
     dyc = dy.to(dt).contiguous()                                   # fused CE hands it over in dt already; torch's CE in fp32
     xc = x.contiguous()
     if b is not None:

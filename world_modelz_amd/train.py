@@ -131,7 +131,19 @@ class _LinearCrossEntropy(torch.autograd.Function):
         R, K = x.shape
         C = w.shape[0]
         dt = x.dtype
-        w_c, wT = _cast.operand(w, dt), Bk._wt(w, dt, 'wT')
+        Cp = -(-C // 8) * 8
+        if Cp != C:
+            # a class count that is no multiple of 8 (the GEMMs' 16-byte granule: the reference takes any --num_embeddings): the
+            # operands carry Cp - C padding classes -- zero weight rows and a bias of -1e30, whose probability is exactly 0, so
+            # loss, log-sum-exp and every gradient of the real classes are untouched and the padding's gradient rows are zero
+            pad = Cp - C
+            w_c = _cast.operand((w,), dt, 'ce_pad', lambda a: F.pad(a, (0, 0, 0, pad)))
+            wT = _cast.operand((w,), dt, 'ce_padT', lambda a: F.pad(a, (0, 0, 0, pad)).t())
+            b_c = (_cast.operand((b,), torch.float32, 'ce_padb', lambda a: F.pad(a, (0, pad), value=-1e30)) if b is not None
+                   else torch.cat([torch.zeros(C, device=x.device), torch.full((pad,), -1e30, device=x.device)]))
+        else:
+            w_c, wT = _cast.operand(w, dt), Bk._wt(w, dt, 'wT')
+            b_c = None if b is None else b.detach()
         loss = torch.empty(R, dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if R > chunk else None
         wbuf, bbuf = getattr(w, '_wmz_grad', None), getattr(b, '_wmz_grad', None) if b is not None else None
@@ -140,9 +152,9 @@ class _LinearCrossEntropy(torch.autograd.Function):
         #  inside Function.forward autograd has switched it off -- round 6: read here, it was always False and the shortcut never
         #  taken: zero fills of [C, K] and [C], three scalings and two accumulations per step, 12 graph nodes at config 5)
         direct = (CE_DIRECT and wbuf is not None and (b is None or bbuf is not None) and bool(grad_on) and ctx.needs_input_grad[1]
-                  and (b is None or ctx.needs_input_grad[2]))
-        dw = wbuf if direct else torch.zeros(w.shape, dtype=torch.float32, device=x.device)
-        db = (bbuf if direct else torch.zeros(C, dtype=torch.float32, device=x.device)) if b is not None else None
+                  and (b is None or ctx.needs_input_grad[2]) and Cp == C)
+        dw = wbuf if direct else torch.zeros((Cp, K), dtype=torch.float32, device=x.device)
+        db = (bbuf if direct else torch.zeros(Cp, dtype=torch.float32, device=x.device)) if b is not None else None
         # d(grad_scale * mean loss) / d(row loss): the scale of gradient accumulation (main.py:274-278) is applied HERE, the
         # parameter gradients are final when forward() returns
         ones = torch.full((min(chunk, R),), float(grad_scale) / R, dtype=torch.float32, device=x.device)
@@ -150,11 +162,11 @@ class _LinearCrossEntropy(torch.autograd.Function):
         for r0 in range(0, R, chunk):
             r1 = min(R, r0 + chunk)
             xs = x[r0:r1]
-            lg = ops.linear_fwd(xs, w_c, bias=None if b is None else b.detach(), out_f32=True)
+            lg = ops.linear_fwd(xs, w_c, bias=b_c, out_f32=True)
             lse = torch.empty(r1 - r0, dtype=torch.float32, device=x.device)
-            d = torch.empty((r1 - r0, C), dtype=dt, device=x.device)
+            d = torch.empty((r1 - r0, Cp), dtype=dt, device=x.device)
             L.call('wmz_ce_fwd_bwd', L.ptr(lg), lg.stride(0), L.ptr(target[r0:r1]), L.ptr(loss[r0:r1]), L.ptr(lse), L.ptr(ones),
-                   L.ptr(d), r1 - r0, C, L.dtype_code(dt), L.stream())
+                   L.ptr(d), r1 - r0, Cp, L.dtype_code(dt), L.stream())
             if r0 == 0 and r1 == R:
                 dx = ops.linear_dgrad(d, wT)               # one chunk (the denoiser's last frame): no staging copy
             else:
@@ -168,6 +180,9 @@ class _LinearCrossEntropy(torch.autograd.Function):
                     ops.linear_wgrad(d, xs, dw, db, join_later=True)
             else:
                 ops.linear_wgrad(d, xs, dw, db)
+        if Cp != C:
+            dw = dw[:C]
+            db = db[:C] if db is not None else None
         ctx.direct = direct
         ctx.params = (w, b)
         ctx.save_for_backward(dx, None if direct else dw, None if (direct or db is None) else db)
