@@ -674,3 +674,49 @@ def test_fused_sampler_loop_runs_the_whole_frame_on_the_device(wmz):
     assert not all(torch.equal(a, b) for a, b in zip(frames, frames_next))    # no reseed -> the generator moved on: fresh noise
     assert not torch.equal(fa[0], fb[0]) and not torch.equal(fc[0], fd[0]) and torch.equal(fc[0], fe[0])
     assert torch.equal(zf[:, 0], z[:, 2]) and torch.equal(zf[:, 1], frames[0]) and torch.equal(zf[:, 2], frames[1])
+
+
+@pytest.mark.parametrize('heads,dh,dtype', [(3, 20, torch.float32), (2, 12, torch.bfloat16), (1, 100, torch.bfloat16), (5, 4, torch.float32)])
+def test_dim_head_that_is_no_multiple_of_8(wmz, heads, dh, dtype):
+    """The reference takes any --dim_head (main.py:181); the attention kernels' granule is 8 elements.  Local3dAttention pads every
+    head of its projections with zeros to the next multiple (and corrects the softmax scale in to_q): module output, the attention
+    core on projected tensors, and a model's logits and training gradients against the fp32 oracle."""
+    from oracle import attention as oattn
+    from oracle import train_step as ots
+    torch.manual_seed(heads * 100 + dh)
+    dim, ext = 64, (1, 2, 2)
+    cfg = wmz['config']
+    f32 = dtype == torch.float32
+    # --- the module and its core
+    att = wmz['l3a'].Local3dAttention(ext, dim, heads=heads, dim_head=dh)
+    x, q = torch.randn(2, 3, 8, 8, dim), torch.randn(2, 3, 8, 8, dim)
+    params = {k: v.detach().clone() for k, v in att.state_dict().items()}
+    kk, vv, qq = (torch.randn(2, 3, 8, 8, heads * dh) for _ in range(3))
+    ref_core = oattn.local_attention(kk, vv, qq, ext, heads)
+    att = att.cuda()
+    with cfg.compute_dtype(dtype), torch.no_grad():
+        core = att.local_attention(kk.cuda(), vv.cuda(), qq.cuda())
+    assert core.shape[-1] == dh and rel(core.reshape(ref_core.shape), ref_core) < (1e-5 if f32 else 1e-2)
+    # --- a model: logits and one training step's gradients
+    C = 48
+    m = wmz['main'].VqVideoDiffusionModel(data_shape=(3, 8, 8), dim=dim, num_classes=C, extents=ext, depth=2, dim_head=dh, mlp_dim=96,
+                                          heads=heads)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    z = torch.randint(0, C + 1, (2, 3, 8, 8))
+    target = torch.randint(0, C, (2, 8, 8))
+    ref_logits = oden.denoiser_forward(sd, z, ext, heads)
+    _, _, loss_ref, grads_ref = ots.step_grads(sd, z, target, ext, heads)
+    m = m.cuda()
+    with cfg.compute_dtype(dtype):
+        with torch.no_grad():
+            y = m(z.cuda())
+        from world_modelz_amd import train
+        tr = train.DenoiserTrainer(m, C, lr=1e-3, warmup=0, max_steps=100, distributed=False)
+        tr.arena.zero_grad()
+        _, mean = tr.forward_backward(z.cuda(), target.cuda())
+    worst = max((float((p.grad.detach().cpu() - grads_ref[n]).norm() / (grads_ref[n].norm() + 1e-12)), n) for n, p in m.named_parameters())
+    print(f'{heads} heads of {dh} {str(dtype)[6:]}: core ok, logits {rel(y, ref_logits):.2e}, loss diff {abs(float(mean) - float(loss_ref)):.1e}, '
+          f'worst gradient {worst[0]:.2e} ({worst[1]})')
+    assert rel(y, ref_logits) < (1e-5 if f32 else 1e-2)
+    assert abs(float(mean) - float(loss_ref)) < (1e-5 if f32 else 2e-2)
+    assert worst[0] < (3e-4 if f32 else 6e-2), worst

@@ -330,3 +330,25 @@ def test_sparse_graphed_training_step(wmz):
         lt = [tt.train_step(z, r=r)[0] for _ in range(12)]
         print('[config-5 graphed] torch-op prologue loss', [f'{v:.3f}' for v in lt])
         assert lt[-1] < lt[0] and abs(lg[-1] - lt[-1]) < 0.15 * lt[0]
+
+
+def test_sparse_model_dim_head_off_the_granule(wmz):
+    """minecraft/transformer.py's Attention with a dim_head that is no multiple of 8 (3 heads of 20): logits and gradients against
+    the fp32 oracle (the heads run zero-padded: transformer.py::_head_padded)."""
+    from oracle import denoiser as oden
+    torch.manual_seed(8)
+    shape, C, heads, dh = (4, 4, 4), 30, 3, 20
+    m = wmz['sd'].VqSparseDiffusionModel(shape=shape, dim=48, num_classes=C, depth=2, dim_head=dh, mlp_dim=64, heads=heads)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = torch.randint(0, C + 1, (2, 32))
+    idx = torch.stack([torch.randperm(64)[:32] for _ in range(2)])
+    ref = oden.sparse_denoiser_forward(leaves, x, idx, shape, heads)
+    ref.square().mean().backward()
+    m = m.cuda()
+    with wmz['config'].compute_dtype(torch.float32):
+        y = m(x.cuda(), idx.cuda())
+        y.square().mean().backward()
+    assert rel(y, ref) < 1e-5
+    worst = max((rel(p.grad, leaves[n].grad), n) for n, p in m.named_parameters() if leaves[n].grad is not None)
+    print(f'sparse model, 3 heads of 20: logits {rel(y, ref):.2e}, worst gradient {worst[0]:.2e} ({worst[1]})')
+    assert worst[0] < 3e-4, worst

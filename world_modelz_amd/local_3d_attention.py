@@ -104,21 +104,40 @@ class Local3dAttention(nn.Module):
         q = x if same else Fw._as_compute(q)
         if residual is not None:
             residual = x if res_same else Fw._as_compute(residual)
+        wq, wk, wv, bv = self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_v.bias
         if isinstance(self.to_out, nn.Identity):
             wo = bo = None
         else:
             wo, bo = self.to_out[0].weight, self.to_out[0].bias
+        if (wq.shape[0] // self.heads) % 8 and wo is not None:
+            wq, wk, wv, bv, wo = self._head_padded()
         if self.dropout > 0 and self.training and wo is not None:
             # to_out = Linear -> Dropout (local_3d_attention.py:50-53): the fused block without its residual, the mask and the
             # residual add as torch device ops behind it (not a fused path: the reference default and every published run use 0)
-            y = Fw.attention_block(x, q, ln, self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_v.bias,
-                                   wo, bo, None, self.extents, self.heads)
+            y = Fw.attention_block(x, q, ln, wq, wk, wv, bv, wo, bo, None, self.extents, self.heads)
             y = torch.nn.functional.dropout(y, self.dropout, True)
             y = y if residual is None else y + residual
             return y.reshape(q.shape[:-1] + (y.shape[-1],))
-        y = Fw.attention_block(x, q, ln, self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_v.bias,
-                               wo, bo, residual, self.extents, self.heads, out_f32=out_f32)
+        y = Fw.attention_block(x, q, ln, wq, wk, wv, bv, wo, bo, residual, self.extents, self.heads, out_f32=out_f32)
         return y.reshape(q.shape[:-1] + (y.shape[-1],))
+
+    def _head_padded(self):
+        """A dim_head that is no multiple of 8 (the kernels' 16-byte granule; the reference takes any --dim_head): every head of
+        the projections zero-padded to the next multiple -- the padding contributes 0 to q . k and carries zeros through v and
+        to_out's padded columns -- with the kernels' 1 / sqrt(padded width) corrected in to_q.  Built by torch ops on the
+        parameters (a rare path): autograd carries the gradients back through the padding."""
+        F = torch.nn.functional
+        h = self.heads
+        dh = self.to_q.weight.shape[0] // h
+        pad = -dh % 8
+        dim = self.to_q.weight.shape[1]
+
+        def rows(w):
+            return F.pad(w.view(h, dh, -1), (0, 0, 0, pad)).reshape(h * (dh + pad), -1)
+        wq = rows(self.to_q.weight) * ((dh + pad) / dh) ** 0.5
+        bv = F.pad(self.to_v.bias.view(h, dh), (0, pad)).reshape(-1)
+        wo = F.pad(self.to_out[0].weight.view(dim, h, dh), (0, pad)).reshape(dim, h * (dh + pad))
+        return wq, rows(self.to_k.weight), rows(self.to_v.weight), bv, wo
 
     def forward(self, x, q):
         return self._run(x, q, None, None, out_f32=q.dtype == torch.float32).to(q.dtype)
@@ -131,9 +150,18 @@ class Local3dAttention(nn.Module):
         [(b s h w), heads, 1, dim_head]."""
         from . import ops
         dt_in = q.dtype
+        dh = q.shape[-1] // self.heads
+        pad = -dh % 8
+        if pad:                                            # (a head width off the 8-element granule: see _head_padded)
+            F = torch.nn.functional
+
+            def heads_padded(t, scale=1.0):
+                return F.pad(t.reshape(t.shape[:-1] + (self.heads, dh)) * scale, (0, pad)).reshape(t.shape[:-1] + (-1,))
+            q, k, v = heads_padded(q, ((dh + pad) / dh) ** 0.5), heads_padded(k), heads_padded(v)
         k, v, q = Fw._as_compute(k), Fw._as_compute(v), Fw._as_compute(q)
         out, _, _ = ops.local3d_attention_fwd(q, k, v, self.extents, self.heads)
-        return out.reshape(-1, self.heads, 1, out.shape[-1] // self.heads).to(dt_in)
+        out = out.reshape(-1, self.heads, 1, out.shape[-1] // self.heads)
+        return (out[..., :dh] if pad else out).to(dt_in)
 
 
 class Local3dAttentionTransformer(nn.Module):

@@ -35,7 +35,26 @@ class Attention(nn.Module):
         if residual is not None:
             residual = x if res_same else Fw._as_compute(residual)
         wo, bo = (None, None) if isinstance(self.to_out, nn.Identity) else (self.to_out[0].weight, self.to_out[0].bias)
-        return Fw.dense_attention_block(x, ln, self.to_qkv.weight, wo, bo, residual, self.heads)
+        wqkv = self.to_qkv.weight
+        if (wqkv.shape[0] // (3 * self.heads)) % 8 and wo is not None:
+            wqkv, wo = self._head_padded()
+        return Fw.dense_attention_block(x, ln, wqkv, wo, bo, residual, self.heads)
+
+    def _head_padded(self):
+        """A dim_head off the kernels' 8-element granule: every head of q | k | v zero-padded to the next multiple, the softmax
+        scale of the padded width corrected in the q rows, to_out's columns padded to match (local_3d_attention.py::_head_padded:
+        torch ops on the parameters, gradients through autograd)."""
+        F = torch.nn.functional
+        h = self.heads
+        w = self.to_qkv.weight
+        dh = w.shape[0] // (3 * h)
+        pad = -dh % 8
+        dim = w.shape[1]
+        w3 = F.pad(w.view(3, h, dh, dim), (0, 0, 0, pad))                       # [3, h, dh + pad, dim]
+        scale = torch.ones(3, 1, 1, 1, device=w.device, dtype=w.dtype)
+        scale[0] = ((dh + pad) / dh) ** 0.5
+        wo = F.pad(self.to_out[0].weight.view(dim, h, dh), (0, pad)).reshape(dim, h * (dh + pad))
+        return (w3 * scale).reshape(3 * h * (dh + pad), dim), wo
 
     def _run_dropout(self, x, ln, residual):
         """Training with dropout > 0 (transformer.py:44-62: softmax -> Dropout on the attention PROBABILITIES -> . V -> to_out ->
