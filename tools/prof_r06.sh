@@ -23,6 +23,17 @@ cp $(ls /tmp/p_vqaeg/*/*_kernel_stats.csv | head -1) $O/vqae_train_graph_kernel_
 # config 5
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_sparse -- python3 tools/prof_sparse.py > $O/sparse.log 2>&1 || true
 cp $(ls /tmp/p_sparse/*/*_kernel_stats.csv | head -1) $O/sparse_kernel_stats.csv || true
+# the captured steps as timelines (one steady-state replay cut at the AdamW launch; torch / runtime glue kernels marked)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_sg -- python3 tools/prof_sparse_graph.py 12 > $O/sparse_graph.log 2>&1 || true
+python3 tools/trace_step.py $(ls /tmp/p_sg/*/*_kernel_trace.csv | head -1) adamw $O/sparse_graph_timeline.txt || true
+cp $(ls /tmp/p_sg/*/*_kernel_stats.csv | head -1) $O/sparse_graph_kernel_stats.csv || true
+python3 tools/trace_step.py $(ls /tmp/p_vqaeg/*/*_kernel_trace.csv | head -1) adamw $O/vqae_train_graph_timeline.txt || true
+for w in config4 dim96; do
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tg_$w -- python3 tools/prof_train_graph.py $w 8 > $O/train_graph_$w.log 2>&1 || true
+  python3 tools/trace_step.py $(ls /tmp/p_tg_$w/*/*_kernel_trace.csv | head -1) adamw $O/train_graph_timeline_$w.txt || true
+done
+python3 tools/stamp_vqae_step.py > $O/stamp_vqae_step.txt 2>&1 || true
+python3 tools/stamp_sparse_step.py > $O/stamp_sparse_step.txt 2>&1 || true
 echo STATS_DONE
 # PMC passes over the conv kernels (separate passes; --kernel-trace only beside --pmc): fabric bytes and issue counters
 python3 tools/pmc_quick.py FETCH_SIZE conv -- python3 tools/prof_encode.py 3 > $O/conv_fetch.log 2>&1
