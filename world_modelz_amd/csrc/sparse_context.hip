@@ -82,6 +82,7 @@ __global__ __launch_bounds__(SC_THREADS) void sparse_context_kernel(ScParams P) 
     const float first = floorf(o * ((float)P.S - frames + 1.f));
     win[0] = (int)first;
     win[1] = (int)frames;
+    sel[0] = SC_BINS - 1;                                      // (overwritten by the scan: the window holds >= n positions)
     sel[1] = 0;
   }
   for (int i = tid; i < SC_BINS; i += SC_THREADS) hist[i] = 0;
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(SC_THREADS) void sparse_context_kernel(ScParams P) 
   // ---- the n smallest: positions, targets, corrupted tokens (the law and the stream layout of corrupt_kernel, loss.hip)
   const float rb = P.r[b];
   for (int i = tid; i < P.n; i += SC_THREADS) {
-    const long pos = (long)(unsigned)cand[i] + (long)first * P.HW;
+    unsigned wpos = (unsigned)cand[i];
+    if (wpos >= (unsigned)Wn) wpos = 0;                        // (never: a sort padding entry would mean fewer than n candidates)
+    const long pos = (long)wpos + (long)first * P.HW;
     const int64_t tok = P.z[b * P.clip_stride + pos];
     unsigned c[4];
     sc_philox4((unsigned long long)b * P.n + i, P.seed, stream, c);
