@@ -268,11 +268,18 @@ class LossAwareSamplerEma:
         return w / (self.n - 1)
 
     def update_with_losses(self, ts, losses):
-        ts, losses = ts.detach().view(-1).cpu(), losses.detach().view(-1).float().cpu()
-        idx = (ts * self.n).long().clamp(0, self.n - 1)
-        self._counts.scatter_add_(0, idx, torch.ones_like(idx))
-        for i, j in enumerate(idx.tolist()):
-            self._weights[j] = self._weights[j] * self.alpha + float(losses[i]) * (1 - self.alpha)
+        # On numpy views of the two state tensors, in the reference's float32 arithmetic and order (a bucket hit twice in one batch
+        # is updated twice).  This runs between a step's read-back and the next step's launch, with the GPU idle: as element-wise
+        # torch indexing it cost 140 us per step at 6 samples (tools/time_replay_host.py), 5 % of config 5's step.
+        import numpy as np
+        ts = ts.detach().reshape(-1).to('cpu', torch.float32).numpy()
+        ls = losses.detach().reshape(-1).to('cpu', torch.float32).tolist()
+        idx = np.clip((ts * np.float32(self.n)).astype(np.int64), 0, self.n - 1).tolist()      # (.long(): truncation, like astype)
+        w, c = self._weights.numpy(), self._counts.numpy()
+        a = np.float32(self.alpha)
+        for j, l in zip(idx, ls):
+            c[j] += 1
+            w[j] = w[j] * a + np.float32(l * (1 - self.alpha))
 
 
 def lr_at(step, base_lr, warmup, max_steps):
@@ -499,6 +506,7 @@ class _TrainerBase(_AdamState):
         nb = example_batch.shape[0]
         self._g_in = torch.zeros(nb + 3, dtype=torch.float32, device=dev)
         self._g_in_host = torch.zeros(nb + 3, dtype=torch.float32).pin_memory()
+        self._g_in_np = self._g_in_host.numpy()
         self._g_r = self._g_in[:nb]
         # the per-call part of the corruption's Philox stream id: graph replays count on the device, eager calls on the host
         # (_corrupt_calls).  Bit 39 keeps the two ranges apart, so a run that mixes replays with eager fallbacks (another batch
@@ -566,8 +574,9 @@ class _TrainerBase(_AdamState):
         ev = getattr(self, '_g_in_ev', None)
         if ev is not None:
             ev.synchronize()               # the last copy out of the pinned buffer is done (a no-op behind a step's read-back)
-        h[:B] = r.to(torch.float32)
-        h[B], h[B + 1], h[B + 2] = lr, bc1, math.sqrt(bc2)
+        hn = self._g_in_np                                 # (a view of the pinned buffer: element writes without tensor indexing --
+        hn[:B] = r.detach().reshape(-1).to('cpu', torch.float32).numpy()     # this runs with the GPU idle between two replays)
+        hn[B], hn[B + 1], hn[B + 2] = lr, bc1, math.sqrt(bc2)
         self._g_in.copy_(h, non_blocking=True)
         if ev is None:
             ev = self._g_in_ev = torch.cuda.Event()
@@ -835,6 +844,8 @@ class VqaeTrainer(_AdamState):
         self.model.train()
         self._g_x = example_batch.contiguous().clone()
         self._g_hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._g_hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()       # (staged through pinned memory: an asynchronous copy)
+        self._g_hyper_np, self._g_hyper_ev = self._g_hyper_host.numpy(), None
         self._g_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         from . import config as _cfg
         side = _cfg.shared_stream('warmup')
@@ -859,7 +870,13 @@ class VqaeTrainer(_AdamState):
         self.step_count += 1
         bc1 = 1.0 - self.betas[0] ** self.step_count
         bc2 = 1.0 - self.betas[1] ** self.step_count
-        self._g_hyper.copy_(torch.tensor([lr, bc1, math.sqrt(bc2)], dtype=torch.float32), non_blocking=True)
+        if self._g_hyper_ev is not None:
+            self._g_hyper_ev.synchronize()     # the last copy out of the pinned buffer is done (a no-op behind a step's read-back)
+        self._g_hyper_np[:] = (lr, bc1, math.sqrt(bc2))
+        self._g_hyper.copy_(self._g_hyper_host, non_blocking=True)
+        if self._g_hyper_ev is None:
+            self._g_hyper_ev = torch.cuda.Event()
+        self._g_hyper_ev.record()
 
     def _graph_body(self):
         a = self.arena
