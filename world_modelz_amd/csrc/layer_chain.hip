@@ -337,8 +337,14 @@ int launch_chain(const ChainParams& P, int head, int tail, hipStream_t st) {
 int CHAIN_GROUP_FN(WMZ_CHAIN_GROUP)(const void* params, int D, int I, int M, int head, int tail, int train, hipStream_t st) {
   const ChainParams& P = *static_cast<const ChainParams*>(params);
 #ifdef WMZ_OP16_F16
-#define CHAIN_TRY(d, i, m, mc) \
-  if (D == d && I == i && M == m) return train ? WMZ_ERR_UNSUPPORTED : launch_chain<d, i, m, mc, false>(P, head, tail, st);
+#define CHAIN_TRY(d, i, m, mc)                                                                            \
+  if (D == d && I == i && M == m) {                                                                       \
+    if (train) {                                                                                          \
+      wmz_set_error("wmz_layer_chain_fwd_train: the half unit is inference only (precise mode)");         \
+      return WMZ_ERR_UNSUPPORTED;                                                                         \
+    }                                                                                                     \
+    return launch_chain<d, i, m, mc, false>(P, head, tail, st);                                           \
+  }
 #else
 #define CHAIN_TRY(d, i, m, mc)    \
   if (D == d && I == i && M == m) \
