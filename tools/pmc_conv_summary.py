@@ -1,4 +1,4 @@
-"""Summarise the conv kernels' PMC passes (tools/prof_r05.sh: conv_fetch / conv_write / conv_issue logs of tools/pmc_quick.py) as
+"""Summarise the conv kernels' PMC passes (tools/prof_r06.sh: conv_fetch / conv_write / conv_issue logs of tools/pmc_quick.py) as
 JSON: fabric bytes per launch (FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md HBM section) and the issue counters' ratios.
 
     python3 tools/pmc_conv_summary.py gpurun_out/prof_r05 profiles/r05/pmc_conv.json"""

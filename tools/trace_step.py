@@ -1,5 +1,5 @@
 """One steady-state step out of a rocprofv3 --kernel-trace csv of graph replays: the step boundary is found from a kernel that runs once
-a step (the AdamW launch), the step = the kernels between its last two occurrences -> the timeline (tools/trace_timeline.py format),
+a step (the AdamW launch), the step = the kernels between its last two occurrences -> the timeline (start offset, duration, gap to the previous end, queue, grid),
 and a summary of the torch / runtime glue kernels (at::native, rocclr) in it.
     python3 tools/trace_step.py <kernel_trace.csv> [marker substring = adamw] [out.txt]"""
 import csv, sys
