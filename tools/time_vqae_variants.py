@@ -23,6 +23,10 @@ def marked(orig):
 for name in sys.argv[1:] or ['product', 'noside', 'marker', 'product', 'noside', 'marker']:
     config.set_wgrad_stream(0 if name == 'noside' else 1)
     ops.WGRAD_BATCH = int(name[5:]) if name.startswith('batch') else 6          # batch<k>: k weight gradients to a side-branch launch
+    ops._wgrad_side.clear()
+    if name.startswith('prio'):                                                 # prio-1 / prio0: the side stream's priority (-1 = high)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        ops._wgrad_side[dev] = [torch.cuda.Stream(device=dev, priority=int(name[4:])), False, None, []]
     ops._issue_pending_conv = marked(orig_conv) if name == 'marker' else orig_conv
     torch.manual_seed(7)
     ae = VqAutoEncoder(embedding_dim=64, num_embeddings=1024, downscale_steps=2, hidden_planes=128).cuda()
