@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WMZ_VERSION 112
+#define WMZ_VERSION 113
 
 enum { WMZ_F32 = 0, WMZ_BF16 = 1,
        WMZ_F16 = 2 /* IEEE half activations / MFMA operands: the PRECISE fused inference mode (wmz_local3d_attn_fwd* on the
@@ -638,14 +638,23 @@ int wmz_corrupt_tokens_dev(const int64_t* z_last, long clip_stride, const float*
 /* Config 5's step prologue as one launch (minecraft/sparse_diffusion.py:44-72 sample_time_dependent, :437 gather, :440-449
  * perturbation & masking): per clip b a frame window whose width grows with the noise level r[b] (placed by o[b] in [0, 1), or
  * uniformly by the in-kernel generator when o is NULL), n distinct positions uniform inside it (random order), the clip's tokens
- * there and their corruption by the law of wmz_corrupt_tokens.  z [B, S * HW] int64 (clip stride clip_stride); indices / tokens /
+ * there and their corruption by the law of wmz_corrupt_tokens with redraw probability r * p_uniform (training: p_uniform = 0.1,
+ * sparse_diffusion.py:447; the sampler, :185-187, masks only: 0).  z [B, S * HW] int64 (clip stride clip_stride); indices / tokens /
  * target [B, n] int64.  Philox keyed by (seed, stream_id); with counter != NULL the low 40 bits of the stream id are read from
  * device memory at run time (hipGraph replays).  wmz_sparse_draw_context_supported: 1 when S * HW <= 65536 positions, n <= 512 and
  * 2 ceil(n / HW) <= S (the reference's precondition: its narrowest window holds n positions); else the host draws with torch ops (world_modelz_amd/sparse_diffusion.py). */
 int wmz_sparse_draw_context_supported(int S, int HW, int n);
 int wmz_sparse_draw_context(const int64_t* z, long clip_stride, const float* r, const float* o, int64_t* indices,
-                            int64_t* tokens, int64_t* target, int B, int S, int HW, int n, int C, unsigned long long seed,
-                            unsigned long long stream_id, const unsigned long long* counter, void* stream);
+                            int64_t* tokens, int64_t* target, int B, int S, int HW, int n, int C, float p_uniform,
+                            unsigned long long seed, unsigned long long stream_id, const unsigned long long* counter,
+                            void* stream);
+/* The draw of config 5's sampler (sparse_diffusion.py:190-197: softmax -> multinomial -> scatter_ into the clip): one class per
+ * row of fp32 logits [R, C] (row stride ld) drawn from softmax(logits) by inverse CDF in class order; with z != NULL written to
+ * z[row / rows_per_clip][indices[row]] (clip stride clip_stride), with samples != NULL also to samples[row].  Philox keyed as
+ * wmz_sparse_draw_context (its own domain of the stream id). */
+int wmz_categorical_scatter(const float* logits, long ld, long R, int C, const int64_t* indices, int64_t* z, long clip_stride,
+                            long rows_per_clip, int64_t* samples, unsigned long long seed, unsigned long long stream_id,
+                            const unsigned long long* counter, void* stream);
 /* One step of the sampler loop between two forward passes (main.py:76-104): per row of fp32 logits [R, C <= 2048] keep the
  * top_k largest (<= 0: all; ties with the k-th kept), softmax, draw a class by the inverse CDF from one in-kernel uniform,
  * re-mask with a second one: the position gets mask_token where u2 > alpha (and, with `last_mask` [R] bytes, in / out, only

@@ -352,3 +352,94 @@ def test_sparse_model_dim_head_off_the_granule(wmz):
     worst = max((rel(p.grad, leaves[n].grad), n) for n, p in m.named_parameters() if leaves[n].grad is not None)
     print(f'sparse model, 3 heads of 20: logits {rel(y, ref):.2e}, worst gradient {worst[0]:.2e} ({worst[1]})')
     assert worst[0] < 3e-4, worst
+
+
+def test_categorical_scatter_vs_softmax(wmz):
+    """wmz_categorical_scatter (sparse_diffusion.py:190-197: softmax -> multinomial -> scatter_): draws follow softmax(logits)
+    (empirical frequencies over 4 000 calls against the probabilities), a dominating logit is always drawn (C = 8192, config 5's
+    vocabulary, three passes over the row), the draw is a function of (seed, call), and only the rows' positions of the clips change."""
+    sdm = wmz['sd']
+    torch.manual_seed(2)
+    B, n, C, G = 2, 8, 12, 40
+    logits = (2.0 * torch.randn(B, n, C, device='cuda')).contiguous()
+    idx = torch.stack([torch.randperm(G, device='cuda')[:n] for _ in range(B)]).contiguous()
+    p = torch.softmax(logits, -1)
+    counts = torch.zeros(B, n, C, device='cuda')
+    base = torch.full((B, G), 99, dtype=torch.int64, device='cuda')
+    reps = 4000
+    for call in range(reps):
+        z = base.clone()
+        sdm.categorical_scatter(logits, idx, z, seed=7, call_id=call)
+        counts.scatter_add_(2, torch.gather(z, 1, idx).unsqueeze(-1), torch.ones(B, n, 1, device='cuda'))
+    untouched = torch.ones(B, G, dtype=torch.bool, device='cuda').scatter_(1, idx, False)
+    assert bool((z[untouched] == 99).all()) and int(torch.gather(z, 1, idx).max()) < C
+    err = (counts / reps - p).abs()
+    assert float(err.max()) < 5 * 0.5 / (reps ** 0.5), float(err.max())                   # 5 sigma of a Bernoulli frequency
+    z1, z2, z3 = base.clone(), base.clone(), base.clone()
+    sdm.categorical_scatter(logits, idx, z1, seed=7, call_id=3)
+    sdm.categorical_scatter(logits, idx, z2, seed=7, call_id=3)
+    sdm.categorical_scatter(logits, idx, z3, seed=8, call_id=3)
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    # config 5's vocabulary: a dominating class per row is drawn with certainty, wherever it sits in the row
+    C = 8192
+    big = torch.randn(3, 16, C, device='cuda')
+    win = torch.randint(0, C, (3, 16), device='cuda')
+    win[0, 0], win[0, 1] = 0, C - 1
+    big.scatter_(2, win.unsqueeze(-1), 60.0)
+    pos = torch.stack([torch.randperm(G, device='cuda')[:16] for _ in range(3)]).contiguous()
+    zz = torch.zeros(3, G, dtype=torch.int64, device='cuda')
+    sdm.categorical_scatter(big.contiguous(), pos, zz, seed=1, call_id=1)
+    assert torch.equal(torch.gather(zz, 1, pos), win)
+
+
+def test_sparse_sampler_plumbing_and_model_run(wmz):
+    """sample_clips (the token side of the reference's evaluate_model, sparse_diffusion.py:139-202).  With a stand-in model whose
+    logits put all mass on `position mod C` the sampler's plumbing is exact: every position a context visited holds its own
+    class, the rest are still masked, the result is a function of the seed; with the real model it runs in both sampling modes,
+    leaves only valid tokens or masks, and evaluate_model returns decoded frames of the reference's shape."""
+    from world_modelz_amd.train_vqae import VqAutoEncoder
+    sdm = wmz['sd']
+    S, H, W, C, n = 8, 4, 4, 24, 32
+    G = S * H * W
+
+    class Oracle(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.shape = (S, H, W)
+            self.embedding = torch.nn.Embedding(C + 1, 8)
+            self.seen_masked = []
+
+        def forward(self, tokens, indices):
+            self.seen_masked.append(float((tokens == C).float().mean()))
+            return 50.0 * torch.nn.functional.one_hot(indices % C, C).float()
+
+    stub = Oracle().cuda()
+    g = torch.Generator().manual_seed(3)
+    z = sdm.sample_clips(stub, 3, C, 'neighbors', num_context=n, num_eval_iterations=5, generator=g, seed=11, use_graph=False)   # (the stand-in reads back)
+    flat = z.view(3, -1)
+    pos = torch.arange(G, device='cuda').expand(3, -1)
+    visited = flat != C
+    assert bool((flat[visited] == (pos % C)[visited]).all()) and float(visited.float().mean()) > 0.9
+    per_iter = G // n + 1
+    # iteration 0 sees only masks; the last one masks nothing itself (what is still masked there was never visited)
+    assert stub.seen_masked[0] == 1.0 and max(stub.seen_masked[-per_iter:]) < 0.35, stub.seen_masked[-per_iter:]
+    z2 = sdm.sample_clips(stub, 3, C, 'neighbors', num_context=n, num_eval_iterations=5, generator=torch.Generator().manual_seed(3), seed=11,
+                          use_graph=False)
+    assert torch.equal(z, z2)
+    zu = sdm.sample_clips(stub, 2, C, 'uniform', num_context=n, num_eval_iterations=3, generator=torch.Generator().manual_seed(3), seed=11)
+    fu = zu.view(2, -1)
+    assert bool((fu == (torch.arange(G, device='cuda') % C)).all())                        # a permutation's slices cover the grid
+    # the real model, both modes
+    torch.manual_seed(4)
+    m = sdm.VqSparseDiffusionModel(shape=(S, H, W), dim=64, num_classes=C, depth=2, dim_head=32, mlp_dim=96, heads=2).cuda()
+    with wmz['config'].compute_dtype(torch.bfloat16):
+        for mode in ('neighbors', 'uniform'):
+            zz = sdm.sample_clips(m, 2, C, mode, num_context=n, num_eval_iterations=3, seed=5, generator=torch.Generator().manual_seed(1))
+            assert zz.shape == (2, S, H, W) and int(zz.min()) >= 0 and int(zz.max()) <= C
+            if mode == 'neighbors':                    # the captured sub-step (default) draws what the eager launches draw
+                ze = sdm.sample_clips(m, 2, C, mode, num_context=n, num_eval_iterations=3, seed=5, generator=torch.Generator().manual_seed(1),
+                                      use_graph=False)
+                assert torch.equal(zz, ze)
+        ae = VqAutoEncoder(embedding_dim=16, num_embeddings=C, downscale_steps=2, hidden_planes=16).cuda().eval()
+        frames = sdm.evaluate_model('cuda', 2, m, ae, (S, H, W), 'neighbors', num_context=n, num_eval_iterations=2)
+    assert frames.shape == (2, S, 3, 4 * H, 4 * W) and bool(torch.isfinite(frames).all())

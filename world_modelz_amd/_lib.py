@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMZ_LIB_PATH') or os.path.join(_HERE, 'libwmz_hip.so')    # override: kernel A/B builds (tools/)
 
 WMZ_F32, WMZ_BF16, WMZ_F16 = 0, 1, 2
-EXPECTED_VERSION = 112      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
+EXPECTED_VERSION = 113      # include/wmz.h WMZ_VERSION: bumped with every ABI change; lib() refuses another build
 WMZ_LIN_GELU = 1
 WMZ_LIN_GELU_IN = 2
 WMZ_LIN_DGELU = 4
@@ -124,7 +124,9 @@ SIGNATURES = {
     'wmz_recon_loss_bwd': [c_void_p] * 4 + [c_long, c_long, c_int, c_int, c_int, c_int, c_void_p],
     'wmz_sparse_draw_context_supported': [c_int, c_int, c_int],
     'wmz_sparse_draw_context': [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p],
+                                c_int, c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p],
+    'wmz_categorical_scatter': [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p, c_long, c_long, c_void_p, ctypes.c_ulonglong,
+                                ctypes.c_ulonglong, c_void_p, c_void_p],
     'wmz_corrupt_tokens_dev': [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
                                ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p],
     'wmz_sample_tokens_dev': [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_long, c_void_p,

@@ -51,6 +51,7 @@ struct ScParams {
   const float* r; const float* o;
   int64_t* indices; int64_t* tokens; int64_t* target;
   int B, S, HW, n, C, NP;
+  float p_uniform;   // redraw probability per unit of r (training: 0.1, sparse_diffusion.py:447 p_max_uniform; the sampler: 0)
   unsigned long long seed, stream;
   const unsigned long long* counter;
 };
@@ -156,12 +157,64 @@ __global__ __launch_bounds__(SC_THREADS) void sparse_context_kernel(ScParams P) 
     unsigned c[4];
     sc_philox4((unsigned long long)b * P.n + i, P.seed, stream, c);
     int64_t d = tok;
-    if (sc_unit(c[0]) < rb * 0.1f) { const int kk = (int)(sc_unit(c[1]) * (float)P.C); d = kk < P.C ? kk : P.C - 1; }
+    if (sc_unit(c[0]) < rb * P.p_uniform) { const int kk = (int)(sc_unit(c[1]) * (float)P.C); d = kk < P.C ? kk : P.C - 1; }
     if (sc_unit(c[2]) < rb) d = P.C;
     const long at = (long)b * P.n + i;
     P.indices[at] = pos;
     P.target[at] = tok;
     P.tokens[at] = d;
+  }
+}
+
+// The other end of config 5's sampler step (sparse_diffusion.py:190-198): p = softmax(logits), one multinomial draw per row,
+// scattered back into the clip at the row's position.  One wave per row of C fp32 logits (C = 8192 at config 5: too wide for
+// registers, so three passes over the row, which sits in L2): the maximum, the sum of exp(l - max), then the inverse CDF in class
+// order -- the first class whose cumulative weight exceeds u * total (lane l owns the contiguous classes [l C / 64, (l + 1) C / 64):
+// lane sums -> a wave prefix -> the owning lane walks its classes).
+__global__ __launch_bounds__(256) void categorical_scatter_kernel(const float* __restrict__ logits, long ld, long R, int C,
+                                                                  const int64_t* __restrict__ indices, int64_t* __restrict__ z,
+                                                                  long clip_stride, long rows_per_clip,
+                                                                  int64_t* __restrict__ samples, unsigned long long seed,
+                                                                  unsigned long long stream,
+                                                                  const unsigned long long* __restrict__ counter) {
+  if (counter != nullptr) stream |= *counter & ((1ull << 40) - 1);
+  const int lane = threadIdx.x & 63;
+  const int per = (C + 63) / 64, c0 = lane * per, c1 = min(c0 + per, C);
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += (long)gridDim.x * 4) {
+    const float* x = logits + row * ld;
+    float m = -INFINITY;
+    for (int c = c0; c < c1; ++c) m = fmaxf(m, x[c]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+    float s = 0.f;
+    for (int c = c0; c < c1; ++c) s += __expf(x[c] - m);
+    float incl = s;                                             // inclusive prefix of the lane sums
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    const float total = __shfl(incl, 63);
+    unsigned cc[4];
+    sc_philox4((unsigned long long)row, seed, stream, cc);
+    const float want = sc_unit(cc[0]) * total;
+    // the owning lane: the first whose inclusive prefix exceeds `want` (the last lane if rounding leaves none)
+    const unsigned long long owners = __ballot(incl > want);
+    const int owner = owners ? (int)__builtin_ctzll(owners) : 63;
+    int pick = C - 1;
+    if (lane == owner) {
+      float acc = incl - s;
+      pick = c1 - 1 < 0 ? 0 : c1 - 1;
+      for (int c = c0; c < c1; ++c) {
+        acc += __expf(x[c] - m);
+        if (acc > want) { pick = c; break; }
+      }
+    }
+    pick = __shfl(pick, owner);
+    if (lane == 0) {
+      if (samples != nullptr) samples[row] = pick;
+      if (z != nullptr) z[(row / rows_per_clip) * clip_stride + indices[row]] = pick;
+    }
   }
 }
 
@@ -179,10 +232,11 @@ extern "C" int wmz_sparse_draw_context_supported(int S, int HW, int n) {
 }
 
 extern "C" int wmz_sparse_draw_context(const int64_t* z, long clip_stride, const float* r, const float* o, int64_t* indices,
-                                       int64_t* tokens, int64_t* target, int B, int S, int HW, int n, int C,
+                                       int64_t* tokens, int64_t* target, int B, int S, int HW, int n, int C, float p_uniform,
                                        unsigned long long seed, unsigned long long stream_id, const unsigned long long* counter,
                                        void* stream) {
   WMZ_REQUIRE(z && r && indices && tokens && target && B > 0 && C > 0, "wmz_sparse_draw_context: bad arguments");
+  WMZ_REQUIRE(p_uniform >= 0.f && p_uniform <= 1.f, "wmz_sparse_draw_context: p_uniform in [0, 1] expected");
   if (!wmz_sparse_draw_context_supported(S, HW, n)) {
     wmz_set_error("wmz_sparse_draw_context: grid %d x %d with %d context positions not built (<= 65536 positions, <= 512 of "
                   "them drawn, 2 ceil(n / HW) <= S)", S, HW, n);
@@ -190,7 +244,7 @@ extern "C" int wmz_sparse_draw_context(const int64_t* z, long clip_stride, const
   }
   ScParams P;
   P.z = z; P.clip_stride = clip_stride; P.r = r; P.o = o; P.indices = indices; P.tokens = tokens; P.target = target;
-  P.B = B; P.S = S; P.HW = HW; P.n = n; P.C = C;
+  P.B = B; P.S = S; P.HW = HW; P.n = n; P.C = C; P.p_uniform = p_uniform;
   int np = 4;
   while (np < S * HW) np <<= 1;
   P.NP = np;
@@ -200,5 +254,22 @@ extern "C" int wmz_sparse_draw_context(const int64_t* z, long clip_stride, const
   P.counter = counter;
   hipLaunchKernelGGL(sparse_context_kernel, dim3(B), dim3(SC_THREADS), 0, (hipStream_t)stream, P);
   WMZ_LAUNCH_CHECK("wmz_sparse_draw_context");
+  return WMZ_OK;
+}
+
+// One multinomial draw per row of fp32 logits [R, C] (row stride ld) from softmax(logits) -- sparse_diffusion.py:190-194 -- and,
+// with z != NULL, its scatter into the clips (:197): z[row / rows_per_clip][indices[row]] = the drawn class.  samples (optional):
+// the draws [R].  Philox keyed as wmz_sparse_draw_context.
+extern "C" int wmz_categorical_scatter(const float* logits, long ld, long R, int C, const int64_t* indices, int64_t* z,
+                                       long clip_stride, long rows_per_clip, int64_t* samples, unsigned long long seed,
+                                       unsigned long long stream_id, const unsigned long long* counter, void* stream) {
+  WMZ_REQUIRE(logits && R > 0 && C > 0 && ld >= C, "wmz_categorical_scatter: bad arguments");
+  WMZ_REQUIRE(z == nullptr || (indices != nullptr && rows_per_clip > 0), "wmz_categorical_scatter: the scatter needs indices and rows_per_clip");
+  WMZ_REQUIRE(z != nullptr || samples != nullptr, "wmz_categorical_scatter: nothing to write");
+  const int grid = (int)((R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048);
+  const unsigned long long sid = (counter != nullptr ? (stream_id & ~((1ull << 40) - 1)) : stream_id) & ~(SC_KEY_DOMAIN | SC_WIN_DOMAIN);
+  hipLaunchKernelGGL(categorical_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, ld, R, C, indices, z, clip_stride,
+                     rows_per_clip, samples, seed, sid | (SC_KEY_DOMAIN | SC_WIN_DOMAIN), counter);
+  WMZ_LAUNCH_CHECK("wmz_categorical_scatter");
   return WMZ_OK;
 }

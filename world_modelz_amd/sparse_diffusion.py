@@ -78,3 +78,128 @@ class VqSparseDiffusionModel(nn.Module):
                                     self.pos_emb_w.weight, self.shape)
         h = self.transformer.forward_compute(h)
         return Fw.linear(h, self.logit_proj.weight, self.logit_proj.bias, out_f32=True)
+
+
+# ------------------------------------------------------------------------------------------------ the sampler (reference :99-202)
+def categorical_scatter(logits, indices, z_flat, seed, call_id=0, rank=0, counter=None):
+    """One multinomial draw per row from softmax(logits) (reference :190-194), written into the clips at the rows' positions
+    (:197 `full_z_flat.scatter_`): logits fp32 [B, n, C], indices int64 [B, n], z_flat int64 [B, G] (in place).  The draw's
+    Philox stream: (seed, rank, call_id) -- or, with counter (device int64 [1]), the call number read on the device."""
+    from . import _lib as L
+    B, n, C = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and indices.is_contiguous() and z_flat.stride(1) == 1
+    sid = (int(rank) << 40) | (0 if counter is not None else int(call_id) & ((1 << 40) - 1))
+    L.call('wmz_categorical_scatter', L.ptr(logits), C, B * n, C, L.ptr(indices), L.ptr(z_flat), z_flat.stride(0), n, None,
+           int(seed) & 0xFFFFFFFFFFFFFFFF, sid, L.ptr(counter), L.stream())
+
+
+@torch.no_grad()
+def sample_clips(model, batch_size, num_embeddings, sampling_type='neighbors', num_context=512, num_eval_iterations=100,
+                 generator=None, seed=None, use_graph=True):
+    """The token side of the reference's evaluate_model (:139-202): clips [batch_size, S, H, W] that start fully masked and are
+    re-drawn num_eval_iterations times -- per iteration G // num_context + 1 contexts, each gathered from the clip, masked with
+    probability 1 - i / (iterations - 1), denoised by the model, sampled from softmax(logits) and scattered back.  'neighbors' (the
+    reference's default): a context = num_context positions of a frame window of width t = 1 - frac placed at the k-th of the
+    iteration's shuffled offsets (sample_time_dependent with o given) -- window, positions, gather and masking are ONE launch
+    (wmz_sparse_draw_context with p_uniform = 0), the draw and the scatter another (wmz_categorical_scatter); nothing returns to
+    the host inside the loop, and with use_graph the whole sub-step (draw, forward, sample, scatter; the call number counted on
+    the device) is ONE hipGraph launch -- same tokens as the eager launches, bit for bit.  'uniform': consecutive num_context-wide slices of one permutation per iteration (the reference
+    slices at k * max_index, which is empty from k = 1 on; the evident intent -- k * num_context -- is what runs here)."""
+    from . import _lib as L
+    from .train import draw_sparse_context
+    if sampling_type not in ('uniform', 'neighbors'):
+        raise ValueError('Specified sampling_type not supported')                 # reference :182
+    if num_eval_iterations < 2:
+        raise ValueError('num_eval_iterations must be at least 2 (the schedule divides by iterations - 1)')
+    S, H, W = (int(v) for v in model.shape)
+    G = S * H * W
+    dev = model.embedding.weight.device
+    n = int(num_context)
+    full_z = torch.full((batch_size, S, H, W), int(num_embeddings), dtype=torch.int64, device=dev)      # all mask tokens (:153-155)
+    flat = full_z.view(batch_size, -1)
+    if seed is None:
+        seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+    fused = sampling_type == 'neighbors' and bool(L.lib().wmz_sparse_draw_context_supported(S, H * W, n))
+    offset_count = G // n + 1
+    was_training = model.training
+    model.eval()
+    graph = None
+    if fused and use_graph:
+        # one captured sub-step on static inputs: the noise level / window width r, the window placement o, the call counter
+        r_s = torch.ones(batch_size, dtype=torch.float32, device=dev)
+        o_s = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def substep():
+            ctr.add_(1)
+            indices, tokens, _ = draw_sparse_context(full_z, r_s, n, (S, H, W), num_embeddings, seed=seed, rank=0, counter=ctr, o=o_s,
+                                                     p_uniform=0.0)
+            logits = model(tokens, indices)
+            categorical_scatter(logits.float().contiguous(), indices, flat, seed, counter=ctr)
+        from . import config as _cfg
+        side = _cfg.shared_stream('warmup')
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            substep()                                   # (allocations and operand caches settle outside the capture)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        from .graph import capture_mode
+        with torch.cuda.graph(graph, capture_error_mode=capture_mode()):
+            substep()
+        full_z.fill_(int(num_embeddings))               # the warm-up wrote tokens: start from all masks, call number 0
+        ctr.zero_()
+    try:
+        for i in range(num_eval_iterations):
+            frac = i / (num_eval_iterations - 1)
+            order = torch.randperm(offset_count, generator=generator)                                    # :168 (host)
+            if sampling_type == 'uniform':
+                perm = torch.randperm(G, device=dev)
+            r = torch.full((batch_size,), 1.0 - frac, dtype=torch.float32, device=dev)
+            o_rows = (order.float() / (offset_count - 1)).to(dev)[:, None].expand(-1, batch_size).contiguous()
+            if graph is not None:
+                r_s.copy_(r)
+            for k in range(offset_count):
+                call = i * offset_count + k + 1              # (the draw's Philox stream id: a function of the seed and the step)
+                if graph is not None:
+                    o_s.copy_(o_rows[k])
+                    graph.replay()
+                    continue
+                if sampling_type == 'uniform':
+                    idx = perm[k * n:(k + 1) * n]
+                    if idx.numel() == 0:
+                        continue
+                    indices = idx.unsqueeze(0).expand(batch_size, -1).contiguous()
+                    tokens = torch.gather(flat, 1, indices)
+                    tokens = torch.where(torch.rand(tokens.shape, device=dev) > frac, torch.full_like(tokens, num_embeddings), tokens)
+                elif fused:
+                    indices, tokens, _ = draw_sparse_context(full_z, r, n, (S, H, W), num_embeddings, seed=seed, rank=0, o=o_rows[k],
+                                                             p_uniform=0.0, call_id=call)
+                else:
+                    indices = sample_time_dependent(batch_size, n, S, H, W, r, dev, o=o_rows[k])
+                    tokens = torch.gather(flat, 1, indices)
+                    tokens = torch.where(torch.rand(tokens.shape, device=dev) > frac, torch.full_like(tokens, num_embeddings), tokens)
+                logits = model(tokens, indices)                                                         # [B, n, C] fp32
+                categorical_scatter(logits.float().contiguous(), indices, flat, seed, call)
+    finally:
+        model.train(was_training)
+    return full_z
+
+
+def decode(decoder_model, batch, decode_N=16):
+    """Token clips [B, S, H, W] -> frames [B, S, C, h, w] through the VQ auto-encoder, decode_N frames at a time (reference
+    :115-136; tokens beyond the codebook -- left-over mask tokens -- decode as code 0)."""
+    batch = batch.clone()
+    batch[batch >= decoder_model.vq.num_embeddings] = 0
+    shape = batch.shape
+    flat = batch.view(-1, shape[2], shape[3])
+    frames = torch.cat([decoder_model.decode(flat[i:i + decode_N]) for i in range(0, flat.shape[0], decode_N)])
+    return frames.view(shape[0], -1, *frames.shape[1:])
+
+
+@torch.no_grad()
+def evaluate_model(device, batch_size, model, decoder_model, shape, sampling_type, num_context=512, num_eval_iterations=100):
+    """The reference's evaluate_model (:139-202), same signature: sampled clips decoded to frames."""
+    assert tuple(int(v) for v in shape) == tuple(int(v) for v in model.shape)
+    z = sample_clips(model, batch_size, decoder_model.vq.num_embeddings, sampling_type, num_context, num_eval_iterations)
+    return decode(decoder_model, z)

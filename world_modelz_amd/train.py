@@ -83,10 +83,12 @@ def corrupt_tokens(tokens, r, num_embeddings, generator=None, seed=None, rank=No
     return out, target
 
 
-def draw_sparse_context(z, r, num_context, shape, num_embeddings, generator=None, seed=None, rank=None, counter=None, o=None):
+def draw_sparse_context(z, r, num_context, shape, num_embeddings, generator=None, seed=None, rank=None, counter=None, o=None,
+                        p_uniform=0.1, call_id=None):
     """Config 5's step prologue by ONE launch (wmz_sparse_draw_context: minecraft/sparse_diffusion.py:44-72 sample_time_dependent,
     :437 gather, :440-449 perturbation & masking): z [B, S, H, W] token clips, r [B] noise levels -> (indices, corrupted tokens,
-    target), each [B, num_context].  o [B]: the window placements (else drawn in the kernel).  Random stream as corrupt_tokens:
+    target), each [B, num_context].  o [B]: the window placements (else drawn in the kernel).  p_uniform: the redraw probability
+    per unit of r (:447 p_max_uniform = 0.1; the sampler masks only: 0).  Random stream as corrupt_tokens:
     (seed, rank, per-call counter -- on the device when `counter` is given: hipGraph replays)."""
     global _corrupt_calls
     assert z.is_cuda and z.dtype == torch.int64
@@ -103,13 +105,15 @@ def draw_sparse_context(z, r, num_context, shape, num_embeddings, generator=None
     if seed is None:
         seed = generator.initial_seed() if generator is not None else torch.initial_seed()
     rank = _dp_rank() if rank is None else int(rank)
-    if counter is None:
+    if counter is not None:
+        stream_id = rank << 40
+    elif call_id is not None:                     # (the caller numbers its own calls: a reproducible sequence for one seed)
+        stream_id = (rank << 40) | (int(call_id) & ((1 << 40) - 1))
+    else:
         _corrupt_calls += 1
         stream_id = (rank << 40) | (_corrupt_calls & ((1 << 40) - 1))
-    else:
-        stream_id = rank << 40
     L.call('wmz_sparse_draw_context', L.ptr(zf), zf.stride(0), L.ptr(r), L.ptr(o), L.ptr(indices), L.ptr(tokens), L.ptr(target),
-           B, S, H * W, n, int(num_embeddings), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_id, L.ptr(counter), L.stream())
+           B, S, H * W, n, int(num_embeddings), float(p_uniform), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_id, L.ptr(counter), L.stream())
     return indices, tokens, target
 
 
