@@ -32,9 +32,10 @@ for c in range(cases):
         Himg, Wimg = rng.choice([(16, 16), (32, 32), (24, 40), (64, 64), (8, 8)])
         B = rng.choice([1, 2, 5])
         training = rng.choice([True, False])
-        # (a training-mode BatchNorm over fewer than 8 values -- a 1 x 1 final map at B = 2 -- amplifies summation-order differences
-        #  by 1 / sqrt(var): not a parity question)
-        if Himg % (1 << ds) or Wimg % (1 << ds) or B * Himg * Wimg * hp > 3 << 20 or B * (Himg >> ds) * (Wimg >> ds) < 8:
+        # (a training-mode BatchNorm over few values -- a 1 x 1 final map at B = 2; 80 values at seed 5 / case 14, where the statistics'
+        #  atomic sums made the SAME build differ from run to run by 2.5e-3 in the last block's gradients -- amplifies summation-order
+        #  differences by 1 / sqrt(var): not a parity question)
+        if Himg % (1 << ds) or Wimg % (1 << ds) or B * Himg * Wimg * hp > 3 << 20 or B * (Himg >> ds) * (Wimg >> ds) < 128:
             continue
         m = VqAutoEncoder(embedding_dim=E, num_embeddings=C, downscale_steps=ds, hidden_planes=hp, in_channels=ic)
         sd = {k: v.clone() for k, v in m.state_dict().items()}

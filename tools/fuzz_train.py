@@ -18,14 +18,15 @@ rng = random.Random(seed)
 bad = 0
 for c in range(cases):
     dim, mlp, dh, heads = rng.choice([(256, 256, 128, 1), (256, 256, 128, 1), (96, 256, 128, 1), (384, 512, 128, 1), (64, 96, 32, 2), (128, 128, 64, 2),
-                                      (160, 256, 128, 1)])
+                                      (160, 256, 128, 1), (128, 256, 64, 3), (128, 512, 64, 2), (192, 512, 128, 1), (256, 512, 128, 1),
+                                      (256, 1024, 128, 2), (512, 1024, 128, 1), (64, 96, 20, 3), (128, 256, 100, 1)])
     H, W = rng.choice([(16, 16), (8, 8), (8, 8), (4, 8), (6, 8), (4, 4), (2, 16), (6, 6), (10, 16)])
     S = rng.choice([1, 2, 3, 4, 6])
     B = rng.choice([1, 2, 3, 4])
     depth = rng.choice([1, 2, 3])
     ext = (rng.choice([1, 2, 3]), rng.choice([0, 1, 3]), rng.choice([0, 1, 3]))
     dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float32])
-    C = rng.choice([64, 40, 128])
+    C = rng.choice([64, 40, 128, 37, 101])
     if B * S * H * W * dim * depth > 3 << 20:
         continue
     torch.manual_seed(seed * 977 + c)
