@@ -147,8 +147,8 @@ def sample_clips(model, batch_size, num_embeddings, sampling_type='neighbors', n
         from .graph import capture_mode
         with torch.cuda.graph(graph, capture_error_mode=capture_mode()):
             substep()
-        full_z.fill_(int(num_embeddings))               # the warm-up wrote tokens: start from all masks, call number 0
-        ctr.zero_()
+        full_z.fill_(int(num_embeddings))               # the warm-up wrote tokens: start from all masks, call number 0 (+ bit 38)
+        ctr.fill_(1 << 38)
     try:
         for i in range(num_eval_iterations):
             frac = i / (num_eval_iterations - 1)
@@ -160,7 +160,8 @@ def sample_clips(model, batch_size, num_embeddings, sampling_type='neighbors', n
             if graph is not None:
                 r_s.copy_(r)
             for k in range(offset_count):
-                call = i * offset_count + k + 1              # (the draw's Philox stream id: a function of the seed and the step)
+                # the draw's Philox stream id: a function of the seed and the step (bit 38: apart from the trainers' eager call numbers)
+                call = (1 << 38) + i * offset_count + k + 1
                 if graph is not None:
                     o_s.copy_(o_rows[k])
                     graph.replay()
