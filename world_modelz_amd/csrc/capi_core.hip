@@ -171,26 +171,63 @@ __global__ __launch_bounds__(256) void embed_indexed_kernel(const int64_t* __res
   }
 }
 
+// Gradient of the indexed embedding sum (config 5: 3 072 tokens x 512 columns into 64 + 16 + 16 position rows and an 8 193-row token
+// table of which ONE row, the mask token's, takes half the tokens).  Four global atomics per element (round 2) meant up to 1 536
+// adds on one address: 57 us at the end of config 5's backward chain.  Here a workgroup owns a slab of EB_COLS columns and a group
+// of tokens: the three position tables and the hot token row (the table's last: the mask token, main.py:27) are summed in LDS
+// (ds_add_f32) and flushed once per workgroup -- 16 adds per address instead of 192 - 1 536 --, the other token rows go to memory
+// directly (mostly distinct addresses).
+constexpr int EB_COLS = 32;
+
 template <typename T>
 __global__ __launch_bounds__(256) void embed_indexed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ pos,
                                                                 const T* __restrict__ dx, float* __restrict__ demb,
                                                                 float* __restrict__ dps, float* __restrict__ dph,
                                                                 float* __restrict__ dpw, long ntok, int S, int H, int W,
-                                                                int D, int num_classes) {
-  const long total = ntok * D;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long t = i / D;
-    const int d = (int)(i - t * D);
-    long p = pos[t];
-    p = p < 0 ? 0 : (p >= (long)S * H * W ? (long)S * H * W - 1 : p);
-    const int w = (int)(p % W), h = (int)((p / W) % H), s = (int)(p / ((long)W * H));
-    long tk = tok[t];
-    tk = tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : tk);
-    const float v = Elem<T>::to_f32(dx[i]);
-    atomicAdd(demb + tk * D + d, v);
-    atomicAdd(dps + (long)s * D + d, v);
-    atomicAdd(dph + (long)h * D + d, v);
-    atomicAdd(dpw + (long)w * D + d, v);
+                                                                int D, int num_classes, int tgroups, int use_lds) {
+  extern __shared__ float tab[];                              // [(S + H + W + 1) rows][EB_COLS]; use_lds == 0 (tables beyond the LDS): all to memory
+  const int nrows = S + H + W + 1;
+  const int slab = blockIdx.x / tgroups, tg = blockIdx.x - slab * tgroups;
+  const int d0 = slab * EB_COLS;
+  const int col = threadIdx.x & (EB_COLS - 1), trow = threadIdx.x / EB_COLS;            // 8 tokens per sweep
+  if (use_lds)
+    for (int i = threadIdx.x; i < nrows * EB_COLS; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int d = d0 + col;
+  const long per = (ntok + tgroups - 1) / tgroups;
+  const long t0 = (long)tg * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  if (d < D) {
+    for (long t = t0 + trow; t < t1; t += 256 / EB_COLS) {
+      long p = pos[t];
+      p = p < 0 ? 0 : (p >= (long)S * H * W ? (long)S * H * W - 1 : p);
+      const int w = (int)(p % W), h = (int)((p / W) % H), s = (int)(p / ((long)W * H));
+      long tk = tok[t];
+      tk = tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : tk);
+      const float v = Elem<T>::to_f32(dx[t * D + d]);
+      if (use_lds) {
+        atomicAdd(&tab[s * EB_COLS + col], v);
+        atomicAdd(&tab[(S + h) * EB_COLS + col], v);
+        atomicAdd(&tab[(S + H + w) * EB_COLS + col], v);
+        if (tk == num_classes - 1) atomicAdd(&tab[(S + H + W) * EB_COLS + col], v);
+        else atomicAdd(demb + tk * D + d, v);
+      } else {
+        atomicAdd(dps + (long)s * D + d, v);
+        atomicAdd(dph + (long)h * D + d, v);
+        atomicAdd(dpw + (long)w * D + d, v);
+        atomicAdd(demb + tk * D + d, v);
+      }
+    }
+  }
+  __syncthreads();
+  if (!use_lds) return;
+  for (int i = threadIdx.x; i < nrows * EB_COLS; i += 256) {
+    const int r = i / EB_COLS, c = d0 + (i - r * EB_COLS);
+    const float v = tab[i];
+    if (c >= D || v == 0.f) continue;
+    if (r < S) atomicAdd(dps + (long)r * D + c, v);
+    else if (r < S + H) atomicAdd(dph + (long)(r - S) * D + c, v);
+    else if (r < S + H + W) atomicAdd(dpw + (long)(r - S - H) * D + c, v);
+    else atomicAdd(demb + (long)(num_classes - 1) * D + c, v);
   }
 }
 
@@ -219,13 +256,20 @@ extern "C" int wmz_embed_indexed_bwd(const int64_t* tok, const int64_t* pos, con
   WMZ_REQUIRE(tok && pos && dx && demb && dpos_s && dpos_h && dpos_w, "wmz_embed_indexed_bwd: null tensor");
   WMZ_REQUIRE(ntok > 0 && S > 0 && H > 0 && W > 0 && D > 0 && num_classes > 0, "wmz_embed_indexed_bwd: bad shape");
   WMZ_REQUIRE(dtype == WMZ_F32 || dtype == WMZ_BF16, "wmz_embed_indexed_bwd: bad dtype %d", dtype);
-  const long total = ntok * D;
-  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  const int slabs = (D + EB_COLS - 1) / EB_COLS;
+  size_t lds = (size_t)(S + H + W + 1) * EB_COLS * sizeof(float);
+  const int use_lds = lds <= 60 * 1024;
+  if (!use_lds) lds = 0;
+  // token groups: enough workgroups to fill the chip, at least 64 tokens each
+  int tgroups = 512 / slabs;
+  if (tgroups < 1) tgroups = 1;
+  while (tgroups > 1 && ntok / tgroups < 64) tgroups >>= 1;
+  const int grid = slabs * tgroups;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == WMZ_BF16)
-    hipLaunchKernelGGL(embed_indexed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, tok, pos, (const bf16_t*)dx, demb, dpos_s, dpos_h, dpos_w, ntok, S, H, W, D, num_classes);
+    hipLaunchKernelGGL(embed_indexed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, tok, pos, (const bf16_t*)dx, demb, dpos_s, dpos_h, dpos_w, ntok, S, H, W, D, num_classes, tgroups, use_lds);
   else
-    hipLaunchKernelGGL(embed_indexed_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, tok, pos, (const float*)dx, demb, dpos_s, dpos_h, dpos_w, ntok, S, H, W, D, num_classes);
+    hipLaunchKernelGGL(embed_indexed_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, tok, pos, (const float*)dx, demb, dpos_s, dpos_h, dpos_w, ntok, S, H, W, D, num_classes, tgroups, use_lds);
   WMZ_LAUNCH_CHECK("wmz_embed_indexed_bwd");
   return WMZ_OK;
 }
