@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void embed_indexed_kernel(const int64_t* __res
 // adds on one address: 57 us at the end of config 5's backward chain.  Here a workgroup owns a slab of EB_COLS columns and a group
 // of tokens: the three position tables and the hot token row (the table's last: the mask token, main.py:27) are summed in LDS
 // (ds_add_f32) and flushed once per workgroup -- 16 adds per address instead of 192 - 1 536 --, the other token rows go to memory
-// directly (mostly distinct addresses).
+// directly (mostly distinct addresses).  Isolated: 57 -> 33 us; by ablation half of what is left is the LDS float atomics
+// themselves (they retire at about a lane a clock), the rest zeroing, flush and index arithmetic.
 constexpr int EB_COLS = 32;
 
 template <typename T>
@@ -197,24 +198,39 @@ __global__ __launch_bounds__(256) void embed_indexed_bwd_kernel(const int64_t* _
   const long per = (ntok + tgroups - 1) / tgroups;
   const long t0 = (long)tg * per, t1 = t0 + per < ntok ? t0 + per : ntok;
   if (d < D) {
-    for (long t = t0 + trow; t < t1; t += 256 / EB_COLS) {
-      long p = pos[t];
-      p = p < 0 ? 0 : (p >= (long)S * H * W ? (long)S * H * W - 1 : p);
-      const int w = (int)(p % W), h = (int)((p / W) % H), s = (int)(p / ((long)W * H));
-      long tk = tok[t];
-      tk = tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : tk);
-      const float v = Elem<T>::to_f32(dx[t * D + d]);
-      if (use_lds) {
-        atomicAdd(&tab[s * EB_COLS + col], v);
-        atomicAdd(&tab[(S + h) * EB_COLS + col], v);
-        atomicAdd(&tab[(S + H + w) * EB_COLS + col], v);
-        if (tk == num_classes - 1) atomicAdd(&tab[(S + H + W) * EB_COLS + col], v);
-        else atomicAdd(demb + tk * D + d, v);
-      } else {
-        atomicAdd(dps + (long)s * D + d, v);
-        atomicAdd(dph + (long)h * D + d, v);
-        atomicAdd(dpw + (long)w * D + d, v);
-        atomicAdd(demb + tk * D + d, v);
+    // four tokens of the thread at a time: their loads are issued together (one token per trip made the loop a chain of load
+    // latencies: 59 us at 384 tokens a workgroup), indices in 32-bit arithmetic
+    constexpr int TS = 256 / EB_COLS, UN = 4;
+    const int HW = H * W, G = S * HW;
+    for (long tb = t0 + trow; tb < t1; tb += TS * UN) {
+      int pi[UN], ti[UN];
+      float v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const long t = tb + (long)u * TS;
+        const bool in = t < t1;
+        const long tt = in ? t : t1 - 1;
+        const long p = pos[tt], tk = tok[tt];
+        pi[u] = p < 0 ? 0 : (p >= G ? G - 1 : (int)p);
+        ti[u] = in ? (tk < 0 ? 0 : (tk >= num_classes ? num_classes - 1 : (int)tk)) : -1;
+        v[u] = Elem<T>::to_f32(dx[tt * D + d]);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (ti[u] < 0) continue;
+        const int sI = pi[u] / HW, rem = pi[u] - sI * HW, h = rem / W, w = rem - h * W;
+        if (use_lds) {
+          atomicAdd(&tab[sI * EB_COLS + col], v[u]);
+          atomicAdd(&tab[(S + h) * EB_COLS + col], v[u]);
+          atomicAdd(&tab[(S + H + w) * EB_COLS + col], v[u]);
+          if (ti[u] == num_classes - 1) atomicAdd(&tab[(S + H + W) * EB_COLS + col], v[u]);
+          else atomicAdd(demb + (long)ti[u] * D + d, v[u]);
+        } else {
+          atomicAdd(dps + (long)sI * D + d, v[u]);
+          atomicAdd(dph + (long)h * D + d, v[u]);
+          atomicAdd(dpw + (long)w * D + d, v[u]);
+          atomicAdd(demb + (long)ti[u] * D + d, v[u]);
+        }
       }
     }
   }
